@@ -1,0 +1,223 @@
+"""ctypes front-end of the CPU oracle (oracle/*.c -> oracle/_build/liboracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, by __graft_entry__.smoke() and by bench.py's cpu_baseline
+leg as the checker / reported baseline.  The product package (wurm_amd/) never imports this module.
+
+All functions take and return numpy arrays (state arrays are modified in place, like the reference's
+tensors).  Argument meaning mirrors the C functions, which cite the reference lines they restate.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, '_build', 'liboracle.so')
+
+OBS_DEFAULT, OBS_RAW, OBS_ONE_CHANNEL, OBS_POSITIONS, OBS_PARTIAL, OBS_NONE = range(6)
+ACT_I64, ACT_I32 = 0, 1
+
+# bits of the per-env error mask returned by single_check (wurm/utils.py:113-178 in the reference)
+CHK_FOOD_VALUE, CHK_ONE_HEAD, CHK_HAS_SNAKE, CHK_HEAD_AT_END, CHK_BODY_RANGE, CHK_MIN_LENGTH, CHK_HEAD_ON_FOOD, \
+    CHK_ONE_FOOD = (1 << i for i in range(8))
+
+
+def build(force: bool = False) -> str:
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith(('.c', '.h'))]
+    stale = (not os.path.exists(_SO)) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs)
+    if force or stale:
+        subprocess.run(['make', '-C', _HERE] + (['-B'] if force else []), check=True, capture_output=True)
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = ctypes.CDLL(_SO)
+        _lib.oracle_single_obs_elems.restype = ctypes.c_int64
+        _lib.oracle_grid_obs_elems.restype = ctypes.c_int64
+        if hasattr(_lib, 'oracle_multi_obs_elems'):
+            _lib.oracle_multi_obs_elems.restype = ctypes.c_int64
+    return _lib
+
+
+def parse_obs_mode(mode: str):
+    """'partial_2' -> (OBS_PARTIAL, 2) etc."""
+    if mode is None or mode == 'none':
+        return OBS_NONE, 0
+    if mode.startswith('partial_'):
+        return OBS_PARTIAL, int(mode.split('_')[-1])
+    return {'default': OBS_DEFAULT, 'raw': OBS_RAW, 'one_channel': OBS_ONE_CHANNEL, 'positions': OBS_POSITIONS,
+            'full': OBS_DEFAULT}[mode], 0
+
+
+def _p(a):
+    if a is None:
+        return None
+    assert a.flags['C_CONTIGUOUS'], 'oracle arrays must be C-contiguous'
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _act_dtype(a):
+    if a.dtype == np.int64:
+        return ACT_I64
+    if a.dtype == np.int32:
+        return ACT_I32
+    raise TypeError('actions must be int64 or int32')
+
+
+def _check(rc):
+    if rc == -2:
+        raise NotImplementedError('oracle: unsupported configuration')
+    if rc != 0:
+        raise RuntimeError(f'oracle error {rc}')
+
+
+def _i32(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.int32)
+
+
+_u64 = ctypes.c_uint64
+_i64 = ctypes.c_int64
+
+
+# ---------------------------------------------------------------- SingleSnake
+
+def single_obs_shape(mode: str, N: int, S: int):
+    m, n = parse_obs_mode(mode)
+    if m in (OBS_DEFAULT, OBS_RAW):
+        return (N, 3, S, S)
+    if m == OBS_ONE_CHANNEL:
+        return (N, 1, S, S)
+    if m == OBS_POSITIONS:
+        return (N, 4)
+    if m == OBS_PARTIAL:
+        return (N, 3 * (2 * n + 1) ** 2)
+    return None
+
+
+def single_observe(envs, mode: str):
+    N, _, S, _ = envs.shape
+    m, n = parse_obs_mode(mode)
+    obs = np.empty(single_obs_shape(mode, N, S), np.float32)
+    _check(lib().oracle_single_observe(_p(envs), _p(obs), m, n, _i64(N), S))
+    return obs
+
+
+def single_step(envs, actions, mode='default', seed=0, call=0, env_offset=0, inject_food=None):
+    """Returns (obs, reward (N,), done (N,) u8, self_collision, edge_collision); envs and actions in place."""
+    N, _, S, _ = envs.shape
+    m, n = parse_obs_mode(mode)
+    shape = single_obs_shape(mode, N, S)
+    obs = np.empty(shape, np.float32) if shape else None
+    reward = np.empty(N, np.float32)
+    done, sc, ec = (np.empty(N, np.uint8) for _ in range(3))
+    inj = _i32(inject_food)
+    _check(lib().oracle_single_step(_p(envs), _p(actions), _act_dtype(actions), _p(reward), _p(done), _p(sc), _p(ec),
+                                    _p(obs), m, n, _i64(N), S, _u64(seed), _u64(call), _i64(env_offset), _p(inj)))
+    return obs, reward, done, sc, ec
+
+
+def single_reset(envs, done, mode='default', seed=0, call=0, env_offset=0, inject_reset=None):
+    N, _, S, _ = envs.shape
+    m, n = parse_obs_mode(mode)
+    shape = single_obs_shape(mode, N, S)
+    obs = np.empty(shape, np.float32) if shape else None
+    d = np.ascontiguousarray(np.asarray(done).reshape(N) != 0, dtype=np.uint8)
+    inj = _i32(inject_reset)
+    _check(lib().oracle_single_reset(_p(envs), _p(d), _p(obs), m, n, _i64(N), S, _u64(seed), _u64(call),
+                                     _i64(env_offset), _p(inj)))
+    return obs
+
+
+def single_rollout(envs, actions, mode='default', seed=0, call0=0, env_offset=0, inject_food=None,
+                   inject_reset=None):
+    """actions (T,N) sanitised in place. Returns dict of (T,N,...) arrays."""
+    N, _, S, _ = envs.shape
+    T = actions.shape[0]
+    m, n = parse_obs_mode(mode)
+    shape = single_obs_shape(mode, N, S)
+    obs = np.empty((T,) + shape, np.float32) if shape else None
+    reward = np.empty((T, N), np.float32)
+    done, sc, ec = (np.empty((T, N), np.uint8) for _ in range(3))
+    inj_f, inj_r = _i32(inject_food), _i32(inject_reset)
+    _check(lib().oracle_single_rollout(_p(envs), _p(actions), _act_dtype(actions), _p(reward), _p(done), _p(sc),
+                                       _p(ec), _p(obs), m, n, _i64(N), S, _i64(T), _u64(seed), _u64(call0),
+                                       _i64(env_offset), _p(inj_f), _p(inj_r)))
+    return dict(obs=obs, reward=reward, done=done, self_collision=sc, edge_collision=ec)
+
+
+def single_check(envs):
+    N, _, S, _ = envs.shape
+    err = np.empty(N, np.uint32)
+    _check(lib().oracle_single_check(_p(envs), _p(err), _i64(N), S))
+    return err
+
+
+# ---------------------------------------------------------------- SimpleGridworld
+
+def grid_obs_shape(mode: str, N: int, S: int):
+    m, _ = parse_obs_mode(mode)
+    if m == OBS_DEFAULT:
+        return (N, 3, S, S)
+    if m == OBS_RAW:
+        return (N, 2, S, S)
+    if m == OBS_POSITIONS:
+        return (N, 4)
+    return None
+
+
+def grid_observe(envs, mode: str):
+    N, _, S, _ = envs.shape
+    m, n = parse_obs_mode(mode)
+    obs = np.empty(grid_obs_shape(mode, N, S), np.float32)
+    _check(lib().oracle_grid_observe(_p(envs), _p(obs), m, n, _i64(N), S))
+    return obs
+
+
+def grid_step(envs, actions, mode='default', seed=0, call=0, env_offset=0, inject_food=None):
+    N, _, S, _ = envs.shape
+    m, n = parse_obs_mode(mode)
+    shape = grid_obs_shape(mode, N, S)
+    obs = np.empty(shape, np.float32) if shape else None
+    reward = np.empty(N, np.float32)
+    done, ec = (np.empty(N, np.uint8) for _ in range(2))
+    inj = _i32(inject_food)
+    _check(lib().oracle_grid_step(_p(envs), _p(actions), _act_dtype(actions), _p(reward), _p(done), _p(ec), _p(obs),
+                                  m, n, _i64(N), S, _u64(seed), _u64(call), _i64(env_offset), _p(inj)))
+    return obs, reward, done, ec
+
+
+def grid_reset(envs, done, start_location, mode='default', seed=0, call=0, env_offset=0, inject_reset=None):
+    N, _, S, _ = envs.shape
+    m, n = parse_obs_mode(mode)
+    shape = grid_obs_shape(mode, N, S)
+    obs = np.empty(shape, np.float32) if shape else None
+    d = np.ascontiguousarray(np.asarray(done).reshape(N) != 0, dtype=np.uint8)
+    inj = _i32(inject_reset)
+    sy, sx = (-1, -1) if start_location is None else start_location
+    _check(lib().oracle_grid_reset(_p(envs), _p(d), _p(obs), m, n, _i64(N), S, int(sy), int(sx), _u64(seed),
+                                   _u64(call), _i64(env_offset), _p(inj)))
+    return obs
+
+
+def grid_rollout(envs, actions, start_location, mode='default', seed=0, call0=0, env_offset=0, inject_food=None,
+                 inject_reset=None):
+    N, _, S, _ = envs.shape
+    T = actions.shape[0]
+    m, n = parse_obs_mode(mode)
+    shape = grid_obs_shape(mode, N, S)
+    obs = np.empty((T,) + shape, np.float32) if shape else None
+    reward = np.empty((T, N), np.float32)
+    done, ec = (np.empty((T, N), np.uint8) for _ in range(2))
+    inj_f, inj_r = _i32(inject_food), _i32(inject_reset)
+    sy, sx = start_location
+    _check(lib().oracle_grid_rollout(_p(envs), _p(actions), _act_dtype(actions), _p(reward), _p(done), _p(ec),
+                                     _p(obs), m, n, _i64(N), S, _i64(T), int(sy), int(sx), _u64(seed), _u64(call0),
+                                     _i64(env_offset), _p(inj_f), _p(inj_r)))
+    return dict(obs=obs, reward=reward, done=done, edge_collision=ec)

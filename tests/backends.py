@@ -1,0 +1,52 @@
+"""Numpy-in / numpy-out adapters with one interface over the two implementations the tests compare:
+
+* OracleBackend — the CPU oracle (oracle/oracle.py); the checker.
+* HipBackend    — the product's C-ABI (wurm_amd/csrc -> libwurm_hip.so) on cuda:0; defined in
+                  tests/hip_backend.py so that not-gpu runs never touch the GPU library's compute calls.
+"""
+from oracle import oracle as _o
+
+
+class OracleBackend(object):
+    name = 'oracle'
+
+    def __init__(self, seed=0, env_offset=0):
+        self.seed = seed
+        self.env_offset = env_offset
+        self.call = 0
+
+    def _next(self, n=1):
+        c = self.call
+        self.call += n
+        return c
+
+    # SingleSnake
+    def single_step(self, envs, actions, mode, inject_food=None):
+        return _o.single_step(envs, actions, mode, self.seed, self._next(), self.env_offset, inject_food)
+
+    def single_reset(self, envs, done, mode, inject_reset=None):
+        return _o.single_reset(envs, done, mode, self.seed, self._next(), self.env_offset, inject_reset)
+
+    def single_observe(self, envs, mode):
+        return _o.single_observe(envs, mode)
+
+    def single_rollout(self, envs, actions, mode, inject_food=None, inject_reset=None):
+        return _o.single_rollout(envs, actions, mode, self.seed, self._next(2 * actions.shape[0]), self.env_offset,
+                                 inject_food, inject_reset)
+
+    def single_check(self, envs):
+        return _o.single_check(envs)
+
+    # SimpleGridworld
+    def grid_step(self, envs, actions, mode, inject_food=None):
+        return _o.grid_step(envs, actions, mode, self.seed, self._next(), self.env_offset, inject_food)
+
+    def grid_reset(self, envs, done, start, mode, inject_reset=None):
+        return _o.grid_reset(envs, done, start, mode, self.seed, self._next(), self.env_offset, inject_reset)
+
+    def grid_observe(self, envs, mode):
+        return _o.grid_observe(envs, mode)
+
+    def grid_rollout(self, envs, actions, start, mode, inject_food=None, inject_reset=None):
+        return _o.grid_rollout(envs, actions, start, mode, self.seed, self._next(2 * actions.shape[0]),
+                               self.env_offset, inject_food, inject_reset)

@@ -1,0 +1,105 @@
+"""Replays a golden fixture (tests/golden/*.npz, recorded from the real reference by make_golden.py) into a
+backend and asserts bit-equality with what the reference produced at every step.
+
+A backend is anything with the numpy-in / numpy-out methods of tests/backends.py: the CPU oracle
+(not-gpu tests) or the HIP kernels reached through the C-ABI (gpu tests).
+"""
+import os
+
+import numpy as np
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def load(name):
+    z = np.load(os.path.join(GOLDEN, name + '.npz'))
+    return {k: z[k] for k in z.files}
+
+
+def _eq(got, want, what, t):
+    got = np.asarray(got)
+    want = np.asarray(want)
+    assert got.shape == want.shape, f'{what} shape {got.shape} != {want.shape} at t={t}'
+    if got.dtype.kind == 'f' or want.dtype.kind == 'f':
+        # bit-exact: compare the fp32 bit patterns, not values within a tolerance
+        g = np.ascontiguousarray(got, np.float32).view(np.uint32)
+        w = np.ascontiguousarray(want, np.float32).view(np.uint32)
+        bad = np.argwhere(g != w)
+    else:
+        bad = np.argwhere(got.astype(np.int64) != want.astype(np.int64))
+    assert len(bad) == 0, f'{what} mismatch at t={t}: {len(bad)} elements, first at {bad[0].tolist()}: ' \
+                          f'got {got[tuple(bad[0])]} want {want[tuple(bad[0])]}'
+
+
+def replay_single(backend, fx, check_reset_obs=True):
+    mode = str(fx['mode'])
+    N, S, T = (int(v) for v in fx['meta'][:3])
+    envs = fx['state0'].astype(np.float32)
+    for t in range(T):
+        a = fx['actions_in'][t].copy()
+        obs, reward, done, sc, ec = backend.single_step(envs, a, mode, inject_food=fx['inject_food'][t])
+        _eq(a, fx['actions_out'][t], 'sanitised actions', t)
+        _eq(envs, fx['state_step'][t].astype(np.float32), 'post-step state', t)
+        _eq(reward, fx['reward'][t], 'reward', t)
+        _eq(done, fx['done'][t], 'done', t)
+        _eq(sc, fx['self_collision'][t], 'self_collision', t)
+        _eq(ec, fx['edge_collision'][t], 'edge_collision', t)
+        _eq(obs, fx['obs_step'][t], 'step observation', t)
+        if fx['reset_called'][t]:
+            obs_r = backend.single_reset(envs, fx['reset_mask'][t], mode, inject_reset=fx['inject_reset'][t])
+            _eq(envs, fx['state_reset'][t].astype(np.float32), 'post-reset state', t)
+            if check_reset_obs:
+                _eq(obs_r, fx['obs_reset'][t], 'reset observation', t)
+    return envs
+
+
+def replay_single_rollout(backend, fx):
+    """Same tape through the fused multi-step entry point (reset after every step only)."""
+    mode = str(fx['mode'])
+    N, S, T = (int(v) for v in fx['meta'][:3])
+    assert int(fx['meta'][4]) == 1
+    envs = fx['state0'].astype(np.float32)
+    actions = fx['actions_in'].copy()
+    out = backend.single_rollout(envs, actions, mode, inject_food=fx['inject_food'], inject_reset=fx['inject_reset'])
+    _eq(actions, fx['actions_out'], 'sanitised actions', 'all')
+    _eq(out['reward'], fx['reward'], 'reward', 'all')
+    _eq(out['done'], fx['done'], 'done', 'all')
+    _eq(out['self_collision'], fx['self_collision'], 'self_collision', 'all')
+    _eq(out['edge_collision'], fx['edge_collision'], 'edge_collision', 'all')
+    _eq(out['obs'], fx['obs_step'], 'step observations', 'all')
+    _eq(envs, fx['state_reset'][-1].astype(np.float32), 'final state', T - 1)
+
+
+def replay_grid(backend, fx):
+    mode = str(fx['mode'])
+    N, S, T = (int(v) for v in fx['meta'][:3])
+    start = (int(fx['meta'][4]), int(fx['meta'][5]))
+    envs = fx['state0'].astype(np.float32)
+    for t in range(T):
+        a = fx['actions_in'][t].copy()
+        obs, reward, done, ec = backend.grid_step(envs, a, mode, inject_food=fx['inject_food'][t])
+        _eq(a, fx['actions_out'][t], 'actions (must be untouched)', t)
+        _eq(envs, fx['state_step'][t].astype(np.float32), 'post-step state', t)
+        _eq(reward, fx['reward'][t], 'reward', t)
+        _eq(done, fx['done'][t], 'done', t)
+        _eq(ec, fx['edge_collision'][t], 'edge_collision', t)
+        _eq(obs, fx['obs_step'][t], 'step observation', t)
+        obs_r = backend.grid_reset(envs, fx['reset_mask'][t], start, mode, inject_reset=fx['inject_reset'][t])
+        _eq(envs, fx['state_reset'][t].astype(np.float32), 'post-reset state', t)
+        _eq(obs_r, fx['obs_reset'][t], 'reset observation', t)
+    return envs
+
+
+def replay_grid_rollout(backend, fx):
+    mode = str(fx['mode'])
+    N, S, T = (int(v) for v in fx['meta'][:3])
+    start = (int(fx['meta'][4]), int(fx['meta'][5]))
+    envs = fx['state0'].astype(np.float32)
+    actions = fx['actions_in'].copy()
+    out = backend.grid_rollout(envs, actions, start, mode, inject_food=fx['inject_food'],
+                               inject_reset=fx['inject_reset'])
+    _eq(out['reward'], fx['reward'], 'reward', 'all')
+    _eq(out['done'], fx['done'], 'done', 'all')
+    _eq(out['edge_collision'], fx['edge_collision'], 'edge_collision', 'all')
+    _eq(out['obs'], fx['obs_step'], 'step observations', 'all')
+    _eq(envs, fx['state_reset'][-1].astype(np.float32), 'final state', T - 1)

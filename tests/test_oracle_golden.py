@@ -1,0 +1,30 @@
+"""Pins the CPU oracle against golden fixtures recorded from the real reference (tests/golden/make_golden.py):
+every step's sanitised actions, state, reward, done, info and observation bits, and every reset."""
+import pytest
+
+from tests import replay
+from tests.backends import OracleBackend
+
+SINGLE = ['single_s9_partial2', 'single_s12_default', 'single_s12_one_channel', 'single_s10_raw',
+          'single_s12_positions', 'single_s11_partial3_i32', 'single_s36_default', 'single_s12_lazyreset']
+GRID = ['grid_s9_default', 'grid_s7_raw']
+
+
+@pytest.mark.parametrize('name', SINGLE)
+def test_single_snake_matches_reference(name):
+    replay.replay_single(OracleBackend(), replay.load(name))
+
+
+@pytest.mark.parametrize('name', [n for n in SINGLE if n != 'single_s12_lazyreset'])
+def test_single_snake_rollout_matches_reference(name):
+    replay.replay_single_rollout(OracleBackend(), replay.load(name))
+
+
+@pytest.mark.parametrize('name', GRID)
+def test_gridworld_matches_reference(name):
+    replay.replay_grid(OracleBackend(), replay.load(name))
+
+
+@pytest.mark.parametrize('name', GRID)
+def test_gridworld_rollout_matches_reference(name):
+    replay.replay_grid_rollout(OracleBackend(), replay.load(name))
