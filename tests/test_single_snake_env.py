@@ -1,0 +1,156 @@
+"""The reference's own SingleSnake test-suite (tests/test_single_snake_env.py in oscarknagg/wurm) re-expressed
+against wurm_amd.envs.SingleSnake: same boards, action tapes and assertions."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+size = 12
+DEVICE = 'cuda'
+
+
+@pytest.fixture(scope='module')
+def api():
+    from wurm_amd.envs import SingleSnake
+    from wurm_amd.utils import get_test_env, head, body, food, env_consistency
+    return dict(SingleSnake=SingleSnake, get_test_env=get_test_env, head=head, body=body, food=food,
+                env_consistency=env_consistency)
+
+
+def _head_position(api, env):
+    idx = api['head'](env.envs)[0, 0].flatten().argmax()
+    return torch.Tensor([idx // size, idx % size])
+
+
+def test_multiple_envs(api):
+    num_envs, num_steps = 100, 100
+    env = api['SingleSnake'](num_envs=num_envs, size=size)
+    actions = torch.randint(4, size=(num_steps, num_envs)).long().to(DEVICE)
+    for a in actions:
+        observations, reward, done, info = env.step(a)
+        env.reset(done)
+        api['env_consistency'](env.envs)
+
+
+def test_setup(api):
+    n = 97
+    env = api['SingleSnake'](num_envs=n, size=size)
+    api['env_consistency'](env.envs)
+    expected_body_sum = env.initial_snake_length * (env.initial_snake_length + 1) / 2
+    assert torch.all(api['body'](env.envs).view(n, -1).sum(dim=-1) == expected_body_sum)
+
+
+def test_reset(api):
+    env = api['SingleSnake'](num_envs=1, size=size)
+    api['env_consistency'](env.envs)
+    env.reset(torch.Tensor([1]).to(DEVICE))
+    api['env_consistency'](env.envs)
+
+
+def test_basic_movement(api):
+    env = api['SingleSnake'](num_envs=1, size=size, manual_setup=True)
+    env.envs = api['get_test_env'](size, 'up').to(DEVICE)
+    actions = torch.Tensor([0, 0, 3, 0, 0, 1]).unsqueeze(1).long().to(DEVICE)
+    expected = torch.Tensor([[6, 4], [7, 4], [7, 5], [8, 5], [9, 5], [9, 4]])
+    for i, a in enumerate(actions):
+        observations, reward, done, info = env.step(a)
+        assert torch.equal(_head_position(api, env), expected[i])
+        assert not torch.any(done)
+
+
+def test_eat_food(api):
+    env = api['SingleSnake'](num_envs=1, size=size, manual_setup=True)
+    env.envs = api['get_test_env'](size, 'up').to(DEVICE)
+    actions = torch.Tensor([0, 3, 3, 0, 0]).unsqueeze(1).long().to(DEVICE)
+    initial_size = api['body'](env.envs).max()
+    rewards = []
+    for a in actions:
+        observations, reward, done, info = env.step(a)
+        rewards.append(reward.item())
+        assert not torch.any(done)
+    assert rewards == [0, 0, 1, 0, 0]
+    assert api['body'](env.envs).max() > initial_size
+    assert api['food'](env.envs).sum() == 1
+    api['env_consistency'](env.envs)
+
+
+def test_hit_boundary(api):
+    env = api['SingleSnake'](num_envs=1, size=size, manual_setup=True)
+    env.envs = api['get_test_env'](size, 'up').to(DEVICE)
+    actions = torch.Tensor([1, ] * 10).unsqueeze(1).long().to(DEVICE)
+    hit_at = None
+    for i, a in enumerate(actions):
+        observations, reward, done, info = env.step(a)
+        if torch.any(done):
+            hit_at = i
+            assert info['edge_collision'].item() and not info['self_collision'].item()
+            break
+    assert hit_at == 3  # head reaches column 0 on the 4th step
+
+
+def test_hit_self(api):
+    env = api['SingleSnake'](num_envs=1, size=size, manual_setup=True)
+    env.envs = api['get_test_env'](size, 'up').to(DEVICE)
+    actions = torch.Tensor([0, 3, 3, 2, 1, 0, 0, 0]).unsqueeze(1).long().to(DEVICE)
+    hit_self = False
+    for a in actions:
+        observations, reward, done, info = env.step(a)
+        if torch.any(done):
+            hit_self = bool(info['self_collision'].item())
+            break
+    assert hit_self
+    assert api['food'](env.envs).sum() == 1
+
+
+def test_cannot_move_backwards(api):
+    env = api['SingleSnake'](num_envs=1, size=size, manual_setup=True)
+    env.envs = api['get_test_env'](size, 'up').to(DEVICE)
+    actions = torch.Tensor([2, 2, 2, 3]).unsqueeze(1).long().to(DEVICE)
+    expected = torch.Tensor([[6, 4], [7, 4], [8, 4], [8, 5]])
+    for i, a in enumerate(actions):
+        observations, reward, done, info = env.step(a)
+        assert torch.equal(_head_position(api, env), expected[i])
+        assert not torch.any(done)
+    # the caller's tensor was sanitised in place: the three reversals became forward moves (reference :222)
+    assert actions.flatten().tolist() == [0, 0, 0, 3]
+
+
+def test_argument_errors(api):
+    env = api['SingleSnake'](num_envs=4, size=size)
+    with pytest.raises(TypeError):
+        env.step(torch.zeros(4, device=DEVICE))
+    with pytest.raises(RuntimeError):
+        env.step(torch.zeros(5, dtype=torch.long, device=DEVICE))
+    with pytest.raises(NotImplementedError):
+        api['SingleSnake'](num_envs=2, size=8)
+
+
+def test_outputs_shapes_and_dtypes(api):
+    env = api['SingleSnake'](num_envs=6, size=9, observation_mode='partial_2')
+    obs, reward, done, info = env.step(torch.zeros(6, dtype=torch.long, device=DEVICE))
+    assert obs.shape == (6, 75) and obs.dtype == torch.float32
+    assert reward.shape == (6, 1) and reward.dtype == torch.float32
+    assert done.shape == (6, 1) and done.dtype == torch.bool
+    assert set(info) == {'self_collision', 'edge_collision'} and info['edge_collision'].shape == (6,)
+    assert env.reset(done).shape == (6, 75)
+    assert env.reset().shape == (6, 75)
+
+
+def test_rollout_equals_python_loop(api):
+    torch.manual_seed(3)
+    N, T = 64, 96
+    a = api['SingleSnake'](num_envs=N, size=9, observation_mode='partial_2', seed=42)
+    b = api['SingleSnake'](num_envs=N, size=9, observation_mode='partial_2', seed=42)
+    assert torch.equal(a.envs, b.envs)
+    actions = torch.randint(4, size=(T, N)).long().to(DEVICE)
+    acts_b = actions.clone()
+    out = b.rollout(acts_b)
+    for t in range(T):
+        act = actions[t].clone()
+        obs, reward, done, info = a.step(act)
+        a.reset(done)
+        assert torch.equal(obs, out['observations'][t])
+        assert torch.equal(reward.squeeze(-1), out['rewards'][t])
+        assert torch.equal(done.squeeze(-1), out['dones'][t])
+        assert torch.equal(act, acts_b[t])
+    assert torch.equal(a.envs, b.envs)

@@ -1,0 +1,108 @@
+"""Loader of libwurm_hip.so (the gfx950 kernels behind a C ABI, include/wurm_hip.h).
+
+There is deliberately NO fallback: if the library is missing, or a call is made without a HIP device, the
+product raises.  The CPU oracle under oracle/ is test infrastructure and is never used from here.
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libwurm_hip.so')
+CSRC = os.path.join(_HERE, 'csrc')
+
+OK, ERR_INVALID_ARG, ERR_UNSUPPORTED, ERR_HIP, ERR_DTYPE = 0, -1, -2, -3, -4
+
+OBS_DEFAULT, OBS_RAW, OBS_ONE_CHANNEL, OBS_POSITIONS, OBS_PARTIAL, OBS_NONE = range(6)
+ACT_I64, ACT_I32 = 0, 1
+
+# every symbol include/wurm_hip.h declares (tests/test_abi.py checks the header against this list and the .so)
+SYMBOLS = [
+    'wurm_version', 'wurm_single_obs_elems', 'wurm_grid_obs_elems',
+    'wurm_single_step', 'wurm_single_reset', 'wurm_single_observe', 'wurm_single_rollout', 'wurm_single_check',
+    'wurm_grid_step', 'wurm_grid_reset', 'wurm_grid_observe', 'wurm_grid_rollout',
+]
+
+
+class WurmHipError(RuntimeError):
+    pass
+
+
+def build(force: bool = False) -> str:
+    """Compiles wurm_amd/csrc/*.hip for gfx950 into wurm_amd/libwurm_hip.so (hipcc cross-compiles without a GPU)."""
+    cmd = ['make', '-C', CSRC] + (['-B'] if force else [])
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise WurmHipError('building libwurm_hip.so failed:\n' + r.stdout[-4000:] + r.stderr[-4000:])
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise WurmHipError(
+                f'{LIB_PATH} is missing: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+                f'(or `make -C wurm_amd/csrc`). There is no CPU fallback.')
+        l = ctypes.CDLL(LIB_PATH)
+        l.wurm_version.restype = ctypes.c_char_p
+        l.wurm_single_obs_elems.restype = ctypes.c_int64
+        l.wurm_grid_obs_elems.restype = ctypes.c_int64
+        _lib = l
+    return _lib
+
+
+def check(rc: int, what: str):
+    """Maps C-ABI error codes onto the exception types the reference raises for the same conditions."""
+    if rc == OK:
+        return
+    if rc == ERR_UNSUPPORTED:
+        raise NotImplementedError(f'{what}: configuration not supported')
+    if rc == ERR_DTYPE:
+        raise TypeError(f'{what}: actions Tensor must be an integer type')
+    if rc == ERR_HIP:
+        raise WurmHipError(f'{what}: HIP kernel launch failed')
+    raise RuntimeError(f'{what}: invalid argument (code {rc})')
+
+
+def parse_obs_mode(mode):
+    if mode is None or mode == 'none':
+        return OBS_NONE, 0
+    if mode.startswith('partial_'):
+        return OBS_PARTIAL, int(mode.split('_')[-1])
+    table = {'default': OBS_DEFAULT, 'raw': OBS_RAW, 'one_channel': OBS_ONE_CHANNEL, 'positions': OBS_POSITIONS,
+             'full': OBS_DEFAULT}
+    if mode not in table:
+        raise ValueError(f'Unrecognised observation mode: {mode}')
+    return table[mode], 0
+
+
+def require_device(device):
+    """Resolves `device` to a torch.device and insists that it is a HIP GPU."""
+    import torch
+    dev = torch.device(device)
+    if dev.type != 'cuda':
+        raise WurmHipError(f"wurm_amd runs on MI355X only: device must be 'cuda[:i]', got '{device}'. "
+                           f'There is no CPU fallback (the CPU oracle under oracle/ is test infrastructure).')
+    if not torch.cuda.is_available():
+        raise WurmHipError('wurm_amd: no HIP device visible (torch.cuda.is_available() is False)')
+    if dev.index is None:
+        dev = torch.device('cuda', torch.cuda.current_device())
+    lib()
+    return dev
+
+
+def ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def stream_ptr():
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+u64 = ctypes.c_uint64
+i64 = ctypes.c_int64

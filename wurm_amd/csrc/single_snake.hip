@@ -1,0 +1,881 @@
+// single_snake.hip — gfx950 kernels and C-ABI entry points for SingleSnake and SimpleGridworld.
+//
+// Replaces the reference's op sequences (cited against oscarknagg/wurm):
+//   SingleSnake.step      wurm/envs/single_snake.py:197-304   (~60 torch op dispatches + 2-3 host syncs)
+//   SingleSnake._observe  wurm/envs/single_snake.py:104-195
+//   SingleSnake.reset     wurm/envs/single_snake.py:322-387
+//   determine_orientations wurm/utils.py:36-65, food respawn wurm/utils.py:181-232
+//   SimpleGridworld.*     wurm/envs/simple_gridworld.py:88-268
+// with ONE fused launch per call: one env per wavefront, the env's cells spread over the lanes
+// (cell c = lane + 64*k), food/head channels held as per-lane bit sets, the body channel as per-lane ints,
+// per-env scalars wave-uniform via ballot / wave-max, no host sync, no MFMA (integer/index work, HBM-bound).
+// The only LDS use is a one-byte-per-cell class map for the cropped `partial_n` observation and for the
+// general (irregular-state) orientation stencil.
+#include "wurm_device.hpp"
+#include "../../include/wurm_hip.h"
+
+namespace wurm {
+
+// ------------------------------------------------------------------------------------------------ state
+
+template <int CPL>
+struct Env {
+    int body[CPL]; // body channel (SingleSnake only), cell lane + 64k
+    u64 food;      // bit k: food at cell lane + 64k
+    u64 head;      // bit k: head / agent at cell lane + 64k
+};
+
+struct Geo {
+    int S, C, lane;
+    float rcpS;
+    u64 valid;    // bit k: lane + 64k < C
+    u64 interior; // bit k: cell is not on the border ring
+};
+
+template <int CPL>
+__device__ __forceinline__ Geo make_geo(int S)
+{
+    Geo g;
+    g.S = S;
+    g.C = S * S;
+    g.lane = (int)(threadIdx.x & 63u);
+    g.rcpS = 1.0f / (float)S;
+    g.valid = 0;
+    g.interior = 0;
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) {
+        int c = g.lane + 64 * k;
+        if (c < g.C) {
+            g.valid |= 1ull << k;
+            int y = div_size(c, g.rcpS), x = c - y * S;
+            if (y >= 1 && y <= S - 2 && x >= 1 && x <= S - 2) g.interior |= 1ull << k;
+        }
+    }
+    return g;
+}
+
+template <int CPL, bool SNAKE>
+__device__ __forceinline__ void load_state(const float *__restrict__ envp, const Geo &g, Env<CPL> &e)
+{
+    float f[CPL], h[CPL], b[CPL];
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) {
+        int c = g.lane + 64 * k;
+        bool v = (g.valid >> k) & 1;
+        f[k] = v ? envp[c] : 0.0f;
+        h[k] = v ? envp[g.C + c] : 0.0f;
+        b[k] = (SNAKE && v) ? envp[2 * g.C + c] : 0.0f;
+    }
+    e.food = 0;
+    e.head = 0;
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) {
+        if (f[k] > 0.5f) e.food |= 1ull << k;
+        if (h[k] > 0.5f) e.head |= 1ull << k;
+        e.body[k] = SNAKE ? __float2int_rn(b[k]) : 0;
+    }
+}
+
+template <int CPL, bool SNAKE>
+__device__ __forceinline__ void store_state(float *__restrict__ envp, const Geo &g, const Env<CPL> &e)
+{
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) {
+        int c = g.lane + 64 * k;
+        if ((g.valid >> k) & 1) {
+            envp[c] = ((e.food >> k) & 1) ? 1.0f : 0.0f;
+            envp[g.C + c] = ((e.head >> k) & 1) ? 1.0f : 0.0f;
+            if (SNAKE) envp[2 * g.C + c] = (float)e.body[k];
+        }
+    }
+}
+
+template <int CPL>
+__device__ __forceinline__ int find_head(const Env<CPL> &e)
+{
+    int cell = -1;
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) {
+        u64 m = ballot((e.head >> k) & 1);
+        if (cell < 0 && m) cell = 64 * k + first_bit(m);
+    }
+    return cell;
+}
+
+// ------------------------------------------------------------------------------------------------ orientation
+
+// General form of determine_orientations (wurm/utils.py:36-65) for states that are not a well-formed snake
+// (e.g. a done env stepped again before reset): neck map in LDS, 4-tap stencil, wave max, first argmax.
+template <int CPL>
+__device__ __noinline__ int slow_orientation(const Env<CPL> &e, const Geo &g, int L, signed char *lds)
+{
+    wave_lds_sync();
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) {
+        int c = g.lane + 64 * k;
+        if ((g.valid >> k) & 1) {
+            int r = e.body[k] - (L - 2);                   // utils.py:51-53 relu(body - (L-2))
+            lds[c] = (signed char)(r <= 0 ? 0 : 2 * r - 3); // utils.py:54-55: r=1 -> -1 (neck), r=2 -> +1 (head)
+        }
+    }
+    wave_lds_sync();
+    int best0 = -128, best1 = -128, best2 = -128, best3 = -128;
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) {
+        int c = g.lane + 64 * k;
+        if ((g.valid >> k) & 1) {
+            int y = div_size(c, g.rcpS), x = c - y * g.S;
+            int own = lds[c];
+            int n0 = y >= 1 ? lds[c - g.S] : 0;       // tap (-1, 0)
+            int n1 = x <= g.S - 2 ? lds[c + 1] : 0;   // tap ( 0,+1)
+            int n2 = y <= g.S - 2 ? lds[c + g.S] : 0; // tap (+1, 0)
+            int n3 = x >= 1 ? lds[c - 1] : 0;         // tap ( 0,-1)
+            best0 = max(best0, n0 - own);
+            best1 = max(best1, n1 - own);
+            best2 = max(best2, n2 - own);
+            best3 = max(best3, n3 - own);
+        }
+    }
+    best0 = wave_max_i32(best0);
+    best1 = wave_max_i32(best1);
+    best2 = wave_max_i32(best2);
+    best3 = wave_max_i32(best3);
+    int o = 0, bv = best0; // utils.py:63 argmax, first maximum wins
+    if (best1 > bv) { bv = best1; o = 1; }
+    if (best2 > bv) { bv = best2; o = 2; }
+    if (best3 > bv) { bv = best3; o = 3; }
+    wave_lds_sync();
+    return uniform(o);
+}
+
+// ------------------------------------------------------------------------------------------------ food respawn
+
+// _get_food_addition (single_snake.py:306-320, simple_gridworld.py:209-223): +1 food on one uniformly random
+// interior cell with nothing on it.  RNG form: the K-th free cell in row-major order, K = mulhi(word, n_free).
+template <int CPL, bool SNAKE, bool WRITE>
+__device__ __forceinline__ void add_food(Env<CPL> &e, const Geo &g, float *__restrict__ envp, bool use_inject,
+                                         int inject_cell, u32 word)
+{
+    if (use_inject) {
+#pragma unroll
+        for (int k = 0; k < CPL; ++k) {
+            int c = g.lane + 64 * k;
+            if (c == inject_cell && ((g.valid >> k) & 1)) {
+                e.food |= 1ull << k;
+                if (WRITE) envp[c] = 1.0f;
+            }
+        }
+        return;
+    }
+    u64 occupied = e.food | e.head;
+    int n_free = 0;
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) {
+        bool fr = ((g.interior >> k) & 1) && !((occupied >> k) & 1) && (!SNAKE || e.body[k] == 0);
+        n_free += popc64(ballot(fr));
+    }
+    if (n_free == 0) return;
+    int K = (int)mulhi_range(word, (u32)n_free);
+    int base = 0;
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) {
+        bool fr = ((g.interior >> k) & 1) && !((occupied >> k) & 1) && (!SNAKE || e.body[k] == 0);
+        u64 m = ballot(fr);
+        if (fr && base + rank_below(m) == K) {
+            e.food |= 1ull << k;
+            if (WRITE) envp[g.lane + 64 * k] = 1.0f;
+        }
+        base += popc64(m);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ step
+
+struct StepOut {
+    long long action; // sanitised action (SingleSnake)
+    int headcell;     // head cell after the move, -1 if it left the grid
+    float reward;
+    int done, selfc, edgec;
+};
+
+// One transition of one env held in registers.  WRITE: changed cells are written through to HBM as they are
+// produced (per-call kernels); !WRITE: registers only (rollout kernel).
+template <int CPL, bool SNAKE, bool WRITE>
+__device__ __forceinline__ void step_core(Env<CPL> &e, const Geo &g, float *__restrict__ envp, long long a_in,
+                                          StepOut &out, u64 seed, u64 call, u64 env_id, bool use_inject,
+                                          int inject_cell, signed char *lds)
+{
+    const int S = g.S, C = g.C, lane = g.lane;
+    long long a = a_in;
+    int L = 0;
+    if (SNAKE) {
+        int lm = 0;
+#pragma unroll
+        for (int k = 0; k < CPL; ++k) lm = max(lm, e.body[k]);
+        L = uniform(wave_max_i32(lm)); // single_snake.py:210 snake_sizes
+
+        // determine_orientations (utils.py:36-65).  Well-formed snake: exactly one cell == L and one == L-1.
+        int cntL = 0, cntN = 0, cellL = -1, cellN = -1;
+#pragma unroll
+        for (int k = 0; k < CPL; ++k) {
+            bool v = (g.valid >> k) & 1;
+            u64 mL = ballot(v && e.body[k] == L);
+            u64 mN = ballot(v && e.body[k] == L - 1);
+            cntL += popc64(mL);
+            cntN += popc64(mN);
+            if (cellL < 0 && mL) cellL = 64 * k + first_bit(mL);
+            if (cellN < 0 && mN) cellN = 64 * k + first_bit(mN);
+        }
+        int o;
+        if (cntL == 1 && cntN == 1 && L >= 2) {
+            int yL = div_size(cellL, g.rcpS), xL = cellL - yL * S;
+            int yN = div_size(cellN, g.rcpS), xN = cellN - yN * S;
+            int dy = yL - yN, dx = xL - xN;
+            o = (dy == 0 && dx == 1) ? 1 : (dy == 1 && dx == 0) ? 2 : (dy == 0 && dx == -1) ? 3 : 0;
+        } else {
+            o = slow_orientation<CPL>(e, g, L, lds);
+        }
+        if ((long long)o == a) a += 2; // single_snake.py:221-222 (written back in place by the caller)
+        a = a % 4;                     // fmod_: sign follows the dividend
+    }
+    const int ai = (int)(((a % 4) + 4) % 4);
+
+    // head shift (single_snake.py:225-233 / simple_gridworld.py:149-157): by -TAP[a]; off-grid => vanishes
+    const int headcell = find_head<CPL>(e);
+    int newhead = -1, ny = -1, nx = -1;
+    if (headcell >= 0) {
+        int hy = div_size(headcell, g.rcpS), hx = headcell - hy * S;
+        ny = hy - tap_y(ai);
+        nx = hx - tap_x(ai);
+        if (ny >= 0 && ny < S && nx >= 0 && nx < S) newhead = ny * S + nx;
+    }
+
+    bool eat_l = false;
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) eat_l |= (lane + 64 * k == newhead) && ((e.food >> k) & 1);
+    const bool EAT = ballot(eat_l) != 0; // single_snake.py:242 head_food_overlap
+
+    bool selfc_l = false;
+    u64 newbits = 0;
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) {
+        const int c = lane + 64 * k;
+        const bool is_new = (c == newhead);
+        if (SNAKE) {
+            const int b0 = e.body[k];
+            int b = b0;
+            if (!EAT) b = max(b - 1, 0); // :246-249 decay unless food was eaten
+            if (is_new) {
+                selfc_l |= b > 0;        // :252 self collision (after the decay)
+                b += L + (EAT ? 1 : 0);  // :258-262 new head segment
+            }
+            if (WRITE && b != b0) envp[2 * C + c] = (float)b;
+            e.body[k] = b;
+        }
+        if (is_new) {
+            newbits |= 1ull << k;
+            if ((e.food >> k) & 1) {     // :270-272 food removal
+                e.food &= ~(1ull << k);
+                if (WRITE) envp[c] = 0.0f;
+            }
+        }
+        if (WRITE && (((e.head >> k) & 1) != (u64)is_new)) envp[C + c] = is_new ? 1.0f : 0.0f;
+    }
+    e.head = newbits;
+    const bool SELFC = SNAKE && (ballot(selfc_l) != 0);
+
+    if (EAT) { // :277-282
+        u32 word = 0;
+        if (!use_inject) word = rng_words(seed, call, env_id, RNG_FOOD, 0).w[0];
+        add_food<CPL, SNAKE, WRITE>(e, g, envp, use_inject, inject_cell, word);
+    }
+
+    // :290-295 edge collision: head not in the interior (on the border ring or gone)
+    const bool EDGEC = !(newhead >= 0 && ny >= 1 && ny <= S - 2 && nx >= 1 && nx <= S - 2);
+
+    out.action = a;
+    out.headcell = newhead;
+    out.reward = EAT ? 1.0f : 0.0f;
+    out.selfc = SELFC;
+    out.edgec = EDGEC;
+    out.done = SELFC | EDGEC;
+}
+
+// ------------------------------------------------------------------------------------------------ reset
+
+// _create_envs for one env (single_snake.py:344-387 / simple_gridworld.py:247-268).  inj: SNAKE {seed_y,
+// seed_x, direction, food_cell}; GRID {food_cell}.
+template <int CPL, bool SNAKE>
+__device__ __forceinline__ void reset_core(Env<CPL> &e, const Geo &g, u64 seed, u64 call, u64 env_id,
+                                           const int *__restrict__ inj, int start_y, int start_x)
+{
+    const int S = g.S, lane = g.lane;
+    const bool use_inject = inj != nullptr;
+    Words w;
+    w.w[0] = w.w[1] = w.w[2] = w.w[3] = 0;
+    if (!use_inject) w = rng_words(seed, call, env_id, RNG_RESET, 0);
+    int hc, sc = -1, tc = -1, foodcell = -1;
+    if (SNAKE) {
+        int sy, sx, d;
+        if (use_inject) {
+            sy = inj[0]; sx = inj[1]; d = inj[2]; foodcell = inj[3];
+        } else { // randint(4, S-4) twice, randint(4) (:358-359,366)
+            sy = 4 + (int)mulhi_range(w.w[0], (u32)(S - 8));
+            sx = 4 + (int)mulhi_range(w.w[1], (u32)(S - 8));
+            d = (int)(w.w[2] >> 30);
+        }
+        // conv2d(seed, LENGTH_3_SNAKES[d]) (:372-376): 3 at seed + TAP[d], 2 at the seed, 1 at seed - TAP[d]
+        hc = (sy + tap_y(d)) * S + sx + tap_x(d);
+        sc = sy * S + sx;
+        tc = (sy - tap_y(d)) * S + sx - tap_x(d);
+    } else {
+        hc = start_y * S + start_x; // simple_gridworld.py:262
+        if (use_inject) foodcell = inj[0];
+    }
+    e.food = 0;
+    e.head = 0;
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) {
+        int c = lane + 64 * k;
+        e.body[k] = SNAKE ? (c == hc ? 3 : c == sc ? 2 : c == tc ? 1 : 0) : 0;
+        if (c == hc) e.head |= 1ull << k;
+    }
+    add_food<CPL, SNAKE, false>(e, g, nullptr, use_inject, foodcell, w.w[3]); // :384-385
+}
+
+// ------------------------------------------------------------------------------------------------ observations
+
+__device__ __forceinline__ float class_rgb(int cls, int ch, bool snake)
+{
+    // classes: 0 background, 1 body, 2 head, 3 food, 4 border ring.  single_snake.py:99-128 paints body
+    // (0,127,0), head (0,255,0), food (255,0,0) on white, ring black; simple_gridworld.py:84-109 on black.
+    switch (cls) {
+    case 0: return snake ? 1.0f : 0.0f;
+    case 1: return ch == 1 ? 127.0f / 255.0f : 0.0f;
+    case 2: return ch == 1 ? 1.0f : 0.0f;
+    case 3: return ch == 0 ? 1.0f : 0.0f;
+    default: return 0.0f;
+    }
+}
+
+template <int CPL, bool SNAKE>
+__device__ __forceinline__ int cell_class(const Env<CPL> &e, const Geo &g, int k)
+{
+    if (!((g.interior >> k) & 1)) return 4;
+    if ((e.food >> k) & 1) return 3;
+    if ((e.head >> k) & 1) return 2;
+    if (SNAKE && e.body[k] > 0) return 1;
+    return 0;
+}
+
+// _observe of one env (single_snake.py:130-195, simple_gridworld.py:111-133) from registers.
+// headcell: the env's head cell (-1 = none).
+template <int CPL, bool SNAKE>
+__device__ __forceinline__ void write_obs(const Env<CPL> &e, const Geo &g, int headcell, float *__restrict__ o,
+                                          int mode, int n, signed char *lds)
+{
+    const int S = g.S, C = g.C, lane = g.lane;
+    if (mode == WURM_OBS_DEFAULT) {
+#pragma unroll
+        for (int k = 0; k < CPL; ++k) {
+            int c = lane + 64 * k;
+            if ((g.valid >> k) & 1) {
+                int cls = cell_class<CPL, SNAKE>(e, g, k);
+                o[c] = class_rgb(cls, 0, SNAKE);
+                o[C + c] = class_rgb(cls, 1, SNAKE);
+                o[2 * C + c] = class_rgb(cls, 2, SNAKE);
+            }
+        }
+    } else if (mode == WURM_OBS_PARTIAL) {
+        const int W = 2 * n + 1, W2 = W * W, E = 3 * W2;
+        wave_lds_sync();
+#pragma unroll
+        for (int k = 0; k < CPL; ++k)
+            if ((g.valid >> k) & 1) lds[lane + 64 * k] = (signed char)cell_class<CPL, SNAKE>(e, g, k);
+        wave_lds_sync();
+        const int hy = headcell >= 0 ? div_size(headcell, g.rcpS) : 0;
+        const int hx = headcell - hy * S;
+        const float rcpW2 = 1.0f / (float)W2, rcpW = 1.0f / (float)W;
+        for (int el = lane; el < E; el += 64) {
+            int ch = div_size(el, rcpW2), w = el - ch * W2;
+            int wy = div_size(w, rcpW), wx = w - wy * W;
+            int y = hy - n + wy, x = hx - n + wx;
+            float v = 0.0f; // F.pad zeros (single_snake.py:179); no head: zeros (the reference raises at :191)
+            if (headcell >= 0 && y >= 0 && y < S && x >= 0 && x < S) v = class_rgb(lds[y * S + x], ch, SNAKE);
+            o[el] = v;
+        }
+        wave_lds_sync();
+    } else if (mode == WURM_OBS_ONE_CHANNEL) { // single_snake.py:142-151
+#pragma unroll
+        for (int k = 0; k < CPL; ++k) {
+            int c = lane + 64 * k;
+            if ((g.valid >> k) & 1) {
+                float v = (e.body[k] > 0 ? 0.5f : 0.0f) + (((e.head >> k) & 1) ? 0.5f : 0.0f) +
+                          (((e.food >> k) & 1) ? 1.5f : 0.0f);
+                if (!((g.interior >> k) & 1)) v = -1.0f;
+                o[c] = v;
+            }
+        }
+    } else if (mode == WURM_OBS_RAW) { // clone of the state
+#pragma unroll
+        for (int k = 0; k < CPL; ++k) {
+            int c = lane + 64 * k;
+            if ((g.valid >> k) & 1) {
+                o[c] = ((e.food >> k) & 1) ? 1.0f : 0.0f;
+                o[C + c] = ((e.head >> k) & 1) ? 1.0f : 0.0f;
+                if (SNAKE) o[2 * C + c] = (float)e.body[k];
+            }
+        }
+    } else if (mode == WURM_OBS_POSITIONS) { // argmax of the head and food channels (first maximum; 0 if empty)
+        int fcell = -1;
+#pragma unroll
+        for (int k = 0; k < CPL; ++k) {
+            u64 m = ballot((e.food >> k) & 1);
+            if (fcell < 0 && m) fcell = 64 * k + first_bit(m);
+        }
+        int h = headcell < 0 ? 0 : headcell, f = fcell < 0 ? 0 : fcell;
+        int hy = div_size(h, g.rcpS), fy = div_size(f, g.rcpS);
+        if (lane < 4) o[lane] = (float)(lane == 0 ? hy : lane == 1 ? h - hy * S : lane == 2 ? fy : f - fy * S);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ kernels
+
+struct StepArgs {
+    float *envs;
+    void *actions;
+    int act_dtype;
+    float *reward;
+    uint8_t *done, *selfc, *edgec;
+    float *obs;
+    int obs_mode, obs_n;
+    long long obs_elems;
+    long long N;
+    int S;
+    long long T;
+    int start_y, start_x;
+    u64 seed, call;
+    long long env_offset;
+    const int *inject_food;
+    const int *inject_reset;
+    const uint8_t *done_in;
+    int lds_per_wave;
+};
+
+__device__ __forceinline__ long long load_action(const void *actions, int dtype, long long i)
+{
+    return dtype == WURM_ACT_I64 ? ((const long long *)actions)[i] : (long long)((const int *)actions)[i];
+}
+
+__device__ __forceinline__ void store_action(void *actions, int dtype, long long i, long long v)
+{
+    if (dtype == WURM_ACT_I64) ((long long *)actions)[i] = v;
+    else ((int *)actions)[i] = (int)v;
+}
+
+extern __shared__ __attribute__((aligned(16))) signed char wurm_lds[];
+
+template <int CPL, bool SNAKE>
+__global__ __launch_bounds__(256) void step_kernel(StepArgs p)
+{
+    const int wave = (int)(threadIdx.x >> 6), wpb = (int)(blockDim.x >> 6);
+    const long long env = (long long)blockIdx.x * wpb + wave;
+    if (env >= p.N) return;
+    signed char *lds = wurm_lds + wave * p.lds_per_wave;
+    const int NCH = SNAKE ? 3 : 2;
+    const Geo g = make_geo<CPL>(p.S);
+    float *envp = p.envs + env * NCH * g.C;
+    Env<CPL> e;
+    load_state<CPL, SNAKE>(envp, g, e);
+    const long long a_in = uniform64(load_action(p.actions, p.act_dtype, env));
+    const bool inj = p.inject_food != nullptr;
+    const int inj_cell = inj ? uniform(p.inject_food[env]) : -1;
+    StepOut out;
+    step_core<CPL, SNAKE, true>(e, g, envp, a_in, out, p.seed, p.call, (u64)(p.env_offset + env), inj, inj_cell, lds);
+    if (g.lane == 0) {
+        if (SNAKE) {
+            store_action(p.actions, p.act_dtype, env, out.action);
+            p.selfc[env] = (uint8_t)out.selfc;
+        }
+        p.reward[env] = out.reward;
+        p.done[env] = (uint8_t)out.done;
+        p.edgec[env] = (uint8_t)out.edgec;
+    }
+    if (p.obs_mode != WURM_OBS_NONE)
+        write_obs<CPL, SNAKE>(e, g, out.headcell, p.obs + env * p.obs_elems, p.obs_mode, p.obs_n, lds);
+}
+
+template <int CPL, bool SNAKE>
+__global__ __launch_bounds__(256) void reset_kernel(StepArgs p)
+{
+    const int wave = (int)(threadIdx.x >> 6), wpb = (int)(blockDim.x >> 6);
+    const long long env = (long long)blockIdx.x * wpb + wave;
+    if (env >= p.N) return;
+    signed char *lds = wurm_lds + wave * p.lds_per_wave;
+    const int NCH = SNAKE ? 3 : 2;
+    const Geo g = make_geo<CPL>(p.S);
+    float *envp = p.envs + env * NCH * g.C;
+    Env<CPL> e;
+    const bool d = uniform((int)p.done_in[env]) != 0;
+    if (d) {
+        const int *inj = p.inject_reset ? p.inject_reset + env * (SNAKE ? 4 : 1) : nullptr;
+        reset_core<CPL, SNAKE>(e, g, p.seed, p.call, (u64)(p.env_offset + env), inj, p.start_y, p.start_x);
+        store_state<CPL, SNAKE>(envp, g, e);
+    } else {
+        if (p.obs_mode == WURM_OBS_NONE) return;
+        load_state<CPL, SNAKE>(envp, g, e);
+    }
+    if (p.obs_mode != WURM_OBS_NONE)
+        write_obs<CPL, SNAKE>(e, g, find_head<CPL>(e), p.obs + env * p.obs_elems, p.obs_mode, p.obs_n, lds);
+}
+
+template <int CPL, bool SNAKE>
+__global__ __launch_bounds__(256) void observe_kernel(StepArgs p)
+{
+    const int wave = (int)(threadIdx.x >> 6), wpb = (int)(blockDim.x >> 6);
+    const long long env = (long long)blockIdx.x * wpb + wave;
+    if (env >= p.N) return;
+    signed char *lds = wurm_lds + wave * p.lds_per_wave;
+    const int NCH = SNAKE ? 3 : 2;
+    const Geo g = make_geo<CPL>(p.S);
+    Env<CPL> e;
+    load_state<CPL, SNAKE>(p.envs + env * NCH * g.C, g, e);
+    write_obs<CPL, SNAKE>(e, g, find_head<CPL>(e), p.obs + env * p.obs_elems, p.obs_mode, p.obs_n, lds);
+}
+
+// T fused step+reset iterations with the env resident in registers.  Lane j of the wave buffers the
+// per-step scalars of step t0+j; they are flushed every 64 steps.
+template <int CPL, bool SNAKE>
+__global__ __launch_bounds__(256) void rollout_kernel(StepArgs p)
+{
+    const int wave = (int)(threadIdx.x >> 6), wpb = (int)(blockDim.x >> 6);
+    const long long env = (long long)blockIdx.x * wpb + wave;
+    if (env >= p.N) return;
+    signed char *lds = wurm_lds + wave * p.lds_per_wave;
+    const int NCH = SNAKE ? 3 : 2;
+    const Geo g = make_geo<CPL>(p.S);
+    float *envp = p.envs + env * NCH * g.C;
+    const u64 env_id = (u64)(p.env_offset + env);
+    Env<CPL> e;
+    load_state<CPL, SNAKE>(envp, g, e);
+    const bool inj_f = p.inject_food != nullptr, inj_r = p.inject_reset != nullptr;
+
+    for (long long t0 = 0; t0 < p.T; t0 += 64) {
+        const int nt = (int)min((long long)64, p.T - t0);
+        const long long my_t = t0 + g.lane;
+        long long my_a = g.lane < nt ? load_action(p.actions, p.act_dtype, my_t * p.N + env) : 0;
+        int my_inj = (inj_f && g.lane < nt) ? p.inject_food[my_t * p.N + env] : -1;
+        float my_r = 0.0f;
+        int my_flags = 0;
+        for (int j = 0; j < nt; ++j) {
+            const long long t = t0 + j;
+            const long long a_in = lane_value64(my_a, j);
+            const int inj_cell = lane_value(my_inj, j);
+            StepOut out;
+            step_core<CPL, SNAKE, false>(e, g, nullptr, a_in, out, p.seed, p.call + 2ull * (u64)t, env_id, inj_f,
+                                         inj_cell, lds);
+            if (g.lane == j) {
+                my_a = out.action;
+                my_r = out.reward;
+                my_flags = out.done | (out.selfc << 1) | (out.edgec << 2);
+            }
+            if (p.obs_mode != WURM_OBS_NONE)
+                write_obs<CPL, SNAKE>(e, g, out.headcell, p.obs + (t * p.N + env) * p.obs_elems, p.obs_mode,
+                                      p.obs_n, lds);
+            if (out.done) {
+                const int *inj = inj_r ? p.inject_reset + (t * p.N + env) * (SNAKE ? 4 : 1) : nullptr;
+                reset_core<CPL, SNAKE>(e, g, p.seed, p.call + 2ull * (u64)t + 1ull, env_id, inj, p.start_y, p.start_x);
+            }
+        }
+        if (g.lane < nt) {
+            const long long i = my_t * p.N + env;
+            if (SNAKE) {
+                store_action(p.actions, p.act_dtype, i, my_a);
+                p.selfc[i] = (uint8_t)((my_flags >> 1) & 1);
+            }
+            p.reward[i] = my_r;
+            p.done[i] = (uint8_t)(my_flags & 1);
+            p.edgec[i] = (uint8_t)((my_flags >> 2) & 1);
+        }
+    }
+    store_state<CPL, SNAKE>(envp, g, e);
+}
+
+// wurm.utils.env_consistency (wurm/utils.py:113-178) per env, as an error bitmask
+template <int CPL>
+__global__ __launch_bounds__(256) void check_kernel(const float *__restrict__ envs, uint32_t *__restrict__ err,
+                                                    long long N, int S)
+{
+    const int wave = (int)(threadIdx.x >> 6), wpb = (int)(blockDim.x >> 6);
+    const long long env = (long long)blockIdx.x * wpb + wave;
+    if (env >= N) return;
+    const Geo g = make_geo<CPL>(S);
+    const float *envp = envs + env * 3 * g.C;
+    int bad_food = 0, hs = 0, bs = 0, bm = 0, hb = 0, hf = 0, fs = 0;
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) {
+        int c = g.lane + 64 * k;
+        if ((g.valid >> k) & 1) {
+            float f = envp[c], h = envp[g.C + c], b = envp[2 * g.C + c];
+            int fi = __float2int_rn(f), hi = __float2int_rn(h), bi = __float2int_rn(b);
+            bad_food |= !(f == 0.0f || f == 1.0f);
+            hs += hi; bs += bi; hb += hi * bi; hf += hi * fi; fs += fi;
+            bm = max(bm, bi);
+        }
+    }
+    bad_food = ballot(bad_food != 0) != 0;
+    hs = wave_sum_i32(hs); bs = wave_sum_i32(bs); hb = wave_sum_i32(hb); hf = wave_sum_i32(hf);
+    fs = wave_sum_i32(fs); bm = wave_max_i32(bm);
+    uint32_t m = 0;
+    if (bad_food) m |= WURM_CHK_FOOD_VALUE;
+    if (hs != 1) m |= WURM_CHK_ONE_HEAD;
+    if (!(bs > 0)) m |= WURM_CHK_HAS_SNAKE;
+    if (bm != hb) m |= WURM_CHK_HEAD_AT_END;
+    if (2 * bs != bm * (bm + 1)) m |= WURM_CHK_BODY_RANGE; // (sqrt(8*bs+1)-1)/2 == bm  <=>  bs is the bm-th triangular number
+    if (!(bs >= 6)) m |= WURM_CHK_MIN_LENGTH;
+    if (hf != 0) m |= WURM_CHK_HEAD_ON_FOOD;
+    if (fs != 1) m |= WURM_CHK_ONE_FOOD;
+    if (g.lane == 0) err[env] = m;
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+
+enum Kind { K_STEP, K_RESET, K_OBSERVE, K_ROLLOUT };
+
+static int pick_cpl(int S)
+{
+    int need = (S * S + 63) / 64;
+    const int opts[] = {2, 4, 8, 16, 24, 32, 48, 64};
+    for (int o : opts)
+        if (need <= o) return o;
+    return -1;
+}
+
+template <int CPL, bool SNAKE>
+static hipError_t launch_one(Kind kind, const StepArgs &p, dim3 grid, dim3 block, size_t lds, hipStream_t st)
+{
+    switch (kind) {
+    case K_STEP: hipLaunchKernelGGL((step_kernel<CPL, SNAKE>), grid, block, lds, st, p); break;
+    case K_RESET: hipLaunchKernelGGL((reset_kernel<CPL, SNAKE>), grid, block, lds, st, p); break;
+    case K_OBSERVE: hipLaunchKernelGGL((observe_kernel<CPL, SNAKE>), grid, block, lds, st, p); break;
+    case K_ROLLOUT: hipLaunchKernelGGL((rollout_kernel<CPL, SNAKE>), grid, block, lds, st, p); break;
+    }
+    return hipGetLastError();
+}
+
+template <bool SNAKE>
+static int launch(Kind kind, StepArgs p, void *stream)
+{
+    if (p.N == 0) return WURM_OK;
+    const int cpl = pick_cpl(p.S);
+    if (cpl < 0) return WURM_ERR_UNSUPPORTED;
+    // small batches: one wave per workgroup so the envs spread over all 256 CUs; large: 4 waves per workgroup
+    const int wpb = p.N <= 4096 ? 1 : 4;
+    p.lds_per_wave = ((p.S * p.S + 15) / 16) * 16;
+    dim3 block(64 * wpb), grid((unsigned)((p.N + wpb - 1) / wpb));
+    size_t lds = (size_t)p.lds_per_wave * wpb;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t err;
+    switch (cpl) {
+    case 2: err = launch_one<2, SNAKE>(kind, p, grid, block, lds, st); break;
+    case 4: err = launch_one<4, SNAKE>(kind, p, grid, block, lds, st); break;
+    case 8: err = launch_one<8, SNAKE>(kind, p, grid, block, lds, st); break;
+    case 16: err = launch_one<16, SNAKE>(kind, p, grid, block, lds, st); break;
+    case 24: err = launch_one<24, SNAKE>(kind, p, grid, block, lds, st); break;
+    case 32: err = launch_one<32, SNAKE>(kind, p, grid, block, lds, st); break;
+    case 48: err = launch_one<48, SNAKE>(kind, p, grid, block, lds, st); break;
+    default: err = launch_one<64, SNAKE>(kind, p, grid, block, lds, st); break;
+    }
+    return err == hipSuccess ? WURM_OK : WURM_ERR_HIP;
+}
+
+static long long obs_elems(bool snake, int mode, int n, int S)
+{
+    const long long C = (long long)S * S;
+    switch (mode) {
+    case WURM_OBS_DEFAULT: return 3 * C;
+    case WURM_OBS_RAW: return (snake ? 3 : 2) * C;
+    case WURM_OBS_ONE_CHANNEL: return snake ? C : 0;
+    case WURM_OBS_POSITIONS: return 4;
+    case WURM_OBS_PARTIAL: return (snake && n >= 0) ? 3ll * (2 * n + 1) * (2 * n + 1) : 0;
+    default: return 0;
+    }
+}
+
+static int check_common(bool snake, const void *envs, long long N, int S, const void *obs, int mode, int n, int dtype)
+{
+    if (N < 0 || S < 3 || S > 64) return S > 64 ? WURM_ERR_UNSUPPORTED : WURM_ERR_INVALID_ARG;
+    if (N > 0 && envs == nullptr) return WURM_ERR_INVALID_ARG;
+    if (dtype != WURM_ACT_I64 && dtype != WURM_ACT_I32) return WURM_ERR_DTYPE;
+    if (mode != WURM_OBS_NONE) {
+        if (obs_elems(snake, mode, n, S) == 0) return WURM_ERR_INVALID_ARG;
+        if (N > 0 && obs == nullptr) return WURM_ERR_INVALID_ARG;
+    }
+    return WURM_OK;
+}
+
+} // namespace wurm
+
+using namespace wurm;
+
+extern "C" {
+
+const char *wurm_version(void) { return "wurm_hip 0.1 gfx950"; }
+
+int64_t wurm_single_obs_elems(int obs_mode, int obs_n, int size) { return obs_elems(true, obs_mode, obs_n, size); }
+int64_t wurm_grid_obs_elems(int obs_mode, int obs_n, int size) { return obs_elems(false, obs_mode, obs_n, size); }
+
+int wurm_single_step(float *envs, void *actions, int actions_dtype, float *reward, uint8_t *done,
+                     uint8_t *self_collision, uint8_t *edge_collision, float *obs, int obs_mode, int obs_n,
+                     int64_t num_envs, int size, uint64_t seed, uint64_t call, int64_t env_offset,
+                     const int32_t *inject_food, void *stream)
+{
+    int rc = check_common(true, envs, num_envs, size, obs, obs_mode, obs_n, actions_dtype);
+    if (rc) return rc;
+    if (num_envs > 0 && (!actions || !reward || !done || !self_collision || !edge_collision)) return WURM_ERR_INVALID_ARG;
+    StepArgs p = {};
+    p.envs = envs; p.actions = actions; p.act_dtype = actions_dtype; p.reward = reward; p.done = done;
+    p.selfc = self_collision; p.edgec = edge_collision; p.obs = obs; p.obs_mode = obs_mode; p.obs_n = obs_n;
+    p.obs_elems = obs_elems(true, obs_mode, obs_n, size); p.N = num_envs; p.S = size; p.seed = seed; p.call = call;
+    p.env_offset = env_offset; p.inject_food = inject_food;
+    return launch<true>(K_STEP, p, stream);
+}
+
+int wurm_single_reset(float *envs, const uint8_t *done, float *obs, int obs_mode, int obs_n, int64_t num_envs,
+                      int size, uint64_t seed, uint64_t call, int64_t env_offset, const int32_t *inject_reset,
+                      void *stream)
+{
+    int rc = check_common(true, envs, num_envs, size, obs, obs_mode, obs_n, WURM_ACT_I64);
+    if (rc) return rc;
+    if (size <= 8) return WURM_ERR_UNSUPPORTED; // single_snake.py:346-347
+    if (num_envs > 0 && !done) return WURM_ERR_INVALID_ARG;
+    StepArgs p = {};
+    p.envs = envs; p.done_in = done; p.obs = obs; p.obs_mode = obs_mode; p.obs_n = obs_n;
+    p.obs_elems = obs_elems(true, obs_mode, obs_n, size); p.N = num_envs; p.S = size; p.seed = seed; p.call = call;
+    p.env_offset = env_offset; p.inject_reset = inject_reset;
+    return launch<true>(K_RESET, p, stream);
+}
+
+int wurm_single_observe(const float *envs, float *obs, int obs_mode, int obs_n, int64_t num_envs, int size,
+                        void *stream)
+{
+    if (obs_mode == WURM_OBS_NONE) return WURM_ERR_INVALID_ARG;
+    int rc = check_common(true, envs, num_envs, size, obs, obs_mode, obs_n, WURM_ACT_I64);
+    if (rc) return rc;
+    StepArgs p = {};
+    p.envs = const_cast<float *>(envs); p.obs = obs; p.obs_mode = obs_mode; p.obs_n = obs_n;
+    p.obs_elems = obs_elems(true, obs_mode, obs_n, size); p.N = num_envs; p.S = size;
+    return launch<true>(K_OBSERVE, p, stream);
+}
+
+int wurm_single_rollout(float *envs, void *actions, int actions_dtype, float *reward, uint8_t *done,
+                        uint8_t *self_collision, uint8_t *edge_collision, float *obs, int obs_mode, int obs_n,
+                        int64_t num_envs, int size, int64_t num_steps, uint64_t seed, uint64_t call0,
+                        int64_t env_offset, const int32_t *inject_food, const int32_t *inject_reset, void *stream)
+{
+    int rc = check_common(true, envs, num_envs, size, obs, obs_mode, obs_n, actions_dtype);
+    if (rc) return rc;
+    if (num_steps < 0) return WURM_ERR_INVALID_ARG;
+    if (size <= 8) return WURM_ERR_UNSUPPORTED;
+    if (num_envs > 0 && num_steps > 0 && (!actions || !reward || !done || !self_collision || !edge_collision))
+        return WURM_ERR_INVALID_ARG;
+    if (num_steps == 0) return WURM_OK;
+    StepArgs p = {};
+    p.envs = envs; p.actions = actions; p.act_dtype = actions_dtype; p.reward = reward; p.done = done;
+    p.selfc = self_collision; p.edgec = edge_collision; p.obs = obs; p.obs_mode = obs_mode; p.obs_n = obs_n;
+    p.obs_elems = obs_elems(true, obs_mode, obs_n, size); p.N = num_envs; p.S = size; p.T = num_steps; p.seed = seed;
+    p.call = call0; p.env_offset = env_offset; p.inject_food = inject_food; p.inject_reset = inject_reset;
+    return launch<true>(K_ROLLOUT, p, stream);
+}
+
+int wurm_single_check(const float *envs, uint32_t *err, int64_t num_envs, int size, void *stream)
+{
+    if (num_envs < 0 || size < 3) return WURM_ERR_INVALID_ARG;
+    if (num_envs == 0) return WURM_OK;
+    if (!envs || !err) return WURM_ERR_INVALID_ARG;
+    const int cpl = pick_cpl(size);
+    if (cpl < 0) return WURM_ERR_UNSUPPORTED;
+    const int wpb = 4;
+    dim3 block(64 * wpb), grid((unsigned)((num_envs + wpb - 1) / wpb));
+    hipStream_t st = (hipStream_t)stream;
+    long long N = num_envs;
+    switch (cpl) {
+    case 2: hipLaunchKernelGGL(check_kernel<2>, grid, block, 0, st, envs, err, N, size); break;
+    case 4: hipLaunchKernelGGL(check_kernel<4>, grid, block, 0, st, envs, err, N, size); break;
+    case 8: hipLaunchKernelGGL(check_kernel<8>, grid, block, 0, st, envs, err, N, size); break;
+    case 16: hipLaunchKernelGGL(check_kernel<16>, grid, block, 0, st, envs, err, N, size); break;
+    case 24: hipLaunchKernelGGL(check_kernel<24>, grid, block, 0, st, envs, err, N, size); break;
+    case 32: hipLaunchKernelGGL(check_kernel<32>, grid, block, 0, st, envs, err, N, size); break;
+    case 48: hipLaunchKernelGGL(check_kernel<48>, grid, block, 0, st, envs, err, N, size); break;
+    default: hipLaunchKernelGGL(check_kernel<64>, grid, block, 0, st, envs, err, N, size); break;
+    }
+    return hipGetLastError() == hipSuccess ? WURM_OK : WURM_ERR_HIP;
+}
+
+/* ---------------------------------------------------------------------------------------- SimpleGridworld */
+
+int wurm_grid_step(float *envs, const void *actions, int actions_dtype, float *reward, uint8_t *done,
+                   uint8_t *edge_collision, float *obs, int obs_mode, int obs_n, int64_t num_envs, int size,
+                   uint64_t seed, uint64_t call, int64_t env_offset, const int32_t *inject_food, void *stream)
+{
+    int rc = check_common(false, envs, num_envs, size, obs, obs_mode, obs_n, actions_dtype);
+    if (rc) return rc;
+    if (num_envs > 0 && (!actions || !reward || !done || !edge_collision)) return WURM_ERR_INVALID_ARG;
+    StepArgs p = {};
+    p.envs = envs; p.actions = const_cast<void *>(actions); p.act_dtype = actions_dtype; p.reward = reward;
+    p.done = done; p.edgec = edge_collision; p.obs = obs; p.obs_mode = obs_mode; p.obs_n = obs_n;
+    p.obs_elems = obs_elems(false, obs_mode, obs_n, size); p.N = num_envs; p.S = size; p.seed = seed; p.call = call;
+    p.env_offset = env_offset; p.inject_food = inject_food;
+    return launch<false>(K_STEP, p, stream);
+}
+
+int wurm_grid_reset(float *envs, const uint8_t *done, float *obs, int obs_mode, int obs_n, int64_t num_envs,
+                    int size, int start_y, int start_x, uint64_t seed, uint64_t call, int64_t env_offset,
+                    const int32_t *inject_reset, void *stream)
+{
+    int rc = check_common(false, envs, num_envs, size, obs, obs_mode, obs_n, WURM_ACT_I64);
+    if (rc) return rc;
+    if (size <= 4) return WURM_ERR_UNSUPPORTED;                                                  // simple_gridworld.py:249-250
+    if (start_y < 0 || start_x < 0 || start_y >= size || start_x >= size) return WURM_ERR_UNSUPPORTED; // :254-260
+    if (num_envs > 0 && !done) return WURM_ERR_INVALID_ARG;
+    StepArgs p = {};
+    p.envs = envs; p.done_in = done; p.obs = obs; p.obs_mode = obs_mode; p.obs_n = obs_n;
+    p.obs_elems = obs_elems(false, obs_mode, obs_n, size); p.N = num_envs; p.S = size; p.start_y = start_y;
+    p.start_x = start_x; p.seed = seed; p.call = call; p.env_offset = env_offset; p.inject_reset = inject_reset;
+    return launch<false>(K_RESET, p, stream);
+}
+
+int wurm_grid_observe(const float *envs, float *obs, int obs_mode, int obs_n, int64_t num_envs, int size,
+                      void *stream)
+{
+    if (obs_mode == WURM_OBS_NONE) return WURM_ERR_INVALID_ARG;
+    int rc = check_common(false, envs, num_envs, size, obs, obs_mode, obs_n, WURM_ACT_I64);
+    if (rc) return rc;
+    StepArgs p = {};
+    p.envs = const_cast<float *>(envs); p.obs = obs; p.obs_mode = obs_mode; p.obs_n = obs_n;
+    p.obs_elems = obs_elems(false, obs_mode, obs_n, size); p.N = num_envs; p.S = size;
+    return launch<false>(K_OBSERVE, p, stream);
+}
+
+int wurm_grid_rollout(float *envs, const void *actions, int actions_dtype, float *reward, uint8_t *done,
+                      uint8_t *edge_collision, float *obs, int obs_mode, int obs_n, int64_t num_envs, int size,
+                      int64_t num_steps, int start_y, int start_x, uint64_t seed, uint64_t call0,
+                      int64_t env_offset, const int32_t *inject_food, const int32_t *inject_reset, void *stream)
+{
+    int rc = check_common(false, envs, num_envs, size, obs, obs_mode, obs_n, actions_dtype);
+    if (rc) return rc;
+    if (num_steps < 0) return WURM_ERR_INVALID_ARG;
+    if (size <= 4) return WURM_ERR_UNSUPPORTED;
+    if (start_y < 0 || start_x < 0 || start_y >= size || start_x >= size) return WURM_ERR_UNSUPPORTED;
+    if (num_envs > 0 && num_steps > 0 && (!actions || !reward || !done || !edge_collision)) return WURM_ERR_INVALID_ARG;
+    if (num_steps == 0) return WURM_OK;
+    StepArgs p = {};
+    p.envs = envs; p.actions = const_cast<void *>(actions); p.act_dtype = actions_dtype; p.reward = reward;
+    p.done = done; p.edgec = edge_collision; p.obs = obs; p.obs_mode = obs_mode; p.obs_n = obs_n;
+    p.obs_elems = obs_elems(false, obs_mode, obs_n, size); p.N = num_envs; p.S = size; p.T = num_steps;
+    p.start_y = start_y; p.start_x = start_x; p.seed = seed; p.call = call0; p.env_offset = env_offset;
+    p.inject_food = inject_food; p.inject_reset = inject_reset;
+    return launch<false>(K_ROLLOUT, p, stream);
+}
+
+} // extern "C"

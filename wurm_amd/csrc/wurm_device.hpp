@@ -1,0 +1,130 @@
+// wurm_device.hpp — device-side helpers shared by the gfx950 env-step kernels.
+//
+// Execution model used throughout: ONE ENVIRONMENT PER 64-LANE WAVEFRONT.  Lane l owns the cells
+// c = l + 64*k (k = 0..CPL-1) of the row-major S*S grid, so every global access of a channel is a run of
+// consecutive dwords across the wave.  Per-env scalars (head cell, snake length, collision flags) are
+// wave-uniform values produced with ballots / wave reductions and live in SGPRs.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace wurm {
+
+typedef unsigned long long u64;
+typedef unsigned int u32;
+
+constexpr int WAVE = 64;
+
+// RNG purposes: one Philox stream per (env, call, purpose, sub-block).  Must match oracle/oracle_common.h.
+enum : u32 {
+    RNG_FOOD = 0,
+    RNG_RESET = 1,
+    RNG_DEATH_FOOD_A = 2,
+    RNG_DEATH_FOOD_B = 3,
+    RNG_BOOST_COST = 4,
+    RNG_RATE_FOOD = 5,
+    RNG_SPAWN = 6,
+    RNG_COLOUR = 7
+};
+
+struct Words {
+    u32 w[4];
+};
+
+// Philox4x32-10, counter = (env_id, call_lo, call_hi, purpose | sub << 8), key = seed.
+__device__ __forceinline__ Words rng_words(u64 seed, u64 call, u64 env_id, u32 purpose, u32 sub)
+{
+    const u32 M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+    u32 c0 = (u32)env_id, c1 = (u32)call, c2 = (u32)(call >> 32), c3 = (purpose & 0xffu) | (sub << 8);
+    u32 k0 = (u32)seed, k1 = (u32)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        u32 hi0 = __umulhi(M0, c0), lo0 = M0 * c0;
+        u32 hi1 = __umulhi(M1, c2), lo1 = M1 * c2;
+        u32 n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += W0; k1 += W1;
+    }
+    Words o;
+    o.w[0] = c0; o.w[1] = c1; o.w[2] = c2; o.w[3] = c3;
+    return o;
+}
+
+__device__ __forceinline__ u32 mulhi_range(u32 w, u32 n) { return __umulhi(w, n); } // uniform in [0,n)
+__device__ __forceinline__ float u01(u32 w) { return (float)(w >> 8) * (1.0f / 16777216.0f); }
+
+__device__ __forceinline__ float cell_u01(u64 seed, u64 call, u64 env_id, u32 purpose, u32 cell)
+{
+    Words o = rng_words(seed, call, env_id, purpose, cell >> 2);
+    u32 j = cell & 3u;
+    u32 w = j == 0 ? o.w[0] : j == 1 ? o.w[1] : j == 2 ? o.w[2] : o.w[3];
+    return u01(w);
+}
+
+// ---- wave-level primitives -------------------------------------------------------------------------------
+
+__device__ __forceinline__ u64 ballot(bool p) { return __ballot(p); }
+__device__ __forceinline__ int popc64(u64 m) { return __popcll(m); }
+__device__ __forceinline__ int first_bit(u64 m) { return __ffsll((long long)m) - 1; } // -1 when empty
+
+// number of set bits of m below this lane
+__device__ __forceinline__ int rank_below(u64 m)
+{
+    return (int)__builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
+}
+
+__device__ __forceinline__ int wave_max_i32(int v)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        int o = __shfl_xor(v, off, WAVE);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
+__device__ __forceinline__ int wave_sum_i32(int v)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, WAVE);
+    return v;
+}
+
+__device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+__device__ __forceinline__ long long uniform64(long long v)
+{
+    u32 lo = (u32)__builtin_amdgcn_readfirstlane((int)(u32)v);
+    u32 hi = (u32)__builtin_amdgcn_readfirstlane((int)(u32)((u64)v >> 32));
+    return (long long)(((u64)hi << 32) | lo);
+}
+
+// value held by lane `src` (src wave-uniform)
+__device__ __forceinline__ int lane_value(int v, int src) { return __shfl(v, src, WAVE); }
+
+__device__ __forceinline__ long long lane_value64(long long v, int src)
+{
+    int lo = __shfl((int)(u32)v, src, WAVE);
+    int hi = __shfl((int)(u32)((u64)v >> 32), src, WAVE);
+    return (long long)(((u64)(u32)hi << 32) | (u32)lo);
+}
+
+// LDS written by some lanes of a wave and read by other lanes of the SAME wave: the hardware runs one wave's
+// LDS instructions in order; this only stops the compiler from moving accesses across the hand-off.
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// exact floor(c / S) for 0 <= c < 2^16, 1 <= S <= 256, via one fp32 multiply (rcpS = 1.0f / S)
+__device__ __forceinline__ int div_size(int c, float rcpS) { return (int)(((float)c + 0.5f) * rcpS); }
+
+// taps of the reference's ORIENTATION_FILTERS (wurm/_filters.py:7-28): orientation i <=> head = neck + TAP[i];
+// action a moves the head by -TAP[a] = [(+1,0),(0,-1),(-1,0),(0,+1)] (row, col).
+__device__ __forceinline__ int tap_y(int i) { return i == 0 ? -1 : (i == 2 ? 1 : 0); }
+__device__ __forceinline__ int tap_x(int i) { return i == 1 ? 1 : (i == 3 ? -1 : 0); }
+
+} // namespace wurm

@@ -1,0 +1,2 @@
+from .single_snake import SingleSnake
+from .simple_gridworld import SimpleGridworld

@@ -1,0 +1,189 @@
+"""SimpleGridworld — drop-in for the reference's wurm.envs.SimpleGridworld (wurm/envs/simple_gridworld.py:15-271)
+on the gfx950 kernels of include/wurm_hip.h.  State `envs` is (num_envs, 2, size, size) fp32 = [food, agent].
+Deviations are the ones listed in wurm_amd/envs/single_snake.py."""
+from collections import namedtuple
+from typing import Tuple
+
+import torch
+
+from wurm_amd import _lib
+from wurm_amd.config import DEFAULT_DEVICE
+from wurm_amd.envs.single_snake import _draw_seed, _INT_TYPES
+
+Spec = namedtuple('Spec', ['reward_threshold'])
+
+
+class SimpleGridworld(object):
+    """Batched gridworld: the agent moves in the 4 cardinal directions, +1 reward on a food square (which then
+    respawns), moving on to the border ring ends the episode (reference simple_gridworld.py:16-42)."""
+
+    spec = Spec(float('inf'))
+
+    def __init__(self,
+                 num_envs: int,
+                 size: int,
+                 on_death: str = 'restart',
+                 observation_mode: str = 'default',
+                 device: str = DEFAULT_DEVICE,
+                 start_location: Tuple[int, int] = None,
+                 manual_setup: bool = False,
+                 verbose: int = 0,
+                 seed: int = None,
+                 env_offset: int = 0):
+        self.num_envs = num_envs
+        self.size = size
+        self.on_death = on_death
+        self.observation_mode = observation_mode
+        self.start_location = start_location
+        self.device = _lib.require_device(device)
+        self.verbose = verbose
+        self.seed = _draw_seed() if seed is None else int(seed)
+        self.env_offset = int(env_offset)
+        self._call = 0
+
+        self.t = 0
+
+        self.envs = torch.zeros((num_envs, 2, size, size), device=self.device)
+        self.done = torch.zeros(num_envs, dtype=torch.bool, device=self.device)
+        if not manual_setup:
+            self._reset(torch.ones(num_envs, dtype=torch.bool, device=self.device), observe=False)
+
+        self.viewer = None
+
+        self.head_colour = torch.tensor((0, 255, 0), dtype=torch.short, device=self.device)
+        self.food_colour = torch.tensor((255, 0, 0), dtype=torch.short, device=self.device)
+        self.edge_colour = torch.tensor((0, 0, 0), dtype=torch.short, device=self.device)
+
+    def _next_call(self, n: int = 1) -> int:
+        c = self._call
+        self._call += n
+        return c
+
+    def _state(self) -> torch.Tensor:
+        e = self.envs
+        if e.shape != (self.num_envs, 2, self.size, self.size):
+            raise RuntimeError(f'env.envs has shape {tuple(e.shape)}, expected '
+                               f'{(self.num_envs, 2, self.size, self.size)}')
+        if e.dtype != torch.float32 or e.device != self.device or not e.is_contiguous():
+            e = e.to(device=self.device, dtype=torch.float32).contiguous()
+            self.envs = e
+        return e
+
+    def _obs_shape(self, mode: str):
+        N, S = self.num_envs, self.size
+        if mode == 'default':
+            return (N, 3, S, S)
+        if mode == 'raw':
+            return (N, 2, S, S)
+        if mode == 'positions':
+            return (N, 4)
+        raise Exception  # reference :132-133
+
+    def _observe(self, observation_mode: str = 'default') -> torch.Tensor:
+        """reference :111-133 ('positions' is generalised from num_envs == 1 to (N, 4))"""
+        shape = self._obs_shape(observation_mode)
+        m, n = _lib.parse_obs_mode(observation_mode)
+        obs = torch.empty(shape, dtype=torch.float32, device=self.device)
+        rc = _lib.lib().wurm_grid_observe(_lib.ptr(self._state()), _lib.ptr(obs), m, n, _lib.i64(self.num_envs),
+                                          self.size, _lib.stream_ptr())
+        _lib.check(rc, 'SimpleGridworld._observe')
+        return obs
+
+    def _get_rgb(self) -> torch.Tensor:
+        """reference :88-109"""
+        return (self._observe('default') * 255).round().short()
+
+    def step(self, actions: torch.Tensor) -> (torch.Tensor, torch.Tensor, torch.Tensor, dict):
+        """reference :135-202 (actions are not modified)"""
+        if actions.dtype not in _INT_TYPES:
+            raise TypeError('actions Tensor must be an integer type i.e. '
+                            '{torch.ShortTensor, torch.IntTensor, torch.LongTensor}')
+
+        if actions.shape[0] != self.num_envs:
+            raise RuntimeError('Must have the same number of actions as environments.')
+
+        if actions.dtype == torch.short:
+            raise RuntimeError('scatter_(): Expected dtype int32/int64 for index')  # reference fails at :153
+
+        envs = self._state()
+        N = self.num_envs
+        act = actions
+        if act.device != self.device or not act.is_contiguous() or act.dim() != 1:
+            act = actions.to(self.device).reshape(N).contiguous()
+        shape = self._obs_shape(self.observation_mode)
+        m, n = _lib.parse_obs_mode(self.observation_mode)
+        obs = torch.empty(shape, dtype=torch.float32, device=self.device)
+        reward = torch.empty(N, dtype=torch.float32, device=self.device)
+        flags = torch.empty((2, N), dtype=torch.bool, device=self.device)
+        done, edge_collision = flags[0], flags[1]
+        rc = _lib.lib().wurm_grid_step(
+            _lib.ptr(envs), _lib.ptr(act), _lib.ACT_I64 if act.dtype == torch.long else _lib.ACT_I32,
+            _lib.ptr(reward), _lib.ptr(done), _lib.ptr(edge_collision), _lib.ptr(obs), m, n, _lib.i64(N), self.size,
+            _lib.u64(self.seed), _lib.u64(self._next_call()), _lib.i64(self.env_offset), None, _lib.stream_ptr())
+        _lib.check(rc, 'SimpleGridworld.step')
+        info = {'edge_collision': edge_collision}
+        self.done = done
+        return obs, reward.unsqueeze(-1), done.unsqueeze(-1), info
+
+    def _reset(self, done: torch.Tensor, observe: bool = True):
+        if self.size <= 4 or self.start_location is None:
+            # reference :249-260 raises only when an env actually has to be created
+            if bool(done.any()):
+                if self.size <= 4:
+                    raise NotImplementedError('Environemnts smaller than this don\'t make sense.')
+                raise NotImplementedError("Haven't implemented random starting locations")
+            return self._observe(self.observation_mode) if observe else None
+        envs = self._state()
+        if observe:
+            m, n = _lib.parse_obs_mode(self.observation_mode)
+            obs = torch.empty(self._obs_shape(self.observation_mode), dtype=torch.float32, device=self.device)
+        else:
+            m, n, obs = _lib.OBS_NONE, 0, None
+        rc = _lib.lib().wurm_grid_reset(
+            _lib.ptr(envs), _lib.ptr(done), _lib.ptr(obs), m, n, _lib.i64(self.num_envs), self.size,
+            int(self.start_location[0]), int(self.start_location[1]), _lib.u64(self.seed),
+            _lib.u64(self._next_call()), _lib.i64(self.env_offset), None, _lib.stream_ptr())
+        _lib.check(rc, 'SimpleGridworld.reset')
+        return obs
+
+    def reset(self, done: torch.Tensor = None, return_observations: bool = True):
+        """reference :225-245"""
+        if done is None:
+            done = self.done
+        done = done.view((done.shape[0]))
+        if done.dtype != torch.bool:
+            done = done != 0
+        if done.device != self.device:
+            done = done.to(self.device)
+        return self._reset(done.contiguous(), observe=return_observations)
+
+    def rollout(self, actions: torch.Tensor, return_observations: bool = True) -> dict:
+        """T iterations of `step(actions[t]); reset(done)` in one launch (see SingleSnake.rollout)."""
+        if actions.dtype not in (torch.int, torch.long):
+            raise TypeError('actions Tensor must be an integer type i.e. {torch.IntTensor, torch.LongTensor}')
+        if actions.dim() != 2 or actions.shape[1] != self.num_envs:
+            raise RuntimeError('Must have the same number of actions as environments.')
+        if not actions.is_contiguous() or actions.device != self.device:
+            raise RuntimeError('rollout actions must be a contiguous device tensor')
+        if self.start_location is None:
+            raise NotImplementedError("Haven't implemented random starting locations")
+        envs = self._state()
+        T, N = actions.shape
+        if return_observations:
+            m, n = _lib.parse_obs_mode(self.observation_mode)
+            obs = torch.empty((T,) + self._obs_shape(self.observation_mode), dtype=torch.float32, device=self.device)
+        else:
+            m, n, obs = _lib.OBS_NONE, 0, None
+        reward = torch.empty((T, N), dtype=torch.float32, device=self.device)
+        flags = torch.empty((2, T, N), dtype=torch.bool, device=self.device)
+        rc = _lib.lib().wurm_grid_rollout(
+            _lib.ptr(envs), _lib.ptr(actions), _lib.ACT_I64 if actions.dtype == torch.long else _lib.ACT_I32,
+            _lib.ptr(reward), _lib.ptr(flags[0]), _lib.ptr(flags[1]), _lib.ptr(obs), m, n, _lib.i64(N), self.size,
+            _lib.i64(T), int(self.start_location[0]), int(self.start_location[1]), _lib.u64(self.seed),
+            _lib.u64(self._next_call(2 * T)), _lib.i64(self.env_offset), None, None, _lib.stream_ptr())
+        _lib.check(rc, 'SimpleGridworld.rollout')
+        self.done = torch.zeros(N, dtype=torch.bool, device=self.device)
+        return {'observations': obs, 'rewards': reward, 'dones': flags[0], 'edge_collision': flags[1]}
+
+    def _consistent(self):
+        pass

@@ -1,0 +1,304 @@
+"""SingleSnake — drop-in for the reference's wurm.envs.SingleSnake (wurm/envs/single_snake.py:17-428) whose
+step / reset / _observe run as fused gfx950 kernels behind the C ABI of include/wurm_hip.h.
+
+Same constructor keywords, public attributes (`envs`, `done`, `num_envs`, `size`, ...), return conventions and
+error types as the reference.  Intentional deviations:
+  * `done` and `info[...]` are torch.bool (the faithful translation of torch-1.1 uint8 masks: `~done` is a
+    logical not, as experiments/main.py:215 needs);
+  * randomness comes from a counter-based Philox generator (`seed`, `env_offset` keywords) instead of torch's
+    global RNG stream, so trajectories do not depend on how the batch is sharded over GPUs;
+  * `partial_n` observations of an env whose head left the grid are zeros (the reference raises at :191);
+  * there is no CPU path: `device` must be a HIP GPU.
+"""
+from collections import namedtuple
+
+import torch
+
+from wurm_amd import _lib
+from wurm_amd.config import DEFAULT_DEVICE
+
+Spec = namedtuple('Spec', ['reward_threshold'])
+
+_INT_TYPES = (torch.short, torch.int, torch.long)
+
+
+def _draw_seed() -> int:
+    # one draw from torch's global generator: `torch.manual_seed(k)` before construction pins the trajectories
+    return int(torch.randint(0, 2 ** 62, (1,)).item())
+
+
+class SingleSnake(object):
+    """Batched snake environment: state `envs` is (num_envs, 3, size, size) fp32 = [food, head, body]
+    (reference single_snake.py:22-47)."""
+
+    spec = Spec(float('inf'))
+    metadata = {
+        'render.modes': ['rgb_array'],
+        'video.frames_per_second': 12
+    }
+
+    def __init__(self,
+                 num_envs: int,
+                 size: int,
+                 max_timesteps: int = None,
+                 initial_snake_length: int = 3,
+                 on_death: str = 'restart',
+                 observation_mode: str = 'one_channel',
+                 device: str = DEFAULT_DEVICE,
+                 manual_setup: bool = False,
+                 verbose: int = 0,
+                 render_args: dict = None,
+                 seed: int = None,
+                 env_offset: int = 0):
+        self.num_envs = num_envs
+        self.size = size
+        self.max_timesteps = max_timesteps
+        self.initial_snake_length = initial_snake_length
+        self.on_death = on_death
+        self.observation_mode = observation_mode
+        self.device = _lib.require_device(device)
+        self.verbose = verbose
+        self.seed = _draw_seed() if seed is None else int(seed)
+        self.env_offset = int(env_offset)
+        self._call = 0
+
+        if render_args is None:
+            self.render_args = {'num_rows': 1, 'num_cols': 1, 'size': 256}
+        else:
+            self.render_args = render_args
+
+        self.envs = torch.zeros((num_envs, 3, size, size), device=self.device)
+        self.t = 0
+        self.done = torch.zeros(num_envs, dtype=torch.bool, device=self.device)
+
+        if not manual_setup:
+            # reference :90-93 _create_envs(num_envs): every env is built by the reset kernel
+            self._reset(torch.ones(num_envs, dtype=torch.bool, device=self.device), observe=False)
+
+        self.viewer = None
+
+        self.body_colour = torch.tensor((0, 127, 0), dtype=torch.short, device=self.device)
+        self.head_colour = torch.tensor((0, 255, 0), dtype=torch.short, device=self.device)
+        self.food_colour = torch.tensor((255, 0, 0), dtype=torch.short, device=self.device)
+        self.edge_colour = torch.tensor((0, 0, 0), dtype=torch.short, device=self.device)
+
+    # ------------------------------------------------------------------ helpers
+
+    def _next_call(self, n: int = 1) -> int:
+        c = self._call
+        self._call += n
+        return c
+
+    def _state(self) -> torch.Tensor:
+        e = self.envs
+        if e.shape != (self.num_envs, 3, self.size, self.size):
+            raise RuntimeError(f'env.envs has shape {tuple(e.shape)}, expected '
+                               f'{(self.num_envs, 3, self.size, self.size)}')
+        if e.dtype != torch.float32 or e.device != self.device or not e.is_contiguous():
+            # callers rebind env.envs (reference tests/test_single_snake_env.py:54): normalise once
+            e = e.to(device=self.device, dtype=torch.float32).contiguous()
+            self.envs = e
+        return e
+
+    def _obs_shape(self, mode: str):
+        m, n = _lib.parse_obs_mode(mode)
+        N, S = self.num_envs, self.size
+        if m in (_lib.OBS_DEFAULT, _lib.OBS_RAW):
+            return (N, 3, S, S)
+        if m == _lib.OBS_ONE_CHANNEL:
+            return (N, 1, S, S)
+        if m == _lib.OBS_POSITIONS:
+            return (N, 4)
+        if m == _lib.OBS_PARTIAL:
+            return (N, 3 * (2 * n + 1) ** 2)
+        raise Exception  # reference :194-195
+
+    def _parse_mode(self, observation_mode: str):
+        if observation_mode in ('default', 'raw', 'one_channel', 'positions'):
+            return _lib.parse_obs_mode(observation_mode)
+        if isinstance(observation_mode, str) and observation_mode.startswith('partial_'):
+            # reference :167 reads the window size from self.observation_mode
+            src = self.observation_mode if self.observation_mode.startswith('partial_') else observation_mode
+            return _lib.OBS_PARTIAL, int(src.split('_')[-1])
+        raise Exception  # reference :194-195
+
+    # ------------------------------------------------------------------ observations
+
+    def _observe(self, observation_mode: str = 'default') -> torch.Tensor:
+        """reference :130-195"""
+        m, n = self._parse_mode(observation_mode)
+        envs = self._state()
+        obs = torch.empty(self._obs_shape(observation_mode if m != _lib.OBS_PARTIAL else f'partial_{n}'),
+                          dtype=torch.float32, device=self.device)
+        rc = _lib.lib().wurm_single_observe(_lib.ptr(envs), _lib.ptr(obs), m, n, _lib.i64(self.num_envs),
+                                            self.size, _lib.stream_ptr())
+        _lib.check(rc, 'SingleSnake._observe')
+        return obs
+
+    def _get_rgb(self) -> torch.Tensor:
+        """reference :104-128 — int16 RGB image (N,3,S,S)"""
+        return (self._observe('default') * 255).round().short()
+
+    # ------------------------------------------------------------------ step
+
+    def step(self, actions: torch.Tensor) -> (torch.Tensor, torch.Tensor, torch.Tensor, dict):
+        """reference :197-304.  `actions` is sanitised in place (reverse moves become forward moves)."""
+        if actions.dtype not in _INT_TYPES:
+            raise TypeError('actions Tensor must be an integer type i.e. '
+                            '{torch.ShortTensor, torch.IntTensor, torch.LongTensor}')
+
+        if actions.shape[0] != self.num_envs:
+            raise RuntimeError('Must have the same number of actions as environments.')
+
+        if actions.dtype == torch.short:
+            # the reference passes its own dtype check and then fails inside scatter_ (:229)
+            raise RuntimeError('scatter_(): Expected dtype int32/int64 for index')
+
+        envs = self._state()
+        N = self.num_envs
+        act = actions
+        if act.device != self.device or not act.is_contiguous() or act.dim() != 1:
+            act = actions.to(self.device).reshape(N).contiguous()
+        m, n = self._parse_mode(self.observation_mode)
+        obs = torch.empty(self._obs_shape(self.observation_mode), dtype=torch.float32, device=self.device)
+        reward = torch.empty(N, dtype=torch.float32, device=self.device)
+        flags = torch.empty((3, N), dtype=torch.bool, device=self.device)
+        done, self_collision, edge_collision = flags[0], flags[1], flags[2]
+
+        rc = _lib.lib().wurm_single_step(
+            _lib.ptr(envs), _lib.ptr(act), _lib.ACT_I64 if act.dtype == torch.long else _lib.ACT_I32,
+            _lib.ptr(reward), _lib.ptr(done), _lib.ptr(self_collision), _lib.ptr(edge_collision), _lib.ptr(obs),
+            m, n, _lib.i64(N), self.size, _lib.u64(self.seed), _lib.u64(self._next_call()),
+            _lib.i64(self.env_offset), None, _lib.stream_ptr())
+        _lib.check(rc, 'SingleSnake.step')
+        if act is not actions:
+            actions.copy_(act.view_as(actions))  # keep the in-place side effect (:222)
+
+        info = {'self_collision': self_collision, 'edge_collision': edge_collision}
+        self.done = done
+        return obs, reward.unsqueeze(-1), done.unsqueeze(-1), info
+
+    # ------------------------------------------------------------------ reset
+
+    def _reset(self, done: torch.Tensor, observe: bool = True):
+        if self.initial_snake_length != 3:
+            raise NotImplementedError('Only initial snake length = 3 has been implemented.')
+        if self.size <= 8:
+            # reference :346-347 raises only when an env actually has to be created
+            if bool(done.any()):
+                raise NotImplementedError('Cannot make an env this small without making this code more clever')
+            return self._observe(self.observation_mode) if observe else None
+        envs = self._state()
+        if observe:
+            m, n = self._parse_mode(self.observation_mode)
+            obs = torch.empty(self._obs_shape(self.observation_mode), dtype=torch.float32, device=self.device)
+        else:
+            m, n, obs = _lib.OBS_NONE, 0, None
+        rc = _lib.lib().wurm_single_reset(
+            _lib.ptr(envs), _lib.ptr(done), _lib.ptr(obs), m, n, _lib.i64(self.num_envs), self.size,
+            _lib.u64(self.seed), _lib.u64(self._next_call()), _lib.i64(self.env_offset), None, _lib.stream_ptr())
+        _lib.check(rc, 'SingleSnake.reset')
+        return obs
+
+    def reset(self, done: torch.Tensor = None, return_observations: bool = True):
+        """Resets environments in which the snake has died (reference :322-342).
+
+        Args:
+            done: A 1D Tensor of length self.num_envs (any dtype; (N,1) is accepted). A non-zero value means the
+                corresponding environment needs to be reset.  None: use the `done` of the last step.
+            return_observations: extension — pass False to skip the observation the reference's callers discard
+                (experiments/main.py:227).
+        """
+        if done is None:
+            done = self.done
+        done = done.view((done.shape[0]))
+        if done.dtype != torch.bool:
+            done = done != 0
+        if done.device != self.device:
+            done = done.to(self.device)
+        return self._reset(done.contiguous(), observe=return_observations)
+
+    def _create_envs(self, num_envs: int) -> torch.Tensor:
+        """reference :344-387 — a fresh batch of `num_envs` environments (does not touch self.envs)."""
+        if self.size <= 8:
+            raise NotImplementedError('Cannot make an env this small without making this code more clever')
+        if self.initial_snake_length != 3:
+            raise NotImplementedError('Only initial snake length = 3 has been implemented.')
+        envs = torch.zeros((num_envs, 3, self.size, self.size), device=self.device)
+        done = torch.ones(num_envs, dtype=torch.bool, device=self.device)
+        rc = _lib.lib().wurm_single_reset(
+            _lib.ptr(envs), _lib.ptr(done), None, _lib.OBS_NONE, 0, _lib.i64(num_envs), self.size,
+            _lib.u64(self.seed), _lib.u64(self._next_call()), _lib.i64(self.env_offset), None, _lib.stream_ptr())
+        _lib.check(rc, 'SingleSnake._create_envs')
+        return envs
+
+    # ------------------------------------------------------------------ fused multi-step loop (extension)
+
+    def rollout(self, actions: torch.Tensor, return_observations: bool = True) -> dict:
+        """T iterations of `obs, r, d, info = env.step(actions[t]); env.reset(d)` in one kernel launch.
+
+        actions: (T, num_envs) int64/int32 on the device, sanitised in place.  Returns a dict of (T, N, ...) tensors
+        (`observations`, `rewards`, `dones`, `self_collision`, `edge_collision`), bit-identical to the Python loop.
+        """
+        if actions.dtype not in (torch.int, torch.long):
+            raise TypeError('actions Tensor must be an integer type i.e. {torch.IntTensor, torch.LongTensor}')
+        if actions.dim() != 2 or actions.shape[1] != self.num_envs:
+            raise RuntimeError('Must have the same number of actions as environments.')
+        if not actions.is_contiguous() or actions.device != self.device:
+            raise RuntimeError('rollout actions must be a contiguous device tensor')
+        envs = self._state()
+        T, N = actions.shape
+        if return_observations:
+            m, n = self._parse_mode(self.observation_mode)
+            obs = torch.empty((T,) + self._obs_shape(self.observation_mode), dtype=torch.float32, device=self.device)
+        else:
+            m, n, obs = _lib.OBS_NONE, 0, None
+        reward = torch.empty((T, N), dtype=torch.float32, device=self.device)
+        flags = torch.empty((3, T, N), dtype=torch.bool, device=self.device)
+        rc = _lib.lib().wurm_single_rollout(
+            _lib.ptr(envs), _lib.ptr(actions), _lib.ACT_I64 if actions.dtype == torch.long else _lib.ACT_I32,
+            _lib.ptr(reward), _lib.ptr(flags[0]), _lib.ptr(flags[1]), _lib.ptr(flags[2]), _lib.ptr(obs), m, n,
+            _lib.i64(N), self.size, _lib.i64(T), _lib.u64(self.seed), _lib.u64(self._next_call(2 * T)),
+            _lib.i64(self.env_offset), None, None, _lib.stream_ptr())
+        _lib.check(rc, 'SingleSnake.rollout')
+        self.done = torch.zeros(N, dtype=torch.bool, device=self.device)  # every done env was reset
+        return {'observations': obs, 'rewards': reward, 'dones': flags[0], 'self_collision': flags[1],
+                'edge_collision': flags[2]}
+
+    # ------------------------------------------------------------------ invariants
+
+    def check_consistency(self):
+        """wurm.utils.env_consistency on self.envs (reference wurm/utils.py:167-178)."""
+        from wurm_amd.utils import env_consistency
+        env_consistency(self._state())
+
+    # ------------------------------------------------------------------ rendering (host side)
+
+    def render(self, mode: str = 'human'):
+        """reference :389-428.  Only 'rgb_array' is provided (the 'human' viewer needs gym/pyglet)."""
+        import numpy as np
+        from PIL import Image
+
+        img = self._get_rgb().cpu().numpy()
+        if self.num_envs == 1:
+            num_cols = num_rows = 1
+            img = np.transpose(img[0], (1, 2, 0))
+        else:
+            num_rows = self.render_args['num_rows']
+            num_cols = self.render_args['num_cols']
+            output = np.zeros((self.size * num_rows, self.size * num_cols, 3))
+            for i in range(num_rows):
+                for j in range(num_cols):
+                    output[i * self.size:(i + 1) * self.size, j * self.size:(j + 1) * self.size, :] = \
+                        np.transpose(img[i * num_cols + j], (1, 2, 0))
+            img = output
+
+        img = np.array(Image.fromarray(img.astype(np.uint8)).resize(
+            (self.render_args['size'] * num_cols, self.render_args['size'] * num_rows)))
+
+        if mode == 'rgb_array':
+            return img
+        elif mode == 'human':
+            raise NotImplementedError("render('human') needs gym's SimpleImageViewer; use mode='rgb_array'")
+        else:
+            raise ValueError('Render mode not recognised.')
