@@ -47,6 +47,9 @@ def lib():
             raise WurmHipError(
                 f'{LIB_PATH} is missing: build it with `python -c "import __graft_entry__ as g; g.build()"` '
                 f'(or `make -C wurm_amd/csrc`). There is no CPU fallback.')
+        # torch bundles its own libamdhip64.so.7 (same SONAME as /opt/rocm's): import torch FIRST so that this
+        # library binds to the HIP runtime that owns torch's device memory and streams, whatever the load order.
+        import torch  # noqa: F401
         l = ctypes.CDLL(LIB_PATH)
         l.wurm_version.restype = ctypes.c_char_p
         l.wurm_single_obs_elems.restype = ctypes.c_int64

@@ -107,7 +107,7 @@ __device__ __forceinline__ int find_head(const Env<CPL> &e)
 // General form of determine_orientations (wurm/utils.py:36-65) for states that are not a well-formed snake
 // (e.g. a done env stepped again before reset): neck map in LDS, 4-tap stencil, wave max, first argmax.
 template <int CPL>
-__device__ __noinline__ int slow_orientation(const Env<CPL> &e, const Geo &g, int L, signed char *lds)
+__device__ __forceinline__ int slow_orientation(const Env<CPL> &e, const Geo &g, int L, signed char *lds)
 {
     wave_lds_sync();
 #pragma unroll
@@ -654,6 +654,7 @@ static int pick_cpl(int S)
 template <int CPL, bool SNAKE>
 static hipError_t launch_one(Kind kind, const StepArgs &p, dim3 grid, dim3 block, size_t lds, hipStream_t st)
 {
+    (void)hipGetLastError(); // drop any stale error left by earlier runtime calls of this thread
     switch (kind) {
     case K_STEP: hipLaunchKernelGGL((step_kernel<CPL, SNAKE>), grid, block, lds, st, p); break;
     case K_RESET: hipLaunchKernelGGL((reset_kernel<CPL, SNAKE>), grid, block, lds, st, p); break;
@@ -799,6 +800,7 @@ int wurm_single_check(const float *envs, uint32_t *err, int64_t num_envs, int si
     dim3 block(64 * wpb), grid((unsigned)((num_envs + wpb - 1) / wpb));
     hipStream_t st = (hipStream_t)stream;
     long long N = num_envs;
+    (void)hipGetLastError();
     switch (cpl) {
     case 2: hipLaunchKernelGGL(check_kernel<2>, grid, block, 0, st, envs, err, N, size); break;
     case 4: hipLaunchKernelGGL(check_kernel<4>, grid, block, 0, st, envs, err, N, size); break;
