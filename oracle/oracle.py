@@ -221,3 +221,132 @@ def grid_rollout(envs, actions, start_location, mode='default', seed=0, call0=0,
                                      _p(obs), m, n, _i64(N), S, _i64(T), int(sy), int(sx), _u64(seed), _u64(call0),
                                      _i64(env_offset), _p(inj_f), _p(inj_r)))
     return dict(obs=obs, reward=reward, done=done, edge_collision=ec)
+
+
+# ---------------------------------------------------------------- MultiSnake
+
+class MultiCfg(ctypes.Structure):
+    _fields_ = [('boost', ctypes.c_int), ('food_on_death', ctypes.c_int), ('death_threshold', ctypes.c_float),
+                ('boost_cost_prob', ctypes.c_float), ('food_mode', ctypes.c_int), ('food_rate', ctypes.c_float),
+                ('max_food', ctypes.c_int), ('reward_on_death', ctypes.c_float), ('respawn_any', ctypes.c_int),
+                ('colour_random', ctypes.c_int)]
+
+
+class MultiInject(ctypes.Structure):
+    _fields_ = [('death_a', ctypes.c_void_p), ('cost', ctypes.c_void_p), ('death_b', ctypes.c_void_p),
+                ('rate', ctypes.c_void_p), ('food_cell', ctypes.c_void_p)]
+
+
+class MultiResetInject(ctypes.Structure):
+    _fields_ = [('create', ctypes.c_void_p), ('create_food', ctypes.c_void_p), ('colours', ctypes.c_void_p),
+                ('respawn', ctypes.c_void_p)]
+
+
+def multi_cfg(num_snakes, boost=True, food_on_death_prob=0.5, boost_cost_prob=0.5, food_mode='only_one',
+              food_rate=5e-4, reward_on_death=-1, respawn_mode='all', colour_mode='random'):
+    """Dynamics parameters with the reference's defaults (multi_snake.py:56-75)."""
+    return MultiCfg(int(bool(boost)), int(food_on_death_prob > 0), np.float32(1 - food_on_death_prob),
+                    np.float32(boost_cost_prob), {'only_one': 0, 'random_rate': 1}[food_mode], np.float32(food_rate),
+                    8 * num_snakes, np.float32(reward_on_death), int(respawn_mode == 'any'),
+                    int(colour_mode == 'random'))
+
+
+def _addr(a):
+    return None if a is None else a.ctypes.data
+
+
+def multi_obs_shape(mode, N, K, S):
+    m, n = parse_obs_mode(mode)
+    if m == OBS_DEFAULT:
+        return (K, N, 3, S, S)
+    if m == OBS_PARTIAL:
+        return (K, N, 3, 2 * n + 1, 2 * n + 1)
+    return None
+
+
+def multi_observe(st, mode):
+    """st: dict with foods, heads, bodies, dones, boost_this_step, colours (numpy, reference shapes)."""
+    N, _, S, _ = st['foods'].shape
+    K = st['heads'].shape[0] // N
+    m, n = parse_obs_mode(mode)
+    obs = np.empty(multi_obs_shape(mode, N, K, S), np.float32)
+    _check(lib().oracle_multi_observe(_p(st['foods']), _p(st['heads']), _p(st['bodies']), _p(st['dones']),
+                                      _p(st['boost_this_step']), _p(st['colours']), _p(obs), m, n, _i64(N), K, S))
+    return obs
+
+
+def multi_step(st, actions, cfg, mode='full', seed=0, call=0, env_offset=0, inject=None):
+    """st: dict of numpy state arrays modified in place: foods (N,1,S,S), heads/bodies (N*K,1,S,S), dones (N*K) u8,
+    orientations (N*K) i64, boost_this_step (N*K) u8, colours (N*K,3) i16.  actions: (K,N) int64.
+    inject: dict with death_a, cost, death_b, rate (uint8) and food_cell (int32), or None.
+    Returns dict(obs (K,N,...), rewards, snake_collision, edge_collision, food, size (all (N*K)), all_done (N))."""
+    N, _, S, _ = st['foods'].shape
+    K = st['heads'].shape[0] // N
+    m, n = parse_obs_mode(mode)
+    shape = multi_obs_shape(mode, N, K, S)
+    obs = np.empty(shape, np.float32) if shape else None
+    rewards, food, size = (np.empty(N * K, np.float32) for _ in range(3))
+    sc, ec = (np.empty(N * K, np.uint8) for _ in range(2))
+    all_done = np.empty(N, np.uint8)
+    actions = np.ascontiguousarray(actions, np.int64)
+    assert actions.shape == (K, N)
+    keep = []
+    inj_ref = None
+    if inject is not None:
+        arrs = [np.ascontiguousarray(inject[k], np.uint8) for k in ('death_a', 'cost', 'death_b', 'rate')]
+        arrs.append(np.ascontiguousarray(inject['food_cell'], np.int32))
+        keep.extend(arrs)
+        inj = MultiInject(*[_addr(a) for a in arrs])
+        inj_ref = ctypes.byref(inj)
+    _check(lib().oracle_multi_step(_p(st['foods']), _p(st['heads']), _p(st['bodies']), _p(st['dones']),
+                                   _p(st['orientations']), _p(actions), _p(st['boost_this_step']), _p(rewards),
+                                   _p(sc), _p(ec), _p(food), _p(size), _p(all_done), _p(st['colours']), _p(obs), m, n,
+                                   _i64(N), K, S, ctypes.byref(cfg), _u64(seed), _u64(call), _i64(env_offset),
+                                   inj_ref))
+    return dict(obs=obs, rewards=rewards, snake_collision=sc, edge_collision=ec, food=food, size=size,
+                all_done=all_done)
+
+
+def multi_reset(st, done_env, cfg, seed=0, call=0, env_offset=0, inject=None):
+    """Rebuilds the envs flagged in done_env (N), re-rolls colours of dead snakes, respawns (respawn_mode 'any').
+    inject: dict with create (N,K,2), create_food (N), colours (N*K,3) i16, respawn (N,2), or None.
+    Returns the number of envs in which a snake could not be placed."""
+    N, _, S, _ = st['foods'].shape
+    K = st['heads'].shape[0] // N
+    d = np.ascontiguousarray(np.asarray(done_env).reshape(N) != 0, dtype=np.uint8)
+    status = np.zeros(1, np.int32)
+    keep = []
+    inj_ref = None
+    if inject is not None:
+        arrs = [np.ascontiguousarray(inject['create'], np.int32), np.ascontiguousarray(inject['create_food'], np.int32),
+                np.ascontiguousarray(inject['colours'], np.int16), np.ascontiguousarray(inject['respawn'], np.int32)]
+        keep.extend(arrs)
+        inj = MultiResetInject(*[_addr(a) for a in arrs])
+        inj_ref = ctypes.byref(inj)
+    _check(lib().oracle_multi_reset(_p(st['foods']), _p(st['heads']), _p(st['bodies']), _p(st['dones']),
+                                    _p(st['orientations']), _p(st['colours']), _p(d), _p(status), _i64(N), K, S,
+                                    ctypes.byref(cfg), _u64(seed), _u64(call), _i64(env_offset), inj_ref))
+    return int(status[0])
+
+
+def multi_check(st):
+    N, _, S, _ = st['foods'].shape
+    K = st['heads'].shape[0] // N
+    err = np.empty(N, np.uint32)
+    _check(lib().oracle_multi_check(_p(st['foods']), _p(st['heads']), _p(st['bodies']), _p(st['dones']), _p(err),
+                                    _i64(N), K, S))
+    return err
+
+
+def multi_empty_state(N, K, S):
+    return dict(foods=np.zeros((N, 1, S, S), np.float32), heads=np.zeros((N * K, 1, S, S), np.float32),
+                bodies=np.zeros((N * K, 1, S, S), np.float32), dones=np.zeros(N * K, np.uint8),
+                orientations=np.zeros(N * K, np.int64), boost_this_step=np.zeros(N * K, np.uint8),
+                colours=np.zeros((N * K, 3), np.int16))
+
+
+def orientations(envs):
+    n, _, S, _ = envs.shape
+    out = np.empty(n, np.int64)
+    _check(lib().oracle_orientations(_p(envs), _p(out), _i64(n), S))
+    return out

@@ -50,3 +50,25 @@ class OracleBackend(object):
     def grid_rollout(self, envs, actions, start, mode, inject_food=None, inject_reset=None):
         return _o.grid_rollout(envs, actions, start, mode, self.seed, self._next(2 * actions.shape[0]),
                                self.env_offset, inject_food, inject_reset)
+
+    # MultiSnake
+    def multi_cfg(self, K, cfg):
+        return _o.multi_cfg(K, boost=cfg['boost'], food_on_death_prob=cfg['food_on_death_prob'],
+                            boost_cost_prob=cfg['boost_cost_prob'], food_mode=cfg['food_mode'],
+                            food_rate=cfg['food_rate'], reward_on_death=cfg['reward_on_death'],
+                            respawn_mode=cfg['respawn_mode'], colour_mode=cfg['colour_mode'])
+
+    def multi_step(self, st, actions, cfg, mode, inject=None):
+        K = st['heads'].shape[0] // st['foods'].shape[0]
+        return _o.multi_step(st, actions, self.multi_cfg(K, cfg), mode, self.seed, self._next(), self.env_offset,
+                             inject)
+
+    def multi_reset(self, st, done_env, cfg, inject=None):
+        K = st['heads'].shape[0] // st['foods'].shape[0]
+        return _o.multi_reset(st, done_env, self.multi_cfg(K, cfg), self.seed, self._next(), self.env_offset, inject)
+
+    def multi_observe(self, st, mode):
+        return _o.multi_observe(st, mode)
+
+    def multi_check(self, st):
+        return _o.multi_check(st)

@@ -103,3 +103,63 @@ def replay_grid_rollout(backend, fx):
     _eq(out['edge_collision'], fx['edge_collision'], 'edge_collision', 'all')
     _eq(out['obs'], fx['obs_step'], 'step observations', 'all')
     _eq(envs, fx['state_reset'][-1].astype(np.float32), 'final state', T - 1)
+
+
+# ------------------------------------------------------------------------------------------- MultiSnake
+
+def load_multi(name):
+    fx = load(name)
+    N, K, S, T = (int(v) for v in fx['meta'][:4])
+    for k in ('death_a', 'death_b', 'rate'):
+        packed = fx['inj_' + k]
+        fx['inj_' + k] = np.stack([np.unpackbits(packed[t])[:N * S * S].reshape(N, S, S) for t in range(T)])
+    fx['cfg_dict'] = eval(str(fx['cfg']), {'__builtins__': {}}, {})
+    return fx
+
+
+def multi_state(fx, prefix, t=None):
+    def g(k):
+        a = fx[prefix + k]
+        return a if t is None else a[t]
+    return dict(foods=g('foods').astype(np.float32), heads=g('heads').astype(np.float32),
+                bodies=g('bodies').astype(np.float32), dones=g('dones').astype(np.uint8).copy(),
+                orientations=g('orientations').astype(np.int64).copy(),
+                boost_this_step=g('boost_this_step').astype(np.uint8).copy(),
+                colours=g('colours').astype(np.int16).copy())
+
+
+def _eq_state(st, fx, prefix, t, what):
+    for k in ('foods', 'heads', 'bodies'):
+        _eq(st[k], fx[prefix + k][t].astype(np.float32), f'{what} {k}', t)
+    for k in ('dones', 'orientations', 'boost_this_step', 'colours'):
+        _eq(st[k], fx[prefix + k][t], f'{what} {k}', t)
+
+
+def _obs_from_code(code):
+    return code.astype(np.float32) / np.float32(255)
+
+
+def replay_multi(backend, fx):
+    mode = str(fx['mode'])
+    N, K, S, T = (int(v) for v in fx['meta'][:4])
+    cfg = fx['cfg_dict']
+    st = multi_state(fx, 'state0_')
+    for t in range(T):
+        inj = {k: fx['inj_' + k][t] for k in ('death_a', 'cost', 'death_b', 'rate', 'food_cell')}
+        r = backend.multi_step(st, fx['actions'][t], cfg, mode, inject=inj)
+        _eq_state(st, fx, 'step_', t, 'post-step')
+        _eq(st['dones'], fx['dones_out'][t], 'dones', t)
+        _eq(r['rewards'], fx['rewards'][t], 'rewards', t)
+        _eq(r['snake_collision'], fx['snake_collision'][t], 'snake_collision', t)
+        _eq(r['edge_collision'], fx['edge_collision'][t], 'edge_collision', t)
+        _eq(r['food'], fx['food'][t], 'food consumed', t)
+        _eq(r['size'], fx['size'][t], 'sizes', t)
+        _eq(st['boost_this_step'], fx['boost'][t], 'boost info', t)
+        _eq(r['all_done'], fx['all_done'][t], '__all__ done', t)
+        _eq(r['obs'], _obs_from_code(fx['obs_step'][t]), 'step observation', t)
+        rinj = {k: fx['rinj_' + k][t] for k in ('create', 'create_food', 'colours', 'respawn')}
+        backend.multi_reset(st, fx['all_done'][t], cfg, inject=rinj)
+        _eq_state(st, fx, 'reset_', t, 'post-reset')
+        if 'obs_reset' in fx:
+            _eq(backend.multi_observe(st, mode), _obs_from_code(fx['obs_reset'][t]), 'reset observation', t)
+    return st
