@@ -129,6 +129,89 @@ int wurm_grid_rollout(float *envs, const void *actions, int actions_dtype, float
                       int64_t num_steps, int start_y, int start_x, uint64_t seed, uint64_t call0,
                       int64_t env_offset, const int32_t *inject_food, const int32_t *inject_reset, void *stream);
 
+/* ------------------------------------------------------------------------------------------- MultiSnake */
+
+/* Dynamics parameters of MultiSnake (attributes the reference lets callers change after construction,
+ * multi_snake.py:121-129; tests/test_multi_snake_env.py:180,288,401-403 set them).  A HOST struct. */
+typedef struct wurm_multi_config {
+    int boost;             /* self.boost                                           multi_snake.py:123 */
+    int food_on_death;     /* self.food_on_death_prob > 0                          :565,662           */
+    float death_threshold; /* (float)(1 - food_on_death_prob): food where u > threshold   :424        */
+    float boost_cost_prob; /* boost cost where u < boost_cost_prob                 :579               */
+    int food_mode;         /* 0 = 'only_one', 1 = 'random_rate'                    :369,380           */
+    float food_rate;       /* rate food where u < food_rate                        :403               */
+    int max_food;          /* num_snakes * 8                                       :127               */
+    float reward_on_death; /*                                                      :684               */
+    int respawn_any;       /* respawn_mode == 'any'                                :805               */
+    int colour_random;     /* colour_mode == 'random'                              :800               */
+} wurm_multi_config;
+
+/* Recorded random outcomes for wurm_multi_step (all DEVICE pointers; pass the struct pointer as NULL for RNG mode). */
+typedef struct wurm_multi_inject {
+    const uint8_t *death_a;   /* (N,S,S) outcome of `rand_like > 1-p`, boost phase    :424 via :574 */
+    const uint8_t *cost;      /* (N*K)   outcome of `rand < boost_cost_prob`          :579          */
+    const uint8_t *death_b;   /* (N,S,S) outcome of `rand_like > 1-p`, regular phase  :424 via :671 */
+    const uint8_t *rate;      /* (N,S,S) outcome of `rand < food_rate`                :401-403      */
+    const int32_t *food_cell; /* (N)     'only_one' respawn cell, -1 = none           :374-379      */
+} wurm_multi_inject;
+
+/* Recorded random outcomes for wurm_multi_reset (DEVICE pointers; NULL struct pointer = RNG mode). */
+typedef struct wurm_multi_reset_inject {
+    const int32_t *create;      /* (N,K,2) seed cell, direction of every snake of a rebuilt env    :996-1019 */
+    const int32_t *create_food; /* (N)     food cell of a rebuilt env                               :1016     */
+    const int16_t *colours;     /* (N*K,3) colour given to snakes still dead after the reset        :800-803  */
+    const int32_t *respawn;     /* (N,2)   respawn_mode 'any': seed cell (-1 = no room), direction  :805-829  */
+} wurm_multi_reset_inject;
+
+/* floats per (agent, env) of an observation: 'full' (WURM_OBS_DEFAULT) 3*S*S, 'partial_n' 3*(2n+1)^2 */
+int64_t wurm_multi_obs_elems(int obs_mode, int obs_n, int size);
+
+/* MultiSnake.step (multi_snake.py:462-731) + _observe (:283-334) in one launch.
+ *   foods (N,1,S,S), heads/bodies (N*K,1,S,S) fp32 in/out; dones (N*K) bytes in/out; orientations (N*K) int64
+ *   in/out; actions (K,N) int64: actions[i*N + e] = agent_i's action (0..7) in env e (the reference stacks its
+ *   dict the same way, :492); colours (N*K,3) int16 (agent_colours, read by 'partial_n').
+ *   Outputs, (N*K) in the reference's agent order env*K + i: boost_this_step, rewards, snake_collision,
+ *   edge_collision, food_consumed (info 'food_i'), sizes (info 'size_i'); all_done (N) = dones['__all__'].
+ *   obs (K,N,elems): obs[i] is agent_i's tensor. */
+int wurm_multi_step(float *foods, float *heads, float *bodies, uint8_t *dones, int64_t *orientations,
+                    const int64_t *actions, uint8_t *boost_this_step, float *rewards, uint8_t *snake_collision,
+                    uint8_t *edge_collision, float *food_consumed, float *sizes, uint8_t *all_done,
+                    const int16_t *colours, float *obs, int obs_mode, int obs_n, int64_t num_envs, int num_snakes,
+                    int size, const wurm_multi_config *cfg, uint64_t seed, uint64_t call, int64_t env_offset,
+                    const wurm_multi_inject *inject, void *stream);
+
+/* MultiSnake.reset (multi_snake.py:771-836): envs flagged in done_env (N bytes) are rebuilt (_create_envs
+ * :996-1019: K snakes placed one after another on free cells away from everything, one food); colours of
+ * snakes that are still dead are re-rolled (colour_random); respawn_any: the first dead snake of every env
+ * respawns if there is room; then every agent is observed (obs may be NULL / WURM_OBS_NONE).
+ *   status: nullable, 1 int32, incremented for every env in which a rebuilt snake found no room (the reference
+ *   raises RuntimeError at :946-947). */
+int wurm_multi_reset(float *foods, float *heads, float *bodies, uint8_t *dones, int64_t *orientations,
+                     int16_t *colours, const uint8_t *done_env, int32_t *status, const uint8_t *boost_this_step,
+                     float *obs, int obs_mode, int obs_n, int64_t num_envs, int num_snakes, int size,
+                     const wurm_multi_config *cfg, uint64_t seed, uint64_t call, int64_t env_offset,
+                     const wurm_multi_reset_inject *inject, void *stream);
+
+/* MultiSnake._observe (multi_snake.py:283-334) */
+int wurm_multi_observe(const float *foods, const float *heads, const float *bodies, const uint8_t *dones,
+                       const uint8_t *boost_this_step, const int16_t *colours, float *obs, int obs_mode, int obs_n,
+                       int64_t num_envs, int num_snakes, int size, void *stream);
+
+/* MultiSnake.check_consistency (multi_snake.py:733-769) as a per-env bitmask: bits 0-6 = WURM_CHK_* of any living
+ * snake, WURM_MCHK_OVERLAP, WURM_MCHK_DEAD_NONZERO. */
+#define WURM_MCHK_OVERLAP 0x100u
+#define WURM_MCHK_DEAD_NONZERO 0x200u
+int wurm_multi_check(const float *foods, const float *heads, const float *bodies, const uint8_t *dones, uint32_t *err,
+                     int64_t num_envs, int num_snakes, int size, void *stream);
+
+/* MultiSnake.get_n_colours (multi_snake.py:163-169) at construction: random colour per agent (fixed = 0) or one
+ * colour per snake index shared by all envs (fixed = 1; :146-148).  colours out (N*K,3) int16. */
+int wurm_multi_colours(int16_t *colours, int64_t num_envs, int num_snakes, int fixed, uint64_t seed, uint64_t call,
+                       int64_t env_offset, void *stream);
+
+/* wurm.utils.determine_orientations (wurm/utils.py:36-65) over a (n,3,S,S) batch; out (n) int64. */
+int wurm_orientations(const float *envs, int64_t *out, int64_t n, int size, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -624,3 +624,16 @@ int oracle_orientations(const float *envs, int64_t *out, int64_t n, int S)
     }
     return ORACLE_OK;
 }
+
+/* get_n_colours at construction (multi_snake.py:143-148): 'random' = one colour per agent, 'fixed' = one colour
+ * per snake index shared by all envs (drawn with the reserved env id 0xffffffff). */
+int oracle_multi_colours(int16_t *colours, int64_t N, int K, int fixed, uint64_t seed, uint64_t call, int64_t env_offset)
+{
+    for (int64_t e = 0; e < N; ++e)
+        for (int s = 0; s < K; ++s) {
+            uint32_t w[4];
+            oracle_rng_words(seed, call, fixed ? 0xffffffffull : (uint64_t)(env_offset + e), RNG_COLOUR, (uint32_t)s, w);
+            random_colour(w, colours + (e * K + s) * 3);
+        }
+    return ORACLE_OK;
+}

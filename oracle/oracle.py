@@ -350,3 +350,9 @@ def orientations(envs):
     out = np.empty(n, np.int64)
     _check(lib().oracle_orientations(_p(envs), _p(out), _i64(n), S))
     return out
+
+
+def multi_colours(N, K, fixed=False, seed=0, call=0, env_offset=0):
+    col = np.empty((N * K, 3), np.int16)
+    _check(lib().oracle_multi_colours(_p(col), _i64(N), K, int(fixed), _u64(seed), _u64(call), _i64(env_offset)))
+    return col

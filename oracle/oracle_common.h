@@ -84,12 +84,13 @@ static inline uint32_t oracle_mulhi(uint32_t w, uint32_t n) { return (uint32_t)(
 /* uniform float32 in [0,1) with 24 random bits (same lattice as torch.rand's float32) */
 static inline float oracle_u01(uint32_t w) { return (float)(w >> 8) * (1.0f / 16777216.0f); }
 
-/* per-cell uniform for cell index `cell` of an env: block = cell/4, word = cell%4 */
+/* per-cell uniform for cell index `cell` of an env.  Cells c, c+64, c+128, c+192 share one Philox block
+ * (sub = (c >> 8) * 64 + (c & 63), word = (c >> 6) & 3): on the GPU one lane owns all four. */
 static inline float oracle_cell_u01(uint64_t seed, uint64_t call, uint64_t env_id, uint32_t purpose, uint32_t cell)
 {
     uint32_t w[4];
-    oracle_rng_words(seed, call, env_id, purpose, cell >> 2, w);
-    return oracle_u01(w[cell & 3u]);
+    oracle_rng_words(seed, call, env_id, purpose, ((cell >> 8) << 6) | (cell & 63u), w);
+    return oracle_u01(w[(cell >> 6) & 3u]);
 }
 
 #ifdef __cplusplus

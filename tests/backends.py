@@ -63,9 +63,17 @@ class OracleBackend(object):
         return _o.multi_step(st, actions, self.multi_cfg(K, cfg), mode, self.seed, self._next(), self.env_offset,
                              inject)
 
-    def multi_reset(self, st, done_env, cfg, inject=None):
+    def multi_reset(self, st, done_env, cfg, inject=None, mode=None):
         K = st['heads'].shape[0] // st['foods'].shape[0]
-        return _o.multi_reset(st, done_env, self.multi_cfg(K, cfg), self.seed, self._next(), self.env_offset, inject)
+        rc = _o.multi_reset(st, done_env, self.multi_cfg(K, cfg), self.seed, self._next(), self.env_offset, inject)
+        self.last_reset_obs = _o.multi_observe(st, mode) if mode else None
+        return rc
+
+    def multi_colours(self, N, K, fixed=False, call=0):
+        return _o.multi_colours(N, K, fixed, self.seed, call, self.env_offset)
+
+    def orientations(self, envs):
+        return _o.orientations(envs)
 
     def multi_observe(self, st, mode):
         return _o.multi_observe(st, mode)

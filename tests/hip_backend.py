@@ -190,3 +190,128 @@ class HipBackend(object):
         actions[...] = a.cpu().numpy()
         return dict(obs=obs.cpu().numpy() if obs is not None else None, reward=reward.cpu().numpy(),
                     done=done.cpu().numpy(), edge_collision=ec.cpu().numpy())
+
+
+# ------------------------------------------------------------------ MultiSnake (methods added to HipBackend below)
+
+def _multi_cfg(K, cfg):
+    return _lib.multi_config(K, cfg['boost'], cfg['food_on_death_prob'], cfg['boost_cost_prob'], cfg['food_mode'],
+                             cfg['food_rate'], cfg['reward_on_death'], cfg['respawn_mode'], cfg['colour_mode'])
+
+
+def _multi_to_dev(self, st):
+    return {k: self._t(v) for k, v in st.items()}
+
+
+def _multi_back(st, dev):
+    for k in st:
+        st[k][...] = dev[k].cpu().numpy()
+
+
+def multi_step(self, st, actions, cfg, mode, inject=None):
+    import ctypes
+    N, _, S, _ = st['foods'].shape
+    K = st['heads'].shape[0] // N
+    m, n = _lib.parse_obs_mode(mode)
+    d = _multi_to_dev(self, st)
+    act = self._t(np.ascontiguousarray(actions, np.int64))
+    shape = _o.multi_obs_shape(mode, N, K, S)
+    obs = self._empty(shape, torch.float32) if shape else None
+    rewards, food, size = (self._empty((N * K,), torch.float32) for _ in range(3))
+    sc, ec = (self._empty((N * K,), torch.uint8) for _ in range(2))
+    all_done = self._empty((N,), torch.uint8)
+    c = _multi_cfg(K, cfg)
+    inj_ref, keep = None, []
+    if inject is not None:
+        keep = [self._t(np.ascontiguousarray(inject[k], np.uint8)) for k in ('death_a', 'cost', 'death_b', 'rate')]
+        keep.append(self._t(np.ascontiguousarray(inject['food_cell'], np.int32)))
+        inj = _lib.MultiInject(*[t.data_ptr() for t in keep])
+        inj_ref = ctypes.byref(inj)
+    rc = self.lib.wurm_multi_step(
+        _lib.ptr(d['foods']), _lib.ptr(d['heads']), _lib.ptr(d['bodies']), _lib.ptr(d['dones']),
+        _lib.ptr(d['orientations']), _lib.ptr(act), _lib.ptr(d['boost_this_step']), _lib.ptr(rewards), _lib.ptr(sc),
+        _lib.ptr(ec), _lib.ptr(food), _lib.ptr(size), _lib.ptr(all_done), _lib.ptr(d['colours']), _lib.ptr(obs), m, n,
+        _lib.i64(N), K, S, ctypes.byref(c), _lib.u64(self.seed), _lib.u64(self._next()), _lib.i64(self.env_offset),
+        inj_ref, self._stream())
+    _lib.check(rc, 'wurm_multi_step')
+    torch.cuda.synchronize()
+    _multi_back(st, d)
+    return dict(obs=obs.cpu().numpy() if obs is not None else None, rewards=rewards.cpu().numpy(),
+                snake_collision=sc.cpu().numpy(), edge_collision=ec.cpu().numpy(), food=food.cpu().numpy(),
+                size=size.cpu().numpy(), all_done=all_done.cpu().numpy())
+
+
+def multi_reset(self, st, done_env, cfg, inject=None, mode=None):
+    import ctypes
+    N, _, S, _ = st['foods'].shape
+    K = st['heads'].shape[0] // N
+    d = _multi_to_dev(self, st)
+    de = self._t((np.asarray(done_env).reshape(N) != 0).astype(np.uint8))
+    status = torch.zeros(1, dtype=torch.int32, device=self.dev)
+    c = _multi_cfg(K, cfg)
+    m, n = _lib.parse_obs_mode(mode)
+    shape = _o.multi_obs_shape(mode, N, K, S) if mode else None
+    obs = self._empty(shape, torch.float32) if shape else None
+    inj_ref, keep = None, []
+    if inject is not None:
+        keep = [self._t(np.ascontiguousarray(inject['create'], np.int32)),
+                self._t(np.ascontiguousarray(inject['create_food'], np.int32)),
+                self._t(np.ascontiguousarray(inject['colours'], np.int16)),
+                self._t(np.ascontiguousarray(inject['respawn'], np.int32))]
+        inj = _lib.MultiResetInject(*[t.data_ptr() for t in keep])
+        inj_ref = ctypes.byref(inj)
+    rc = self.lib.wurm_multi_reset(
+        _lib.ptr(d['foods']), _lib.ptr(d['heads']), _lib.ptr(d['bodies']), _lib.ptr(d['dones']),
+        _lib.ptr(d['orientations']), _lib.ptr(d['colours']), _lib.ptr(de), _lib.ptr(status),
+        _lib.ptr(d['boost_this_step']), _lib.ptr(obs), m, n, _lib.i64(N), K, S, ctypes.byref(c), _lib.u64(self.seed),
+        _lib.u64(self._next()), _lib.i64(self.env_offset), inj_ref, self._stream())
+    _lib.check(rc, 'wurm_multi_reset')
+    torch.cuda.synchronize()
+    _multi_back(st, d)
+    self.last_reset_obs = obs.cpu().numpy() if obs is not None else None
+    return int(status.item())
+
+
+def multi_observe(self, st, mode):
+    N, _, S, _ = st['foods'].shape
+    K = st['heads'].shape[0] // N
+    m, n = _lib.parse_obs_mode(mode)
+    d = _multi_to_dev(self, st)
+    obs = self._empty(_o.multi_obs_shape(mode, N, K, S), torch.float32)
+    rc = self.lib.wurm_multi_observe(_lib.ptr(d['foods']), _lib.ptr(d['heads']), _lib.ptr(d['bodies']),
+                                     _lib.ptr(d['dones']), _lib.ptr(d['boost_this_step']), _lib.ptr(d['colours']),
+                                     _lib.ptr(obs), m, n, _lib.i64(N), K, S, self._stream())
+    _lib.check(rc, 'wurm_multi_observe')
+    return obs.cpu().numpy()
+
+
+def multi_check(self, st):
+    N, _, S, _ = st['foods'].shape
+    K = st['heads'].shape[0] // N
+    d = _multi_to_dev(self, st)
+    err = self._empty((N,), torch.int32)
+    rc = self.lib.wurm_multi_check(_lib.ptr(d['foods']), _lib.ptr(d['heads']), _lib.ptr(d['bodies']),
+                                   _lib.ptr(d['dones']), _lib.ptr(err), _lib.i64(N), K, S, self._stream())
+    _lib.check(rc, 'wurm_multi_check')
+    return err.cpu().numpy().astype(np.uint32)
+
+
+def multi_colours(self, N, K, fixed=False, call=0):
+    col = self._empty((N * K, 3), torch.int16)
+    rc = self.lib.wurm_multi_colours(_lib.ptr(col), _lib.i64(N), K, int(fixed), _lib.u64(self.seed), _lib.u64(call),
+                                     _lib.i64(self.env_offset), self._stream())
+    _lib.check(rc, 'wurm_multi_colours')
+    return col.cpu().numpy()
+
+
+def orientations(self, envs):
+    n, _, S, _ = envs.shape
+    e = self._t(envs)
+    out = self._empty((n,), torch.int64)
+    rc = self.lib.wurm_orientations(_lib.ptr(e), _lib.ptr(out), _lib.i64(n), S, self._stream())
+    _lib.check(rc, 'wurm_orientations')
+    return out.cpu().numpy()
+
+
+for _f in (multi_step, multi_reset, multi_observe, multi_check, multi_colours, orientations):
+    setattr(HipBackend, _f.__name__, _f)

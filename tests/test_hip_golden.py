@@ -35,3 +35,12 @@ def test_gridworld_matches_reference(hip, name):
 @pytest.mark.parametrize('name', GRID)
 def test_gridworld_rollout_matches_reference(hip, name):
     replay.replay_grid_rollout(hip(), replay.load(name))
+
+
+MULTI = ['multi_k2_s12_default', 'multi_k4_s25_default', 'multi_k4_s25_train', 'multi_k3_s14_noboost',
+         'multi_k6_s10_crowded']
+
+
+@pytest.mark.parametrize('name', MULTI)
+def test_multi_snake_matches_reference(hip, name):
+    replay.replay_multi(hip(), replay.load_multi(name))

@@ -1,0 +1,106 @@
+"""GPU parity for MultiSnake with the build's own RNG (no injection): HIP kernels vs the CPU oracle, bit-exact on
+state, per-agent outputs and observations, over step / reset / respawn cycles."""
+import numpy as np
+import pytest
+
+from oracle import oracle as _o
+from tests.backends import OracleBackend
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def hip():
+    from tests.hip_backend import HipBackend
+    return HipBackend
+
+
+def _same(a, b, what):
+    if a is None and b is None:
+        return
+    if a.dtype.kind == 'f':
+        a32, b32 = np.ascontiguousarray(a, np.float32), np.ascontiguousarray(b, np.float32)
+        assert np.array_equal(a32.view(np.uint32), b32.view(np.uint32)), what
+    else:
+        assert np.array_equal(a, b), what
+
+
+def _same_state(a, b, what):
+    for k in a:
+        _same(a[k], b[k], f'{what}: {k}')
+
+
+CFGS = {
+    'default': dict(boost=True, food_on_death_prob=0.5, boost_cost_prob=0.5, food_mode='only_one', food_rate=5e-4,
+                    reward_on_death=-1, respawn_mode='all', colour_mode='random'),
+    'train': dict(boost=True, food_on_death_prob=0.33, boost_cost_prob=0.25, food_mode='random_rate',
+                  food_rate=2.5e-4, reward_on_death=-1, respawn_mode='any', colour_mode='random'),
+    'dense': dict(boost=True, food_on_death_prob=0.9, boost_cost_prob=0.8, food_mode='random_rate', food_rate=2e-2,
+                  reward_on_death=-2, respawn_mode='any', colour_mode='fixed'),
+    'noboost': dict(boost=False, food_on_death_prob=0.0, boost_cost_prob=0.5, food_mode='only_one', food_rate=5e-4,
+                    reward_on_death=-1, respawn_mode='any', colour_mode='random'),
+}
+
+
+@pytest.mark.parametrize('N,K,S,T,mode,cfg', [
+    (24, 2, 12, 120, 'full', 'default'),
+    (10, 4, 25, 80, 'full', 'default'),        # BASELINE cfg4 shape
+    (10, 4, 25, 120, 'partial_5', 'train'),    # tests/test_multi_snake_env.py:100-104 dynamics
+    (8, 6, 14, 100, 'partial_2', 'dense'),
+    (9, 3, 10, 100, 'full', 'noboost'),
+    (3, 10, 36, 40, 'partial_3', 'train'),     # experiments/speeds.py shape (10 agents, 36x36)
+    (5, 1, 9, 60, 'full', 'dense'),
+])
+def test_multi_step_reset_loop(hip, N, K, S, T, mode, cfg):
+    cfg = CFGS[cfg]
+    rng = np.random.RandomState(100 + K * S)
+    o, h = OracleBackend(seed=77, env_offset=500), hip(seed=77, env_offset=500)
+    so, sh = _o.multi_empty_state(N, K, S), _o.multi_empty_state(N, K, S)
+    fixed = cfg['colour_mode'] == 'fixed'
+    so['colours'][...] = o.multi_colours(N, K, fixed, call=0)
+    sh['colours'][...] = h.multi_colours(N, K, fixed, call=0)
+    _same(so['colours'], sh['colours'], 'initial colours')
+    o._next(); h._next()
+    assert o.multi_reset(so, np.ones(N), cfg) == 0
+    assert h.multi_reset(sh, np.ones(N), cfg) == 0
+    _same_state(so, sh, 'fresh envs')
+    assert (o.multi_check(so) == 0).all()
+    deaths = 0
+    for t in range(T):
+        a = rng.randint(0, 8, size=(K, N)).astype(np.int64)
+        ro, rh = o.multi_step(so, a, cfg, mode), h.multi_step(sh, a, cfg, mode)
+        _same_state(so, sh, f'state t={t}')
+        for k in ro:
+            _same(ro[k], rh[k], f'{k} t={t}')
+        deaths += int(so['dones'].sum())
+        o.multi_reset(so, ro['all_done'], cfg, mode=mode)
+        h.multi_reset(sh, rh['all_done'], cfg, mode=mode)
+        _same_state(so, sh, f'reset state t={t}')
+        _same(o.last_reset_obs, h.last_reset_obs, f'reset obs t={t}')
+        _same(o.multi_check(so), h.multi_check(sh), f'consistency mask t={t}')
+        assert (o.multi_check(so) == 0).all(), f'inconsistent after reset at t={t}'
+    assert deaths > 0
+
+
+def test_orientations(hip):
+    rng = np.random.RandomState(5)
+    o, h = OracleBackend(), hip()
+    for S in (9, 12, 25):
+        N = 40
+        envs = np.zeros((N, 3, S, S), np.float32)
+        o.single_reset(envs, np.ones(N), 'none')
+        for t in range(10):
+            o.single_step(envs, rng.randint(0, 4, size=N).astype(np.int64), 'none')
+        _same(o.orientations(envs), h.orientations(envs), f'orientations S={S}')
+
+
+def test_observe_entry_point(hip):
+    o, h = OracleBackend(seed=3), hip(seed=3)
+    N, K, S = 6, 3, 16
+    cfg = CFGS['train']
+    st = _o.multi_empty_state(N, K, S)
+    st['colours'][...] = o.multi_colours(N, K, False, call=0)
+    o._next()
+    o.multi_reset(st, np.ones(N), cfg)
+    for mode in ('full', 'partial_4'):
+        _same(o.multi_observe(st, mode), h.multi_observe(st, mode), mode)

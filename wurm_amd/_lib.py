@@ -21,7 +21,40 @@ SYMBOLS = [
     'wurm_version', 'wurm_single_obs_elems', 'wurm_grid_obs_elems',
     'wurm_single_step', 'wurm_single_reset', 'wurm_single_observe', 'wurm_single_rollout', 'wurm_single_check',
     'wurm_grid_step', 'wurm_grid_reset', 'wurm_grid_observe', 'wurm_grid_rollout',
+    'wurm_multi_obs_elems', 'wurm_multi_step', 'wurm_multi_reset', 'wurm_multi_observe', 'wurm_multi_check',
+    'wurm_multi_colours', 'wurm_orientations',
 ]
+
+
+class MultiConfig(ctypes.Structure):
+    """wurm_multi_config of include/wurm_hip.h (host struct)"""
+    _fields_ = [('boost', ctypes.c_int), ('food_on_death', ctypes.c_int), ('death_threshold', ctypes.c_float),
+                ('boost_cost_prob', ctypes.c_float), ('food_mode', ctypes.c_int), ('food_rate', ctypes.c_float),
+                ('max_food', ctypes.c_int), ('reward_on_death', ctypes.c_float), ('respawn_any', ctypes.c_int),
+                ('colour_random', ctypes.c_int)]
+
+
+class MultiInject(ctypes.Structure):
+    """wurm_multi_inject: device pointers"""
+    _fields_ = [('death_a', ctypes.c_void_p), ('cost', ctypes.c_void_p), ('death_b', ctypes.c_void_p),
+                ('rate', ctypes.c_void_p), ('food_cell', ctypes.c_void_p)]
+
+
+class MultiResetInject(ctypes.Structure):
+    """wurm_multi_reset_inject: device pointers"""
+    _fields_ = [('create', ctypes.c_void_p), ('create_food', ctypes.c_void_p), ('colours', ctypes.c_void_p),
+                ('respawn', ctypes.c_void_p)]
+
+
+def multi_config(num_snakes, boost, food_on_death_prob, boost_cost_prob, food_mode, food_rate, reward_on_death,
+                 respawn_mode, colour_mode):
+    import numpy as np
+    if food_mode not in ('only_one', 'random_rate'):
+        raise ValueError('food_mechanics not recognised')
+    return MultiConfig(int(bool(boost)), int(food_on_death_prob > 0), float(np.float32(1 - food_on_death_prob)),
+                       float(np.float32(boost_cost_prob)), 0 if food_mode == 'only_one' else 1,
+                       float(np.float32(food_rate)), 8 * num_snakes, float(np.float32(reward_on_death)),
+                       int(respawn_mode == 'any'), int(colour_mode == 'random'))
 
 
 class WurmHipError(RuntimeError):
@@ -54,6 +87,7 @@ def lib():
         l.wurm_version.restype = ctypes.c_char_p
         l.wurm_single_obs_elems.restype = ctypes.c_int64
         l.wurm_grid_obs_elems.restype = ctypes.c_int64
+        l.wurm_multi_obs_elems.restype = ctypes.c_int64
         _lib = l
     return _lib
 

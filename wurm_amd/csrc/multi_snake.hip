@@ -1,0 +1,997 @@
+// multi_snake.hip — gfx950 kernels and C-ABI entry points for MultiSnake.
+//
+// Replaces (citations into oscarknagg/wurm):
+//   MultiSnake.step     wurm/envs/multi_snake.py:462-731   two phases (boost, regular) of move / eat / decay /
+//                       collide / grow / edge, food-on-death, boost cost, food respawn, death reward
+//   MultiSnake._observe wurm/envs/multi_snake.py:175-227,268-334   'full' (per-agent RGB) and 'partial_n'
+//   MultiSnake.reset    wurm/envs/multi_snake.py:771-1019  env re-creation, colour re-roll, respawn 'any'
+//   check_consistency   wurm/envs/multi_snake.py:733-769
+// The reference runs these as conv2d / einsum / repeat_interleave(xK) / masked scatter sequences with many host
+// syncs; here each call is ONE launch, one env per wavefront, runtime K and S:
+//   * the env's K body grids live in LDS as 16-bit cells [K][S*S] (bit 15 = "must be written back"), the food grid
+//     as bytes; lane l owns cells l + 64k of every grid, so HBM traffic is coalesced dword runs and every grid
+//     update is a conflict-free LDS access;
+//   * per-SNAKE scalars (head cell, length, done, orientation, reward ...) live one per lane in lanes 0..K-1, so
+//     the snake-level logic of all K snakes runs in parallel and exchanges values with shuffles / ballots;
+//   * cross-cell lookups (food under a head, bodies under a head) are single LDS reads at the head cell.
+// Integer/index work: no MFMA.  Bound: HBM ((1+2K)*S*S*4 B read + observation written per env-step).
+#include "wurm_device.hpp"
+#include "../../include/wurm_hip.h"
+
+namespace wurm {
+
+constexpr unsigned short DIRTY = 0x8000u;
+constexpr unsigned short VMASK = 0x7fffu;
+
+struct MultiArgs {
+    float *foods, *heads, *bodies;
+    uint8_t *dones;
+    long long *orientations;
+    const long long *actions;
+    uint8_t *boost;
+    float *rewards;
+    uint8_t *snakecol, *edgecol;
+    float *foodcons, *sizes;
+    uint8_t *all_done;
+    short *colours;
+    float *obs;
+    int obs_mode, obs_n;
+    long long obs_elems;
+    long long N;
+    int K, S;
+    wurm_multi_config cfg;
+    u64 seed, call;
+    long long env_offset;
+    wurm_multi_inject inj;
+    int has_inj;
+    const uint8_t *done_env;
+    int *status;
+    wurm_multi_reset_inject rinj;
+    int has_rinj;
+    uint32_t *err;
+    int lds_per_wave, off_body, off_food, off_occ, off_img, off_col;
+};
+
+struct Ctx {
+    int S, C, K, lane, cpl;
+    float rcpS;
+    int *hcell;            // [K] head cell per snake (-1 = none)
+    int *lmax;             // [K] max body value per snake
+    unsigned short *body;  // [K][C]
+    unsigned char *food;   // [C]
+    unsigned char *occ;    // [C] scratch (reset: occupancy)
+    short *img;            // [3][C] env image (partial_n)
+    float *colf;           // [K][4]: r, g, b, 1 + 0.5*boost
+};
+
+extern __shared__ __attribute__((aligned(16))) unsigned char wurm_multi_lds[];
+
+__device__ __forceinline__ Ctx make_ctx(const MultiArgs &p, int wave)
+{
+    Ctx cx;
+    unsigned char *base = wurm_multi_lds + (size_t)wave * p.lds_per_wave;
+    cx.S = p.S;
+    cx.C = p.S * p.S;
+    cx.K = p.K;
+    cx.lane = (int)(threadIdx.x & 63u);
+    cx.cpl = (cx.C + 63) >> 6;
+    cx.rcpS = 1.0f / (float)p.S;
+    cx.hcell = (int *)base;
+    cx.lmax = (int *)(base + 4 * p.K);
+    cx.body = (unsigned short *)(base + p.off_body);
+    cx.food = base + p.off_food;
+    cx.occ = base + p.off_occ;
+    cx.img = (short *)(base + p.off_img);
+    cx.colf = (float *)(base + p.off_col);
+    return cx;
+}
+
+__device__ __forceinline__ int BV(const Ctx &cx, int s, int c) { return cx.body[s * cx.C + c] & VMASK; }
+
+// ------------------------------------------------------------------------------------------------ load / store
+
+// HBM -> LDS.  Returns the lane's original food bits (bit k = food at cell lane + 64k).
+__device__ __forceinline__ u64 load_env(const Ctx &cx, const float *__restrict__ foodp,
+                                        const float *__restrict__ headp, const float *__restrict__ bodyp)
+{
+    const int C = cx.C, lane = cx.lane;
+    if (lane < cx.K) {
+        cx.hcell[lane] = -1;
+        cx.lmax[lane] = 0;
+    }
+    wave_lds_sync();
+    u64 fbits = 0;
+    for (int k = 0; k < cx.cpl; ++k) {
+        int c = lane + 64 * k;
+        if (c < C) {
+            int f = foodp[c] > 0.5f;
+            cx.food[c] = (unsigned char)f;
+            fbits |= (u64)f << k;
+        }
+    }
+    for (int s = 0; s < cx.K; ++s) {
+        const float *hp = headp + (size_t)s * C, *bp = bodyp + (size_t)s * C;
+#pragma unroll 4
+        for (int k = 0; k < cx.cpl; ++k) {
+            int c = lane + 64 * k;
+            if (c < C) {
+                float h = hp[c], b = bp[c];
+                int bi = __float2int_rn(b);
+                cx.body[s * C + c] = (unsigned short)(bi != 0 ? ((bi & VMASK) | DIRTY) : 0);
+                if (h > 0.5f) cx.hcell[s] = c;
+                if (bi > 0) atomicMax(&cx.lmax[s], bi);
+            }
+        }
+    }
+    wave_lds_sync();
+    return fbits;
+}
+
+// LDS -> HBM: body cells flagged DIRTY, the two head cells that changed, food cells that changed.
+__device__ __forceinline__ void store_env(const Ctx &cx, float *__restrict__ foodp, float *__restrict__ headp,
+                                          float *__restrict__ bodyp, u64 fbits0, int hc0, int hc, bool full)
+{
+    const int C = cx.C, lane = cx.lane;
+    for (int s = 0; s < cx.K; ++s) {
+        float *bp = bodyp + (size_t)s * C, *hp = headp + (size_t)s * C;
+        int hs = cx.hcell[s];
+        for (int k = 0; k < cx.cpl; ++k) {
+            int c = lane + 64 * k;
+            if (c < C) {
+                unsigned short v = cx.body[s * C + c];
+                if (full || (v & DIRTY)) bp[c] = (float)(v & VMASK);
+                if (full) hp[c] = (c == hs) ? 1.0f : 0.0f;
+            }
+        }
+    }
+    if (!full && lane < cx.K && hc != hc0) {
+        float *hp = headp + (size_t)lane * C;
+        if (hc0 >= 0) hp[hc0] = 0.0f;
+        if (hc >= 0) hp[hc] = 1.0f;
+    }
+    for (int k = 0; k < cx.cpl; ++k) {
+        int c = lane + 64 * k;
+        if (c < C) {
+            int f = cx.food[c] != 0;
+            if (full || f != (int)((fbits0 >> k) & 1)) foodp[c] = f ? 1.0f : 0.0f;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ step pieces
+
+// One phase of MultiSnake.step (boost phase multi_snake.py:509-563, regular phase :613-660) for the snakes
+// (lanes) with who == true.  All per-snake values are per-lane (lane = snake index).
+__device__ __forceinline__ void run_phase(const Ctx &cx, bool who, int dir, int &hc, int &L, bool &done,
+                                          float &reward, float &foodcons, bool &snakecol, bool &edgecol)
+{
+    const int S = cx.S, C = cx.C, K = cx.K, lane = cx.lane;
+    const bool snake = lane < K;
+    // move heads (:509 / :613, _move_heads :341-353): by -TAP[dir]; off the grid => the head vanishes
+    if (who && hc >= 0) {
+        int y = div_size(hc, cx.rcpS), x = hc - y * S;
+        int ny = y - tap_y(dir), nx = x - tap_x(dir);
+        hc = (ny >= 0 && ny < S && nx >= 0 && nx < S) ? ny * S + nx : -1;
+    }
+    // food overlap of ALL snakes (:514 / :618); each eaten cell loses its food once (:517-518 / :622)
+    const bool ov = snake && hc >= 0 && cx.food[hc] != 0;
+    wave_lds_sync();
+    if (ov) cx.food[hc] = 0;
+    // decay the movers that did not eat (:523-526 / :627-628)
+    u64 m = ballot(who && !ov);
+    while (m) {
+        int s = first_bit(m);
+        m &= m - 1;
+        unsigned short *b = cx.body + s * C;
+        for (int k = 0; k < cx.cpl; ++k) {
+            int c = lane + 64 * k;
+            if (c < C) {
+                int v = b[c] & VMASK;
+                if (v > 0) b[c] = (unsigned short)((v - 1) | DIRTY);
+            }
+        }
+    }
+    if (who && ov) { // :527-529 / :629-631
+        reward += 1.0f;
+        foodcons += 1.0f;
+    }
+    wave_lds_sync();
+    // collisions with any body (after the decay) or another snake's head (:534-547 / :636-644)
+    bool coll = false;
+    if (who && hc >= 0) {
+        int sum = 0;
+        for (int t = 0; t < K; ++t) sum += BV(cx, t, hc);
+        coll = sum > 0;
+    }
+    for (int o = 0; o < K; ++o) {
+        int ho = __shfl(hc, o, WAVE);
+        if (who && hc >= 0 && o != lane && ho == hc) coll = true;
+    }
+    done |= coll;
+    snakecol |= coll;
+    wave_lds_sync();
+    // new head segment (:552-555 / :649-652)
+    if (who && hc >= 0) {
+        int v = BV(cx, lane, hc);
+        cx.body[lane * C + hc] = (unsigned short)(((v + L + (ov ? 1 : 0)) & VMASK) | DIRTY);
+    }
+    if (who && ov) L += 1;
+    // edge collisions (:560-562 / :657-659)
+    if (who && hc >= 0) {
+        int y = div_size(hc, cx.rcpS), x = hc - y * S;
+        bool e = y == 0 || x == 0 || y == S - 1 || x == S - 1;
+        done |= e;
+        edgecol |= e;
+    }
+    wave_lds_sync();
+}
+
+// _food_from_death (:416-428) as applied at :565-576 / :662-673
+__device__ __forceinline__ void food_from_death(const Ctx &cx, bool done, bool has_body, const uint8_t *inj,
+                                                float thr, u64 seed, u64 call, u64 env_id, u32 purpose)
+{
+    const int S = cx.S, C = cx.C, lane = cx.lane;
+    const bool snake = lane < cx.K;
+    const u64 dead = ballot(snake && done && has_body);
+    if (!dead) return;
+    const u64 live = ballot(snake && !done);
+    for (int k = 0; k < cx.cpl; ++k) {
+        int c = lane + 64 * k;
+        if (c >= C) continue;
+        int y = div_size(c, cx.rcpS), x = c - y * S;
+        if (y == 1 || x == 0 || y == S - 1 || x == S - 1) continue; // :418-421 (row 1, sic)
+        bool d = false;
+        for (u64 m = dead; m; m &= m - 1) d |= BV(cx, first_bit(m), c) > 0;
+        if (!d) continue;
+        bool l = false;
+        for (u64 m = live; m; m &= m - 1) l |= BV(cx, first_bit(m), c) > 0;
+        if (l) continue; // :426 not under a living body
+        bool hit = inj ? inj[c] != 0 : cell_u01(seed, call, env_id, purpose, (u32)c) > thr; // :424
+        if (hit) cx.food[c] = 1; // += 1 then clamp(0,1) (:575,603 / :672,692)
+    }
+    wave_lds_sync();
+}
+
+// delete done snakes (:595-596 / :676-677)
+__device__ __forceinline__ void delete_done(const Ctx &cx, bool done, bool &has_body, int &hc)
+{
+    const int C = cx.C, lane = cx.lane;
+    u64 m = ballot(lane < cx.K && done && has_body);
+    while (m) {
+        int s = first_bit(m);
+        m &= m - 1;
+        unsigned short *b = cx.body + s * C;
+        for (int k = 0; k < cx.cpl; ++k) {
+            int c = lane + 64 * k;
+            if (c < C && (b[c] & VMASK)) b[c] = DIRTY;
+        }
+    }
+    if (lane < cx.K && done) {
+        has_body = false;
+        hc = -1;
+    }
+    wave_lds_sync();
+}
+
+// bit k set <=> cell lane + 64k is interior and has no food, head or body on it (:439-445, :393-399)
+__device__ __forceinline__ u64 free_cells(const Ctx &cx, int hc, int margin)
+{
+    const int S = cx.S, C = cx.C, lane = cx.lane;
+    u64 headbits = 0;
+    for (int s = 0; s < cx.K; ++s) {
+        int h = __shfl(hc, s, WAVE);
+        if (h >= 0 && (h & 63) == lane) headbits |= 1ull << (h >> 6);
+    }
+    u64 fr = 0;
+    for (int k = 0; k < cx.cpl; ++k) {
+        int c = lane + 64 * k;
+        if (c >= C) continue;
+        int y = div_size(c, cx.rcpS), x = c - y * S;
+        if (y < margin || x < margin || y > S - 1 - margin || x > S - 1 - margin) continue;
+        if (cx.food[c] || ((headbits >> k) & 1)) continue;
+        bool occ = false;
+        for (int s = 0; s < cx.K; ++s) occ |= BV(cx, s, c) > 0;
+        if (!occ) fr |= 1ull << k;
+    }
+    return fr;
+}
+
+// the K-th set bit over all lanes' `bits` in row-major cell order (cell = lane + 64k): returns true in the
+// lane/bit that owns it through `hit_k` (>= 0), -1 elsewhere
+__device__ __forceinline__ int rank_select(const Ctx &cx, u64 bits, int K_rank)
+{
+    int base = 0, hit = -1;
+    for (int k = 0; k < cx.cpl; ++k) {
+        bool b = (bits >> k) & 1;
+        u64 m = ballot(b);
+        if (b && base + rank_below(m) == K_rank) hit = k;
+        base += popc64(m);
+    }
+    return hit;
+}
+
+// wave-uniform cell index of the (single) lane/bit chosen by rank_select, -1 if none
+__device__ __forceinline__ int selected_cell(int k)
+{
+    u64 m = ballot(k >= 0);
+    if (!m) return -1;
+    int owner = first_bit(m);
+    return owner + 64 * __shfl(k, owner, WAVE);
+}
+
+__device__ __forceinline__ int count_bits(const Ctx &cx, u64 bits)
+{
+    int n = 0;
+    for (int k = 0; k < cx.cpl; ++k) n += popc64(ballot((bits >> k) & 1));
+    return n;
+}
+
+// ------------------------------------------------------------------------------------------------ observations
+
+// 'full' observation (_observe_agent :268-281 + _make_generic_rgb :175-192) of every agent from LDS
+__device__ __forceinline__ void observe_full(const Ctx &cx, const MultiArgs &p, long long env, int hc)
+{
+    const int S = cx.S, C = cx.C, K = cx.K, lane = cx.lane;
+    // head owner per cell: occ[c] = 1 + snake index (consistent states have at most one head per cell)
+    for (int k = 0; k < cx.cpl; ++k) {
+        int c = lane + 64 * k;
+        if (c < C) cx.occ[c] = 0;
+    }
+    wave_lds_sync();
+    if (lane < K && hc >= 0) cx.occ[hc] = (unsigned char)(lane + 1);
+    wave_lds_sync();
+    const float G1 = 192.0f / 255.0f, G2 = 96.0f / 255.0f;
+    for (int k = 0; k < cx.cpl; ++k) {
+        int c = lane + 64 * k;
+        if (c >= C) continue;
+        int y = div_size(c, cx.rcpS), x = c - y * S;
+        bool edge = y == 0 || x == 0 || y == S - 1 || x == S - 1;
+        u64 bm = 0;
+        for (int s = 0; s < K; ++s) bm |= (u64)(BV(cx, s, c) > 0) << s;
+        int ho = (int)cx.occ[c] - 1;
+        bool fd = cx.food[c] != 0;
+        for (int a = 0; a < K; ++a) {
+            float r, g, b;
+            if (edge) { r = g = b = 0.0f; }
+            else if (ho >= 0 && ho != a) { r = 0.0f; g = 0.0f; b = G1; }            // other head (0,0,192)
+            else if (bm & ~(1ull << a)) { r = 0.0f; g = 0.0f; b = G2; }             // other body (0,0,96)
+            else if (ho == a) { r = 0.0f; g = G1; b = 0.0f; }                       // own head (0,192,0)
+            else if ((bm >> a) & 1) { r = 0.0f; g = G2; b = 0.0f; }                 // own body (0,96,0)
+            else if (fd) { r = 1.0f; g = 0.0f; b = 0.0f; }                          // food (255,0,0)
+            else { r = g = b = 1.0f; }
+            float *o = p.obs + ((long long)a * p.N + env) * p.obs_elems;
+            o[c] = r;
+            o[C + c] = g;
+            o[2 * C + c] = b;
+        }
+    }
+    wave_lds_sync();
+}
+
+// 'partial_n' observation (:289-332): env image (_get_env_images :194-227) into LDS, then one crop per agent
+__device__ __forceinline__ void observe_partial(const Ctx &cx, const MultiArgs &p, long long env, int hc, bool done,
+                                                bool boosted)
+{
+    const int S = cx.S, C = cx.C, K = cx.K, lane = cx.lane, n = p.obs_n;
+    if (lane < K) {
+        const short *col = p.colours + (env * K + lane) * 3;
+        cx.colf[lane * 4 + 0] = (float)col[0];
+        cx.colf[lane * 4 + 1] = (float)col[1];
+        cx.colf[lane * 4 + 2] = (float)col[2];
+        cx.colf[lane * 4 + 3] = 1.0f + 0.5f * (boosted ? 1.0f : 0.0f); // :198
+        cx.hcell[lane] = hc;
+    }
+    wave_lds_sync();
+    for (int k = 0; k < cx.cpl; ++k) {
+        int c = lane + 64 * k;
+        if (c >= C) continue;
+        int y = div_size(c, cx.rcpS), x = c - y * S;
+        float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;
+        for (int s = 0; s < K; ++s) {
+            float bf = BV(cx, s, c) > 0 ? 1.0f : 0.0f, hf = cx.hcell[s] == c ? 1.0f : 0.0f;
+            float inten = bf * 1.0f / 3.0f + hf * 1.0f / 3.0f; // :197
+            inten *= cx.colf[s * 4 + 3];
+            a0 += inten * cx.colf[s * 4 + 0]; // :201-205
+            a1 += inten * cx.colf[s * 4 + 1];
+            a2 += inten * cx.colf[s * 4 + 2];
+        }
+        int r = (int)a0, g = (int)a1, b = (int)a2; // :206 .short() truncates
+        if (cx.food[c]) r += 255;                   // :208-209
+        if (r == 0 && g == 0 && b == 0) r = g = b = 255; // :214-219
+        if (y == 0 || x == 0 || y == S - 1 || x == S - 1) r = g = b = 0; // :225
+        cx.img[c] = (short)r;
+        cx.img[C + c] = (short)g;
+        cx.img[2 * C + c] = (short)b;
+    }
+    wave_lds_sync();
+    const int W = 2 * n + 1, W2 = W * W, E = 3 * W2;
+    const float rcpW2 = 1.0f / (float)W2, rcpW = 1.0f / (float)W;
+    for (int a = 0; a < K; ++a) {
+        const int h = __shfl(hc, a, WAVE);
+        const bool dead = __shfl((int)done, a, WAVE) != 0;
+        const int hy = h >= 0 ? div_size(h, cx.rcpS) : 0, hx = h - hy * S;
+        float *o = p.obs + ((long long)a * p.N + env) * p.obs_elems;
+        for (int el = lane; el < E; el += 64) {
+            int ch = div_size(el, rcpW2), w = el - ch * W2;
+            int wy = div_size(w, rcpW), wx = w - wy * W;
+            int y = hy - n + wy, x = hx - n + wx;
+            float v = 0.0f; // dead snakes (:320-323) and the zero padding (:302)
+            if (!dead && h >= 0 && y >= 0 && y < S && x >= 0 && x < S) v = (float)cx.img[ch * C + y * S + x] / 255.0f;
+            o[el] = v;
+        }
+    }
+    wave_lds_sync();
+}
+
+__device__ __forceinline__ void observe(const Ctx &cx, const MultiArgs &p, long long env, int hc, bool done,
+                                        bool boosted)
+{
+    if (p.obs_mode == WURM_OBS_DEFAULT) observe_full(cx, p, env, hc);
+    else if (p.obs_mode == WURM_OBS_PARTIAL) observe_partial(cx, p, env, hc, done, boosted);
+}
+
+// ------------------------------------------------------------------------------------------------ step kernel
+
+__global__ __launch_bounds__(256) void multi_step_kernel(MultiArgs p)
+{
+    const int wave = (int)(threadIdx.x >> 6), wpb = (int)(blockDim.x >> 6);
+    const long long env = (long long)blockIdx.x * wpb + wave;
+    if (env >= p.N) return;
+    const Ctx cx = make_ctx(p, wave);
+    const int C = cx.C, K = cx.K, lane = cx.lane;
+    const bool snake = lane < K;
+    const u64 env_id = (u64)(p.env_offset + env);
+    float *foodp = p.foods + env * C, *headp = p.heads + env * K * C, *bodyp = p.bodies + env * K * C;
+
+    const u64 fbits0 = load_env(cx, foodp, headp, bodyp);
+    int hc = snake ? cx.hcell[lane] : -1, L = snake ? cx.lmax[lane] : 0;
+    const int hc0 = hc;
+    bool has_body = L > 0;
+    const long long agent = env * K + lane;
+
+    // prologue (:475-502)
+    bool done = snake ? p.dones[agent] != 0 : true;
+    const bool done0 = done;
+    long long a = snake ? p.actions[(long long)lane * p.N + env] : 0;
+    long long orient = snake ? p.orientations[agent] : 0;
+    long long d = a % 4;                        // :483
+    const bool boost_act = a > 3;               // :484
+    if (orient == d) d = (d + 2) % 4;           // :493 sanitize_movements
+    orient = (d + 2) % 4;                       // :494
+    const int dir = (int)(((d % 4) + 4) % 4);
+    const bool boosted = snake && boost_act && L >= 4; // :497-499
+    float reward = 0.0f, foodcons = 0.0f;
+    bool snakecol = false, edgecol = false;
+
+    if (p.cfg.boost && ballot(boosted) != 0) {  // :503 (per env; the batch-global gate has no per-env effect)
+        run_phase(cx, boosted, dir, hc, L, done, reward, foodcons, snakecol, edgecol);
+        if (p.cfg.food_on_death)                // :565-576
+            food_from_death(cx, done, has_body, p.has_inj ? p.inj.death_a + env * C : nullptr, p.cfg.death_threshold,
+                            p.seed, p.call, env_id, RNG_DEATH_FOOD_A);
+        // boost cost (:579-592): tail cell becomes food, body decays, reward -1
+        bool pay = false;
+        if (boosted) {
+            if (p.has_inj) pay = p.inj.cost[agent] != 0;
+            else pay = u01(rng_words(p.seed, p.call, env_id, RNG_BOOST_COST, (u32)lane).w[0]) < p.cfg.boost_cost_prob;
+        }
+        u64 m = ballot(pay);
+        while (m) {
+            int s = first_bit(m);
+            m &= m - 1;
+            unsigned short *b = cx.body + s * C;
+            for (int k = 0; k < cx.cpl; ++k) {
+                int c = lane + 64 * k;
+                if (c < C) {
+                    int v = b[c] & VMASK;
+                    if (v == 1) cx.food[c] = 1;
+                    if (v > 0) b[c] = (unsigned short)((v - 1) | DIRTY);
+                }
+            }
+        }
+        if (pay) {
+            reward -= 1.0f;
+            L -= 1;
+        }
+        wave_lds_sync();
+        delete_done(cx, done, has_body, hc);    // :595-596
+    }
+
+    run_phase(cx, snake, dir, hc, L, done, reward, foodcons, snakecol, edgecol); // :613-660
+    if (p.cfg.food_on_death)                    // :662-673
+        food_from_death(cx, done, has_body, p.has_inj ? p.inj.death_b + env * C : nullptr, p.cfg.death_threshold,
+                        p.seed, p.call, env_id, RNG_DEATH_FOOD_B);
+    delete_done(cx, done, has_body, hc);        // :676-677
+
+    // _add_food (:368-410)
+    {
+        u64 fb = 0;
+        for (int k = 0; k < cx.cpl; ++k) {
+            int c = lane + 64 * k;
+            if (c < C && cx.food[c]) fb |= 1ull << k;
+        }
+        const int nfood = count_bits(cx, fb);
+        if (p.cfg.food_mode == 0) {
+            if (nfood == 0) {                   // :371-379
+                if (p.has_inj) {
+                    int cell = p.inj.food_cell[env];
+                    if (cell >= 0 && cell < C && lane == 0) cx.food[cell] = 1;
+                } else {
+                    u64 fr = free_cells(cx, hc, 1);
+                    int nf = count_bits(cx, fr);
+                    if (nf > 0) {
+                        int Kr = (int)mulhi_range(rng_words(p.seed, p.call, env_id, RNG_FOOD, 0).w[0], (u32)nf);
+                        int k = rank_select(cx, fr, Kr);
+                        if (k >= 0) cx.food[lane + 64 * k] = 1;
+                    }
+                }
+            }
+        } else if (nfood < p.cfg.max_food) {    // :382-408
+            u64 fr = free_cells(cx, hc, 1);
+            for (int k = 0; k < cx.cpl; ++k) {
+                if (!((fr >> k) & 1)) continue;
+                int c = lane + 64 * k;
+                bool hit = p.has_inj ? p.inj.rate[env * C + c] != 0
+                                     : cell_u01(p.seed, p.call, env_id, RNG_RATE_FOOD, (u32)c) < p.cfg.food_rate;
+                if (hit) cx.food[c] = 1;
+            }
+        }
+        wave_lds_sync();
+    }
+
+    if (snake && done && !done0) reward += p.cfg.reward_on_death; // :683-685
+
+    // outputs (:701-729)
+    if (snake) {
+        p.dones[agent] = (uint8_t)done;
+        p.orientations[agent] = orient;
+        p.boost[agent] = (uint8_t)boosted;
+        p.rewards[agent] = reward;
+        p.snakecol[agent] = (uint8_t)snakecol;
+        p.edgecol[agent] = (uint8_t)edgecol;
+        p.foodcons[agent] = foodcons;
+        p.sizes[agent] = (float)L;
+    }
+    const bool alld = ballot(snake && !done) == 0; // :703
+    if (lane == 0) p.all_done[env] = (uint8_t)alld;
+
+    if (snake) cx.hcell[lane] = hc;
+    wave_lds_sync();
+    store_env(cx, foodp, headp, bodyp, fbits0, hc0, hc, false);
+    if (p.obs_mode != WURM_OBS_NONE) observe(cx, p, env, hc, done, boosted);
+}
+
+// ------------------------------------------------------------------------------------------------ reset kernel
+
+// availability of _add_snake (:927-941) / _get_snake_addition (:848-858): the 3x3 neighbourhood is empty and the
+// cell is at least 2 from the border.  occ[] holds the occupancy (food, heads, bodies).
+__device__ __forceinline__ u64 spawn_cells(const Ctx &cx)
+{
+    const int S = cx.S, C = cx.C, lane = cx.lane;
+    u64 av = 0;
+    for (int k = 0; k < cx.cpl; ++k) {
+        int c = lane + 64 * k;
+        if (c >= C) continue;
+        int y = div_size(c, cx.rcpS), x = c - y * S;
+        if (y < 2 || x < 2 || y > S - 3 || x > S - 3) continue;
+        int any = 0;
+        for (int dy = -1; dy <= 1; ++dy)
+            for (int dx = -1; dx <= 1; ++dx) any |= cx.occ[c + dy * S + dx];
+        if (!any) av |= 1ull << k;
+    }
+    return av;
+}
+
+// occupancy of the env currently in LDS
+__device__ __forceinline__ void build_occ(const Ctx &cx, int hc)
+{
+    const int C = cx.C, lane = cx.lane;
+    for (int k = 0; k < cx.cpl; ++k) {
+        int c = lane + 64 * k;
+        if (c >= C) continue;
+        bool o = cx.food[c] != 0;
+        for (int s = 0; s < cx.K; ++s) o |= BV(cx, s, c) > 0;
+        cx.occ[c] = (unsigned char)o;
+    }
+    wave_lds_sync();
+    if (lane < cx.K && hc >= 0) cx.occ[hc] = 1;
+    wave_lds_sync();
+}
+
+// writes a 3-segment snake `s` at `cell` heading `d` into LDS (body, occ); cell < 0: nothing
+__device__ __forceinline__ int place_snake(const Ctx &cx, int s, int cell, int d)
+{
+    const int S = cx.S, C = cx.C;
+    if (cell < 0) return -1;
+    int sy = div_size(cell, cx.rcpS), sx = cell - sy * S;
+    int hcell = (sy + tap_y(d)) * S + sx + tap_x(d), tcell = (sy - tap_y(d)) * S + sx - tap_x(d);
+    if (cx.lane == 0) { // LENGTH_3_SNAKES (:965-973): 3 at seed + TAP[d], 2 at the seed, 1 at seed - TAP[d]
+        cx.body[s * C + hcell] = (unsigned short)(3 | DIRTY);
+        cx.body[s * C + cell] = (unsigned short)(2 | DIRTY);
+        cx.body[s * C + tcell] = (unsigned short)(1 | DIRTY);
+        cx.occ[hcell] = 1;
+        cx.occ[cell] = 1;
+        cx.occ[tcell] = 1;
+    }
+    wave_lds_sync();
+    return hcell;
+}
+
+__device__ __forceinline__ void colour_from_words(const Words &w, short out[3])
+{
+    // get_n_colours (:163-169): rand(3); red / 1.5; normalise; * 192; .short()
+    float c0 = __fdiv_rn(u01(w.w[0]), 1.5f), c1 = u01(w.w[1]), c2 = u01(w.w[2]);
+    float norm = __fsqrt_rn(c0 * c0 + c1 * c1 + c2 * c2);
+    out[0] = (short)(__fdiv_rn(c0, norm) * 192.0f);
+    out[1] = (short)(__fdiv_rn(c1, norm) * 192.0f);
+    out[2] = (short)(__fdiv_rn(c2, norm) * 192.0f);
+}
+
+__global__ __launch_bounds__(256) void multi_reset_kernel(MultiArgs p)
+{
+    const int wave = (int)(threadIdx.x >> 6), wpb = (int)(blockDim.x >> 6);
+    const long long env = (long long)blockIdx.x * wpb + wave;
+    if (env >= p.N) return;
+    const Ctx cx = make_ctx(p, wave);
+    const int C = cx.C, K = cx.K, lane = cx.lane;
+    const bool snake = lane < K;
+    const u64 env_id = (u64)(p.env_offset + env);
+    const long long agent = env * K + lane;
+    float *foodp = p.foods + env * C, *headp = p.heads + env * K * C, *bodyp = p.bodies + env * K * C;
+
+    const bool rebuild = uniform((int)p.done_env[env]) != 0;
+    bool done = snake ? p.dones[agent] != 0 : false;
+    if (rebuild) done = false; // :798
+    const bool any_dead = ballot(snake && done) != 0;
+    const bool respawn = p.cfg.respawn_any && any_dead;
+    const bool want_obs = p.obs_mode != WURM_OBS_NONE;
+
+    // colours of snakes that are still dead are re-rolled on every reset (:800-803)
+    if (p.cfg.colour_random && snake && done) {
+        short col[3];
+        if (p.has_rinj) {
+            col[0] = p.rinj.colours[agent * 3];
+            col[1] = p.rinj.colours[agent * 3 + 1];
+            col[2] = p.rinj.colours[agent * 3 + 2];
+        } else {
+            colour_from_words(rng_words(p.seed, p.call, env_id, RNG_COLOUR, (u32)lane), col);
+        }
+        p.colours[agent * 3] = col[0];
+        p.colours[agent * 3 + 1] = col[1];
+        p.colours[agent * 3 + 2] = col[2];
+    }
+    if (!rebuild && !respawn && !want_obs) return;
+
+    int hc = -1, hc0 = -1;
+    u64 fbits0 = 0;
+    long long orient = 0;
+    bool orient_dirty = false;
+    if (rebuild) { // _create_envs (:996-1019)
+        for (int i = lane; i < K * C; i += 64) cx.body[i] = 0;
+        for (int k = 0; k < cx.cpl; ++k) {
+            int c = lane + 64 * k;
+            if (c < C) { cx.food[c] = 0; cx.occ[c] = 0; }
+        }
+        wave_lds_sync();
+        for (int s = 0; s < K; ++s) { // _add_snake (:911-994), one snake after another
+            int cell = -1, dnew = 0;
+            if (p.has_rinj) {
+                cell = p.rinj.create[(env * K + s) * 2];
+                dnew = p.rinj.create[(env * K + s) * 2 + 1];
+            } else {
+                Words w = rng_words(p.seed, p.call, env_id, RNG_SPAWN, (u32)s);
+                dnew = (int)(w.w[1] >> 30);
+                u64 av = spawn_cells(cx);
+                int n = count_bits(cx, av);
+                if (n > 0) cell = selected_cell(rank_select(cx, av, (int)mulhi_range(w.w[0], (u32)n)));
+            }
+            cell = uniform(cell);
+            if (cell < 0 && p.status && lane == 0) atomicAdd(p.status, 1); // the reference raises (:946-947)
+            int h = place_snake(cx, s, cell, dnew);
+            if (lane == s) {
+                hc = h;
+                orient = dnew;
+                orient_dirty = true;
+            }
+        }
+        { // food (:1016-1017)
+            if (p.has_rinj) {
+                int cell = p.rinj.create_food[env];
+                if (cell >= 0 && cell < C && lane == 0) cx.food[cell] = 1;
+            } else {
+                u64 fr = free_cells(cx, hc, 1);
+                int nf = count_bits(cx, fr);
+                if (nf > 0) {
+                    int k = rank_select(cx, fr, (int)mulhi_range(rng_words(p.seed, p.call, env_id, RNG_RESET, 0).w[3], (u32)nf));
+                    if (k >= 0) cx.food[lane + 64 * k] = 1;
+                }
+            }
+            wave_lds_sync();
+        }
+    } else {
+        fbits0 = load_env(cx, foodp, headp, bodyp);
+        hc = snake ? cx.hcell[lane] : -1;
+        hc0 = hc;
+    }
+
+    if (respawn) { // :805-831 the first dead snake of the env respawns if there is room
+        const int f = first_bit(ballot(snake && done));
+        build_occ(cx, hc);
+        int cell = -1, dnew = 0;
+        if (p.has_rinj) {
+            cell = p.rinj.respawn[env * 2];
+            dnew = p.rinj.respawn[env * 2 + 1];
+        } else {
+            Words w = rng_words(p.seed, p.call, env_id, RNG_SPAWN, (u32)K);
+            dnew = (int)(w.w[1] >> 30);
+            u64 av = spawn_cells(cx);
+            int n = count_bits(cx, av);
+            if (n > 0) cell = selected_cell(rank_select(cx, av, (int)mulhi_range(w.w[0], (u32)n)));
+        }
+        cell = uniform(cell);
+        // bodies[first] = new_bodies (:826): the dead snake's grid is replaced (it is all-zero in consistent states)
+        for (int k = 0; k < cx.cpl; ++k) {
+            int c = lane + 64 * k;
+            if (c < C && (cx.body[f * C + c] & VMASK)) cx.body[f * C + c] = DIRTY;
+        }
+        wave_lds_sync();
+        int h = place_snake(cx, f, cell, dnew);
+        if (lane == f) {
+            hc = h;
+            orient = dnew;        // :828 assigned whether or not the snake found room
+            orient_dirty = true;
+            done = cell < 0;      // :829
+        }
+    }
+
+    if (snake) {
+        if (rebuild || respawn) p.dones[agent] = (uint8_t)done;
+        if (orient_dirty) p.orientations[agent] = orient;
+        cx.hcell[lane] = hc;
+    }
+    wave_lds_sync();
+    if (rebuild) store_env(cx, foodp, headp, bodyp, 0, -1, hc, true);
+    else if (respawn) store_env(cx, foodp, headp, bodyp, fbits0, hc0, hc, false);
+    if (want_obs) {
+        const bool boosted = snake ? p.boost[agent] != 0 : false;
+        observe(cx, p, env, hc, done, boosted);
+    }
+}
+
+__global__ __launch_bounds__(256) void multi_observe_kernel(MultiArgs p)
+{
+    const int wave = (int)(threadIdx.x >> 6), wpb = (int)(blockDim.x >> 6);
+    const long long env = (long long)blockIdx.x * wpb + wave;
+    if (env >= p.N) return;
+    const Ctx cx = make_ctx(p, wave);
+    const int C = cx.C, K = cx.K, lane = cx.lane;
+    load_env(cx, p.foods + env * C, p.heads + env * K * C, p.bodies + env * K * C);
+    const bool snake = lane < K;
+    int hc = snake ? cx.hcell[lane] : -1;
+    bool done = snake ? p.dones[env * K + lane] != 0 : false;
+    bool boosted = snake ? p.boost[env * K + lane] != 0 : false;
+    observe(cx, p, env, hc, done, boosted);
+}
+
+// check_consistency (:733-769) -> per-env bitmask
+__global__ __launch_bounds__(256) void multi_check_kernel(MultiArgs p)
+{
+    const int wave = (int)(threadIdx.x >> 6), wpb = (int)(blockDim.x >> 6);
+    const long long env = (long long)blockIdx.x * wpb + wave;
+    if (env >= p.N) return;
+    const int S = p.S, C = S * S, K = p.K, lane = (int)(threadIdx.x & 63u), cpl = (C + 63) >> 6;
+    const float *foodp = p.foods + env * C;
+    uint32_t m = 0;
+    for (int s = 0; s < K; ++s) {
+        const float *hp = p.heads + (env * K + s) * C, *bp = p.bodies + (env * K + s) * C;
+        const bool dead = p.dones[env * K + s] != 0;
+        int badf = 0, hs = 0, bs = 0, bm = 0, hb = 0, hf = 0, nz = 0;
+        for (int k = 0; k < cpl; ++k) {
+            int c = lane + 64 * k;
+            if (c < C) {
+                float f = foodp[c], h = hp[c], b = bp[c];
+                int fi = __float2int_rn(f), hi = __float2int_rn(h), bi = __float2int_rn(b);
+                badf |= !(f == 0.0f || f == 1.0f);
+                hs += hi; bs += bi; hb += hi * bi; hf += hi * fi;
+                bm = max(bm, bi);
+                nz |= (h != 0.0f) || (b != 0.0f);
+            }
+        }
+        if (dead) {
+            if (ballot(nz != 0)) m |= WURM_MCHK_DEAD_NONZERO;
+            continue;
+        }
+        if (ballot(badf != 0)) m |= WURM_CHK_FOOD_VALUE;
+        hs = wave_sum_i32(hs); bs = wave_sum_i32(bs); hb = wave_sum_i32(hb); hf = wave_sum_i32(hf);
+        bm = wave_max_i32(bm);
+        if (hs != 1) m |= WURM_CHK_ONE_HEAD;
+        if (!(bs > 0)) m |= WURM_CHK_HAS_SNAKE;
+        if (bm != hb) m |= WURM_CHK_HEAD_AT_END;
+        if (2 * bs != bm * (bm + 1)) m |= WURM_CHK_BODY_RANGE;
+        if (!(bs >= 6)) m |= WURM_CHK_MIN_LENGTH;
+        if (hf != 0) m |= WURM_CHK_HEAD_ON_FOOD;
+    }
+    int over = 0;
+    for (int k = 0; k < cpl; ++k) {
+        int c = lane + 64 * k;
+        if (c < C) {
+            int cnt = 0;
+            for (int s = 0; s < K; ++s) cnt += p.bodies[(env * K + s) * C + c] > 1e-6f;
+            over |= cnt > 1;
+        }
+    }
+    if (ballot(over != 0)) m |= WURM_MCHK_OVERLAP;
+    if (lane == 0) p.err[env] = m;
+}
+
+__global__ void multi_colours_kernel(short *colours, long long N, int K, int fixed, u64 seed, u64 call, long long env_offset)
+{
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * K) return;
+    long long env = i / K;
+    int s = (int)(i - env * K);
+    u64 env_id = fixed ? 0xffffffffull : (u64)(env_offset + env);
+    short col[3];
+    colour_from_words(rng_words(seed, call, env_id, RNG_COLOUR, (u32)s), col);
+    colours[i * 3] = col[0];
+    colours[i * 3 + 1] = col[1];
+    colours[i * 3 + 2] = col[2];
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+
+static int multi_layout(MultiArgs &p, bool need_img)
+{
+    const int C = p.S * p.S, K = p.K;
+    int off = 8 * K;                       // hcell, lmax
+    p.off_col = off; off += 16 * K;        // colf
+    off = (off + 15) & ~15;
+    p.off_body = off; off += 2 * K * C;
+    off = (off + 15) & ~15;
+    p.off_food = off; off += C;
+    off = (off + 15) & ~15;
+    p.off_occ = off; off += C;
+    off = (off + 15) & ~15;
+    p.off_img = off; if (need_img) off += 6 * C;
+    p.lds_per_wave = (off + 15) & ~15;
+    return p.lds_per_wave;
+}
+
+enum MKind { MK_STEP, MK_RESET, MK_OBSERVE, MK_CHECK };
+
+static int multi_launch(MKind kind, MultiArgs &p, void *stream)
+{
+    if (p.N == 0) return WURM_OK;
+    const int lds = multi_layout(p, p.obs_mode == WURM_OBS_PARTIAL);
+    if (lds > 65536) return WURM_ERR_UNSUPPORTED;
+    int wpb = p.N <= 4096 ? 1 : 4;
+    while (wpb > 1 && lds * wpb > 65536) wpb >>= 1;
+    dim3 block(64 * wpb), grid((unsigned)((p.N + wpb - 1) / wpb));
+    size_t shmem = kind == MK_CHECK ? 0 : (size_t)lds * wpb;
+    hipStream_t st = (hipStream_t)stream;
+    (void)hipGetLastError();
+    switch (kind) {
+    case MK_STEP: hipLaunchKernelGGL(multi_step_kernel, grid, block, shmem, st, p); break;
+    case MK_RESET: hipLaunchKernelGGL(multi_reset_kernel, grid, block, shmem, st, p); break;
+    case MK_OBSERVE: hipLaunchKernelGGL(multi_observe_kernel, grid, block, shmem, st, p); break;
+    case MK_CHECK: hipLaunchKernelGGL(multi_check_kernel, grid, block, shmem, st, p); break;
+    }
+    return hipGetLastError() == hipSuccess ? WURM_OK : WURM_ERR_HIP;
+}
+
+static long long multi_obs_elems(int mode, int n, int S)
+{
+    if (mode == WURM_OBS_DEFAULT) return 3ll * S * S;
+    if (mode == WURM_OBS_PARTIAL && n >= 0) return 3ll * (2 * n + 1) * (2 * n + 1);
+    return 0;
+}
+
+static int multi_check_args(long long N, int K, int S, int mode, int n, const void *obs)
+{
+    if (N < 0 || K < 1 || S < 3) return WURM_ERR_INVALID_ARG;
+    if (K > 64 || S > 64) return WURM_ERR_UNSUPPORTED;
+    if (mode != WURM_OBS_NONE) {
+        if (multi_obs_elems(mode, n, S) == 0) return WURM_ERR_INVALID_ARG;
+        if (N > 0 && obs == nullptr) return WURM_ERR_INVALID_ARG;
+    }
+    return WURM_OK;
+}
+
+} // namespace wurm
+
+using namespace wurm;
+
+extern "C" {
+
+int64_t wurm_multi_obs_elems(int obs_mode, int obs_n, int size) { return multi_obs_elems(obs_mode, obs_n, size); }
+
+int wurm_multi_step(float *foods, float *heads, float *bodies, uint8_t *dones, int64_t *orientations,
+                    const int64_t *actions, uint8_t *boost_this_step, float *rewards, uint8_t *snake_collision,
+                    uint8_t *edge_collision, float *food_consumed, float *sizes, uint8_t *all_done,
+                    const int16_t *colours, float *obs, int obs_mode, int obs_n, int64_t num_envs, int num_snakes,
+                    int size, const wurm_multi_config *cfg, uint64_t seed, uint64_t call, int64_t env_offset,
+                    const wurm_multi_inject *inject, void *stream)
+{
+    int rc = multi_check_args(num_envs, num_snakes, size, obs_mode, obs_n, obs);
+    if (rc) return rc;
+    if (!cfg) return WURM_ERR_INVALID_ARG;
+    if (num_envs > 0 && (!foods || !heads || !bodies || !dones || !orientations || !actions || !boost_this_step ||
+                         !rewards || !snake_collision || !edge_collision || !food_consumed || !sizes || !all_done))
+        return WURM_ERR_INVALID_ARG;
+    if (obs_mode == WURM_OBS_PARTIAL && num_envs > 0 && !colours) return WURM_ERR_INVALID_ARG;
+    MultiArgs p = {};
+    p.foods = foods; p.heads = heads; p.bodies = bodies; p.dones = dones; p.orientations = (long long *)orientations;
+    p.actions = (const long long *)actions; p.boost = boost_this_step; p.rewards = rewards; p.snakecol = snake_collision;
+    p.edgecol = edge_collision; p.foodcons = food_consumed; p.sizes = sizes; p.all_done = all_done;
+    p.colours = const_cast<short *>(colours); p.obs = obs; p.obs_mode = obs_mode; p.obs_n = obs_n;
+    p.obs_elems = multi_obs_elems(obs_mode, obs_n, size); p.N = num_envs; p.K = num_snakes; p.S = size; p.cfg = *cfg;
+    p.seed = seed; p.call = call; p.env_offset = env_offset;
+    if (inject) { p.inj = *inject; p.has_inj = 1; }
+    return multi_launch(MK_STEP, p, stream);
+}
+
+int wurm_multi_reset(float *foods, float *heads, float *bodies, uint8_t *dones, int64_t *orientations,
+                     int16_t *colours, const uint8_t *done_env, int32_t *status, const uint8_t *boost_this_step,
+                     float *obs, int obs_mode, int obs_n, int64_t num_envs, int num_snakes, int size,
+                     const wurm_multi_config *cfg, uint64_t seed, uint64_t call, int64_t env_offset,
+                     const wurm_multi_reset_inject *inject, void *stream)
+{
+    int rc = multi_check_args(num_envs, num_snakes, size, obs_mode, obs_n, obs);
+    if (rc) return rc;
+    if (!cfg) return WURM_ERR_INVALID_ARG;
+    if (size < 7) return WURM_ERR_UNSUPPORTED; // no cell is >= 2 from the border with a free 3x3 neighbourhood
+    if (num_envs > 0 && (!foods || !heads || !bodies || !dones || !orientations || !done_env || !colours))
+        return WURM_ERR_INVALID_ARG;
+    if (obs_mode != WURM_OBS_NONE && num_envs > 0 && !boost_this_step) return WURM_ERR_INVALID_ARG;
+    MultiArgs p = {};
+    p.foods = foods; p.heads = heads; p.bodies = bodies; p.dones = dones; p.orientations = (long long *)orientations;
+    p.colours = colours; p.done_env = done_env; p.status = status; p.boost = const_cast<uint8_t *>(boost_this_step);
+    p.obs = obs; p.obs_mode = obs_mode; p.obs_n = obs_n; p.obs_elems = multi_obs_elems(obs_mode, obs_n, size);
+    p.N = num_envs; p.K = num_snakes; p.S = size; p.cfg = *cfg; p.seed = seed; p.call = call; p.env_offset = env_offset;
+    if (inject) { p.rinj = *inject; p.has_rinj = 1; }
+    return multi_launch(MK_RESET, p, stream);
+}
+
+int wurm_multi_observe(const float *foods, const float *heads, const float *bodies, const uint8_t *dones,
+                       const uint8_t *boost_this_step, const int16_t *colours, float *obs, int obs_mode, int obs_n,
+                       int64_t num_envs, int num_snakes, int size, void *stream)
+{
+    if (obs_mode == WURM_OBS_NONE) return WURM_ERR_INVALID_ARG;
+    int rc = multi_check_args(num_envs, num_snakes, size, obs_mode, obs_n, obs);
+    if (rc) return rc;
+    if (num_envs > 0 && (!foods || !heads || !bodies || !dones || !boost_this_step)) return WURM_ERR_INVALID_ARG;
+    if (obs_mode == WURM_OBS_PARTIAL && num_envs > 0 && !colours) return WURM_ERR_INVALID_ARG;
+    MultiArgs p = {};
+    p.foods = const_cast<float *>(foods); p.heads = const_cast<float *>(heads); p.bodies = const_cast<float *>(bodies);
+    p.dones = const_cast<uint8_t *>(dones); p.boost = const_cast<uint8_t *>(boost_this_step);
+    p.colours = const_cast<short *>(colours); p.obs = obs; p.obs_mode = obs_mode; p.obs_n = obs_n;
+    p.obs_elems = multi_obs_elems(obs_mode, obs_n, size); p.N = num_envs; p.K = num_snakes; p.S = size;
+    return multi_launch(MK_OBSERVE, p, stream);
+}
+
+int wurm_multi_check(const float *foods, const float *heads, const float *bodies, const uint8_t *dones, uint32_t *err,
+                     int64_t num_envs, int num_snakes, int size, void *stream)
+{
+    int rc = multi_check_args(num_envs, num_snakes, size, WURM_OBS_NONE, 0, nullptr);
+    if (rc) return rc;
+    if (num_envs > 0 && (!foods || !heads || !bodies || !dones || !err)) return WURM_ERR_INVALID_ARG;
+    MultiArgs p = {};
+    p.foods = const_cast<float *>(foods); p.heads = const_cast<float *>(heads); p.bodies = const_cast<float *>(bodies);
+    p.dones = const_cast<uint8_t *>(dones); p.err = err; p.obs_mode = WURM_OBS_NONE; p.N = num_envs; p.K = num_snakes;
+    p.S = size;
+    return multi_launch(MK_CHECK, p, stream);
+}
+
+int wurm_multi_colours(int16_t *colours, int64_t num_envs, int num_snakes, int fixed, uint64_t seed, uint64_t call,
+                       int64_t env_offset, void *stream)
+{
+    if (num_envs < 0 || num_snakes < 1) return WURM_ERR_INVALID_ARG;
+    if (num_envs == 0) return WURM_OK;
+    if (!colours) return WURM_ERR_INVALID_ARG;
+    long long n = (long long)num_envs * num_snakes;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(multi_colours_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       colours, (long long)num_envs, num_snakes, fixed, seed, call, (long long)env_offset);
+    return hipGetLastError() == hipSuccess ? WURM_OK : WURM_ERR_HIP;
+}
+
+} // extern "C"

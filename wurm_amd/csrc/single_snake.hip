@@ -148,6 +148,32 @@ __device__ __forceinline__ int slow_orientation(const Env<CPL> &e, const Geo &g,
     return uniform(o);
 }
 
+// determine_orientations (wurm/utils.py:36-65) of the env in registers.  Well-formed snake (exactly one cell == L
+// and one == L-1, L >= 2): the filter response is 2 only for the tap pointing from the neck to the head, so the
+// orientation follows from the two cells; anything else takes the exact stencil path.
+template <int CPL>
+__device__ __forceinline__ int orientation_of(const Env<CPL> &e, const Geo &g, int L, signed char *lds)
+{
+    int cntL = 0, cntN = 0, cellL = -1, cellN = -1;
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) {
+        bool v = (g.valid >> k) & 1;
+        u64 mL = ballot(v && e.body[k] == L);
+        u64 mN = ballot(v && e.body[k] == L - 1);
+        cntL += popc64(mL);
+        cntN += popc64(mN);
+        if (cellL < 0 && mL) cellL = 64 * k + first_bit(mL);
+        if (cellN < 0 && mN) cellN = 64 * k + first_bit(mN);
+    }
+    if (cntL == 1 && cntN == 1 && L >= 2) {
+        int yL = div_size(cellL, g.rcpS), xL = cellL - yL * g.S;
+        int yN = div_size(cellN, g.rcpS), xN = cellN - yN * g.S;
+        int dy = yL - yN, dx = xL - xN;
+        return (dy == 0 && dx == 1) ? 1 : (dy == 1 && dx == 0) ? 2 : (dy == 0 && dx == -1) ? 3 : 0;
+    }
+    return slow_orientation<CPL>(e, g, L, lds);
+}
+
 // ------------------------------------------------------------------------------------------------ food respawn
 
 // _get_food_addition (single_snake.py:306-320, simple_gridworld.py:209-223): +1 food on one uniformly random
@@ -214,27 +240,7 @@ __device__ __forceinline__ void step_core(Env<CPL> &e, const Geo &g, float *__re
         for (int k = 0; k < CPL; ++k) lm = max(lm, e.body[k]);
         L = uniform(wave_max_i32(lm)); // single_snake.py:210 snake_sizes
 
-        // determine_orientations (utils.py:36-65).  Well-formed snake: exactly one cell == L and one == L-1.
-        int cntL = 0, cntN = 0, cellL = -1, cellN = -1;
-#pragma unroll
-        for (int k = 0; k < CPL; ++k) {
-            bool v = (g.valid >> k) & 1;
-            u64 mL = ballot(v && e.body[k] == L);
-            u64 mN = ballot(v && e.body[k] == L - 1);
-            cntL += popc64(mL);
-            cntN += popc64(mN);
-            if (cellL < 0 && mL) cellL = 64 * k + first_bit(mL);
-            if (cellN < 0 && mN) cellN = 64 * k + first_bit(mN);
-        }
-        int o;
-        if (cntL == 1 && cntN == 1 && L >= 2) {
-            int yL = div_size(cellL, g.rcpS), xL = cellL - yL * S;
-            int yN = div_size(cellN, g.rcpS), xN = cellN - yN * S;
-            int dy = yL - yN, dx = xL - xN;
-            o = (dy == 0 && dx == 1) ? 1 : (dy == 1 && dx == 0) ? 2 : (dy == 0 && dx == -1) ? 3 : 0;
-        } else {
-            o = slow_orientation<CPL>(e, g, L, lds);
-        }
+        const int o = orientation_of<CPL>(e, g, L, lds); // utils.py:36-65
         if ((long long)o == a) a += 2; // single_snake.py:221-222 (written back in place by the caller)
         a = a % 4;                     // fmod_: sign follows the dividend
     }
@@ -638,6 +644,26 @@ __global__ __launch_bounds__(256) void check_kernel(const float *__restrict__ en
     if (g.lane == 0) err[env] = m;
 }
 
+// wurm.utils.determine_orientations over a (n,3,S,S) batch
+template <int CPL>
+__global__ __launch_bounds__(256) void orientations_kernel(const float *__restrict__ envs, long long *__restrict__ out,
+                                                           long long N, int S, int lds_per_wave)
+{
+    const int wave = (int)(threadIdx.x >> 6), wpb = (int)(blockDim.x >> 6);
+    const long long env = (long long)blockIdx.x * wpb + wave;
+    if (env >= N) return;
+    signed char *lds = wurm_lds + wave * lds_per_wave;
+    const Geo g = make_geo<CPL>(S);
+    Env<CPL> e;
+    load_state<CPL, true>(envs + env * 3 * g.C, g, e);
+    int lm = 0;
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) lm = max(lm, e.body[k]);
+    const int L = uniform(wave_max_i32(lm));
+    const int o = orientation_of<CPL>(e, g, L, lds);
+    if (g.lane == 0) out[env] = o;
+}
+
 // ------------------------------------------------------------------------------------------------ host side
 
 enum Kind { K_STEP, K_RESET, K_OBSERVE, K_ROLLOUT };
@@ -810,6 +836,33 @@ int wurm_single_check(const float *envs, uint32_t *err, int64_t num_envs, int si
     case 32: hipLaunchKernelGGL(check_kernel<32>, grid, block, 0, st, envs, err, N, size); break;
     case 48: hipLaunchKernelGGL(check_kernel<48>, grid, block, 0, st, envs, err, N, size); break;
     default: hipLaunchKernelGGL(check_kernel<64>, grid, block, 0, st, envs, err, N, size); break;
+    }
+    return hipGetLastError() == hipSuccess ? WURM_OK : WURM_ERR_HIP;
+}
+
+int wurm_orientations(const float *envs, int64_t *out, int64_t n, int size, void *stream)
+{
+    if (n < 0 || size < 3) return WURM_ERR_INVALID_ARG;
+    if (n == 0) return WURM_OK;
+    if (!envs || !out) return WURM_ERR_INVALID_ARG;
+    const int cpl = pick_cpl(size);
+    if (cpl < 0) return WURM_ERR_UNSUPPORTED;
+    const int wpb = 4, lpw = ((size * size + 15) / 16) * 16;
+    dim3 block(64 * wpb), grid((unsigned)((n + wpb - 1) / wpb));
+    hipStream_t st = (hipStream_t)stream;
+    long long N = n;
+    long long *o = (long long *)out;
+    size_t lds = (size_t)lpw * wpb;
+    (void)hipGetLastError();
+    switch (cpl) {
+    case 2: hipLaunchKernelGGL(orientations_kernel<2>, grid, block, lds, st, envs, o, N, size, lpw); break;
+    case 4: hipLaunchKernelGGL(orientations_kernel<4>, grid, block, lds, st, envs, o, N, size, lpw); break;
+    case 8: hipLaunchKernelGGL(orientations_kernel<8>, grid, block, lds, st, envs, o, N, size, lpw); break;
+    case 16: hipLaunchKernelGGL(orientations_kernel<16>, grid, block, lds, st, envs, o, N, size, lpw); break;
+    case 24: hipLaunchKernelGGL(orientations_kernel<24>, grid, block, lds, st, envs, o, N, size, lpw); break;
+    case 32: hipLaunchKernelGGL(orientations_kernel<32>, grid, block, lds, st, envs, o, N, size, lpw); break;
+    case 48: hipLaunchKernelGGL(orientations_kernel<48>, grid, block, lds, st, envs, o, N, size, lpw); break;
+    default: hipLaunchKernelGGL(orientations_kernel<64>, grid, block, lds, st, envs, o, N, size, lpw); break;
     }
     return hipGetLastError() == hipSuccess ? WURM_OK : WURM_ERR_HIP;
 }

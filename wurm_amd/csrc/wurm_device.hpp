@@ -54,10 +54,12 @@ __device__ __forceinline__ Words rng_words(u64 seed, u64 call, u64 env_id, u32 p
 __device__ __forceinline__ u32 mulhi_range(u32 w, u32 n) { return __umulhi(w, n); } // uniform in [0,n)
 __device__ __forceinline__ float u01(u32 w) { return (float)(w >> 8) * (1.0f / 16777216.0f); }
 
+// per-cell uniform: cells c, c+64, c+128, c+192 share one Philox block (sub = (c >> 8) * 64 + (c & 63),
+// word = (c >> 6) & 3), so the lane that owns them (c & 63) computes one block for four of its cells.
 __device__ __forceinline__ float cell_u01(u64 seed, u64 call, u64 env_id, u32 purpose, u32 cell)
 {
-    Words o = rng_words(seed, call, env_id, purpose, cell >> 2);
-    u32 j = cell & 3u;
+    Words o = rng_words(seed, call, env_id, purpose, ((cell >> 8) << 6) | (cell & 63u));
+    u32 j = (cell >> 6) & 3u;
     u32 w = j == 0 ? o.w[0] : j == 1 ? o.w[1] : j == 2 ? o.w[2] : o.w[3];
     return u01(w);
 }
