@@ -1,0 +1,401 @@
+"""MultiSnake — drop-in for the reference's wurm.envs.MultiSnake (wurm/envs/multi_snake.py:18-1019): K snakes per
+environment, boost moves, food-on-death, respawning; step / reset / _observe run as fused gfx950 kernels behind
+the C ABI of include/wurm_hip.h (wurm_multi_*).
+
+State tensors keep the reference's names, shapes and agent order (agent = env * num_snakes + i):
+`foods (N,1,S,S)`, `heads` / `bodies (N*K,1,S,S)`, `dones (N*K)`, `orientations (N*K)` int64, `boost_this_step`,
+`rewards`, `agent_colours (N*K,3)` int16.  Callers may write into them or rebind them between calls (the
+reference's tests do, tests/test_multi_snake_env.py:21-47).  Dynamics attributes (`boost`, `food_on_death_prob`,
+`boost_cost_prob`, `food_mode`, `food_rate`, `respawn_mode`, `reward_on_death`) are read at every call and may be
+changed after construction, as the reference allows.
+
+Deviations: see wurm_amd/envs/single_snake.py (bool masks, Philox RNG via `seed` / `env_offset`, GPU only); only
+`dtype=torch.float` is supported; a snake that finds no room during env creation stays dead instead of raising
+(the constructor checks and raises like the reference, `reset()` does not sync to check).
+"""
+import ctypes
+from collections import namedtuple, OrderedDict
+from typing import Dict, Optional, Tuple
+
+import torch
+
+from wurm_amd import _lib
+from wurm_amd.config import DEFAULT_DEVICE, EPS
+from wurm_amd.envs.single_snake import _draw_seed
+
+Spec = namedtuple('Spec', ['reward_threshold'])
+
+_INT_TYPES = (torch.short, torch.int, torch.long)
+
+
+class MultiSnake(object):
+    """Batched multi-agent snake environment (reference multi_snake.py:18-48)."""
+
+    spec = Spec(float('inf'))
+    metadata = {
+        'render.modes': ['rgb_array'],
+        'video.frames_per_second': 12
+    }
+
+    def __init__(self,
+                 num_envs: int,
+                 num_snakes: int,
+                 size: int,
+                 initial_snake_length: int = 3,
+                 on_death: str = 'restart',
+                 observation_mode: str = 'full',
+                 device: str = DEFAULT_DEVICE,
+                 dtype: torch.dtype = torch.float,
+                 manual_setup: bool = False,
+                 food_on_death_prob: float = 0.5,
+                 boost: bool = True,
+                 boost_cost_prob: float = 0.5,
+                 food_mode: str = 'only_one',
+                 food_rate: float = 5e-4,
+                 respawn_mode: str = 'all',
+                 reward_on_death: int = -1,
+                 verbose: int = 0,
+                 render_args: dict = None,
+                 agent_colours: str = 'random',
+                 seed: int = None,
+                 env_offset: int = 0):
+        self.num_envs = num_envs
+        self.num_snakes = num_snakes
+        self.size = size
+        self.initial_snake_length = initial_snake_length
+        self.on_death = on_death
+        self.device = _lib.require_device(device)
+        self.verbose = verbose
+        if dtype != torch.float:
+            raise NotImplementedError('wurm_amd.MultiSnake keeps its state in fp32 (dtype=torch.float) only')
+        self.dtype = dtype
+        self.observation_mode = observation_mode
+        if observation_mode.startswith('partial_'):
+            self.observation_width = int(observation_mode.split('_')[1])
+            self.observation_size = 2 * int(observation_mode.split('_')[1]) + 1
+        self.seed = _draw_seed() if seed is None else int(seed)
+        self.env_offset = int(env_offset)
+        self._call = 0
+
+        if render_args is None:
+            self.render_args = {'num_rows': 1, 'num_cols': 1, 'size': 256}
+        else:
+            self.render_args = render_args
+
+        N, K, S, dev = num_envs, num_snakes, size, self.device
+        self.foods = torch.zeros((N, 1, S, S), dtype=self.dtype, device=dev)
+        self.heads = torch.zeros((N * K, 1, S, S), dtype=self.dtype, device=dev)
+        self.bodies = torch.zeros((N * K, 1, S, S), dtype=self.dtype, device=dev)
+        self.dones = torch.zeros(N * K, dtype=torch.bool, device=dev)
+        self.boost_this_step = torch.zeros(N * K, dtype=torch.bool, device=dev)
+        self.rewards = torch.zeros(N * K, dtype=torch.float, device=dev)
+        self.env_lifetimes = torch.zeros(N, dtype=torch.long, device=dev)
+        self.snake_lifetimes = torch.zeros((N, K), dtype=torch.long, device=dev)
+        self.orientations = torch.zeros(N * K, dtype=torch.long, device=dev)
+        self.viewer = None
+
+        ###################################
+        # Environment dynamics parameters #
+        ###################################
+        self.respawn_mode = respawn_mode
+        self.food_on_death_prob = food_on_death_prob
+        self.boost = boost
+        self.boost_cost_prob = boost_cost_prob
+        self.food_mode = food_mode
+        self.food_rate = food_rate
+        self.max_food = self.num_snakes * 8
+        self.max_env_lifetime = 5000
+        self.reward_on_death = reward_on_death
+
+        # Rendering parameters (reference :131-141)
+        self.self_colour = torch.tensor((0, 192, 0), dtype=torch.short, device=dev)
+        self.self_boost_colour = torch.tensor((0, 255, 0), dtype=torch.short, device=dev)
+        self.other_colour = torch.tensor((0, 0, 192), dtype=torch.short, device=dev)
+        self.other_boost_colour = torch.tensor((0, 0, 255), dtype=torch.short, device=dev)
+        self.food_colour = torch.tensor((255, 0, 0), dtype=torch.short, device=dev)
+        self.edge_colour = torch.tensor((0, 0, 0), dtype=torch.short, device=dev)
+
+        if agent_colours == 'random':
+            self.colour_mode = 'random'
+        elif agent_colours == 'fixed':
+            self.colour_mode = 'fixed'
+        else:
+            raise ValueError('agent_colours must in {random, fixed}')
+        self.agent_colours = torch.empty((N * K, 3), dtype=torch.short, device=dev)
+        rc = _lib.lib().wurm_multi_colours(_lib.ptr(self.agent_colours), _lib.i64(N), K,
+                                           int(self.colour_mode == 'fixed'), _lib.u64(self.seed),
+                                           _lib.u64(self._next_call()), _lib.i64(self.env_offset), _lib.stream_ptr())
+        _lib.check(rc, 'MultiSnake.get_n_colours')
+        self.num_colours = self.agent_colours.shape[0]
+
+        self.info = {}
+
+        self.edge_locations_mask = torch.zeros((1, 1, S, S), dtype=self.dtype, device=dev)
+        self.edge_locations_mask[:, :, :1, :] = 1
+        self.edge_locations_mask[:, :, :, :1] = 1
+        self.edge_locations_mask[:, :, -1:, :] = 1
+        self.edge_locations_mask[:, :, :, -1:] = 1
+
+        if not manual_setup:
+            # reference :111-116 _create_envs(num_envs); raises if a snake cannot be placed (:946-947)
+            failures = self._reset_kernel(torch.ones(N, dtype=torch.bool, device=dev), observe=False,
+                                          want_status=True)
+            if failures:
+                raise RuntimeError('There is no available locations to create snake!')
+
+    # ------------------------------------------------------------------ helpers
+
+    def _next_call(self, n: int = 1) -> int:
+        c = self._call
+        self._call += n
+        return c
+
+    def _log(self, msg: str):
+        if self.verbose > 0:
+            print(msg)
+
+    def _cfg(self) -> _lib.MultiConfig:
+        return _lib.multi_config(self.num_snakes, self.boost, self.food_on_death_prob, self.boost_cost_prob,
+                                 self.food_mode, self.food_rate, self.reward_on_death, self.respawn_mode,
+                                 self.colour_mode)
+
+    def _norm(self, name: str, shape, dtype):
+        """State tensors may have been rebound by the caller: bring them to the layout the kernels read."""
+        t = getattr(self, name)
+        if tuple(t.shape) != tuple(shape):
+            raise RuntimeError(f'env.{name} has shape {tuple(t.shape)}, expected {tuple(shape)}')
+        if t.dtype != dtype or t.device != self.device or not t.is_contiguous():
+            if dtype == torch.bool and t.dtype != torch.bool:
+                t = t != 0
+            t = t.to(device=self.device, dtype=dtype).contiguous()
+            setattr(self, name, t)
+        return t
+
+    def _state(self):
+        N, K, S = self.num_envs, self.num_snakes, self.size
+        return (self._norm('foods', (N, 1, S, S), torch.float32), self._norm('heads', (N * K, 1, S, S), torch.float32),
+                self._norm('bodies', (N * K, 1, S, S), torch.float32), self._norm('dones', (N * K,), torch.bool),
+                self._norm('orientations', (N * K,), torch.long),
+                self._norm('agent_colours', (N * K, 3), torch.short),
+                self._norm('boost_this_step', (N * K,), torch.bool))
+
+    def _obs_args(self, mode: Optional[str]):
+        if mode is None:
+            return _lib.OBS_NONE, 0, None
+        if mode == 'full':
+            m, n = _lib.OBS_DEFAULT, 0
+            shape = (self.num_snakes, self.num_envs, 3, self.size, self.size)
+        elif isinstance(mode, str) and mode.startswith('partial_'):
+            m, n = _lib.OBS_PARTIAL, int(mode.split('_')[1])
+            shape = (self.num_snakes, self.num_envs, 3, 2 * n + 1, 2 * n + 1)
+        else:
+            raise ValueError('Unrecognised observation mode.')
+        return m, n, torch.empty(shape, dtype=torch.float32, device=self.device)
+
+    def _obs_dict(self, obs: torch.Tensor) -> Dict[str, torch.Tensor]:
+        return OrderedDict([(f'agent_{i}', o) for i, o in enumerate(obs.unbind(0))])
+
+    def _per_agent(self, tensor: torch.Tensor, key: str) -> Dict[str, torch.Tensor]:
+        """reference :459-460 / :701-729: (N*K) -> {key_i: (N,)} fresh tensors"""
+        cols = tensor.view(self.num_envs, self.num_snakes).t().contiguous().unbind(0)
+        return {f'{key}{i}': d for i, d in enumerate(cols)}
+
+    # ------------------------------------------------------------------ colours / rendering (host side, torch ops)
+
+    def get_n_colours(self, n: int) -> torch.Tensor:
+        """reference :163-169"""
+        colours = torch.rand((n, 3), device=self.device)
+        colours[:, 0] /= 1.5  # Reduce red
+        colours /= colours.norm(2, dim=1, keepdim=True)
+        colours *= 192
+        return colours.short()
+
+    def _get_env_images(self) -> torch.Tensor:
+        """reference :194-227 — (N,3,S,S) int16 image of every env; not on the step path (used by render())."""
+        N, K, S = self.num_envs, self.num_snakes, self.size
+        foods, heads, bodies, dones, _, colours, boost = self._state()
+        inten = bodies.gt(EPS).float() * 1 / 3 + heads.gt(EPS).float() * 1 / 3
+        inten = (inten * (1 + 0.5 * boost.float())[:, None, None, None]).squeeze(1)
+        img = (inten[:, None] * colours.float()[:, :, None, None]).reshape(N, K, 3, S, S).sum(dim=1).short()
+        img[:, 0] += (foods.gt(EPS).squeeze(1) * 255).short()
+        black = (img == 0).all(dim=1, keepdim=True)
+        img = torch.where(black, torch.full_like(img, 255), img)
+        img = img * (1 - self.edge_locations_mask).short()
+        return img
+
+    def render(self, mode: str = 'human', env: int = None):
+        """reference :229-266 ('rgb_array' only; the 'human' viewer needs gym/pyglet)"""
+        import numpy as np
+        from PIL import Image
+
+        img = self._get_env_images().cpu().numpy()
+        if self.num_envs == 1 or env is not None:
+            num_cols = num_rows = 1
+            img = np.transpose(img[env or 0], (1, 2, 0))
+        else:
+            num_rows = self.render_args['num_rows']
+            num_cols = self.render_args['num_cols']
+            output = np.zeros((self.size * num_rows, self.size * num_cols, 3))
+            for i in range(num_rows):
+                for j in range(num_cols):
+                    output[i * self.size:(i + 1) * self.size, j * self.size:(j + 1) * self.size, :] = \
+                        np.transpose(img[i * num_cols + j], (1, 2, 0))
+            img = output
+        img = np.array(Image.fromarray(img.astype(np.uint8)).resize(
+            (self.render_args['size'] * num_cols, self.render_args['size'] * num_rows)))
+        if mode == 'rgb_array':
+            return img
+        elif mode == 'human':
+            raise NotImplementedError("render('human') needs gym's SimpleImageViewer; use mode='rgb_array'")
+        else:
+            raise ValueError('Render mode not recognised.')
+
+    # ------------------------------------------------------------------ observations
+
+    def _observe(self, mode: str = None) -> Dict[str, torch.Tensor]:
+        """reference :283-334"""
+        if mode is None:
+            mode = self.observation_mode
+        m, n, obs = self._obs_args(mode)
+        foods, heads, bodies, dones, _, colours, boost = self._state()
+        rc = _lib.lib().wurm_multi_observe(_lib.ptr(foods), _lib.ptr(heads), _lib.ptr(bodies), _lib.ptr(dones),
+                                           _lib.ptr(boost), _lib.ptr(colours), _lib.ptr(obs), m, n,
+                                           _lib.i64(self.num_envs), self.num_snakes, self.size, _lib.stream_ptr())
+        _lib.check(rc, 'MultiSnake._observe')
+        return self._obs_dict(obs)
+
+    def _observe_agent(self, agent: int) -> torch.Tensor:
+        """reference :268-281"""
+        return self._observe('full')[f'agent_{agent}']
+
+    # ------------------------------------------------------------------ step
+
+    def step(self, actions: Dict[str, torch.Tensor]) -> Tuple[Dict[str, torch.Tensor], dict, dict, dict]:
+        """reference :462-731"""
+        if len(actions) != self.num_snakes:
+            raise RuntimeError('Must have a Tensor of actions for each snake')
+
+        for agent, act in actions.items():
+            if act.dtype not in _INT_TYPES:
+                raise TypeError('actions Tensor must be an integer type i.e. '
+                                '{torch.ShortTensor, torch.IntTensor, torch.LongTensor}')
+
+            if act.shape[0] != self.num_envs:
+                raise RuntimeError('Must have the same number of actions as environments.')
+
+        N, K, S, dev = self.num_envs, self.num_snakes, self.size, self.device
+        # reference :492: stack in dict order -> (K, N); the kernel reads agent i's action of env e at [i*N + e]
+        stacked = torch.stack([v.reshape(N) for v in actions.values()]).to(device=dev, dtype=torch.long).contiguous()
+        foods, heads, bodies, dones, orientations, colours, _ = self._state()
+        m, n, obs = self._obs_args(self.observation_mode)
+
+        fl = torch.empty((3, N * K), dtype=torch.float32, device=dev)   # rewards, food consumed, sizes
+        bl = torch.empty((3, N * K), dtype=torch.bool, device=dev)      # boost_this_step, snake / edge collision
+        all_done = torch.empty(N, dtype=torch.bool, device=dev)
+        cfg = self._cfg()
+        rc = _lib.lib().wurm_multi_step(
+            _lib.ptr(foods), _lib.ptr(heads), _lib.ptr(bodies), _lib.ptr(dones), _lib.ptr(orientations),
+            _lib.ptr(stacked), _lib.ptr(bl[0]), _lib.ptr(fl[0]), _lib.ptr(bl[1]), _lib.ptr(bl[2]), _lib.ptr(fl[1]),
+            _lib.ptr(fl[2]), _lib.ptr(all_done), _lib.ptr(colours), _lib.ptr(obs), m, n, _lib.i64(N), K, S,
+            ctypes.byref(cfg), _lib.u64(self.seed), _lib.u64(self._next_call()), _lib.i64(self.env_offset), None,
+            _lib.stream_ptr())
+        _lib.check(rc, 'MultiSnake.step')
+
+        self.boost_this_step = bl[0]
+        self.rewards = fl[0]
+
+        dones_out = self._per_agent(dones, 'agent_')
+        dones_out['__all__'] = all_done | (self.env_lifetimes > self.max_env_lifetime)  # :703-705
+        rewards = self._per_agent(self.rewards, 'agent_')
+
+        self.info = {}
+        self.info.update(self._per_agent(bl[1], 'snake_collision_'))
+        self.info.update(self._per_agent(bl[2], 'edge_collision_'))
+        self.info.update(self._per_agent(fl[1], 'food_'))
+        self.info.update(self._per_agent(bl[0], 'boost_'))
+        self.info.update(self._per_agent(fl[2], 'size_'))
+
+        return self._obs_dict(obs), rewards, dones_out, self.info
+
+    # ------------------------------------------------------------------ invariants
+
+    def check_consistency(self):
+        """reference :733-769: raises RuntimeError if any env is inconsistent"""
+        foods, heads, bodies, dones, _, _, _ = self._state()
+        err = torch.empty(self.num_envs, dtype=torch.int32, device=self.device)
+        rc = _lib.lib().wurm_multi_check(_lib.ptr(foods), _lib.ptr(heads), _lib.ptr(bodies), _lib.ptr(dones),
+                                         _lib.ptr(err), _lib.i64(self.num_envs), self.num_snakes, self.size,
+                                         _lib.stream_ptr())
+        _lib.check(rc, 'MultiSnake.check_consistency')
+        from wurm_amd.utils import _raise_for
+        bits = (err.unsqueeze(-1) >> torch.arange(10, device=self.device, dtype=torch.int32)) & 1
+        present = bits.any(dim=0).cpu().tolist()
+        mask = sum((1 << i) for i, p in enumerate(present) if p)
+        _raise_for(mask & 0x7f, one_food=False)
+        if mask & 0x100:
+            raise RuntimeError('An environment contains overlapping snakes')
+        if mask & 0x200:
+            raise RuntimeError('Dead snake contains non-zero elements.')
+
+    # ------------------------------------------------------------------ reset
+
+    def _reset_kernel(self, done: torch.Tensor, observe: bool, want_status: bool = False):
+        foods, heads, bodies, dones, orientations, colours, boost = self._state()
+        m, n, obs = self._obs_args(self.observation_mode if observe else None)
+        status = torch.zeros(1, dtype=torch.int32, device=self.device) if want_status else None
+        cfg = self._cfg()
+        rc = _lib.lib().wurm_multi_reset(
+            _lib.ptr(foods), _lib.ptr(heads), _lib.ptr(bodies), _lib.ptr(dones), _lib.ptr(orientations),
+            _lib.ptr(colours), _lib.ptr(done), _lib.ptr(status), _lib.ptr(boost), _lib.ptr(obs), m, n,
+            _lib.i64(self.num_envs), self.num_snakes, self.size, ctypes.byref(cfg), _lib.u64(self.seed),
+            _lib.u64(self._next_call()), _lib.i64(self.env_offset), None, _lib.stream_ptr())
+        _lib.check(rc, 'MultiSnake.reset')
+        if want_status:
+            return int(status.item())
+        return obs
+
+    def reset(self, done: torch.Tensor = None, return_observations: bool = True) -> Optional[Dict[str, torch.Tensor]]:
+        """Resets environments in which the snake has died (reference :771-836)
+
+        Args:
+            done: A 1D Tensor of length self.num_envs. A value of 1 means the corresponding environment needs to be
+                reset.  None: every env whose snakes are all dead.
+        """
+        if self.initial_snake_length != 3:
+            raise NotImplementedError('Only initial snake length = 3 has been implemented.')
+        if done is None:
+            done = self._norm('dones', (self.num_envs * self.num_snakes,), torch.bool) \
+                .view(self.num_envs, self.num_snakes).all(dim=1)
+        done = done.view((done.shape[0]))
+        if done.dtype != torch.bool:
+            done = done != 0
+        done = done.to(self.device).contiguous()
+        self.env_lifetimes.masked_fill_(done, 0)  # :797
+        obs = self._reset_kernel(done, observe=return_observations)
+        if return_observations:
+            return self._obs_dict(obs)
+
+    def _create_envs(self, num_envs: int):
+        """reference :996-1019 — a fresh batch: ((foods, heads, bodies), orientations); self is not modified."""
+        if self.initial_snake_length != 3:
+            raise NotImplementedError('Only initial snake length = 3 has been implemented.')
+        K, S, dev = self.num_snakes, self.size, self.device
+        foods = torch.zeros((num_envs, 1, S, S), device=dev)
+        heads = torch.zeros((num_envs * K, 1, S, S), device=dev)
+        bodies = torch.zeros((num_envs * K, 1, S, S), device=dev)
+        dones = torch.zeros(num_envs * K, dtype=torch.bool, device=dev)
+        orientations = torch.zeros(num_envs * K, dtype=torch.long, device=dev)
+        colours = torch.zeros((num_envs * K, 3), dtype=torch.short, device=dev)
+        ones = torch.ones(num_envs, dtype=torch.bool, device=dev)
+        status = torch.zeros(1, dtype=torch.int32, device=dev)
+        cfg = self._cfg()
+        cfg.respawn_any = 0
+        rc = _lib.lib().wurm_multi_reset(
+            _lib.ptr(foods), _lib.ptr(heads), _lib.ptr(bodies), _lib.ptr(dones), _lib.ptr(orientations),
+            _lib.ptr(colours), _lib.ptr(ones), _lib.ptr(status), None, None, _lib.OBS_NONE, 0, _lib.i64(num_envs), K,
+            S, ctypes.byref(cfg), _lib.u64(self.seed), _lib.u64(self._next_call()), _lib.i64(self.env_offset), None,
+            _lib.stream_ptr())
+        _lib.check(rc, 'MultiSnake._create_envs')
+        if int(status.item()):
+            raise RuntimeError('There is no available locations to create snake!')
+        return (foods, heads, bodies), orientations

@@ -101,3 +101,18 @@ def _or_reduce(mask: torch.Tensor) -> int:
     bits = (mask.unsqueeze(-1) >> torch.arange(8, device=mask.device, dtype=torch.int32)) & 1
     present = bits.any(dim=0).cpu().tolist()
     return sum((1 << i) for i, p in enumerate(present) if p)
+
+
+def determine_orientations(envs: torch.Tensor) -> torch.Tensor:
+    """Returns a batch of snake orientations {0,1,2,3} from a (n,3,size,size) batch of envs
+    (reference wurm/utils.py:36-65): orientation o <=> the head sits at neck + [(-1,0),(0,+1),(+1,0),(0,-1)][o]."""
+    if envs.dim() != 4 or envs.shape[1] != 3 or envs.shape[2] != envs.shape[3]:
+        raise RuntimeError('expected a (n, 3, size, size) tensor')
+    if envs.device.type != 'cuda':
+        raise _lib.WurmHipError('determine_orientations runs on the GPU: envs must be a device tensor')
+    e = envs.to(torch.float32).contiguous()
+    n, S = e.shape[0], e.shape[2]
+    out = torch.empty(n, dtype=torch.long, device=e.device)
+    rc = _lib.lib().wurm_orientations(_lib.ptr(e), _lib.ptr(out), _lib.i64(n), S, _lib.stream_ptr())
+    _lib.check(rc, 'determine_orientations')
+    return out
