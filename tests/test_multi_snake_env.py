@@ -16,9 +16,10 @@ def api():
     return dict(MultiSnake=MultiSnake, determine_orientations=determine_orientations)
 
 
-def get_test_env(api, num_envs=1):
-    """Two length-4 snakes per env (reference tests/test_multi_snake_env.py:21-47)."""
-    env = api['MultiSnake'](num_envs=num_envs, num_snakes=2, size=size, manual_setup=True)
+def get_test_env(api, num_envs=1, seed=1):
+    """Two length-4 snakes per env (reference tests/test_multi_snake_env.py:21-47).  The reference seeds torch's
+    global RNG once (`torch.random.manual_seed(1)`, :18); here the env's own seed is pinned."""
+    env = api['MultiSnake'](num_envs=num_envs, num_snakes=2, size=size, manual_setup=True, seed=seed)
     for i in range(num_envs):
         env.heads[2 * i, 0, 5, 5] = 1
         for v, (y, x) in zip((4, 3, 2, 1), ((5, 5), (4, 5), (4, 4), (4, 3))):
@@ -222,7 +223,8 @@ def test_boost_rendering(api):
     for i, obs, rewards, dones, info in run(env, tape([4, 1, 2], [0, 1, 3]), check=False):
         env.reset(dones['__all__'], return_observations=False)
         img = env._get_env_images()
-        colours.append(img[0, :, 4, 5].float().norm().item())  # a body cell of agent_0
+        colours.append(img[0, :, 5, 5].float().norm().item())  # a body cell of agent_0 (the reference samples
+        # pixel (127,127) of the 256-px render = cell (5,5))
         env.check_consistency()
     assert colours[0] > colours[1]  # the body appears brighter while boosting
     assert env.render(mode='rgb_array').shape == (256, 256, 3)
@@ -245,7 +247,8 @@ def test_partial_observations(api):
     assert list(observations) == [f'agent_{i}' for i in range(4)]
     for v in observations.values():
         assert v.shape == (256, 3, 11, 11) and v.dtype == torch.float32
-        assert torch.all(v[:, 1, 5, 5] > 0)  # the window is centred on the agent's own (coloured) head
+        centre = v[:, :, 5, 5]  # the window is centred on the agent's own head: coloured, not background white
+        assert torch.all((centre < 1).any(dim=1))
 
 
 def test_argument_errors(api):
