@@ -28,10 +28,10 @@ def _bits(a):
 def _same(a, b, what):
     if a is None and b is None:
         return
-    if a.dtype.kind == 'f':
-        assert np.array_equal(_bits(a), _bits(b)), what
-    else:
-        assert np.array_equal(a, b), what
+    x, y = (_bits(a), _bits(b)) if a.dtype.kind == 'f' else (np.asarray(a), np.asarray(b))
+    assert x.shape == y.shape, f'{what}: shape {x.shape} vs {y.shape}'
+    bad = np.argwhere(x != y)
+    assert len(bad) == 0, f'{what}: {len(bad)} mismatches, first at {bad[0].tolist()}: {a[tuple(bad[0])]} vs {b[tuple(bad[0])]}'
 
 
 @pytest.mark.parametrize('N,S,T,mode,dtype', [
@@ -89,6 +89,34 @@ def test_single_rollout_equals_loop(hip, N, S, T, mode):
         _same(d, rh['done'][t], f'loop done t={t}')
         h2.single_reset(eh2, d, 'none')
     _same(eh2, eh, 'loop final state')
+
+
+@pytest.mark.parametrize('S,mode', [(9, 'partial_2'), (12, 'default'), (20, 'partial_3')])
+def test_rollout_from_irregular_states(hip, S, mode):
+    """The rollout kernel carries head / length / orientation / food as scalars only when the start state is a
+    well-formed snake; otherwise it must fall back to the generic path.  Start from states that are NOT well formed:
+    done envs that were stepped on without a reset (vanished heads, overlapping body values), envs with two foods,
+    with no food, with two cells holding the maximum body value.  (More than one head per env is outside the
+    kernels' domain)"""
+    N, T = 48, 70
+    rng = np.random.RandomState(21)
+    o, h = OracleBackend(seed=9), hip(seed=9)
+    envs = _fresh_single(o, N, S)
+    for t in range(12):  # no resets: many envs end up irregular
+        o.single_step(envs, rng.randint(0, 4, size=N).astype(np.int64), 'none')
+    envs[0, 0, 2, 2] = 1          # a second food
+    envs[1, 0] = 0                # no food at all
+    envs[3, 2, 5, 5] = envs[3, 2].max()  # two cells hold the maximum body value
+    assert (o.single_check(envs) != 0).sum() > 2
+    eo, eh = envs.copy(), envs.copy()
+    actions = rng.randint(0, 4, size=(T, N)).astype(np.int64)
+    ao, ah = actions.copy(), actions.copy()
+    o.call = h.call = 100
+    ro, rh = o.single_rollout(eo, ao, mode), h.single_rollout(eh, ah, mode)
+    for k in ro:
+        _same(ro[k], rh[k], k)
+    _same(ao, ah, 'actions')
+    _same(eo, eh, 'final state')
 
 
 @pytest.mark.parametrize('N,S,T,mode', [(64, 9, 150, 'default'), (20, 7, 60, 'raw'), (8, 30, 50, 'positions')])

@@ -204,7 +204,7 @@ __device__ __forceinline__ void run_phase(const Ctx &cx, bool who, int dir, int 
         coll = sum > 0;
     }
     for (int o = 0; o < K; ++o) {
-        int ho = __shfl(hc, o, WAVE);
+        int ho = lane_value(hc, o);
         if (who && hc >= 0 && o != lane && ho == hc) coll = true;
     }
     done |= coll;
@@ -279,7 +279,7 @@ __device__ __forceinline__ u64 free_cells(const Ctx &cx, int hc, int margin)
     const int S = cx.S, C = cx.C, lane = cx.lane;
     u64 headbits = 0;
     for (int s = 0; s < cx.K; ++s) {
-        int h = __shfl(hc, s, WAVE);
+        int h = lane_value(hc, s);
         if (h >= 0 && (h & 63) == lane) headbits |= 1ull << (h >> 6);
     }
     u64 fr = 0;
@@ -316,7 +316,7 @@ __device__ __forceinline__ int selected_cell(int k)
     u64 m = ballot(k >= 0);
     if (!m) return -1;
     int owner = first_bit(m);
-    return owner + 64 * __shfl(k, owner, WAVE);
+    return owner + 64 * lane_value(k, owner);
 }
 
 __device__ __forceinline__ int count_bits(const Ctx &cx, u64 bits)
@@ -407,8 +407,8 @@ __device__ __forceinline__ void observe_partial(const Ctx &cx, const MultiArgs &
     const int W = 2 * n + 1, W2 = W * W, E = 3 * W2;
     const float rcpW2 = 1.0f / (float)W2, rcpW = 1.0f / (float)W;
     for (int a = 0; a < K; ++a) {
-        const int h = __shfl(hc, a, WAVE);
-        const bool dead = __shfl((int)done, a, WAVE) != 0;
+        const int h = lane_value(hc, a);
+        const bool dead = lane_value((int)done, a) != 0;
         const int hy = h >= 0 ? div_size(h, cx.rcpS) : 0, hx = h - hy * S;
         float *o = p.obs + ((long long)a * p.N + env) * p.obs_elems;
         for (int el = lane; el < E; el += 64) {

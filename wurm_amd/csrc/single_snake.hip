@@ -393,7 +393,9 @@ __device__ __forceinline__ void write_obs(const Env<CPL> &e, const Geo &g, int h
             }
         }
     } else if (mode == WURM_OBS_PARTIAL) {
-        const int W = 2 * n + 1, W2 = W * W, E = 3 * W2;
+        // (2n+1)^2 crop of the zero-padded RGB image around the head, channel-major (single_snake.py:166-193).
+        // Each window cell is classified once and written to its three channel planes.
+        const int W = 2 * n + 1, W2 = W * W;
         wave_lds_sync();
 #pragma unroll
         for (int k = 0; k < CPL; ++k)
@@ -401,14 +403,16 @@ __device__ __forceinline__ void write_obs(const Env<CPL> &e, const Geo &g, int h
         wave_lds_sync();
         const int hy = headcell >= 0 ? div_size(headcell, g.rcpS) : 0;
         const int hx = headcell - hy * S;
-        const float rcpW2 = 1.0f / (float)W2, rcpW = 1.0f / (float)W;
-        for (int el = lane; el < E; el += 64) {
-            int ch = div_size(el, rcpW2), w = el - ch * W2;
+        const float rcpW = 1.0f / (float)W;
+        for (int w = lane; w < W2; w += 64) {
             int wy = div_size(w, rcpW), wx = w - wy * W;
             int y = hy - n + wy, x = hx - n + wx;
-            float v = 0.0f; // F.pad zeros (single_snake.py:179); no head: zeros (the reference raises at :191)
-            if (headcell >= 0 && y >= 0 && y < S && x >= 0 && x < S) v = class_rgb(lds[y * S + x], ch, SNAKE);
-            o[el] = v;
+            // F.pad zeros (single_snake.py:179); no head: zeros (the reference raises at :191)
+            int cls = 4;
+            if (headcell >= 0 && y >= 0 && y < S && x >= 0 && x < S) cls = lds[y * S + x];
+            o[w] = class_rgb(cls, 0, SNAKE);
+            o[W2 + w] = class_rgb(cls, 1, SNAKE);
+            o[2 * W2 + w] = class_rgb(cls, 2, SNAKE);
         }
         wave_lds_sync();
     } else if (mode == WURM_OBS_ONE_CHANNEL) { // single_snake.py:142-151
@@ -549,6 +553,230 @@ __global__ __launch_bounds__(256) void observe_kernel(StepArgs p)
     write_obs<CPL, SNAKE>(e, g, find_head<CPL>(e), p.obs + env * p.obs_elems, p.obs_mode, p.obs_n, lds);
 }
 
+// ------------------------------------------------------------------------------------------------ rollout fast path
+//
+// Inside a rollout nothing but this wave touches the env, so the quantities step_core re-derives from the grid on
+// every call — head cell, snake length, orientation, food cell — are known wave-uniform scalars that can simply be
+// carried from step to step.  Exactness (same results as step_core on the same state) needs the state to be a
+// well-formed snake when the carry starts: at most one head cell, at most one food cell, exactly one body cell == L
+// (under the head, if there is a head) and exactly one == L-1, L >= 2.  Then, for an env that is not done:
+//   * the new head cell holds L + eat and is the unique maximum, the old head cell holds the unique maximum - 1
+//     => next length = L + eat, next orientation = (action + 2) % 4 (head = neck + TAP[o] with the move being -TAP[a]);
+//   * a done env (self collision / edge) is rebuilt by the reset that follows every step of a rollout.
+// Any other start state runs the generic loop (step_core), which makes no assumption.
+struct Fast {
+    int hc, hy, hx; // head cell (-1: none) and its row / column
+    int L;          // snake length = max body value
+    int o;          // orientation
+    int food;       // food cell (-1: none)
+};
+
+template <int CPL>
+__device__ __forceinline__ bool fast_init(const Env<CPL> &e, const Geo &g, Fast &f)
+{
+    int nhead = 0, nfood = 0, hc = -1, fc = -1, lm = 0;
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) {
+        u64 mh = ballot((e.head >> k) & 1), mf = ballot((e.food >> k) & 1);
+        nhead += popc64(mh);
+        nfood += popc64(mf);
+        if (hc < 0 && mh) hc = 64 * k + first_bit(mh);
+        if (fc < 0 && mf) fc = 64 * k + first_bit(mf);
+        lm = max(lm, e.body[k]);
+    }
+    const int L = wave_max_i32(lm);
+    int cntL = 0, cntN = 0, cellL = -1, cellN = -1;
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) {
+        bool v = (g.valid >> k) & 1;
+        u64 mL = ballot(v && e.body[k] == L), mN = ballot(v && e.body[k] == L - 1);
+        cntL += popc64(mL);
+        cntN += popc64(mN);
+        if (cellL < 0 && mL) cellL = 64 * k + first_bit(mL);
+        if (cellN < 0 && mN) cellN = 64 * k + first_bit(mN);
+    }
+    if (nhead > 1 || nfood > 1 || cntL != 1 || cntN != 1 || L < 2 || (hc >= 0 && hc != cellL)) return false;
+    int yL = div_size(cellL, g.rcpS), xL = cellL - yL * g.S;
+    int yN = div_size(cellN, g.rcpS), xN = cellN - yN * g.S;
+    int dy = yL - yN, dx = xL - xN;
+    f.o = (dy == 0 && dx == 1) ? 1 : (dy == 1 && dx == 0) ? 2 : (dy == 0 && dx == -1) ? 3 : 0; // as orientation_of
+    f.hc = hc;
+    f.hy = hc >= 0 ? div_size(hc, g.rcpS) : 0;
+    f.hx = hc - f.hy * g.S;
+    f.L = L;
+    f.food = fc;
+    return true;
+}
+
+// K-th free interior cell (body == 0; the head cell has body > 0 and the only food was just eaten / the grid was
+// just rebuilt) in row-major order — the same choice add_food makes.  Returns the cell or -1.
+template <int CPL>
+__device__ __forceinline__ int fast_food_cell(const Env<CPL> &e, const Geo &g, u32 word)
+{
+    int n_free = 0;
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) n_free += popc64(ballot(((g.interior >> k) & 1) && e.body[k] == 0));
+    if (n_free == 0) return -1;
+    const int K = (int)mulhi_range(word, (u32)n_free);
+    int base = 0, cell = -1;
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) {
+        u64 m = ballot(((g.interior >> k) & 1) && e.body[k] == 0);
+        int cnt = popc64(m);
+        if (cell < 0 && K < base + cnt) { // the (K - base)-th set bit of m
+            u64 hit = ballot(((m >> g.lane) & 1) && rank_below(m) == K - base);
+            cell = 64 * k + first_bit(hit);
+        }
+        base += cnt;
+    }
+    return cell;
+}
+
+// step_core with carried scalars (single_snake.py:197-304; same line references as step_core)
+template <int CPL>
+__device__ __forceinline__ void fast_step(Env<CPL> &e, const Geo &g, Fast &f, long long a_in, StepOut &out, u64 seed,
+                                          u64 call, u64 env_id, bool use_inject, int inject_cell)
+{
+    const int S = g.S;
+    const bool rev = (long long)f.o == a_in;                              // :221-222
+    const long long a_out = rev ? (long long)((f.o + 2) & 3) : a_in % 4;
+    const int ai = (int)(((a_out % 4) + 4) % 4);
+    int newhead = -1, ny = -1, nx = -1;
+    if (f.hc >= 0) {                                                      // :225-233
+        ny = f.hy - tap_y(ai);
+        nx = f.hx - tap_x(ai);
+        if (ny >= 0 && ny < S && nx >= 0 && nx < S) newhead = ny * S + nx;
+    }
+    const bool inside = newhead >= 0;
+    const bool EAT = inside && newhead == f.food;                         // :242
+    int sel = 0;
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) sel = (newhead >> 6) == k ? e.body[k] : sel;
+    const int bnew = inside ? lane_value(sel, newhead & 63) : 0;
+    const int bdec = EAT ? bnew : max(bnew - 1, 0);
+    const bool SELFC = inside && bdec > 0;                                // :252
+    const int grow = f.L + (EAT ? 1 : 0);
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) {
+        int b = e.body[k];
+        if (!EAT) b = max(b - 1, 0);                                      // :246-249
+        if (g.lane + 64 * k == newhead) b += grow;                        // :258-262
+        e.body[k] = b;
+    }
+    const bool EDGEC = !(inside && ny >= 1 && ny <= S - 2 && nx >= 1 && nx <= S - 2); // :290-295
+    f.hc = newhead; f.hy = ny; f.hx = nx;
+    f.L = grow;
+    f.o = (ai + 2) & 3;
+    if (EAT) {                                                            // :270-282
+        if (use_inject) f.food = (inject_cell >= 0 && inject_cell < g.C) ? inject_cell : -1;
+        else f.food = fast_food_cell<CPL>(e, g, rng_words(seed, call, env_id, RNG_FOOD, 0).w[0]);
+    }
+    out.action = a_out;
+    out.headcell = newhead;
+    out.reward = EAT ? 1.0f : 0.0f;
+    out.selfc = SELFC;
+    out.edgec = EDGEC;
+    out.done = SELFC | EDGEC;
+}
+
+// reset_core with carried scalars (single_snake.py:344-387)
+template <int CPL>
+__device__ __forceinline__ void fast_reset(Env<CPL> &e, const Geo &g, Fast &f, u64 seed, u64 call, u64 env_id,
+                                           const int *__restrict__ inj)
+{
+    const int S = g.S;
+    Words w;
+    w.w[0] = w.w[1] = w.w[2] = w.w[3] = 0;
+    int sy, sx, d, fc = -1;
+    if (inj) {
+        sy = inj[0]; sx = inj[1]; d = inj[2]; fc = inj[3];
+        if (fc >= g.C) fc = -1;
+    } else {
+        w = rng_words(seed, call, env_id, RNG_RESET, 0);
+        sy = 4 + (int)mulhi_range(w.w[0], (u32)(S - 8));
+        sx = 4 + (int)mulhi_range(w.w[1], (u32)(S - 8));
+        d = (int)(w.w[2] >> 30);
+    }
+    const int hy = sy + tap_y(d), hx = sx + tap_x(d);
+    const int hc = hy * S + hx, sc = sy * S + sx, tc = (sy - tap_y(d)) * S + sx - tap_x(d);
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) {
+        int c = g.lane + 64 * k;
+        e.body[k] = c == hc ? 3 : c == sc ? 2 : c == tc ? 1 : 0;
+    }
+    f.hc = hc; f.hy = hy; f.hx = hx;
+    f.L = 3;
+    f.o = d;
+    f.food = inj ? fc : fast_food_cell<CPL>(e, g, w.w[3]);
+}
+
+// food / head bit sets of the Env from the carried scalars (for the generic observation writer and store_state)
+template <int CPL>
+__device__ __forceinline__ void fast_sync_bits(Env<CPL> &e, const Geo &g, const Fast &f)
+{
+    e.food = 0;
+    e.head = 0;
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) {
+        int c = g.lane + 64 * k;
+        if (c == f.food) e.food |= 1ull << k;
+        if (c == f.hc) e.head |= 1ull << k;
+    }
+}
+
+// Per-lane geometry of the partial_n crop, computed once per kernel: lane owns window cells w = lane + 64*i.
+constexpr int CROP_NI = 3; // (2n+1)^2 <= 192, i.e. n <= 6
+struct Crop {
+    int W2;
+    int dy[CROP_NI], dx[CROP_NI]; // window cell offset from the head; dy = INT_MIN/2 marks "no such cell"
+};
+
+__device__ __forceinline__ Crop make_crop(int lane, int n)
+{
+    Crop c;
+    const int W = 2 * n + 1;
+    c.W2 = W * W;
+    const float rcpW = 1.0f / (float)W;
+#pragma unroll
+    for (int i = 0; i < CROP_NI; ++i) {
+        int w = lane + 64 * i;
+        int wy = div_size(w, rcpW), wx = w - wy * W;
+        c.dy[i] = w < c.W2 ? wy - n : -(1 << 20);
+        c.dx[i] = wx - n;
+    }
+    return c;
+}
+
+// partial_n crop for grids of at most 128 cells (single_snake.py:166-193): body occupancy as two ballot masks, the
+// head and food cells as scalars — no LDS.  A window cell that is off the grid, on the border ring, or seen from
+// an env without a head is (0,0,0); otherwise food (1,0,0), head (0,1,0), body (0,127/255,0), background (1,1,1).
+template <int CPL>
+__device__ __forceinline__ void fast_partial_small(const Env<CPL> &e, const Geo &g, const Fast &f,
+                                                   float *__restrict__ o, const Crop &cg)
+{
+    static_assert(CPL <= 2, "ballot-mask crop needs <= 128 cells");
+    const int S = g.S, W2 = cg.W2;
+    const u64 m0 = ballot(e.body[0] > 0), m1 = CPL > 1 ? ballot(e.body[CPL - 1] > 0) : 0;
+    const bool has_head = f.hc >= 0;
+#pragma unroll
+    for (int i = 0; i < CROP_NI; ++i) {
+        if (64 * i >= W2) break;
+        const int y = f.hy + cg.dy[i], x = f.hx + cg.dx[i];
+        if (cg.dy[i] <= -(1 << 19)) continue;
+        const bool live = has_head && (unsigned)(y - 1) < (unsigned)(S - 2) && (unsigned)(x - 1) < (unsigned)(S - 2);
+        const int cell = y * S + x;
+        const bool fd = cell == f.food, hd = cell == f.hc;
+        const bool bd = (((cell < 64 ? m0 : m1) >> (cell & 63)) & 1) != 0;
+        const float bg = (live && !fd && !hd && !bd) ? 1.0f : 0.0f;
+        const float r = (live && fd) ? 1.0f : bg;
+        const float gr = (live && !fd) ? (hd ? 1.0f : (bd ? 127.0f / 255.0f : bg)) : 0.0f;
+        const int w = g.lane + 64 * i;
+        o[w] = r;
+        o[W2 + w] = gr;
+        o[2 * W2 + w] = bg;
+    }
+}
+
 // T fused step+reset iterations with the env resident in registers.  Lane j of the wave buffers the
 // per-step scalars of step t0+j; they are flushed every 64 steps.
 template <int CPL, bool SNAKE>
@@ -565,6 +793,12 @@ __global__ __launch_bounds__(256) void rollout_kernel(StepArgs p)
     Env<CPL> e;
     load_state<CPL, SNAKE>(envp, g, e);
     const bool inj_f = p.inject_food != nullptr, inj_r = p.inject_reset != nullptr;
+    Fast f = {-1, 0, 0, 0, 0, -1};
+    bool fast = false;
+    if (SNAKE) fast = fast_init<CPL>(e, g, f);
+    const bool small_crop = SNAKE && CPL <= 2 && p.obs_mode == WURM_OBS_PARTIAL && p.obs_n <= 6;
+    const Crop cg = make_crop(g.lane, small_crop ? p.obs_n : 0);
+    const long long obs_stride = p.N * p.obs_elems;
 
     for (long long t0 = 0; t0 < p.T; t0 += 64) {
         const int nt = (int)min((long long)64, p.T - t0);
@@ -573,24 +807,41 @@ __global__ __launch_bounds__(256) void rollout_kernel(StepArgs p)
         int my_inj = (inj_f && g.lane < nt) ? p.inject_food[my_t * p.N + env] : -1;
         float my_r = 0.0f;
         int my_flags = 0;
+        // Retire the two prefetch loads HERE.  Otherwise the compiler, seeing a register that may still be in flight
+        // on loop entry, puts `s_waitcnt vmcnt(0)` in front of the per-step readlane, and every step then also waits
+        // for the previous step's observation stores to be acknowledged by HBM (vmcnt counts loads and stores).
+        asm volatile("" : "+v"(my_a), "+v"(my_inj));
         for (int j = 0; j < nt; ++j) {
             const long long t = t0 + j;
             const long long a_in = lane_value64(my_a, j);
             const int inj_cell = lane_value(my_inj, j);
+            const u64 call = p.call + 2ull * (u64)t;
+            float *obs_t = p.obs + env * p.obs_elems + t * obs_stride;
             StepOut out;
-            step_core<CPL, SNAKE, false>(e, g, nullptr, a_in, out, p.seed, p.call + 2ull * (u64)t, env_id, inj_f,
-                                         inj_cell, lds);
+            if (SNAKE && fast) {
+                fast_step<CPL>(e, g, f, a_in, out, p.seed, call, env_id, inj_f, inj_cell);
+                if (small_crop) {
+                    if constexpr (CPL <= 2) fast_partial_small<CPL>(e, g, f, obs_t, cg);
+                } else if (p.obs_mode != WURM_OBS_NONE) {
+                    fast_sync_bits<CPL>(e, g, f);
+                    write_obs<CPL, SNAKE>(e, g, f.hc, obs_t, p.obs_mode, p.obs_n, lds);
+                }
+                if (out.done)
+                    fast_reset<CPL>(e, g, f, p.seed, call + 1ull, env_id,
+                                    inj_r ? p.inject_reset + (t * p.N + env) * 4 : nullptr);
+            } else {
+                step_core<CPL, SNAKE, false>(e, g, nullptr, a_in, out, p.seed, call, env_id, inj_f, inj_cell, lds);
+                if (p.obs_mode != WURM_OBS_NONE)
+                    write_obs<CPL, SNAKE>(e, g, out.headcell, obs_t, p.obs_mode, p.obs_n, lds);
+                if (out.done) {
+                    const int *inj = inj_r ? p.inject_reset + (t * p.N + env) * (SNAKE ? 4 : 1) : nullptr;
+                    reset_core<CPL, SNAKE>(e, g, p.seed, call + 1ull, env_id, inj, p.start_y, p.start_x);
+                }
+            }
             if (g.lane == j) {
                 my_a = out.action;
                 my_r = out.reward;
                 my_flags = out.done | (out.selfc << 1) | (out.edgec << 2);
-            }
-            if (p.obs_mode != WURM_OBS_NONE)
-                write_obs<CPL, SNAKE>(e, g, out.headcell, p.obs + (t * p.N + env) * p.obs_elems, p.obs_mode,
-                                      p.obs_n, lds);
-            if (out.done) {
-                const int *inj = inj_r ? p.inject_reset + (t * p.N + env) * (SNAKE ? 4 : 1) : nullptr;
-                reset_core<CPL, SNAKE>(e, g, p.seed, p.call + 2ull * (u64)t + 1ull, env_id, inj, p.start_y, p.start_x);
             }
         }
         if (g.lane < nt) {
@@ -604,6 +855,7 @@ __global__ __launch_bounds__(256) void rollout_kernel(StepArgs p)
             p.edgec[i] = (uint8_t)((my_flags >> 2) & 1);
         }
     }
+    if (SNAKE && fast) fast_sync_bits<CPL>(e, g, f);
     store_state<CPL, SNAKE>(envp, g, e);
 }
 

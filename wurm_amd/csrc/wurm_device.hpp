@@ -76,21 +76,38 @@ __device__ __forceinline__ int rank_below(u64 m)
     return (int)__builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
 }
 
+// DPP lane exchange inside a row of 16 lanes (VALU latency; no LDS round trip like ds_bpermute / __shfl).
+template <int CTRL>
+__device__ __forceinline__ int dpp_row(int v)
+{
+    return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false);
+}
+
+constexpr int DPP_QUAD_XOR1 = 0xB1;        // quad_perm:[1,0,3,2]
+constexpr int DPP_QUAD_XOR2 = 0x4E;        // quad_perm:[2,3,0,1]
+constexpr int DPP_ROW_HALF_MIRROR = 0x141; // lane i <-> 7-i within each 8
+constexpr int DPP_ROW_MIRROR = 0x140;      // lane i <-> 15-i within each 16
+
+// wave-wide max, result wave-uniform (SGPR): 4 DPP steps inside each 16-lane row, then 4 readlanes
 __device__ __forceinline__ int wave_max_i32(int v)
 {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        int o = __shfl_xor(v, off, WAVE);
-        v = o > v ? o : v;
-    }
-    return v;
+    v = max(v, dpp_row<DPP_QUAD_XOR1>(v));
+    v = max(v, dpp_row<DPP_QUAD_XOR2>(v));
+    v = max(v, dpp_row<DPP_ROW_HALF_MIRROR>(v));
+    v = max(v, dpp_row<DPP_ROW_MIRROR>(v));
+    int r0 = __builtin_amdgcn_readlane(v, 0), r1 = __builtin_amdgcn_readlane(v, 16);
+    int r2 = __builtin_amdgcn_readlane(v, 32), r3 = __builtin_amdgcn_readlane(v, 48);
+    return max(max(r0, r1), max(r2, r3));
 }
 
 __device__ __forceinline__ int wave_sum_i32(int v)
 {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, WAVE);
-    return v;
+    v += dpp_row<DPP_QUAD_XOR1>(v);
+    v += dpp_row<DPP_QUAD_XOR2>(v);
+    v += dpp_row<DPP_ROW_HALF_MIRROR>(v);
+    v += dpp_row<DPP_ROW_MIRROR>(v);
+    return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) +
+           __builtin_amdgcn_readlane(v, 48);
 }
 
 __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -102,14 +119,14 @@ __device__ __forceinline__ long long uniform64(long long v)
     return (long long)(((u64)hi << 32) | lo);
 }
 
-// value held by lane `src` (src wave-uniform)
-__device__ __forceinline__ int lane_value(int v, int src) { return __shfl(v, src, WAVE); }
+// value held by lane `src`; src must be wave-uniform (v_readlane_b32 with an SGPR lane select)
+__device__ __forceinline__ int lane_value(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
 
 __device__ __forceinline__ long long lane_value64(long long v, int src)
 {
-    int lo = __shfl((int)(u32)v, src, WAVE);
-    int hi = __shfl((int)(u32)((u64)v >> 32), src, WAVE);
-    return (long long)(((u64)(u32)hi << 32) | (u32)lo);
+    u32 lo = (u32)__builtin_amdgcn_readlane((int)(u32)v, src);
+    u32 hi = (u32)__builtin_amdgcn_readlane((int)(u32)((u64)v >> 32), src);
+    return (long long)(((u64)hi << 32) | lo);
 }
 
 // LDS written by some lanes of a wave and read by other lanes of the SAME wave: the hardware runs one wave's
