@@ -779,7 +779,10 @@ __device__ __forceinline__ void fast_partial_small(const Env<CPL> &e, const Geo 
 
 // T fused step+reset iterations with the env resident in registers.  Lane j of the wave buffers the
 // per-step scalars of step t0+j; they are flushed every 64 steps.
-template <int CPL, bool SNAKE>
+// OBSK >= 0 fixes the observation mode at compile time and INJ = false compiles the injection plumbing out: the
+// flagship configuration (9x9, partial_n / no observation, RNG mode) gets a lean instantiation, everything else the
+// fully general one (OBSK = -1, INJ = true).
+template <int CPL, bool SNAKE, int OBSK = -1, bool INJ = true>
 __global__ __launch_bounds__(256) void rollout_kernel(StepArgs p)
 {
     const int wave = (int)(threadIdx.x >> 6), wpb = (int)(blockDim.x >> 6);
@@ -792,13 +795,16 @@ __global__ __launch_bounds__(256) void rollout_kernel(StepArgs p)
     const u64 env_id = (u64)(p.env_offset + env);
     Env<CPL> e;
     load_state<CPL, SNAKE>(envp, g, e);
-    const bool inj_f = p.inject_food != nullptr, inj_r = p.inject_reset != nullptr;
+    const bool inj_f = INJ && p.inject_food != nullptr, inj_r = INJ && p.inject_reset != nullptr;
+    const int obs_mode = OBSK >= 0 ? OBSK : p.obs_mode;
     Fast f = {-1, 0, 0, 0, 0, -1};
     bool fast = false;
     if (SNAKE) fast = fast_init<CPL>(e, g, f);
-    const bool small_crop = SNAKE && CPL <= 2 && p.obs_mode == WURM_OBS_PARTIAL && p.obs_n <= 6;
+    const bool small_crop = SNAKE && CPL <= 2 && obs_mode == WURM_OBS_PARTIAL && p.obs_n <= 6;
     const Crop cg = make_crop(g.lane, small_crop ? p.obs_n : 0);
     const long long obs_stride = p.N * p.obs_elems;
+    float *obs_t = p.obs + env * p.obs_elems; // observation of step t; advanced by obs_stride per step
+    u64 call = p.call;                        // step t uses call0 + 2t, its reset call0 + 2t + 1
 
     for (long long t0 = 0; t0 < p.T; t0 += 64) {
         const int nt = (int)min((long long)64, p.T - t0);
@@ -811,30 +817,27 @@ __global__ __launch_bounds__(256) void rollout_kernel(StepArgs p)
         // on loop entry, puts `s_waitcnt vmcnt(0)` in front of the per-step readlane, and every step then also waits
         // for the previous step's observation stores to be acknowledged by HBM (vmcnt counts loads and stores).
         asm volatile("" : "+v"(my_a), "+v"(my_inj));
-        for (int j = 0; j < nt; ++j) {
-            const long long t = t0 + j;
+        for (int j = 0; j < nt; ++j, obs_t += obs_stride, call += 2) {
             const long long a_in = lane_value64(my_a, j);
-            const int inj_cell = lane_value(my_inj, j);
-            const u64 call = p.call + 2ull * (u64)t;
-            float *obs_t = p.obs + env * p.obs_elems + t * obs_stride;
+            const int inj_cell = INJ ? lane_value(my_inj, j) : -1;
             StepOut out;
             if (SNAKE && fast) {
                 fast_step<CPL>(e, g, f, a_in, out, p.seed, call, env_id, inj_f, inj_cell);
                 if (small_crop) {
                     if constexpr (CPL <= 2) fast_partial_small<CPL>(e, g, f, obs_t, cg);
-                } else if (p.obs_mode != WURM_OBS_NONE) {
+                } else if (obs_mode != WURM_OBS_NONE) {
                     fast_sync_bits<CPL>(e, g, f);
-                    write_obs<CPL, SNAKE>(e, g, f.hc, obs_t, p.obs_mode, p.obs_n, lds);
+                    write_obs<CPL, SNAKE>(e, g, f.hc, obs_t, obs_mode, p.obs_n, lds);
                 }
                 if (out.done)
                     fast_reset<CPL>(e, g, f, p.seed, call + 1ull, env_id,
-                                    inj_r ? p.inject_reset + (t * p.N + env) * 4 : nullptr);
+                                    inj_r ? p.inject_reset + ((t0 + j) * p.N + env) * 4 : nullptr);
             } else {
                 step_core<CPL, SNAKE, false>(e, g, nullptr, a_in, out, p.seed, call, env_id, inj_f, inj_cell, lds);
-                if (p.obs_mode != WURM_OBS_NONE)
-                    write_obs<CPL, SNAKE>(e, g, out.headcell, obs_t, p.obs_mode, p.obs_n, lds);
+                if (obs_mode != WURM_OBS_NONE)
+                    write_obs<CPL, SNAKE>(e, g, out.headcell, obs_t, obs_mode, p.obs_n, lds);
                 if (out.done) {
-                    const int *inj = inj_r ? p.inject_reset + (t * p.N + env) * (SNAKE ? 4 : 1) : nullptr;
+                    const int *inj = inj_r ? p.inject_reset + ((t0 + j) * p.N + env) * (SNAKE ? 4 : 1) : nullptr;
                     reset_core<CPL, SNAKE>(e, g, p.seed, call + 1ull, env_id, inj, p.start_y, p.start_x);
                 }
             }
@@ -937,7 +940,20 @@ static hipError_t launch_one(Kind kind, const StepArgs &p, dim3 grid, dim3 block
     case K_STEP: hipLaunchKernelGGL((step_kernel<CPL, SNAKE>), grid, block, lds, st, p); break;
     case K_RESET: hipLaunchKernelGGL((reset_kernel<CPL, SNAKE>), grid, block, lds, st, p); break;
     case K_OBSERVE: hipLaunchKernelGGL((observe_kernel<CPL, SNAKE>), grid, block, lds, st, p); break;
-    case K_ROLLOUT: hipLaunchKernelGGL((rollout_kernel<CPL, SNAKE>), grid, block, lds, st, p); break;
+    case K_ROLLOUT:
+        if constexpr (SNAKE && CPL == 2) {
+            const bool rng_mode = p.inject_food == nullptr && p.inject_reset == nullptr;
+            if (rng_mode && p.obs_mode == WURM_OBS_PARTIAL && p.obs_n <= 6) {
+                hipLaunchKernelGGL((rollout_kernel<CPL, SNAKE, WURM_OBS_PARTIAL, false>), grid, block, lds, st, p);
+                break;
+            }
+            if (rng_mode && p.obs_mode == WURM_OBS_NONE) {
+                hipLaunchKernelGGL((rollout_kernel<CPL, SNAKE, WURM_OBS_NONE, false>), grid, block, lds, st, p);
+                break;
+            }
+        }
+        hipLaunchKernelGGL((rollout_kernel<CPL, SNAKE>), grid, block, lds, st, p);
+        break;
     }
     return hipGetLastError();
 }
