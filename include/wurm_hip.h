@@ -172,13 +172,16 @@ int64_t wurm_multi_obs_elems(int obs_mode, int obs_n, int size);
  *   dict the same way, :492); colours (N*K,3) int16 (agent_colours, read by 'partial_n').
  *   Outputs, (N*K) in the reference's agent order env*K + i: boost_this_step, rewards, snake_collision,
  *   edge_collision, food_consumed (info 'food_i'), sizes (info 'size_i'); all_done (N) = dones['__all__'].
- *   obs (K,N,elems): obs[i] is agent_i's tensor. */
+ *   obs (K,N,elems): obs[i] is agent_i's tensor.
+ *   agent_major_f32 / agent_major_u8: nullable.  The same per-agent outputs transposed to agent-major (K,N) rows, so
+ *   that the per-agent dicts of :701-729 are plain row views: f32 (3,K,N) = rewards, food_consumed, sizes;
+ *   u8 (4,K,N) = dones, boost_this_step, snake_collision, edge_collision. */
 int wurm_multi_step(float *foods, float *heads, float *bodies, uint8_t *dones, int64_t *orientations,
                     const int64_t *actions, uint8_t *boost_this_step, float *rewards, uint8_t *snake_collision,
                     uint8_t *edge_collision, float *food_consumed, float *sizes, uint8_t *all_done,
                     const int16_t *colours, float *obs, int obs_mode, int obs_n, int64_t num_envs, int num_snakes,
                     int size, const wurm_multi_config *cfg, uint64_t seed, uint64_t call, int64_t env_offset,
-                    const wurm_multi_inject *inject, void *stream);
+                    const wurm_multi_inject *inject, float *agent_major_f32, uint8_t *agent_major_u8, void *stream);
 
 /* MultiSnake.reset (multi_snake.py:771-836): envs flagged in done_env (N bytes) are rebuilt (_create_envs
  * :996-1019: K snakes placed one after another on free cells away from everything, one food); colours of

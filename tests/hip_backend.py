@@ -220,6 +220,7 @@ def multi_step(self, st, actions, cfg, mode, inject=None):
     rewards, food, size = (self._empty((N * K,), torch.float32) for _ in range(3))
     sc, ec = (self._empty((N * K,), torch.uint8) for _ in range(2))
     all_done = self._empty((N,), torch.uint8)
+    am_f, am_b = self._empty((3, K, N), torch.float32), self._empty((4, K, N), torch.uint8)
     c = _multi_cfg(K, cfg)
     inj_ref, keep = None, []
     if inject is not None:
@@ -232,10 +233,16 @@ def multi_step(self, st, actions, cfg, mode, inject=None):
         _lib.ptr(d['orientations']), _lib.ptr(act), _lib.ptr(d['boost_this_step']), _lib.ptr(rewards), _lib.ptr(sc),
         _lib.ptr(ec), _lib.ptr(food), _lib.ptr(size), _lib.ptr(all_done), _lib.ptr(d['colours']), _lib.ptr(obs), m, n,
         _lib.i64(N), K, S, ctypes.byref(c), _lib.u64(self.seed), _lib.u64(self._next()), _lib.i64(self.env_offset),
-        inj_ref, self._stream())
+        inj_ref, _lib.ptr(am_f), _lib.ptr(am_b), self._stream())
     _lib.check(rc, 'wurm_multi_step')
     torch.cuda.synchronize()
     _multi_back(st, d)
+    # the agent-major copies must be the transposes of the env-major outputs
+    t = lambda x: x.view(N, K).t().contiguous().view(-1)
+    for row, ref in zip(am_f, (rewards, food, size)):
+        assert torch.equal(row.view(-1), t(ref)), 'agent-major f32 copy'
+    for row, ref in zip(am_b, (d['dones'], d['boost_this_step'], sc, ec)):
+        assert torch.equal(row.view(-1), t(ref)), 'agent-major u8 copy'
     return dict(obs=obs.cpu().numpy() if obs is not None else None, rewards=rewards.cpu().numpy(),
                 snake_collision=sc.cpu().numpy(), edge_collision=ec.cpu().numpy(), food=food.cpu().numpy(),
                 size=size.cpu().numpy(), all_done=all_done.cpu().numpy())

@@ -49,6 +49,8 @@ struct MultiArgs {
     wurm_multi_reset_inject rinj;
     int has_rinj;
     uint32_t *err;
+    float *am_f32;
+    uint8_t *am_u8;
     int lds_per_wave, off_body, off_food, off_occ, off_img, off_col;
 };
 
@@ -550,6 +552,16 @@ __global__ __launch_bounds__(256) void multi_step_kernel(MultiArgs p)
         p.edgecol[agent] = (uint8_t)edgecol;
         p.foodcons[agent] = foodcons;
         p.sizes[agent] = (float)L;
+        if (p.am_f32) { // agent-major copies: row i = agent_i over all envs
+            const long long KN = (long long)K * p.N, am = (long long)lane * p.N + env;
+            p.am_f32[am] = reward;
+            p.am_f32[KN + am] = foodcons;
+            p.am_f32[2 * KN + am] = (float)L;
+            p.am_u8[am] = (uint8_t)done;
+            p.am_u8[KN + am] = (uint8_t)boosted;
+            p.am_u8[2 * KN + am] = (uint8_t)snakecol;
+            p.am_u8[3 * KN + am] = (uint8_t)edgecol;
+        }
     }
     const bool alld = ballot(snake && !done) == 0; // :703
     if (lane == 0) p.all_done[env] = (uint8_t)alld;
@@ -909,7 +921,7 @@ int wurm_multi_step(float *foods, float *heads, float *bodies, uint8_t *dones, i
                     uint8_t *edge_collision, float *food_consumed, float *sizes, uint8_t *all_done,
                     const int16_t *colours, float *obs, int obs_mode, int obs_n, int64_t num_envs, int num_snakes,
                     int size, const wurm_multi_config *cfg, uint64_t seed, uint64_t call, int64_t env_offset,
-                    const wurm_multi_inject *inject, void *stream)
+                    const wurm_multi_inject *inject, float *agent_major_f32, uint8_t *agent_major_u8, void *stream)
 {
     int rc = multi_check_args(num_envs, num_snakes, size, obs_mode, obs_n, obs);
     if (rc) return rc;
@@ -926,6 +938,7 @@ int wurm_multi_step(float *foods, float *heads, float *bodies, uint8_t *dones, i
     p.obs_elems = multi_obs_elems(obs_mode, obs_n, size); p.N = num_envs; p.K = num_snakes; p.S = size; p.cfg = *cfg;
     p.seed = seed; p.call = call; p.env_offset = env_offset;
     if (inject) { p.inj = *inject; p.has_inj = 1; }
+    if (agent_major_f32 && agent_major_u8) { p.am_f32 = agent_major_f32; p.am_u8 = agent_major_u8; }
     return multi_launch(MK_STEP, p, stream);
 }
 

@@ -90,16 +90,22 @@ __device__ __forceinline__ void store_state(float *__restrict__ envp, const Geo 
     }
 }
 
+constexpr int NO_CELL = 1 << 20;
+
+// lowest cell (row-major) whose bit is set in the per-lane bit set `bits` (bit k <=> cell lane + 64k), or -1.
+// One per-lane ctz + one DPP min reduction — no per-k ballots (they cost two SGPRs each and, fully unrolled for
+// large grids, drown the kernel in SGPR spills).
+__device__ __forceinline__ int first_cell(u64 bits, int lane)
+{
+    int mine = bits ? lane + 64 * (__ffsll((long long)bits) - 1) : NO_CELL;
+    int c = wave_min_i32(mine);
+    return c >= NO_CELL ? -1 : c;
+}
+
 template <int CPL>
 __device__ __forceinline__ int find_head(const Env<CPL> &e)
 {
-    int cell = -1;
-#pragma unroll
-    for (int k = 0; k < CPL; ++k) {
-        u64 m = ballot((e.head >> k) & 1);
-        if (cell < 0 && m) cell = 64 * k + first_bit(m);
-    }
-    return cell;
+    return first_cell(e.head, (int)(threadIdx.x & 63u));
 }
 
 // ------------------------------------------------------------------------------------------------ orientation
@@ -151,20 +157,33 @@ __device__ __forceinline__ int slow_orientation(const Env<CPL> &e, const Geo &g,
 // determine_orientations (wurm/utils.py:36-65) of the env in registers.  Well-formed snake (exactly one cell == L
 // and one == L-1, L >= 2): the filter response is 2 only for the tap pointing from the neck to the head, so the
 // orientation follows from the two cells; anything else takes the exact stencil path.
+// determine_orientations (wurm/utils.py:36-65) of the env in registers.  Well-formed snake (exactly one cell == L
+// and one == L-1, L >= 2): the filter response is 2 only for the tap pointing from the neck to the head, so the
+// orientation follows from the two cells; anything else takes the exact stencil path.
+// top_two: count of cells equal to L and to L-1 and the lowest such cells (per-lane partials + 3 wave reductions).
+template <int CPL>
+__device__ __forceinline__ void top_two(const Env<CPL> &e, const Geo &g, int L, int &cntL, int &cntN, int &cellL,
+                                        int &cellN)
+{
+    int packed = 0, cL = NO_CELL, cN = NO_CELL;
+#pragma unroll
+    for (int k = CPL - 1; k >= 0; --k) {
+        const bool v = (g.valid >> k) & 1;
+        if (v && e.body[k] == L) { packed += 1; cL = g.lane + 64 * k; }
+        if (v && e.body[k] == L - 1) { packed += 1 << 16; cN = g.lane + 64 * k; }
+    }
+    packed = wave_sum_i32(packed);
+    cntL = packed & 0xffff;
+    cntN = packed >> 16;
+    cellL = wave_min_i32(cL);
+    cellN = wave_min_i32(cN);
+}
+
 template <int CPL>
 __device__ __forceinline__ int orientation_of(const Env<CPL> &e, const Geo &g, int L, signed char *lds)
 {
-    int cntL = 0, cntN = 0, cellL = -1, cellN = -1;
-#pragma unroll
-    for (int k = 0; k < CPL; ++k) {
-        bool v = (g.valid >> k) & 1;
-        u64 mL = ballot(v && e.body[k] == L);
-        u64 mN = ballot(v && e.body[k] == L - 1);
-        cntL += popc64(mL);
-        cntN += popc64(mN);
-        if (cellL < 0 && mL) cellL = 64 * k + first_bit(mL);
-        if (cellN < 0 && mN) cellN = 64 * k + first_bit(mN);
-    }
+    int cntL, cntN, cellL, cellN;
+    top_two<CPL>(e, g, L, cntL, cntN, cellL, cellN);
     if (cntL == 1 && cntN == 1 && L >= 2) {
         int yL = div_size(cellL, g.rcpS), xL = cellL - yL * g.S;
         int yN = div_size(cellN, g.rcpS), xN = cellN - yN * g.S;
@@ -193,25 +212,29 @@ __device__ __forceinline__ void add_food(Env<CPL> &e, const Geo &g, float *__res
         }
         return;
     }
-    u64 occupied = e.food | e.head;
-    int n_free = 0;
+    const u64 occupied = e.food | e.head;
+    u64 fr = 0; // bit k: cell lane + 64k is free
 #pragma unroll
-    for (int k = 0; k < CPL; ++k) {
-        bool fr = ((g.interior >> k) & 1) && !((occupied >> k) & 1) && (!SNAKE || e.body[k] == 0);
-        n_free += popc64(ballot(fr));
-    }
+    for (int k = 0; k < CPL; ++k)
+        if (((g.interior >> k) & 1) && !((occupied >> k) & 1) && (!SNAKE || e.body[k] == 0)) fr |= 1ull << k;
+    const int n_free = wave_sum_i32(__popcll(fr));
     if (n_free == 0) return;
-    int K = (int)mulhi_range(word, (u32)n_free);
+    const int K = (int)mulhi_range(word, (u32)n_free);
+    // row-major order = k-major, lane-minor: walk the k planes (NOT unrolled: one live ballot at a time)
     int base = 0;
-#pragma unroll
+#pragma unroll 1
     for (int k = 0; k < CPL; ++k) {
-        bool fr = ((g.interior >> k) & 1) && !((occupied >> k) & 1) && (!SNAKE || e.body[k] == 0);
-        u64 m = ballot(fr);
-        if (fr && base + rank_below(m) == K) {
-            e.food |= 1ull << k;
-            if (WRITE) envp[g.lane + 64 * k] = 1.0f;
+        const bool b = (fr >> k) & 1;
+        const u64 m = ballot(b);
+        const int cnt = popc64(m);
+        if (K < base + cnt) {
+            if (b && base + rank_below(m) == K) {
+                e.food |= 1ull << k;
+                if (WRITE) envp[g.lane + 64 * k] = 1.0f;
+            }
+            break;
         }
-        base += popc64(m);
+        base += cnt;
     }
 }
 
@@ -437,12 +460,7 @@ __device__ __forceinline__ void write_obs(const Env<CPL> &e, const Geo &g, int h
             }
         }
     } else if (mode == WURM_OBS_POSITIONS) { // argmax of the head and food channels (first maximum; 0 if empty)
-        int fcell = -1;
-#pragma unroll
-        for (int k = 0; k < CPL; ++k) {
-            u64 m = ballot((e.food >> k) & 1);
-            if (fcell < 0 && m) fcell = 64 * k + first_bit(m);
-        }
+        const int fcell = first_cell(e.food, lane);
         int h = headcell < 0 ? 0 : headcell, f = fcell < 0 ? 0 : fcell;
         int hy = div_size(h, g.rcpS), fy = div_size(f, g.rcpS);
         if (lane < 4) o[lane] = (float)(lane == 0 ? hy : lane == 1 ? h - hy * S : lane == 2 ? fy : f - fy * S);
@@ -574,27 +592,15 @@ struct Fast {
 template <int CPL>
 __device__ __forceinline__ bool fast_init(const Env<CPL> &e, const Geo &g, Fast &f)
 {
-    int nhead = 0, nfood = 0, hc = -1, fc = -1, lm = 0;
+    int lm = 0;
 #pragma unroll
-    for (int k = 0; k < CPL; ++k) {
-        u64 mh = ballot((e.head >> k) & 1), mf = ballot((e.food >> k) & 1);
-        nhead += popc64(mh);
-        nfood += popc64(mf);
-        if (hc < 0 && mh) hc = 64 * k + first_bit(mh);
-        if (fc < 0 && mf) fc = 64 * k + first_bit(mf);
-        lm = max(lm, e.body[k]);
-    }
+    for (int k = 0; k < CPL; ++k) lm = max(lm, e.body[k]);
+    const int counts = wave_sum_i32(__popcll(e.head) | (__popcll(e.food) << 16));
+    const int nhead = counts & 0xffff, nfood = counts >> 16;
+    const int hc = first_cell(e.head, g.lane), fc = first_cell(e.food, g.lane);
     const int L = wave_max_i32(lm);
-    int cntL = 0, cntN = 0, cellL = -1, cellN = -1;
-#pragma unroll
-    for (int k = 0; k < CPL; ++k) {
-        bool v = (g.valid >> k) & 1;
-        u64 mL = ballot(v && e.body[k] == L), mN = ballot(v && e.body[k] == L - 1);
-        cntL += popc64(mL);
-        cntN += popc64(mN);
-        if (cellL < 0 && mL) cellL = 64 * k + first_bit(mL);
-        if (cellN < 0 && mN) cellN = 64 * k + first_bit(mN);
-    }
+    int cntL, cntN, cellL, cellN;
+    top_two<CPL>(e, g, L, cntL, cntN, cellL, cellN);
     if (nhead > 1 || nfood > 1 || cntL != 1 || cntN != 1 || L < 2 || (hc >= 0 && hc != cellL)) return false;
     int yL = div_size(cellL, g.rcpS), xL = cellL - yL * g.S;
     int yN = div_size(cellN, g.rcpS), xN = cellN - yN * g.S;
@@ -613,23 +619,25 @@ __device__ __forceinline__ bool fast_init(const Env<CPL> &e, const Geo &g, Fast 
 template <int CPL>
 __device__ __forceinline__ int fast_food_cell(const Env<CPL> &e, const Geo &g, u32 word)
 {
-    int n_free = 0;
+    u64 fr = 0;
 #pragma unroll
-    for (int k = 0; k < CPL; ++k) n_free += popc64(ballot(((g.interior >> k) & 1) && e.body[k] == 0));
+    for (int k = 0; k < CPL; ++k)
+        if (((g.interior >> k) & 1) && e.body[k] == 0) fr |= 1ull << k;
+    const int n_free = wave_sum_i32(__popcll(fr));
     if (n_free == 0) return -1;
     const int K = (int)mulhi_range(word, (u32)n_free);
-    int base = 0, cell = -1;
-#pragma unroll
+    int base = 0;
+#pragma unroll 1
     for (int k = 0; k < CPL; ++k) {
-        u64 m = ballot(((g.interior >> k) & 1) && e.body[k] == 0);
-        int cnt = popc64(m);
-        if (cell < 0 && K < base + cnt) { // the (K - base)-th set bit of m
-            u64 hit = ballot(((m >> g.lane) & 1) && rank_below(m) == K - base);
-            cell = 64 * k + first_bit(hit);
+        const u64 m = ballot((fr >> k) & 1);
+        const int cnt = popc64(m);
+        if (K < base + cnt) { // the (K - base)-th set bit of m
+            const u64 hit = ballot(((m >> g.lane) & 1) && rank_below(m) == K - base);
+            return 64 * k + first_bit(hit);
         }
         base += cnt;
     }
-    return cell;
+    return -1;
 }
 
 // step_core with carried scalars (single_snake.py:197-304; same line references as step_core)

@@ -100,6 +100,17 @@ __device__ __forceinline__ int wave_max_i32(int v)
     return max(max(r0, r1), max(r2, r3));
 }
 
+__device__ __forceinline__ int wave_min_i32(int v)
+{
+    v = min(v, dpp_row<DPP_QUAD_XOR1>(v));
+    v = min(v, dpp_row<DPP_QUAD_XOR2>(v));
+    v = min(v, dpp_row<DPP_ROW_HALF_MIRROR>(v));
+    v = min(v, dpp_row<DPP_ROW_MIRROR>(v));
+    int r0 = __builtin_amdgcn_readlane(v, 0), r1 = __builtin_amdgcn_readlane(v, 16);
+    int r2 = __builtin_amdgcn_readlane(v, 32), r3 = __builtin_amdgcn_readlane(v, 48);
+    return min(min(r0, r1), min(r2, r3));
+}
+
 __device__ __forceinline__ int wave_sum_i32(int v)
 {
     v += dpp_row<DPP_QUAD_XOR1>(v);

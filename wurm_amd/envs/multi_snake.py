@@ -124,7 +124,7 @@ class MultiSnake(object):
         self.agent_colours = torch.empty((N * K, 3), dtype=torch.short, device=dev)
         rc = _lib.lib().wurm_multi_colours(_lib.ptr(self.agent_colours), _lib.i64(N), K,
                                            int(self.colour_mode == 'fixed'), _lib.u64(self.seed),
-                                           _lib.u64(self._next_call()), _lib.i64(self.env_offset), _lib.stream_ptr())
+                                           _lib.u64(self._next_call()), _lib.i64(self.env_offset), _lib.stream_ptr(self.device.index))
         _lib.check(rc, 'MultiSnake.get_n_colours')
         self.num_colours = self.agent_colours.shape[0]
 
@@ -260,7 +260,7 @@ class MultiSnake(object):
         foods, heads, bodies, dones, _, colours, boost = self._state()
         rc = _lib.lib().wurm_multi_observe(_lib.ptr(foods), _lib.ptr(heads), _lib.ptr(bodies), _lib.ptr(dones),
                                            _lib.ptr(boost), _lib.ptr(colours), _lib.ptr(obs), m, n,
-                                           _lib.i64(self.num_envs), self.num_snakes, self.size, _lib.stream_ptr())
+                                           _lib.i64(self.num_envs), self.num_snakes, self.size, _lib.stream_ptr(self.device.index))
         _lib.check(rc, 'MultiSnake._observe')
         return self._obs_dict(obs)
 
@@ -289,8 +289,10 @@ class MultiSnake(object):
         foods, heads, bodies, dones, orientations, colours, _ = self._state()
         m, n, obs = self._obs_args(self.observation_mode)
 
-        fl = torch.empty((3, N * K), dtype=torch.float32, device=dev)   # rewards, food consumed, sizes
+        fl = torch.empty((3, N * K), dtype=torch.float32, device=dev)   # rewards, food consumed, sizes (env-major)
         bl = torch.empty((3, N * K), dtype=torch.bool, device=dev)      # boost_this_step, snake / edge collision
+        am_f = torch.empty((3, K, N), dtype=torch.float32, device=dev)  # agent-major: rewards, food, sizes
+        am_b = torch.empty((4, K, N), dtype=torch.bool, device=dev)     # agent-major: dones, boost, snake, edge
         all_done = torch.empty(N, dtype=torch.bool, device=dev)
         cfg = self._cfg()
         rc = _lib.lib().wurm_multi_step(
@@ -298,22 +300,24 @@ class MultiSnake(object):
             _lib.ptr(stacked), _lib.ptr(bl[0]), _lib.ptr(fl[0]), _lib.ptr(bl[1]), _lib.ptr(bl[2]), _lib.ptr(fl[1]),
             _lib.ptr(fl[2]), _lib.ptr(all_done), _lib.ptr(colours), _lib.ptr(obs), m, n, _lib.i64(N), K, S,
             ctypes.byref(cfg), _lib.u64(self.seed), _lib.u64(self._next_call()), _lib.i64(self.env_offset), None,
-            _lib.stream_ptr())
+            _lib.ptr(am_f), _lib.ptr(am_b), _lib.stream_ptr(self.device.index))
         _lib.check(rc, 'MultiSnake.step')
 
         self.boost_this_step = bl[0]
         self.rewards = fl[0]
 
-        dones_out = self._per_agent(dones, 'agent_')
+        # reference :701-729 — per-agent dicts; the kernel wrote agent-major rows, so these are plain views
+        agents = range(K)
+        dones_out = {f'agent_{i}': am_b[0, i] for i in agents}
         dones_out['__all__'] = all_done | (self.env_lifetimes > self.max_env_lifetime)  # :703-705
-        rewards = self._per_agent(self.rewards, 'agent_')
+        rewards = {f'agent_{i}': am_f[0, i] for i in agents}
 
         self.info = {}
-        self.info.update(self._per_agent(bl[1], 'snake_collision_'))
-        self.info.update(self._per_agent(bl[2], 'edge_collision_'))
-        self.info.update(self._per_agent(fl[1], 'food_'))
-        self.info.update(self._per_agent(bl[0], 'boost_'))
-        self.info.update(self._per_agent(fl[2], 'size_'))
+        self.info.update({f'snake_collision_{i}': am_b[2, i] for i in agents})
+        self.info.update({f'edge_collision_{i}': am_b[3, i] for i in agents})
+        self.info.update({f'food_{i}': am_f[1, i] for i in agents})
+        self.info.update({f'boost_{i}': am_b[1, i] for i in agents})
+        self.info.update({f'size_{i}': am_f[2, i] for i in agents})
 
         return self._obs_dict(obs), rewards, dones_out, self.info
 
@@ -325,7 +329,7 @@ class MultiSnake(object):
         err = torch.empty(self.num_envs, dtype=torch.int32, device=self.device)
         rc = _lib.lib().wurm_multi_check(_lib.ptr(foods), _lib.ptr(heads), _lib.ptr(bodies), _lib.ptr(dones),
                                          _lib.ptr(err), _lib.i64(self.num_envs), self.num_snakes, self.size,
-                                         _lib.stream_ptr())
+                                         _lib.stream_ptr(self.device.index))
         _lib.check(rc, 'MultiSnake.check_consistency')
         from wurm_amd.utils import _raise_for
         bits = (err.unsqueeze(-1) >> torch.arange(10, device=self.device, dtype=torch.int32)) & 1
@@ -348,7 +352,7 @@ class MultiSnake(object):
             _lib.ptr(foods), _lib.ptr(heads), _lib.ptr(bodies), _lib.ptr(dones), _lib.ptr(orientations),
             _lib.ptr(colours), _lib.ptr(done), _lib.ptr(status), _lib.ptr(boost), _lib.ptr(obs), m, n,
             _lib.i64(self.num_envs), self.num_snakes, self.size, ctypes.byref(cfg), _lib.u64(self.seed),
-            _lib.u64(self._next_call()), _lib.i64(self.env_offset), None, _lib.stream_ptr())
+            _lib.u64(self._next_call()), _lib.i64(self.env_offset), None, _lib.stream_ptr(self.device.index))
         _lib.check(rc, 'MultiSnake.reset')
         if want_status:
             return int(status.item())
@@ -394,7 +398,7 @@ class MultiSnake(object):
             _lib.ptr(foods), _lib.ptr(heads), _lib.ptr(bodies), _lib.ptr(dones), _lib.ptr(orientations),
             _lib.ptr(colours), _lib.ptr(ones), _lib.ptr(status), None, None, _lib.OBS_NONE, 0, _lib.i64(num_envs), K,
             S, ctypes.byref(cfg), _lib.u64(self.seed), _lib.u64(self._next_call()), _lib.i64(self.env_offset), None,
-            _lib.stream_ptr())
+            _lib.stream_ptr(self.device.index))
         _lib.check(rc, 'MultiSnake._create_envs')
         if int(status.item()):
             raise RuntimeError('There is no available locations to create snake!')

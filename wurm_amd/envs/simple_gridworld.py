@@ -85,7 +85,7 @@ class SimpleGridworld(object):
         m, n = _lib.parse_obs_mode(observation_mode)
         obs = torch.empty(shape, dtype=torch.float32, device=self.device)
         rc = _lib.lib().wurm_grid_observe(_lib.ptr(self._state()), _lib.ptr(obs), m, n, _lib.i64(self.num_envs),
-                                          self.size, _lib.stream_ptr())
+                                          self.size, _lib.stream_ptr(self.device.index))
         _lib.check(rc, 'SimpleGridworld._observe')
         return obs
 
@@ -119,7 +119,7 @@ class SimpleGridworld(object):
         rc = _lib.lib().wurm_grid_step(
             _lib.ptr(envs), _lib.ptr(act), _lib.ACT_I64 if act.dtype == torch.long else _lib.ACT_I32,
             _lib.ptr(reward), _lib.ptr(done), _lib.ptr(edge_collision), _lib.ptr(obs), m, n, _lib.i64(N), self.size,
-            _lib.u64(self.seed), _lib.u64(self._next_call()), _lib.i64(self.env_offset), None, _lib.stream_ptr())
+            _lib.u64(self.seed), _lib.u64(self._next_call()), _lib.i64(self.env_offset), None, _lib.stream_ptr(self.device.index))
         _lib.check(rc, 'SimpleGridworld.step')
         info = {'edge_collision': edge_collision}
         self.done = done
@@ -142,7 +142,7 @@ class SimpleGridworld(object):
         rc = _lib.lib().wurm_grid_reset(
             _lib.ptr(envs), _lib.ptr(done), _lib.ptr(obs), m, n, _lib.i64(self.num_envs), self.size,
             int(self.start_location[0]), int(self.start_location[1]), _lib.u64(self.seed),
-            _lib.u64(self._next_call()), _lib.i64(self.env_offset), None, _lib.stream_ptr())
+            _lib.u64(self._next_call()), _lib.i64(self.env_offset), None, _lib.stream_ptr(self.device.index))
         _lib.check(rc, 'SimpleGridworld.reset')
         return obs
 
@@ -180,7 +180,7 @@ class SimpleGridworld(object):
             _lib.ptr(envs), _lib.ptr(actions), _lib.ACT_I64 if actions.dtype == torch.long else _lib.ACT_I32,
             _lib.ptr(reward), _lib.ptr(flags[0]), _lib.ptr(flags[1]), _lib.ptr(obs), m, n, _lib.i64(N), self.size,
             _lib.i64(T), int(self.start_location[0]), int(self.start_location[1]), _lib.u64(self.seed),
-            _lib.u64(self._next_call(2 * T)), _lib.i64(self.env_offset), None, None, _lib.stream_ptr())
+            _lib.u64(self._next_call(2 * T)), _lib.i64(self.env_offset), None, None, _lib.stream_ptr(self.device.index))
         _lib.check(rc, 'SimpleGridworld.rollout')
         self.done = torch.zeros(N, dtype=torch.bool, device=self.device)
         return {'observations': obs, 'rewards': reward, 'dones': flags[0], 'edge_collision': flags[1]}

@@ -61,6 +61,7 @@ class SingleSnake(object):
         self.seed = _draw_seed() if seed is None else int(seed)
         self.env_offset = int(env_offset)
         self._call = 0
+        self._mode_cache = {}
 
         if render_args is None:
             self.render_args = {'num_rows': 1, 'num_cols': 1, 'size': 256}
@@ -122,16 +123,26 @@ class SingleSnake(object):
             return _lib.OBS_PARTIAL, int(src.split('_')[-1])
         raise Exception  # reference :194-195
 
+    def _mode_info(self, observation_mode: str):
+        """(mode code, window size, observation shape) of an observation mode string, cached per string."""
+        key = (observation_mode, self.observation_mode if isinstance(observation_mode, str) and
+               observation_mode.startswith('partial_') else None)
+        info = self._mode_cache.get(key)
+        if info is None:
+            m, n = self._parse_mode(observation_mode)
+            shape = self._obs_shape(observation_mode if m != _lib.OBS_PARTIAL else f'partial_{n}')
+            info = self._mode_cache[key] = (m, n, shape)
+        return info
+
     # ------------------------------------------------------------------ observations
 
     def _observe(self, observation_mode: str = 'default') -> torch.Tensor:
         """reference :130-195"""
-        m, n = self._parse_mode(observation_mode)
+        m, n, shape = self._mode_info(observation_mode)
         envs = self._state()
-        obs = torch.empty(self._obs_shape(observation_mode if m != _lib.OBS_PARTIAL else f'partial_{n}'),
-                          dtype=torch.float32, device=self.device)
+        obs = torch.empty(shape, dtype=torch.float32, device=self.device)
         rc = _lib.lib().wurm_single_observe(_lib.ptr(envs), _lib.ptr(obs), m, n, _lib.i64(self.num_envs),
-                                            self.size, _lib.stream_ptr())
+                                            self.size, _lib.stream_ptr(self.device.index))
         _lib.check(rc, 'SingleSnake._observe')
         return obs
 
@@ -159,8 +170,8 @@ class SingleSnake(object):
         act = actions
         if act.device != self.device or not act.is_contiguous() or act.dim() != 1:
             act = actions.to(self.device).reshape(N).contiguous()
-        m, n = self._parse_mode(self.observation_mode)
-        obs = torch.empty(self._obs_shape(self.observation_mode), dtype=torch.float32, device=self.device)
+        m, n, shape = self._mode_info(self.observation_mode)
+        obs = torch.empty(shape, dtype=torch.float32, device=self.device)
         reward = torch.empty(N, dtype=torch.float32, device=self.device)
         flags = torch.empty((3, N), dtype=torch.bool, device=self.device)
         done, self_collision, edge_collision = flags[0], flags[1], flags[2]
@@ -169,7 +180,7 @@ class SingleSnake(object):
             _lib.ptr(envs), _lib.ptr(act), _lib.ACT_I64 if act.dtype == torch.long else _lib.ACT_I32,
             _lib.ptr(reward), _lib.ptr(done), _lib.ptr(self_collision), _lib.ptr(edge_collision), _lib.ptr(obs),
             m, n, _lib.i64(N), self.size, _lib.u64(self.seed), _lib.u64(self._next_call()),
-            _lib.i64(self.env_offset), None, _lib.stream_ptr())
+            _lib.i64(self.env_offset), None, _lib.stream_ptr(self.device.index))
         _lib.check(rc, 'SingleSnake.step')
         if act is not actions:
             actions.copy_(act.view_as(actions))  # keep the in-place side effect (:222)
@@ -190,13 +201,13 @@ class SingleSnake(object):
             return self._observe(self.observation_mode) if observe else None
         envs = self._state()
         if observe:
-            m, n = self._parse_mode(self.observation_mode)
-            obs = torch.empty(self._obs_shape(self.observation_mode), dtype=torch.float32, device=self.device)
+            m, n, shape = self._mode_info(self.observation_mode)
+            obs = torch.empty(shape, dtype=torch.float32, device=self.device)
         else:
             m, n, obs = _lib.OBS_NONE, 0, None
         rc = _lib.lib().wurm_single_reset(
             _lib.ptr(envs), _lib.ptr(done), _lib.ptr(obs), m, n, _lib.i64(self.num_envs), self.size,
-            _lib.u64(self.seed), _lib.u64(self._next_call()), _lib.i64(self.env_offset), None, _lib.stream_ptr())
+            _lib.u64(self.seed), _lib.u64(self._next_call()), _lib.i64(self.env_offset), None, _lib.stream_ptr(self.device.index))
         _lib.check(rc, 'SingleSnake.reset')
         return obs
 
@@ -228,7 +239,7 @@ class SingleSnake(object):
         done = torch.ones(num_envs, dtype=torch.bool, device=self.device)
         rc = _lib.lib().wurm_single_reset(
             _lib.ptr(envs), _lib.ptr(done), None, _lib.OBS_NONE, 0, _lib.i64(num_envs), self.size,
-            _lib.u64(self.seed), _lib.u64(self._next_call()), _lib.i64(self.env_offset), None, _lib.stream_ptr())
+            _lib.u64(self.seed), _lib.u64(self._next_call()), _lib.i64(self.env_offset), None, _lib.stream_ptr(self.device.index))
         _lib.check(rc, 'SingleSnake._create_envs')
         return envs
 
@@ -249,8 +260,8 @@ class SingleSnake(object):
         envs = self._state()
         T, N = actions.shape
         if return_observations:
-            m, n = self._parse_mode(self.observation_mode)
-            obs = torch.empty((T,) + self._obs_shape(self.observation_mode), dtype=torch.float32, device=self.device)
+            m, n, shape = self._mode_info(self.observation_mode)
+            obs = torch.empty((T,) + shape, dtype=torch.float32, device=self.device)
         else:
             m, n, obs = _lib.OBS_NONE, 0, None
         reward = torch.empty((T, N), dtype=torch.float32, device=self.device)
@@ -259,7 +270,7 @@ class SingleSnake(object):
             _lib.ptr(envs), _lib.ptr(actions), _lib.ACT_I64 if actions.dtype == torch.long else _lib.ACT_I32,
             _lib.ptr(reward), _lib.ptr(flags[0]), _lib.ptr(flags[1]), _lib.ptr(flags[2]), _lib.ptr(obs), m, n,
             _lib.i64(N), self.size, _lib.i64(T), _lib.u64(self.seed), _lib.u64(self._next_call(2 * T)),
-            _lib.i64(self.env_offset), None, None, _lib.stream_ptr())
+            _lib.i64(self.env_offset), None, None, _lib.stream_ptr(self.device.index))
         _lib.check(rc, 'SingleSnake.rollout')
         self.done = torch.zeros(N, dtype=torch.bool, device=self.device)  # every done env was reset
         return {'observations': obs, 'rewards': reward, 'dones': flags[0], 'self_collision': flags[1],
