@@ -93,35 +93,59 @@ __device__ __forceinline__ int BV(const Ctx &cx, int s, int c) { return cx.body[
 // ------------------------------------------------------------------------------------------------ load / store
 
 // HBM -> LDS.  Returns the lane's original food bits (bit k = food at cell lane + 64k).
+// heads and bodies of one env are each one contiguous run of K*C floats with the same [K][C] layout as the LDS body
+// grid, so they are copied as flat lane-strided streams, LOAD_CHUNK dwords per lane in flight at a time (the wave is
+// alone with its latency at 16 waves/CU: few large batches of loads, not many small ones).
+constexpr int LOAD_CHUNK = 16;
+
 __device__ __forceinline__ u64 load_env(const Ctx &cx, const float *__restrict__ foodp,
                                         const float *__restrict__ headp, const float *__restrict__ bodyp)
 {
-    const int C = cx.C, lane = cx.lane;
+    const int C = cx.C, lane = cx.lane, KC = cx.K * C;
     if (lane < cx.K) {
         cx.hcell[lane] = -1;
         cx.lmax[lane] = 0;
     }
     wave_lds_sync();
-    u64 fbits = 0;
-    for (int k = 0; k < cx.cpl; ++k) {
-        int c = lane + 64 * k;
-        if (c < C) {
-            int f = foodp[c] > 0.5f;
-            cx.food[c] = (unsigned char)f;
-            fbits |= (u64)f << k;
+    const float rcpC = 1.0f / (float)C;
+    for (int base = 0; base < KC; base += 64 * LOAD_CHUNK) {
+        float hv[LOAD_CHUNK], bv[LOAD_CHUNK];
+#pragma unroll
+        for (int j = 0; j < LOAD_CHUNK; ++j) {
+            // unconditional loads (index clamped into the env): a `cond ? load : 0` would make the compiler wait
+            // for every load at its own join point and serialise the batch
+            const int i = min(base + lane + 64 * j, KC - 1);
+            hv[j] = headp[i];
+            bv[j] = bodyp[i];
+        }
+#pragma unroll
+        for (int j = 0; j < LOAD_CHUNK; ++j) {
+            const int i = base + lane + 64 * j;
+            if (i < KC) {
+                const int bi = __float2int_rn(bv[j]);
+                cx.body[i] = (unsigned short)(bi != 0 ? ((bi & VMASK) | DIRTY) : 0);
+                if (hv[j] > 0.5f || bi > 0) { // rare: a head cell or a body cell
+                    const int s = div_size(i, rcpC);
+                    if (hv[j] > 0.5f) cx.hcell[s] = i - s * C;
+                    if (bi > 0) atomicMax(&cx.lmax[s], bi);
+                }
+            }
         }
     }
-    for (int s = 0; s < cx.K; ++s) {
-        const float *hp = headp + (size_t)s * C, *bp = bodyp + (size_t)s * C;
-#pragma unroll 4
-        for (int k = 0; k < cx.cpl; ++k) {
-            int c = lane + 64 * k;
-            if (c < C) {
-                float h = hp[c], b = bp[c];
-                int bi = __float2int_rn(b);
-                cx.body[s * C + c] = (unsigned short)(bi != 0 ? ((bi & VMASK) | DIRTY) : 0);
-                if (h > 0.5f) cx.hcell[s] = c;
-                if (bi > 0) atomicMax(&cx.lmax[s], bi);
+    u64 fbits = 0;
+    for (int k0 = 0; k0 < cx.cpl; k0 += LOAD_CHUNK) {
+        float fv[LOAD_CHUNK];
+#pragma unroll
+        for (int j = 0; j < LOAD_CHUNK; ++j) {
+            fv[j] = foodp[min(lane + 64 * (k0 + j), C - 1)];
+        }
+#pragma unroll
+        for (int j = 0; j < LOAD_CHUNK; ++j) {
+            const int c = lane + 64 * (k0 + j);
+            if (k0 + j < cx.cpl && c < C) {
+                const int f = fv[j] > 0.5f;
+                cx.food[c] = (unsigned char)f;
+                fbits |= (u64)f << (k0 + j);
             }
         }
     }
@@ -137,6 +161,7 @@ __device__ __forceinline__ void store_env(const Ctx &cx, float *__restrict__ foo
     for (int s = 0; s < cx.K; ++s) {
         float *bp = bodyp + (size_t)s * C, *hp = headp + (size_t)s * C;
         int hs = cx.hcell[s];
+#pragma unroll 4
         for (int k = 0; k < cx.cpl; ++k) {
             int c = lane + 64 * k;
             if (c < C) {
@@ -185,6 +210,7 @@ __device__ __forceinline__ void run_phase(const Ctx &cx, bool who, int dir, int 
         int s = first_bit(m);
         m &= m - 1;
         unsigned short *b = cx.body + s * C;
+#pragma unroll 4
         for (int k = 0; k < cx.cpl; ++k) {
             int c = lane + 64 * k;
             if (c < C) {
@@ -202,6 +228,7 @@ __device__ __forceinline__ void run_phase(const Ctx &cx, bool who, int dir, int 
     bool coll = false;
     if (who && hc >= 0) {
         int sum = 0;
+#pragma unroll 4
         for (int t = 0; t < K; ++t) sum += BV(cx, t, hc);
         coll = sum > 0;
     }
@@ -292,6 +319,7 @@ __device__ __forceinline__ u64 free_cells(const Ctx &cx, int hc, int margin)
         if (y < margin || x < margin || y > S - 1 - margin || x > S - 1 - margin) continue;
         if (cx.food[c] || ((headbits >> k) & 1)) continue;
         bool occ = false;
+#pragma unroll 4
         for (int s = 0; s < cx.K; ++s) occ |= BV(cx, s, c) > 0;
         if (!occ) fr |= 1ull << k;
     }
@@ -349,6 +377,7 @@ __device__ __forceinline__ void observe_full(const Ctx &cx, const MultiArgs &p, 
         int y = div_size(c, cx.rcpS), x = c - y * S;
         bool edge = y == 0 || x == 0 || y == S - 1 || x == S - 1;
         u64 bm = 0;
+#pragma unroll 4
         for (int s = 0; s < K; ++s) bm |= (u64)(BV(cx, s, c) > 0) << s;
         int ho = (int)cx.occ[c] - 1;
         bool fd = cx.food[c] != 0;
@@ -389,6 +418,7 @@ __device__ __forceinline__ void observe_partial(const Ctx &cx, const MultiArgs &
         if (c >= C) continue;
         int y = div_size(c, cx.rcpS), x = c - y * S;
         float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;
+#pragma unroll 2
         for (int s = 0; s < K; ++s) {
             float bf = BV(cx, s, c) > 0 ? 1.0f : 0.0f, hf = cx.hcell[s] == c ? 1.0f : 0.0f;
             float inten = bf * 1.0f / 3.0f + hf * 1.0f / 3.0f; // :197
@@ -601,6 +631,7 @@ __device__ __forceinline__ void build_occ(const Ctx &cx, int hc)
         int c = lane + 64 * k;
         if (c >= C) continue;
         bool o = cx.food[c] != 0;
+#pragma unroll 4
         for (int s = 0; s < cx.K; ++s) o |= BV(cx, s, c) > 0;
         cx.occ[c] = (unsigned char)o;
     }
