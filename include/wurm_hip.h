@@ -215,6 +215,31 @@ int wurm_multi_colours(int16_t *colours, int64_t num_envs, int num_snakes, int f
 /* wurm.utils.determine_orientations (wurm/utils.py:36-65) over a (n,3,S,S) batch; out (n) int64. */
 int wurm_orientations(const float *envs, int64_t *out, int64_t n, int size, void *stream);
 
+/* ------------------------------------------------------------------------------------------- learner-side glue
+ * (the consumers of the env's outputs in experiments/main.py) */
+
+/* Return computation of wurm.rl.A2C.loss (wurm/rl/a2c.py:49-66): reverse scan over time per env.
+ *   rewards, values, returns (T,N) fp32 row-major; dones (T,N) bytes; bootstrap (N) fp32.
+ *   use_gae = 0: R = bootstrap * !done[T-1]; R_t = r_t + gamma * R_{t+1} * !done_t            (:60-64; values unused)
+ *   use_gae = 1: delta_t = r_t + gamma * v_{t+1} * !done_t - v_t; gae_t = delta_t + gamma_lambda * !done_t * gae_{t+1};
+ *                R_t = gae_t + v_t, with gamma_lambda = (float)(gamma * gae_lambda)            (:50-59)
+ * fp32 in the reference's operation order: bit-identical to its torch-CPU path. */
+int wurm_a2c_returns(const float *bootstrap, const float *rewards, const float *values, const uint8_t *dones,
+                     float gamma, int use_gae, float gamma_lambda, float *returns, int64_t num_steps, int64_t num_envs,
+                     void *stream);
+
+/* Gradient of the scan above: given grad_returns (T,N), writes grad_values (T,N; nullable) and grad_bootstrap (N;
+ * nullable) — what torch autograd computes through the reference's op-by-op construction of `returns`. */
+int wurm_a2c_returns_backward(const float *grad_returns, const uint8_t *dones, float gamma, int use_gae,
+                              float gamma_lambda, float *grad_values, float *grad_bootstrap, int64_t num_steps,
+                              int64_t num_envs, void *stream);
+
+/* The per-step logging reductions of experiments/main.py:252-274 in one launch: adds to accum (5 doubles on the
+ * device, zeroed by the caller) the batch sums of done, reward, edge_collision, self_collision and snake length
+ * (max of the body channel of envs (N,3,S,S)). */
+int wurm_single_stats(const float *envs, const float *reward, const uint8_t *done, const uint8_t *self_collision,
+                      const uint8_t *edge_collision, double *accum, int64_t num_envs, int size, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

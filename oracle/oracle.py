@@ -356,3 +356,29 @@ def multi_colours(N, K, fixed=False, seed=0, call=0, env_offset=0):
     col = np.empty((N * K, 3), np.int16)
     _check(lib().oracle_multi_colours(_p(col), _i64(N), K, int(fixed), _u64(seed), _u64(call), _i64(env_offset)))
     return col
+
+
+# ---------------------------------------------------------------- RL glue next to the env
+
+def a2c_returns(bootstrap, rewards, values, dones, gamma, use_gae=False, gae_lambda=None):
+    """(T,N) returns of the reference's A2C.loss (wurm/rl/a2c.py:49-66).  fp32 arrays; dones uint8/bool."""
+    rewards = np.ascontiguousarray(rewards, np.float32)
+    T, N = rewards.shape
+    values = np.ascontiguousarray(values, np.float32).reshape(T, N)
+    bootstrap = np.ascontiguousarray(bootstrap, np.float32).reshape(N)
+    d = np.ascontiguousarray(np.asarray(dones).reshape(T, N) != 0, dtype=np.uint8)
+    out = np.empty((T, N), np.float32)
+    gl = np.float32(gamma * gae_lambda) if use_gae else np.float32(0)
+    _check(lib().oracle_a2c_returns(_p(bootstrap), _p(rewards), _p(values), _p(d), ctypes.c_float(np.float32(gamma)),
+                                    int(bool(use_gae)), ctypes.c_float(gl), _p(out), _i64(T), _i64(N)))
+    return out
+
+
+def single_stats(envs, reward, done, self_collision, edge_collision):
+    N, _, S, _ = envs.shape
+    out = np.empty(5, np.float64)
+    _check(lib().oracle_single_stats(_p(envs), _p(np.ascontiguousarray(reward, np.float32)),
+                                     _p(np.ascontiguousarray(done, np.uint8)),
+                                     _p(np.ascontiguousarray(self_collision, np.uint8)),
+                                     _p(np.ascontiguousarray(edge_collision, np.uint8)), _p(out), _i64(N), S))
+    return out
