@@ -78,8 +78,8 @@ def run_rollouts(env, actions, first, steps, chunk, events=None):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=32768, help='timed batch-steps (K)')
-    ap.add_argument('--warmup', type=int, default=1024, help='untimed batch-steps (W)')
+    ap.add_argument('--steps', type=int, default=262144, help='timed batch-steps (K)')
+    ap.add_argument('--warmup', type=int, default=4096, help='untimed batch-steps (W)')
     ap.add_argument('--num-envs', type=int, default=512, help='envs per GPU (BASELINE configs[1]: 512)')
     ap.add_argument('--chunk', type=int, default=256, help='batch-steps per rollout launch')
     ap.add_argument('--no-extra', action='store_true', help='skip the secondary measurements')
@@ -154,7 +154,7 @@ def main():
                        'state_dtype': 'fp32 NCHW (exact integers)', 'chunk': args.chunk},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
-                         'kernel': 'rollout_kernel<CPL=2,SNAKE>', 'avg_launch_ms': avg_launch_s * 1e3,
+                         'kernel': 'wurm::rollout_kernel<2, true, 4, false> (lean instantiation: CPL=2, SingleSnake, partial_n obs, RNG mode)', 'avg_launch_ms': avg_launch_s * 1e3,
                          'algorithmic_bytes_per_env_step': algorithmic_bytes_per_env_step(SIZE, OBS_ELEMS),
                          'env_steps_per_launch': N * full[0][1],
                          'note': 'this config is latency-bound (512 waves on 256 CUs), not HBM-bound: '
