@@ -64,7 +64,7 @@ class WurmHipError(RuntimeError):
 
 def build(force: bool = False) -> str:
     """Compiles wurm_amd/csrc/*.hip for gfx950 into wurm_amd/libwurm_hip.so (hipcc cross-compiles without a GPU)."""
-    cmd = ['make', '-C', CSRC] + (['-B'] if force else [])
+    cmd = ['make', '-j4', '-C', CSRC] + (['-B'] if force else [])
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise WurmHipError('building libwurm_hip.so failed:\n' + r.stdout[-4000:] + r.stderr[-4000:])

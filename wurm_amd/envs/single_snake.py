@@ -287,29 +287,9 @@ class SingleSnake(object):
 
     def render(self, mode: str = 'human'):
         """reference :389-428.  Only 'rgb_array' is provided (the 'human' viewer needs gym/pyglet)."""
-        import numpy as np
-        from PIL import Image
-
-        img = self._get_rgb().cpu().numpy()
-        if self.num_envs == 1:
-            num_cols = num_rows = 1
-            img = np.transpose(img[0], (1, 2, 0))
-        else:
-            num_rows = self.render_args['num_rows']
-            num_cols = self.render_args['num_cols']
-            output = np.zeros((self.size * num_rows, self.size * num_cols, 3))
-            for i in range(num_rows):
-                for j in range(num_cols):
-                    output[i * self.size:(i + 1) * self.size, j * self.size:(j + 1) * self.size, :] = \
-                        np.transpose(img[i * num_cols + j], (1, 2, 0))
-            img = output
-
-        img = np.array(Image.fromarray(img.astype(np.uint8)).resize(
-            (self.render_args['size'] * num_cols, self.render_args['size'] * num_rows)))
-
-        if mode == 'rgb_array':
-            return img
-        elif mode == 'human':
+        if mode == 'human':
             raise NotImplementedError("render('human') needs gym's SimpleImageViewer; use mode='rgb_array'")
-        else:
+        if mode != 'rgb_array':
             raise ValueError('Render mode not recognised.')
+        from wurm_amd._render import frame
+        return frame(self._get_rgb().cpu().numpy(), self.num_envs, self.render_args)
