@@ -20,7 +20,7 @@ from typing import Dict, Optional, Tuple
 import torch
 
 from wurm_amd import _lib
-from wurm_amd.config import DEFAULT_DEVICE, EPS
+from wurm_amd.constants import DEFAULT_DEVICE, EPS
 from wurm_amd.envs.single_snake import _draw_seed
 
 Spec = namedtuple('Spec', ['reward_threshold'])

@@ -7,7 +7,7 @@ from typing import Tuple
 import torch
 
 from wurm_amd import _lib
-from wurm_amd.config import DEFAULT_DEVICE
+from wurm_amd.constants import DEFAULT_DEVICE
 from wurm_amd.envs.single_snake import _draw_seed, _INT_TYPES
 
 Spec = namedtuple('Spec', ['reward_threshold'])

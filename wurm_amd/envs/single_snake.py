@@ -15,7 +15,7 @@ from collections import namedtuple
 import torch
 
 from wurm_amd import _lib
-from wurm_amd.config import DEFAULT_DEVICE
+from wurm_amd.constants import DEFAULT_DEVICE
 
 Spec = namedtuple('Spec', ['reward_threshold'])
 

@@ -6,7 +6,7 @@ that returns a per-env error bitmask; the exception types and messages are the r
 import torch
 
 from wurm_amd import _lib
-from wurm_amd.config import FOOD_CHANNEL, HEAD_CHANNEL, BODY_CHANNEL
+from wurm_amd.constants import FOOD_CHANNEL, HEAD_CHANNEL, BODY_CHANNEL
 
 CHK_FOOD_VALUE, CHK_ONE_HEAD, CHK_HAS_SNAKE, CHK_HEAD_AT_END, CHK_BODY_RANGE, CHK_MIN_LENGTH, CHK_HEAD_ON_FOOD, \
     CHK_ONE_FOOD = (1 << i for i in range(8))
