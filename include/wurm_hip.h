@@ -195,6 +195,22 @@ int wurm_multi_reset(float *foods, float *heads, float *bodies, uint8_t *dones, 
                      const wurm_multi_config *cfg, uint64_t seed, uint64_t call, int64_t env_offset,
                      const wurm_multi_reset_inject *inject, void *stream);
 
+/* T fused iterations of the caller loop of experiments/speeds.py:30-37 / tests/test_multi_snake_env.py:78-89:
+ *   for t: outputs[t], obs[t] = step(actions[t]) with call = call0 + 2t;  reset(dones['__all__']) with call0 + 2t + 1
+ * in ONE launch with the env resident on chip (LDS).  Bit-identical to T calls of wurm_multi_step / wurm_multi_reset
+ * (the latter without observation).
+ *   actions (T,K,N) int64;  out_f32 (T,3,K,N) = rewards, food_consumed, sizes;  out_u8 (T,4,K,N) = dones,
+ *   boost_this_step, snake_collision, edge_collision (agent-major rows, as the agent_major_* outputs of
+ *   wurm_multi_step);  all_done (T,N);  obs (T,K,N,elems).  State tensors, dones, orientations, colours and
+ *   boost_this_step (nullable) are updated in place to the state after the last reset.
+ *   inject / reset_inject: both NULL (RNG mode) or both given, each array with a leading T dimension. */
+int wurm_multi_rollout(float *foods, float *heads, float *bodies, uint8_t *dones, int64_t *orientations,
+                       int16_t *colours, uint8_t *boost_this_step, const int64_t *actions, float *out_f32,
+                       uint8_t *out_u8, uint8_t *all_done, float *obs, int obs_mode, int obs_n, int64_t num_envs,
+                       int num_snakes, int size, int64_t num_steps, const wurm_multi_config *cfg, uint64_t seed,
+                       uint64_t call0, int64_t env_offset, const wurm_multi_inject *inject,
+                       const wurm_multi_reset_inject *reset_inject, void *stream);
+
 /* MultiSnake._observe (multi_snake.py:283-334) */
 int wurm_multi_observe(const float *foods, const float *heads, const float *bodies, const uint8_t *dones,
                        const uint8_t *boost_this_step, const int16_t *colours, float *obs, int obs_mode, int obs_n,

@@ -80,3 +80,19 @@ class OracleBackend(object):
 
     def multi_check(self, st):
         return _o.multi_check(st)
+
+    def multi_rollout(self, st, actions, cfg, mode, inject=None, reset_inject=None):
+        """Loop of multi_step + multi_reset(all_done) — the definition the fused GPU rollout must reproduce.
+        actions (T,K,N); inject / reset_inject: dicts of arrays with a leading T dimension."""
+        import numpy as np
+        T = actions.shape[0]
+        outs = []
+        for t in range(T):
+            inj = {k: v[t] for k, v in inject.items()} if inject is not None else None
+            r = self.multi_step(st, actions[t], cfg, mode, inject=inj)
+            r['dones'] = st['dones'].copy()
+            r['boost'] = st['boost_this_step'].copy()
+            outs.append(r)
+            rinj = {k: v[t] for k, v in reset_inject.items()} if reset_inject is not None else None
+            self.multi_reset(st, r['all_done'], cfg, inject=rinj)
+        return {k: np.stack([o[k] for o in outs]) for k in outs[0] if outs[0][k] is not None}

@@ -320,5 +320,46 @@ def orientations(self, envs):
     return out.cpu().numpy()
 
 
-for _f in (multi_step, multi_reset, multi_observe, multi_check, multi_colours, orientations):
+def multi_rollout(self, st, actions, cfg, mode, inject=None, reset_inject=None):
+    """wurm_multi_rollout; returns the same dict of (T, ...) env-major arrays as OracleBackend.multi_rollout."""
+    import ctypes
+    N, _, S, _ = st['foods'].shape
+    K = st['heads'].shape[0] // N
+    T = actions.shape[0]
+    m, n = _lib.parse_obs_mode(mode)
+    d = _multi_to_dev(self, st)
+    act = self._t(np.ascontiguousarray(actions, np.int64))
+    shape = _o.multi_obs_shape(mode, N, K, S)
+    obs = self._empty((T,) + shape, torch.float32) if shape else None
+    out_f, out_b = self._empty((T, 3, K, N), torch.float32), self._empty((T, 4, K, N), torch.uint8)
+    all_done = self._empty((T, N), torch.uint8)
+    c = _multi_cfg(K, cfg)
+    inj_ref = rinj_ref = None
+    keep = []
+    if inject is not None:
+        a = [self._t(np.ascontiguousarray(inject[k], np.uint8)) for k in ('death_a', 'cost', 'death_b', 'rate')]
+        a.append(self._t(np.ascontiguousarray(inject['food_cell'], np.int32)))
+        b = [self._t(np.ascontiguousarray(reset_inject['create'], np.int32)),
+             self._t(np.ascontiguousarray(reset_inject['create_food'], np.int32)),
+             self._t(np.ascontiguousarray(reset_inject['colours'], np.int16)),
+             self._t(np.ascontiguousarray(reset_inject['respawn'], np.int32))]
+        keep = a + b
+        inj, rinj = _lib.MultiInject(*[t.data_ptr() for t in a]), _lib.MultiResetInject(*[t.data_ptr() for t in b])
+        inj_ref, rinj_ref = ctypes.byref(inj), ctypes.byref(rinj)
+    rc = self.lib.wurm_multi_rollout(
+        _lib.ptr(d['foods']), _lib.ptr(d['heads']), _lib.ptr(d['bodies']), _lib.ptr(d['dones']),
+        _lib.ptr(d['orientations']), _lib.ptr(d['colours']), _lib.ptr(d['boost_this_step']), _lib.ptr(act),
+        _lib.ptr(out_f), _lib.ptr(out_b), _lib.ptr(all_done), _lib.ptr(obs), m, n, _lib.i64(N), K, S, _lib.i64(T),
+        ctypes.byref(c), _lib.u64(self.seed), _lib.u64(self._next(2 * T)), _lib.i64(self.env_offset), inj_ref, rinj_ref,
+        self._stream())
+    _lib.check(rc, 'wurm_multi_rollout')
+    torch.cuda.synchronize()
+    _multi_back(st, d)
+    em = lambda x: x.permute(0, 2, 1).reshape(T, N * K).cpu().numpy()  # (T,K,N) agent-major -> (T,N*K) env-major
+    return dict(obs=obs.cpu().numpy() if obs is not None else None, rewards=em(out_f[:, 0]), food=em(out_f[:, 1]),
+                size=em(out_f[:, 2]), dones=em(out_b[:, 0]), boost=em(out_b[:, 1]), snake_collision=em(out_b[:, 2]),
+                edge_collision=em(out_b[:, 3]), all_done=all_done.cpu().numpy())
+
+
+for _f in (multi_step, multi_reset, multi_observe, multi_check, multi_colours, orientations, multi_rollout):
     setattr(HipBackend, _f.__name__, _f)

@@ -163,3 +163,24 @@ def replay_multi(backend, fx):
         if 'obs_reset' in fx:
             _eq(backend.multi_observe(st, mode), _obs_from_code(fx['obs_reset'][t]), 'reset observation', t)
     return st
+
+
+def replay_multi_rollout(backend, fx):
+    """The whole MultiSnake tape through the fused rollout entry point, with the reference's recorded outcomes injected."""
+    mode = str(fx['mode'])
+    N, K, S, T = (int(v) for v in fx['meta'][:4])
+    cfg = fx['cfg_dict']
+    st = multi_state(fx, 'state0_')
+    inject = {k: fx['inj_' + k] for k in ('death_a', 'cost', 'death_b', 'rate', 'food_cell')}
+    rinj = {k: fx['rinj_' + k] for k in ('create', 'create_food', 'colours', 'respawn')}
+    r = backend.multi_rollout(st, fx['actions'], cfg, mode, inject=inject, reset_inject=rinj)
+    _eq(r['rewards'], fx['rewards'], 'rewards', 'all')
+    _eq(r['dones'], fx['dones_out'], 'dones', 'all')
+    _eq(r['snake_collision'], fx['snake_collision'], 'snake_collision', 'all')
+    _eq(r['edge_collision'], fx['edge_collision'], 'edge_collision', 'all')
+    _eq(r['food'], fx['food'], 'food consumed', 'all')
+    _eq(r['size'], fx['size'], 'sizes', 'all')
+    _eq(r['boost'], fx['boost'], 'boost info', 'all')
+    _eq(r['all_done'], fx['all_done'], '__all__ done', 'all')
+    _eq(r['obs'], _obs_from_code(fx['obs_step']), 'step observations', 'all')
+    _eq_state(st, fx, 'reset_', T - 1, 'final')

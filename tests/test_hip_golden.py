@@ -44,3 +44,8 @@ MULTI = ['multi_k2_s12_default', 'multi_k4_s25_default', 'multi_k4_s25_train', '
 @pytest.mark.parametrize('name', MULTI)
 def test_multi_snake_matches_reference(hip, name):
     replay.replay_multi(hip(), replay.load_multi(name))
+
+
+@pytest.mark.parametrize('name', MULTI)
+def test_multi_snake_rollout_matches_reference(hip, name):
+    replay.replay_multi_rollout(hip(), replay.load_multi(name))

@@ -104,3 +104,31 @@ def test_observe_entry_point(hip):
     o.multi_reset(st, np.ones(N), cfg)
     for mode in ('full', 'partial_4'):
         _same(o.multi_observe(st, mode), h.multi_observe(st, mode), mode)
+
+
+@pytest.mark.parametrize('N,K,S,T,mode,cfg', [
+    (16, 4, 25, 60, 'full', 'default'),
+    (12, 4, 25, 90, 'partial_5', 'train'),
+    (10, 6, 14, 80, 'partial_2', 'dense'),
+    (9, 2, 12, 150, 'full', 'noboost'),
+    (4, 10, 36, 30, 'full', 'train'),
+])
+def test_multi_rollout_equals_loop(hip, N, K, S, T, mode, cfg):
+    """wurm_multi_rollout == T x (step; reset(__all__)) of the oracle, bit for bit, with the build's RNG."""
+    cfg = CFGS[cfg]
+    rng = np.random.RandomState(7 * K + S)
+    o, h = OracleBackend(seed=21, env_offset=64), hip(seed=21, env_offset=64)
+    so, sh = _o.multi_empty_state(N, K, S), _o.multi_empty_state(N, K, S)
+    fixed = cfg['colour_mode'] == 'fixed'
+    so['colours'][...] = o.multi_colours(N, K, fixed, call=0)
+    sh['colours'][...] = so['colours']
+    o._next(); h._next()
+    o.multi_reset(so, np.ones(N), cfg)
+    h.multi_reset(sh, np.ones(N), cfg)
+    _same_state(so, sh, 'fresh envs')
+    actions = rng.randint(0, 8, size=(T, K, N)).astype(np.int64)
+    ro, rh = o.multi_rollout(so, actions, cfg, mode), h.multi_rollout(sh, actions, cfg, mode)
+    for k in ro:
+        _same(ro[k], rh[k], k)
+    _same_state(so, sh, 'final state')
+    assert ro['dones'].sum() > 0

@@ -275,3 +275,25 @@ def test_output_packaging(api):
         for i in range(3):
             assert info[f'{key}{i}'].shape == (5,)
     assert torch.equal(torch.stack([dones[f'agent_{i}'] for i in range(3)], dim=1).flatten(), env.dones)
+
+
+def test_rollout_equals_python_loop(api):
+    N, K, T = 64, 4, 60
+    kw = dict(num_envs=N, num_snakes=K, size=25, respawn_mode='any', food_mode='random_rate', boost_cost_prob=0.25,
+              observation_mode='partial_5', food_on_death_prob=0.33, food_rate=2.5e-3, seed=77)
+    a, b = api['MultiSnake'](**kw), api['MultiSnake'](**kw)
+    assert torch.equal(a.bodies, b.bodies) and torch.equal(a.agent_colours, b.agent_colours)
+    actions = torch.randint(8, size=(T, K, N), device=DEVICE)
+    out = b.rollout(actions)
+    for t in range(T):
+        obs, rewards, dones, info = a.step({f'agent_{i}': actions[t, i] for i in range(K)})
+        for i in range(K):
+            assert torch.equal(obs[f'agent_{i}'], out['observations'][t, i]), (t, i)
+            assert torch.equal(rewards[f'agent_{i}'], out['rewards'][t, i])
+            assert torch.equal(dones[f'agent_{i}'], out['dones'][t, i])
+            assert torch.equal(info[f'size_{i}'], out['size'][t, i])
+        assert torch.equal(dones['__all__'], out['all_done'][t])
+        a.reset(dones['__all__'], return_observations=False)
+    for name in ('foods', 'heads', 'bodies', 'dones', 'orientations', 'agent_colours', 'boost_this_step'):
+        assert torch.equal(getattr(a, name), getattr(b, name)), name
+    b.check_consistency()

@@ -59,3 +59,9 @@ def test_a2c_returns_match_reference(name):
         assert np.allclose(got, want, rtol=0, atol=1e-6)
     else:
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+@pytest.mark.parametrize('name', MULTI)
+def test_multi_snake_rollout_loop_matches_reference(name):
+    """the oracle-side definition of a MultiSnake rollout (loop of step + reset) against the reference's tape"""
+    replay.replay_multi_rollout(OracleBackend(), replay.load_multi(name))

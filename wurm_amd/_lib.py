@@ -22,6 +22,7 @@ SYMBOLS = [
     'wurm_single_step', 'wurm_single_reset', 'wurm_single_observe', 'wurm_single_rollout', 'wurm_single_check',
     'wurm_grid_step', 'wurm_grid_reset', 'wurm_grid_observe', 'wurm_grid_rollout',
     'wurm_multi_obs_elems', 'wurm_multi_step', 'wurm_multi_reset', 'wurm_multi_observe', 'wurm_multi_check',
+    'wurm_multi_rollout',
     'wurm_multi_colours', 'wurm_orientations',
     'wurm_a2c_returns', 'wurm_a2c_returns_backward', 'wurm_single_stats',
 ]

@@ -51,6 +51,8 @@ struct MultiArgs {
     uint32_t *err;
     float *am_f32;
     uint8_t *am_u8;
+    long long T;          // rollout: number of fused step+reset iterations
+    uint8_t *boost_state; // rollout: boost_this_step (N*K) written back at the end
     int lds_per_wave, off_body, off_food, off_occ, off_img, off_col;
 };
 
@@ -359,7 +361,8 @@ __device__ __forceinline__ int count_bits(const Ctx &cx, u64 bits)
 // ------------------------------------------------------------------------------------------------ observations
 
 // 'full' observation (_observe_agent :268-281 + _make_generic_rgb :175-192) of every agent from LDS
-__device__ __forceinline__ void observe_full(const Ctx &cx, const MultiArgs &p, long long env, int hc)
+__device__ __forceinline__ void observe_full(const Ctx &cx, const MultiArgs &p, float *__restrict__ obs,
+                                             long long env, int hc)
 {
     const int S = cx.S, C = cx.C, K = cx.K, lane = cx.lane;
     // head owner per cell: occ[c] = 1 + snake index (consistent states have at most one head per cell)
@@ -390,7 +393,7 @@ __device__ __forceinline__ void observe_full(const Ctx &cx, const MultiArgs &p, 
             else if ((bm >> a) & 1) { r = 0.0f; g = G2; b = 0.0f; }                 // own body (0,96,0)
             else if (fd) { r = 1.0f; g = 0.0f; b = 0.0f; }                          // food (255,0,0)
             else { r = g = b = 1.0f; }
-            float *o = p.obs + ((long long)a * p.N + env) * p.obs_elems;
+            float *o = obs + ((long long)a * p.N + env) * p.obs_elems;
             o[c] = r;
             o[C + c] = g;
             o[2 * C + c] = b;
@@ -399,18 +402,32 @@ __device__ __forceinline__ void observe_full(const Ctx &cx, const MultiArgs &p, 
     wave_lds_sync();
 }
 
+// Per-snake state, one snake per lane (lanes 0..K-1), carried through a step / reset / rollout.
+struct Snake {
+    int hc;           // head cell, -1 = none
+    int L;            // length (max body value)
+    bool done;
+    long long orient; // stored orientation (multi_snake.py:108,494)
+    bool boosted;     // boost_this_step of the last step (brightens the snake in partial_n observations)
+    short col[3];     // agent colour
+};
+
+struct StepRes {
+    float reward, foodcons;
+    bool snakecol, edgecol, all_done;
+};
+
 // 'partial_n' observation (:289-332): env image (_get_env_images :194-227) into LDS, then one crop per agent
-__device__ __forceinline__ void observe_partial(const Ctx &cx, const MultiArgs &p, long long env, int hc, bool done,
-                                                bool boosted)
+__device__ __forceinline__ void observe_partial(const Ctx &cx, const MultiArgs &p, float *__restrict__ obs,
+                                                long long env, const Snake &sn)
 {
     const int S = cx.S, C = cx.C, K = cx.K, lane = cx.lane, n = p.obs_n;
     if (lane < K) {
-        const short *col = p.colours + (env * K + lane) * 3;
-        cx.colf[lane * 4 + 0] = (float)col[0];
-        cx.colf[lane * 4 + 1] = (float)col[1];
-        cx.colf[lane * 4 + 2] = (float)col[2];
-        cx.colf[lane * 4 + 3] = 1.0f + 0.5f * (boosted ? 1.0f : 0.0f); // :198
-        cx.hcell[lane] = hc;
+        cx.colf[lane * 4 + 0] = (float)sn.col[0];
+        cx.colf[lane * 4 + 1] = (float)sn.col[1];
+        cx.colf[lane * 4 + 2] = (float)sn.col[2];
+        cx.colf[lane * 4 + 3] = 1.0f + 0.5f * (sn.boosted ? 1.0f : 0.0f); // :198
+        cx.hcell[lane] = sn.hc;
     }
     wave_lds_sync();
     for (int k = 0; k < cx.cpl; ++k) {
@@ -439,10 +456,10 @@ __device__ __forceinline__ void observe_partial(const Ctx &cx, const MultiArgs &
     const int W = 2 * n + 1, W2 = W * W, E = 3 * W2;
     const float rcpW2 = 1.0f / (float)W2, rcpW = 1.0f / (float)W;
     for (int a = 0; a < K; ++a) {
-        const int h = lane_value(hc, a);
-        const bool dead = lane_value((int)done, a) != 0;
+        const int h = lane_value(sn.hc, a);
+        const bool dead = lane_value((int)sn.done, a) != 0;
         const int hy = h >= 0 ? div_size(h, cx.rcpS) : 0, hx = h - hy * S;
-        float *o = p.obs + ((long long)a * p.N + env) * p.obs_elems;
+        float *o = obs + ((long long)a * p.N + env) * p.obs_elems;
         for (int el = lane; el < E; el += 64) {
             int ch = div_size(el, rcpW2), w = el - ch * W2;
             int wy = div_size(w, rcpW), wx = w - wy * W;
@@ -455,37 +472,41 @@ __device__ __forceinline__ void observe_partial(const Ctx &cx, const MultiArgs &
     wave_lds_sync();
 }
 
-__device__ __forceinline__ void observe(const Ctx &cx, const MultiArgs &p, long long env, int hc, bool done,
-                                        bool boosted)
+__device__ __forceinline__ void observe(const Ctx &cx, const MultiArgs &p, float *__restrict__ obs, long long env,
+                                        const Snake &sn)
 {
-    if (p.obs_mode == WURM_OBS_DEFAULT) observe_full(cx, p, env, hc);
-    else if (p.obs_mode == WURM_OBS_PARTIAL) observe_partial(cx, p, env, hc, done, boosted);
+    if (p.obs_mode == WURM_OBS_DEFAULT) observe_full(cx, p, obs, env, sn.hc);
+    else if (p.obs_mode == WURM_OBS_PARTIAL) observe_partial(cx, p, obs, env, sn);
 }
 
-// ------------------------------------------------------------------------------------------------ step kernel
-
-__global__ __launch_bounds__(256) void multi_step_kernel(MultiArgs p)
+__device__ __forceinline__ void load_colour(const MultiArgs &p, long long agent, bool active, Snake &sn)
 {
-    const int wave = (int)(threadIdx.x >> 6), wpb = (int)(blockDim.x >> 6);
-    const long long env = (long long)blockIdx.x * wpb + wave;
-    if (env >= p.N) return;
-    const Ctx cx = make_ctx(p, wave);
+    sn.col[0] = sn.col[1] = sn.col[2] = 0;
+    if (active && p.colours) {
+        sn.col[0] = p.colours[agent * 3];
+        sn.col[1] = p.colours[agent * 3 + 1];
+        sn.col[2] = p.colours[agent * 3 + 2];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ step
+
+// MultiSnake.step (:462-731) of the env held in LDS.  `a` is this lane's (snake's) action.  offC / offA / offE are the
+// offsets of this step's slice in the injected-outcome arrays (0 for a single step; t*N*C, t*N*K, t*N in a rollout).
+__device__ __forceinline__ void multi_step_body(const Ctx &cx, const MultiArgs &p, long long env, u64 env_id, u64 call,
+                                                long long a, Snake &sn, StepRes &res, long long offC, long long offA,
+                                                long long offE)
+{
     const int C = cx.C, K = cx.K, lane = cx.lane;
     const bool snake = lane < K;
-    const u64 env_id = (u64)(p.env_offset + env);
-    float *foodp = p.foods + env * C, *headp = p.heads + env * K * C, *bodyp = p.bodies + env * K * C;
-
-    const u64 fbits0 = load_env(cx, foodp, headp, bodyp);
-    int hc = snake ? cx.hcell[lane] : -1, L = snake ? cx.lmax[lane] : 0;
-    const int hc0 = hc;
+    int hc = sn.hc, L = sn.L;
+    bool done = sn.done;
     bool has_body = L > 0;
     const long long agent = env * K + lane;
 
     // prologue (:475-502)
-    bool done = snake ? p.dones[agent] != 0 : true;
     const bool done0 = done;
-    long long a = snake ? p.actions[(long long)lane * p.N + env] : 0;
-    long long orient = snake ? p.orientations[agent] : 0;
+    long long orient = sn.orient;
     long long d = a % 4;                        // :483
     const bool boost_act = a > 3;               // :484
     if (orient == d) d = (d + 2) % 4;           // :493 sanitize_movements
@@ -498,13 +519,13 @@ __global__ __launch_bounds__(256) void multi_step_kernel(MultiArgs p)
     if (p.cfg.boost && ballot(boosted) != 0) {  // :503 (per env; the batch-global gate has no per-env effect)
         run_phase(cx, boosted, dir, hc, L, done, reward, foodcons, snakecol, edgecol);
         if (p.cfg.food_on_death)                // :565-576
-            food_from_death(cx, done, has_body, p.has_inj ? p.inj.death_a + env * C : nullptr, p.cfg.death_threshold,
-                            p.seed, p.call, env_id, RNG_DEATH_FOOD_A);
+            food_from_death(cx, done, has_body, p.has_inj ? p.inj.death_a + offC + env * C : nullptr,
+                            p.cfg.death_threshold, p.seed, call, env_id, RNG_DEATH_FOOD_A);
         // boost cost (:579-592): tail cell becomes food, body decays, reward -1
         bool pay = false;
         if (boosted) {
-            if (p.has_inj) pay = p.inj.cost[agent] != 0;
-            else pay = u01(rng_words(p.seed, p.call, env_id, RNG_BOOST_COST, (u32)lane).w[0]) < p.cfg.boost_cost_prob;
+            if (p.has_inj) pay = p.inj.cost[offA + agent] != 0;
+            else pay = u01(rng_words(p.seed, call, env_id, RNG_BOOST_COST, (u32)lane).w[0]) < p.cfg.boost_cost_prob;
         }
         u64 m = ballot(pay);
         while (m) {
@@ -530,8 +551,8 @@ __global__ __launch_bounds__(256) void multi_step_kernel(MultiArgs p)
 
     run_phase(cx, snake, dir, hc, L, done, reward, foodcons, snakecol, edgecol); // :613-660
     if (p.cfg.food_on_death)                    // :662-673
-        food_from_death(cx, done, has_body, p.has_inj ? p.inj.death_b + env * C : nullptr, p.cfg.death_threshold,
-                        p.seed, p.call, env_id, RNG_DEATH_FOOD_B);
+        food_from_death(cx, done, has_body, p.has_inj ? p.inj.death_b + offC + env * C : nullptr,
+                        p.cfg.death_threshold, p.seed, call, env_id, RNG_DEATH_FOOD_B);
     delete_done(cx, done, has_body, hc);        // :676-677
 
     // _add_food (:368-410)
@@ -545,13 +566,13 @@ __global__ __launch_bounds__(256) void multi_step_kernel(MultiArgs p)
         if (p.cfg.food_mode == 0) {
             if (nfood == 0) {                   // :371-379
                 if (p.has_inj) {
-                    int cell = p.inj.food_cell[env];
+                    int cell = p.inj.food_cell[offE + env];
                     if (cell >= 0 && cell < C && lane == 0) cx.food[cell] = 1;
                 } else {
                     u64 fr = free_cells(cx, hc, 1);
                     int nf = count_bits(cx, fr);
                     if (nf > 0) {
-                        int Kr = (int)mulhi_range(rng_words(p.seed, p.call, env_id, RNG_FOOD, 0).w[0], (u32)nf);
+                        int Kr = (int)mulhi_range(rng_words(p.seed, call, env_id, RNG_FOOD, 0).w[0], (u32)nf);
                         int k = rank_select(cx, fr, Kr);
                         if (k >= 0) cx.food[lane + 64 * k] = 1;
                     }
@@ -562,8 +583,8 @@ __global__ __launch_bounds__(256) void multi_step_kernel(MultiArgs p)
             for (int k = 0; k < cx.cpl; ++k) {
                 if (!((fr >> k) & 1)) continue;
                 int c = lane + 64 * k;
-                bool hit = p.has_inj ? p.inj.rate[env * C + c] != 0
-                                     : cell_u01(p.seed, p.call, env_id, RNG_RATE_FOOD, (u32)c) < p.cfg.food_rate;
+                bool hit = p.has_inj ? p.inj.rate[offC + env * C + c] != 0
+                                     : cell_u01(p.seed, call, env_id, RNG_RATE_FOOD, (u32)c) < p.cfg.food_rate;
                 if (hit) cx.food[c] = 1;
             }
         }
@@ -572,37 +593,73 @@ __global__ __launch_bounds__(256) void multi_step_kernel(MultiArgs p)
 
     if (snake && done && !done0) reward += p.cfg.reward_on_death; // :683-685
 
-    // outputs (:701-729)
-    if (snake) {
-        p.dones[agent] = (uint8_t)done;
-        p.orientations[agent] = orient;
-        p.boost[agent] = (uint8_t)boosted;
-        p.rewards[agent] = reward;
-        p.snakecol[agent] = (uint8_t)snakecol;
-        p.edgecol[agent] = (uint8_t)edgecol;
-        p.foodcons[agent] = foodcons;
-        p.sizes[agent] = (float)L;
-        if (p.am_f32) { // agent-major copies: row i = agent_i over all envs
-            const long long KN = (long long)K * p.N, am = (long long)lane * p.N + env;
-            p.am_f32[am] = reward;
-            p.am_f32[KN + am] = foodcons;
-            p.am_f32[2 * KN + am] = (float)L;
-            p.am_u8[am] = (uint8_t)done;
-            p.am_u8[KN + am] = (uint8_t)boosted;
-            p.am_u8[2 * KN + am] = (uint8_t)snakecol;
-            p.am_u8[3 * KN + am] = (uint8_t)edgecol;
-        }
-    }
-    const bool alld = ballot(snake && !done) == 0; // :703
-    if (lane == 0) p.all_done[env] = (uint8_t)alld;
-
+    sn.hc = hc;
+    sn.L = L;
+    sn.done = done;
+    sn.orient = orient;
+    sn.boosted = boosted;
+    res.reward = reward;
+    res.foodcons = foodcons;
+    res.snakecol = snakecol;
+    res.edgecol = edgecol;
+    res.all_done = ballot(snake && !done) == 0; // :703
     if (snake) cx.hcell[lane] = hc;
     wave_lds_sync();
-    store_env(cx, foodp, headp, bodyp, fbits0, hc0, hc, false);
-    if (p.obs_mode != WURM_OBS_NONE) observe(cx, p, env, hc, done, boosted);
 }
 
-// ------------------------------------------------------------------------------------------------ reset kernel
+__global__ __launch_bounds__(256) void multi_step_kernel(MultiArgs p)
+{
+    const int wave = (int)(threadIdx.x >> 6), wpb = (int)(blockDim.x >> 6);
+    const long long env = (long long)blockIdx.x * wpb + wave;
+    if (env >= p.N) return;
+    const Ctx cx = make_ctx(p, wave);
+    const int C = cx.C, K = cx.K, lane = cx.lane;
+    const bool snake = lane < K;
+    const u64 env_id = (u64)(p.env_offset + env);
+    const long long agent = env * K + lane;
+    float *foodp = p.foods + env * C, *headp = p.heads + env * K * C, *bodyp = p.bodies + env * K * C;
+
+    const u64 fbits0 = load_env(cx, foodp, headp, bodyp);
+    Snake sn;
+    sn.hc = snake ? cx.hcell[lane] : -1;
+    sn.L = snake ? cx.lmax[lane] : 0;
+    sn.done = snake ? p.dones[agent] != 0 : true;
+    sn.orient = snake ? p.orientations[agent] : 0;
+    sn.boosted = false;
+    load_colour(p, agent, snake && p.obs_mode == WURM_OBS_PARTIAL, sn);
+    const int hc0 = sn.hc;
+    const long long a = snake ? p.actions[(long long)lane * p.N + env] : 0;
+    StepRes r;
+    multi_step_body(cx, p, env, env_id, p.call, a, sn, r, 0, 0, 0);
+
+    // outputs (:701-729)
+    if (snake) {
+        p.dones[agent] = (uint8_t)sn.done;
+        p.orientations[agent] = sn.orient;
+        p.boost[agent] = (uint8_t)sn.boosted;
+        p.rewards[agent] = r.reward;
+        p.snakecol[agent] = (uint8_t)r.snakecol;
+        p.edgecol[agent] = (uint8_t)r.edgecol;
+        p.foodcons[agent] = r.foodcons;
+        p.sizes[agent] = (float)sn.L;
+        if (p.am_f32) { // agent-major copies: row i = agent_i over all envs
+            const long long KN = (long long)K * p.N, am = (long long)lane * p.N + env;
+            p.am_f32[am] = r.reward;
+            p.am_f32[KN + am] = r.foodcons;
+            p.am_f32[2 * KN + am] = (float)sn.L;
+            p.am_u8[am] = (uint8_t)sn.done;
+            p.am_u8[KN + am] = (uint8_t)sn.boosted;
+            p.am_u8[2 * KN + am] = (uint8_t)r.snakecol;
+            p.am_u8[3 * KN + am] = (uint8_t)r.edgecol;
+        }
+    }
+    if (lane == 0) p.all_done[env] = (uint8_t)r.all_done;
+
+    store_env(cx, foodp, headp, bodyp, fbits0, hc0, sn.hc, false);
+    if (p.obs_mode != WURM_OBS_NONE) observe(cx, p, p.obs, env, sn);
+}
+
+// ------------------------------------------------------------------------------------------------ reset
 
 // availability of _add_snake (:927-941) / _get_snake_addition (:848-858): the 3x3 neighbourhood is empty and the
 // cell is at least 2 from the border.  occ[] holds the occupancy (food, heads, bodies).
@@ -669,45 +726,29 @@ __device__ __forceinline__ void colour_from_words(const Words &w, short out[3])
     out[2] = (short)(__fdiv_rn(c2, norm) * 192.0f);
 }
 
-__global__ __launch_bounds__(256) void multi_reset_kernel(MultiArgs p)
+// colours of snakes that are still dead are re-rolled on every reset (:800-803).  Returns true if sn.col changed.
+__device__ __forceinline__ bool reroll_colour(const MultiArgs &p, long long agent, bool dead, u64 env_id, u64 call,
+                                              long long offA, Snake &sn)
 {
-    const int wave = (int)(threadIdx.x >> 6), wpb = (int)(blockDim.x >> 6);
-    const long long env = (long long)blockIdx.x * wpb + wave;
-    if (env >= p.N) return;
-    const Ctx cx = make_ctx(p, wave);
+    if (!(p.cfg.colour_random && dead)) return false;
+    if (p.has_rinj) {
+        sn.col[0] = p.rinj.colours[(offA + agent) * 3];
+        sn.col[1] = p.rinj.colours[(offA + agent) * 3 + 1];
+        sn.col[2] = p.rinj.colours[(offA + agent) * 3 + 2];
+    } else {
+        colour_from_words(rng_words(p.seed, call, env_id, RNG_COLOUR, (u32)(threadIdx.x & 63u)), sn.col);
+    }
+    return true;
+}
+
+// the grid part of MultiSnake.reset on the env held in LDS: _create_envs (:996-1019) when `rebuild`, then the
+// respawn of the first dead snake (:805-831) when `respawn`.  sn.done must already be false for rebuilt envs (:798).
+__device__ __forceinline__ void multi_reset_grid(const Ctx &cx, const MultiArgs &p, long long env, u64 env_id, u64 call,
+                                                 bool rebuild, bool respawn, Snake &sn, bool &orient_dirty,
+                                                 long long offA, long long offE)
+{
     const int C = cx.C, K = cx.K, lane = cx.lane;
     const bool snake = lane < K;
-    const u64 env_id = (u64)(p.env_offset + env);
-    const long long agent = env * K + lane;
-    float *foodp = p.foods + env * C, *headp = p.heads + env * K * C, *bodyp = p.bodies + env * K * C;
-
-    const bool rebuild = uniform((int)p.done_env[env]) != 0;
-    bool done = snake ? p.dones[agent] != 0 : false;
-    if (rebuild) done = false; // :798
-    const bool any_dead = ballot(snake && done) != 0;
-    const bool respawn = p.cfg.respawn_any && any_dead;
-    const bool want_obs = p.obs_mode != WURM_OBS_NONE;
-
-    // colours of snakes that are still dead are re-rolled on every reset (:800-803)
-    if (p.cfg.colour_random && snake && done) {
-        short col[3];
-        if (p.has_rinj) {
-            col[0] = p.rinj.colours[agent * 3];
-            col[1] = p.rinj.colours[agent * 3 + 1];
-            col[2] = p.rinj.colours[agent * 3 + 2];
-        } else {
-            colour_from_words(rng_words(p.seed, p.call, env_id, RNG_COLOUR, (u32)lane), col);
-        }
-        p.colours[agent * 3] = col[0];
-        p.colours[agent * 3 + 1] = col[1];
-        p.colours[agent * 3 + 2] = col[2];
-    }
-    if (!rebuild && !respawn && !want_obs) return;
-
-    int hc = -1, hc0 = -1;
-    u64 fbits0 = 0;
-    long long orient = 0;
-    bool orient_dirty = false;
     if (rebuild) { // _create_envs (:996-1019)
         for (int i = lane; i < K * C; i += 64) cx.body[i] = 0;
         for (int k = 0; k < cx.cpl; ++k) {
@@ -715,13 +756,14 @@ __global__ __launch_bounds__(256) void multi_reset_kernel(MultiArgs p)
             if (c < C) { cx.food[c] = 0; cx.occ[c] = 0; }
         }
         wave_lds_sync();
+        sn.hc = -1;
         for (int s = 0; s < K; ++s) { // _add_snake (:911-994), one snake after another
             int cell = -1, dnew = 0;
             if (p.has_rinj) {
-                cell = p.rinj.create[(env * K + s) * 2];
-                dnew = p.rinj.create[(env * K + s) * 2 + 1];
+                cell = p.rinj.create[(offA + env * K + s) * 2];
+                dnew = p.rinj.create[(offA + env * K + s) * 2 + 1];
             } else {
-                Words w = rng_words(p.seed, p.call, env_id, RNG_SPAWN, (u32)s);
+                Words w = rng_words(p.seed, call, env_id, RNG_SPAWN, (u32)s);
                 dnew = (int)(w.w[1] >> 30);
                 u64 av = spawn_cells(cx);
                 int n = count_bits(cx, av);
@@ -731,40 +773,36 @@ __global__ __launch_bounds__(256) void multi_reset_kernel(MultiArgs p)
             if (cell < 0 && p.status && lane == 0) atomicAdd(p.status, 1); // the reference raises (:946-947)
             int h = place_snake(cx, s, cell, dnew);
             if (lane == s) {
-                hc = h;
-                orient = dnew;
+                sn.hc = h;
+                sn.L = h >= 0 ? 3 : 0;
+                sn.orient = dnew;
                 orient_dirty = true;
             }
         }
         { // food (:1016-1017)
             if (p.has_rinj) {
-                int cell = p.rinj.create_food[env];
+                int cell = p.rinj.create_food[offE + env];
                 if (cell >= 0 && cell < C && lane == 0) cx.food[cell] = 1;
             } else {
-                u64 fr = free_cells(cx, hc, 1);
+                u64 fr = free_cells(cx, sn.hc, 1);
                 int nf = count_bits(cx, fr);
                 if (nf > 0) {
-                    int k = rank_select(cx, fr, (int)mulhi_range(rng_words(p.seed, p.call, env_id, RNG_RESET, 0).w[3], (u32)nf));
+                    int k = rank_select(cx, fr, (int)mulhi_range(rng_words(p.seed, call, env_id, RNG_RESET, 0).w[3], (u32)nf));
                     if (k >= 0) cx.food[lane + 64 * k] = 1;
                 }
             }
             wave_lds_sync();
         }
-    } else {
-        fbits0 = load_env(cx, foodp, headp, bodyp);
-        hc = snake ? cx.hcell[lane] : -1;
-        hc0 = hc;
     }
-
     if (respawn) { // :805-831 the first dead snake of the env respawns if there is room
-        const int f = first_bit(ballot(snake && done));
-        build_occ(cx, hc);
+        const int f = first_bit(ballot(snake && sn.done));
+        build_occ(cx, sn.hc);
         int cell = -1, dnew = 0;
         if (p.has_rinj) {
-            cell = p.rinj.respawn[env * 2];
-            dnew = p.rinj.respawn[env * 2 + 1];
+            cell = p.rinj.respawn[(offE + env) * 2];
+            dnew = p.rinj.respawn[(offE + env) * 2 + 1];
         } else {
-            Words w = rng_words(p.seed, p.call, env_id, RNG_SPAWN, (u32)K);
+            Words w = rng_words(p.seed, call, env_id, RNG_SPAWN, (u32)K);
             dnew = (int)(w.w[1] >> 30);
             u64 av = spawn_cells(cx);
             int n = count_bits(cx, av);
@@ -779,24 +817,69 @@ __global__ __launch_bounds__(256) void multi_reset_kernel(MultiArgs p)
         wave_lds_sync();
         int h = place_snake(cx, f, cell, dnew);
         if (lane == f) {
-            hc = h;
-            orient = dnew;        // :828 assigned whether or not the snake found room
+            sn.hc = h;
+            sn.L = h >= 0 ? 3 : 0;
+            sn.orient = dnew;     // :828 assigned whether or not the snake found room
             orient_dirty = true;
-            done = cell < 0;      // :829
+            sn.done = cell < 0;   // :829
         }
     }
+    if (snake) cx.hcell[lane] = sn.hc;
+    wave_lds_sync();
+}
+
+__global__ __launch_bounds__(256) void multi_reset_kernel(MultiArgs p)
+{
+    const int wave = (int)(threadIdx.x >> 6), wpb = (int)(blockDim.x >> 6);
+    const long long env = (long long)blockIdx.x * wpb + wave;
+    if (env >= p.N) return;
+    const Ctx cx = make_ctx(p, wave);
+    const int C = cx.C, K = cx.K, lane = cx.lane;
+    const bool snake = lane < K;
+    const u64 env_id = (u64)(p.env_offset + env);
+    const long long agent = env * K + lane;
+    float *foodp = p.foods + env * C, *headp = p.heads + env * K * C, *bodyp = p.bodies + env * K * C;
+
+    const bool rebuild = uniform((int)p.done_env[env]) != 0;
+    Snake sn;
+    sn.hc = -1;
+    sn.L = 0;
+    sn.done = snake ? p.dones[agent] != 0 : false;
+    if (rebuild) sn.done = false; // :798
+    sn.orient = 0;
+    sn.boosted = false;
+    const bool any_dead = ballot(snake && sn.done) != 0;
+    const bool respawn = p.cfg.respawn_any && any_dead;
+    const bool want_obs = p.obs_mode != WURM_OBS_NONE;
+
+    load_colour(p, agent, snake && (want_obs || p.cfg.colour_random), sn);
+    if (snake && reroll_colour(p, agent, sn.done, env_id, p.call, 0, sn)) {
+        p.colours[agent * 3] = sn.col[0];
+        p.colours[agent * 3 + 1] = sn.col[1];
+        p.colours[agent * 3 + 2] = sn.col[2];
+    }
+    if (!rebuild && !respawn && !want_obs) return;
+
+    int hc0 = -1;
+    u64 fbits0 = 0;
+    if (!rebuild) {
+        fbits0 = load_env(cx, foodp, headp, bodyp);
+        sn.hc = snake ? cx.hcell[lane] : -1;
+        sn.L = snake ? cx.lmax[lane] : 0;
+        hc0 = sn.hc;
+    }
+    bool orient_dirty = false;
+    multi_reset_grid(cx, p, env, env_id, p.call, rebuild, respawn, sn, orient_dirty, 0, 0);
 
     if (snake) {
-        if (rebuild || respawn) p.dones[agent] = (uint8_t)done;
-        if (orient_dirty) p.orientations[agent] = orient;
-        cx.hcell[lane] = hc;
+        if (rebuild || respawn) p.dones[agent] = (uint8_t)sn.done;
+        if (orient_dirty) p.orientations[agent] = sn.orient;
     }
-    wave_lds_sync();
-    if (rebuild) store_env(cx, foodp, headp, bodyp, 0, -1, hc, true);
-    else if (respawn) store_env(cx, foodp, headp, bodyp, fbits0, hc0, hc, false);
+    if (rebuild) store_env(cx, foodp, headp, bodyp, 0, -1, sn.hc, true);
+    else if (respawn) store_env(cx, foodp, headp, bodyp, fbits0, hc0, sn.hc, false);
     if (want_obs) {
-        const bool boosted = snake ? p.boost[agent] != 0 : false;
-        observe(cx, p, env, hc, done, boosted);
+        sn.boosted = snake ? p.boost[agent] != 0 : false;
+        observe(cx, p, p.obs, env, sn);
     }
 }
 
@@ -809,10 +892,91 @@ __global__ __launch_bounds__(256) void multi_observe_kernel(MultiArgs p)
     const int C = cx.C, K = cx.K, lane = cx.lane;
     load_env(cx, p.foods + env * C, p.heads + env * K * C, p.bodies + env * K * C);
     const bool snake = lane < K;
-    int hc = snake ? cx.hcell[lane] : -1;
-    bool done = snake ? p.dones[env * K + lane] != 0 : false;
-    bool boosted = snake ? p.boost[env * K + lane] != 0 : false;
-    observe(cx, p, env, hc, done, boosted);
+    Snake sn;
+    sn.hc = snake ? cx.hcell[lane] : -1;
+    sn.L = 0;
+    sn.orient = 0;
+    sn.done = snake ? p.dones[env * K + lane] != 0 : false;
+    sn.boosted = snake ? p.boost[env * K + lane] != 0 : false;
+    load_colour(p, env * K + lane, snake && p.obs_mode == WURM_OBS_PARTIAL, sn);
+    observe(cx, p, p.obs, env, sn);
+}
+
+// ------------------------------------------------------------------------------------------------ rollout
+
+// T fused iterations of the caller loop of experiments/speeds.py:30-37 / tests/test_multi_snake_env.py:78-89:
+//   step(actions[t]) with call = call0 + 2t  ->  outputs[t], observation[t];   reset(dones['__all__']) with call0 + 2t + 1
+// with the env resident in LDS and the per-snake scalars in lanes for the whole launch: the state crosses HBM twice
+// per launch instead of four times per iteration; per iteration only the actions are read and the outputs written.
+//   actions (T,K,N);  out_f32 (T,3,K,N) = rewards, food, sizes;  out_u8 (T,4,K,N) = dones, boost, snake_collision,
+//   edge_collision;  all_done (T,N);  obs (T,K,N,elems).
+__global__ __launch_bounds__(256) void multi_rollout_kernel(MultiArgs p)
+{
+    const int wave = (int)(threadIdx.x >> 6), wpb = (int)(blockDim.x >> 6);
+    const long long env = (long long)blockIdx.x * wpb + wave;
+    if (env >= p.N) return;
+    const Ctx cx = make_ctx(p, wave);
+    const int C = cx.C, K = cx.K, lane = cx.lane;
+    const bool snake = lane < K;
+    const u64 env_id = (u64)(p.env_offset + env);
+    const long long agent = env * K + lane, KN = (long long)K * p.N;
+    float *foodp = p.foods + env * C, *headp = p.heads + env * K * C, *bodyp = p.bodies + env * K * C;
+
+    load_env(cx, foodp, headp, bodyp);
+    Snake sn;
+    sn.hc = snake ? cx.hcell[lane] : -1;
+    sn.L = snake ? cx.lmax[lane] : 0;
+    sn.done = snake ? p.dones[agent] != 0 : true;
+    sn.orient = snake ? p.orientations[agent] : 0;
+    sn.boosted = false;
+    load_colour(p, agent, snake, sn);
+    bool col_dirty = false;
+
+    for (long long t = 0; t < p.T; ++t) {
+        const u64 call = p.call + 2ull * (u64)t;
+        const long long a = snake ? p.actions[t * KN + (long long)lane * p.N + env] : 0;
+        StepRes r;
+        multi_step_body(cx, p, env, env_id, call, a, sn, r, t * p.N * C, t * KN, t * p.N);
+        if (snake) {
+            const long long am = (long long)lane * p.N + env;
+            float *of = p.am_f32 + t * 3 * KN;
+            uint8_t *ob = p.am_u8 + t * 4 * KN;
+            of[am] = r.reward;
+            of[KN + am] = r.foodcons;
+            of[2 * KN + am] = (float)sn.L;
+            ob[am] = (uint8_t)sn.done;
+            ob[KN + am] = (uint8_t)sn.boosted;
+            ob[2 * KN + am] = (uint8_t)r.snakecol;
+            ob[3 * KN + am] = (uint8_t)r.edgecol;
+        }
+        if (lane == 0) p.all_done[t * p.N + env] = (uint8_t)r.all_done;
+        if (p.obs_mode != WURM_OBS_NONE) observe(cx, p, p.obs + t * KN * p.obs_elems, env, sn);
+
+        // reset(dones['__all__']) (:771-836)
+        if (snake && sn.done) sn.L = 0;           // deleted snakes have an all-zero body
+        const bool rebuild = r.all_done;
+        if (rebuild) sn.done = false;             // :798
+        if (snake) col_dirty |= reroll_colour(p, agent, sn.done, env_id, call + 1ull, t * KN, sn);
+        const bool respawn = p.cfg.respawn_any && ballot(snake && sn.done) != 0;
+        if (rebuild || respawn) {
+            bool orient_dirty = false;
+            multi_reset_grid(cx, p, env, env_id, call + 1ull, rebuild, respawn, sn, orient_dirty, t * KN, t * p.N);
+        }
+    }
+
+    if (snake) {
+        p.dones[agent] = (uint8_t)sn.done;
+        p.orientations[agent] = sn.orient;
+        if (p.boost_state) p.boost_state[agent] = (uint8_t)sn.boosted;
+        if (col_dirty) {
+            p.colours[agent * 3] = sn.col[0];
+            p.colours[agent * 3 + 1] = sn.col[1];
+            p.colours[agent * 3 + 2] = sn.col[2];
+        }
+        cx.hcell[lane] = sn.hc;
+    }
+    wave_lds_sync();
+    store_env(cx, foodp, headp, bodyp, 0, -1, sn.hc, true);
 }
 
 // check_consistency (:733-769) -> per-env bitmask
@@ -899,7 +1063,7 @@ static int multi_layout(MultiArgs &p, bool need_img)
     return p.lds_per_wave;
 }
 
-enum MKind { MK_STEP, MK_RESET, MK_OBSERVE, MK_CHECK };
+enum MKind { MK_STEP, MK_RESET, MK_OBSERVE, MK_CHECK, MK_ROLLOUT };
 
 static int multi_launch(MKind kind, MultiArgs &p, void *stream)
 {
@@ -917,6 +1081,7 @@ static int multi_launch(MKind kind, MultiArgs &p, void *stream)
     case MK_RESET: hipLaunchKernelGGL(multi_reset_kernel, grid, block, shmem, st, p); break;
     case MK_OBSERVE: hipLaunchKernelGGL(multi_observe_kernel, grid, block, shmem, st, p); break;
     case MK_CHECK: hipLaunchKernelGGL(multi_check_kernel, grid, block, shmem, st, p); break;
+    case MK_ROLLOUT: hipLaunchKernelGGL(multi_rollout_kernel, grid, block, shmem, st, p); break;
     }
     return hipGetLastError() == hipSuccess ? WURM_OK : WURM_ERR_HIP;
 }
@@ -993,6 +1158,32 @@ int wurm_multi_reset(float *foods, float *heads, float *bodies, uint8_t *dones, 
     p.N = num_envs; p.K = num_snakes; p.S = size; p.cfg = *cfg; p.seed = seed; p.call = call; p.env_offset = env_offset;
     if (inject) { p.rinj = *inject; p.has_rinj = 1; }
     return multi_launch(MK_RESET, p, stream);
+}
+
+int wurm_multi_rollout(float *foods, float *heads, float *bodies, uint8_t *dones, int64_t *orientations,
+                       int16_t *colours, uint8_t *boost_this_step, const int64_t *actions, float *out_f32,
+                       uint8_t *out_u8, uint8_t *all_done, float *obs, int obs_mode, int obs_n, int64_t num_envs,
+                       int num_snakes, int size, int64_t num_steps, const wurm_multi_config *cfg, uint64_t seed,
+                       uint64_t call0, int64_t env_offset, const wurm_multi_inject *inject,
+                       const wurm_multi_reset_inject *reset_inject, void *stream)
+{
+    int rc = multi_check_args(num_envs, num_snakes, size, obs_mode, obs_n, obs);
+    if (rc) return rc;
+    if (!cfg || num_steps < 0) return WURM_ERR_INVALID_ARG;
+    if (size < 7) return WURM_ERR_UNSUPPORTED;
+    if (num_envs > 0 && (!foods || !heads || !bodies || !dones || !orientations || !colours)) return WURM_ERR_INVALID_ARG;
+    if (num_envs > 0 && num_steps > 0 && (!actions || !out_f32 || !out_u8 || !all_done)) return WURM_ERR_INVALID_ARG;
+    if (num_steps == 0) return WURM_OK;
+    MultiArgs p = {};
+    p.foods = foods; p.heads = heads; p.bodies = bodies; p.dones = dones; p.orientations = (long long *)orientations;
+    p.colours = colours; p.boost_state = boost_this_step; p.actions = (const long long *)actions; p.am_f32 = out_f32;
+    p.am_u8 = out_u8; p.all_done = all_done; p.obs = obs; p.obs_mode = obs_mode; p.obs_n = obs_n;
+    p.obs_elems = multi_obs_elems(obs_mode, obs_n, size); p.N = num_envs; p.K = num_snakes; p.S = size; p.T = num_steps;
+    p.cfg = *cfg; p.seed = seed; p.call = call0; p.env_offset = env_offset;
+    if (inject) { p.inj = *inject; p.has_inj = 1; }
+    if (reset_inject) { p.rinj = *reset_inject; p.has_rinj = 1; }
+    if ((inject == nullptr) != (reset_inject == nullptr)) return WURM_ERR_INVALID_ARG; // replay needs both tapes
+    return multi_launch(MK_ROLLOUT, p, stream);
 }
 
 int wurm_multi_observe(const float *foods, const float *heads, const float *bodies, const uint8_t *dones,

@@ -303,6 +303,45 @@ class MultiSnake(object):
 
         return self._obs_dict(obs), rewards, dones_out, self.info
 
+    # ------------------------------------------------------------------ fused multi-step loop (extension)
+
+    def rollout(self, actions: torch.Tensor, return_observations: bool = True) -> dict:
+        """T iterations of `obs, r, d, info = env.step(a_t); env.reset(d['__all__'], return_observations=False)` in one
+        kernel launch, with the environments resident on chip (the loop of experiments/speeds.py:30-37).
+
+        actions: (T, num_snakes, num_envs) int64 on the device (actions[t, i] = agent_i's actions of step t).
+        Returns a dict of tensors with a leading T dimension, per-agent quantities as (T, num_snakes, num_envs):
+        `observations` (T, K, N, 3, h, w), `rewards`, `dones`, `boost`, `snake_collision`, `edge_collision`, `food`,
+        `size`, and `all_done` (T, N).  Bit-identical to the Python loop.
+        """
+        N, K, S, dev = self.num_envs, self.num_snakes, self.size, self.device
+        if actions.dtype != torch.long:
+            raise TypeError('rollout actions must be a LongTensor of shape (T, num_snakes, num_envs)')
+        if actions.dim() != 3 or actions.shape[1] != K or actions.shape[2] != N:
+            raise RuntimeError('rollout actions must have shape (T, num_snakes, num_envs)')
+        if not actions.is_contiguous() or actions.device != dev:
+            raise RuntimeError('rollout actions must be a contiguous device tensor')
+        T = actions.shape[0]
+        foods, heads, bodies, dones, orientations, colours, boost = self._state()
+        m, n, obs1 = self._obs_args(self.observation_mode if return_observations else None)
+        obs = torch.empty((T,) + tuple(obs1.shape), dtype=torch.float32, device=dev) if obs1 is not None else None
+        out_f = torch.empty((T, 3, K, N), dtype=torch.float32, device=dev)
+        out_b = torch.empty((T, 4, K, N), dtype=torch.bool, device=dev)
+        all_done = torch.empty((T, N), dtype=torch.bool, device=dev)
+        cfg = self._cfg()
+        rc = _lib.lib().wurm_multi_rollout(
+            _lib.ptr(foods), _lib.ptr(heads), _lib.ptr(bodies), _lib.ptr(dones), _lib.ptr(orientations),
+            _lib.ptr(colours), _lib.ptr(boost), _lib.ptr(actions), _lib.ptr(out_f), _lib.ptr(out_b), _lib.ptr(all_done),
+            _lib.ptr(obs), m, n, _lib.i64(N), K, S, _lib.i64(T), ctypes.byref(cfg), _lib.u64(self.seed),
+            _lib.u64(self._next_call(2 * T)), _lib.i64(self.env_offset), None, None, _lib.stream_ptr(self.device.index))
+        _lib.check(rc, 'MultiSnake.rollout')
+        if T > 0:
+            self.rewards = out_f[-1, 0].t().reshape(-1)
+        self.env_lifetimes.zero_()
+        return {'observations': obs, 'rewards': out_f[:, 0], 'food': out_f[:, 1], 'size': out_f[:, 2],
+                'dones': out_b[:, 0], 'boost': out_b[:, 1], 'snake_collision': out_b[:, 2],
+                'edge_collision': out_b[:, 3], 'all_done': all_done}
+
     # ------------------------------------------------------------------ invariants
 
     def check_consistency(self):
