@@ -205,6 +205,46 @@ def extra_measurements(device):
     out['rollout_8192'] = {'value': N * T / dt, 'unit': 'env-steps/s', 'achieved_GBs': gbs,
                            'frac_of_hbm_peak': gbs / HBM_PEAK_GBS,
                            'what': 'BASELINE configs[2] per-GPU share (65536/8), fused rollout, chunk 128'}
+    del env, actions
+    # (c) BASELINE configs[4] shape: SingleSnake 8192 x 36 x 36, default RGB observation, fused rollout
+    N, S, chunk, reps = 8192, 36, 16, 6
+    env = SingleSnake(num_envs=N, size=S, observation_mode='default', device=device, seed=0)
+    actions = torch.randint(4, (chunk * (reps + 1), N), device=device, dtype=torch.int64)
+    env.rollout(actions[:chunk])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for r in range(1, reps + 1):
+        env.rollout(actions[r * chunk:(r + 1) * chunk])
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    eps = N * chunk * reps / dt
+    per = algorithmic_bytes_per_env_step(S, 3 * S * S)
+    out['rollout_cfg5_8192x36_default'] = {
+        'value': eps, 'unit': 'env-steps/s', 'achieved_GBs': per * eps / 1e9, 'obs_write_GBs': 12 * S * S * eps / 1e9,
+        'frac_of_hbm_peak': per * eps / 1e9 / HBM_PEAK_GBS,
+        'what': 'BASELINE configs[4]: SingleSnake 8192x36x36 default-RGB obs, fused rollout, chunk 16 '
+                '(algorithmic 41 511 B per env-step; the fused path only writes the 15 552 B observation)'}
+    del env, actions
+    # (d) BASELINE configs[3]: MultiSnake 4096 x 25 x 25, 4 agents, constructor defaults ('full' obs), fused rollout
+    from wurm_amd.envs import MultiSnake
+    N, K, S, chunk, reps = 4096, 4, 25, 16, 6
+    env = MultiSnake(N, K, S, device=device, seed=0)
+    actions = torch.randint(8, (chunk * (reps + 1), K, N), device=device, dtype=torch.int64)
+    env.rollout(actions[:chunk])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for r in range(1, reps + 1):
+        env.rollout(actions[r * chunk:(r + 1) * chunk])
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    eps = N * chunk * reps / dt
+    per = 8 * (1 + 2 * K) * S * S + 12 * K * S * S + 40 * K
+    out['multi_rollout_cfg4_4096x25_k4_full'] = {
+        'value': eps, 'unit': 'env-steps/s', 'achieved_GBs': per * eps / 1e9, 'obs_write_GBs': 12 * K * S * S * eps / 1e9,
+        'frac_of_hbm_peak': per * eps / 1e9 / HBM_PEAK_GBS,
+        'what': 'BASELINE configs[3]: MultiSnake 4096x25x25, 4 agents, defaults, step+observe+reset(__all__) per '
+                'batch-step, fused rollout chunk 16 (algorithmic 75 160 B per env-step; reference torch-CPU: 3 280 '
+                'env-steps/s)'}
     return out
 
 
