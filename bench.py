@@ -81,7 +81,7 @@ def main():
     ap.add_argument('--steps', type=int, default=262144, help='timed batch-steps (K)')
     ap.add_argument('--warmup', type=int, default=4096, help='untimed batch-steps (W)')
     ap.add_argument('--num-envs', type=int, default=512, help='envs per GPU (BASELINE configs[1]: 512)')
-    ap.add_argument('--chunk', type=int, default=256, help='batch-steps per rollout launch')
+    ap.add_argument('--chunk', type=int, default=1024, help='batch-steps per rollout launch')
     ap.add_argument('--no-extra', action='store_true', help='skip the secondary measurements')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
