@@ -641,14 +641,16 @@ __device__ __forceinline__ int fast_food_cell(const Env<CPL> &e, const Geo &g, u
 }
 
 // step_core with carried scalars (single_snake.py:197-304; same line references as step_core)
+// a_small = the action if it is one of 0..3, else -1;  a_mod = action % 4 (C semantics: -3..3).  Both are computed
+// once per 64-step tape chunk so that the per-step sanitisation is 32-bit scalar work.
 template <int CPL>
-__device__ __forceinline__ void fast_step(Env<CPL> &e, const Geo &g, Fast &f, long long a_in, StepOut &out, u64 seed,
-                                          u64 call, u64 env_id, bool use_inject, int inject_cell)
+__device__ __forceinline__ void fast_step(Env<CPL> &e, const Geo &g, Fast &f, int a_small, int a_mod, StepOut &out,
+                                          u64 seed, u64 call, u64 env_id, bool use_inject, int inject_cell)
 {
     const int S = g.S;
-    const bool rev = (long long)f.o == a_in;                              // :221-222
-    const long long a_out = rev ? (long long)((f.o + 2) & 3) : a_in % 4;
-    const int ai = (int)(((a_out % 4) + 4) % 4);
+    const bool rev = f.o == a_small;                                      // :221-222
+    const int a_out = rev ? ((f.o + 2) & 3) : a_mod;
+    const int ai = a_out & 3;                                             // == ((a_out % 4) + 4) % 4 for -3..3
     int newhead = -1, ny = -1, nx = -1;
     if (f.hc >= 0) {                                                      // :225-233
         ny = f.hy - tap_y(ai);
@@ -819,18 +821,19 @@ __global__ __launch_bounds__(256) void rollout_kernel(StepArgs p)
         const long long my_t = t0 + g.lane;
         long long my_a = g.lane < nt ? load_action(p.actions, p.act_dtype, my_t * p.N + env) : 0;
         int my_inj = (inj_f && g.lane < nt) ? p.inject_food[my_t * p.N + env] : -1;
-        float my_r = 0.0f;
-        int my_flags = 0;
+        int my_flags = 0; // bit 0 done, 1 self collision, 2 edge collision, 3 reward
         // Retire the two prefetch loads HERE.  Otherwise the compiler, seeing a register that may still be in flight
         // on loop entry, puts `s_waitcnt vmcnt(0)` in front of the per-step readlane, and every step then also waits
         // for the previous step's observation stores to be acknowledged by HBM (vmcnt counts loads and stores).
         asm volatile("" : "+v"(my_a), "+v"(my_inj));
+        const int my_small = (my_a >= 0 && my_a < 4) ? (int)my_a : -1, my_mod = (int)(my_a % 4);
+        int my_out = 0; // sanitised action of step t0 + lane (always in -3..3)
         for (int j = 0; j < nt; ++j, obs_t += obs_stride, call += 2) {
-            const long long a_in = lane_value64(my_a, j);
             const int inj_cell = INJ ? lane_value(my_inj, j) : -1;
             StepOut out;
             if (SNAKE && fast) {
-                fast_step<CPL>(e, g, f, a_in, out, p.seed, call, env_id, inj_f, inj_cell);
+                fast_step<CPL>(e, g, f, lane_value(my_small, j), lane_value(my_mod, j), out, p.seed, call, env_id, inj_f,
+                               inj_cell);
                 if (small_crop) {
                     if constexpr (CPL <= 2) fast_partial_small<CPL>(e, g, f, obs_t, cg);
                 } else if (obs_mode != WURM_OBS_NONE) {
@@ -841,6 +844,7 @@ __global__ __launch_bounds__(256) void rollout_kernel(StepArgs p)
                     fast_reset<CPL>(e, g, f, p.seed, call + 1ull, env_id,
                                     inj_r ? p.inject_reset + ((t0 + j) * p.N + env) * 4 : nullptr);
             } else {
+                const long long a_in = lane_value64(my_a, j);
                 step_core<CPL, SNAKE, false>(e, g, nullptr, a_in, out, p.seed, call, env_id, inj_f, inj_cell, lds);
                 if (obs_mode != WURM_OBS_NONE)
                     write_obs<CPL, SNAKE>(e, g, out.headcell, obs_t, obs_mode, p.obs_n, lds);
@@ -850,18 +854,17 @@ __global__ __launch_bounds__(256) void rollout_kernel(StepArgs p)
                 }
             }
             if (g.lane == j) {
-                my_a = out.action;
-                my_r = out.reward;
-                my_flags = out.done | (out.selfc << 1) | (out.edgec << 2);
+                my_out = (int)out.action;
+                my_flags = out.done | (out.selfc << 1) | (out.edgec << 2) | (out.reward != 0.0f ? 8 : 0);
             }
         }
         if (g.lane < nt) {
             const long long i = my_t * p.N + env;
             if (SNAKE) {
-                store_action(p.actions, p.act_dtype, i, my_a);
+                store_action(p.actions, p.act_dtype, i, (long long)my_out);
                 p.selfc[i] = (uint8_t)((my_flags >> 1) & 1);
             }
-            p.reward[i] = my_r;
+            p.reward[i] = (my_flags & 8) ? 1.0f : 0.0f;
             p.done[i] = (uint8_t)(my_flags & 1);
             p.edgec[i] = (uint8_t)((my_flags >> 2) & 1);
         }
