@@ -1,0 +1,153 @@
+#!/usr/bin/env python3
+"""Randomised parity fuzz on the GPU box: random shapes, observation modes, dynamics and seeds; HIP (C ABI) vs the CPU
+oracle, bit-exact on every output of every step, per-call and rollout entry points.  Not part of the default test
+suite (run time is the argument); failures print the configuration that reproduces them.
+
+    python tools/fuzz_parity.py --seconds 120 [--seed 0]"""
+import argparse
+import os
+import sys
+import time
+import traceback
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+
+from oracle import oracle as _o  # noqa: E402
+from tests.backends import OracleBackend  # noqa: E402
+from tests.hip_backend import HipBackend  # noqa: E402
+
+
+def same(a, b, what):
+    if a is None and b is None:
+        return
+    x, y = np.asarray(a), np.asarray(b)
+    if x.dtype.kind == 'f':
+        x, y = np.ascontiguousarray(x, np.float32).view(np.uint32), np.ascontiguousarray(y, np.float32).view(np.uint32)
+    assert x.shape == y.shape, f'{what}: shapes {x.shape} {y.shape}'
+    bad = np.argwhere(x != y)
+    assert len(bad) == 0, f'{what}: {len(bad)} mismatches, first {bad[0].tolist()}'
+
+
+def fuzz_single(rng):
+    S = int(rng.choice([9, 9, 10, 11, 12, 13, 16, 20, 25, 31, 36, 40, 48, 57, 64]))
+    N = int(rng.randint(1, 70 if S <= 16 else 12))
+    T = int(rng.randint(5, 120 if S <= 16 else 40))
+    modes = ['default', 'raw', 'one_channel', 'positions', f'partial_{rng.randint(1, 7)}', 'none']
+    mode = modes[rng.randint(len(modes))]
+    seed, off = int(rng.randint(1 << 30)), int(rng.randint(1 << 20))
+    desc = f'single S={S} N={N} T={T} mode={mode} seed={seed} off={off}'
+    o, h = OracleBackend(seed, off), HipBackend(seed, off)
+    eo, eh = np.zeros((N, 3, S, S), np.float32), np.zeros((N, 3, S, S), np.float32)
+    o.single_reset(eo, np.ones(N), 'none'); h.single_reset(eh, np.ones(N), 'none')
+    same(eo, eh, desc + ' fresh')
+    dtype = np.int64 if rng.rand() < 0.7 else np.int32
+    if rng.rand() < 0.5:   # per-call loop with occasional skipped resets
+        skip = rng.rand() < 0.5 and not mode.startswith('partial')
+        for t in range(T):
+            a = rng.randint(0, 4, N).astype(dtype)
+            ao, ah = a.copy(), a.copy()
+            ro, rh = o.single_step(eo, ao, mode), h.single_step(eh, ah, mode)
+            same(ao, ah, f'{desc} actions t={t}'); same(eo, eh, f'{desc} state t={t}')
+            for x, y, w in zip(ro, rh, 'obs reward done sc ec'.split()):
+                same(x, y, f'{desc} {w} t={t}')
+            if skip and t % 4 == 3:
+                o._next(); h._next()
+            else:
+                same(o.single_reset(eo, ro[2], mode), h.single_reset(eh, rh[2], mode), f'{desc} reset obs t={t}')
+                same(eo, eh, f'{desc} reset state t={t}')
+    else:
+        a = rng.randint(0, 4, (T, N)).astype(dtype)
+        ao, ah = a.copy(), a.copy()
+        ro, rh = o.single_rollout(eo, ao, mode), h.single_rollout(eh, ah, mode)
+        for k in ro:
+            same(ro[k], rh[k], f'{desc} rollout {k}')
+        same(ao, ah, desc + ' rollout actions'); same(eo, eh, desc + ' rollout state')
+    return desc
+
+
+def fuzz_grid(rng):
+    S = int(rng.choice([5, 7, 9, 12, 20, 33, 64]))
+    N, T = int(rng.randint(1, 40)), int(rng.randint(5, 80))
+    mode = ['default', 'raw', 'positions', 'none'][rng.randint(4)]
+    start = (int(rng.randint(1, S - 1)), int(rng.randint(1, S - 1)))
+    seed = int(rng.randint(1 << 30))
+    desc = f'grid S={S} N={N} T={T} mode={mode} start={start} seed={seed}'
+    o, h = OracleBackend(seed), HipBackend(seed)
+    eo, eh = np.zeros((N, 2, S, S), np.float32), np.zeros((N, 2, S, S), np.float32)
+    o.grid_reset(eo, np.ones(N), start, 'none'); h.grid_reset(eh, np.ones(N), start, 'none')
+    a = rng.randint(0, 4, (T, N)).astype(np.int64)
+    ro, rh = o.grid_rollout(eo, a.copy(), start, mode), h.grid_rollout(eh, a.copy(), start, mode)
+    for k in ro:
+        same(ro[k], rh[k], f'{desc} {k}')
+    same(eo, eh, desc + ' state')
+    return desc
+
+
+def fuzz_multi(rng):
+    S = int(rng.choice([8, 10, 12, 14, 18, 25, 30, 36, 44]))
+    K = int(rng.choice([1, 2, 2, 3, 4, 4, 5, 8, 10, 16]))
+    while 2 * K * S * S + 8 * S * S > 60000:
+        K = max(1, K // 2)
+    N, T = int(rng.randint(1, 20 if S <= 18 else 6)), int(rng.randint(5, 60 if S <= 18 else 25))
+    mode = ['full', f'partial_{rng.randint(1, 6)}'][rng.randint(2)]
+    cfg = dict(boost=bool(rng.rand() < 0.8), food_on_death_prob=float(rng.choice([0.0, 0.2, 0.5, 0.9, 1.0])),
+               boost_cost_prob=float(rng.choice([0.0, 0.25, 0.5, 1.0])), food_mode=['only_one', 'random_rate'][rng.randint(2)],
+               food_rate=float(rng.choice([5e-4, 5e-3, 5e-2])), reward_on_death=float(rng.choice([-1, -2, 0])),
+               respawn_mode=['all', 'any'][rng.randint(2)], colour_mode=['random', 'fixed'][rng.randint(2)])
+    seed, off = int(rng.randint(1 << 30)), int(rng.randint(1 << 20))
+    desc = f'multi S={S} K={K} N={N} T={T} mode={mode} seed={seed} off={off} cfg={cfg}'
+    o, h = OracleBackend(seed, off), HipBackend(seed, off)
+    so, sh = _o.multi_empty_state(N, K, S), _o.multi_empty_state(N, K, S)
+    so['colours'][...] = o.multi_colours(N, K, cfg['colour_mode'] == 'fixed', call=0)
+    sh['colours'][...] = h.multi_colours(N, K, cfg['colour_mode'] == 'fixed', call=0)
+    o._next(); h._next()
+    fo, fh = o.multi_reset(so, np.ones(N), cfg), h.multi_reset(sh, np.ones(N), cfg)
+    assert fo == fh, f'{desc}: spawn failures {fo} vs {fh}'
+    for k in so:
+        same(so[k], sh[k], f'{desc} fresh {k}')
+    a = rng.randint(0, 8, (T, K, N)).astype(np.int64)
+    if rng.rand() < 0.5:
+        for t in range(T):
+            ro, rh = o.multi_step(so, a[t], cfg, mode), h.multi_step(sh, a[t], cfg, mode)
+            for k in ro:
+                same(ro[k], rh[k], f'{desc} {k} t={t}')
+            for k in so:
+                same(so[k], sh[k], f'{desc} state {k} t={t}')
+            done_env = ro['all_done'] if rng.rand() < 0.8 else (rng.rand(N) < 0.2)
+            o.multi_reset(so, done_env, cfg, mode=mode); h.multi_reset(sh, done_env, cfg, mode=mode)
+            for k in so:
+                same(so[k], sh[k], f'{desc} reset {k} t={t}')
+            same(o.last_reset_obs, h.last_reset_obs, f'{desc} reset obs t={t}')
+    else:
+        ro, rh = o.multi_rollout(so, a, cfg, mode), h.multi_rollout(sh, a, cfg, mode)
+        for k in ro:
+            same(ro[k], rh[k], f'{desc} rollout {k}')
+        for k in so:
+            same(so[k], sh[k], f'{desc} rollout state {k}')
+    same(o.multi_check(so), h.multi_check(sh), desc + ' check')
+    return desc
+
+
+if __name__ == '__main__':
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--seconds', type=float, default=60)
+    ap.add_argument('--seed', type=int, default=0)
+    args = ap.parse_args()
+    rng = np.random.RandomState(args.seed)
+    t0, n, fails = time.time(), {'single': 0, 'grid': 0, 'multi': 0}, 0
+    while time.time() - t0 < args.seconds:
+        kind = ['single', 'grid', 'multi'][rng.choice(3, p=[0.4, 0.1, 0.5])]
+        try:
+            {'single': fuzz_single, 'grid': fuzz_grid, 'multi': fuzz_multi}[kind](rng)
+            n[kind] += 1
+        except AssertionError as e:
+            fails += 1
+            print('MISMATCH:', str(e)[:600])
+        except Exception:
+            fails += 1
+            traceback.print_exc()
+        if fails >= 5:
+            break
+    print(f'fuzz done: {n} cases, {fails} failures, {time.time() - t0:.0f} s')
+    sys.exit(1 if fails else 0)

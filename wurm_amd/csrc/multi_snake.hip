@@ -719,11 +719,14 @@ __device__ __forceinline__ int place_snake(const Ctx &cx, int s, int cell, int d
 __device__ __forceinline__ void colour_from_words(const Words &w, short out[3])
 {
     // get_n_colours (:163-169): rand(3); red / 1.5; normalise; * 192; .short()
-    float c0 = __fdiv_rn(u01(w.w[0]), 1.5f), c1 = u01(w.w[1]), c2 = u01(w.w[2]);
-    float norm = __fsqrt_rn(c0 * c0 + c1 * c1 + c2 * c2);
-    out[0] = (short)(__fdiv_rn(c0, norm) * 192.0f);
-    out[1] = (short)(__fdiv_rn(c1, norm) * 192.0f);
-    out[2] = (short)(__fdiv_rn(c2, norm) * 192.0f);
+    // plain `/` and sqrtf are the correctly rounded IEEE operations here (hipcc's default
+    // -fhip-fp32-correctly-rounded-divide-sqrt); the __fdiv_rn / __fsqrt_rn intrinsics are NOT (found by
+    // tools/fuzz_parity.py: one colour component in thousands came out one lower than on the CPU)
+    float c0 = u01(w.w[0]) / 1.5f, c1 = u01(w.w[1]), c2 = u01(w.w[2]);
+    float norm = sqrtf(c0 * c0 + c1 * c1 + c2 * c2);
+    out[0] = (short)(c0 / norm * 192.0f);
+    out[1] = (short)(c1 / norm * 192.0f);
+    out[2] = (short)(c2 / norm * 192.0f);
 }
 
 // colours of snakes that are still dead are re-rolled on every reset (:800-803).  Returns true if sn.col changed.
