@@ -39,6 +39,8 @@ def pack(a: np.ndarray) -> np.ndarray:
 
 
 def save(name, **arrays):
+    if name is None:  # in-memory use (tests/test_oracle_vs_live_reference.py)
+        return
     path = os.path.join(HERE, name + '.npz')
     np.savez_compressed(path, **arrays)
     print(f'{name}: {os.path.getsize(path) / 1024:.0f} KiB')
@@ -103,6 +105,7 @@ def record_single(name, N, S, T, mode, seed, reset_every=1, act_dtype=torch.long
     rec['meta'] = np.array([N, S, T, seed, reset_every], np.int64)
     rec['mode'] = np.array(mode)
     save(name, **rec)
+    return rec
 
 
 # ------------------------------------------------------------------------------------------- SimpleGridworld
@@ -141,6 +144,7 @@ def record_grid(name, N, S, T, mode, seed, start):
     rec['meta'] = np.array([N, S, T, seed, start[0], start[1]], np.int64)
     rec['mode'] = np.array(mode)
     save(name, **rec)
+    return rec
 
 
 SCENARIOS = {

@@ -230,11 +230,14 @@ def record_multi(name, N, K, S, T, seed, n_actions=8, return_reset_obs=True, **k
                 food_mode=env.food_mode, food_rate=env.food_rate, reward_on_death=env.reward_on_death,
                 respawn_mode=env.respawn_mode, colour_mode=env.colour_mode)
     out['cfg'] = np.array(repr(cfgd))
+    if name is None:  # in-memory use (tests/test_oracle_vs_live_reference.py)
+        return out
     path = os.path.join(HERE, name + '.npz')
     np.savez_compressed(path, **out)
     print(f'{name}: {os.path.getsize(path) / 1024:.0f} KiB; deaths {int(out["dones_out"].sum())}, '
           f'boost steps {int(out["boost"].sum())}, env resets {int(out["all_done"].sum())}, '
           f'food eaten {float(out["food"].sum()):.0f}')
+    return out
 
 
 SCENARIOS = {

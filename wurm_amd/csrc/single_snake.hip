@@ -8,9 +8,12 @@
 //   SimpleGridworld.*     wurm/envs/simple_gridworld.py:88-268
 // with ONE fused launch per call: one env per wavefront, the env's cells spread over the lanes
 // (cell c = lane + 64*k), food/head channels held as per-lane bit sets, the body channel as per-lane ints,
-// per-env scalars wave-uniform via ballot / wave-max, no host sync, no MFMA (integer/index work, HBM-bound).
-// The only LDS use is a one-byte-per-cell class map for the cropped `partial_n` observation and for the
-// general (irregular-state) orientation stencil.
+// per-env scalars wave-uniform via ballots and DPP wave reductions (per-lane partials + one reduction, never one
+// ballot per k), no host sync, no MFMA (integer/index work, HBM-bound).
+// The only LDS use is a one-byte-per-cell class map for the cropped `partial_n` observation on grids > 128 cells and
+// for the general (irregular-state) orientation stencil.
+// rollout_kernel fuses T step+reset iterations with the env resident in registers; for well-formed start states it
+// carries head cell / length / orientation / food cell as scalars (fast_step) instead of re-deriving them.
 #include "wurm_device.hpp"
 #include "../../include/wurm_hip.h"
 

@@ -195,11 +195,6 @@ class MultiSnake(object):
     def _obs_dict(self, obs: torch.Tensor) -> Dict[str, torch.Tensor]:
         return OrderedDict([(f'agent_{i}', o) for i, o in enumerate(obs.unbind(0))])
 
-    def _per_agent(self, tensor: torch.Tensor, key: str) -> Dict[str, torch.Tensor]:
-        """reference :459-460 / :701-729: (N*K) -> {key_i: (N,)} fresh tensors"""
-        cols = tensor.view(self.num_envs, self.num_snakes).t().contiguous().unbind(0)
-        return {f'{key}{i}': d for i, d in enumerate(cols)}
-
     # ------------------------------------------------------------------ colours / rendering (host side, torch ops)
 
     def get_n_colours(self, n: int) -> torch.Tensor:
