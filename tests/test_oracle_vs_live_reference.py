@@ -75,8 +75,13 @@ def test_multi_snake_random_config(rec, seed):
               respawn_mode=['all', 'any'][rng.randint(2)], agent_colours=['random', 'fixed'][rng.randint(2)],
               observation_mode=['full', f'partial_{rng.randint(1, 5)}'][rng.randint(2)],
               reward_on_death=int(rng.choice([-1, -2, 0])))
-    out = rec[1].record_multi(None, N=int(rng.randint(2, 10)), K=K, S=S, T=int(rng.randint(15, 50)), seed=3000 + seed,
-                              **kw)
+    try:
+        out = rec[1].record_multi(None, N=int(rng.randint(2, 10)), K=K, S=S, T=int(rng.randint(15, 50)),
+                                  seed=3000 + seed, **kw)
+    except RuntimeError as e:
+        if 'no available locations' in str(e):
+            pytest.skip('the reference itself cannot place the snakes of this random configuration')
+        raise
     fx = _multi_fx(out)
     replay.replay_multi(OracleBackend(), fx)
     replay.replay_multi_rollout(OracleBackend(), fx)

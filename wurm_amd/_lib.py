@@ -147,5 +147,16 @@ def stream_ptr(device_index=None):
     return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(device_index))
 
 
+def call(device_index, fn, *args):
+    """Calls a C-ABI entry point with `device_index` as the current HIP device (kernels launch on the current device;
+    the stream handed over belongs to `device_index`).  The check is one cheap C call; the guard is only entered when
+    a process that drives several GPUs has another device current."""
+    import torch
+    if torch._C._cuda_getDevice() != device_index:
+        with torch.cuda.device(device_index):
+            return fn(*args)
+    return fn(*args)
+
+
 u64 = ctypes.c_uint64
 i64 = ctypes.c_int64

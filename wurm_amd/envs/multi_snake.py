@@ -122,7 +122,7 @@ class MultiSnake(object):
         else:
             raise ValueError('agent_colours must in {random, fixed}')
         self.agent_colours = torch.empty((N * K, 3), dtype=torch.short, device=dev)
-        rc = _lib.lib().wurm_multi_colours(_lib.ptr(self.agent_colours), _lib.i64(N), K,
+        rc = _lib.call(self.device.index, _lib.lib().wurm_multi_colours, _lib.ptr(self.agent_colours), _lib.i64(N), K,
                                            int(self.colour_mode == 'fixed'), _lib.u64(self.seed),
                                            _lib.u64(self._next_call()), _lib.i64(self.env_offset), _lib.stream_ptr(self.device.index))
         _lib.check(rc, 'MultiSnake.get_n_colours')
@@ -235,7 +235,7 @@ class MultiSnake(object):
             mode = self.observation_mode
         m, n, obs = self._obs_args(mode)
         foods, heads, bodies, dones, _, colours, boost = self._state()
-        rc = _lib.lib().wurm_multi_observe(_lib.ptr(foods), _lib.ptr(heads), _lib.ptr(bodies), _lib.ptr(dones),
+        rc = _lib.call(self.device.index, _lib.lib().wurm_multi_observe, _lib.ptr(foods), _lib.ptr(heads), _lib.ptr(bodies), _lib.ptr(dones),
                                            _lib.ptr(boost), _lib.ptr(colours), _lib.ptr(obs), m, n,
                                            _lib.i64(self.num_envs), self.num_snakes, self.size, _lib.stream_ptr(self.device.index))
         _lib.check(rc, 'MultiSnake._observe')
@@ -272,7 +272,7 @@ class MultiSnake(object):
         am_b = torch.empty((4, K, N), dtype=torch.bool, device=dev)     # agent-major: dones, boost, snake, edge
         all_done = torch.empty(N, dtype=torch.bool, device=dev)
         cfg = self._cfg()
-        rc = _lib.lib().wurm_multi_step(
+        rc = _lib.call(self.device.index, _lib.lib().wurm_multi_step, 
             _lib.ptr(foods), _lib.ptr(heads), _lib.ptr(bodies), _lib.ptr(dones), _lib.ptr(orientations),
             _lib.ptr(stacked), _lib.ptr(bl[0]), _lib.ptr(fl[0]), _lib.ptr(bl[1]), _lib.ptr(bl[2]), _lib.ptr(fl[1]),
             _lib.ptr(fl[2]), _lib.ptr(all_done), _lib.ptr(colours), _lib.ptr(obs), m, n, _lib.i64(N), K, S,
@@ -324,7 +324,7 @@ class MultiSnake(object):
         out_b = torch.empty((T, 4, K, N), dtype=torch.bool, device=dev)
         all_done = torch.empty((T, N), dtype=torch.bool, device=dev)
         cfg = self._cfg()
-        rc = _lib.lib().wurm_multi_rollout(
+        rc = _lib.call(self.device.index, _lib.lib().wurm_multi_rollout, 
             _lib.ptr(foods), _lib.ptr(heads), _lib.ptr(bodies), _lib.ptr(dones), _lib.ptr(orientations),
             _lib.ptr(colours), _lib.ptr(boost), _lib.ptr(actions), _lib.ptr(out_f), _lib.ptr(out_b), _lib.ptr(all_done),
             _lib.ptr(obs), m, n, _lib.i64(N), K, S, _lib.i64(T), ctypes.byref(cfg), _lib.u64(self.seed),
@@ -343,7 +343,7 @@ class MultiSnake(object):
         """reference :733-769: raises RuntimeError if any env is inconsistent"""
         foods, heads, bodies, dones, _, _, _ = self._state()
         err = torch.empty(self.num_envs, dtype=torch.int32, device=self.device)
-        rc = _lib.lib().wurm_multi_check(_lib.ptr(foods), _lib.ptr(heads), _lib.ptr(bodies), _lib.ptr(dones),
+        rc = _lib.call(self.device.index, _lib.lib().wurm_multi_check, _lib.ptr(foods), _lib.ptr(heads), _lib.ptr(bodies), _lib.ptr(dones),
                                          _lib.ptr(err), _lib.i64(self.num_envs), self.num_snakes, self.size,
                                          _lib.stream_ptr(self.device.index))
         _lib.check(rc, 'MultiSnake.check_consistency')
@@ -364,7 +364,7 @@ class MultiSnake(object):
         m, n, obs = self._obs_args(self.observation_mode if observe else None)
         status = torch.zeros(1, dtype=torch.int32, device=self.device) if want_status else None
         cfg = self._cfg()
-        rc = _lib.lib().wurm_multi_reset(
+        rc = _lib.call(self.device.index, _lib.lib().wurm_multi_reset, 
             _lib.ptr(foods), _lib.ptr(heads), _lib.ptr(bodies), _lib.ptr(dones), _lib.ptr(orientations),
             _lib.ptr(colours), _lib.ptr(done), _lib.ptr(status), _lib.ptr(boost), _lib.ptr(obs), m, n,
             _lib.i64(self.num_envs), self.num_snakes, self.size, ctypes.byref(cfg), _lib.u64(self.seed),
@@ -410,7 +410,7 @@ class MultiSnake(object):
         status = torch.zeros(1, dtype=torch.int32, device=dev)
         cfg = self._cfg()
         cfg.respawn_any = 0
-        rc = _lib.lib().wurm_multi_reset(
+        rc = _lib.call(self.device.index, _lib.lib().wurm_multi_reset, 
             _lib.ptr(foods), _lib.ptr(heads), _lib.ptr(bodies), _lib.ptr(dones), _lib.ptr(orientations),
             _lib.ptr(colours), _lib.ptr(ones), _lib.ptr(status), None, None, _lib.OBS_NONE, 0, _lib.i64(num_envs), K,
             S, ctypes.byref(cfg), _lib.u64(self.seed), _lib.u64(self._next_call()), _lib.i64(self.env_offset), None,

@@ -84,7 +84,7 @@ class SimpleGridworld(object):
         shape = self._obs_shape(observation_mode)
         m, n = _lib.parse_obs_mode(observation_mode)
         obs = torch.empty(shape, dtype=torch.float32, device=self.device)
-        rc = _lib.lib().wurm_grid_observe(_lib.ptr(self._state()), _lib.ptr(obs), m, n, _lib.i64(self.num_envs),
+        rc = _lib.call(self.device.index, _lib.lib().wurm_grid_observe, _lib.ptr(self._state()), _lib.ptr(obs), m, n, _lib.i64(self.num_envs),
                                           self.size, _lib.stream_ptr(self.device.index))
         _lib.check(rc, 'SimpleGridworld._observe')
         return obs
@@ -116,7 +116,7 @@ class SimpleGridworld(object):
         reward = torch.empty(N, dtype=torch.float32, device=self.device)
         flags = torch.empty((2, N), dtype=torch.bool, device=self.device)
         done, edge_collision = flags[0], flags[1]
-        rc = _lib.lib().wurm_grid_step(
+        rc = _lib.call(self.device.index, _lib.lib().wurm_grid_step, 
             _lib.ptr(envs), _lib.ptr(act), _lib.ACT_I64 if act.dtype == torch.long else _lib.ACT_I32,
             _lib.ptr(reward), _lib.ptr(done), _lib.ptr(edge_collision), _lib.ptr(obs), m, n, _lib.i64(N), self.size,
             _lib.u64(self.seed), _lib.u64(self._next_call()), _lib.i64(self.env_offset), None, _lib.stream_ptr(self.device.index))
@@ -139,7 +139,7 @@ class SimpleGridworld(object):
             obs = torch.empty(self._obs_shape(self.observation_mode), dtype=torch.float32, device=self.device)
         else:
             m, n, obs = _lib.OBS_NONE, 0, None
-        rc = _lib.lib().wurm_grid_reset(
+        rc = _lib.call(self.device.index, _lib.lib().wurm_grid_reset, 
             _lib.ptr(envs), _lib.ptr(done), _lib.ptr(obs), m, n, _lib.i64(self.num_envs), self.size,
             int(self.start_location[0]), int(self.start_location[1]), _lib.u64(self.seed),
             _lib.u64(self._next_call()), _lib.i64(self.env_offset), None, _lib.stream_ptr(self.device.index))
@@ -176,7 +176,7 @@ class SimpleGridworld(object):
             m, n, obs = _lib.OBS_NONE, 0, None
         reward = torch.empty((T, N), dtype=torch.float32, device=self.device)
         flags = torch.empty((2, T, N), dtype=torch.bool, device=self.device)
-        rc = _lib.lib().wurm_grid_rollout(
+        rc = _lib.call(self.device.index, _lib.lib().wurm_grid_rollout, 
             _lib.ptr(envs), _lib.ptr(actions), _lib.ACT_I64 if actions.dtype == torch.long else _lib.ACT_I32,
             _lib.ptr(reward), _lib.ptr(flags[0]), _lib.ptr(flags[1]), _lib.ptr(obs), m, n, _lib.i64(N), self.size,
             _lib.i64(T), int(self.start_location[0]), int(self.start_location[1]), _lib.u64(self.seed),

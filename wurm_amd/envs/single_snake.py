@@ -141,7 +141,7 @@ class SingleSnake(object):
         m, n, shape = self._mode_info(observation_mode)
         envs = self._state()
         obs = torch.empty(shape, dtype=torch.float32, device=self.device)
-        rc = _lib.lib().wurm_single_observe(_lib.ptr(envs), _lib.ptr(obs), m, n, _lib.i64(self.num_envs),
+        rc = _lib.call(self.device.index, _lib.lib().wurm_single_observe, _lib.ptr(envs), _lib.ptr(obs), m, n, _lib.i64(self.num_envs),
                                             self.size, _lib.stream_ptr(self.device.index))
         _lib.check(rc, 'SingleSnake._observe')
         return obs
@@ -176,7 +176,7 @@ class SingleSnake(object):
         flags = torch.empty((3, N), dtype=torch.bool, device=self.device)
         done, self_collision, edge_collision = flags[0], flags[1], flags[2]
 
-        rc = _lib.lib().wurm_single_step(
+        rc = _lib.call(self.device.index, _lib.lib().wurm_single_step, 
             _lib.ptr(envs), _lib.ptr(act), _lib.ACT_I64 if act.dtype == torch.long else _lib.ACT_I32,
             _lib.ptr(reward), _lib.ptr(done), _lib.ptr(self_collision), _lib.ptr(edge_collision), _lib.ptr(obs),
             m, n, _lib.i64(N), self.size, _lib.u64(self.seed), _lib.u64(self._next_call()),
@@ -205,7 +205,7 @@ class SingleSnake(object):
             obs = torch.empty(shape, dtype=torch.float32, device=self.device)
         else:
             m, n, obs = _lib.OBS_NONE, 0, None
-        rc = _lib.lib().wurm_single_reset(
+        rc = _lib.call(self.device.index, _lib.lib().wurm_single_reset, 
             _lib.ptr(envs), _lib.ptr(done), _lib.ptr(obs), m, n, _lib.i64(self.num_envs), self.size,
             _lib.u64(self.seed), _lib.u64(self._next_call()), _lib.i64(self.env_offset), None, _lib.stream_ptr(self.device.index))
         _lib.check(rc, 'SingleSnake.reset')
@@ -237,7 +237,7 @@ class SingleSnake(object):
             raise NotImplementedError('Only initial snake length = 3 has been implemented.')
         envs = torch.zeros((num_envs, 3, self.size, self.size), device=self.device)
         done = torch.ones(num_envs, dtype=torch.bool, device=self.device)
-        rc = _lib.lib().wurm_single_reset(
+        rc = _lib.call(self.device.index, _lib.lib().wurm_single_reset, 
             _lib.ptr(envs), _lib.ptr(done), None, _lib.OBS_NONE, 0, _lib.i64(num_envs), self.size,
             _lib.u64(self.seed), _lib.u64(self._next_call()), _lib.i64(self.env_offset), None, _lib.stream_ptr(self.device.index))
         _lib.check(rc, 'SingleSnake._create_envs')
@@ -266,7 +266,7 @@ class SingleSnake(object):
             m, n, obs = _lib.OBS_NONE, 0, None
         reward = torch.empty((T, N), dtype=torch.float32, device=self.device)
         flags = torch.empty((3, T, N), dtype=torch.bool, device=self.device)
-        rc = _lib.lib().wurm_single_rollout(
+        rc = _lib.call(self.device.index, _lib.lib().wurm_single_rollout, 
             _lib.ptr(envs), _lib.ptr(actions), _lib.ACT_I64 if actions.dtype == torch.long else _lib.ACT_I32,
             _lib.ptr(reward), _lib.ptr(flags[0]), _lib.ptr(flags[1]), _lib.ptr(flags[2]), _lib.ptr(obs), m, n,
             _lib.i64(N), self.size, _lib.i64(T), _lib.u64(self.seed), _lib.u64(self._next_call(2 * T)),

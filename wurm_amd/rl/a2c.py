@@ -23,7 +23,7 @@ class _Returns(torch.autograd.Function):
     def forward(ctx, bootstrap, rewards, values, dones, gamma, use_gae, gamma_lambda):
         T, N = rewards.shape
         returns = torch.empty((T, N), dtype=torch.float32, device=rewards.device)
-        rc = _lib.lib().wurm_a2c_returns(_lib.ptr(bootstrap), _lib.ptr(rewards), _lib.ptr(values), _lib.ptr(dones),
+        rc = _lib.call(rewards.device.index, _lib.lib().wurm_a2c_returns, _lib.ptr(bootstrap), _lib.ptr(rewards), _lib.ptr(values), _lib.ptr(dones),
                                          ctypes.c_float(gamma), int(use_gae), ctypes.c_float(gamma_lambda),
                                          _lib.ptr(returns), _lib.i64(T), _lib.i64(N),
                                          _lib.stream_ptr(rewards.device.index))
@@ -41,7 +41,7 @@ class _Returns(torch.autograd.Function):
         need_b, _, need_v = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
         grad_values = torch.empty((T, N), dtype=torch.float32, device=g.device) if need_v else None
         grad_boot = torch.empty(N, dtype=torch.float32, device=g.device) if need_b else None
-        rc = _lib.lib().wurm_a2c_returns_backward(_lib.ptr(g), _lib.ptr(dones), ctypes.c_float(gamma), int(use_gae),
+        rc = _lib.call(g.device.index, _lib.lib().wurm_a2c_returns_backward, _lib.ptr(g), _lib.ptr(dones), ctypes.c_float(gamma), int(use_gae),
                                                   ctypes.c_float(gamma_lambda), _lib.ptr(grad_values),
                                                   _lib.ptr(grad_boot), _lib.i64(T), _lib.i64(N),
                                                   _lib.stream_ptr(g.device.index))

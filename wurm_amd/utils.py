@@ -56,7 +56,7 @@ def consistency_mask(envs: torch.Tensor) -> torch.Tensor:
     e = envs.to(torch.float32).contiguous()
     n, S = e.shape[0], e.shape[2]
     err = torch.empty(n, dtype=torch.int32, device=e.device)
-    rc = _lib.lib().wurm_single_check(_lib.ptr(e), _lib.ptr(err), _lib.i64(n), S, _lib.stream_ptr(e.device.index))
+    rc = _lib.call(e.device.index, _lib.lib().wurm_single_check, _lib.ptr(e), _lib.ptr(err), _lib.i64(n), S, _lib.stream_ptr(e.device.index))
     _lib.check(rc, 'env_consistency')
     return err
 
@@ -113,6 +113,6 @@ def determine_orientations(envs: torch.Tensor) -> torch.Tensor:
     e = envs.to(torch.float32).contiguous()
     n, S = e.shape[0], e.shape[2]
     out = torch.empty(n, dtype=torch.long, device=e.device)
-    rc = _lib.lib().wurm_orientations(_lib.ptr(e), _lib.ptr(out), _lib.i64(n), S, _lib.stream_ptr(e.device.index))
+    rc = _lib.call(e.device.index, _lib.lib().wurm_orientations, _lib.ptr(e), _lib.ptr(out), _lib.i64(n), S, _lib.stream_ptr(e.device.index))
     _lib.check(rc, 'determine_orientations')
     return out
