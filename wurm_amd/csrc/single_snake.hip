@@ -795,19 +795,11 @@ __device__ __forceinline__ void fast_partial_small(const Env<CPL> &e, const Geo 
 // OBSK >= 0 fixes the observation mode at compile time and INJ = false compiles the injection plumbing out: the
 // flagship configuration (9x9, partial_n / no observation, RNG mode) gets a lean instantiation, everything else the
 // fully general one (OBSK = -1, INJ = true).
-template <int CPL, bool SNAKE, int OBSK = -1, bool INJ = true>
-__global__ __launch_bounds__(256) void rollout_kernel(StepArgs p)
+template <int CPL, bool SNAKE, int OBSK, bool INJ>
+__device__ __forceinline__ void rollout_generic(const StepArgs &p, long long env, float *__restrict__ envp, const Geo &g,
+                                                Env<CPL> &e, signed char *lds)
 {
-    const int wave = (int)(threadIdx.x >> 6), wpb = (int)(blockDim.x >> 6);
-    const long long env = (long long)blockIdx.x * wpb + wave;
-    if (env >= p.N) return;
-    signed char *lds = wurm_lds + wave * p.lds_per_wave;
-    const int NCH = SNAKE ? 3 : 2;
-    const Geo g = make_geo<CPL>(p.S);
-    float *envp = p.envs + env * NCH * g.C;
     const u64 env_id = (u64)(p.env_offset + env);
-    Env<CPL> e;
-    load_state<CPL, SNAKE>(envp, g, e);
     const bool inj_f = INJ && p.inject_food != nullptr, inj_r = INJ && p.inject_reset != nullptr;
     const int obs_mode = OBSK >= 0 ? OBSK : p.obs_mode;
     Fast f = {-1, 0, 0, 0, 0, -1};
@@ -874,6 +866,236 @@ __global__ __launch_bounds__(256) void rollout_kernel(StepArgs p)
     }
     if (SNAKE && fast) fast_sync_bits<CPL>(e, g, f);
     store_state<CPL, SNAKE>(envp, g, e);
+}
+
+template <int CPL, bool SNAKE, int OBSK = -1, bool INJ = true>
+__global__ __launch_bounds__(256) void rollout_kernel(StepArgs p)
+{
+    const int wave = uniform((int)(threadIdx.x >> 6)), wpb = (int)(blockDim.x >> 6);
+    const long long env = (long long)blockIdx.x * wpb + wave;
+    if (env >= p.N) return;
+    signed char *lds = wurm_lds + wave * p.lds_per_wave;
+    const Geo g = make_geo<CPL>(p.S);
+    float *envp = p.envs + env * (SNAKE ? 3 : 2) * g.C;
+    Env<CPL> e;
+    load_state<CPL, SNAKE>(envp, g, e);
+    rollout_generic<CPL, SNAKE, OBSK, INJ>(p, env, envp, g, e, lds);
+}
+
+// ---------------------------------------------------------------------------------------------- lean rollout
+// The headline shape — SingleSnake on a grid of at most 128 cells (S <= 11), partial_n crop of at most 64 window
+// cells (n <= 3) or no observation, RNG mode — runs 512 envs as 512 lone waves on 1024 SIMDs: nothing hides
+// latency, every instruction costs its full issue slot and every taken branch an instruction-fetch bubble, so the
+// loop below is written for instruction count (PMC: 205 -> ~95 instructions per env-step).  On top of the scalar
+// carry of `Fast` it uses
+//   * a virtual clock for the body channel: cell value = max(expire - T, 0).  A step that does not eat advances T
+//     (= "every body cell decays by one", single_snake.py:246-249) and a step that eats leaves it alone; only the new
+//     head cell is written (expire = T + L), so the decay costs no per-cell work;
+//   * everything a reset needs (single_snake.py:344-387: seed cell, direction, the three body cells, the food cell)
+//     depends only on (seed, env, call), never on the state: lane j of the wave computes the would-be reset of step
+//     t0+j — both Philox blocks included — once per 64-step chunk, in parallel, and a reset is two readlanes;
+//   * the food draw of an eating step (purpose RNG_FOOD) is precomputed the same way; only the rank select over the
+//     free cells, which does depend on the state, runs when food is eaten;
+//   * observation masks combined as 64-bit scalar lane masks; lanes past the window duplicate its last cell
+//     instead of being masked off.
+// Preconditions (else the kernel runs rollout_generic): fast_init's well-formed snake, a head strictly inside the
+// border ring, and no food on a body cell.  They are preserved by step + reset, so they are checked once.
+// A state that self-collided is rebuilt by the reset of the same iteration, so the value under the new head is not
+// accumulated (only its occupancy is observable, through the crop).
+
+struct LeanReset {
+    int a; // hy | hx << 4 | d << 8 | food cell << 10
+    int b; // head cell | seed cell << 7 | tail cell << 14
+};
+
+// would-be reset of (env, call): reset_core / fast_reset in closed form.  After a rebuild the free interior cells
+// are the (S-2)^2 interior cells minus the three collinear snake cells, so the K-th free cell in row-major order is
+// the K-th interior cell pushed past the snake cells' interior ranks in ascending order.
+__device__ __forceinline__ LeanReset lean_reset_draw(u64 seed, u64 call, u64 env_id, int S, float rcpSm2)
+{
+    const Words w = rng_words(seed, call, env_id, RNG_RESET, 0);
+    const int Sm2 = S - 2;
+    const int sy = 4 + (int)mulhi_range(w.w[0], (u32)(S - 8));
+    const int sx = 4 + (int)mulhi_range(w.w[1], (u32)(S - 8));
+    const int d = (int)(w.w[2] >> 30);
+    const int ty = tap_y(d), tx = tap_x(d);
+    const int hy = sy + ty, hx = sx + tx;
+    const int rs = (sy - 1) * Sm2 + sx - 1, dr = ty * Sm2 + tx; // interior rank of the seed cell; head = rs + dr
+    const int lo = rs - abs(dr), hi = rs + abs(dr);
+    int K = (int)mulhi_range(w.w[3], (u32)(Sm2 * Sm2 - 3));
+    K += K >= lo;
+    K += K >= rs;
+    K += K >= hi;
+    const int qy = div_size(K, rcpSm2), qx = K - qy * Sm2;
+    const int food = (qy + 1) * S + qx + 1;
+    const int sc = sy * S + sx, dc = ty * S + tx;
+    LeanReset r;
+    r.a = hy | (hx << 4) | (d << 8) | (food << 10);
+    r.b = (sc + dc) | (sc << 7) | ((sc - dc) << 14);
+    return r;
+}
+
+// K-th free interior cell (K = mulhi(word, n_free)) given the occupancy masks of cells 0..63 / 64..127; -1 if none
+__device__ __forceinline__ int lean_food_cell(u64 m0, u64 m1, u64 int0, u64 int1, u32 word, int lane)
+{
+    const u64 F0 = int0 & ~m0, F1 = int1 & ~m1;
+    const int n0 = popc64(F0), n_free = n0 + popc64(F1);
+    if (n_free == 0) return -1;
+    const int K = (int)mulhi_range(word, (u32)n_free);
+    const bool second = K >= n0;
+    const u64 F = second ? F1 : F0;
+    const int K2 = second ? K - n0 : K;
+    const u64 hit = ballot((int)((F >> lane) & 1) & (int)(rank_below(F) == K2));
+    return (second ? 64 : 0) + first_bit(hit);
+}
+
+template <int OBSK, bool COMPACT>
+__global__ __launch_bounds__(256) void rollout_lean_kernel(StepArgs p)
+{
+    constexpr int CPL = 2;
+    static_assert(OBSK == WURM_OBS_PARTIAL || OBSK == WURM_OBS_NONE, "lean rollout: partial_n or no observation");
+    const int wave = uniform((int)(threadIdx.x >> 6)), wpb = (int)(blockDim.x >> 6);
+    const long long env = (long long)blockIdx.x * wpb + wave;
+    if (env >= p.N) return;
+    const Geo g = make_geo<CPL>(p.S);
+    const int S = g.S, Sm2 = S - 2, lane = g.lane;
+    float *envp = p.envs + env * 3 * g.C;
+    Env<CPL> e;
+    load_state<CPL, true>(envp, g, e);
+
+    Fast f = {-1, 0, 0, 0, 0, -1};
+    bool lean = fast_init<CPL>(e, g, f);
+    if (lean) {
+        const bool head_in = f.hc >= 0 && (unsigned)(f.hy - 1) < (unsigned)Sm2 && (unsigned)(f.hx - 1) < (unsigned)Sm2;
+        int under_food = 0;
+        if (f.food >= 0) under_food = lane_value(f.food >= 64 ? e.body[1] : e.body[0], f.food & 63);
+        lean = head_in && under_food == 0;
+    }
+    if (!uniform((int)lean)) {
+        rollout_generic<CPL, true, OBSK, false>(p, env, envp, g, e, wurm_lds + wave * p.lds_per_wave);
+        return;
+    }
+
+    const u64 env_id = (u64)(p.env_offset + env);
+    const u64 int0 = ballot((g.interior & 1) != 0), int1 = ballot((g.interior & 2) != 0);
+    const float rcpSm2 = 1.0f / (float)Sm2;
+    int hy = uniform(f.hy), hx = uniform(f.hx), hc = uniform(f.hc), L = uniform(f.L), o = uniform(f.o);
+    int food = uniform(f.food);
+    int T = 0;
+    int ex0 = e.body[0], ex1 = e.body[1]; // expiry clock of cells lane, lane + 64
+
+    // partial_n crop: lane owns window cell w (lanes past the window repeat its last cell: same address, same value)
+    const int n = OBSK == WURM_OBS_PARTIAL ? p.obs_n : 0, W = 2 * n + 1, W2 = W * W;
+    const int w = min(lane, W2 - 1), wy = div_size(w, 1.0f / (float)W), wx = w - wy * W;
+    const int dy1 = wy - n - 1, dx1 = wx - n - 1;                       // window row / column offset, minus one
+    const int doff = (wy - n) * S + (wx - n) - (COMPACT ? S + 1 : 0);   // cell offset from the head cell
+    const bool centre = w == n * W + n;
+    const u32 off_r = (u32)w * 4u, off_g = (u32)(W2 + w) * 4u, off_b = (u32)(2 * W2 + w) * 4u;
+    const long long obs_stride = p.N * p.obs_elems;
+    float *obs_t = p.obs + env * p.obs_elems;
+
+    for (long long t0 = 0; t0 < p.T; t0 += 64) {
+        const int nt = (int)min((long long)64, p.T - t0);
+        const long long my_t = t0 + lane;
+        long long my_a = lane < nt ? load_action(p.actions, p.act_dtype, my_t * p.N + env) : 0;
+        asm volatile("" : "+v"(my_a)); // retire the load here, not in front of the first readlane of the step loop
+        // a_small (the action if it is one of 0..3, else 7) | (action % 4 + 3) << 3
+        const int my_pack = ((my_a >= 0 && my_a < 4) ? (int)my_a : 7) | (((int)(my_a % 4) + 3) << 3);
+        const u64 my_call = p.call + 2ull * (u64)my_t; // step t uses call0 + 2t, its reset call0 + 2t + 1
+        const LeanReset my_reset = lean_reset_draw(p.seed, my_call + 1ull, env_id, S, rcpSm2);
+        const int my_food = (int)rng_words(p.seed, my_call, env_id, RNG_FOOD, 0).w[0];
+        int my_out = 0; // sanitised action & 7 | done << 3 | self collision << 4 | edge collision << 5 | ate << 6
+        // re-base the clock so that it cannot overflow however long the tape is
+        ex0 = max(ex0 - T, 0);
+        ex1 = max(ex1 - T, 0);
+        T = 0;
+
+        for (int j = 0; j < nt; ++j) {
+            // ---- step (single_snake.py:197-304; same line references as step_core / fast_step)
+            const int pk = lane_value(my_pack, j);
+            const int a_small = pk & 7, a_mod = (pk >> 3) - 3;
+            const int a_out = o == a_small ? (o ^ 2) : a_mod;              // :221-222
+            const int ai = a_out & 3;
+            // head - TAP[ai] (:225-233; the head is off the border ring, so the move stays on the grid):
+            // 1 - tap_y = {0,1,2,1}, 1 - tap_x = {1,2,1,0} as 2-bit fields of one constant
+            const int tap = 0x1964 >> (2 * ai);
+            const int ny = hy + 1 - (tap & 3), nx = hx + 1 - ((tap >> 8) & 3);
+            const int nh = ny * S + nx;
+            const int ate = nh == food ? 1 : 0;                            // :242
+            const bool eat = ate != 0;
+            T += 1 - ate;                                                  // :246-249
+            L += ate;
+            const int under = lane_value(nh >= 64 ? ex1 : ex0, nh & 63);
+            const bool selfc = under > T;                                  // :252
+            const bool edgec = !((unsigned)(ny - 1) < (unsigned)Sm2 && (unsigned)(nx - 1) < (unsigned)Sm2); // :290-295
+            const bool done = selfc | edgec;
+            const int grown = T + L;                                       // :258-262
+            ex0 = lane == nh ? grown : ex0;
+            ex1 = lane + 64 == nh ? grown : ex1;
+            hy = ny; hx = nx; hc = nh;
+            o = ai ^ 2;
+            u64 m0 = 0, m1 = 0;
+            if (OBSK == WURM_OBS_PARTIAL || eat) {
+                m0 = ballot(ex0 > T);
+                m1 = ballot(ex1 > T);
+            }
+            if (eat) food = lean_food_cell(m0, m1, int0, int1, (u32)lane_value(my_food, j), lane); // :270-282
+
+            // ---- observation of the stepped state (single_snake.py:166-193): a window cell that is off the grid or
+            // on the border ring is (0,0,0); food (1,0,0), head (0,1,0), body (0,127/255,0), background (1,1,1)
+            if (OBSK == WURM_OBS_PARTIAL) {
+                const bool live = (unsigned)(hy + dy1) < (unsigned)Sm2 && (unsigned)(hx + dx1) < (unsigned)Sm2;
+                const int cell = hc + doff;
+                bool occ;
+                if (COMPACT) { // interior cells S+1 .. S*S-S-2 fit one 64-bit mask
+                    const u64 M = (m0 >> (S + 1)) | (m1 << (63 - S));
+                    occ = ((M >> (cell & 63)) & 1) != 0;
+                } else {
+                    occ = (((cell < 64 ? m0 : m1) >> (cell & 63)) & 1) != 0;
+                }
+                const bool is_food = cell + (COMPACT ? S + 1 : 0) == food;
+                const bool red = live & !occ, bg = red & !is_food;
+                const float vb = bg ? 1.0f : 0.0f, vr = red ? 1.0f : 0.0f;
+                float vg = (live & occ) ? 127.0f / 255.0f : vb;
+                vg = (live & centre) ? 1.0f : vg;
+                // scalar base + 32-bit lane offset form, spelled out: the compiler hoists the zero-extension of the
+                // lane offsets out of the loop and then pays a 64-bit VALU add per store.  (Untracked stores are
+                // harmless for its vmcnt bookkeeping: nothing is read back and waits only become conservative.)
+                asm volatile("global_store_dword %0, %1, %2" : : "v"(off_r), "v"(vr), "s"(obs_t) : "memory");
+                asm volatile("global_store_dword %0, %1, %2" : : "v"(off_g), "v"(vg), "s"(obs_t) : "memory");
+                asm volatile("global_store_dword %0, %1, %2" : : "v"(off_b), "v"(vb), "s"(obs_t) : "memory");
+                obs_t += obs_stride;
+            }
+
+            const int po = (a_out & 7) | (done ? 8 : 0) | (selfc ? 16 : 0) | (edgec ? 32 : 0) | (eat ? 64 : 0);
+            my_out = lane == j ? po : my_out; // lane j keeps step t0 + j
+
+            // ---- reset of a finished env (single_snake.py:322-387)
+            if (done) {
+                const int ra = lane_value(my_reset.a, j), rb = lane_value(my_reset.b, j);
+                hy = ra & 15; hx = (ra >> 4) & 15; o = (ra >> 8) & 3; food = ra >> 10;
+                hc = rb & 127;
+                const int sc = (rb >> 7) & 127, tc = rb >> 14;
+                const int c1 = lane + 64;
+                ex0 = lane == tc ? T + 1 : 0; ex0 = lane == sc ? T + 2 : ex0; ex0 = lane == hc ? T + 3 : ex0;
+                ex1 = c1 == tc ? T + 1 : 0;   ex1 = c1 == sc ? T + 2 : ex1;   ex1 = c1 == hc ? T + 3 : ex1;
+                L = 3;
+            }
+        }
+        if (lane < nt) {
+            const long long i = my_t * p.N + env;
+            store_action(p.actions, p.act_dtype, i, (long long)((my_out << 29) >> 29));
+            p.reward[i] = (my_out & 64) ? 1.0f : 0.0f;
+            p.done[i] = (uint8_t)((my_out >> 3) & 1);
+            p.selfc[i] = (uint8_t)((my_out >> 4) & 1);
+            p.edgec[i] = (uint8_t)((my_out >> 5) & 1);
+        }
+    }
+    e.body[0] = max(ex0 - T, 0);
+    e.body[1] = max(ex1 - T, 0);
+    f.hc = hc; f.hy = hy; f.hx = hx; f.L = L; f.o = o; f.food = food;
+    fast_sync_bits<CPL>(e, g, f);
+    store_state<CPL, true>(envp, g, e);
 }
 
 // wurm.utils.env_consistency (wurm/utils.py:113-178) per env, as an error bitmask
@@ -957,6 +1179,15 @@ static hipError_t launch_one(Kind kind, const StepArgs &p, dim3 grid, dim3 block
     case K_ROLLOUT:
         if constexpr (SNAKE && CPL == 2) {
             const bool rng_mode = p.inject_food == nullptr && p.inject_reset == nullptr;
+            if (rng_mode && p.S >= 9 && ((p.obs_mode == WURM_OBS_PARTIAL && p.obs_n <= 3) || p.obs_mode == WURM_OBS_NONE)) {
+                if (p.obs_mode == WURM_OBS_NONE)
+                    hipLaunchKernelGGL((rollout_lean_kernel<WURM_OBS_NONE, false>), grid, block, lds, st, p);
+                else if (p.S <= 9)
+                    hipLaunchKernelGGL((rollout_lean_kernel<WURM_OBS_PARTIAL, true>), grid, block, lds, st, p);
+                else
+                    hipLaunchKernelGGL((rollout_lean_kernel<WURM_OBS_PARTIAL, false>), grid, block, lds, st, p);
+                break;
+            }
             if (rng_mode && p.obs_mode == WURM_OBS_PARTIAL && p.obs_n <= 6) {
                 hipLaunchKernelGGL((rollout_kernel<CPL, SNAKE, WURM_OBS_PARTIAL, false>), grid, block, lds, st, p);
                 break;
