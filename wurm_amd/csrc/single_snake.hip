@@ -981,8 +981,21 @@ __global__ __launch_bounds__(256) void rollout_lean_kernel(StepArgs p)
     const float rcpSm2 = 1.0f / (float)Sm2;
     int hy = uniform(f.hy), hx = uniform(f.hx), hc = uniform(f.hc), L = uniform(f.L), o = uniform(f.o);
     int food = uniform(f.food);
-    int T = 0;
-    int ex0 = e.body[0], ex1 = e.body[1]; // expiry clock of cells lane, lane + 64
+    int foodc = food - (COMPACT ? S + 1 : 0); // the food cell in the crop's cell numbering
+    int G = L;                                // G = T + L: the expiry clock a new head cell gets; +1 every step
+    int ex0 = e.body[0], ex1 = e.body[1];     // expiry clock of cells lane, lane + 64
+
+    // Move table, one entry per lane: lane = orientation * 16 + action code (0..3: that action; 4..10: an action
+    // outside 0..3 with action % 4 = code - 7).  Entry = sanitised action (single_snake.py:221-222) & 7
+    // | next orientation << 3 | (row step & 3) << 5 | (column step & 3) << 7 | cell step << 9, the step being -TAP[action].
+    int move_tab;
+    {
+        const int to = lane >> 4, tc = lane & 15;
+        const int a_small = tc < 4 ? tc : 7, a_mod = tc < 4 ? tc : tc - 7;
+        const int a_out = to == a_small ? (to ^ 2) : a_mod;
+        const int ai = a_out & 3, dy = -tap_y(ai), dx = -tap_x(ai);
+        move_tab = (a_out & 7) | ((ai ^ 2) << 3) | ((dy & 3) << 5) | ((dx & 3) << 7) | ((dy * S + dx) << 9);
+    }
 
     // partial_n crop: lane owns window cell w (lanes past the window repeat its last cell: same address, same value)
     const int n = OBSK == WURM_OBS_PARTIAL ? p.obs_n : 0, W = 2 * n + 1, W2 = W * W;
@@ -999,62 +1012,58 @@ __global__ __launch_bounds__(256) void rollout_lean_kernel(StepArgs p)
         const long long my_t = t0 + lane;
         long long my_a = lane < nt ? load_action(p.actions, p.act_dtype, my_t * p.N + env) : 0;
         asm volatile("" : "+v"(my_a)); // retire the load here, not in front of the first readlane of the step loop
-        // a_small (the action if it is one of 0..3, else 7) | (action % 4 + 3) << 3
-        const int my_pack = ((my_a >= 0 && my_a < 4) ? (int)my_a : 7) | (((int)(my_a % 4) + 3) << 3);
+        const int my_code = (my_a >= 0 && my_a < 4) ? (int)my_a : (int)(my_a % 4) + 7;
         const u64 my_call = p.call + 2ull * (u64)my_t; // step t uses call0 + 2t, its reset call0 + 2t + 1
         const LeanReset my_reset = lean_reset_draw(p.seed, my_call + 1ull, env_id, S, rcpSm2);
         const int my_food = (int)rng_words(p.seed, my_call, env_id, RNG_FOOD, 0).w[0];
-        int my_out = 0; // sanitised action & 7 | done << 3 | self collision << 4 | edge collision << 5 | ate << 6
-        // re-base the clock so that it cannot overflow however long the tape is
-        ex0 = max(ex0 - T, 0);
-        ex1 = max(ex1 - T, 0);
-        T = 0;
+        // what lane j keeps of step t0 + j: its move-table entry, whether it ate, self collision | edge collision << 1
+        int my_rec = 0, my_ate = 0, my_fl = 0;
+        {   // re-base the clocks so that they cannot overflow however long the tape is
+            const int T = G - L;
+            ex0 = max(ex0 - T, 0);
+            ex1 = max(ex1 - T, 0);
+            G = L;
+        }
 
         for (int j = 0; j < nt; ++j) {
             // ---- step (single_snake.py:197-304; same line references as step_core / fast_step)
-            const int pk = lane_value(my_pack, j);
-            const int a_small = pk & 7, a_mod = (pk >> 3) - 3;
-            const int a_out = o == a_small ? (o ^ 2) : a_mod;              // :221-222
-            const int ai = a_out & 3;
-            // head - TAP[ai] (:225-233; the head is off the border ring, so the move stays on the grid):
-            // 1 - tap_y = {0,1,2,1}, 1 - tap_x = {1,2,1,0} as 2-bit fields of one constant
-            const int tap = 0x1964 >> (2 * ai);
-            const int ny = hy + 1 - (tap & 3), nx = hx + 1 - ((tap >> 8) & 3);
-            const int nh = ny * S + nx;
-            const int ate = nh == food ? 1 : 0;                            // :242
-            const bool eat = ate != 0;
-            T += 1 - ate;                                                  // :246-249
-            L += ate;
-            const int under = lane_value(nh >= 64 ? ex1 : ex0, nh & 63);
-            const bool selfc = under > T;                                  // :252
-            const bool edgec = !((unsigned)(ny - 1) < (unsigned)Sm2 && (unsigned)(nx - 1) < (unsigned)Sm2); // :290-295
-            const bool done = selfc | edgec;
-            const int grown = T + L;                                       // :258-262
-            ex0 = lane == nh ? grown : ex0;
-            ex1 = lane + 64 == nh ? grown : ex1;
-            hy = ny; hx = nx; hc = nh;
-            o = ai ^ 2;
-            u64 m0 = 0, m1 = 0;
-            if (OBSK == WURM_OBS_PARTIAL || eat) {
-                m0 = ballot(ex0 > T);
-                m1 = ballot(ex1 > T);
+            const int ent = lane_value(move_tab, o * 16 + lane_value(my_code, j));
+            o = (ent >> 3) & 3;
+            hy += (ent << 25) >> 30;                 // :225-233 (the head is off the border ring: the move stays on the grid)
+            hx += (ent << 23) >> 30;
+            hc += ent >> 9;
+            G += 1;
+            const bool eat = hc == food;             // :242
+            L += eat ? 1 : 0;
+            const int T = G - L;                     // :246-249: the clock stands still on the step that eats
+            const u64 p0 = ballot(ex0 > T), p1 = ballot(ex1 > T); // body after the decay, before the head is written
+            const bool selfc = (((hc >= 64 ? p1 : p0) >> (hc & 63)) & 1) != 0;                   // :252
+            const bool edgec = max((unsigned)(hy - 1), (unsigned)(hx - 1)) >= (unsigned)Sm2;    // :290-295
+            ex0 = lane == hc ? G : ex0;              // :258-262
+            ex1 = lane + 64 == hc ? G : ex1;
+            if (__builtin_expect(eat, 0)) {          // :270-282
+                my_ate = lane == j ? 1 : my_ate;
+                u64 m0 = p0, m1 = p1;
+                if (hc >= 64) m1 |= 1ull << (hc - 64);
+                else m0 |= 1ull << hc;
+                food = lean_food_cell(m0, m1, int0, int1, (u32)lane_value(my_food, j), lane);
+                foodc = food - (COMPACT ? S + 1 : 0);
             }
-            if (eat) food = lean_food_cell(m0, m1, int0, int1, (u32)lane_value(my_food, j), lane); // :270-282
 
             // ---- observation of the stepped state (single_snake.py:166-193): a window cell that is off the grid or
             // on the border ring is (0,0,0); food (1,0,0), head (0,1,0), body (0,127/255,0), background (1,1,1)
             if (OBSK == WURM_OBS_PARTIAL) {
-                const bool live = (unsigned)(hy + dy1) < (unsigned)Sm2 && (unsigned)(hx + dx1) < (unsigned)Sm2;
+                const bool live = max((unsigned)(hy + dy1), (unsigned)(hx + dx1)) < (unsigned)Sm2;
                 const int cell = hc + doff;
                 bool occ;
                 if (COMPACT) { // interior cells S+1 .. S*S-S-2 fit one 64-bit mask
-                    const u64 M = (m0 >> (S + 1)) | (m1 << (63 - S));
-                    occ = ((M >> (cell & 63)) & 1) != 0;
+                    const u64 M = (p0 >> (S + 1)) | (p1 << (63 - S));
+                    occ = ((u32)(M >> (cell & 63)) & 1u) != 0;
                 } else {
-                    occ = (((cell < 64 ? m0 : m1) >> (cell & 63)) & 1) != 0;
+                    occ = ((u32)((cell < 64 ? p0 : p1) >> (cell & 63)) & 1u) != 0;
                 }
-                const bool is_food = cell + (COMPACT ? S + 1 : 0) == food;
-                const bool red = live & !occ, bg = red & !is_food;
+                occ |= centre; // the head cell itself
+                const bool red = live & !occ, bg = red & (cell != foodc);
                 const float vb = bg ? 1.0f : 0.0f, vr = red ? 1.0f : 0.0f;
                 float vg = (live & occ) ? 127.0f / 255.0f : vb;
                 vg = (live & centre) ? 1.0f : vg;
@@ -1066,31 +1075,33 @@ __global__ __launch_bounds__(256) void rollout_lean_kernel(StepArgs p)
                 asm volatile("global_store_dword %0, %1, %2" : : "v"(off_b), "v"(vb), "s"(obs_t) : "memory");
                 obs_t += obs_stride;
             }
-
-            const int po = (a_out & 7) | (done ? 8 : 0) | (selfc ? 16 : 0) | (edgec ? 32 : 0) | (eat ? 64 : 0);
-            my_out = lane == j ? po : my_out; // lane j keeps step t0 + j
+            my_rec = lane == j ? ent : my_rec;
 
             // ---- reset of a finished env (single_snake.py:322-387)
-            if (done) {
+            if (__builtin_expect(selfc | edgec, 0)) {
+                my_fl = lane == j ? (selfc ? 1 : 0) | (edgec ? 2 : 0) : my_fl;
                 const int ra = lane_value(my_reset.a, j), rb = lane_value(my_reset.b, j);
                 hy = ra & 15; hx = (ra >> 4) & 15; o = (ra >> 8) & 3; food = ra >> 10;
+                foodc = food - (COMPACT ? S + 1 : 0);
                 hc = rb & 127;
                 const int sc = (rb >> 7) & 127, tc = rb >> 14;
                 const int c1 = lane + 64;
                 ex0 = lane == tc ? T + 1 : 0; ex0 = lane == sc ? T + 2 : ex0; ex0 = lane == hc ? T + 3 : ex0;
                 ex1 = c1 == tc ? T + 1 : 0;   ex1 = c1 == sc ? T + 2 : ex1;   ex1 = c1 == hc ? T + 3 : ex1;
                 L = 3;
+                G = T + 3;
             }
         }
         if (lane < nt) {
             const long long i = my_t * p.N + env;
-            store_action(p.actions, p.act_dtype, i, (long long)((my_out << 29) >> 29));
-            p.reward[i] = (my_out & 64) ? 1.0f : 0.0f;
-            p.done[i] = (uint8_t)((my_out >> 3) & 1);
-            p.selfc[i] = (uint8_t)((my_out >> 4) & 1);
-            p.edgec[i] = (uint8_t)((my_out >> 5) & 1);
+            store_action(p.actions, p.act_dtype, i, (long long)((my_rec << 29) >> 29));
+            p.reward[i] = my_ate ? 1.0f : 0.0f;
+            p.done[i] = (uint8_t)(my_fl != 0);
+            p.selfc[i] = (uint8_t)(my_fl & 1);
+            p.edgec[i] = (uint8_t)(my_fl >> 1);
         }
     }
+    const int T = G - L;
     e.body[0] = max(ex0 - T, 0);
     e.body[1] = max(ex1 - T, 0);
     f.hc = hc; f.hy = hy; f.hx = hx; f.L = L; f.o = o; f.food = food;
