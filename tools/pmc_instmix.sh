@@ -1,10 +1,13 @@
+# Instruction-mix / wave-cycle PMC passes over the rollout kernel (run on the GPU box: bash tools/pmc_instmix.sh [noobs])
 cd /tmp && export TMPDIR=/tmp
 R=/root/repo
-mkdir -p $R/gpurun_out/pmc2
+V=${1:-obs}
+OUT=$R/gpurun_out/pmc_$V
+mkdir -p $OUT
 i=0
-for C in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM" "SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_INSTS_BRANCH SQ_INSTS_LDS" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY" "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM" "SQ_INST_CYCLES_SALU SQ_INST_CYCLES_VMEM SQ_IFETCH SQ_WAIT_IFETCH" "GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_I8 SQ_INSTS_FLAT SQ_INSTS_SENDMSG"; do
+for C in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM" "SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_INSTS_BRANCH SQ_INSTS_LDS" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY" "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM" "SQ_INST_CYCLES_SALU SQ_INST_CYCLES_VMEM SQ_IFETCH SQ_WAIT_IFETCH"; do
   i=$((i+1))
-  timeout 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $R/gpurun_out/pmc2/p$i -o p -- python3 $R/tools/rollout_only.py 512 256 > $R/gpurun_out/pmc2/p$i.log 2>&1
+  timeout 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/p$i -o p -- python3 $R/tools/rollout_only.py 512 256 $V > $OUT/p$i.log 2>&1
   echo "pass $i rc=$?"
 done
-python3 $R/tools/parse_pmc.py $(find $R/gpurun_out/pmc2 -name '*counter_collection.csv') > $R/gpurun_out/pmc2/summary.json
+python3 $R/tools/parse_pmc.py $(find $OUT -name '*counter_collection.csv') > $OUT/summary.json

@@ -949,6 +949,9 @@ __device__ __forceinline__ int lean_food_cell(u64 m0, u64 m1, u64 int0, u64 int1
     return (second ? 64 : 0) + first_bit(hit);
 }
 
+// lane mask of a per-lane predicate (folds with the compares / logic that produce it; __ballot goes through an int)
+__device__ __forceinline__ u64 lane_mask(bool b) { return __builtin_amdgcn_ballot_w64(b); }
+
 template <int OBSK, bool COMPACT>
 __global__ __launch_bounds__(256) void rollout_lean_kernel(StepArgs p)
 {
@@ -979,7 +982,8 @@ __global__ __launch_bounds__(256) void rollout_lean_kernel(StepArgs p)
     const u64 env_id = (u64)(p.env_offset + env);
     const u64 int0 = ballot((g.interior & 1) != 0), int1 = ballot((g.interior & 2) != 0);
     const float rcpSm2 = 1.0f / (float)Sm2;
-    int hy = uniform(f.hy), hx = uniform(f.hx), hc = uniform(f.hc), L = uniform(f.L), o = uniform(f.o);
+    // carried scalars: head row - 1, head column - 1, head cell, length, orientation * 16, food cell
+    int hy1 = uniform(f.hy) - 1, hx1 = uniform(f.hx) - 1, hc = uniform(f.hc), L = uniform(f.L), o16 = uniform(f.o) << 4;
     int food = uniform(f.food);
     int foodc = food - (COMPACT ? S + 1 : 0); // the food cell in the crop's cell numbering
     int G = L;                                // G = T + L: the expiry clock a new head cell gets; +1 every step
@@ -987,22 +991,26 @@ __global__ __launch_bounds__(256) void rollout_lean_kernel(StepArgs p)
 
     // Move table, one entry per lane: lane = orientation * 16 + action code (0..3: that action; 4..10: an action
     // outside 0..3 with action % 4 = code - 7).  Entry = sanitised action (single_snake.py:221-222) & 7
-    // | next orientation << 3 | (row step & 3) << 5 | (column step & 3) << 7 | cell step << 9, the step being -TAP[action].
+    // | next orientation << 4 | (row step & 3) << 6 | (column step & 3) << 8 | cell step << 10, the step being
+    // -TAP[action] (:225-233).
     int move_tab;
     {
         const int to = lane >> 4, tc = lane & 15;
         const int a_small = tc < 4 ? tc : 7, a_mod = tc < 4 ? tc : tc - 7;
         const int a_out = to == a_small ? (to ^ 2) : a_mod;
         const int ai = a_out & 3, dy = -tap_y(ai), dx = -tap_x(ai);
-        move_tab = (a_out & 7) | ((ai ^ 2) << 3) | ((dy & 3) << 5) | ((dx & 3) << 7) | ((dy * S + dx) << 9);
+        move_tab = (a_out & 7) | ((ai ^ 2) << 4) | ((dy & 3) << 6) | ((dx & 3) << 8) | ((dy * S + dx) << 10);
     }
 
-    // partial_n crop: lane owns window cell w (lanes past the window repeat its last cell: same address, same value)
+    // partial_n crop: lane owns window cell w (lanes past the window repeat its last cell: same address, same value).
+    // COMPACT (S <= 9): the interior cells S+1 .. S*S-S-2 fit one 64-bit occupancy mask M with bit 63 to spare;
+    // bit 63 is kept set and the centre lane (the head cell itself) looks at it, the others at head cell + offset.
     const int n = OBSK == WURM_OBS_PARTIAL ? p.obs_n : 0, W = 2 * n + 1, W2 = W * W;
     const int w = min(lane, W2 - 1), wy = div_size(w, 1.0f / (float)W), wx = w - wy * W;
-    const int dy1 = wy - n - 1, dx1 = wx - n - 1;                       // window row / column offset, minus one
-    const int doff = (wy - n) * S + (wx - n) - (COMPACT ? S + 1 : 0);   // cell offset from the head cell
+    const int dy0 = wy - n, dx0 = wx - n;                                // window row / column offset from the head
     const bool centre = w == n * W + n;
+    const int cell_d = dy0 * S + dx0 - (COMPACT ? S + 1 : 0);           // crop cell = head cell + cell_d
+    const float green = centre ? 1.0f : 127.0f / 255.0f;                 // what an occupied cell shows in channel 1
     const u32 off_r = (u32)w * 4u, off_g = (u32)(W2 + w) * 4u, off_b = (u32)(2 * W2 + w) * 4u;
     const long long obs_stride = p.N * p.obs_elems;
     float *obs_t = p.obs + env * p.obs_elems;
@@ -1027,46 +1035,46 @@ __global__ __launch_bounds__(256) void rollout_lean_kernel(StepArgs p)
 
         for (int j = 0; j < nt; ++j) {
             // ---- step (single_snake.py:197-304; same line references as step_core / fast_step)
-            const int ent = lane_value(move_tab, o * 16 + lane_value(my_code, j));
-            o = (ent >> 3) & 3;
-            hy += (ent << 25) >> 30;                 // :225-233 (the head is off the border ring: the move stays on the grid)
-            hx += (ent << 23) >> 30;
-            hc += ent >> 9;
+            const int ent = lane_value(move_tab, o16 + lane_value(my_code, j));
+            o16 = ent & 48;
+            hy1 += (ent << 24) >> 30;                // the head is off the border ring: the move stays on the grid
+            hx1 += (ent << 22) >> 30;
+            hc += ent >> 10;
             G += 1;
-            const bool eat = hc == food;             // :242
-            L += eat ? 1 : 0;
+            // L += (head cell == food cell)  (:242; spelled out: the compiler detours through a 64-bit lane mask)
+            asm("s_cmp_eq_u32 %1, %2\n\ts_addc_u32 %0, %0, 0" : "+s"(L) : "s"(hc), "s"(food) : "scc");
             const int T = G - L;                     // :246-249: the clock stands still on the step that eats
-            const u64 p0 = ballot(ex0 > T), p1 = ballot(ex1 > T); // body after the decay, before the head is written
-            const bool selfc = (((hc >= 64 ? p1 : p0) >> (hc & 63)) & 1) != 0;                   // :252
-            const bool edgec = max((unsigned)(hy - 1), (unsigned)(hx - 1)) >= (unsigned)Sm2;    // :290-295
-            ex0 = lane == hc ? G : ex0;              // :258-262
-            ex1 = lane + 64 == hc ? G : ex1;
-            if (__builtin_expect(eat, 0)) {          // :270-282
+            const bool b0 = ex0 > T, b1 = ex1 > T;   // body after the decay, before the head is written
+            const bool h0 = lane == hc, h1 = lane + 64 == hc;
+            const u64 p0 = lane_mask(b0), p1 = lane_mask(b1), q0 = lane_mask(h0), q1 = lane_mask(h1);
+            const bool selfc = ((p0 & q0) | (p1 & q1)) != 0;                                     // :252
+            const bool edgec = max((unsigned)hy1, (unsigned)hx1) >= (unsigned)Sm2;               // :290-295
+            ex0 = h0 ? G : ex0;                      // :258-262
+            ex1 = h1 ? G : ex1;
+            if (__builtin_expect(hc == food, 0)) {   // :270-282
                 my_ate = lane == j ? 1 : my_ate;
-                u64 m0 = p0, m1 = p1;
-                if (hc >= 64) m1 |= 1ull << (hc - 64);
-                else m0 |= 1ull << hc;
-                food = lean_food_cell(m0, m1, int0, int1, (u32)lane_value(my_food, j), lane);
+                food = lean_food_cell(p0 | q0, p1 | q1, int0, int1, (u32)lane_value(my_food, j), lane);
                 foodc = food - (COMPACT ? S + 1 : 0);
             }
 
             // ---- observation of the stepped state (single_snake.py:166-193): a window cell that is off the grid or
             // on the border ring is (0,0,0); food (1,0,0), head (0,1,0), body (0,127/255,0), background (1,1,1)
             if (OBSK == WURM_OBS_PARTIAL) {
-                const bool live = max((unsigned)(hy + dy1), (unsigned)(hx + dx1)) < (unsigned)Sm2;
-                const int cell = hc + doff;
+                const bool live = max((unsigned)(hy1 + dy0), (unsigned)(hx1 + dx0)) < (unsigned)Sm2;
+                const int cell = (COMPACT && centre) ? 63 : hc + cell_d;
                 bool occ;
-                if (COMPACT) { // interior cells S+1 .. S*S-S-2 fit one 64-bit mask
-                    const u64 M = (p0 >> (S + 1)) | (p1 << (63 - S));
-                    occ = ((u32)(M >> (cell & 63)) & 1u) != 0;
+                if (COMPACT) {
+                    const u64 M = (p0 >> (S + 1)) | (p1 << (63 - S)) | (1ull << 63);
+                    u64 sh; // M >> cell; spelled out: the compiler prefers (1 << cell) & M, two 64-bit VALU ops more
+                    asm("v_lshrrev_b64 %0, %1, %2" : "=v"(sh) : "v"(cell), "s"(M));
+                    occ = ((u32)sh & 1u) != 0;
                 } else {
                     occ = ((u32)((cell < 64 ? p0 : p1) >> (cell & 63)) & 1u) != 0;
+                    occ |= centre;
                 }
-                occ |= centre; // the head cell itself
                 const bool red = live & !occ, bg = red & (cell != foodc);
                 const float vb = bg ? 1.0f : 0.0f, vr = red ? 1.0f : 0.0f;
-                float vg = (live & occ) ? 127.0f / 255.0f : vb;
-                vg = (live & centre) ? 1.0f : vg;
+                const float vg = (live & occ) ? green : vb;
                 // scalar base + 32-bit lane offset form, spelled out: the compiler hoists the zero-extension of the
                 // lane offsets out of the loop and then pays a 64-bit VALU add per store.  (Untracked stores are
                 // harmless for its vmcnt bookkeeping: nothing is read back and waits only become conservative.)
@@ -1078,10 +1086,15 @@ __global__ __launch_bounds__(256) void rollout_lean_kernel(StepArgs p)
             my_rec = lane == j ? ent : my_rec;
 
             // ---- reset of a finished env (single_snake.py:322-387)
-            if (__builtin_expect(selfc | edgec, 0)) {
+            bool finished = edgec;
+            if (__builtin_expect(!finished, 1)) {
+                asm volatile(""); // two compare-and-branch pairs, not one branch on a combined 64-bit mask
+                finished = selfc;
+            }
+            if (__builtin_expect(finished, 0)) {
                 my_fl = lane == j ? (selfc ? 1 : 0) | (edgec ? 2 : 0) : my_fl;
                 const int ra = lane_value(my_reset.a, j), rb = lane_value(my_reset.b, j);
-                hy = ra & 15; hx = (ra >> 4) & 15; o = (ra >> 8) & 3; food = ra >> 10;
+                hy1 = (ra & 15) - 1; hx1 = ((ra >> 4) & 15) - 1; o16 = ((ra >> 8) & 3) << 4; food = ra >> 10;
                 foodc = food - (COMPACT ? S + 1 : 0);
                 hc = rb & 127;
                 const int sc = (rb >> 7) & 127, tc = rb >> 14;
@@ -1104,7 +1117,7 @@ __global__ __launch_bounds__(256) void rollout_lean_kernel(StepArgs p)
     const int T = G - L;
     e.body[0] = max(ex0 - T, 0);
     e.body[1] = max(ex1 - T, 0);
-    f.hc = hc; f.hy = hy; f.hx = hx; f.L = L; f.o = o; f.food = food;
+    f.hc = hc; f.hy = hy1 + 1; f.hx = hx1 + 1; f.L = L; f.o = o16 >> 4; f.food = food;
     fast_sync_bits<CPL>(e, g, f);
     store_state<CPL, true>(envp, g, e);
 }
