@@ -988,19 +988,9 @@ __global__ __launch_bounds__(256) void rollout_lean_kernel(StepArgs p)
     int foodc = food - (COMPACT ? S + 1 : 0); // the food cell in the crop's cell numbering
     int G = L;                                // G = T + L: the expiry clock a new head cell gets; +1 every step
     int ex0 = e.body[0], ex1 = e.body[1];     // expiry clock of cells lane, lane + 64
-
-    // Move table, one entry per lane: lane = orientation * 16 + action code (0..3: that action; 4..10: an action
-    // outside 0..3 with action % 4 = code - 7).  Entry = sanitised action (single_snake.py:221-222) & 7
-    // | next orientation << 4 | (row step & 3) << 6 | (column step & 3) << 8 | cell step << 10, the step being
-    // -TAP[action] (:225-233).
-    int move_tab;
-    {
-        const int to = lane >> 4, tc = lane & 15;
-        const int a_small = tc < 4 ? tc : 7, a_mod = tc < 4 ? tc : tc - 7;
-        const int a_out = to == a_small ? (to ^ 2) : a_mod;
-        const int ai = a_out & 3, dy = -tap_y(ai), dx = -tap_x(ai);
-        move_tab = (a_out & 7) | ((ai ^ 2) << 4) | ((dy & 3) << 6) | ((dx & 3) << 8) | ((dy * S + dx) << 10);
-    }
+    // cells whose entry makes a step "eventful" besides body cells: the border ring (edge collision) and the food cell
+    const u64 ring0 = lane_mask((g.valid & 1) != 0) & ~int0, ring1 = lane_mask((g.valid & 2) != 0) & ~int1;
+    u64 X0 = ring0 | ((unsigned)food < 64u ? 1ull << food : 0), X1 = ring1 | (food >= 64 ? 1ull << (food - 64) : 0);
 
     // partial_n crop: lane owns window cell w (lanes past the window repeat its last cell: same address, same value).
     // COMPACT (S <= 9): the interior cells S+1 .. S*S-S-2 fit one 64-bit occupancy mask M with bit 63 to spare;
@@ -1020,11 +1010,29 @@ __global__ __launch_bounds__(256) void rollout_lean_kernel(StepArgs p)
         const long long my_t = t0 + lane;
         long long my_a = lane < nt ? load_action(p.actions, p.act_dtype, my_t * p.N + env) : 0;
         asm volatile("" : "+v"(my_a)); // retire the load here, not in front of the first readlane of the step loop
-        const int my_code = (my_a >= 0 && my_a < 4) ? (int)my_a : (int)(my_a % 4) + 7;
+        // Moves of step t0 + lane for each of the four orientations the snake may have by then, 16 bits each:
+        // sanitised action (single_snake.py:221-222) & 7 | next orientation << 4 | (row step & 3) << 6
+        // | (column step & 3) << 8 | (cell step & 63) << 10, the step being -TAP[action] (:225-233).  The step loop
+        // reads both words with readlanes that do not depend on the state (so they are off its critical path) and
+        // picks one with the carried orientation.
+        int my_mov01, my_mov23;
+        {
+            const bool in_range = my_a >= 0 && my_a < 4;
+            const int a_small = in_range ? (int)my_a : 7, a_mod = (int)(my_a % 4);
+            int ent[4];
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                const int a_out = o == a_small ? (o ^ 2) : a_mod;
+                const int ai = a_out & 3, dy = -tap_y(ai), dx = -tap_x(ai);
+                ent[o] = (a_out & 7) | ((ai ^ 2) << 4) | ((dy & 3) << 6) | ((dx & 3) << 8) | (((dy * S + dx) & 63) << 10);
+            }
+            my_mov01 = ent[0] | (ent[1] << 16);
+            my_mov23 = ent[2] | (ent[3] << 16);
+        }
         const u64 my_call = p.call + 2ull * (u64)my_t; // step t uses call0 + 2t, its reset call0 + 2t + 1
         const LeanReset my_reset = lean_reset_draw(p.seed, my_call + 1ull, env_id, S, rcpSm2);
         const int my_food = (int)rng_words(p.seed, my_call, env_id, RNG_FOOD, 0).w[0];
-        // what lane j keeps of step t0 + j: its move-table entry, whether it ate, self collision | edge collision << 1
+        // what lane j keeps of step t0 + j: its move entry, whether it ate, self collision | edge collision << 1
         int my_rec = 0, my_ate = 0, my_fl = 0;
         {   // re-base the clocks so that they cannot overflow however long the tape is
             const int T = G - L;
@@ -1035,46 +1043,56 @@ __global__ __launch_bounds__(256) void rollout_lean_kernel(StepArgs p)
 
         for (int j = 0; j < nt; ++j) {
             // ---- step (single_snake.py:197-304; same line references as step_core / fast_step)
-            const int ent = lane_value(move_tab, o16 + lane_value(my_code, j));
+            const int m01 = lane_value(my_mov01, j), m23 = lane_value(my_mov23, j);
+            const int ent = ((o16 & 32) ? m23 : m01) >> (o16 & 16);
             o16 = ent & 48;
             hy1 += (ent << 24) >> 30;                // the head is off the border ring: the move stays on the grid
             hx1 += (ent << 22) >> 30;
-            hc += ent >> 10;
+            hc += (ent << 16) >> 26;
             G += 1;
             // L += (head cell == food cell)  (:242; spelled out: the compiler detours through a 64-bit lane mask)
             asm("s_cmp_eq_u32 %1, %2\n\ts_addc_u32 %0, %0, 0" : "+s"(L) : "s"(hc), "s"(food) : "scc");
             const int T = G - L;                     // :246-249: the clock stands still on the step that eats
-            const bool b0 = ex0 > T, b1 = ex1 > T;   // body after the decay, before the head is written
-            const bool h0 = lane == hc, h1 = lane + 64 == hc;
-            const u64 p0 = lane_mask(b0), p1 = lane_mask(b1), q0 = lane_mask(h0), q1 = lane_mask(h1);
-            const bool selfc = ((p0 & q0) | (p1 & q1)) != 0;                                     // :252
-            const bool edgec = max((unsigned)hy1, (unsigned)hx1) >= (unsigned)Sm2;               // :290-295
-            ex0 = h0 ? G : ex0;                      // :258-262
-            ex1 = h1 ? G : ex1;
-            if (__builtin_expect(hc == food, 0)) {   // :270-282
-                my_ate = lane == j ? 1 : my_ate;
-                food = lean_food_cell(p0 | q0, p1 | q1, int0, int1, (u32)lane_value(my_food, j), lane);
-                foodc = food - (COMPACT ? S + 1 : 0);
+            const u64 p0 = lane_mask(ex0 > T), p1 = lane_mask(ex1 > T); // body after the decay, before the head is written
+            ex0 = lane == hc ? G : ex0;              // :258-262
+            ex1 = lane + 64 == hc ? G : ex1;
+            // One test for everything that is not a plain move: the head entered a body cell (:252), the border ring
+            // (:290-295) or the food cell (:242).
+            const u64 special = hc >= 64 ? (p1 | X1) : (p0 | X0);
+            bool finished = false, selfc = false, edgec = false;
+            if (__builtin_expect(((special >> (hc & 63)) & 1) != 0, 0)) {
+                if (hc == food) {                    // :270-282
+                    my_ate = lane == j ? 1 : my_ate;
+                    const u64 head0 = (unsigned)hc < 64u ? 1ull << hc : 0, head1 = hc >= 64 ? 1ull << (hc - 64) : 0;
+                    food = lean_food_cell(p0 | head0, p1 | head1, int0, int1, (u32)lane_value(my_food, j), lane);
+                    foodc = food - (COMPACT ? S + 1 : 0);
+                    X0 = ring0 | ((unsigned)food < 64u ? 1ull << food : 0);
+                    X1 = ring1 | (food >= 64 ? 1ull << (food - 64) : 0);
+                }
+                selfc = (((hc >= 64 ? p1 : p0) >> (hc & 63)) & 1) != 0;
+                edgec = max((unsigned)hy1, (unsigned)hx1) >= (unsigned)Sm2;
+                finished = selfc | edgec;
             }
 
             // ---- observation of the stepped state (single_snake.py:166-193): a window cell that is off the grid or
-            // on the border ring is (0,0,0); food (1,0,0), head (0,1,0), body (0,127/255,0), background (1,1,1)
+            // on the border ring is (0,0,0); food (1,0,0), head (0,1,0), body (0,127/255,0), background (1,1,1).
+            // The class logic stays in the VALU (compare -> select through vcc): every detour of a lane mask through
+            // scalar logic and back costs a lone wave about two extra issue slots.
             if (OBSK == WURM_OBS_PARTIAL) {
-                const bool live = max((unsigned)(hy1 + dy0), (unsigned)(hx1 + dx0)) < (unsigned)Sm2;
+                const unsigned off_grid = max((unsigned)(hy1 + dy0), (unsigned)(hx1 + dx0)); // < S-2: a live cell
                 const int cell = (COMPACT && centre) ? 63 : hc + cell_d;
-                bool occ;
+                unsigned occ;
                 if (COMPACT) {
                     const u64 M = (p0 >> (S + 1)) | (p1 << (63 - S)) | (1ull << 63);
                     u64 sh; // M >> cell; spelled out: the compiler prefers (1 << cell) & M, two 64-bit VALU ops more
                     asm("v_lshrrev_b64 %0, %1, %2" : "=v"(sh) : "v"(cell), "s"(M));
-                    occ = ((u32)sh & 1u) != 0;
+                    occ = (u32)sh & 1u;
                 } else {
-                    occ = ((u32)((cell < 64 ? p0 : p1) >> (cell & 63)) & 1u) != 0;
-                    occ |= centre;
+                    occ = ((u32)((cell < 64 ? p0 : p1) >> (cell & 63)) & 1u) | (centre ? 1u : 0u);
                 }
-                const bool red = live & !occ, bg = red & (cell != foodc);
-                const float vb = bg ? 1.0f : 0.0f, vr = red ? 1.0f : 0.0f;
-                const float vg = (live & occ) ? green : vb;
+                const float vr = (off_grid | (occ << 30)) < (unsigned)Sm2 ? 1.0f : 0.0f;          // live and free
+                const float vb = cell == foodc ? 0.0f : vr;                                       // ... and not food
+                const float vg = (off_grid | ((occ ^ 1u) << 30)) < (unsigned)Sm2 ? green : vb;    // live and occupied
                 // scalar base + 32-bit lane offset form, spelled out: the compiler hoists the zero-extension of the
                 // lane offsets out of the loop and then pays a 64-bit VALU add per store.  (Untracked stores are
                 // harmless for its vmcnt bookkeeping: nothing is read back and waits only become conservative.)
@@ -1086,16 +1104,13 @@ __global__ __launch_bounds__(256) void rollout_lean_kernel(StepArgs p)
             my_rec = lane == j ? ent : my_rec;
 
             // ---- reset of a finished env (single_snake.py:322-387)
-            bool finished = edgec;
-            if (__builtin_expect(!finished, 1)) {
-                asm volatile(""); // two compare-and-branch pairs, not one branch on a combined 64-bit mask
-                finished = selfc;
-            }
             if (__builtin_expect(finished, 0)) {
                 my_fl = lane == j ? (selfc ? 1 : 0) | (edgec ? 2 : 0) : my_fl;
                 const int ra = lane_value(my_reset.a, j), rb = lane_value(my_reset.b, j);
                 hy1 = (ra & 15) - 1; hx1 = ((ra >> 4) & 15) - 1; o16 = ((ra >> 8) & 3) << 4; food = ra >> 10;
                 foodc = food - (COMPACT ? S + 1 : 0);
+                X0 = ring0 | ((unsigned)food < 64u ? 1ull << food : 0);
+                X1 = ring1 | (food >= 64 ? 1ull << (food - 64) : 0);
                 hc = rb & 127;
                 const int sc = (rb >> 7) & 127, tc = rb >> 14;
                 const int c1 = lane + 64;
