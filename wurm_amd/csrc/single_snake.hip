@@ -1137,6 +1137,254 @@ __global__ __launch_bounds__(256) void rollout_lean_kernel(StepArgs p)
     store_state<CPL, true>(envp, g, e);
 }
 
+// ------------------------------------------------------------------------------------------- 9 x 9 rollout
+// The reference's default grid (size 9: 7 x 7 interior cells) gets one more specialisation of the lean loop.
+// Cells are numbered code = 8 * row + column.  The 49 interior cells have distinct codes in 9..63, so ONE lane per
+// interior cell holds the whole body channel (one expiry clock per lane, one 64-bit occupancy mask); the border
+// ring's codes alias only each other, also modulo 64 (column 8 of a row = column 0 of the next, row 8 = row 0), so
+//   * "the head entered the ring, a body cell or the food cell" is one bit test on (occupancy | RING | food bit);
+//   * which window cells of the crop are inside the ring is a per-lane constant 64-bit table indexed by the head
+//     code (valid while the head is inside the ring; the final observation of an env whose head is on the ring is
+//     computed from row / column arithmetic on the rare path).
+// Extra preconditions (else rollout_generic): no body and no food on the ring.
+
+struct S9Reset {
+    int a; // orientation | food code << 2
+    int b; // head code | seed code << 7 | tail code << 14
+};
+
+// lean_reset_draw in code numbering (single_snake.py:344-387)
+__device__ __forceinline__ S9Reset s9_reset_draw(u64 seed, u64 call, u64 env_id)
+{
+    const Words w = rng_words(seed, call, env_id, RNG_RESET, 0);
+    const int sy = 4 + (int)mulhi_range(w.w[0], 1u), sx = 4 + (int)mulhi_range(w.w[1], 1u); // S - 8 = 1
+    const int d = (int)(w.w[2] >> 30);
+    const int ty = tap_y(d), tx = tap_x(d);
+    const int rs = (sy - 1) * 7 + sx - 1, dr = ty * 7 + tx; // interior rank of the seed cell; head = rs + dr
+    const int lo = rs - abs(dr), hi = rs + abs(dr);
+    int K = (int)mulhi_range(w.w[3], 46u); // 49 interior cells - 3 snake cells
+    K += K >= lo;
+    K += K >= rs;
+    K += K >= hi;
+    const int qy = div_size(K, 1.0f / 7.0f), qx = K - qy * 7;
+    const int sc = sy * 8 + sx, dc = ty * 8 + tx;
+    S9Reset r;
+    r.a = d | (((qy + 1) * 8 + qx + 1) << 2);
+    r.b = (sc + dc) | (sc << 7) | ((sc - dc) << 14);
+    return r;
+}
+
+// v = value in the lanes of `lanes`, unchanged elsewhere — with the lane mask taken from an SGPR pair as it is (the
+// compiler has no way to say that; `lane == j` costs a VALU compare and drags the scalar j into a VGPR)
+__device__ __forceinline__ int keep_in_lane(int v, int value, u64 lanes)
+{
+    asm("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(v) : "v"(value), "s"(lanes));
+    return v;
+}
+
+template <int OBSK>
+__global__ __launch_bounds__(256) void rollout_s9_kernel(StepArgs p)
+{
+    constexpr int CPL = 2, S = 9;
+    static_assert(OBSK == WURM_OBS_PARTIAL || OBSK == WURM_OBS_NONE, "9x9 rollout: partial_n or no observation");
+    const int wave = uniform((int)(threadIdx.x >> 6)), wpb = (int)(blockDim.x >> 6);
+    const long long env = (long long)blockIdx.x * wpb + wave;
+    if (env >= p.N) return;
+    const Geo g = make_geo<CPL>(S);
+    const int lane = g.lane;
+    float *envp = p.envs + env * 3 * (S * S);
+    Env<CPL> e;
+    load_state<CPL, true>(envp, g, e);
+
+    Fast f = {-1, 0, 0, 0, 0, -1};
+    bool lean = fast_init<CPL>(e, g, f);
+    if (lean) {
+        const bool head_in = f.hc >= 0 && (unsigned)(f.hy - 1) < 7u && (unsigned)(f.hx - 1) < 7u;
+        const int fy = f.food >= 0 ? div_size(f.food, g.rcpS) : 1, fx = f.food >= 0 ? f.food - fy * S : 1;
+        const bool food_in = (unsigned)(fy - 1) < 7u && (unsigned)(fx - 1) < 7u;
+        int under_food = 0;
+        if (f.food >= 0) under_food = lane_value(f.food >= 64 ? e.body[1] : e.body[0], f.food & 63);
+        const bool ring_body = lane_mask((e.body[0] > 0 && !(g.interior & 1)) || (e.body[1] > 0 && !(g.interior & 2))) != 0;
+        lean = head_in && food_in && under_food == 0 && !ring_body;
+    }
+    if (!uniform((int)lean)) {
+        rollout_generic<CPL, true, OBSK, false>(p, env, envp, g, e, wurm_lds + wave * p.lds_per_wave);
+        return;
+    }
+
+    const u64 env_id = (u64)(p.env_offset + env);
+    // code layout: lane = 8 * row + column holds that cell if it is inside the ring
+    const int ly = lane >> 3, lx = lane & 7;
+    const bool lane_in = ly >= 1 && lx >= 1;
+    const int my_cell = ly * S + lx;
+    const u64 RING = ~lane_mask(lane_in);
+    int ex = lane_in ? __float2int_rn(envp[2 * S * S + my_cell]) : 0; // expiry clock of the lane's cell (body, re-read)
+    // carried scalars: head code, length, orientation * 16, food code (-1: none), G = clock + length
+    int c = uniform(f.hy) * 8 + uniform(f.hx), L = uniform(f.L), o16 = uniform(f.o) << 4;
+    int foodc = -1;
+    if (f.food >= 0) {
+        const int fy = uniform(div_size(f.food, g.rcpS)); // (float arithmetic: a VALU result, back to an SGPR)
+        foodc = fy * 8 + (uniform(f.food) - fy * S);
+    }
+    u64 XF = RING | (foodc >= 0 ? 1ull << foodc : 0); // ring + food: the non-body cells that make a step eventful
+    int G = L;
+
+    // partial_n crop: lane owns window cell w (lanes past the window repeat its last cell: same address, same value)
+    const int n = OBSK == WURM_OBS_PARTIAL ? p.obs_n : 0, W = 2 * n + 1, W2 = W * W;
+    const int w = min(lane, W2 - 1), wy = div_size(w, 1.0f / (float)W), wx = w - wy * W;
+    const int dy0 = wy - n, dx0 = wx - n;      // window row / column offset from the head
+    const int code_d = dy0 * 8 + dx0;          // code of the window cell = head code + code_d
+    const float green = (w == n * W + n) ? 1.0f : 127.0f / 255.0f; // what an occupied cell shows in channel 1
+    u64 live_tab = 0;                          // bit (8 * row + column): with the head there, this window cell is inside the ring
+#pragma unroll
+    for (int y = 1; y <= 7; ++y) {
+        u32 cols = 0;
+#pragma unroll
+        for (int x = 1; x <= 7; ++x)
+            if ((unsigned)(x + dx0 - 1) < 7u) cols |= 1u << x;
+        if ((unsigned)(y + dy0 - 1) < 7u) live_tab |= (u64)cols << (8 * y);
+    }
+    const u32 off_r = (u32)w * 4u, off_g = (u32)(W2 + w) * 4u, off_b = (u32)(2 * W2 + w) * 4u;
+    const long long obs_stride = p.N * p.obs_elems;
+    float *obs_t = p.obs + env * p.obs_elems;
+
+    for (long long t0 = 0; t0 < p.T; t0 += 64) {
+        const int nt = (int)min((long long)64, p.T - t0);
+        const long long my_t = t0 + lane;
+        long long my_a = lane < nt ? load_action(p.actions, p.act_dtype, my_t * p.N + env) : 0;
+        asm volatile("" : "+v"(my_a)); // retire the load here, not in front of the first readlane of the step loop
+        // Moves of step t0 + lane for each of the four orientations the snake may have by then, 16 bits each:
+        // sanitised action (single_snake.py:221-222) & 7 | next orientation << 4 | (code step & 63) << 6, the step
+        // being -TAP[action] (:225-233).  The step loop reads both words with readlanes that do not depend on the
+        // state and picks one with the carried orientation.
+        int my_mov01, my_mov23;
+        {
+            const bool in_range = my_a >= 0 && my_a < 4;
+            const int a_small = in_range ? (int)my_a : 7, a_mod = (int)(my_a % 4);
+            int ent[4];
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                const int a_out = o == a_small ? (o ^ 2) : a_mod;
+                const int ai = a_out & 3;
+                ent[o] = (a_out & 7) | ((ai ^ 2) << 4) | (((-tap_y(ai) * 8 - tap_x(ai)) & 63) << 6);
+            }
+            my_mov01 = ent[0] | (ent[1] << 16);
+            my_mov23 = ent[2] | (ent[3] << 16);
+        }
+        const u64 my_call = p.call + 2ull * (u64)my_t; // step t uses call0 + 2t, its reset call0 + 2t + 1
+        const S9Reset my_reset = s9_reset_draw(p.seed, my_call + 1ull, env_id);
+        const int my_food = (int)rng_words(p.seed, my_call, env_id, RNG_FOOD, 0).w[0];
+        // what lane j keeps of step t0 + j: its move entry, whether it ate, self collision | edge collision << 1
+        int my_rec = 0, my_ate = 0, my_fl = 0;
+        {   // re-base the clocks so that they cannot overflow however long the tape is
+            const int T = G - L;
+            ex = max(ex - T, 0);
+            G = L;
+        }
+
+        for (int j = 0; j < nt; ++j) {
+            const u64 lane_j = 1ull << j; // lane j keeps the record of step t0 + j
+            // ---- step (single_snake.py:197-304; same line references as step_core / fast_step)
+            const int m01 = lane_value(my_mov01, j), m23 = lane_value(my_mov23, j);
+            const int ent = ((o16 & 32) ? m23 : m01) >> (o16 & 16);
+            o16 = ent & 48;
+            c += (ent << 20) >> 26;                  // the head is inside the ring: the move stays on the grid
+            G += 1;
+            int ate; // head == food (:242; spelled out: the compiler detours through a 64-bit lane mask)
+            asm("s_cmp_eq_u32 %1, %2\n\ts_cselect_b32 %0, 1, 0" : "=s"(ate) : "s"(c), "s"(foodc) : "scc");
+            L += ate;
+            const int T = G - L;                     // :246-249: the clock stands still on the step that eats
+            const u64 body = lane_mask(ex > T);      // after the decay, before the head is written
+            ex = lane == c ? G : ex;                 // :258-262
+            const u64 occ = body | (1ull << (c & 63));
+
+            // what the crop shows: per lane, is the window cell inside the ring (0 / 1), its code, the occupancy mask
+            unsigned inside = 0;
+            int code = c + code_d;
+            u64 mask = occ;
+            if (OBSK == WURM_OBS_PARTIAL) {
+                u64 lv; // live_tab >> head code
+                asm("v_lshrrev_b64 %0, %1, %2" : "=v"(lv) : "s"(c), "v"(live_tab));
+                inside = (u32)lv & 1u;
+            }
+
+            // One test for everything that is not a plain move: the head entered a body cell (:252), the border ring
+            // (:290-295) or the food cell (:242).
+            int event = 0; // 1: self collision, 2: edge collision
+            if (__builtin_expect((((body | XF) >> (c & 63)) & 1) != 0, 0)) {
+                if (c == foodc) {                    // :270-282: K-th free interior cell in row-major order
+                    my_ate = keep_in_lane(my_ate, 1, lane_j);
+                    const u64 fr = ~(occ | RING);
+                    const int n_free = popc64(fr);
+                    foodc = -1;
+                    if (n_free > 0) {
+                        const int K = (int)mulhi_range((u32)lane_value(my_food, j), (u32)n_free);
+                        foodc = first_bit(lane_mask((int)((fr >> lane) & 1) & (int)(rank_below(fr) == K)));
+                    }
+                    XF = RING | (foodc >= 0 ? 1ull << foodc : 0);
+                }
+                event = ((RING >> (c & 63)) & 1) ? 2 : ((body >> (c & 63)) & 1) ? 1 : 0;
+                if (OBSK == WURM_OBS_PARTIAL && event == 2) {
+                    // the head is on the ring and its code may have wrapped: row / column arithmetic from the cell it left
+                    const int ai = ent & 3, pc = c - ((ent << 20) >> 26);
+                    const int hy = (pc >> 3) - tap_y(ai), hx = (pc & 7) - tap_x(ai);
+                    inside = max((unsigned)(hy + dy0 - 1), (unsigned)(hx + dx0 - 1)) < 7u ? 1u : 0u;
+                    code = (hy + dy0) * 8 + hx + dx0;
+                    mask = body;
+                }
+            }
+
+            // ---- crop of the stepped state (single_snake.py:166-193): a window cell that is off the grid or on the
+            // ring is (0,0,0); food (1,0,0), head (0,1,0), body (0,127/255,0), background (1,1,1).  `inside` / `taken`
+            // are 0 / 1 per lane; the class logic stays in the VALU (compare -> select through vcc).
+            if (OBSK == WURM_OBS_PARTIAL) {
+                u64 sh; // mask >> code; spelled out: the compiler prefers (1 << code) & mask, two 64-bit VALU ops more
+                asm("v_lshrrev_b64 %0, %1, %2" : "=v"(sh) : "v"(code), "s"(mask));
+                const unsigned taken = (u32)sh & 1u;
+                const float vr = inside > taken ? 1.0f : 0.0f;     // inside the ring and free
+                const float vb = code == foodc ? 0.0f : vr;        // ... and not the food
+                const float vg = (inside & taken) ? green : vb;    // inside the ring and occupied
+                // scalar base + 32-bit lane offset form, spelled out: the compiler hoists the zero-extension of the
+                // lane offsets out of the loop and then pays a 64-bit VALU add per store.  (Untracked stores are
+                // harmless for its vmcnt bookkeeping: nothing is read back and waits only become conservative.)
+                asm volatile("global_store_dword %0, %1, %2" : : "v"(off_r), "v"(vr), "s"(obs_t) : "memory");
+                asm volatile("global_store_dword %0, %1, %2" : : "v"(off_g), "v"(vg), "s"(obs_t) : "memory");
+                asm volatile("global_store_dword %0, %1, %2" : : "v"(off_b), "v"(vb), "s"(obs_t) : "memory");
+                obs_t += obs_stride;
+            }
+            my_rec = keep_in_lane(my_rec, ent, lane_j);
+
+            // ---- reset of a finished env (single_snake.py:322-387)
+            if (__builtin_expect(event != 0, 0)) {
+                my_fl = keep_in_lane(my_fl, event, lane_j);
+                const int ra = lane_value(my_reset.a, j), rb = lane_value(my_reset.b, j);
+                o16 = (ra & 3) << 4;
+                foodc = ra >> 2;
+                XF = RING | (1ull << foodc);
+                c = rb & 127;
+                const int sc = (rb >> 7) & 127, tc = rb >> 14;
+                ex = lane == tc ? T + 1 : 0; ex = lane == sc ? T + 2 : ex; ex = lane == c ? T + 3 : ex;
+                L = 3;
+                G = T + 3;
+            }
+        }
+        if (lane < nt) {
+            const long long i = my_t * p.N + env;
+            store_action(p.actions, p.act_dtype, i, (long long)((my_rec << 29) >> 29));
+            p.reward[i] = my_ate ? 1.0f : 0.0f;
+            p.done[i] = (uint8_t)(my_fl != 0);
+            p.selfc[i] = (uint8_t)(my_fl & 1);
+            p.edgec[i] = (uint8_t)(my_fl >> 1);
+        }
+    }
+    if (lane_in) { // the ring was empty and still is
+        const int T = G - L;
+        envp[my_cell] = lane == foodc ? 1.0f : 0.0f;
+        envp[S * S + my_cell] = lane == c ? 1.0f : 0.0f;
+        envp[2 * S * S + my_cell] = (float)max(ex - T, 0);
+    }
+}
+
 // wurm.utils.env_consistency (wurm/utils.py:113-178) per env, as an error bitmask
 template <int CPL>
 __global__ __launch_bounds__(256) void check_kernel(const float *__restrict__ envs, uint32_t *__restrict__ err,
@@ -1219,7 +1467,11 @@ static hipError_t launch_one(Kind kind, const StepArgs &p, dim3 grid, dim3 block
         if constexpr (SNAKE && CPL == 2) {
             const bool rng_mode = p.inject_food == nullptr && p.inject_reset == nullptr;
             if (rng_mode && p.S >= 9 && ((p.obs_mode == WURM_OBS_PARTIAL && p.obs_n <= 3) || p.obs_mode == WURM_OBS_NONE)) {
-                if (p.obs_mode == WURM_OBS_NONE)
+                if (p.S == 9 && p.obs_mode == WURM_OBS_NONE)
+                    hipLaunchKernelGGL((rollout_s9_kernel<WURM_OBS_NONE>), grid, block, lds, st, p);
+                else if (p.S == 9)
+                    hipLaunchKernelGGL((rollout_s9_kernel<WURM_OBS_PARTIAL>), grid, block, lds, st, p);
+                else if (p.obs_mode == WURM_OBS_NONE)
                     hipLaunchKernelGGL((rollout_lean_kernel<WURM_OBS_NONE, false>), grid, block, lds, st, p);
                 else if (p.S <= 9)
                     hipLaunchKernelGGL((rollout_lean_kernel<WURM_OBS_PARTIAL, true>), grid, block, lds, st, p);
