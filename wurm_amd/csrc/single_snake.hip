@@ -1295,8 +1295,9 @@ __global__ __launch_bounds__(256) void rollout_s9_kernel(StepArgs p)
             L += ate;
             const int T = G - L;                     // :246-249: the clock stands still on the step that eats
             const u64 body = lane_mask(ex > T);      // after the decay, before the head is written
-            ex = lane == c ? G : ex;                 // :258-262
-            const u64 occ = body | (1ull << (c & 63));
+            const u64 head = 1ull << (c & 63);
+            ex = keep_in_lane(ex, G, head);          // :258-262 (a head on the ring may land in a wrong lane: it is reset below)
+            const u64 occ = body | head;
 
             // what the crop shows: per lane, is the window cell inside the ring (0 / 1), its code, the occupancy mask
             unsigned inside = 0;
@@ -1341,15 +1342,27 @@ __global__ __launch_bounds__(256) void rollout_s9_kernel(StepArgs p)
                 u64 sh; // mask >> code; spelled out: the compiler prefers (1 << code) & mask, two 64-bit VALU ops more
                 asm("v_lshrrev_b64 %0, %1, %2" : "=v"(sh) : "v"(code), "s"(mask));
                 const unsigned taken = (u32)sh & 1u;
-                const float vr = inside > taken ? 1.0f : 0.0f;     // inside the ring and free
-                const float vb = code == foodc ? 0.0f : vr;        // ... and not the food
-                const float vg = (inside & taken) ? green : vb;    // inside the ring and occupied
+                // vr = inside > taken ? 1 : 0        (inside the ring and free)
+                // vb = code == food ? 0 : vr         (... and not the food)
+                // vg = inside & taken ? green : vb   (inside the ring and occupied)
+                // Spelled out: three compares into three SGPR pairs, then three selects.  The compiler funnels all of
+                // them through vcc and pads each compare -> select pair with s_nop (gfx950 needs two wait states there).
+                const unsigned both = inside & taken;
+                float vr, vb, vg;
+                u64 m_free, m_not_food, m_taken;
+                asm("v_cmp_gt_u32_e64 %3, %6, %7\n\t"
+                    "v_cmp_ne_u32_e64 %4, %8, %9\n\t"
+                    "v_cmp_ne_u32_e64 %5, 0, %10\n\t"
+                    "v_cndmask_b32_e64 %0, 0, 1.0, %3\n\t"
+                    "v_cndmask_b32_e64 %1, 0, %0, %4\n\t"
+                    "v_cndmask_b32_e64 %2, %1, %11, %5"
+                    : "=&v"(vr), "=&v"(vb), "=&v"(vg), "=&s"(m_free), "=&s"(m_not_food), "=&s"(m_taken)
+                    : "v"(inside), "v"(taken), "s"(foodc), "v"(code), "v"(both), "v"(green));
                 // scalar base + 32-bit lane offset form, spelled out: the compiler hoists the zero-extension of the
                 // lane offsets out of the loop and then pays a 64-bit VALU add per store.  (Untracked stores are
                 // harmless for its vmcnt bookkeeping: nothing is read back and waits only become conservative.)
-                asm volatile("global_store_dword %0, %1, %2" : : "v"(off_r), "v"(vr), "s"(obs_t) : "memory");
-                asm volatile("global_store_dword %0, %1, %2" : : "v"(off_g), "v"(vg), "s"(obs_t) : "memory");
-                asm volatile("global_store_dword %0, %1, %2" : : "v"(off_b), "v"(vb), "s"(obs_t) : "memory");
+                asm volatile("global_store_dword %0, %1, %6\n\tglobal_store_dword %2, %3, %6\n\tglobal_store_dword %4, %5, %6"
+                             : : "v"(off_r), "v"(vr), "v"(off_g), "v"(vg), "v"(off_b), "v"(vb), "s"(obs_t) : "memory");
                 obs_t += obs_stride;
             }
             my_rec = keep_in_lane(my_rec, ent, lane_j);
