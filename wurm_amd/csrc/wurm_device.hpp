@@ -40,8 +40,8 @@ __device__ __forceinline__ Words rng_words(u64 seed, u64 call, u64 env_id, u32 p
     u32 k0 = (u32)seed, k1 = (u32)(seed >> 32);
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        u32 hi0 = __umulhi(M0, c0), lo0 = M0 * c0;
-        u32 hi1 = __umulhi(M1, c2), lo1 = M1 * c2;
+        const u64 p0 = (u64)M0 * c0, p1 = (u64)M1 * c2; // one 32x32->64 multiply each (v_mad_u64_u32 per lane)
+        const u32 hi0 = (u32)(p0 >> 32), lo0 = (u32)p0, hi1 = (u32)(p1 >> 32), lo1 = (u32)p1;
         u32 n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
         c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
         k0 += W0; k1 += W1;
