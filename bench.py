@@ -127,7 +127,7 @@ def main():
     elapsed = float(t.item())
     total_env_steps = N * K * n_gpus
 
-    # dominant kernel: rollout_kernel<2,true>; per-launch duration from HIP events on the launch stream
+    # dominant kernel: rollout_s9_kernel<4>; per-launch duration from HIP events on the launch stream
     full = [(e0.elapsed_time(e1) * 1e-3, n) for e0, e1, n in events if n == args.chunk] or \
            [(e0.elapsed_time(e1) * 1e-3, n) for e0, e1, n in events]
     avg_launch_s = sum(d for d, _ in full) / len(full)
@@ -154,11 +154,12 @@ def main():
                        'state_dtype': 'fp32 NCHW (exact integers)', 'chunk': args.chunk},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
-                         'kernel': 'wurm::rollout_kernel<2, true, 4, false> (lean instantiation: CPL=2, SingleSnake, partial_n obs, RNG mode)', 'avg_launch_ms': avg_launch_s * 1e3,
+                         'kernel': 'wurm::rollout_s9_kernel<4> (9x9 SingleSnake, partial_n crop, RNG mode; one wave per env)', 'avg_launch_ms': avg_launch_s * 1e3,
                          'algorithmic_bytes_per_env_step': algorithmic_bytes_per_env_step(SIZE, OBS_ELEMS),
                          'env_steps_per_launch': N * full[0][1],
-                         'note': 'this config is latency-bound (512 waves on 256 CUs), not HBM-bound: '
-                                 'SURVEY.md §0 fact 10'},
+                         'note': 'this config is issue-bound, not HBM-bound: 512 envs = 512 lone waves on 1024 SIMDs, '
+                                 '~60 instructions per env-step at 5-6 cycles each (DESIGN.md §4.4); `traffic` is '
+                                 'below the algorithmic bytes because the env state never leaves the registers'},
         }
         if n_gpus == 1 and not args.no_extra:
             line['extra'] = extra_measurements(device)

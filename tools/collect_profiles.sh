@@ -1,0 +1,30 @@
+#!/bin/bash
+# Re-creates the artefacts under profiles/ on the GPU box (run through gpurun from the repo root):
+#   bash tools/collect_profiles.sh <tag>      ->  gpurun_out/profiles_<tag>/
+# rocprofv3 is always given the program itself after `--` and counters are collected in their own passes.
+TAG=${1:-r01}
+R=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$R/gpurun_out/profiles_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+# 1. the bench line (un-profiled)
+python3 $R/bench.py > $OUT/${TAG}_bench_cfg2.json 2> $OUT/bench.err
+# 2. kernel trace + stats of the same command (short form)
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o $TAG -- python3 $R/bench.py --steps 32768 --warmup 2048 --no-extra --no-cpu-baseline > $OUT/${TAG}_cfg2_rollout_bench_under_rocprof.json 2> $OUT/trace.err
+cp $(find $OUT/trace -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_cfg2_rollout_kernel_stats.csv
+cp $(find $OUT/trace -name "*domain_stats.csv" | head -1) $OUT/${TAG}_cfg2_rollout_domain_stats.csv
+# 3. HBM traffic: FETCH_SIZE and WRITE_SIZE in separate passes over the calibrated workload
+for C in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_$C -o p -- python3 $R/tools/traffic_workload.py > $OUT/pmc_$C.log 2>&1
+done
+python3 $R/tools/parse_pmc.py $(find $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE -name '*counter_collection.csv') > $OUT/${TAG}_pmc_fetch_write_summary.json
+python3 $R/tools/make_traffic_json.py $OUT/${TAG}_pmc_fetch_write_summary.json > $OUT/hbm_traffic.json
+# 4. instruction mix / wave cycles of the rollout kernel
+bash $R/tools/pmc_instmix.sh obs > /dev/null
+cp $R/gpurun_out/pmc_obs/summary.json $OUT/${TAG}_cfg2_rollout_instmix_pmc.json
+# 5. the other BASELINE shapes
+python3 $R/tools/bench_configs.py > $OUT/${TAG}_percall_all_configs.jsonl 2>/dev/null
+python3 $R/tools/bench_rollout_configs.py > $OUT/${TAG}_rollout_single_configs.jsonl 2>/dev/null
+python3 $R/tools/bench_multi_rollout.py > $OUT/${TAG}_rollout_multi_configs.jsonl 2>/dev/null
+rm -rf $OUT/trace $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE
+ls -la $OUT

@@ -38,11 +38,11 @@ out = {
         'copy_1GiB_FETCH_SIZE_KiB': copy['FETCH_SIZE']['mean'], 'copy_1GiB_WRITE_SIZE_KiB': copy['WRITE_SIZE']['mean'],
         'note': 'FETCH_SIZE reads 1/2 of the true bytes for 16 B/lane copies AND for the kernels\' dword-per-lane '
                 'coalesced reads; WRITE_SIZE is exact for both.'},
-    'rollout_512x9_chunk1024': traffic('void wurm::rollout_kernel<2, true', 32768)['total_bytes'],
-    'rollout_8192x9_chunk128': traffic('void wurm::rollout_kernel<2, true', 524288)['total_bytes'],
+    'rollout_512x9_chunk1024': traffic('void wurm::rollout_s9_kernel<4>', 32768)['total_bytes'],
+    'rollout_8192x9_chunk128': traffic('void wurm::rollout_s9_kernel<4>', 524288)['total_bytes'],
     'detail': {
-        'rollout_512x9_chunk1024': traffic('void wurm::rollout_kernel<2, true', 32768),
-        'rollout_8192x9_chunk128': traffic('void wurm::rollout_kernel<2, true', 524288),
+        'rollout_512x9_chunk1024': traffic('void wurm::rollout_s9_kernel<4>', 32768),
+        'rollout_8192x9_chunk128': traffic('void wurm::rollout_s9_kernel<4>', 524288),
         'step_512x9_partial2': traffic('void wurm::step_kernel<2, true>', 32768),
         'reset_512x9_partial2': traffic('void wurm::reset_kernel<2, true>', 32768),
         'step_8192x9_partial2': traffic('void wurm::step_kernel<2, true>', 524288),
