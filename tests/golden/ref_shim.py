@@ -58,8 +58,10 @@ def install():
     sys.modules.setdefault('gym.envs.classic_control.rendering', rendering)
 
     # 3
+    # at the END of sys.path: the reference has its own top-level `tests` package, which must not shadow this repo's
+    # (spawned gloo workers of tests/test_sharding_gloo.py inherit sys.path and import tests.test_sharding_gloo)
     if REFERENCE_ROOT not in sys.path:
-        sys.path.insert(0, REFERENCE_ROOT)
+        sys.path.append(REFERENCE_ROOT)
     import config
     config.DEFAULT_DEVICE = 'cpu'
 
