@@ -150,3 +150,35 @@ def test_chained_launches_equal_one_launch(hip):
         _same(whole[k], np.concatenate([first[k], second[k]]), k)
     _same(e1, e2, 'final state')
     _same(a1, a2, 'actions')
+
+
+@pytest.mark.parametrize('S,mode', [(9, 'partial_2'), (9, 'none'), (10, 'partial_1'), (12, 'partial_2')])
+def test_four_waves_per_workgroup(hip, S, mode):
+    """Batches above 4096 envs launch four waves (four envs) per workgroup, the last workgroup partly empty."""
+    N, T = 4096 + 37, 70
+    rng = np.random.RandomState(S)
+    o, h = OracleBackend(seed=31, env_offset=(1 << 33) + 5), hip(seed=31, env_offset=(1 << 33) + 5)
+    envs = _fresh(o, N, S)
+    o.call = h.call = (1 << 40) + 3      # call counters and env ids beyond 32 bits
+    _compare_rollout(o, h, envs, rng.randint(0, 4, size=(T, N)).astype(np.int64), mode)
+
+
+def test_full_size_rollout_equals_per_call_loop(hip):
+    """BASELINE cfg3's per-GPU share (8192 x 9 x 9, partial_2): the fused rollout == the per-call loop, on the GPU."""
+    N, S, T = 8192, 9, 64
+    rng = np.random.RandomState(0)
+    actions = rng.randint(0, 4, size=(T, N)).astype(np.int64)
+    h1, h2 = hip(seed=12), hip(seed=12)
+    e1, e2 = _fresh(h1, N, S), _fresh(h2, N, S)
+    a1, a2 = actions.copy(), actions.copy()
+    out = h1.single_rollout(e1, a1, 'partial_2')
+    for t in range(T):
+        obs, r, d, sc, ec = h2.single_step(e2, a2[t], 'partial_2')
+        _same(obs, out['obs'][t], f'obs t={t}')
+        _same(r, out['reward'][t], f'reward t={t}')
+        _same(d, out['done'][t], f'done t={t}')
+        _same(sc, out['self_collision'][t], f'self collision t={t}')
+        _same(ec, out['edge_collision'][t], f'edge collision t={t}')
+        h2.single_reset(e2, d, 'none')
+    _same(e1, e2, 'final state')
+    _same(a1, a2, 'sanitised actions')
