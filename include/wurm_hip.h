@@ -96,6 +96,24 @@ int wurm_single_rollout(float *envs, void *actions, int actions_dtype, float *re
                         int64_t num_envs, int size, int64_t num_steps, uint64_t seed, uint64_t call0,
                         int64_t env_offset, const int32_t *inject_food, const int32_t *inject_reset, void *stream);
 
+/* The acting half of the single-agent loop, experiments/main.py:207-212,227, T iterations in ONE launch:
+ *   probs, value = model(state)            FeedforwardAgent, wurm/agents/feedforward.py:8-28: E -> 64 -> 64 -> {4, 1}
+ *   action = Categorical(probs).sample()   main.py:208-210
+ *   state, reward, done, info = env.step(action);  env.reset(done)     (`state`: the PRE-reset observation, :212)
+ * obs0 (N,E): the observation the policy acts on at step 0 (the caller's `state`), E = 3 (2 obs_n + 1)^2.
+ * params: W1 (64,E) b1 (64) W2 (64,64) b2 (64) Wp (4,64) bp (4) Wv (64) bv (1), fp32, torch Linear layout,
+ * concatenated.  Outputs (T,N,..): actions int64 (sanitised by step as in the reference), probs (4), values, reward,
+ * done, collision flags, obs (E) = the observation step t returned = the policy input of step t+1.
+ * status (N) uint8: 0 = rolled out; 1 = the env's state is outside the kernel's domain (not a well-formed snake):
+ * it is left untouched and its outputs are not written.  Step t uses call0 + 2t (env step and the sampling draw),
+ * its reset call0 + 2t + 1.  Arithmetic order of the policy: see wurm_amd/csrc/policy_rollout.hpp.
+ * Supported: 9 <= size <= 11, 0 <= obs_n <= 3. */
+int wurm_single_policy_rollout(float *envs, const float *obs0, const float *params, int64_t *actions, float *probs,
+                               float *values, float *reward, uint8_t *done, uint8_t *self_collision,
+                               uint8_t *edge_collision, float *obs, uint8_t *status, int obs_n, int64_t num_envs,
+                               int size, int64_t num_steps, uint64_t seed, uint64_t call0, int64_t env_offset,
+                               void *stream);
+
 /* wurm.utils.env_consistency / snake_consistency (wurm/utils.py:113-178) as a per-env error bitmask
  * (bit i = i-th check failed, WURM_CHK_*; 0 = consistent).  err out (N) uint32. */
 #define WURM_CHK_FOOD_VALUE 1u

@@ -382,3 +382,50 @@ def single_stats(envs, reward, done, self_collision, edge_collision):
                                      _p(np.ascontiguousarray(self_collision, np.uint8)),
                                      _p(np.ascontiguousarray(edge_collision, np.uint8)), _p(out), _i64(N), S))
     return out
+
+
+# ---------------------------------------------------------------- policy in the loop (oracle/policy.c)
+
+def policy_param_count(E: int) -> int:
+    return 64 * E + 64 + 64 * 64 + 64 + 4 * 64 + 4 + 64 + 1
+
+
+def policy_forward(params, x):
+    """x (M,E) -> probs (M,4), values (M): the build's arithmetic spec of FeedforwardAgent + softmax."""
+    x = np.ascontiguousarray(x, np.float32)
+    params = np.ascontiguousarray(params, np.float32)
+    M, E = x.shape
+    assert params.size == policy_param_count(E)
+    probs, values = np.empty((M, 4), np.float32), np.empty(M, np.float32)
+    f = lib().oracle_policy_forward
+    f.restype = None
+    for i in range(M):
+        f(_p(params), int(E), _p(x[i]), _p(probs[i]), _p(values[i:i + 1]))
+    return probs, values
+
+
+def exp_spec(x):
+    f = lib().oracle_exp_spec
+    f.restype = ctypes.c_float
+    f.argtypes = [ctypes.c_float]
+    return np.asarray([f(float(v)) for v in np.asarray(x, np.float32).ravel()], np.float32).reshape(np.shape(x))
+
+
+def single_policy_rollout(envs, obs0, params, T, obs_n=2, seed=0, call0=0, env_offset=0):
+    """T iterations of (policy forward, sample, step, reset) over the envs (updated in place).  Returns dict of
+    (T,N,...) arrays: actions, probs, values, reward, done, self_collision, edge_collision, obs."""
+    N, _, S, _ = envs.shape
+    E = 3 * (2 * obs_n + 1) ** 2
+    obs0 = np.ascontiguousarray(obs0, np.float32).reshape(N, E)
+    params = np.ascontiguousarray(params, np.float32)
+    assert params.size == policy_param_count(E)
+    actions = np.empty((T, N), np.int64)
+    probs = np.empty((T, N, 4), np.float32)
+    values, reward = np.empty((T, N), np.float32), np.empty((T, N), np.float32)
+    done, sc, ec = (np.empty((T, N), np.uint8) for _ in range(3))
+    obs = np.empty((T, N, E), np.float32)
+    _check(lib().oracle_single_policy_rollout(_p(envs), _p(obs0), _p(params), _p(actions), _p(probs), _p(values),
+                                              _p(reward), _p(done), _p(sc), _p(ec), _p(obs), int(obs_n), _i64(N), S,
+                                              _i64(T), _u64(seed), _u64(call0), _i64(env_offset)))
+    return dict(actions=actions, probs=probs, values=values, reward=reward, done=done, self_collision=sc,
+                edge_collision=ec, obs=obs)

@@ -34,6 +34,9 @@ class OracleBackend(object):
         return _o.single_rollout(envs, actions, mode, self.seed, self._next(2 * actions.shape[0]), self.env_offset,
                                  inject_food, inject_reset)
 
+    def single_policy_rollout(self, envs, obs0, params, T, obs_n):
+        return _o.single_policy_rollout(envs, obs0, params, T, obs_n, self.seed, self._next(2 * T), self.env_offset)
+
     def single_check(self, envs):
         return _o.single_check(envs)
 

@@ -114,6 +114,28 @@ class HipBackend(object):
         return dict(obs=obs.cpu().numpy() if obs is not None else None, reward=reward.cpu().numpy(),
                     done=done.cpu().numpy(), self_collision=sc.cpu().numpy(), edge_collision=ec.cpu().numpy())
 
+    def single_policy_rollout(self, envs, obs0, params, T, obs_n):
+        N, _, S, _ = envs.shape
+        E = 3 * (2 * obs_n + 1) ** 2
+        e, x0, w = self._t(envs), self._t(np.asarray(obs0, np.float32).reshape(N, E)), self._t(np.asarray(params, np.float32))
+        actions = self._empty((T, N), torch.int64)
+        probs = self._empty((T, N, 4), torch.float32)
+        values, reward = self._empty((T, N), torch.float32), self._empty((T, N), torch.float32)
+        done, sc, ec = (self._empty((T, N), torch.uint8) for _ in range(3))
+        obs = self._empty((T, N, E), torch.float32)
+        status = self._empty((N,), torch.uint8)
+        rc = self.lib.wurm_single_policy_rollout(_lib.ptr(e), _lib.ptr(x0), _lib.ptr(w), _lib.ptr(actions), _lib.ptr(probs),
+                                                 _lib.ptr(values), _lib.ptr(reward), _lib.ptr(done), _lib.ptr(sc),
+                                                 _lib.ptr(ec), _lib.ptr(obs), _lib.ptr(status), int(obs_n), _lib.i64(N), S,
+                                                 _lib.i64(T), _lib.u64(self.seed), _lib.u64(self._next(2 * T)),
+                                                 _lib.i64(self.env_offset), self._stream())
+        _lib.check(rc, 'wurm_single_policy_rollout')
+        torch.cuda.synchronize()
+        envs[...] = e.cpu().numpy()
+        return dict(actions=actions.cpu().numpy(), probs=probs.cpu().numpy(), values=values.cpu().numpy(),
+                    reward=reward.cpu().numpy(), done=done.cpu().numpy(), self_collision=sc.cpu().numpy(),
+                    edge_collision=ec.cpu().numpy(), obs=obs.cpu().numpy(), status=status.cpu().numpy())
+
     def single_check(self, envs):
         N, _, S, _ = envs.shape
         e = self._t(envs)

@@ -24,7 +24,7 @@ SYMBOLS = [
     'wurm_multi_obs_elems', 'wurm_multi_step', 'wurm_multi_reset', 'wurm_multi_observe', 'wurm_multi_check',
     'wurm_multi_rollout',
     'wurm_multi_colours', 'wurm_orientations',
-    'wurm_a2c_returns', 'wurm_a2c_returns_backward', 'wurm_single_stats',
+    'wurm_a2c_returns', 'wurm_a2c_returns_backward', 'wurm_single_stats', 'wurm_single_policy_rollout',
 ]
 
 

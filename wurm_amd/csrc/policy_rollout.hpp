@@ -1,0 +1,196 @@
+// policy_rollout.hpp — the acting half of the reference's single-agent loop as ONE kernel.
+// Included by single_snake.hip (it uses that file's Env / Geo / Fast machinery); not a standalone header.
+//
+// Per env (= per wave) and per step, experiments/main.py:207-212,227:
+//     probs, value = model(state)            FeedforwardAgent (wurm/agents/feedforward.py:8-28): E -> 64 -> 64 -> {4, 1}
+//     action = Categorical(probs).sample()
+//     state, reward, done, info = env.step(action)      (`state`: the PRE-reset observation)
+//     env.reset(done)
+// so the observation never leaves the chip between env and policy: the crop of step t is written to HBM (the learner
+// wants it) and, from the same registers, to LDS, where the 64 lanes — one hidden unit each — read it back with
+// broadcast ds_read_b128s as the input of step t+1.
+//
+// Arithmetic spec (what the reference leaves open; identical in oracle/policy.c, so the two are bit-identical):
+// every dot product is a sequential fmaf chain in index order starting from the bias; exp_spec (Cody-Waite +
+// degree-6 polynomial in fmaf / ldexp); softmax with the sum ((e0+e1)+e2)+e3 and IEEE division; inverse-CDF
+// sampling with u = u01(Philox(seed; env, step call, RNG_POLICY).w0).
+//
+// Domain: SingleSnake, grids of at most 128 cells (S <= 11), partial_n crop with n <= 3, envs in a well-formed state
+// (fast_init: what reset / step+reset produce).  An env outside the domain is left untouched and flagged in `status`.
+#pragma once
+
+namespace wurm {
+
+enum : u32 { RNG_POLICY = 8 };
+
+struct PolicyArgs {
+    float *envs;
+    const float *obs0;   // (N,E) the observation the policy acts on at step 0
+    const float *params; // W1 (64,E) b1 (64) W2 (64,64) b2 (64) Wp (4,64) bp (4) Wv (64) bv (1)
+    long long *actions;  // (T,N) sanitised sampled actions
+    float *probs;        // (T,N,4)
+    float *values;       // (T,N)
+    float *reward;       // (T,N)
+    uint8_t *done, *selfc, *edgec; // (T,N)
+    float *obs;          // (T,N,E) observation returned by step t (pre-reset) = policy input of step t+1
+    uint8_t *status;     // (N) 0: done, 1: env outside the domain (left untouched, outputs not written)
+    long long N, T;
+    int S;
+    u64 seed, call;
+    long long env_offset;
+};
+
+__device__ __forceinline__ float exp_spec(float x) // oracle/policy.c: oracle_exp_spec
+{
+    const float n = rintf(x * 1.44269504088896341f);
+    float r = fmaf(-n, 0.693359375f, x);
+    r = fmaf(-n, -2.12194440e-4f, r);
+    float p = 1.0f / 720.0f;
+    p = fmaf(p, r, 1.0f / 120.0f);
+    p = fmaf(p, r, 1.0f / 24.0f);
+    p = fmaf(p, r, 1.0f / 6.0f);
+    p = fmaf(p, r, 0.5f);
+    p = fmaf(p, r, 1.0f);
+    p = fmaf(p, r, 1.0f);
+    return x > -87.3f ? ldexpf(p, (int)n) : 0.0f;
+}
+
+template <int NOBS>
+__global__ __launch_bounds__(64) void policy_rollout_kernel(PolicyArgs p)
+{
+    constexpr int CPL = 2, W = 2 * NOBS + 1, W2 = W * W, E = 3 * W2, EP = (E + 3) & ~3, H = 64;
+    static_assert(W2 <= 64, "one window cell per lane");
+    const long long env = blockIdx.x;
+    const Geo g = make_geo<CPL>(p.S);
+    const int lane = g.lane;
+    float *envp = p.envs + env * 3 * g.C;
+    Env<CPL> e;
+    load_state<CPL, true>(envp, g, e);
+    Fast f = {-1, 0, 0, 0, 0, -1};
+    if (!uniform((int)fast_init<CPL>(e, g, f))) {
+        if (lane == 0) p.status[env] = 1;
+        return;
+    }
+    if (lane == 0) p.status[env] = 0;
+    const u64 env_id = (u64)(p.env_offset + env);
+
+    // LDS: x[EP] (policy input, zero padded to a multiple of 4), then two 64-float buffers for the hidden layers
+    float *lds_x = (float *)wurm_lds, *lds_h1 = lds_x + EP, *lds_h2 = lds_h1 + H;
+    // weights of "my" unit in registers: lane j is hidden unit j of both layers; lanes 0..3 the action scores, lane 4 the value
+    const float *W1 = p.params, *b1 = W1 + (long long)H * E, *W2p = b1 + H, *b2 = W2p + H * H, *Wp = b2 + H, *bp = Wp + 4 * H,
+                *Wv = bp + 4, *bv = Wv + H;
+    float w1[EP], w2[H], wh[H];
+#pragma unroll
+    for (int k = 0; k < EP; ++k) w1[k] = k < E ? W1[(long long)lane * E + k] : 0.0f;
+#pragma unroll
+    for (int k = 0; k < H; ++k) w2[k] = W2p[lane * H + k];
+    const float *head_row = lane < 4 ? Wp + lane * H : Wv; // lanes past 4 compute a copy of the value (unused)
+#pragma unroll
+    for (int k = 0; k < H; ++k) wh[k] = head_row[k];
+    const float bias1 = b1[lane], bias2 = b2[lane], biash = lane < 4 ? bp[lane] : bv[0];
+
+    for (int k = lane; k < EP; k += 64) lds_x[k] = k < E ? p.obs0[env * E + k] : 0.0f;
+    const Crop cg = make_crop(lane, NOBS);
+    const long long obs_stride = p.N * E;
+    float *obs_t = p.obs + env * E;
+    u64 call = p.call;
+
+    for (long long t0 = 0; t0 < p.T; t0 += 64) {
+        const int nt = (int)min((long long)64, p.T - t0);
+        const long long my_t = t0 + lane;
+        // the sampling uniform of step t0 + lane
+        const float my_u = u01(rng_words(p.seed, p.call + 2ull * (u64)my_t, env_id, RNG_POLICY, 0).w[0]);
+        int my_act = 0, my_flags = 0;
+        float my_val = 0.0f, my_p0 = 0.0f, my_p1 = 0.0f, my_p2 = 0.0f, my_p3 = 0.0f;
+
+        for (int j = 0; j < nt; ++j, obs_t += obs_stride, call += 2) {
+            // ---- policy forward (wurm/agents/feedforward.py:24-28)
+            wave_lds_sync();
+            float acc = bias1;
+#pragma unroll
+            for (int k = 0; k < EP; k += 4) {
+                const float4 xs = *(const float4 *)(lds_x + k);
+                acc = fmaf(w1[k], xs.x, acc);
+                acc = fmaf(w1[k + 1], xs.y, acc);
+                acc = fmaf(w1[k + 2], xs.z, acc);
+                acc = fmaf(w1[k + 3], xs.w, acc);
+            }
+            lds_h1[lane] = acc > 0.0f ? acc : 0.0f;
+            wave_lds_sync();
+            acc = bias2;
+#pragma unroll
+            for (int k = 0; k < H; k += 4) {
+                const float4 hs = *(const float4 *)(lds_h1 + k);
+                acc = fmaf(w2[k], hs.x, acc);
+                acc = fmaf(w2[k + 1], hs.y, acc);
+                acc = fmaf(w2[k + 2], hs.z, acc);
+                acc = fmaf(w2[k + 3], hs.w, acc);
+            }
+            lds_h2[lane] = acc > 0.0f ? acc : 0.0f;
+            wave_lds_sync();
+            acc = biash;
+#pragma unroll
+            for (int k = 0; k < H; k += 4) {
+                const float4 hs = *(const float4 *)(lds_h2 + k);
+                acc = fmaf(wh[k], hs.x, acc);
+                acc = fmaf(wh[k + 1], hs.y, acc);
+                acc = fmaf(wh[k + 2], hs.z, acc);
+                acc = fmaf(wh[k + 3], hs.w, acc);
+            }
+            const int acc_bits = __float_as_int(acc);
+            const float l0 = __int_as_float(lane_value(acc_bits, 0)), l1 = __int_as_float(lane_value(acc_bits, 1));
+            const float l2 = __int_as_float(lane_value(acc_bits, 2)), l3 = __int_as_float(lane_value(acc_bits, 3));
+            const float value = __int_as_float(lane_value(acc_bits, 4));
+            // softmax (:28) and Categorical(probs).sample() (main.py:208-210)
+            const float m = fmaxf(fmaxf(l0, l1), fmaxf(l2, l3));
+            const float e0 = exp_spec(l0 - m), e1 = exp_spec(l1 - m), e2 = exp_spec(l2 - m), e3 = exp_spec(l3 - m);
+            const float s = ((e0 + e1) + e2) + e3;
+            const float p0 = e0 / s, p1 = e1 / s, p2 = e2 / s, p3 = e3 / s;
+            const float u = __int_as_float(lane_value(__float_as_int(my_u), j));
+            const float c0 = p0, c1 = c0 + p1, c2 = c1 + p2;
+            const int a = uniform((u >= c0 ? 1 : 0) + (u >= c1 ? 1 : 0) + (u >= c2 ? 1 : 0));
+
+            // ---- env.step(action) (single_snake.py:197-304), crop to HBM and to LDS, env.reset(done)
+            StepOut out;
+            fast_step<CPL>(e, g, f, a, a, out, p.seed, call, env_id, false, -1);
+            fast_partial_small<CPL>(e, g, f, obs_t, cg, lds_x);
+            if (lane == j) {
+                my_act = (int)out.action;
+                my_flags = out.done | (out.selfc << 1) | (out.edgec << 2) | (out.reward != 0.0f ? 8 : 0);
+                my_val = value; my_p0 = p0; my_p1 = p1; my_p2 = p2; my_p3 = p3;
+            }
+            if (out.done) fast_reset<CPL>(e, g, f, p.seed, call + 1ull, env_id, nullptr);
+        }
+        if (lane < nt) {
+            const long long i = my_t * p.N + env;
+            p.actions[i] = (long long)my_act;
+            p.values[i] = my_val;
+            *(float4 *)(p.probs + 4 * i) = make_float4(my_p0, my_p1, my_p2, my_p3);
+            p.reward[i] = (my_flags & 8) ? 1.0f : 0.0f;
+            p.done[i] = (uint8_t)(my_flags & 1);
+            p.selfc[i] = (uint8_t)((my_flags >> 1) & 1);
+            p.edgec[i] = (uint8_t)((my_flags >> 2) & 1);
+        }
+    }
+    fast_sync_bits<CPL>(e, g, f);
+    store_state<CPL, true>(envp, g, e);
+}
+
+static int launch_policy_rollout(const PolicyArgs &p, int obs_n, void *stream)
+{
+    const int W2 = (2 * obs_n + 1) * (2 * obs_n + 1), EP = (3 * W2 + 3) & ~3;
+    const size_t lds = (size_t)(EP + 128) * sizeof(float);
+    dim3 grid((unsigned)p.N), block(64);
+    hipStream_t st = (hipStream_t)stream;
+    (void)hipGetLastError();
+    switch (obs_n) {
+    case 0: hipLaunchKernelGGL(policy_rollout_kernel<0>, grid, block, lds, st, p); break;
+    case 1: hipLaunchKernelGGL(policy_rollout_kernel<1>, grid, block, lds, st, p); break;
+    case 2: hipLaunchKernelGGL(policy_rollout_kernel<2>, grid, block, lds, st, p); break;
+    case 3: hipLaunchKernelGGL(policy_rollout_kernel<3>, grid, block, lds, st, p); break;
+    default: return WURM_ERR_UNSUPPORTED;
+    }
+    return hipGetLastError() == hipSuccess ? WURM_OK : WURM_ERR_HIP;
+}
+
+} // namespace wurm

@@ -765,7 +765,7 @@ __device__ __forceinline__ Crop make_crop(int lane, int n)
 // an env without a head is (0,0,0); otherwise food (1,0,0), head (0,1,0), body (0,127/255,0), background (1,1,1).
 template <int CPL>
 __device__ __forceinline__ void fast_partial_small(const Env<CPL> &e, const Geo &g, const Fast &f,
-                                                   float *__restrict__ o, const Crop &cg)
+                                                   float *__restrict__ o, const Crop &cg, float *lds_copy = nullptr)
 {
     static_assert(CPL <= 2, "ballot-mask crop needs <= 128 cells");
     const int S = g.S, W2 = cg.W2;
@@ -787,6 +787,11 @@ __device__ __forceinline__ void fast_partial_small(const Env<CPL> &e, const Geo 
         o[w] = r;
         o[W2 + w] = gr;
         o[2 * W2 + w] = bg;
+        if (lds_copy) { // the same observation for a consumer inside the kernel (policy_rollout.hpp)
+            lds_copy[w] = r;
+            lds_copy[W2 + w] = gr;
+            lds_copy[2 * W2 + w] = bg;
+        }
     }
 }
 
@@ -1560,6 +1565,8 @@ static int check_common(bool snake, const void *envs, long long N, int S, const 
 
 } // namespace wurm
 
+#include "policy_rollout.hpp"
+
 using namespace wurm;
 
 extern "C" {
@@ -1630,6 +1637,26 @@ int wurm_single_rollout(float *envs, void *actions, int actions_dtype, float *re
     p.obs_elems = obs_elems(true, obs_mode, obs_n, size); p.N = num_envs; p.S = size; p.T = num_steps; p.seed = seed;
     p.call = call0; p.env_offset = env_offset; p.inject_food = inject_food; p.inject_reset = inject_reset;
     return launch<true>(K_ROLLOUT, p, stream);
+}
+
+int wurm_single_policy_rollout(float *envs, const float *obs0, const float *params, int64_t *actions, float *probs,
+                               float *values, float *reward, uint8_t *done, uint8_t *self_collision,
+                               uint8_t *edge_collision, float *obs, uint8_t *status, int obs_n, int64_t num_envs,
+                               int size, int64_t num_steps, uint64_t seed, uint64_t call0, int64_t env_offset,
+                               void *stream)
+{
+    if (num_envs < 0 || num_steps < 0 || size < 3) return WURM_ERR_INVALID_ARG;
+    if (size <= 8 || size > 11 || obs_n < 0 || obs_n > 3) return WURM_ERR_UNSUPPORTED;
+    if (num_envs == 0 || num_steps == 0) return WURM_OK;
+    if (!envs || !obs0 || !params || !actions || !probs || !values || !reward || !done || !self_collision ||
+        !edge_collision || !obs || !status)
+        return WURM_ERR_INVALID_ARG;
+    PolicyArgs p = {};
+    p.envs = envs; p.obs0 = obs0; p.params = params; p.actions = (long long *)actions; p.probs = probs;
+    p.values = values; p.reward = reward; p.done = done; p.selfc = self_collision; p.edgec = edge_collision;
+    p.obs = obs; p.status = status; p.N = num_envs; p.T = num_steps; p.S = size; p.seed = seed; p.call = call0;
+    p.env_offset = env_offset;
+    return launch_policy_rollout(p, obs_n, stream);
 }
 
 int wurm_single_check(const float *envs, uint32_t *err, int64_t num_envs, int size, void *stream)

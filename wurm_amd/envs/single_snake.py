@@ -276,6 +276,52 @@ class SingleSnake(object):
         return {'observations': obs, 'rewards': reward, 'dones': flags[0], 'self_collision': flags[1],
                 'edge_collision': flags[2]}
 
+    def policy_rollout(self, params: torch.Tensor, state: torch.Tensor, num_steps: int, check: bool = True) -> dict:
+        """T iterations of the acting half of experiments/main.py:207-227 in one kernel launch:
+
+            probs, value = model(state); action = Categorical(probs).sample()
+            state, reward, done, info = env.step(action); env.reset(done)
+
+        params: `wurm_amd.agents.pack_policy_params(agent)` (inputs -> 64 -> 64 -> {4, 1}); state: the observation the
+        policy acts on first, (num_envs, 3, 2n+1, 2n+1) as returned by reset / step; the env must be in a
+        `partial_n` mode with n <= 3 and size <= 11.  Returns (T, N, ...) tensors: `actions` (sanitised, int64),
+        `probs`, `values` (no grad — the learner recomputes them from `observations`), `rewards`, `dones`,
+        `self_collision`, `edge_collision`, `observations` (what step t returned, i.e. the policy input of step t+1)
+        and `state` = observations[-1].  `check=True` synchronises once and raises if any env was outside the
+        kernel's domain (not a well-formed snake — only possible if `env.envs` was edited by hand)."""
+        m, n, shape = self._mode_info(self.observation_mode)
+        if m != _lib.OBS_PARTIAL or n > 3 or self.size > 11:
+            raise NotImplementedError('policy_rollout: partial_n observation with n <= 3 on grids of size <= 11')
+        E = 3 * (2 * n + 1) ** 2
+        N, T = self.num_envs, int(num_steps)
+        if params.dtype != torch.float32 or params.device != self.device or not params.is_contiguous() or \
+                params.numel() != 64 * E + 64 + 64 * 64 + 64 + 4 * 64 + 4 + 64 + 1:
+            raise RuntimeError('params must be the contiguous fp32 device tensor of pack_policy_params for this observation size')
+        if state.device != self.device or state.numel() != N * E:
+            raise RuntimeError('state must be the current observation of every env on the env device')
+        state = state.to(torch.float32).contiguous()
+        envs = self._state()
+        dev = self.device
+        actions = torch.empty((T, N), dtype=torch.long, device=dev)
+        probs = torch.empty((T, N, 4), dtype=torch.float32, device=dev)
+        values = torch.empty((T, N), dtype=torch.float32, device=dev)
+        reward = torch.empty((T, N), dtype=torch.float32, device=dev)
+        flags = torch.empty((3, T, N), dtype=torch.bool, device=dev)
+        obs = torch.empty((T,) + shape, dtype=torch.float32, device=dev)
+        status = torch.empty(N, dtype=torch.uint8, device=dev)
+        rc = _lib.call(dev.index, _lib.lib().wurm_single_policy_rollout,
+                       _lib.ptr(envs), _lib.ptr(state), _lib.ptr(params), _lib.ptr(actions), _lib.ptr(probs),
+                       _lib.ptr(values), _lib.ptr(reward), _lib.ptr(flags[0]), _lib.ptr(flags[1]), _lib.ptr(flags[2]),
+                       _lib.ptr(obs), _lib.ptr(status), n, _lib.i64(N), self.size, _lib.i64(T), _lib.u64(self.seed),
+                       _lib.u64(self._next_call(2 * T)), _lib.i64(self.env_offset), _lib.stream_ptr(dev.index))
+        _lib.check(rc, 'SingleSnake.policy_rollout')
+        if check and T > 0 and bool(status.any()):
+            raise RuntimeError('policy_rollout: some envs are not well-formed snakes (status != 0); they were left untouched')
+        self.done = torch.zeros(N, dtype=torch.bool, device=dev)  # every done env was reset
+        return {'actions': actions, 'probs': probs, 'values': values, 'rewards': reward, 'dones': flags[0],
+                'self_collision': flags[1], 'edge_collision': flags[2], 'observations': obs,
+                'state': obs[-1] if T > 0 else state.reshape(shape), 'status': status}
+
     # ------------------------------------------------------------------ invariants
 
     def check_consistency(self):
