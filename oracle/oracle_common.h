@@ -48,7 +48,8 @@ enum {
     RNG_BOOST_COST = 4,  /* per-snake uniform (multi_snake.py:579)                */
     RNG_RATE_FOOD = 5,   /* per-cell uniforms (multi_snake.py:401)                */
     RNG_SPAWN = 6,       /* sub = snake index: words: cell rank, direction        */
-    RNG_COLOUR = 7       /* sub = snake index: 3 uniforms (multi_snake.py:163-169)*/
+    RNG_COLOUR = 7,      /* sub = snake index: 3 uniforms (multi_snake.py:163-169)*/
+    RNG_POLICY = 8       /* word 0: the uniform of Categorical(probs).sample() (experiments/main.py:210) */
 };
 
 /* Philox4x32-10 (Salmon et al., SC'11).  counter = (env_id, call_lo, call_hi, purpose | sub<<8),

@@ -30,7 +30,6 @@
 
 #include "oracle_common.h"
 
-enum { RNG_POLICY = 8 };
 enum { HIDDEN = 64, N_ACTIONS = 4 };
 
 int oracle_single_step(float *envs, void *actions, int act_dtype, float *reward, uint8_t *done,

@@ -21,8 +21,6 @@
 
 namespace wurm {
 
-enum : u32 { RNG_POLICY = 8 };
-
 struct PolicyArgs {
     float *envs;
     const float *obs0;   // (N,E) the observation the policy acts on at step 0

@@ -25,7 +25,8 @@ enum : u32 {
     RNG_BOOST_COST = 4,
     RNG_RATE_FOOD = 5,
     RNG_SPAWN = 6,
-    RNG_COLOUR = 7
+    RNG_COLOUR = 7,
+    RNG_POLICY = 8
 };
 
 struct Words {
