@@ -15,10 +15,13 @@
  * What the reference fixes: the architecture, softmax, "sample from Categorical(probs)", the data flow.  What it does
  * not fix (torch's accumulation order inside addmm, libm's expf, the multinomial sampler's use of the global RNG
  * stream) is this build's own spec, stated here so that the HIP kernel can be bit-identical to this file:
- *   - every dot product is a sequential fused-multiply-add chain in index order starting from the bias:
+ *   - the two hidden layers: a sequential fused-multiply-add chain in index order starting from the bias:
  *         acc = b[j]; for k = 0..K-1: acc = fmaf(W[j][k], x[k], acc)
+ *   - the five head outputs (4 action scores, 1 value): bias added to tree_sum() of the 64 rounded products
+ *     W[a][k] * h2[k] — pairs, quads, eights, sixteens, then ((r0 + r1) + r2) + r3 over the four groups of 16
+ *     (the association of a DPP butterfly over a 64-lane wave);
  *   - exp_spec(): exp on (-inf, 0] by Cody-Waite reduction + a degree-6 polynomial, all in fmaf / ldexpf;
- *   - softmax: e_a = exp_spec(l_a - max l), p_a = e_a / (((e_0 + e_1) + e_2) + e_3)  (IEEE division);
+ *   - softmax: e_a = exp_spec(l_a - max l), p_a = e_a * (1 / (((e_0 + e_1) + e_2) + e_3))  (one IEEE reciprocal);
  *   - sampling: u = u01(word 0 of Philox(seed; env id, step call counter, RNG_POLICY)), action = number of
  *     cumulative sums c_0 = p_0, c_1 = c_0 + p_1, c_2 = c_1 + p_2 that are <= u (inverse CDF, clamped to 3).
  * Against torch (fp32, CPU) these agree to ~1e-6 relative on probs / values; tests/test_policy_rollout*.py check that,
@@ -58,6 +61,22 @@ float oracle_exp_spec(float x)
     return ldexpf(p, (int)n);
 }
 
+/* sum of 64 floats with the association of a DPP butterfly over a wave: within each group of 16, pairs (i, i^1), quads,
+ * eights, sixteens; then ((r0 + r1) + r2) + r3 */
+static float tree_sum(const float t[HIDDEN])
+{
+    float r[4];
+    for (int g = 0; g < 4; ++g) {
+        float q[4];
+        for (int m = 0; m < 4; ++m) {
+            const float *u = t + 16 * g + 4 * m;
+            q[m] = (u[0] + u[1]) + (u[2] + u[3]);
+        }
+        r[g] = (q[0] + q[1]) + (q[2] + q[3]);
+    }
+    return ((r[0] + r[1]) + r[2]) + r[3];
+}
+
 /* params: W1 (64 x E, row-major [unit][input]), b1 (64), W2 (64 x 64), b2 (64), Wp (4 x 64), bp (4), Wv (64), bv (1)
  * — the layout of torch's Linear.weight / .bias tensors concatenated in that order. */
 void oracle_policy_forward(const float *params, int E, const float *x, float probs[4], float *value)
@@ -75,20 +94,20 @@ void oracle_policy_forward(const float *params, int E, const float *x, float pro
         for (int k = 0; k < HIDDEN; ++k) acc = fmaf(W2[j * HIDDEN + k], h1[k], acc);
         h2[j] = acc > 0.0f ? acc : 0.0f;
     }
+    float t[HIDDEN];
     for (int a = 0; a < N_ACTIONS; ++a) {
-        float acc = bp[a];
-        for (int k = 0; k < HIDDEN; ++k) acc = fmaf(Wp[a * HIDDEN + k], h2[k], acc);
-        l[a] = acc;
+        for (int k = 0; k < HIDDEN; ++k) t[k] = Wp[a * HIDDEN + k] * h2[k];
+        l[a] = tree_sum(t) + bp[a];
     }
-    float v = bv[0];
-    for (int k = 0; k < HIDDEN; ++k) v = fmaf(Wv[k], h2[k], v);
-    *value = v;
+    for (int k = 0; k < HIDDEN; ++k) t[k] = Wv[k] * h2[k];
+    *value = tree_sum(t) + bv[0];
     float m = l[0];
     for (int a = 1; a < N_ACTIONS; ++a) m = l[a] > m ? l[a] : m;
     float e[N_ACTIONS];
     for (int a = 0; a < N_ACTIONS; ++a) e[a] = oracle_exp_spec(l[a] - m);
     const float s = ((e[0] + e[1]) + e[2]) + e[3];
-    for (int a = 0; a < N_ACTIONS; ++a) probs[a] = e[a] / s;
+    const float rs = 1.0f / s;
+    for (int a = 0; a < N_ACTIONS; ++a) probs[a] = e[a] * rs;
 }
 
 int oracle_policy_sample(const float probs[4], uint64_t seed, uint64_t call, uint64_t env_id)

@@ -11,9 +11,11 @@
 // broadcast ds_read_b128s as the input of step t+1.
 //
 // Arithmetic spec (what the reference leaves open; identical in oracle/policy.c, so the two are bit-identical):
-// every dot product is a sequential fmaf chain in index order starting from the bias; exp_spec (Cody-Waite +
-// degree-6 polynomial in fmaf / ldexp); softmax with the sum ((e0+e1)+e2)+e3 and IEEE division; inverse-CDF
-// sampling with u = u01(Philox(seed; env, step call, RNG_POLICY).w0).
+// the two hidden layers are sequential fmaf chains in index order starting from the bias; the five head outputs are
+// bias + a fixed-shape tree sum of the 64 products (pairs, quads, eights, sixteens, then ((r0+r1)+r2)+r3 over the four
+// 16-lane rows — the shape of a DPP butterfly); exp_spec (Cody-Waite + degree-6 polynomial in fmaf / ldexp); softmax
+// with the sum ((e0+e1)+e2)+e3 and one IEEE reciprocal; inverse-CDF sampling with
+// u = u01(Philox(seed; env, step call, RNG_POLICY).w0).
 //
 // Domain: SingleSnake, grids of at most 128 cells (S <= 11), partial_n crop with n <= 3, envs in a well-formed state
 // (fast_init: what reset / step+reset produce).  An env outside the domain is left untouched and flagged in `status`.
@@ -53,6 +55,20 @@ __device__ __forceinline__ float exp_spec(float x) // oracle/policy.c: oracle_ex
     return x > -87.3f ? ldexpf(p, (int)n) : 0.0f;
 }
 
+// wave-wide fp32 sum with a fixed association (oracle/policy.c: tree_sum): DPP butterfly inside each row of 16 lanes
+// (pairs, quads, eights, sixteens), then ((r0 + r1) + r2) + r3 over the four rows.  Result wave-uniform.
+__device__ __forceinline__ float tree_sum(float v)
+{
+    v += __int_as_float(dpp_row<DPP_QUAD_XOR1>(__float_as_int(v)));
+    v += __int_as_float(dpp_row<DPP_QUAD_XOR2>(__float_as_int(v)));
+    v += __int_as_float(dpp_row<DPP_ROW_HALF_MIRROR>(__float_as_int(v)));
+    v += __int_as_float(dpp_row<DPP_ROW_MIRROR>(__float_as_int(v)));
+    const int b = __float_as_int(v);
+    const float r0 = __int_as_float(lane_value(b, 0)), r1 = __int_as_float(lane_value(b, 16));
+    const float r2 = __int_as_float(lane_value(b, 32)), r3 = __int_as_float(lane_value(b, 48));
+    return ((r0 + r1) + r2) + r3;
+}
+
 template <int NOBS>
 __global__ __launch_bounds__(64) void policy_rollout_kernel(PolicyArgs p)
 {
@@ -72,20 +88,20 @@ __global__ __launch_bounds__(64) void policy_rollout_kernel(PolicyArgs p)
     if (lane == 0) p.status[env] = 0;
     const u64 env_id = (u64)(p.env_offset + env);
 
-    // LDS: x[EP] (policy input, zero padded to a multiple of 4), then two 64-float buffers for the hidden layers
-    float *lds_x = (float *)wurm_lds, *lds_h1 = lds_x + EP, *lds_h2 = lds_h1 + H;
-    // weights of "my" unit in registers: lane j is hidden unit j of both layers; lanes 0..3 the action scores, lane 4 the value
+    // LDS: x[EP] (policy input, zero padded to a multiple of 4), then 64 floats for the first hidden layer
+    float *lds_x = (float *)wurm_lds, *lds_h1 = lds_x + EP;
+    // weights of "my" unit in registers: lane j is hidden unit j of both layers
     const float *W1 = p.params, *b1 = W1 + (long long)H * E, *W2p = b1 + H, *b2 = W2p + H * H, *Wp = b2 + H, *bp = Wp + 4 * H,
                 *Wv = bp + 4, *bv = Wv + H;
-    float w1[EP], w2[H], wh[H];
+    float w1[EP], w2[H];
 #pragma unroll
     for (int k = 0; k < EP; ++k) w1[k] = k < E ? W1[(long long)lane * E + k] : 0.0f;
 #pragma unroll
     for (int k = 0; k < H; ++k) w2[k] = W2p[lane * H + k];
-    const float *head_row = lane < 4 ? Wp + lane * H : Wv; // lanes past 4 compute a copy of the value (unused)
-#pragma unroll
-    for (int k = 0; k < H; ++k) wh[k] = head_row[k];
-    const float bias1 = b1[lane], bias2 = b2[lane], biash = lane < 4 ? bp[lane] : bv[0];
+    // heads: lane k holds column k of the five output rows (4 action scores, 1 value)
+    const float wp0 = Wp[lane], wp1 = Wp[H + lane], wp2 = Wp[2 * H + lane], wp3 = Wp[3 * H + lane], wv = Wv[lane];
+    const float bias1 = b1[lane], bias2 = b2[lane];
+    const float bp0 = bp[0], bp1 = bp[1], bp2 = bp[2], bp3 = bp[3], bv0 = bv[0];
 
     for (int k = lane; k < EP; k += 64) lds_x[k] = k < E ? p.obs0[env * E + k] : 0.0f;
     const Crop cg = make_crop(lane, NOBS);
@@ -104,46 +120,57 @@ __global__ __launch_bounds__(64) void policy_rollout_kernel(PolicyArgs p)
         for (int j = 0; j < nt; ++j, obs_t += obs_stride, call += 2) {
             // ---- policy forward (wurm/agents/feedforward.py:24-28)
             wave_lds_sync();
+            // The broadcast reads are issued in batches of 8 x 16 bytes and each batch is followed by its 32 fmafs
+            // (sched_barrier): left alone the scheduler keeps two reads in flight and the lone wave eats one LDS
+            // latency per 4 inputs; a whole layer in flight costs 76 registers and with them the occupancy that large
+            // batches need.
+            constexpr int BATCH = 8;
             float acc = bias1;
 #pragma unroll
-            for (int k = 0; k < EP; k += 4) {
-                const float4 xs = *(const float4 *)(lds_x + k);
-                acc = fmaf(w1[k], xs.x, acc);
-                acc = fmaf(w1[k + 1], xs.y, acc);
-                acc = fmaf(w1[k + 2], xs.z, acc);
-                acc = fmaf(w1[k + 3], xs.w, acc);
+            for (int k0 = 0; k0 < EP / 4; k0 += BATCH) {
+                float4 xs[BATCH];
+#pragma unroll
+                for (int k = 0; k < BATCH; ++k)
+                    if (k0 + k < EP / 4) xs[k] = *(const float4 *)(lds_x + 4 * (k0 + k));
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int k = 0; k < BATCH; ++k)
+                    if (k0 + k < EP / 4) {
+                        acc = fmaf(w1[4 * (k0 + k)], xs[k].x, acc);
+                        acc = fmaf(w1[4 * (k0 + k) + 1], xs[k].y, acc);
+                        acc = fmaf(w1[4 * (k0 + k) + 2], xs[k].z, acc);
+                        acc = fmaf(w1[4 * (k0 + k) + 3], xs[k].w, acc);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
             }
             lds_h1[lane] = acc > 0.0f ? acc : 0.0f;
             wave_lds_sync();
             acc = bias2;
 #pragma unroll
-            for (int k = 0; k < H; k += 4) {
-                const float4 hs = *(const float4 *)(lds_h1 + k);
-                acc = fmaf(w2[k], hs.x, acc);
-                acc = fmaf(w2[k + 1], hs.y, acc);
-                acc = fmaf(w2[k + 2], hs.z, acc);
-                acc = fmaf(w2[k + 3], hs.w, acc);
-            }
-            lds_h2[lane] = acc > 0.0f ? acc : 0.0f;
-            wave_lds_sync();
-            acc = biash;
+            for (int k0 = 0; k0 < H / 4; k0 += BATCH) {
+                float4 hs[BATCH];
 #pragma unroll
-            for (int k = 0; k < H; k += 4) {
-                const float4 hs = *(const float4 *)(lds_h2 + k);
-                acc = fmaf(wh[k], hs.x, acc);
-                acc = fmaf(wh[k + 1], hs.y, acc);
-                acc = fmaf(wh[k + 2], hs.z, acc);
-                acc = fmaf(wh[k + 3], hs.w, acc);
+                for (int k = 0; k < BATCH; ++k) hs[k] = *(const float4 *)(lds_h1 + 4 * (k0 + k));
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int k = 0; k < BATCH; ++k) {
+                    acc = fmaf(w2[4 * (k0 + k)], hs[k].x, acc);
+                    acc = fmaf(w2[4 * (k0 + k) + 1], hs[k].y, acc);
+                    acc = fmaf(w2[4 * (k0 + k) + 2], hs[k].z, acc);
+                    acc = fmaf(w2[4 * (k0 + k) + 3], hs[k].w, acc);
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
-            const int acc_bits = __float_as_int(acc);
-            const float l0 = __int_as_float(lane_value(acc_bits, 0)), l1 = __int_as_float(lane_value(acc_bits, 1));
-            const float l2 = __int_as_float(lane_value(acc_bits, 2)), l3 = __int_as_float(lane_value(acc_bits, 3));
-            const float value = __int_as_float(lane_value(acc_bits, 4));
+            const float h2 = acc > 0.0f ? acc : 0.0f;
+            const float l0 = tree_sum(wp0 * h2) + bp0, l1 = tree_sum(wp1 * h2) + bp1;
+            const float l2 = tree_sum(wp2 * h2) + bp2, l3 = tree_sum(wp3 * h2) + bp3;
+            const float value = tree_sum(wv * h2) + bv0;
             // softmax (:28) and Categorical(probs).sample() (main.py:208-210)
             const float m = fmaxf(fmaxf(l0, l1), fmaxf(l2, l3));
             const float e0 = exp_spec(l0 - m), e1 = exp_spec(l1 - m), e2 = exp_spec(l2 - m), e3 = exp_spec(l3 - m);
             const float s = ((e0 + e1) + e2) + e3;
-            const float p0 = e0 / s, p1 = e1 / s, p2 = e2 / s, p3 = e3 / s;
+            const float rs = 1.0f / s;
+            const float p0 = e0 * rs, p1 = e1 * rs, p2 = e2 * rs, p3 = e3 * rs;
             const float u = __int_as_float(lane_value(__float_as_int(my_u), j));
             const float c0 = p0, c1 = c0 + p1, c2 = c1 + p2;
             const int a = uniform((u >= c0 ? 1 : 0) + (u >= c1 ? 1 : 0) + (u >= c2 ? 1 : 0));
@@ -177,7 +204,7 @@ __global__ __launch_bounds__(64) void policy_rollout_kernel(PolicyArgs p)
 static int launch_policy_rollout(const PolicyArgs &p, int obs_n, void *stream)
 {
     const int W2 = (2 * obs_n + 1) * (2 * obs_n + 1), EP = (3 * W2 + 3) & ~3;
-    const size_t lds = (size_t)(EP + 128) * sizeof(float);
+    const size_t lds = (size_t)(EP + 64) * sizeof(float);
     dim3 grid((unsigned)p.N), block(64);
     hipStream_t st = (hipStream_t)stream;
     (void)hipGetLastError();
