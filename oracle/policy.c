@@ -15,8 +15,10 @@
  * What the reference fixes: the architecture, softmax, "sample from Categorical(probs)", the data flow.  What it does
  * not fix (torch's accumulation order inside addmm, libm's expf, the multinomial sampler's use of the global RNG
  * stream) is this build's own spec, stated here so that the HIP kernel can be bit-identical to this file:
- *   - the two hidden layers: a sequential fused-multiply-add chain in index order starting from the bias:
- *         acc = b[j]; for k = 0..K-1: acc = fmaf(W[j][k], x[k], acc)
+ *   - a hidden unit: two interleaved fused-multiply-add chains in index order, added at the end:
+ *         even = b[j]; odd = 0; for k = 0, 2, ..: even = fmaf(W[j][k], x[k], even); odd = fmaf(W[j][k+1], x[k+1], odd)
+ *         unit = even + odd            (a missing last odd input leaves `odd` as it is)
+ *     (one v_pk_fma_f32 per pair on the GPU);
  *   - the five head outputs (4 action scores, 1 value): bias added to tree_sum() of the 64 rounded products
  *     W[a][k] * h2[k] — pairs, quads, eights, sixteens, then ((r0 + r1) + r2) + r3 over the four groups of 16
  *     (the association of a DPP butterfly over a 64-lane wave);
@@ -61,6 +63,17 @@ float oracle_exp_spec(float x)
     return ldexpf(p, (int)n);
 }
 
+/* bias + w . x as two interleaved fmaf chains (even indices from the bias, odd indices from 0) */
+static float two_chain_dot(const float *w, const float *x, int K, float bias)
+{
+    float even = bias, odd = 0.0f;
+    for (int k = 0; k < K; k += 2) {
+        even = fmaf(w[k], x[k], even);
+        if (k + 1 < K) odd = fmaf(w[k + 1], x[k + 1], odd);
+    }
+    return even + odd;
+}
+
 /* sum of 64 floats with the association of a DPP butterfly over a wave: within each group of 16, pairs (i, i^1), quads,
  * eights, sixteens; then ((r0 + r1) + r2) + r3 */
 static float tree_sum(const float t[HIDDEN])
@@ -85,13 +98,11 @@ void oracle_policy_forward(const float *params, int E, const float *x, float pro
     const float *Wp = b2 + HIDDEN, *bp = Wp + N_ACTIONS * HIDDEN, *Wv = bp + N_ACTIONS, *bv = Wv + HIDDEN;
     float h1[HIDDEN], h2[HIDDEN], l[N_ACTIONS];
     for (int j = 0; j < HIDDEN; ++j) {
-        float acc = b1[j];
-        for (int k = 0; k < E; ++k) acc = fmaf(W1[(size_t)j * E + k], x[k], acc);
+        const float acc = two_chain_dot(W1 + (size_t)j * E, x, E, b1[j]);
         h1[j] = acc > 0.0f ? acc : 0.0f;
     }
     for (int j = 0; j < HIDDEN; ++j) {
-        float acc = b2[j];
-        for (int k = 0; k < HIDDEN; ++k) acc = fmaf(W2[j * HIDDEN + k], h1[k], acc);
+        const float acc = two_chain_dot(W2 + j * HIDDEN, h1, HIDDEN, b2[j]);
         h2[j] = acc > 0.0f ? acc : 0.0f;
     }
     float t[HIDDEN];

@@ -19,7 +19,7 @@
         long long t0 = __builtin_amdgcn_s_memtime();                                                \
         for (int i = 0; i < iters; ++i) {                                                           \
             asm volatile(BODY : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3) \
-                         : "s"(sink) : "vcc", "scc", "s40", "s41", "s42", "s43", "s44", "v10", "v11", "memory");      \
+                         : "s"(sink) : "vcc", "scc", "s40", "s41", "s42", "s43", "s44", "v10", "v11", "v12", "v13", "v14", "v15", "memory");      \
         }                                                                                           \
         long long t1 = __builtin_amdgcn_s_memtime();                                                \
         if (threadIdx.x == 0) { out[0] = t1 - t0; out[1] = NINSTR; }                                \
@@ -51,6 +51,8 @@ BENCH(salu64_dep, 32, REP32("s_and_b64 s[40:41], s[40:41], exec\n"))
 BENCH(vmul_lo, 32, REP16("v_mul_lo_u32 %0, %0, %1\n v_mul_lo_u32 %2, %2, %3\n"))
 BENCH(vmul_hi, 32, REP16("v_mul_hi_u32 %0, %0, %1\n v_mul_hi_u32 %2, %2, %3\n"))
 BENCH(vmad64, 32, REP32("v_mad_u64_u32 v[10:11], s[40:41], %0, %1, v[10:11]\n"))
+BENCH(vfma_dep, 32, REP32("v_fma_f32 %0, %1, %2, %0\n"))
+BENCH(vpkfma_dep, 32, REP32("v_pk_fma_f32 v[10:11], v[12:13], v[14:15], v[10:11]\n"))
 BENCH(smul, 32, REP16("s_mul_i32 %4, %4, %5\n s_mul_hi_u32 %6, %6, %5\n"))
 BENCH(vcmp_vcnd_sgpr, 32, REP16("v_cmp_lt_i32 s[40:41], %4, %0\n v_cndmask_b32 %0, %0, %1, s[40:41]\n"))
 BENCH(vcmp3_vcnd3, 96, REP4(REP4("v_cmp_lt_i32 s[40:41], %4, %0\n v_cmp_lt_i32 s[42:43], %4, %1\n v_cmp_lt_i32 vcc, %4, %2\n v_cndmask_b32 %0, %0, %3, s[40:41]\n v_cndmask_b32 %1, %1, %3, s[42:43]\n v_cndmask_b32 %2, %2, %3, vcc\n")) )
@@ -70,7 +72,7 @@ int main()
                    {"readlane_chain(+s_nop 3)", readlane_chain}, {"readlane_const", readlane_const},
                    {"readlane_only", readlane_only}, {"s_nop 0", snop0}, {"scmp_cselect", scmp_cselect},
                    {"branch_taken", branch_taken}, {"branch_not_taken", branch_not_taken}, {"store3+8valu+4salu", store3},
-                   {"v_lshrrev_b64", vlshr64}, {"salu64_dep", salu64_dep}, {"v_mul_lo_u32", vmul_lo}, {"v_mul_hi_u32", vmul_hi}, {"v_mad_u64_u32", vmad64}, {"s_mul_i32/s_mul_hi_u32", smul}, {"vcmp->vcndmask via sgpr pair", vcmp_vcnd_sgpr}, {"3 vcmp then 3 vcndmask", vcmp3_vcnd3}};
+                   {"v_lshrrev_b64", vlshr64}, {"salu64_dep", salu64_dep}, {"v_mul_lo_u32", vmul_lo}, {"v_mul_hi_u32", vmul_hi}, {"v_mad_u64_u32", vmad64}, {"v_fma_f32 dependent", vfma_dep}, {"v_pk_fma_f32 dependent", vpkfma_dep}, {"s_mul_i32/s_mul_hi_u32", smul}, {"vcmp->vcndmask via sgpr pair", vcmp_vcnd_sgpr}, {"3 vcmp then 3 vcndmask", vcmp3_vcnd3}};
     const int iters = 2000;
     for (auto &b : benches) {
         long long h[2];

@@ -11,7 +11,8 @@
 // broadcast ds_read_b128s as the input of step t+1.
 //
 // Arithmetic spec (what the reference leaves open; identical in oracle/policy.c, so the two are bit-identical):
-// the two hidden layers are sequential fmaf chains in index order starting from the bias; the five head outputs are
+// a hidden unit is TWO interleaved fmaf chains — even inputs starting from the bias, odd inputs starting from 0 — added
+// at the end (one v_pk_fma_f32 advances both: it issues as fast as a scalar v_fma_f32); the five head outputs are
 // bias + a fixed-shape tree sum of the 64 products (pairs, quads, eights, sixteens, then ((r0+r1)+r2)+r3 over the four
 // 16-lane rows — the shape of a DPP butterfly); exp_spec (Cody-Waite + degree-6 polynomial in fmaf / ldexp); softmax
 // with the sum ((e0+e1)+e2)+e3 and one IEEE reciprocal; inverse-CDF sampling with
@@ -93,11 +94,18 @@ __global__ __launch_bounds__(64) void policy_rollout_kernel(PolicyArgs p)
     // weights of "my" unit in registers: lane j is hidden unit j of both layers
     const float *W1 = p.params, *b1 = W1 + (long long)H * E, *W2p = b1 + H, *b2 = W2p + H * H, *Wp = b2 + H, *bp = Wp + 4 * H,
                 *Wv = bp + 4, *bv = Wv + H;
-    float w1[EP], w2[H];
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 w1[EP / 2], w2[H / 2]; // (even input, odd input) pairs
 #pragma unroll
-    for (int k = 0; k < EP; ++k) w1[k] = k < E ? W1[(long long)lane * E + k] : 0.0f;
+    for (int k = 0; k < EP / 2; ++k) {
+        w1[k].x = 2 * k < E ? W1[(long long)lane * E + 2 * k] : 0.0f;
+        w1[k].y = 2 * k + 1 < E ? W1[(long long)lane * E + 2 * k + 1] : 0.0f;
+    }
 #pragma unroll
-    for (int k = 0; k < H; ++k) w2[k] = W2p[lane * H + k];
+    for (int k = 0; k < H / 2; ++k) {
+        w2[k].x = W2p[lane * H + 2 * k];
+        w2[k].y = W2p[lane * H + 2 * k + 1];
+    }
     // heads: lane k holds column k of the five output rows (4 action scores, 1 value)
     const float wp0 = Wp[lane], wp1 = Wp[H + lane], wp2 = Wp[2 * H + lane], wp3 = Wp[3 * H + lane], wv = Wv[lane];
     const float bias1 = b1[lane], bias2 = b2[lane];
@@ -125,7 +133,7 @@ __global__ __launch_bounds__(64) void policy_rollout_kernel(PolicyArgs p)
             // latency per 4 inputs; a whole layer in flight costs 76 registers and with them the occupancy that large
             // batches need.
             constexpr int BATCH = 8;
-            float acc = bias1;
+            f2 acc2 = {bias1, 0.0f};
 #pragma unroll
             for (int k0 = 0; k0 < EP / 4; k0 += BATCH) {
                 float4 xs[BATCH];
@@ -136,16 +144,17 @@ __global__ __launch_bounds__(64) void policy_rollout_kernel(PolicyArgs p)
 #pragma unroll
                 for (int k = 0; k < BATCH; ++k)
                     if (k0 + k < EP / 4) {
-                        acc = fmaf(w1[4 * (k0 + k)], xs[k].x, acc);
-                        acc = fmaf(w1[4 * (k0 + k) + 1], xs[k].y, acc);
-                        acc = fmaf(w1[4 * (k0 + k) + 2], xs[k].z, acc);
-                        acc = fmaf(w1[4 * (k0 + k) + 3], xs[k].w, acc);
+                        const f2 lo = {xs[k].x, xs[k].y}, hi = {xs[k].z, xs[k].w};
+                        acc2 = __builtin_elementwise_fma(w1[2 * (k0 + k)], lo, acc2);
+                        acc2 = __builtin_elementwise_fma(w1[2 * (k0 + k) + 1], hi, acc2);
                     }
                 __builtin_amdgcn_sched_barrier(0);
             }
+            float acc = acc2.x + acc2.y;
             lds_h1[lane] = acc > 0.0f ? acc : 0.0f;
             wave_lds_sync();
-            acc = bias2;
+            acc2.x = bias2;
+            acc2.y = 0.0f;
 #pragma unroll
             for (int k0 = 0; k0 < H / 4; k0 += BATCH) {
                 float4 hs[BATCH];
@@ -154,13 +163,13 @@ __global__ __launch_bounds__(64) void policy_rollout_kernel(PolicyArgs p)
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int k = 0; k < BATCH; ++k) {
-                    acc = fmaf(w2[4 * (k0 + k)], hs[k].x, acc);
-                    acc = fmaf(w2[4 * (k0 + k) + 1], hs[k].y, acc);
-                    acc = fmaf(w2[4 * (k0 + k) + 2], hs[k].z, acc);
-                    acc = fmaf(w2[4 * (k0 + k) + 3], hs[k].w, acc);
+                    const f2 lo = {hs[k].x, hs[k].y}, hi = {hs[k].z, hs[k].w};
+                    acc2 = __builtin_elementwise_fma(w2[2 * (k0 + k)], lo, acc2);
+                    acc2 = __builtin_elementwise_fma(w2[2 * (k0 + k) + 1], hi, acc2);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+            acc = acc2.x + acc2.y;
             const float h2 = acc > 0.0f ? acc : 0.0f;
             const float l0 = tree_sum(wp0 * h2) + bp0, l1 = tree_sum(wp1 * h2) + bp1;
             const float l2 = tree_sum(wp2 * h2) + bp2, l3 = tree_sum(wp3 * h2) + bp3;
