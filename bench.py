@@ -246,6 +246,25 @@ def extra_measurements(device):
         'what': 'BASELINE configs[3]: MultiSnake 4096x25x25, 4 agents, defaults, step+observe+reset(__all__) per '
                 'batch-step, fused rollout chunk 16 (algorithmic 75 160 B per env-step; reference torch-CPU: 3 280 '
                 'env-steps/s)'}
+    del env, actions
+    # (e) the acting loop with the policy inside the env kernel: MLP 75->64->64->{4,1} + sampling
+    from wurm_amd.agents import FeedforwardAgent, pack_policy_params
+    N, T, reps = 512, 256, 8
+    torch.manual_seed(0)
+    env = SingleSnake(num_envs=N, size=SIZE, observation_mode=OBS_MODE, device=device, seed=0)
+    params = pack_policy_params(FeedforwardAgent(4, 2, 64, OBS_ELEMS).to(device))
+    state = env.reset()
+    state = env.policy_rollout(params, state, T, check=False)['state']
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        state = env.policy_rollout(params, state, T, check=False)['state']
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out['policy_rollout_512'] = {
+        'value': N * T * reps / dt, 'unit': 'env-steps/s',
+        'what': 'policy forward (random-init FeedforwardAgent) + Categorical sample + step + observe + reset per '
+                'env-step, fused in one kernel, launches of 256 batch-steps'}
     return out
 
 
