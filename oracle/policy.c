@@ -20,8 +20,8 @@
  *         unit = even + odd            (a missing last odd input leaves `odd` as it is)
  *     (one v_pk_fma_f32 per pair on the GPU);
  *   - the five head outputs (4 action scores, 1 value): bias added to tree_sum() of the 64 rounded products
- *     W[a][k] * h2[k] — pairs, quads, eights, sixteens, then ((r0 + r1) + r2) + r3 over the four groups of 16
- *     (the association of a DPP butterfly over a 64-lane wave);
+ *     W[a][k] * h2[k] — pairs, quads, eights, sixteens, then (r0 + r1) + (r2 + r3) over the four groups of 16
+ *     (the association of a DPP reduction over a 64-lane wave);
  *   - exp_spec(): exp on (-inf, 0] by Cody-Waite reduction + a degree-6 polynomial, all in fmaf / ldexpf;
  *   - softmax: e_a = exp_spec(l_a - max l), p_a = e_a * (1 / (((e_0 + e_1) + e_2) + e_3))  (one IEEE reciprocal);
  *   - sampling: u = u01(word 0 of Philox(seed; env id, step call counter, RNG_POLICY)), action = number of
@@ -75,7 +75,7 @@ static float two_chain_dot(const float *w, const float *x, int K, float bias)
 }
 
 /* sum of 64 floats with the association of a DPP butterfly over a wave: within each group of 16, pairs (i, i^1), quads,
- * eights, sixteens; then ((r0 + r1) + r2) + r3 */
+ * eights, sixteens; then (r0 + r1) + (r2 + r3) (row broadcasts) */
 static float tree_sum(const float t[HIDDEN])
 {
     float r[4];
@@ -87,7 +87,7 @@ static float tree_sum(const float t[HIDDEN])
         }
         r[g] = (q[0] + q[1]) + (q[2] + q[3]);
     }
-    return ((r[0] + r[1]) + r[2]) + r[3];
+    return (r[0] + r[1]) + (r[2] + r[3]);
 }
 
 /* params: W1 (64 x E, row-major [unit][input]), b1 (64), W2 (64 x 64), b2 (64), Wp (4 x 64), bp (4), Wv (64), bv (1)

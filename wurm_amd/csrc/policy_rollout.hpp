@@ -13,8 +13,8 @@
 // Arithmetic spec (what the reference leaves open; identical in oracle/policy.c, so the two are bit-identical):
 // a hidden unit is TWO interleaved fmaf chains — even inputs starting from the bias, odd inputs starting from 0 — added
 // at the end (one v_pk_fma_f32 advances both: it issues as fast as a scalar v_fma_f32); the five head outputs are
-// bias + a fixed-shape tree sum of the 64 products (pairs, quads, eights, sixteens, then ((r0+r1)+r2)+r3 over the four
-// 16-lane rows — the shape of a DPP butterfly); exp_spec (Cody-Waite + degree-6 polynomial in fmaf / ldexp); softmax
+// bias + a fixed-shape tree sum of the 64 products (pairs, quads, eights, sixteens, then the four
+// 16-lane rows as (r0+r1)+(r2+r3) — the shape of a DPP wave reduction); exp_spec (Cody-Waite + degree-6 polynomial in fmaf / ldexp); softmax
 // with the sum ((e0+e1)+e2)+e3 and one IEEE reciprocal; inverse-CDF sampling with
 // u = u01(Philox(seed; env, step call, RNG_POLICY).w0).
 //
@@ -56,18 +56,34 @@ __device__ __forceinline__ float exp_spec(float x) // oracle/policy.c: oracle_ex
     return x > -87.3f ? ldexpf(p, (int)n) : 0.0f;
 }
 
-// wave-wide fp32 sum with a fixed association (oracle/policy.c: tree_sum): DPP butterfly inside each row of 16 lanes
-// (pairs, quads, eights, sixteens), then ((r0 + r1) + r2) + r3 over the four rows.  Result wave-uniform.
-__device__ __forceinline__ float tree_sum(float v)
+// Five wave-wide fp32 sums at once, each with the fixed association of oracle/policy.c: tree_sum — a DPP butterfly
+// inside each row of 16 lanes (pairs, quads, eights, sixteens), then (r0 + r1) + (r2 + r3) over the four rows with the
+// wave-level row broadcasts; the totals end up in lane 63.  Written out because the compiler turns every
+// `v += dpp(v)` into mov + nop + mov_dpp + add; interleaving the five chains keeps every DPP read two or more
+// instructions behind the write it depends on, so no wait states are needed inside the block.
+__device__ __forceinline__ void tree_sum5(float &a, float &b, float &c, float &d, float &e)
 {
-    v += __int_as_float(dpp_row<DPP_QUAD_XOR1>(__float_as_int(v)));
-    v += __int_as_float(dpp_row<DPP_QUAD_XOR2>(__float_as_int(v)));
-    v += __int_as_float(dpp_row<DPP_ROW_HALF_MIRROR>(__float_as_int(v)));
-    v += __int_as_float(dpp_row<DPP_ROW_MIRROR>(__float_as_int(v)));
-    const int b = __float_as_int(v);
-    const float r0 = __int_as_float(lane_value(b, 0)), r1 = __int_as_float(lane_value(b, 16));
-    const float r2 = __int_as_float(lane_value(b, 32)), r3 = __int_as_float(lane_value(b, 48));
-    return ((r0 + r1) + r2) + r3;
+#define WURM_DPP5(CTRL)                                   \
+    "v_add_f32_dpp %0, %0, %0 " CTRL "\n\t"               \
+    "v_add_f32_dpp %1, %1, %1 " CTRL "\n\t"               \
+    "v_add_f32_dpp %2, %2, %2 " CTRL "\n\t"               \
+    "v_add_f32_dpp %3, %3, %3 " CTRL "\n\t"               \
+    "v_add_f32_dpp %4, %4, %4 " CTRL "\n\t"
+    asm("s_nop 1\n\t"
+        WURM_DPP5("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+        WURM_DPP5("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
+        WURM_DPP5("row_half_mirror row_mask:0xf bank_mask:0xf")
+        WURM_DPP5("row_mirror row_mask:0xf bank_mask:0xf")
+        WURM_DPP5("row_bcast:15 row_mask:0xa bank_mask:0xf")
+        WURM_DPP5("row_bcast:31 row_mask:0xc bank_mask:0xf")
+        "s_nop 1"
+        : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e));
+#undef WURM_DPP5
+    a = __int_as_float(lane_value(__float_as_int(a), 63));
+    b = __int_as_float(lane_value(__float_as_int(b), 63));
+    c = __int_as_float(lane_value(__float_as_int(c), 63));
+    d = __int_as_float(lane_value(__float_as_int(d), 63));
+    e = __int_as_float(lane_value(__float_as_int(e), 63));
 }
 
 template <int NOBS>
@@ -171,9 +187,9 @@ __global__ __launch_bounds__(64) void policy_rollout_kernel(PolicyArgs p)
             }
             acc = acc2.x + acc2.y;
             const float h2 = acc > 0.0f ? acc : 0.0f;
-            const float l0 = tree_sum(wp0 * h2) + bp0, l1 = tree_sum(wp1 * h2) + bp1;
-            const float l2 = tree_sum(wp2 * h2) + bp2, l3 = tree_sum(wp3 * h2) + bp3;
-            const float value = tree_sum(wv * h2) + bv0;
+            float t0 = wp0 * h2, t1 = wp1 * h2, t2 = wp2 * h2, t3 = wp3 * h2, t4 = wv * h2;
+            tree_sum5(t0, t1, t2, t3, t4);
+            const float l0 = t0 + bp0, l1 = t1 + bp1, l2 = t2 + bp2, l3 = t3 + bp3, value = t4 + bv0;
             // softmax (:28) and Categorical(probs).sample() (main.py:208-210)
             const float m = fmaxf(fmaxf(l0, l1), fmaxf(l2, l3));
             const float e0 = exp_spec(l0 - m), e1 = exp_spec(l1 - m), e2 = exp_spec(l2 - m), e3 = exp_spec(l3 - m);
