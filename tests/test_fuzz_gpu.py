@@ -10,10 +10,11 @@ pytestmark = pytest.mark.gpu
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
 
 
-@pytest.mark.parametrize('kind,seed,cases', [('single', 101, 40), ('grid', 102, 15), ('multi', 103, 40)])
+@pytest.mark.parametrize('kind,seed,cases', [('single', 101, 40), ('grid', 102, 15), ('multi', 103, 40), ('lean', 104, 40),
+                                             ('policy', 105, 20)])
 def test_random_cases(kind, seed, cases):
     import fuzz_parity
     rng = np.random.RandomState(seed)
-    fn = {'single': fuzz_parity.fuzz_single, 'grid': fuzz_parity.fuzz_grid, 'multi': fuzz_parity.fuzz_multi}[kind]
+    fn = getattr(fuzz_parity, 'fuzz_' + kind)
     for _ in range(cases):
         fn(rng)

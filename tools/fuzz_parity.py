@@ -66,6 +66,60 @@ def fuzz_single(rng):
     return desc
 
 
+def fuzz_lean(rng):
+    """The shapes the lean / 9x9 rollout kernels take: chained launches, tape lengths around the 64-step chunk, action
+    values outside 0..3, an occasional per-call step without reset in between (irregular states -> generic path)."""
+    S = int(rng.choice([9, 9, 9, 10, 11]))
+    N = int(rng.choice([1, 3, 17, 64, 65, 200]))
+    mode = ['partial_0', 'partial_1', 'partial_2', 'partial_2', 'partial_3', 'none'][rng.randint(6)]
+    seed, off = int(rng.randint(1 << 30)), int(rng.randint(1 << 40))
+    desc = f'lean S={S} N={N} mode={mode} seed={seed} off={off}'
+    o, h = OracleBackend(seed, off), HipBackend(seed, off)
+    eo, eh = np.zeros((N, 3, S, S), np.float32), np.zeros((N, 3, S, S), np.float32)
+    o.single_reset(eo, np.ones(N), 'none'); h.single_reset(eh, np.ones(N), 'none')
+    o.call = h.call = int(rng.randint(1 << 50))
+    for launch in range(int(rng.randint(1, 4))):
+        T = int(rng.choice([1, 2, 30, 63, 64, 65, 127, 128, 129, 200]))
+        dtype = np.int64 if rng.rand() < 0.7 else np.int32
+        a = rng.randint(0, 4, (T, N)).astype(dtype)
+        if rng.rand() < 0.3:
+            wild = rng.rand(T, N) < 0.2
+            a[wild] = rng.randint(-50, 50, int(wild.sum()))
+        ao, ah = a.copy(), a.copy()
+        ro, rh = o.single_rollout(eo, ao, mode), h.single_rollout(eh, ah, mode)
+        for k in ro:
+            same(ro[k], rh[k], f'{desc} launch {launch} T={T} {k}')
+        same(ao, ah, f'{desc} launch {launch} actions'); same(eo, eh, f'{desc} launch {launch} state')
+        if rng.rand() < 0.3:   # leave some envs done-but-not-reset for the next launch
+            a1 = rng.randint(0, 4, N).astype(np.int64)
+            for _ in range(int(rng.randint(1, 6))):
+                o.single_step(eo, a1.copy(), 'none'); h.single_step(eh, a1.copy(), 'none')
+            same(eo, eh, f'{desc} un-reset steps')
+    return desc
+
+
+def fuzz_policy(rng):
+    S, n = int(rng.choice([9, 9, 10, 11])), int(rng.randint(0, 4))
+    N, T = int(rng.choice([1, 5, 33, 64, 100])), int(rng.choice([1, 7, 64, 65, 130]))
+    E = 3 * (2 * n + 1) ** 2
+    seed, off = int(rng.randint(1 << 30)), int(rng.randint(1 << 40))
+    params = (rng.randn(_o.policy_param_count(E)) * float(rng.choice([0.05, 0.3, 1.0, 3.0]))).astype(np.float32)
+    desc = f'policy S={S} n={n} N={N} T={T} seed={seed} off={off}'
+    o, h = OracleBackend(seed, off), HipBackend(seed, off)
+    eo = np.zeros((N, 3, S, S), np.float32)
+    obs0 = o.single_reset(eo, np.ones(N), f'partial_{n}')
+    eh = eo.copy()
+    o.call = h.call = int(rng.randint(1 << 50))
+    for launch in range(2):
+        ro, rh = o.single_policy_rollout(eo, obs0, params, T, n), h.single_policy_rollout(eh, obs0, params, T, n)
+        assert (rh['status'] == 0).all(), desc + ' status'
+        for k in ro:
+            same(ro[k], rh[k], f'{desc} launch {launch} {k}')
+        same(eo, eh, f'{desc} launch {launch} state')
+        obs0 = ro['obs'][-1]
+    return desc
+
+
 def fuzz_grid(rng):
     S = int(rng.choice([5, 7, 9, 12, 20, 33, 64]))
     N, T = int(rng.randint(1, 40)), int(rng.randint(5, 80))
@@ -135,11 +189,12 @@ if __name__ == '__main__':
     ap.add_argument('--seed', type=int, default=0)
     args = ap.parse_args()
     rng = np.random.RandomState(args.seed)
-    t0, n, fails = time.time(), {'single': 0, 'grid': 0, 'multi': 0}, 0
+    t0, n, fails = time.time(), {'single': 0, 'lean': 0, 'policy': 0, 'grid': 0, 'multi': 0}, 0
     while time.time() - t0 < args.seconds:
-        kind = ['single', 'grid', 'multi'][rng.choice(3, p=[0.4, 0.1, 0.5])]
+        kind = ['single', 'lean', 'policy', 'grid', 'multi'][rng.choice(5, p=[0.25, 0.2, 0.1, 0.05, 0.4])]
         try:
-            {'single': fuzz_single, 'grid': fuzz_grid, 'multi': fuzz_multi}[kind](rng)
+            {'single': fuzz_single, 'lean': fuzz_lean, 'policy': fuzz_policy, 'grid': fuzz_grid,
+             'multi': fuzz_multi}[kind](rng)
             n[kind] += 1
         except AssertionError as e:
             fails += 1
