@@ -384,15 +384,25 @@ __device__ __forceinline__ void observe_full(const Ctx &cx, const MultiArgs &p, 
         for (int s = 0; s < K; ++s) bm |= (u64)(BV(cx, s, c) > 0) << s;
         int ho = (int)cx.occ[c] - 1;
         bool fd = cx.food[c] != 0;
+        // What an agent sees that has neither its head nor its body on this cell: border (0,0,0), somebody's head
+        // (0,0,192), somebody's body (0,0,96), food (255,0,0), background (255,255,255).  Most (cell row, agent) pairs
+        // are of this kind, so the per-agent priority chain below runs only for rows where a lane holds that agent.
+        const bool snake_here = !edge && (ho >= 0 || bm != 0);
+        const float ro = (edge || snake_here) ? 0.0f : 1.0f;
+        const float go = (edge || snake_here || fd) ? 0.0f : 1.0f;
+        const float bo = edge ? 0.0f : (ho >= 0 ? G1 : (bm != 0 ? G2 : (fd ? 0.0f : 1.0f)));
+        const bool row_has_snake = ballot(snake_here) != 0;
         for (int a = 0; a < K; ++a) {
-            float r, g, b;
-            if (edge) { r = g = b = 0.0f; }
-            else if (ho >= 0 && ho != a) { r = 0.0f; g = 0.0f; b = G1; }            // other head (0,0,192)
-            else if (bm & ~(1ull << a)) { r = 0.0f; g = 0.0f; b = G2; }             // other body (0,0,96)
-            else if (ho == a) { r = 0.0f; g = G1; b = 0.0f; }                       // own head (0,192,0)
-            else if ((bm >> a) & 1) { r = 0.0f; g = G2; b = 0.0f; }                 // own body (0,96,0)
-            else if (fd) { r = 1.0f; g = 0.0f; b = 0.0f; }                          // food (255,0,0)
-            else { r = g = b = 1.0f; }
+            float r = ro, g = go, b = bo;
+            if (row_has_snake) {
+                const bool mine = snake_here && (ho == a || ((bm >> a) & 1));
+                if (ballot(mine) != 0 && mine) {
+                    if (ho >= 0 && ho != a) { r = 0.0f; g = 0.0f; b = G1; }             // other head (0,0,192)
+                    else if (bm & ~(1ull << a)) { r = 0.0f; g = 0.0f; b = G2; }         // other body (0,0,96)
+                    else if (ho == a) { r = 0.0f; g = G1; b = 0.0f; }                   // own head (0,192,0)
+                    else { r = 0.0f; g = G2; b = 0.0f; }                                // own body (0,96,0)
+                }
+            }
             float *o = obs + ((long long)a * p.N + env) * p.obs_elems;
             o[c] = r;
             o[C + c] = g;
