@@ -153,6 +153,31 @@ def test_status_flags_envs_outside_the_domain(hip):
 
 
 @pytest.mark.gpu
+def test_food_on_the_ring_takes_the_generic_loop(hip):
+    """Well-formed snakes whose food lies on the border ring are inside the kernel's domain but outside the 9x9 fast
+    loop's: same results either way."""
+    N, S, n, T = 10, 9, 2, 60
+    params = _params(75, seed=8)
+    o, h = OracleBackend(seed=2), hip(seed=2)
+    envs, _ = _start(o, N, S, 'partial_2')
+    h._next()
+    for i in (1, 4, 7):
+        envs[i, 0] = 0
+        envs[i, 0, 0, 3 + i % 3] = 1
+    obs0 = _o_observe(envs, 'partial_2')
+    eo, eh = envs.copy(), envs.copy()
+    ro, rh = o.single_policy_rollout(eo, obs0, params, T, n), h.single_policy_rollout(eh, obs0, params, T, n)
+    assert (rh['status'] == 0).all()
+    for k in ro:
+        _same(ro[k], rh[k], k)
+    _same(eo, eh, 'final state')
+
+
+def _o_observe(envs, mode):
+    return O.single_observe(envs, mode)
+
+
+@pytest.mark.gpu
 def test_python_api(hip):
     from wurm_amd.agents import FeedforwardAgent, pack_policy_params
     from wurm_amd.envs import SingleSnake
