@@ -453,7 +453,7 @@ static int launch_policy_rollout(const PolicyArgs &p, int obs_n, void *stream)
     dim3 grid((unsigned)p.N), block(64);
     hipStream_t st = (hipStream_t)stream;
     (void)hipGetLastError();
-    const bool s9 = p.S == 9 && !getenv("WURM_POLICY_GENERIC");
+    const bool s9 = p.S == 9 && !getenv("WURM_POLICY_GENERIC"); // (debug switch: time / test the generic loop on 9x9 grids)
     switch (obs_n) {
     case 0:
         if (s9) hipLaunchKernelGGL(policy_rollout_s9_kernel<0>, grid, block, lds, st, p);
