@@ -86,12 +86,28 @@ def lib():
         # library binds to the HIP runtime that owns torch's device memory and streams, whatever the load order.
         import torch  # noqa: F401
         l = ctypes.CDLL(LIB_PATH)
-        l.wurm_version.restype = ctypes.c_char_p
-        l.wurm_single_obs_elems.restype = ctypes.c_int64
-        l.wurm_grid_obs_elems.restype = ctypes.c_int64
-        l.wurm_multi_obs_elems.restype = ctypes.c_int64
+        _declare_prototypes(l)
         _lib = l
     return _lib
+
+
+_CTYPES = {'int': ctypes.c_int, 'int64_t': ctypes.c_int64, 'uint64_t': ctypes.c_uint64, 'float': ctypes.c_float}
+
+
+def _declare_prototypes(l):
+    """argtypes / restype of every entry point, read from include/wurm_hip.h itself (pointers of any kind ->
+    c_void_p).  With them ctypes converts plain Python ints / None per call instead of wrapper objects built in Python
+    (~4 us per call on the per-step path), and a call with the wrong number of arguments fails loudly."""
+    import re
+    header = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'include', 'wurm_hip.h')
+    text = re.sub(r'/\*.*?\*/', ' ', open(header).read(), flags=re.S)
+    for ret, name, params in re.findall(r'\b(const char \*|int64_t|int)\s*(wurm_[a-z_0-9]+)\s*\(([^)]*)\)\s*;', text):
+        fn = getattr(l, name)
+        fn.restype = {'const char *': ctypes.c_char_p, 'int64_t': ctypes.c_int64, 'int': ctypes.c_int}[ret]
+        args = [a.strip() for a in params.split(',')]
+        if args == ['void']:
+            args = []
+        fn.argtypes = [ctypes.c_void_p if '*' in a else _CTYPES[a.replace('const ', '').split()[0]] for a in args]
 
 
 def check(rc: int, what: str):
@@ -135,28 +151,47 @@ def require_device(device):
 
 
 def ptr(t):
-    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    """device address of a tensor (or NULL) as ctypes converts it for a pointer parameter"""
+    return t.data_ptr() if t is not None else None
+
+
+_get_raw_stream = None
+_get_device = None
+
+
+def _torch_accessors():
+    global _get_raw_stream, _get_device
+    import torch
+    _get_raw_stream, _get_device = torch._C._cuda_getCurrentRawStream, torch._C._cuda_getDevice
 
 
 def stream_ptr(device_index=None):
     """torch's current HIP stream on `device_index` as a raw hipStream_t.  Uses the C accessor directly:
     torch.cuda.current_stream() costs ~8 us per call (device resolution, availability checks)."""
-    import torch
+    if _get_raw_stream is None:
+        _torch_accessors()
     if device_index is None:
-        device_index = torch.cuda.current_device()
-    return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(device_index))
+        device_index = _get_device()
+    return _get_raw_stream(device_index)
 
 
 def call(device_index, fn, *args):
     """Calls a C-ABI entry point with `device_index` as the current HIP device (kernels launch on the current device;
     the stream handed over belongs to `device_index`).  The check is one cheap C call; the guard is only entered when
     a process that drives several GPUs has another device current."""
-    import torch
-    if torch._C._cuda_getDevice() != device_index:
+    if _get_device is None:
+        _torch_accessors()
+    if _get_device() != device_index:
+        import torch
         with torch.cuda.device(device_index):
             return fn(*args)
     return fn(*args)
 
 
-u64 = ctypes.c_uint64
-i64 = ctypes.c_int64
+def u64(x):
+    """a Python int as the unsigned 64-bit argument it stands for (prototypes are declared: ctypes converts)"""
+    return int(x) & 0xFFFFFFFFFFFFFFFF
+
+
+def i64(x):
+    return int(x)
