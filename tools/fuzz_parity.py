@@ -37,6 +37,8 @@ def fuzz_single(rng):
     mode = modes[rng.randint(len(modes))]
     seed, off = int(rng.randint(1 << 30)), int(rng.randint(1 << 20))
     desc = f'single S={S} N={N} T={T} mode={mode} seed={seed} off={off}'
+    if os.environ.get('WURM_FUZZ_VERBOSE'):
+        print('start:', desc, flush=True)
     o, h = OracleBackend(seed, off), HipBackend(seed, off)
     eo, eh = np.zeros((N, 3, S, S), np.float32), np.zeros((N, 3, S, S), np.float32)
     o.single_reset(eo, np.ones(N), 'none'); h.single_reset(eh, np.ones(N), 'none')
@@ -74,6 +76,8 @@ def fuzz_lean(rng):
     mode = ['partial_0', 'partial_1', 'partial_2', 'partial_2', 'partial_3', 'none'][rng.randint(6)]
     seed, off = int(rng.randint(1 << 30)), int(rng.randint(1 << 40))
     desc = f'lean S={S} N={N} mode={mode} seed={seed} off={off}'
+    if os.environ.get('WURM_FUZZ_VERBOSE'):
+        print('start:', desc, flush=True)
     o, h = OracleBackend(seed, off), HipBackend(seed, off)
     eo, eh = np.zeros((N, 3, S, S), np.float32), np.zeros((N, 3, S, S), np.float32)
     o.single_reset(eo, np.ones(N), 'none'); h.single_reset(eh, np.ones(N), 'none')
@@ -105,6 +109,8 @@ def fuzz_policy(rng):
     seed, off = int(rng.randint(1 << 30)), int(rng.randint(1 << 40))
     params = (rng.randn(_o.policy_param_count(E)) * float(rng.choice([0.05, 0.3, 1.0, 3.0]))).astype(np.float32)
     desc = f'policy S={S} n={n} N={N} T={T} seed={seed} off={off}'
+    if os.environ.get('WURM_FUZZ_VERBOSE'):
+        print('start:', desc, flush=True)
     o, h = OracleBackend(seed, off), HipBackend(seed, off)
     eo = np.zeros((N, 3, S, S), np.float32)
     obs0 = o.single_reset(eo, np.ones(N), f'partial_{n}')
@@ -127,6 +133,8 @@ def fuzz_grid(rng):
     start = (int(rng.randint(1, S - 1)), int(rng.randint(1, S - 1)))
     seed = int(rng.randint(1 << 30))
     desc = f'grid S={S} N={N} T={T} mode={mode} start={start} seed={seed}'
+    if os.environ.get('WURM_FUZZ_VERBOSE'):
+        print('start:', desc, flush=True)
     o, h = OracleBackend(seed), HipBackend(seed)
     eo, eh = np.zeros((N, 2, S, S), np.float32), np.zeros((N, 2, S, S), np.float32)
     o.grid_reset(eo, np.ones(N), start, 'none'); h.grid_reset(eh, np.ones(N), start, 'none')
@@ -151,6 +159,8 @@ def fuzz_multi(rng):
                respawn_mode=['all', 'any'][rng.randint(2)], colour_mode=['random', 'fixed'][rng.randint(2)])
     seed, off = int(rng.randint(1 << 30)), int(rng.randint(1 << 20))
     desc = f'multi S={S} K={K} N={N} T={T} mode={mode} seed={seed} off={off} cfg={cfg}'
+    if os.environ.get('WURM_FUZZ_VERBOSE'):
+        print('start:', desc, flush=True)
     o, h = OracleBackend(seed, off), HipBackend(seed, off)
     so, sh = _o.multi_empty_state(N, K, S), _o.multi_empty_state(N, K, S)
     so['colours'][...] = o.multi_colours(N, K, cfg['colour_mode'] == 'fixed', call=0)

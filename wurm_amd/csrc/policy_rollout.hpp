@@ -70,7 +70,7 @@ __device__ __forceinline__ void tree_sum5(float &a, float &b, float &c, float &d
     "v_add_f32_dpp %2, %2, %2 " CTRL "\n\t"               \
     "v_add_f32_dpp %3, %3, %3 " CTRL "\n\t"               \
     "v_add_f32_dpp %4, %4, %4 " CTRL "\n\t"
-    asm("s_nop 1\n\t"
+    asm volatile("s_nop 1\n\t"
         WURM_DPP5("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
         WURM_DPP5("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
         WURM_DPP5("row_half_mirror row_mask:0xf bank_mask:0xf")
