@@ -1,4 +1,4 @@
-// checks wurm_device.hpp's hand-written DPP wave reductions against a host loop
+// checks the wave reductions of wurm_device.hpp (wave_max / min / sum_i32) against a host loop
 #include "../../wurm_amd/csrc/wurm_device.hpp"
 #include <cstdio>
 #include <cstdlib>
