@@ -178,6 +178,26 @@ def _o_observe(envs, mode):
 
 
 @pytest.mark.gpu
+def test_sharding_invariance(hip):
+    """Sampling draws and env randomness are keyed by the global env id: two shards (env_offset 0 / 16) == one batch."""
+    N, S, n, T = 32, 9, 2, 80
+    params = _params(75, seed=4)
+    full = hip(seed=9)
+    envs = np.zeros((N, 3, S, S), np.float32)
+    obs0 = full.single_reset(envs, np.ones(N, np.uint8), 'partial_2')
+    start = envs.copy()
+    out = full.single_policy_rollout(envs, obs0, params, T, n)
+    for lo in (0, 16):
+        shard = hip(seed=9, env_offset=lo)
+        shard.call = 1
+        es = np.ascontiguousarray(start[lo:lo + 16])
+        rs = shard.single_policy_rollout(es, np.ascontiguousarray(obs0[lo:lo + 16]), params, T, n)
+        for k in ('actions', 'probs', 'values', 'reward', 'done', 'obs'):
+            _same(rs[k], out[k][:, lo:lo + 16], f'shard {lo} {k}')
+        _same(es, envs[lo:lo + 16], f'shard {lo} final state')
+
+
+@pytest.mark.gpu
 def test_python_api(hip):
     from wurm_amd.agents import FeedforwardAgent, pack_policy_params
     from wurm_amd.envs import SingleSnake
