@@ -1,23 +1,32 @@
 #!/usr/bin/env python3
 """bench.py — env-steps/s of the batched environment step on MI355X (BASELINE.json metric).
 
-Workload (BASELINE.json configs[1]): SingleSnake, 512 envs per GPU, 9x9, observation_mode='partial_2', uniform random
-actions, the reference's test loop `obs, r, done, info = env.step(a[t]); env.reset(done)`
-(tests/test_single_snake_env.py:24-31 in oscarknagg/wurm).
+Default workload (BASELINE.json configs[1], `--workload cfg2`): SingleSnake, 512 envs per GPU, 9x9,
+observation_mode='partial_2', uniform random actions, the reference's test loop
+`obs, r, done, info = env.step(a[t]); env.reset(done)` (tests/test_single_snake_env.py:24-31,
+experiments/speeds.py:30-44 in oscarknagg/wurm).
 
-One bench STEP = one batch-step: every env of the batch advanced by one step(), observed, and reset if done.
-K steps are executed through the fused rollout entry point (wurm_single_rollout, `--chunk` batch-steps per
-launch, bit-identical to K step()/reset() call pairs — tests/test_hip_vs_oracle.py); inputs (state, action
-tape) are resident in HBM before the timed region; observations, rewards and dones of every step are written
-to HBM inside it.  `value` = env-steps of all ranks / max-over-ranks wall time.
+One bench STEP = ONE PASS OF THE HOT PATH OVER ONE BATCH OF SYNTHETIC INPUT = one launch of the fused rollout entry
+point (wurm_single_rollout) over one (chunk, num_envs) block of the action tape, i.e. `chunk` iterations of the loop
+above for every env of the batch (bit-identical to `chunk` step()/reset() call pairs: tests/test_hip_vs_oracle.py).
+`--steps K --warmup W` therefore times exactly K launches of the stated shape after W untimed ones;
+`ms_per_step` is per launch; env-steps = K * chunk * num_envs * n_gpus.  Inputs (state, action tape) are resident in
+HBM before the timed region; observations, rewards, dones of every env-step are written to HBM inside it.
+`value` = env-steps of all ranks / max-over-ranks wall time.
 
-Multi-GPU (weak scaling): one process per GPU, each stepping its own contiguous block of env ids
-(env_offset = rank * num_envs) with no data-path collective — envs never interact; RCCL is used only for the
-barrier, the max-over-ranks time and the summed episode statistics.
+Multi-GPU: one process per GPU, each stepping its own contiguous block of global env ids (env_offset) with no
+data-path collective — envs never interact; RCCL is used only for the barrier, the max-over-ranks time and the summed
+episode statistics.  `python bench.py --gpus N` with N > 1 STARTS ITS OWN N RANKS (a fresh
+`python -m torch.distributed.run` child, launched before this process touches the GPU) and relays rank 0's JSON
+line; when the driver has already started the ranks (WORLD_SIZE / RANK in the environment) this process is one of them.
+  --workload cfg2 : 512 envs per GPU (weak scaling; the default and the headline)
+  --workload cfg3 : BASELINE configs[2] — 65 536 envs in total, split 65 536/N per rank (strong scaling)
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,12 +34,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
-
 SIZE = 9
 OBS_MODE = 'partial_2'
 OBS_ELEMS = 75
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s measured achievable
+MAX_TAPE_BLOCKS = 160  # distinct (chunk, N) action blocks kept in HBM; longer runs cycle through them
 
 
 def algorithmic_bytes_per_env_step(size: int, obs_elems: int) -> int:
@@ -38,240 +46,391 @@ def algorithmic_bytes_per_env_step(size: int, obs_elems: int) -> int:
     return 20 * size * size + 4 * obs_elems + 39
 
 
-def cpu_baseline(num_envs: int, budget_s: float = 12.0):
-    """The CPU oracle (scalar C port of the reference's algorithm, 1 thread) on the same workload, bounded."""
-    import numpy as np
-    from oracle import oracle
-    envs = np.zeros((num_envs, 3, SIZE, SIZE), np.float32)
-    oracle.single_reset(envs, np.ones(num_envs, np.uint8), 'none', seed=0, call=0)
-    rng = np.random.RandomState(0)
-    chunk, steps, call = 100, 0, 1
-    t0 = time.perf_counter()
-    while time.perf_counter() - t0 < budget_s:
-        actions = rng.randint(0, 4, size=(chunk, num_envs)).astype(np.int64)
-        oracle.single_rollout(envs, actions, OBS_MODE, seed=0, call0=call)
-        call += 2 * chunk
-        steps += chunk
-    dt = time.perf_counter() - t0
-    return {'value': num_envs * steps / dt, 'unit': 'env-steps/s', 'cores': 1, 'kind': 'port',
-            'sample': f'oracle/single_snake.c (scalar C restatement, 1 thread): SingleSnake {num_envs}x{SIZE}x{SIZE} '
-                      f'{OBS_MODE}, {steps} batch-steps of step+observe+reset in {dt:.1f} s; the reference torch-CPU '
-                      f'path itself measured 52 372 env-steps/s on 8 vCPU in the build container (BASELINE.md §2)'}
+# ------------------------------------------------------------------------------------------------ launcher
 
-
-def run_rollouts(env, actions, first, steps, chunk, events=None):
-    """`steps` batch-steps starting at row `first` of the action tape, `chunk` per launch."""
-    done_eps = None
-    for c in range(0, steps, chunk):
-        n = min(chunk, steps - c)
-        if events is not None:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-        out = env.rollout(actions[first + c:first + c + n])
-        if events is not None:
-            e1.record()
-            events.append((e0, e1, n))
-        done_eps = out
-    return done_eps
-
-
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=262144, help='timed batch-steps (K)')
-    ap.add_argument('--warmup', type=int, default=4096, help='untimed batch-steps (W)')
-    ap.add_argument('--num-envs', type=int, default=512, help='envs per GPU (BASELINE configs[1]: 512)')
-    ap.add_argument('--chunk', type=int, default=1024, help='batch-steps per rollout launch')
+    ap.add_argument('--steps', type=int, default=128, help='timed rollout launches (K)')
+    ap.add_argument('--warmup', type=int, default=8, help='untimed rollout launches (W)')
+    ap.add_argument('--workload', choices=('cfg2', 'cfg3'), default='cfg2')
+    ap.add_argument('--num-envs', type=int, default=None, help='envs per GPU (cfg2: 512) / in total (cfg3: 65536)')
+    ap.add_argument('--chunk', type=int, default=None, help='batch-steps per rollout launch (cfg2: 1024)')
     ap.add_argument('--no-extra', action='store_true', help='skip the secondary measurements')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    args = ap.parse_args()
+    ap.add_argument('--dry-run', action='store_true',
+                    help='launcher / collective plumbing only: gloo on CPU, the rollout launch replaced by a sleep')
+    ap.add_argument('--worker', action='store_true', help=argparse.SUPPRESS)
+    return ap.parse_args(argv)
 
+
+def free_port() -> int:
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def spawn_ranks(args) -> int:
+    """Starts `--gpus` fresh rank processes (this process has not touched the GPU and never will), relays rank 0's
+    JSON line.  A failed child means a non-zero exit code."""
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+           '--master-addr', '127.0.0.1', '--master-port', str(free_port()), os.path.abspath(__file__), '--worker']
+    cmd += [a for a in sys.argv[1:] if a != '--worker']
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', '1')
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    for ln in r.stdout.splitlines():
+        if not ln.startswith('{'):
+            print(ln, file=sys.stderr)
+    if r.returncode != 0 or not lines:
+        print(f'bench.py: rank processes failed (exit code {r.returncode})', file=sys.stderr)
+        return r.returncode or 1
+    print(lines[-1])
+    return 0
+
+
+# ------------------------------------------------------------------------------------------------ CPU baselines
+
+def cpu_baseline(num_envs: int, budget_s: float = 7.0):
+    """The reference's algorithm on the host cores of this box, on a bounded sample of the cfg2 workload
+    (step + observe + reset per batch-step, random actions).  Three legs (SURVEY.md §8(d) i-iii):
+      value           torch-op restatement of the convolution-and-mask algorithm (oracle/torch_port.py), all cores
+      c_port_1thread  scalar C restatement (oracle/single_snake.c), one thread
+      c_port_allcores the same, env batch split over one thread per core
+    The reference itself cannot travel to the GPU box; its own number measured in the build container is quoted."""
+    import numpy as np
+    import torch
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import oracle
+    from oracle.torch_port import TorchSingleSnake
+    cores = os.cpu_count() or 1
+    out = {}
+
+    # (ii) torch-op restatement, all cores
+    torch.set_num_threads(cores)
+    env = TorchSingleSnake(num_envs, SIZE, OBS_MODE, seed=0)
+    g = torch.Generator().manual_seed(0)
+    for _ in range(5):
+        _, _, d, _ = env.step(torch.randint(4, (num_envs,), generator=g))
+        env.reset(d)
+    steps, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < budget_s:
+        acts = torch.randint(4, (50, num_envs), generator=g)
+        for t in range(50):
+            _, _, d, _ = env.step(acts[t])
+            env.reset(d)
+        steps += 50
+    dt = time.perf_counter() - t0
+    torch_rate = num_envs * steps / dt
+    torch_sample = f'{steps} batch-steps in {dt:.1f} s, torch {torch.__version__}, {torch.get_num_threads()} threads'
+
+    # (iii) scalar C restatement: 1 thread, then one thread per core (ctypes releases the GIL during the call)
+    def c_port(n_threads):
+        bounds = [num_envs * i // n_threads for i in range(n_threads + 1)]
+        shards = []
+        for lo, hi in zip(bounds, bounds[1:]):
+            e = np.zeros((hi - lo, 3, SIZE, SIZE), np.float32)
+            if hi > lo:
+                oracle.single_reset(e, np.ones(hi - lo, np.uint8), 'none', seed=0, call=0, env_offset=lo)
+            shards.append((lo, hi, e))
+        rng = np.random.RandomState(0)
+        chunk, steps, call = 200, 0, 1
+        pool = ThreadPoolExecutor(n_threads) if n_threads > 1 else None
+
+        def run(shard, actions, call0):
+            lo, hi, e = shard
+            if hi > lo:
+                oracle.single_rollout(e, np.ascontiguousarray(actions[:, lo:hi]), OBS_MODE, seed=0, call0=call0,
+                                      env_offset=lo)
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < budget_s:
+            actions = rng.randint(0, 4, size=(chunk, num_envs)).astype(np.int64)
+            if pool:
+                list(pool.map(lambda s: run(s, actions, call), shards))
+            else:
+                run(shards[0], actions, call)
+            call += 2 * chunk
+            steps += chunk
+        dt = time.perf_counter() - t0
+        if pool:
+            pool.shutdown()
+        return num_envs * steps / dt, steps, dt
+
+    r1, s1, d1 = c_port(1)
+    n_thr = max(1, min(cores, num_envs))
+    rn, sn, dn = c_port(n_thr)
+    cpu_model = 'unknown'
+    try:
+        for ln in open('/proc/cpuinfo'):
+            if ln.startswith('model name'):
+                cpu_model = ln.split(':', 1)[1].strip()
+                break
+    except OSError:
+        pass
+    out.update({
+        'value': torch_rate, 'unit': 'env-steps/s', 'cores': cores, 'kind': 'port',
+        'sample': f'oracle/torch_port.py (torch-op restatement of the reference\'s conv-and-mask algorithm, bit-equal '
+                  f'to the oracle: tests/test_torch_port.py): SingleSnake {num_envs}x{SIZE}x{SIZE} {OBS_MODE}, '
+                  f'step+observe+reset per batch-step, {torch_sample}',
+        'cpu_model': cpu_model,
+        'c_port_1thread': {'value': r1, 'cores': 1, 'sample': f'oracle/single_snake.c, {s1} batch-steps in {d1:.1f} s'},
+        'c_port_allcores': {'value': rn, 'cores': n_thr,
+                            'sample': f'oracle/single_snake.c, env batch split over {n_thr} threads, {sn} batch-steps '
+                                      f'in {dn:.1f} s'},
+        'reference_measured_elsewhere': {'value': 52372, 'cores': 8,
+                                         'sample': 'the real reference (torch-CPU, 8 vCPU Xeon 2.1 GHz, build '
+                                                   'container), BASELINE.md §2 — cannot travel to the GPU box'},
+    })
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ worker
+
+def worker(args) -> int:
+    import torch
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     distributed = world > 1
+    dist = None
     if distributed:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
-    n_gpus = world if distributed else 1
+        if args.dry_run:
+            dist.init_process_group('gloo')
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    n_gpus = world
     if args.gpus != n_gpus and rank == 0:
-        print(f'# note: --gpus {args.gpus} but WORLD_SIZE={world}; using {n_gpus}', file=sys.stderr)
-    device = torch.device('cuda', local_rank)
+        print(f'# note: --gpus {args.gpus} but WORLD_SIZE={world}; running {n_gpus} rank(s)', file=sys.stderr)
+    device = torch.device('cpu') if args.dry_run else torch.device('cuda', local_rank)
 
-    from wurm_amd.envs import SingleSnake
-    N, K, W = args.num_envs, args.steps, args.warmup
-    env = SingleSnake(num_envs=N, size=SIZE, observation_mode=OBS_MODE, device=device, seed=0, env_offset=rank * N)
-    gen = torch.Generator(device=device).manual_seed(1000 + rank)
-    actions = torch.randint(4, (W + K, N), generator=gen, device=device, dtype=torch.int64)
+    from wurm_amd.sharding import shard_range
+    K, W = max(args.steps, 1), max(args.warmup, 0)
+    if args.workload == 'cfg2':
+        N = args.num_envs or 512
+        offset, global_envs, scaling = rank * N, N * n_gpus, 'weak'
+        chunk = args.chunk or 1024
+    else:
+        global_envs = args.num_envs or 65536
+        offset, N = shard_range(global_envs, rank, n_gpus)
+        scaling = 'strong'
+        chunk = args.chunk or (64 if N > 16384 else 128)
+
+    blocks = min(W + K, MAX_TAPE_BLOCKS)
+    if args.dry_run:
+        env, tape = None, None
+    else:
+        from wurm_amd.envs import SingleSnake
+        env = SingleSnake(num_envs=N, size=SIZE, observation_mode=OBS_MODE, device=device, seed=0, env_offset=offset)
+        gen = torch.Generator(device=device).manual_seed(1000 + rank)
+        tape = torch.randint(4, (blocks, chunk, N), generator=gen, device=device, dtype=torch.int64)
+
+    def launch(i):
+        if args.dry_run:
+            time.sleep(0.001)
+            return None
+        return env.rollout(tape[i % blocks])
 
     def barrier():
         if distributed:
             dist.barrier()
 
-    run_rollouts(env, actions, 0, W, args.chunk)
-    # one more untimed launch with the shape of the timed launches (a small --steps / --warmup would otherwise time the
-    # allocator's first encounter with these output sizes); it is not counted in W
-    prime = torch.randint(4, (min(args.chunk, max(K, 1)), N), generator=gen, device=device, dtype=torch.int64)
-    env.rollout(prime)
-    del prime
-    torch.cuda.synchronize()
+    def sync():
+        if not args.dry_run:
+            torch.cuda.synchronize()
+
+    for i in range(W):
+        launch(i)
+    sync()
     barrier()
-    torch.cuda.synchronize()
+    sync()
     events = []
     t0 = time.perf_counter()
-    run_rollouts(env, actions, W, K, args.chunk, events)
-    torch.cuda.synchronize()
+    for i in range(W, W + K):
+        if args.dry_run:
+            launch(i)
+            continue
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        launch(i)
+        e1.record()
+        events.append((e0, e1))
+    sync()
     barrier()
-    torch.cuda.synchronize()
+    sync()
     elapsed = time.perf_counter() - t0
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    t = torch.tensor([elapsed, float(N * chunk * K)], dtype=torch.float64, device=device)
     if distributed:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
-    total_env_steps = N * K * n_gpus
+        dist.all_reduce(t[:1], op=dist.ReduceOp.MAX)
+        dist.all_reduce(t[1:], op=dist.ReduceOp.SUM)
+    elapsed, total_env_steps = float(t[0].item()), float(t[1].item())
 
-    # dominant kernel: rollout_s9_kernel<4>; per-launch duration from HIP events on the launch stream
-    full = [(e0.elapsed_time(e1) * 1e-3, n) for e0, e1, n in events if n == args.chunk] or \
-           [(e0.elapsed_time(e1) * 1e-3, n) for e0, e1, n in events]
-    avg_launch_s = sum(d for d, _ in full) / len(full)
-    bytes_per_launch = algorithmic_bytes_per_env_step(SIZE, OBS_ELEMS) * N * full[0][1]
-    achieved = bytes_per_launch / avg_launch_s / 1e9
-
+    rc = 0
     if rank == 0:
-        traffic = None
+        per = algorithmic_bytes_per_env_step(SIZE, OBS_ELEMS)
+        if events:
+            avg_launch_s = sum(e0.elapsed_time(e1) for e0, e1 in events) * 1e-3 / len(events)
+        else:
+            avg_launch_s = elapsed / K
+        bytes_per_launch = per * N * chunk
+        achieved = bytes_per_launch / avg_launch_s / 1e9
+        traffic, frac_real = None, None
         tpath = os.path.join(ROOT, 'profiles', 'hbm_traffic.json')
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get(f'rollout_{N}x{SIZE}_chunk{args.chunk}')
+        if os.path.exists(tpath) and not args.dry_run:
+            try:  # counter bytes of exactly this launch shape (N, S, chunk), else null
+                traffic = json.load(open(tpath)).get(f'rollout_{N}x{SIZE}_chunk{chunk}')
             except Exception:
                 traffic = None
+        if traffic:
+            frac_real = traffic / avg_launch_s / 1e9 / HBM_PEAK_GBS
+        kernel = 'wurm::rollout_s9_kernel<4> (9x9 SingleSnake, partial_n crop, RNG mode; one wave per env)'
         line = {
             'metric': 'env_steps_per_s', 'value': total_env_steps / elapsed, 'unit': 'env-steps/s',
             'n_gpus': n_gpus, 'steps': K, 'warmup': W, 'ms_per_step': elapsed / K * 1e3,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'i32',
+            'higher_is_better': True, 'scaling': scaling, 'vs_baseline': None, 'dtype': 'i32',
             'data': 'synthetic',
-            'config': {'workload': f'SingleSnake num_envs={N}/GPU size={SIZE} obs={OBS_MODE} random actions, '
-                                   f'step+observe+reset per batch-step, fused rollout launches of {args.chunk} '
-                                   f'batch-steps', 'num_envs_per_gpu': N, 'global_num_envs': N * n_gpus,
-                       'size': SIZE, 'observation_mode': OBS_MODE, 'parallelism': f'env-batch split x{n_gpus}',
-                       'state_dtype': 'fp32 NCHW (exact integers)', 'chunk': args.chunk},
+            'config': {'workload': f'SingleSnake {N} envs/GPU ({int(global_envs)} in total) size={SIZE} obs={OBS_MODE} '
+                                   f'random actions; one bench step = one fused rollout launch of {chunk} batch-steps '
+                                   f'(step+observe+reset per batch-step) = {N * chunk} env-steps per GPU; {K} such '
+                                   f'launches timed after {W} untimed',
+                       'baseline_config': 'BASELINE.json configs[1]' if args.workload == 'cfg2'
+                                          else 'BASELINE.json configs[2]',
+                       'num_envs_per_gpu': N, 'global_num_envs': int(global_envs), 'size': SIZE,
+                       'observation_mode': OBS_MODE, 'batch_steps_per_launch': chunk,
+                       'env_steps_per_launch_per_gpu': N * chunk,
+                       'parallelism': f'env-batch split x{n_gpus} (no data-path collective)',
+                       'world_size': world, 'backend': (dist.get_backend() if distributed else None),
+                       'state_dtype': 'fp32 NCHW (exact integers)',
+                       'action_tape_blocks': blocks},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
-                         'kernel': 'wurm::rollout_s9_kernel<4> (9x9 SingleSnake, partial_n crop, RNG mode; one wave per env)', 'avg_launch_ms': avg_launch_s * 1e3,
-                         'algorithmic_bytes_per_env_step': algorithmic_bytes_per_env_step(SIZE, OBS_ELEMS),
-                         'env_steps_per_launch': N * full[0][1],
-                         'note': 'this config is issue-bound, not HBM-bound: 512 envs = 512 lone waves on 1024 SIMDs, '
-                                 '~60 instructions per env-step at 5-6 cycles each (DESIGN.md §4.4); `traffic` is '
-                                 'below the algorithmic bytes because the env state never leaves the registers'},
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'frac_real': frac_real,
+                         'kernel': kernel, 'avg_launch_ms': avg_launch_s * 1e3,
+                         'algorithmic_bytes_per_env_step': per, 'env_steps_per_launch': N * chunk,
+                         'limiter': 'instruction issue' if N <= 1024 else 'instruction issue / observation stores',
+                         'note': '`achieved` prices the launch at the SURVEY §8(d) bytes of an UNFUSED step/reset pair; '
+                                 '`traffic` (rocprofv3 FETCH_SIZE + WRITE_SIZE per launch of this exact shape, '
+                                 'profiles/hbm_traffic.json) and `frac_real` are what the fused kernel really moves — '
+                                 'far less, because the env state never leaves the registers between steps. 512 envs '
+                                 'are 512 lone waves on 1024 SIMDs: the kernel is bound by one wave\'s instruction '
+                                 'issue rate, not by HBM (DESIGN.md §4.4)'},
         }
-        if n_gpus == 1 and not args.no_extra:
+        if args.dry_run:
+            line['dry_run'] = True
+        if n_gpus == 1 and not args.no_extra and not args.dry_run:
             line['extra'] = extra_measurements(device)
         if n_gpus == 1 and not args.no_cpu_baseline:
-            line['cpu_baseline'] = cpu_baseline(N)
+            try:
+                line['cpu_baseline'] = cpu_baseline(512 if args.workload == 'cfg2' else 512,
+                                                    budget_s=0.5 if args.dry_run else 7.0)
+            except Exception as e:  # the baseline is a reported extra: never lose the bench line over it
+                line['cpu_baseline'] = {'error': repr(e)}
         print(json.dumps(line))
+        sys.stdout.flush()
     if distributed:
+        dist.barrier()
         dist.destroy_process_group()
+    return rc
+
+
+def _timed(fn, reps):
+    import torch
+    fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps
 
 
 def extra_measurements(device):
-    """Secondary numbers (not the headline): the per-call Python API on the same workload and one GPU's share of
-    BASELINE configs[2] (8192 envs)."""
-    from wurm_amd.envs import SingleSnake
+    """Secondary numbers (not the headline): the per-call Python API on the same workload, the other BASELINE configs
+    through the fused rollout, the fused acting loop.  GB/s figures are REAL streams (the observation bytes the launch
+    writes), never the unfused byte model."""
+    import torch
+    from wurm_amd.envs import SingleSnake, MultiSnake
     out = {}
-    # (a) step()/reset() call pairs from Python — what a policy-in-the-loop caller pays
-    N, T = 512, 2000
+    # (a) step()/reset() call pairs from Python — the drop-in loop of experiments/main.py:212-227
+    N, T = 512, 4000
     env = SingleSnake(num_envs=N, size=SIZE, observation_mode=OBS_MODE, device=device, seed=0)
-    actions = torch.randint(4, (T + 200, N), device=device, dtype=torch.int64)
-    for t in range(200):
-        _, _, d, _ = env.step(actions[t])
-        env.reset(d, return_observations=False)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for t in range(200, 200 + T):
-        _, _, d, _ = env.step(actions[t])
-        env.reset(d, return_observations=False)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    out['per_call_api_512'] = {'value': N * T / dt, 'unit': 'env-steps/s', 'us_per_batch_step': dt / T * 1e6,
-                               'what': 'Python loop of env.step(a); env.reset(done) (2 launches per batch-step)'}
-    # (b) one GPU's share of configs[2]: 8192 envs
-    N, T, chunk = 8192, 2048, 128
-    env = SingleSnake(num_envs=N, size=SIZE, observation_mode=OBS_MODE, device=device, seed=0)
-    actions = torch.randint(4, (chunk + T, N), device=device, dtype=torch.int64)
-    env.rollout(actions[:chunk])
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for c in range(chunk, chunk + T, chunk):
-        env.rollout(actions[c:c + chunk])
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    gbs = algorithmic_bytes_per_env_step(SIZE, OBS_ELEMS) * N * T / dt / 1e9
-    out['rollout_8192'] = {'value': N * T / dt, 'unit': 'env-steps/s', 'achieved_GBs': gbs,
-                           'frac_of_hbm_peak': gbs / HBM_PEAK_GBS,
-                           'what': 'BASELINE configs[2] per-GPU share (65536/8), fused rollout, chunk 128'}
+    actions = torch.randint(4, (T + 400, N), device=device, dtype=torch.int64)
+    for variant, kw in (('per_call_api_512', {'return_observations': False}), ('per_call_api_512_reset_obs', {})):
+        for t in range(400):
+            _, _, d, _ = env.step(actions[t])
+            env.reset(d, **kw)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for t in range(400, 400 + T):
+            _, _, d, _ = env.step(actions[t])
+            env.reset(d, **kw)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out[variant] = {'value': N * T / dt, 'unit': 'env-steps/s', 'us_per_batch_step': dt / T * 1e6,
+                        'what': 'Python loop of `obs, r, d, info = env.step(a); env.reset(d%s)`'
+                                % (', return_observations=False' if kw else '')}
     del env, actions
-    # (c) BASELINE configs[4] shape: SingleSnake 8192 x 36 x 36, default RGB observation, fused rollout
-    N, S, chunk, reps = 8192, 36, 16, 6
-    env = SingleSnake(num_envs=N, size=S, observation_mode='default', device=device, seed=0)
-    actions = torch.randint(4, (chunk * (reps + 1), N), device=device, dtype=torch.int64)
-    env.rollout(actions[:chunk])
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for r in range(1, reps + 1):
-        env.rollout(actions[r * chunk:(r + 1) * chunk])
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    eps = N * chunk * reps / dt
-    per = algorithmic_bytes_per_env_step(S, 3 * S * S)
-    out['rollout_cfg5_8192x36_default'] = {
-        'value': eps, 'unit': 'env-steps/s', 'achieved_GBs': per * eps / 1e9, 'obs_write_GBs': 12 * S * S * eps / 1e9,
-        'frac_of_hbm_peak': per * eps / 1e9 / HBM_PEAK_GBS,
-        'what': 'BASELINE configs[4]: SingleSnake 8192x36x36 default-RGB obs, fused rollout, chunk 16 '
-                '(algorithmic 41 511 B per env-step; the fused path only writes the 15 552 B observation)'}
-    del env, actions
-    # (d) BASELINE configs[3]: MultiSnake 4096 x 25 x 25, 4 agents, constructor defaults ('full' obs), fused rollout
-    from wurm_amd.envs import MultiSnake
-    N, K, S, chunk, reps = 4096, 4, 25, 16, 6
-    env = MultiSnake(N, K, S, device=device, seed=0)
-    actions = torch.randint(8, (chunk * (reps + 1), K, N), device=device, dtype=torch.int64)
-    env.rollout(actions[:chunk])
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for r in range(1, reps + 1):
-        env.rollout(actions[r * chunk:(r + 1) * chunk])
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    eps = N * chunk * reps / dt
-    per = 8 * (1 + 2 * K) * S * S + 12 * K * S * S + 40 * K
-    out['multi_rollout_cfg4_4096x25_k4_full'] = {
-        'value': eps, 'unit': 'env-steps/s', 'achieved_GBs': per * eps / 1e9, 'obs_write_GBs': 12 * K * S * S * eps / 1e9,
-        'frac_of_hbm_peak': per * eps / 1e9 / HBM_PEAK_GBS,
-        'what': 'BASELINE configs[3]: MultiSnake 4096x25x25, 4 agents, defaults, step+observe+reset(__all__) per '
-                'batch-step, fused rollout chunk 16 (algorithmic 75 160 B per env-step; reference torch-CPU: 3 280 '
-                'env-steps/s)'}
-    del env, actions
+
+    def rollout_case(key, make_env, shape_actions, A, chunk, reps, obs_bytes, what):
+        env = make_env()
+        acts = torch.randint(A, (reps + 1,) + shape_actions(chunk), device=device, dtype=torch.int64)
+        it = iter(range(reps + 1))
+        dt = _timed(lambda: env.rollout(acts[next(it)]), reps)
+        n_env = env.num_envs
+        eps = n_env * chunk / dt
+        out[key] = {'value': eps, 'unit': 'env-steps/s', 'ms_per_launch': dt * 1e3, 'batch_steps_per_launch': chunk,
+                    'obs_write_GBs': obs_bytes * eps / 1e9, 'obs_write_frac_of_hbm_peak': obs_bytes * eps / 1e9 / HBM_PEAK_GBS,
+                    'what': what}
+
+    # (b) one GPU's share of configs[2] (8192 envs) and all of configs[2] on one GPU
+    rollout_case('rollout_8192', lambda: SingleSnake(8192, SIZE, observation_mode=OBS_MODE, device=device, seed=0),
+                 lambda c: (c, 8192), 4, 128, 16, 4 * OBS_ELEMS + 7 + 16,
+                 'BASELINE configs[2] per-GPU share (65536/8), fused rollout, 128 batch-steps per launch')
+    rollout_case('rollout_cfg3_65536', lambda: SingleSnake(65536, SIZE, observation_mode=OBS_MODE, device=device, seed=0),
+                 lambda c: (c, 65536), 4, 64, 8, 4 * OBS_ELEMS + 7 + 16,
+                 'BASELINE configs[2] whole (65536 envs) on ONE GPU, fused rollout, 64 batch-steps per launch')
+    # (c) BASELINE configs[4]: SingleSnake 8192 x 36 x 36, default RGB observation
+    rollout_case('rollout_cfg5_8192x36_default',
+                 lambda: SingleSnake(8192, 36, observation_mode='default', device=device, seed=0),
+                 lambda c: (c, 8192), 4, 16, 6, 12 * 36 * 36,
+                 'BASELINE configs[4]: SingleSnake 8192x36x36 default-RGB obs, fused rollout, 16 batch-steps per launch '
+                 '(the launch writes the 15 552 B observation per env-step; SURVEY byte model of an unfused pair: 41 511 B)')
+    # (d) BASELINE configs[3]: MultiSnake 4096 x 25 x 25, 4 agents, constructor defaults ('full' obs)
+    rollout_case('multi_rollout_cfg4_4096x25_k4_full', lambda: MultiSnake(4096, 4, 25, device=device, seed=0),
+                 lambda c: (c, 4, 4096), 8, 16, 6, 12 * 4 * 25 * 25,
+                 'BASELINE configs[3]: MultiSnake 4096x25x25, 4 agents, defaults, step+observe+reset(__all__) per '
+                 'batch-step, fused rollout, 16 batch-steps per launch (30 000 B of observations per env-step; SURVEY byte '
+                 'model of an unfused pair: 75 160 B; reference torch-CPU: 3 280 env-steps/s)')
     # (e) the acting loop with the policy inside the env kernel (SURVEY 8f row 2): MLP 75->64->64->{4,1} + sampling
     from wurm_amd.agents import FeedforwardAgent, pack_policy_params
     N, T, reps = 512, 256, 8
     torch.manual_seed(0)
     env = SingleSnake(num_envs=N, size=SIZE, observation_mode=OBS_MODE, device=device, seed=0)
     params = pack_policy_params(FeedforwardAgent(4, 2, 64, OBS_ELEMS).to(device))
-    state = env.reset()
-    state = env.policy_rollout(params, state, T, check=False)['state']
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        state = env.policy_rollout(params, state, T, check=False)['state']
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    state = [env.reset()]
+
+    def act():
+        state[0] = env.policy_rollout(params, state[0], T, check=False)['state']
+    dt = _timed(act, reps)
     out['policy_rollout_512'] = {
-        'value': N * T * reps / dt, 'unit': 'env-steps/s',
+        'value': N * T / dt, 'unit': 'env-steps/s',
         'what': 'policy forward (random-init FeedforwardAgent) + Categorical sample + step + observe + reset per '
                 'env-step, fused in one kernel, launches of 256 batch-steps'}
     return out
 
 
+def main() -> int:
+    args = parse_args()
+    in_world = 'WORLD_SIZE' in os.environ and 'RANK' in os.environ
+    if args.gpus > 1 and not in_world and not args.worker:
+        return spawn_ranks(args)
+    return worker(args)
+
+
 if __name__ == '__main__':
-    main()
+    sys.exit(main())

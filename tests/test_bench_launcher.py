@@ -1,0 +1,61 @@
+"""bench.py --gpus N must start its own N ranks: the parent spawns a fresh torch.distributed.run
+child before touching any GPU and relays rank 0's JSON line.  Exercised here with --dry-run (gloo on CPU, the rollout
+launch replaced by a sleep): rendezvous, barrier, max-over-ranks time, summed env-steps, one JSON line."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(*flags, env=None):
+    e = dict(os.environ)
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        e.pop(k, None)
+    e.update(env or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), *flags], capture_output=True, text=True,
+                       env=e, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout
+    return json.loads(lines[0])
+
+
+def test_gpus_2_spawns_two_ranks():
+    d = _run('--gpus', '2', '--dry-run', '--steps', '3', '--warmup', '1')
+    assert d['n_gpus'] == 2 and d['config']['world_size'] == 2 and d['config']['backend'] == 'gloo'
+    assert d['steps'] == 3 and d['warmup'] == 1 and d['scaling'] == 'weak'
+    # whole-job value: both ranks' env-steps over the max-over-ranks time
+    per_launch = d['config']['env_steps_per_launch_per_gpu']
+    assert abs(d['value'] - 2 * 3 * per_launch / (d['ms_per_step'] * 1e-3 * 3)) / d['value'] < 1e-6
+    assert 'cpu_baseline' not in d and 'extra' not in d
+
+
+def test_cfg3_is_split_over_the_ranks():
+    d = _run('--gpus', '2', '--dry-run', '--steps', '2', '--warmup', '0', '--workload', 'cfg3')
+    assert d['config']['global_num_envs'] == 65536 and d['config']['num_envs_per_gpu'] == 32768
+    assert d['scaling'] == 'strong' and d['config']['baseline_config'] == 'BASELINE.json configs[2]'
+
+
+def test_single_process_default_and_cpu_baseline_legs():
+    d = _run('--dry-run', '--steps', '2', '--warmup', '1')
+    assert d['n_gpus'] == 1 and d['config']['world_size'] == 1
+    assert str(d['config']['batch_steps_per_launch']) in d['config']['workload']
+    cb = d['cpu_baseline']
+    assert cb['kind'] == 'port' and cb['value'] > 0 and cb['cores'] >= 1
+    assert cb['c_port_1thread']['value'] > 0 and cb['c_port_allcores']['value'] > 0
+
+
+def test_worker_under_an_external_torchrun():
+    """the driver's own launch line for N > 1: python -m torch.distributed.run ... bench.py --gpus N"""
+    from bench import free_port
+    e = dict(os.environ)
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+                        '--master-addr', '127.0.0.1', '--master-port', str(free_port()),
+                        os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--dry-run', '--steps', '2', '--warmup', '1'],
+                       capture_output=True, text=True, env=e, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1
+    assert json.loads(lines[0])['n_gpus'] == 2
