@@ -96,6 +96,66 @@ int wurm_single_rollout(float *envs, void *actions, int actions_dtype, float *re
                         int64_t num_envs, int size, int64_t num_steps, uint64_t seed, uint64_t call0,
                         int64_t env_offset, const int32_t *inject_food, const int32_t *inject_reset, void *stream);
 
+/* Arguments of wurm_single_step_reset / wurm_grid_step_reset (a HOST struct of device pointers and sizes; the fields
+ * shared with wurm_single_step / wurm_single_reset mean the same). */
+typedef struct wurm_single_call {
+    float *envs;                     /* in/out (N,3,S,S) [SimpleGridworld: (N,2,S,S)]                            */
+    void *actions;                   /* in/out (N) int64|int32 (SimpleGridworld: read only)                      */
+    float *reward;                   /* out (N)                                                                  */
+    uint8_t *done;                   /* out (N)                                                                  */
+    uint8_t *self_collision;         /* out (N), SingleSnake only                                                */
+    uint8_t *edge_collision;         /* out (N)                                                                  */
+    float *obs;                      /* out: observation of the post-step, PRE-reset state (single_snake.py:304) */
+    float *obs_after;                /* nullable out: what reset(done) returns (:342) — the observation of every
+                                        env once the envs that just finished are rebuilt with call + 1          */
+    uint8_t *done_copy;              /* nullable out (N): second copy of `done`                                  */
+    const uint8_t *pre_done;         /* nullable in (N): envs flagged here are rebuilt BEFORE the step, exactly as
+                                        wurm_single_reset(done = pre_done, call = pre_call) would               */
+    const int32_t *inject_food;      /* nullable, as wurm_single_step                                            */
+    const int32_t *inject_reset;     /* nullable (N,4) [grid: (N)]: outcomes of the reset that follows the step  */
+    const int32_t *inject_pre_reset; /* nullable (N,4) [grid: (N)]: outcomes of the reset in front of the step   */
+    int64_t num_envs;
+    int64_t env_offset;
+    uint64_t seed;
+    uint64_t call;                   /* counter of the step; the reset that follows it uses call + 1             */
+    uint64_t pre_call;               /* counter of the reset in front of the step                                */
+    int actions_dtype, obs_mode, obs_n, size;
+    int post_reset;                  /* != 0: envs that finished are rebuilt (call + 1) and STORED after `obs`   */
+    int start_y, start_x;            /* SimpleGridworld start location (simple_gridworld.py:254-262)             */
+} wurm_single_call;
+
+/* One launch for one iteration of the caller loop of tests/test_single_snake_env.py:24-31 /
+ * experiments/main.py:212-227,
+ *     obs, reward, done, info = env.step(actions);  env.reset(done)
+ * in either grouping: post_reset != 0 = [step, observe, reset] (what wurm_single_rollout does per iteration); pre_done
+ * given = [the reset the caller postponed, step, observe] — the host class defers reset(done) into the next step's
+ * launch and flushes it with wurm_single_reset if the state is looked at in between, so `envs` is always what the
+ * reference would show.  Bit-identical to the wurm_single_step / wurm_single_reset pair with the same counters. */
+int wurm_single_step_reset(const wurm_single_call *c, void *stream);
+
+/* The same for SimpleGridworld (simple_gridworld.py:135-202,225-268). */
+int wurm_grid_step_reset(const wurm_single_call *c, void *stream);
+
+/* Caller-allocated output slabs holding the fresh output tensors of the next `steps` step() calls (the host classes
+ * carve the tensors they return out of them; a slab is never written twice).  Layouts: obs, obs_after
+ * (steps, N, elems) fp32; reward (steps, N) fp32; flags (3, steps, N) bytes = done, self_collision, edge_collision. */
+typedef struct wurm_single_slabs {
+    float *obs;
+    float *obs_after; /* nullable */
+    float *reward;
+    uint8_t *flags;
+    int64_t steps;
+} wurm_single_slabs;
+
+/* wurm_single_step_reset with the per-call bookkeeping of the host class done here instead of in Python (at 512 envs
+ * the loop of experiments/main.py:212-227 is bound by host time per call): fills c->actions / actions_dtype / call and
+ * the output pointers of slot `slot` of the slabs (obs_after only if want_obs_after), sets c->pre_done = c->done_copy
+ * and c->pre_call when `apply_pending` (the reset the caller postponed), else clears c->pre_done, and launches.
+ * Everything else in *c (envs, sizes, seed, modes, done_copy, injections) is left as the caller set it. */
+int wurm_single_step_slot(wurm_single_call *c, const wurm_single_slabs *slabs, int64_t slot, void *actions,
+                          int actions_dtype, uint64_t call, int apply_pending, uint64_t pre_call, int want_obs_after,
+                          void *stream);
+
 /* The acting half of the single-agent loop, experiments/main.py:207-212,227, T iterations in ONE launch:
  *   probs, value = model(state)            FeedforwardAgent, wurm/agents/feedforward.py:8-28: E -> 64 -> 64 -> {4, 1}
  *   action = Categorical(probs).sample()   main.py:208-210

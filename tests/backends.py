@@ -30,6 +30,29 @@ class OracleBackend(object):
     def single_observe(self, envs, mode):
         return _o.single_observe(envs, mode)
 
+    def single_step_reset(self, envs, actions, mode, call, pre_done=None, pre_call=None, post_reset=False,
+                          want_obs_after=False, inject_food=None, inject_reset=None, inject_pre_reset=None, grid=None):
+        """The definition wurm_single_step_reset / wurm_grid_step_reset must reproduce, composed from the per-call
+        oracle functions with explicit counters: [reset(pre_done, pre_call)]; step(call); [reset(done, call + 1)].
+        grid: None for SingleSnake, the start location for SimpleGridworld."""
+        def reset(e, d, m, c, inj):
+            if grid is None:
+                return _o.single_reset(e, d, m, self.seed, c, self.env_offset, inj)
+            return _o.grid_reset(e, d, grid, m, self.seed, c, self.env_offset, inj)
+        if pre_done is not None:
+            reset(envs, pre_done, 'none', pre_call, inject_pre_reset)
+        if grid is None:
+            obs, reward, done, sc, ec = _o.single_step(envs, actions, mode, self.seed, call, self.env_offset, inject_food)
+        else:
+            obs, reward, done, ec = _o.grid_step(envs, actions, mode, self.seed, call, self.env_offset, inject_food)
+            sc = None
+        out = dict(obs=obs, reward=reward, done=done, self_collision=sc, edge_collision=ec, obs_after=None)
+        if post_reset or want_obs_after:
+            target = envs if post_reset else envs.copy()
+            oa = reset(target, done, mode, call + 1, inject_reset)
+            out['obs_after'] = oa if want_obs_after else None
+        return out
+
     def single_rollout(self, envs, actions, mode, inject_food=None, inject_reset=None):
         return _o.single_rollout(envs, actions, mode, self.seed, self._next(2 * actions.shape[0]), self.env_offset,
                                  inject_food, inject_reset)

@@ -83,6 +83,41 @@ class HipBackend(object):
         envs[...] = e.cpu().numpy()
         return obs.cpu().numpy() if obs is not None else None
 
+    def single_step_reset(self, envs, actions, mode, call, pre_done=None, pre_call=None, post_reset=False,
+                          want_obs_after=False, inject_food=None, inject_reset=None, inject_pre_reset=None, grid=None):
+        """wurm_single_step_reset / wurm_grid_step_reset through the wurm_single_call argument block"""
+        N, _, S, _ = envs.shape
+        m, n = _lib.parse_obs_mode(mode)
+        e, a = self._t(envs), self._t(actions)
+        shape = (_o.single_obs_shape if grid is None else _o.grid_obs_shape)(mode, N, S)
+        obs = self._empty(shape, torch.float32) if shape else None
+        obs_after = self._empty(shape, torch.float32) if (shape and want_obs_after) else None
+        reward = self._empty((N,), torch.float32)
+        done, sc, ec, copy = (self._empty((N,), torch.uint8) for _ in range(4))
+        pd = self._t((np.asarray(pre_done).reshape(N) != 0).astype(np.uint8)) if pre_done is not None else None
+        inj_f, inj_r, inj_p = (self._t(x, torch.int32) for x in (inject_food, inject_reset, inject_pre_reset))
+        c = _lib.SingleCall()
+        c.envs, c.actions, c.reward, c.done = _lib.ptr(e), _lib.ptr(a), _lib.ptr(reward), _lib.ptr(done)
+        c.self_collision, c.edge_collision, c.obs, c.obs_after = _lib.ptr(sc), _lib.ptr(ec), _lib.ptr(obs), _lib.ptr(obs_after)
+        c.done_copy, c.pre_done = _lib.ptr(copy), _lib.ptr(pd)
+        c.inject_food, c.inject_reset, c.inject_pre_reset = _lib.ptr(inj_f), _lib.ptr(inj_r), _lib.ptr(inj_p)
+        c.num_envs, c.env_offset, c.seed, c.call = N, self.env_offset, _lib.u64(self.seed), _lib.u64(call)
+        c.pre_call = _lib.u64(pre_call if pre_call is not None else 0)
+        c.actions_dtype, c.obs_mode, c.obs_n, c.size, c.post_reset = self._act(a), m, n, S, int(bool(post_reset))
+        c.start_y, c.start_x = (-1, -1) if grid is None else grid
+        import ctypes
+        fn = self.lib.wurm_single_step_reset if grid is None else self.lib.wurm_grid_step_reset
+        rc = fn(ctypes.addressof(c), self._stream())
+        _lib.check(rc, 'wurm_single_step_reset')
+        torch.cuda.synchronize()
+        envs[...] = e.cpu().numpy()
+        actions[...] = a.cpu().numpy()
+        assert torch.equal(copy, done), 'done_copy != done'
+        return dict(obs=obs.cpu().numpy() if obs is not None else None, reward=reward.cpu().numpy(),
+                    done=done.cpu().numpy(), self_collision=sc.cpu().numpy() if grid is None else None,
+                    edge_collision=ec.cpu().numpy(),
+                    obs_after=obs_after.cpu().numpy() if obs_after is not None else None)
+
     def single_observe(self, envs, mode):
         N, _, S, _ = envs.shape
         m, n = _lib.parse_obs_mode(mode)

@@ -20,12 +20,32 @@ ACT_I64, ACT_I32 = 0, 1
 SYMBOLS = [
     'wurm_version', 'wurm_single_obs_elems', 'wurm_grid_obs_elems',
     'wurm_single_step', 'wurm_single_reset', 'wurm_single_observe', 'wurm_single_rollout', 'wurm_single_check',
+    'wurm_single_step_reset', 'wurm_grid_step_reset', 'wurm_single_step_slot',
     'wurm_grid_step', 'wurm_grid_reset', 'wurm_grid_observe', 'wurm_grid_rollout',
     'wurm_multi_obs_elems', 'wurm_multi_step', 'wurm_multi_reset', 'wurm_multi_observe', 'wurm_multi_check',
     'wurm_multi_rollout',
     'wurm_multi_colours', 'wurm_orientations',
     'wurm_a2c_returns', 'wurm_a2c_returns_backward', 'wurm_single_stats', 'wurm_single_policy_rollout',
 ]
+
+
+class SingleCall(ctypes.Structure):
+    """wurm_single_call of include/wurm_hip.h (host struct of device pointers and sizes)"""
+    _fields_ = [('envs', ctypes.c_void_p), ('actions', ctypes.c_void_p), ('reward', ctypes.c_void_p),
+                ('done', ctypes.c_void_p), ('self_collision', ctypes.c_void_p), ('edge_collision', ctypes.c_void_p),
+                ('obs', ctypes.c_void_p), ('obs_after', ctypes.c_void_p), ('done_copy', ctypes.c_void_p),
+                ('pre_done', ctypes.c_void_p), ('inject_food', ctypes.c_void_p), ('inject_reset', ctypes.c_void_p),
+                ('inject_pre_reset', ctypes.c_void_p), ('num_envs', ctypes.c_int64), ('env_offset', ctypes.c_int64),
+                ('seed', ctypes.c_uint64), ('call', ctypes.c_uint64), ('pre_call', ctypes.c_uint64),
+                ('actions_dtype', ctypes.c_int), ('obs_mode', ctypes.c_int), ('obs_n', ctypes.c_int),
+                ('size', ctypes.c_int), ('post_reset', ctypes.c_int), ('start_y', ctypes.c_int),
+                ('start_x', ctypes.c_int)]
+
+
+class SingleSlabs(ctypes.Structure):
+    """wurm_single_slabs of include/wurm_hip.h"""
+    _fields_ = [('obs', ctypes.c_void_p), ('obs_after', ctypes.c_void_p), ('reward', ctypes.c_void_p),
+                ('flags', ctypes.c_void_p), ('steps', ctypes.c_int64)]
 
 
 class MultiConfig(ctypes.Structure):
@@ -99,15 +119,42 @@ def _declare_prototypes(l):
     c_void_p).  With them ctypes converts plain Python ints / None per call instead of wrapper objects built in Python
     (~4 us per call on the per-step path), and a call with the wrong number of arguments fails loudly."""
     import re
-    header = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'include', 'wurm_hip.h')
+    # the repo's include/wurm_hip.h, or the copy `make` places next to the library (wurm_amd/ installed on its own)
+    header = os.path.join(os.path.dirname(_HERE), 'include', 'wurm_hip.h')
+    if not os.path.exists(header):
+        header = os.path.join(_HERE, 'wurm_hip.h')
     text = re.sub(r'/\*.*?\*/', ' ', open(header).read(), flags=re.S)
+    declared = set()
     for ret, name, params in re.findall(r'\b(const char \*|int64_t|int)\s*(wurm_[a-z_0-9]+)\s*\(([^)]*)\)\s*;', text):
+        declared.add(name)
         fn = getattr(l, name)
         fn.restype = {'const char *': ctypes.c_char_p, 'int64_t': ctypes.c_int64, 'int': ctypes.c_int}[ret]
         args = [a.strip() for a in params.split(',')]
         if args == ['void']:
             args = []
         fn.argtypes = [ctypes.c_void_p if '*' in a else _CTYPES[a.replace('const ', '').split()[0]] for a in args]
+    missing = [n for n in SYMBOLS if n not in declared]
+    if missing:  # a symbol without argtypes would get ctypes' default int conversion for 64-bit arguments
+        raise WurmHipError(f'{header}: no prototype found for {missing}')
+
+
+_step_slot = None
+
+
+def step_slot_fn():
+    """wurm_single_step_slot as the cheapest callable available: through the CPython shim wurm_amd/_fastcall (built
+    by `make`; ~1 us less host time per call than ctypes), else the ctypes function itself — same arguments, same
+    library, same kernels either way."""
+    global _step_slot
+    if _step_slot is None:
+        fn = lib().wurm_single_step_slot
+        try:
+            from wurm_amd import _fastcall
+            _fastcall.bind(ctypes.cast(fn, ctypes.c_void_p).value)
+            _step_slot = _fastcall.step_slot
+        except ImportError:
+            _step_slot = fn
+    return _step_slot
 
 
 def check(rc: int, what: str):
@@ -162,7 +209,19 @@ _get_device = None
 def _torch_accessors():
     global _get_raw_stream, _get_device
     import torch
-    _get_raw_stream, _get_device = torch._C._cuda_getCurrentRawStream, torch._C._cuda_getDevice
+    _get_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+    _get_device = getattr(torch._C, '_cuda_getDevice', None)
+    if _get_raw_stream is None:  # public (slower) route if the private accessors ever go away
+        _get_raw_stream = lambda index: torch.cuda.current_stream(index).cuda_stream
+    if _get_device is None:
+        _get_device = torch.cuda.current_device
+
+
+def accessors():
+    """(current-device getter, raw-stream getter) for callers that inline `call` / `stream_ptr` on a hot path"""
+    if _get_raw_stream is None:
+        _torch_accessors()
+    return _get_device, _get_raw_stream
 
 
 def stream_ptr(device_index=None):

@@ -491,6 +491,12 @@ struct StepArgs {
     const int *inject_reset;
     const uint8_t *done_in;
     int lds_per_wave;
+    // fused step (+ deferred / immediate reset): wurm_single_step_reset
+    float *obs_after;
+    uint8_t *done_copy;
+    const int *inject_pre_reset;
+    u64 pre_call;
+    int post_reset;
 };
 
 __device__ __forceinline__ long long load_action(const void *actions, int dtype, long long i)
@@ -534,6 +540,65 @@ __global__ __launch_bounds__(256) void step_kernel(StepArgs p)
     }
     if (p.obs_mode != WURM_OBS_NONE)
         write_obs<CPL, SNAKE>(e, g, out.headcell, p.obs + env * p.obs_elems, p.obs_mode, p.obs_n, lds);
+}
+
+// One launch for the caller loop `obs, r, d, info = env.step(a); env.reset(d)` (tests/test_single_snake_env.py:24-31,
+// experiments/main.py:212-227), in either of two groupings:
+//   * deferred reset: envs flagged in p.done_in (the `done` of the PREVIOUS step, whose reset(done) call the host
+//     side postponed) are rebuilt first — exactly reset_kernel with call = p.pre_call — then every env is stepped
+//     (call = p.call) and observed;
+//   * immediate reset (p.post_reset): after the observation of the post-step state (:304) done envs are rebuilt
+//     (call = p.call + 1) and stored, as rollout_kernel does per iteration.
+// p.obs_after (nullable): what reset(done) returns — the observation of every env after done envs are rebuilt —
+// written whether or not the rebuilt state is stored (the deferred reset of the next launch recreates it from the
+// same counters).  p.done_copy (nullable): second copy of `done` in a buffer the caller cannot modify.
+template <int CPL, bool SNAKE>
+__global__ __launch_bounds__(256) void fused_step_kernel(StepArgs p)
+{
+    const int wave = (int)(threadIdx.x >> 6), wpb = (int)(blockDim.x >> 6);
+    const long long env = (long long)blockIdx.x * wpb + wave;
+    if (env >= p.N) return;
+    signed char *lds = wurm_lds + wave * p.lds_per_wave;
+    const int NCH = SNAKE ? 3 : 2;
+    const Geo g = make_geo<CPL>(p.S);
+    float *envp = p.envs + env * NCH * g.C;
+    const u64 env_id = (u64)(p.env_offset + env);
+    Env<CPL> e;
+    const bool pre = p.done_in != nullptr && uniform((int)p.done_in[env]) != 0;
+    if (pre) {
+        const int *inj = p.inject_pre_reset ? p.inject_pre_reset + env * (SNAKE ? 4 : 1) : nullptr;
+        reset_core<CPL, SNAKE>(e, g, p.seed, p.pre_call, env_id, inj, p.start_y, p.start_x);
+        store_state<CPL, SNAKE>(envp, g, e); // step_core then writes the cells it changes on top (same wave: in order)
+    } else {
+        load_state<CPL, SNAKE>(envp, g, e);
+    }
+    const long long a_in = uniform64(load_action(p.actions, p.act_dtype, env));
+    const bool inj = p.inject_food != nullptr;
+    const int inj_cell = inj ? uniform(p.inject_food[env]) : -1;
+    StepOut out;
+    step_core<CPL, SNAKE, true>(e, g, envp, a_in, out, p.seed, p.call, env_id, inj, inj_cell, lds);
+    if (g.lane == 0) {
+        if (SNAKE) {
+            store_action(p.actions, p.act_dtype, env, out.action);
+            p.selfc[env] = (uint8_t)out.selfc;
+        }
+        p.reward[env] = out.reward;
+        p.done[env] = (uint8_t)out.done;
+        p.edgec[env] = (uint8_t)out.edgec;
+        if (p.done_copy) p.done_copy[env] = (uint8_t)out.done;
+    }
+    if (p.obs_mode != WURM_OBS_NONE)
+        write_obs<CPL, SNAKE>(e, g, out.headcell, p.obs + env * p.obs_elems, p.obs_mode, p.obs_n, lds);
+    if (!p.post_reset && p.obs_after == nullptr) return;
+    int headcell = out.headcell;
+    if (out.done) {
+        const int *inj_r = p.inject_reset ? p.inject_reset + env * (SNAKE ? 4 : 1) : nullptr;
+        reset_core<CPL, SNAKE>(e, g, p.seed, p.call + 1ull, env_id, inj_r, p.start_y, p.start_x);
+        if (p.post_reset) store_state<CPL, SNAKE>(envp, g, e);
+        headcell = find_head<CPL>(e);
+    }
+    if (p.obs_after != nullptr && p.obs_mode != WURM_OBS_NONE)
+        write_obs<CPL, SNAKE>(e, g, headcell, p.obs_after + env * p.obs_elems, p.obs_mode, p.obs_n, lds);
 }
 
 template <int CPL, bool SNAKE>
@@ -1462,7 +1527,7 @@ __global__ __launch_bounds__(256) void orientations_kernel(const float *__restri
 
 // ------------------------------------------------------------------------------------------------ host side
 
-enum Kind { K_STEP, K_RESET, K_OBSERVE, K_ROLLOUT };
+enum Kind { K_STEP, K_RESET, K_OBSERVE, K_ROLLOUT, K_FUSED };
 
 static int pick_cpl(int S)
 {
@@ -1481,6 +1546,7 @@ static hipError_t launch_one(Kind kind, const StepArgs &p, dim3 grid, dim3 block
     case K_STEP: hipLaunchKernelGGL((step_kernel<CPL, SNAKE>), grid, block, lds, st, p); break;
     case K_RESET: hipLaunchKernelGGL((reset_kernel<CPL, SNAKE>), grid, block, lds, st, p); break;
     case K_OBSERVE: hipLaunchKernelGGL((observe_kernel<CPL, SNAKE>), grid, block, lds, st, p); break;
+    case K_FUSED: hipLaunchKernelGGL((fused_step_kernel<CPL, SNAKE>), grid, block, lds, st, p); break;
     case K_ROLLOUT:
         if constexpr (SNAKE && CPL == 2) {
             const bool rng_mode = p.inject_food == nullptr && p.inject_reset == nullptr;
@@ -1637,6 +1703,60 @@ int wurm_single_rollout(float *envs, void *actions, int actions_dtype, float *re
     p.obs_elems = obs_elems(true, obs_mode, obs_n, size); p.N = num_envs; p.S = size; p.T = num_steps; p.seed = seed;
     p.call = call0; p.env_offset = env_offset; p.inject_food = inject_food; p.inject_reset = inject_reset;
     return launch<true>(K_ROLLOUT, p, stream);
+}
+
+static int fused_entry(bool snake, const wurm_single_call *c, void *stream)
+{
+    if (!c) return WURM_ERR_INVALID_ARG;
+    int rc = check_common(snake, c->envs, c->num_envs, c->size, c->obs, c->obs_mode, c->obs_n, c->actions_dtype);
+    if (rc) return rc;
+    const int64_t N = c->num_envs;
+    if (N > 0 && (!c->actions || !c->reward || !c->done || !c->edge_collision || (snake && !c->self_collision)))
+        return WURM_ERR_INVALID_ARG;
+    const bool resets = c->pre_done || c->post_reset || c->obs_after;
+    if (resets) { // the same limits as wurm_single_reset / wurm_grid_reset
+        if (snake && c->size <= 8) return WURM_ERR_UNSUPPORTED;
+        if (!snake && (c->size <= 4 || c->start_y < 0 || c->start_x < 0 || c->start_y >= c->size || c->start_x >= c->size))
+            return WURM_ERR_UNSUPPORTED;
+    }
+    StepArgs p = {};
+    p.envs = c->envs; p.actions = c->actions; p.act_dtype = c->actions_dtype; p.reward = c->reward; p.done = c->done;
+    p.selfc = c->self_collision; p.edgec = c->edge_collision; p.obs = c->obs; p.obs_mode = c->obs_mode;
+    p.obs_n = c->obs_n; p.obs_elems = obs_elems(snake, c->obs_mode, c->obs_n, c->size); p.N = N; p.S = c->size;
+    p.start_y = c->start_y; p.start_x = c->start_x; p.seed = c->seed; p.call = c->call; p.env_offset = c->env_offset;
+    p.inject_food = c->inject_food; p.inject_reset = c->inject_reset; p.done_in = c->pre_done;
+    p.obs_after = c->obs_after; p.done_copy = c->done_copy; p.inject_pre_reset = c->inject_pre_reset;
+    p.pre_call = c->pre_call; p.post_reset = c->post_reset;
+    return snake ? launch<true>(K_FUSED, p, stream) : launch<false>(K_FUSED, p, stream);
+}
+
+int wurm_single_step_reset(const wurm_single_call *c, void *stream) { return fused_entry(true, c, stream); }
+
+int wurm_grid_step_reset(const wurm_single_call *c, void *stream) { return fused_entry(false, c, stream); }
+
+int wurm_single_step_slot(wurm_single_call *c, const wurm_single_slabs *s, int64_t slot, void *actions,
+                          int actions_dtype, uint64_t call, int apply_pending, uint64_t pre_call, int want_obs_after,
+                          void *stream)
+{
+    if (!c || !s || slot < 0 || slot >= s->steps) return WURM_ERR_INVALID_ARG;
+    const int64_t N = c->num_envs, elems = obs_elems(true, c->obs_mode, c->obs_n, c->size);
+    c->actions = actions;
+    c->actions_dtype = actions_dtype;
+    c->call = call;
+    c->obs = s->obs ? s->obs + slot * N * elems : nullptr;
+    c->obs_after = (want_obs_after && s->obs_after) ? s->obs_after + slot * N * elems : nullptr;
+    c->reward = s->reward + slot * N;
+    c->done = s->flags + slot * N;
+    c->self_collision = s->flags + (s->steps + slot) * N;
+    c->edge_collision = s->flags + (2 * s->steps + slot) * N;
+    if (apply_pending) {
+        if (!c->done_copy) return WURM_ERR_INVALID_ARG;
+        c->pre_done = c->done_copy;
+        c->pre_call = pre_call;
+    } else {
+        c->pre_done = nullptr;
+    }
+    return fused_entry(true, c, stream);
 }
 
 int wurm_single_policy_rollout(float *envs, const float *obs0, const float *params, int64_t *actions, float *probs,
