@@ -95,7 +95,7 @@ def spawn_ranks(args) -> int:
 
 # ------------------------------------------------------------------------------------------------ CPU baselines
 
-def cpu_baseline(num_envs: int, budget_s: float = 7.0):
+def cpu_baseline(num_envs: int, budget_s: float = 5.0):
     """The reference's algorithm on the host cores of this box, on a bounded sample of the cfg2 workload
     (step + observe + reset per batch-step, random actions).  Three legs (SURVEY.md §8(d) i-iii):
       value           torch-op restatement of the convolution-and-mask algorithm (oracle/torch_port.py), all cores
@@ -110,23 +110,30 @@ def cpu_baseline(num_envs: int, budget_s: float = 7.0):
     cores = os.cpu_count() or 1
     out = {}
 
-    # (ii) torch-op restatement, all cores
-    torch.set_num_threads(cores)
-    env = TorchSingleSnake(num_envs, SIZE, OBS_MODE, seed=0)
-    g = torch.Generator().manual_seed(0)
-    for _ in range(5):
+    # (ii) torch-op restatement.  The reference's own number was taken at 8 torch threads; tiny tensors
+    # and hundreds of OpenMP threads do not mix (each op pays the fork/join of the whole team), so the leg is timed at 1,
+    # 8 and all cores, each bounded per batch-step, and `value` is the best of them (with its thread count as `cores`).
+    def torch_leg(threads, budget):
+        torch.set_num_threads(threads)
+        env = TorchSingleSnake(num_envs, SIZE, OBS_MODE, seed=0)
+        g = torch.Generator().manual_seed(0)
         _, _, d, _ = env.step(torch.randint(4, (num_envs,), generator=g))
         env.reset(d)
-    steps, t0 = 0, time.perf_counter()
-    while time.perf_counter() - t0 < budget_s:
-        acts = torch.randint(4, (50, num_envs), generator=g)
-        for t in range(50):
-            _, _, d, _ = env.step(acts[t])
+        steps, t0 = 0, time.perf_counter()
+        while True:
+            _, _, d, _ = env.step(torch.randint(4, (num_envs,), generator=g))
             env.reset(d)
-        steps += 50
-    dt = time.perf_counter() - t0
-    torch_rate = num_envs * steps / dt
-    torch_sample = f'{steps} batch-steps in {dt:.1f} s, torch {torch.__version__}, {torch.get_num_threads()} threads'
+            steps += 1
+            if time.perf_counter() - t0 >= budget:
+                break
+        dt = time.perf_counter() - t0
+        return {'value': num_envs * steps / dt, 'cores': threads, 'sample': f'{steps} batch-steps in {dt:.1f} s'}
+    legs = [torch_leg(t, budget_s / 2) for t in sorted({1, min(8, cores), cores})]
+    best = max(legs, key=lambda l: l['value'])
+    torch_rate, torch_cores = best['value'], best['cores']
+    torch_sample = f"{best['sample']}, torch {torch.__version__}, {best['cores']} threads (best of " + \
+                   ', '.join(f"{l['cores']} thr: {l['value']:.3g}" for l in legs) + ' env-steps/s)'
+    torch.set_num_threads(min(8, cores))
 
     # (iii) scalar C restatement: 1 thread, then one thread per core (ctypes releases the GIL during the call)
     def c_port(n_threads):
@@ -172,7 +179,8 @@ def cpu_baseline(num_envs: int, budget_s: float = 7.0):
     except OSError:
         pass
     out.update({
-        'value': torch_rate, 'unit': 'env-steps/s', 'cores': cores, 'kind': 'port',
+        'value': torch_rate, 'unit': 'env-steps/s', 'cores': torch_cores, 'kind': 'port', 'host_cores': cores,
+        'torch_port_by_threads': legs,
         'sample': f'oracle/torch_port.py (torch-op restatement of the reference\'s conv-and-mask algorithm, bit-equal '
                   f'to the oracle: tests/test_torch_port.py): SingleSnake {num_envs}x{SIZE}x{SIZE} {OBS_MODE}, '
                   f'step+observe+reset per batch-step, {torch_sample}',
@@ -327,7 +335,7 @@ def worker(args) -> int:
         if n_gpus == 1 and not args.no_cpu_baseline:
             try:
                 line['cpu_baseline'] = cpu_baseline(512 if args.workload == 'cfg2' else 512,
-                                                    budget_s=0.5 if args.dry_run else 7.0)
+                                                    budget_s=0.5 if args.dry_run else 5.0)
             except Exception as e:  # the baseline is a reported extra: never lose the bench line over it
                 line['cpu_baseline'] = {'error': repr(e)}
         print(json.dumps(line))

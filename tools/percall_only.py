@@ -9,8 +9,8 @@ from wurm_amd.envs import SingleSnake  # noqa: E402
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 env = SingleSnake(num_envs=N, size=9, observation_mode='partial_2', device='cuda', seed=0)
-a = torch.randint(4, (8, N), device='cuda')
-for t in range(8):
+a = torch.randint(4, (400, N), device='cuda')
+for t in range(400):
     _, _, d, _ = env.step(a[t])
     env.reset(d, return_observations=False)
 torch.cuda.synchronize()
