@@ -26,8 +26,11 @@
  *   - softmax: e_a = exp_spec(l_a - max l), p_a = e_a * (1 / (((e_0 + e_1) + e_2) + e_3))  (one IEEE reciprocal);
  *   - sampling: u = u01(word 0 of Philox(seed; env id, step call counter, RNG_POLICY)), action = number of
  *     cumulative sums c_0 = p_0, c_1 = c_0 + p_1, c_2 = c_1 + p_2 that are <= u (inverse CDF, clamped to 3).
- * Against torch (fp32, CPU) these agree to ~1e-6 relative on probs / values; tests/test_policy_rollout*.py check that,
- * and the sampling distribution.
+ * Parity status: PINNED — probabilities and values agree with the REAL reference agent (wurm.agents.FeedforwardAgent,
+ * imported in the build container by tests/golden/make_golden_policy.py, weights as torch initialises them and a
+ * sharpened copy, real 'partial_n' observations) to 2e-6 absolute / 1e-5 relative: tests/golden/policy_ff_*.npz,
+ * tests/test_policy_rollout.py::test_spec_forward_matches_the_reference_agent; the sampling distribution is checked by
+ * a chi-square test.  What cannot be pinned is WHICH action torch's multinomial draws from its global RNG stream.
  */
 #include <math.h>
 #include <stdlib.h>

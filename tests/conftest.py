@@ -3,6 +3,11 @@ import sys
 
 import pytest
 
+# Nothing may ever be written under the read-only reference tree: importing it (tests/golden/ref_shim.py, in this
+# process or in a spawned worker that inherits the environment) must not drop __pycache__ there.
+sys.dont_write_bytecode = True
+os.environ['PYTHONDONTWRITEBYTECODE'] = '1'
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -227,3 +227,44 @@ def test_python_api(hip):
     with pytest.raises(NotImplementedError):
         SingleSnake(num_envs=4, size=9, observation_mode='default', device='cuda').policy_rollout(
             pack_policy_params(agent), state[:4], 3)
+
+
+# ------------------------------------------------------------------------------------------- pinned to the reference
+
+POLICY_FIXTURES = ['policy_ff_n2_s9', 'policy_ff_n1_s10', 'policy_ff_n3_s11', 'policy_ff_n2_s9_sharp']
+# Tolerance of the arithmetic spec against the reference's torch forward: the spec fixes the
+# accumulation order of every dot product, torch's addmm / softmax do not.
+PROB_ATOL, VALUE_RTOL = 2e-6, 1e-5
+
+
+def _load_policy(name):
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', name + '.npz'))
+    return {k: z[k] for k in z.files}
+
+
+@pytest.mark.parametrize('name', POLICY_FIXTURES)
+def test_spec_forward_matches_the_reference_agent(name):
+    """oracle/policy.c against probabilities / values recorded from the REAL wurm.agents.FeedforwardAgent
+    (tests/golden/make_golden_policy.py; wurm/agents/feedforward.py:8-28) on real observations."""
+    fx = _load_policy(name)
+    p, v = O.policy_forward(fx['params'], fx['obs'])
+    assert np.abs(p - fx['probs']).max() < PROB_ATOL
+    assert np.abs(v - fx['values'][:, 0]).max() < VALUE_RTOL * max(1.0, np.abs(fx['values']).max())
+    assert (p.argmax(1) == fx['probs'].argmax(1)).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', POLICY_FIXTURES)
+def test_hip_policy_matches_the_reference_agent(name):
+    """the fused acting kernel's probs / values of step 0 (policy applied to obs0) against the reference's forward"""
+    from tests.hip_backend import HipBackend
+    fx = _load_policy(name)
+    M, E, n, S = (int(x) for x in fx['meta'])
+    h = HipBackend(seed=3)
+    envs = np.zeros((M, 3, S, S), np.float32)
+    h.single_reset(envs, np.ones(M, np.uint8), 'none')
+    out = h.single_policy_rollout(envs, fx['obs'], fx['params'], 1, n)
+    assert (out['status'] == 0).all()
+    assert np.abs(out['probs'][0] - fx['probs']).max() < PROB_ATOL
+    assert np.abs(out['values'][0] - fx['values'][:, 0]).max() < VALUE_RTOL * max(1.0, np.abs(fx['values']).max())
