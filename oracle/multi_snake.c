@@ -496,7 +496,7 @@ int oracle_multi_reset(float *foods, float *heads, float *bodies, uint8_t *dones
                        const oracle_multi_reset_inject *inj)
 {
     int C = S * S;
-    if (K < 1 || K > 64 || S < 7) return S < 7 ? ORACLE_ERR_UNSUPPORTED : ORACLE_ERR_INVALID;
+    if (K < 1 || K > 64 || S < 5) return S < 5 ? ORACLE_ERR_UNSUPPORTED : ORACLE_ERR_INVALID; /* seeds need rows 2..S-3 (:938-941) */
     for (int64_t e = 0; e < N; ++e) {
         float *food = foods + e * C, *hd = heads + e * K * C, *bd = bodies + e * K * C;
         uint8_t *dn = dones + e * K;

@@ -50,6 +50,8 @@ CFGS = {
     (9, 3, 10, 100, 'full', 'noboost'),
     (3, 10, 36, 40, 'partial_3', 'train'),     # experiments/speeds.py shape (10 agents, 36x36)
     (5, 1, 9, 60, 'full', 'dense'),
+    (7, 1, 5, 60, 'full', 'default'),          # the smallest grid the reference can populate (seed rows 2..S-3)
+    (7, 1, 6, 60, 'partial_1', 'train'),
 ])
 def test_multi_step_reset_loop(hip, N, K, S, T, mode, cfg):
     cfg = CFGS[cfg]

@@ -64,3 +64,15 @@ def test_records_real_envs(tmp_path):
     rec.close()
     frames = np.load(tmp_path / 'multi.npy')
     assert frames.ndim == 4 and frames.shape[0] == 1 and frames.shape[-1] == 3 and frames.max() > 0
+
+
+def test_mp4_needs_ffmpeg_and_says_so(tmp_path):
+    import shutil
+    rec = VideoRecorder(_FakeEnv(), path=str(tmp_path / 'run.mp4'))
+    rec.capture_frame()
+    if shutil.which('ffmpeg') or shutil.which('avconv'):
+        rec.close()
+        assert (tmp_path / 'run.mp4').stat().st_size > 0
+    else:
+        with pytest.raises(RuntimeError, match='ffmpeg'):
+            rec.close()

@@ -1160,7 +1160,7 @@ int wurm_multi_reset(float *foods, float *heads, float *bodies, uint8_t *dones, 
     int rc = multi_check_args(num_envs, num_snakes, size, obs_mode, obs_n, obs);
     if (rc) return rc;
     if (!cfg) return WURM_ERR_INVALID_ARG;
-    if (size < 7) return WURM_ERR_UNSUPPORTED; // no cell is >= 2 from the border with a free 3x3 neighbourhood
+    if (size < 5) return WURM_ERR_UNSUPPORTED; // no cell is >= 2 from the border (multi_snake.py:938-941)
     if (num_envs > 0 && (!foods || !heads || !bodies || !dones || !orientations || !done_env || !colours))
         return WURM_ERR_INVALID_ARG;
     if (obs_mode != WURM_OBS_NONE && num_envs > 0 && !boost_this_step) return WURM_ERR_INVALID_ARG;
@@ -1183,7 +1183,7 @@ int wurm_multi_rollout(float *foods, float *heads, float *bodies, uint8_t *dones
     int rc = multi_check_args(num_envs, num_snakes, size, obs_mode, obs_n, obs);
     if (rc) return rc;
     if (!cfg || num_steps < 0) return WURM_ERR_INVALID_ARG;
-    if (size < 7) return WURM_ERR_UNSUPPORTED;
+    if (size < 5) return WURM_ERR_UNSUPPORTED;
     if (num_envs > 0 && (!foods || !heads || !bodies || !dones || !orientations || !colours)) return WURM_ERR_INVALID_ARG;
     if (num_envs > 0 && num_steps > 0 && (!actions || !out_f32 || !out_u8 || !all_done)) return WURM_ERR_INVALID_ARG;
     if (num_steps == 0) return WURM_OK;

@@ -3,7 +3,12 @@ with preallocated (capacity, ...) device buffers instead of Python lists + `torc
 copies one (num_envs, ...) row into the next slot, the properties return the filled prefix as a view.
 
 Rows that carry autograd history (log_prob, value, entropy) keep it: the copy into the buffer is an in-place op that
-autograd tracks; `clear()` drops the buffers' history so the next rollout starts a fresh graph."""
+autograd tracks; `clear()` drops the buffers' history so the next rollout starts a fresh graph.
+
+Aliasing: a tensor read from a property is a view of the buffer.  Like the reference's `torch.stack` copies it must stay
+valid after `clear()` and the next rollout (callers keep trajectories for logging or a delayed backward), so `clear()`
+lets go of every buffer that has been handed out since the last clear and the next `append` allocates a new one; buffers
+nobody looked at are reused."""
 import torch
 
 _FIELDS = ('state', 'action', 'log_prob', 'reward', 'value', 'done', 'entropy', 'hidden_state')
@@ -16,6 +21,7 @@ class TrajectoryStore(object):
         self.capacity = capacity
         self._buf = {}
         self._len = {}
+        self._handed_out = set()
         self.clear()
 
     def _put(self, name: str, x: torch.Tensor):
@@ -41,13 +47,15 @@ class TrajectoryStore(object):
 
     def clear(self):
         """reference :50-58"""
+        self._buf = {k: v.detach() for k, v in self._buf.items() if k not in self._handed_out}
         self._len = {k: 0 for k in self._buf}
-        self._buf = {k: v.detach() for k, v in self._buf.items()}
+        self._handed_out = set()
 
     def _get(self, name: str) -> torch.Tensor:
         n = self._len.get(name, 0)
         if n == 0:
             raise RuntimeError('stack expects a non-empty TensorList')  # what torch.stack([]) raises in the reference
+        self._handed_out.add(name)
         return self._buf[name][:n]
 
     states = property(lambda self: self._get('state'))

@@ -53,8 +53,15 @@ def make_sharded(env_cls, global_num_envs: int, *args, seed: Optional[int] = Non
     rank = r if rank is None else rank
     world_size = w if world_size is None else world_size
     offset, count = shard_range(global_num_envs, rank, world_size)
-    dev = kwargs.get('device', 'cpu')
-    bdev = dev if (_dist() and _dist().get_backend() == 'nccl') else 'cpu'
+    if _dist() and _dist().get_backend() == 'nccl':
+        # NCCL / RCCL broadcasts device tensors only; the env classes default to the current HIP device
+        bdev = torch.device(kwargs.get('device', 'cuda'))
+        if bdev.type != 'cuda':
+            raise ValueError('make_sharded under the nccl backend needs a HIP device')
+        if bdev.index is None:
+            bdev = torch.device('cuda', torch.cuda.current_device())
+    else:
+        bdev = 'cpu'
     return env_cls(count, *args, seed=shared_seed(seed, device=bdev), env_offset=offset, **kwargs)
 
 
