@@ -210,3 +210,20 @@ def test_full_size_properties(hip):
             assert int(err.abs().max()) == 0, f'inconsistent env after reset at t={t}'
             total_reward += float(reward.sum())
         assert total_reward > 0
+
+
+@pytest.mark.parametrize('S,mode', [(12, 'one_channel'), (14, 'partial_2')])
+def test_grid_rollout_long_tape_rebases_clocks(hip, S, mode):
+    """The LDS clock-grid rollout (grid_rollout.hip) keeps 16-bit expiry clocks and re-bases them between 64-step chunks
+    once they pass 0xC000: a tape long enough to cross that several times must still equal the oracle bit for bit."""
+    N, T = 3, 120000
+    rng = np.random.RandomState(S)
+    actions = rng.randint(0, 4, size=(T, N)).astype(np.int64)
+    o, h = OracleBackend(seed=13), hip(seed=13)
+    eo, eh = _fresh_single(o, N, S), _fresh_single(h, N, S)
+    ao, ah = actions.copy(), actions.copy()
+    ro, rh = o.single_rollout(eo, ao, mode), h.single_rollout(eh, ah, mode)
+    _same(ao, ah, 'actions')
+    for k in ro:
+        _same(ro[k], rh[k], k)
+    _same(eo, eh, 'final state')

@@ -17,8 +17,10 @@ typedef float vf2 __attribute__((ext_vector_type(2)));
 typedef float vf4 __attribute__((ext_vector_type(4)));
 
 template <int W, bool NT, int VALU>
-__global__ __launch_bounds__(256) void store_kernel(float *out, int floats_per_env_step, int T, long long N)
+__global__ __launch_bounds__(256) void store_kernel(float *out, int floats_per_env_step, int T, long long N, int skew)
 {
+    extern __shared__ int dummy_lds[];
+    if (skew > 0) { const int g = (int)(((unsigned)(blockIdx.x * 4 + (threadIdx.x >> 6)) * 2654435761u) >> 29); for (int i = 0; i < g * skew; ++i) __builtin_amdgcn_s_sleep(127); }
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
     const long long env = (long long)blockIdx.x * wpb + wave;
     if (env >= N) return;
@@ -46,46 +48,46 @@ __global__ __launch_bounds__(256) void store_kernel(float *out, int floats_per_e
 }
 
 template <int W, bool NT, int VALU>
-static void run(const char *name, float *buf, int fpe, int T, long long N, int wpb)
+static void run(const char *name, float *buf, int fpe, int T, long long N, int wpb, int lds_bytes = 0, int skew = 0)
 {
     dim3 block(64 * wpb), grid((unsigned)((N + wpb - 1) / wpb));
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((store_kernel<W, NT, VALU>), grid, block, 0, 0, buf, fpe, T, N);
+    for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((store_kernel<W, NT, VALU>), grid, block, lds_bytes, 0, buf, fpe, T, N, skew);
     hipEventRecord(e0);
     const int reps = 5;
-    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((store_kernel<W, NT, VALU>), grid, block, 0, 0, buf, fpe, T, N);
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((store_kernel<W, NT, VALU>), grid, block, lds_bytes, 0, buf, fpe, T, N, skew);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     ms /= reps;
     double bytes = 4.0 * fpe * T * N;
-    printf("%-28s N=%6lld fpe=%6d T=%3d wpb=%d valu=%4d : %8.3f ms  %7.2f TB/s\n", name, N, fpe, T, wpb, VALU, ms, bytes / ms / 1e9);
+    printf("%-28s N=%6lld fpe=%6d T=%3d wpb=%d valu=%4d lds=%6d skew=%d : %8.3f ms  %7.2f TB/s\n", name, N, fpe, T, wpb, VALU, lds_bytes, skew, ms, bytes / ms / 1e9);
 }
 
 int main()
 {
-    const long long N = 8192; const int fpe = 3 * 36 * 36, T = 16;
-    float *buf; hipMalloc(&buf, 4ull * fpe * T * N);
-    for (int wpb : {1, 4}) {
-        run<1, false, 0>("dword", buf, fpe, T, N, wpb);
-        run<2, false, 0>("dwordx2", buf, fpe, T, N, wpb);
-        run<4, false, 0>("dwordx4", buf, fpe, T, N, wpb);
-        run<4, true, 0>("dwordx4 nt", buf, fpe, T, N, wpb);
-        run<1, true, 0>("dword nt", buf, fpe, T, N, wpb);
-        run<1, false, 1024>("dword + 1024 valu/step", buf, fpe, T, N, wpb);
-        run<4, false, 1024>("dwordx4 + 1024 valu/step", buf, fpe, T, N, wpb);
-        run<1, false, 4096>("dword + 4096 valu/step", buf, fpe, T, N, wpb);
-        run<4, false, 4096>("dwordx4 + 4096 valu/step", buf, fpe, T, N, wpb);
+    const long long N = 8192; const int fpe = 3 * 36 * 36;
+    float *buf; hipMalloc(&buf, 4ull * fpe * 64 * N);
+    // (1) does a longer launch stream faster (waves drifting out of lockstep)?
+    for (int T : {16, 64}) {
+        run<4, false, 0>("dwordx4", buf, fpe, T, N, 4);
+        run<1, false, 0>("dword", buf, fpe, T, N, 4);
     }
-    // cfg4 shape: 4096 envs x 30 000 B
-    const long long N4 = 4096; const int fpe4 = 12 * 625;
-    run<1, false, 0>("cfg4 dword", buf, fpe4, T, N4, 4);
-    run<4, false, 0>("cfg4 dwordx4", buf, fpe4, T, N4, 4);
-    run<4, true, 0>("cfg4 dwordx4 nt", buf, fpe4, T, N4, 4);
-    // cfg3 shape: 65536 envs x 300 B, 64 steps
-    const long long N3 = 65536; const int fpe3 = 75;
-    run<1, false, 0>("cfg3 dword", buf, fpe3, 64, N3, 4);
-    run<1, true, 0>("cfg3 dword nt", buf, fpe3, 64, N3, 4);
+    // (2) waves per CU limited through dynamic LDS per 4-wave block: 160 KB / lds = blocks per CU
+    for (int lds : {0, 20480, 26624, 40960, 65536}) {
+        run<4, false, 0>("dwordx4 occupancy", buf, fpe, 16, N, 4, lds);
+        run<4, false, 0>("dwordx4 occupancy", buf, fpe, 64, N, 4, lds);
+    }
+    // (3) start-up skew of pseudo-random wave groups (8 groups x skew x ~3.4 us)
+    for (int skew : {1, 2, 4, 8}) {
+        run<4, false, 0>("dwordx4 skew", buf, fpe, 16, N, 4, 0, skew);
+        run<4, false, 0>("dwordx4 skew", buf, fpe, 64, N, 4, 0, skew);
+    }
+    // (4) with some arithmetic per step (the real kernel: ~300 VALU per step)
+    for (int lds : {0, 26624}) {
+        run<4, false, 64>("dwordx4 + 64 loop iters", buf, fpe, 16, N, 4, lds);
+        run<4, false, 64>("dwordx4 + 64 loop iters", buf, fpe, 64, N, 4, lds);
+    }
     return 0;
 }

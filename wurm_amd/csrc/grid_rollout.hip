@@ -1,0 +1,455 @@
+// grid_rollout.hip — SingleSnake rollout for grids of 12 x 12 and larger with the env resident in LDS as a CLOCK GRID.
+//
+// Same contract as rollout_kernel (single_snake.hip): T fused iterations of the caller loop
+//     obs, reward, done, info = env.step(actions[t]);  env.reset(done)
+// (tests/test_single_snake_env.py:24-31, experiments/main.py:212-227; step = wurm/envs/single_snake.py:197-304, reset
+// = :322-387), bit-identical to T calls of wurm_single_step / wurm_single_reset.  What differs is where the env lives.
+// The register-resident kernel keeps ceil(S^2/64) body values per lane and touches every one of them on every step
+// (decay, class, colour): 171 VGPRs + ~500 spilled SGPRs at 36 x 36, two waves per SIMD, ~1000 instructions per
+// env-step — its observation stores and its arithmetic add up instead of overlapping (round 1: 3.7 of the 5.3 TB/s a pure
+// store stream reaches).  Here:
+//   * one 16-bit clock per cell in LDS (2.5 KB per 36 x 36 env), lane l owning cells 256 i + 4 l .. + 3 (one ds_read_b64 /
+//     three global_store_dwordx4 per 256 cells): few VGPRs, 8 waves per SIMD — all 8192 envs of BASELINE configs[4]
+//     resident in ONE round — so the store stream of one wave hides behind the others' work;
+//   * the cell holds an EXPIRY CLOCK: body value = max(ex - T, 0).  A step that does not eat advances T ("every body
+//     cell decays", :246-249), one that eats leaves it; only the new head cell is written (ex = T + L = G).  A reset
+//     jumps T past every clock (T = G) instead of clearing the grid.  Nothing is per-cell except the observation;
+//   * ring cells hold the marker EX_RING and the food cell EX_FOOD, so ONE broadcast LDS read of the cell the head
+//     moves to classifies the step: <= T plain move, EX_FOOD eat (:242), EX_RING edge collision (:290-295), anything
+//     else > T self collision (:252); and the head is the one cell with ex == G — the whole observation is a function
+//     of (ex, T, G).  Clocks are re-based (ex -= T) between 64-step chunks before they can reach the markers;
+//   * per-step outputs are kept by lane j for step t0 + j and flushed every 64 steps, as in rollout_kernel.
+// Domain (checked per env at entry; anything else is left untouched, marked GRID_SKIPPED and rolled out by
+// rollout_kernel in a second launch): a well-formed snake — one head, on the unique maximum L >= 2 of the body channel,
+// a unique cell L - 1, at most one food cell, not under the body — strictly inside an empty border ring.  The domain
+// is closed under step + reset.  All observation modes; RNG mode and injected outcomes.
+#include "step_args.hpp"
+#include <algorithm>
+#include <cstdlib>
+
+namespace wurm {
+
+extern __shared__ __attribute__((aligned(16))) unsigned char grid_lds_raw[];
+
+namespace {
+
+constexpr int NO_CELL_G = 1 << 20;
+constexpr int EX_RING = 0xffff;      // border ring and the padding behind the last cell
+constexpr int EX_FOOD = 0xfffe;
+#ifdef GRID_W32
+typedef int cell_t;
+#else
+typedef unsigned short cell_t;
+#endif
+constexpr int EX_MAX_BODY = 0x7000;  // a longer snake (impossible on a 64 x 64 grid) goes to the generic kernel
+constexpr int EX_REBASE = 0xc000;    // re-base the clocks once G passes this (a 64-step chunk adds at most 4 * 64)
+
+typedef unsigned short ushort4v __attribute__((ext_vector_type(4)));
+typedef int int4v __attribute__((ext_vector_type(4)));
+
+struct Grid;
+#ifdef GRID_W32
+__device__ __forceinline__ int4v read4(const cell_t *ex, int c0) { return *(const int4v *)(ex + c0); }
+__device__ __forceinline__ void write4(cell_t *ex, int c0, const int4v &e) { *(int4v *)(ex + c0) = e; }
+#else
+__device__ __forceinline__ int4v read4(const cell_t *ex, int c0)
+{
+    const ushort4v v = *(const ushort4v *)(ex + c0);
+    int4v r = {(int)v.x, (int)v.y, (int)v.z, (int)v.w};
+    return r;
+}
+__device__ __forceinline__ void write4(cell_t *ex, int c0, const int4v &e)
+{
+    const ushort4v e16 = {(cell_t)e.x, (cell_t)e.y, (cell_t)e.z, (cell_t)e.w};
+    *(ushort4v *)(ex + c0) = e16;
+}
+#endif
+typedef float float4v __attribute__((ext_vector_type(4)));
+
+struct Grid {
+    cell_t *ex; // this wave's clock grid, iters * 256 cells
+    int S, C, iters, lane;
+    float rcpS;
+};
+
+__device__ __forceinline__ bool ring_cell(const Grid &g, int c)
+{
+    const int y = div_size(c, g.rcpS), x = c - y * g.S;
+    return y == 0 || x == 0 || y == g.S - 1 || x == g.S - 1;
+}
+
+// K-th cell (row-major) with ex <= T — a free interior cell: markers and live clocks are > T — with K = mulhi(word,
+// number of such cells): the choice add_food / fast_food_cell make (single_snake.py:306-320).  -1 if none is free.
+__device__ __forceinline__ int grid_pick_free(const Grid &g, int T, u32 word)
+{
+    int n_free = 0;
+    for (int it = 0; it < g.iters; ++it) {
+        const int4v e = read4(g.ex, it * 256 + 4 * g.lane);
+        n_free += popc64(ballot(e.x <= T)) + popc64(ballot(e.y <= T)) + popc64(ballot(e.z <= T)) + popc64(ballot(e.w <= T));
+    }
+    if (n_free == 0) return -1;
+    int K = (int)mulhi_range(word, (u32)n_free);
+    for (int it = 0; it < g.iters; ++it) {
+        const int4v e = read4(g.ex, it * 256 + 4 * g.lane);
+        const bool f0 = e.x <= T, f1 = e.y <= T, f2 = e.z <= T, f3 = e.w <= T;
+        const u64 b0 = ballot(f0), b1 = ballot(f1), b2 = ballot(f2), b3 = ballot(f3);
+        const int cnt = popc64(b0) + popc64(b1) + popc64(b2) + popc64(b3);
+        if (K < cnt) {
+            // order inside the 256 cells: lane-major, then the lane's four cells
+            const int below = rank_below(b0) + rank_below(b1) + rank_below(b2) + rank_below(b3);
+            const int mine = (int)f0 + (int)f1 + (int)f2 + (int)f3;
+            const int tl = first_bit(ballot(K >= below && K < below + mine));
+            const int nib = lane_value((int)f0 | ((int)f1 << 1) | ((int)f2 << 2) | ((int)f3 << 3), tl);
+            int r = K - lane_value(below, tl), j = 0;
+            for (; j < 4; ++j) {
+                if ((nib >> j) & 1) {
+                    if (r == 0) break;
+                    --r;
+                }
+            }
+            return it * 256 + 4 * tl + j;
+        }
+        K -= cnt;
+    }
+    return -1;
+}
+
+// what one step leaves for the observation besides the grid itself
+struct StepView {
+    int hc, hy, hx; // head cell (on an edge collision: the ring cell it moved to) and its row / column
+    int food;       // food cell, -1 = none
+    int T, G;
+    int head_body;  // body value under the head: L (+ the value it ran into on a self collision, :252-262)
+};
+
+template <bool VEC>
+__device__ __forceinline__ void store3(float *__restrict__ o, int C, int c0, const float4v &a, const float4v &b, const float4v &c)
+{
+    if (VEC) {
+        if (c0 < C) {
+            *(float4v *)(o + c0) = a;
+            *(float4v *)(o + C + c0) = b;
+            *(float4v *)(o + 2 * C + c0) = c;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (c0 + j < C) {
+                o[c0 + j] = a[j];
+                o[C + c0 + j] = b[j];
+                o[2 * C + c0 + j] = c[j];
+            }
+    }
+}
+
+// _observe of the stepped (pre-reset) state (single_snake.py:130-195) from the clock grid
+template <bool VEC>
+__device__ __forceinline__ void grid_observe(const Grid &g, const StepView &s, float *__restrict__ o, int mode, int n)
+{
+    const int C = g.C, lane = g.lane;
+    if (mode == WURM_OBS_DEFAULT) {
+        // _get_rgb (:104-128): body (0,127,0), head (0,255,0), food (255,0,0) on white, ring black, / 255
+        const float c127 = 127.0f / 255.0f;
+        for (int it = 0; it < g.iters; ++it) {
+            const int c0 = it * 256 + 4 * lane;
+            const int4v e = read4(g.ex, c0);
+            float4v r, gr, b;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int x = e[j];
+                const bool occ = x > s.T;
+                r[j] = occ ? (x == EX_FOOD ? 1.0f : 0.0f) : 1.0f;
+                gr[j] = occ ? (x == s.G ? 1.0f : (x >= EX_FOOD ? 0.0f : c127)) : 1.0f;
+                b[j] = occ ? 0.0f : 1.0f;
+            }
+            store3<VEC>(o, C, c0, r, gr, b);
+        }
+    } else if (mode == WURM_OBS_RAW) { // clone of the state: food, head, body
+        for (int it = 0; it < g.iters; ++it) {
+            const int c0 = it * 256 + 4 * lane;
+            const int4v e = read4(g.ex, c0);
+            float4v f, h, b;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int x = e[j];
+                const bool head = c0 + j == s.hc;
+                f[j] = x == EX_FOOD ? 1.0f : 0.0f;
+                h[j] = head ? 1.0f : 0.0f;
+                b[j] = head ? (float)s.head_body : ((x > s.T && x < EX_FOOD) ? (float)(x - s.T) : 0.0f);
+            }
+            store3<VEC>(o, C, c0, f, h, b);
+        }
+    } else if (mode == WURM_OBS_ONE_CHANNEL) { // :142-151: 0.5 body + 0.5 head + 1.5 food, ring -1
+        for (int it = 0; it < g.iters; ++it) {
+            const int c0 = it * 256 + 4 * lane;
+            const int4v e = read4(g.ex, c0);
+            float4v v;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int x = e[j];
+                v[j] = x == EX_RING ? -1.0f : x == EX_FOOD ? 1.5f : x == s.G ? 1.0f : x > s.T ? 0.5f : 0.0f;
+            }
+            if (VEC) {
+                if (c0 < C) *(float4v *)(o + c0) = v;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (c0 + j < C) o[c0 + j] = v[j];
+            }
+        }
+    } else if (mode == WURM_OBS_PARTIAL) {
+        // (2n+1)^2 crop of the zero-padded RGB image around the head, channel-major (:166-193)
+        const int W = 2 * n + 1, W2 = W * W;
+        const float rcpW = 1.0f / (float)W, c127 = 127.0f / 255.0f;
+        for (int w = lane; w < W2; w += 64) {
+            const int wy = div_size(w, rcpW), wx = w - wy * W;
+            const int y = s.hy - n + wy, x = s.hx - n + wx;
+            int v = EX_RING; // off the grid: F.pad zeros (:179)
+            if (y >= 0 && y < g.S && x >= 0 && x < g.S) v = (int)g.ex[y * g.S + x];
+            const bool occ = v > s.T;
+            o[w] = occ ? (v == EX_FOOD ? 1.0f : 0.0f) : 1.0f;
+            o[W2 + w] = occ ? (v == s.G ? 1.0f : (v >= EX_FOOD ? 0.0f : c127)) : 1.0f;
+            o[2 * W2 + w] = occ ? 0.0f : 1.0f;
+        }
+    } else if (mode == WURM_OBS_POSITIONS) { // head y, x, food y, x (first maximum of an empty channel: cell 0)
+        const int f = s.food < 0 ? 0 : s.food, fy = div_size(f, g.rcpS);
+        if (lane < 4) o[lane] = (float)(lane == 0 ? s.hy : lane == 1 ? s.hx : lane == 2 ? fy : f - fy * g.S);
+    }
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void grid_rollout_kernel(StepArgs p)
+{
+    const int wave = uniform((int)(threadIdx.x >> 6)), wpb = (int)(blockDim.x >> 6);
+    const long long env = (long long)blockIdx.x * wpb + wave;
+    if (env >= p.N) return;
+    Grid g;
+    g.S = p.S;
+    g.C = p.S * p.S;
+    g.iters = (g.C + 255) >> 8;
+    g.lane = (int)(threadIdx.x & 63u);
+    g.rcpS = 1.0f / (float)p.S;
+    g.ex = (cell_t *)grid_lds_raw + wave * (g.iters * 256);
+    const int S = g.S, C = g.C, lane = g.lane;
+    float *envp = p.envs + env * 3 * C;
+    const u64 env_id = (u64)(p.env_offset + env);
+
+    // ---- the state: fp32 [food, head, body] -> clock grid (T = 0: ex = body value), markers on ring and food
+    int lmax = 0, counts = 0, myh = NO_CELL_G, myf = NO_CELL_G;
+    bool bad_l = false;
+    for (int it = 0; it < g.iters; ++it) {
+        const int c0 = it * 256 + 4 * lane;
+        float4v f = {0, 0, 0, 0}, h = {0, 0, 0, 0}, b = {0, 0, 0, 0};
+        if (VEC) {
+            if (c0 < C) {
+                f = *(const float4v *)(envp + c0);
+                h = *(const float4v *)(envp + C + c0);
+                b = *(const float4v *)(envp + 2 * C + c0);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (c0 + j < C) {
+                    f[j] = envp[c0 + j];
+                    h[j] = envp[C + c0 + j];
+                    b[j] = envp[2 * C + c0 + j];
+                }
+        }
+        int4v e;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = c0 + j;
+            const bool inb = c < C, ring = !inb || ring_cell(g, c);
+            const bool fd = f[j] > 0.5f, hd = h[j] > 0.5f; // as load_state reads the channels
+            const int bi = __float2int_rn(b[j]);
+            bad_l |= ring && inb && (fd || hd || bi != 0);   // the ring must be empty
+            bad_l |= fd && (hd || bi != 0);                  // nothing under the food
+            bad_l |= bi < 0 || bi > EX_MAX_BODY;
+            e[j] = ring ? EX_RING : fd ? EX_FOOD : bi;
+            if (!ring && !fd) lmax = max(lmax, bi);
+            counts += (int)hd + ((int)fd << 16);
+            if (hd) myh = min(myh, c);
+            if (fd) myf = min(myf, c);
+        }
+        write4(g.ex, c0, e);
+    }
+    wave_lds_sync();
+    counts = wave_sum_i32(counts);
+    const int nhead = counts & 0xffff, nfood = counts >> 16;
+    int hc = wave_min_i32(myh), food = wave_min_i32(myf), L = wave_max_i32(lmax);
+    if (food >= NO_CELL_G) food = -1;
+    int packed = 0, cL = NO_CELL_G, cN = NO_CELL_G;
+    for (int it = 0; it < g.iters; ++it) {
+        const int c0 = it * 256 + 4 * lane;
+        const int4v e = read4(g.ex, c0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (e[j] == L) { packed += 1; cL = min(cL, c0 + j); }
+            if (e[j] == L - 1) { packed += 1 << 16; cN = min(cN, c0 + j); }
+        }
+    }
+    packed = wave_sum_i32(packed);
+    const int cellL = wave_min_i32(cL), cellN = wave_min_i32(cN);
+    const bool ok = ballot(bad_l) == 0 && nhead == 1 && nfood <= 1 && L >= 2 && (packed & 0xffff) == 1 &&
+                    (packed >> 16) == 1 && cellL == hc && p.T <= (1ll << 26);
+    if (!uniform((int)ok)) { // outside the domain: rollout_kernel takes this env (second launch, only_flagged)
+        if (lane == 0) p.done[env] = GRID_SKIPPED;
+        return;
+    }
+    int hy = div_size(hc, g.rcpS), hx = hc - hy * S;
+    int o;
+    {   // orientation from the two newest cells, as orientation_of / fast_init (wurm/utils.py:36-65)
+        const int yN = div_size(cellN, g.rcpS), xN = cellN - yN * S;
+        const int dy = hy - yN, dx = hx - xN;
+        o = (dy == 0 && dx == 1) ? 1 : (dy == 1 && dx == 0) ? 2 : (dy == 0 && dx == -1) ? 3 : 0;
+    }
+    hc = uniform(hc); hy = uniform(hy); hx = uniform(hx); L = uniform(L); o = uniform(o); food = uniform(food);
+    int G = L, T = 0; // G = T + L
+
+    const bool inj_f = p.inject_food != nullptr, inj_r = p.inject_reset != nullptr;
+    const long long obs_stride = p.N * p.obs_elems;
+    float *obs_t = p.obs + env * p.obs_elems;
+    u64 call = p.call; // step t uses call0 + 2t, its reset call0 + 2t + 1
+
+    for (long long t0 = 0; t0 < p.T; t0 += 64) {
+        const int nt = (int)min((long long)64, p.T - t0);
+        const long long my_t = t0 + lane;
+        long long my_a = lane < nt ? load_action(p.actions, p.act_dtype, my_t * p.N + env) : 0;
+        int my_inj = (inj_f && lane < nt) ? p.inject_food[my_t * p.N + env] : -1;
+        asm volatile("" : "+v"(my_a), "+v"(my_inj)); // retire the prefetch here, not in front of the first readlane
+        const int my_small = (my_a >= 0 && my_a < 4) ? (int)my_a : -1, my_mod = (int)(my_a % 4);
+        int my_out = 0, my_flags = 0; // of step t0 + lane: sanitised action; done | selfc << 1 | edgec << 2 | reward << 3
+        if (G > EX_REBASE) { // keep the 16-bit clocks away from the markers: ex -= T for the live cells, 0 for the rest
+            for (int it = 0; it < g.iters; ++it) {
+                const int c0 = it * 256 + 4 * lane;
+                int4v e = read4(g.ex, c0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) e[q] = e[q] >= EX_FOOD ? e[q] : max(e[q] - T, 0);
+                write4(g.ex, c0, e);
+            }
+            G -= T;
+            T = 0;
+            wave_lds_sync();
+        }
+
+        for (int j = 0; j < nt; ++j, obs_t += obs_stride, call += 2) {
+            // ---- step (single_snake.py:197-304; line references as step_core / fast_step)
+            const int a_small = lane_value(my_small, j), a_mod = lane_value(my_mod, j);
+            const int a_out = o == a_small ? ((o + 2) & 3) : a_mod;                    // :221-222
+            const int ai = a_out & 3, dy = -tap_y(ai), dx = -tap_x(ai);
+            hy += dy; hx += dx; hc += dy * S + dx;                                     // :225-233 (the head was inside the ring)
+            o = (ai + 2) & 3;
+            const int v = uniform((int)g.ex[hc]);                                           // what the head runs into
+            const bool eat = v == EX_FOOD, edgec = v == EX_RING;                       // :242, :290-295
+            G += 1;
+            L += (int)eat;
+            T = G - L;                                                                 // :246-249: no decay on the step that eats
+            const bool selfc = !eat && !edgec && v > T;                                // :252
+            if (!edgec && lane == 0) g.ex[hc] = (cell_t)G;                                     // :258-262 (a ring cell keeps its marker)
+            wave_lds_sync();
+            if (eat) {                                                                 // :270-282
+                if (inj_f) {
+                    const int ic = lane_value(my_inj, j);
+                    food = (ic >= 0 && ic < C && uniform((int)g.ex[ic]) <= T) ? ic : -1;
+                } else {
+                    food = grid_pick_free(g, T, rng_words(p.seed, call, env_id, RNG_FOOD, 0).w[0]);
+                }
+                if (food >= 0 && lane == 0) g.ex[food] = (cell_t)EX_FOOD;
+                wave_lds_sync();
+            }
+            if (p.obs_mode != WURM_OBS_NONE) {
+                StepView s;
+                s.hc = hc; s.hy = hy; s.hx = hx; s.food = food; s.T = T; s.G = G;
+                s.head_body = L + (selfc ? v - T : 0);
+                grid_observe<VEC>(g, s, obs_t, p.obs_mode, p.obs_n);
+            }
+            if (lane == j) {
+                my_out = a_out;
+                my_flags = (int)(selfc | edgec) | ((int)selfc << 1) | ((int)edgec << 2) | ((int)eat << 3);
+            }
+
+            // ---- reset of a finished env (single_snake.py:322-387)
+            if (selfc | edgec) {
+                wave_lds_sync();
+                T = G; // every clock of the dead snake is <= G: the grid is empty without touching it
+                if (food >= 0 && lane == 0) g.ex[food] = 0;
+                int sy, sx, d, fc = -1;
+                Words w;
+                w.w[0] = w.w[1] = w.w[2] = w.w[3] = 0;
+                if (inj_r) {
+                    const int *inj = p.inject_reset + ((t0 + j) * p.N + env) * 4;
+                    sy = uniform(inj[0]); sx = uniform(inj[1]); d = uniform(inj[2]); fc = uniform(inj[3]);
+                } else { // randint(4, S-4) twice, randint(4) (:358-359,366)
+                    w = rng_words(p.seed, call + 1ull, env_id, RNG_RESET, 0);
+                    sy = 4 + (int)mulhi_range(w.w[0], (u32)(S - 8));
+                    sx = 4 + (int)mulhi_range(w.w[1], (u32)(S - 8));
+                    d = (int)(w.w[2] >> 30);
+                }
+                sy = uniform(sy); sx = uniform(sx); d = uniform(d);
+                hy = sy + tap_y(d); hx = sx + tap_x(d);
+                hc = hy * S + hx;
+                const int sc = sy * S + sx, tc = (sy - tap_y(d)) * S + sx - tap_x(d);
+                if (lane == 0) { // conv2d(seed, LENGTH_3_SNAKES[d]) (:372-376)
+                    g.ex[tc] = (cell_t)(T + 1);
+                    g.ex[sc] = (cell_t)(T + 2);
+                    g.ex[hc] = (cell_t)(T + 3);
+                }
+                L = 3;
+                G = T + 3;
+                o = d;
+                wave_lds_sync();
+                if (inj_r) food = (fc >= 0 && fc < C && uniform((int)g.ex[fc]) <= T) ? fc : -1;
+                else food = grid_pick_free(g, T, w.w[3]);                               // :384-385
+                if (food >= 0 && lane == 0) g.ex[food] = (cell_t)EX_FOOD;
+                wave_lds_sync();
+            }
+        }
+        if (lane < nt) {
+            const long long i = my_t * p.N + env;
+            store_action(p.actions, p.act_dtype, i, (long long)my_out);
+            p.reward[i] = (my_flags & 8) ? 1.0f : 0.0f;
+            p.done[i] = (uint8_t)(my_flags & 1);
+            p.selfc[i] = (uint8_t)((my_flags >> 1) & 1);
+            p.edgec[i] = (uint8_t)((my_flags >> 2) & 1);
+        }
+    }
+
+    // ---- back to the reference layout (every done env was reset: the head is on the grid, inside the ring)
+    wave_lds_sync();
+    StepView s;
+    s.hc = hc; s.hy = hy; s.hx = hx; s.food = food; s.T = T; s.G = G; s.head_body = L;
+    grid_observe<VEC>(g, s, envp, WURM_OBS_RAW, 0);
+}
+
+} // namespace
+
+bool grid_rollout_eligible(const StepArgs &p)
+{
+    return p.S >= 12 && p.S <= 64 && p.T <= (1ll << 26);
+}
+
+hipError_t launch_grid_rollout(const StepArgs &p_in, hipStream_t stream)
+{
+    StepArgs p = p_in;
+    const int C = p.S * p.S, iters = (C + 255) >> 8;
+    const int wpb = p.N <= 4096 ? 1 : 4;
+    dim3 block(64 * wpb), grid((unsigned)((p.N + wpb - 1) / wpb));
+    size_t lds = (size_t)iters * 256 * sizeof(cell_t) * wpb;
+    // Residency.  Dynamic LDS is the only per-launch handle on how many waves share a CU.  Measured on MI355X (BASELINE
+    // configs[4], 16-step launches, median of 5 x 20 launches): 0.38-0.39 ms at 8-12 waves per CU, 0.39-0.46 ms with all
+    // 32 resident — with every wave resident the launch runs in lockstep (all probing, then all storing) more often.
+    // The effect is at the edge of the run-to-run noise; 12 is kept, WURM_GRID_WAVES_PER_CU overrides it.
+    int waves_per_cu = 12;
+    if (const char *e = getenv("WURM_GRID_WAVES_PER_CU")) waves_per_cu = std::max(1, atoi(e)); // tuning knob
+    const size_t per_wave_target = (160u * 1024u / (unsigned)waves_per_cu) & ~255u;
+    lds = std::min<size_t>(std::max(lds, per_wave_target * wpb), 64u * 1024u);
+    (void)hipGetLastError();
+    const bool aligned = ((uintptr_t)p.envs % 16 == 0) && ((uintptr_t)p.obs % 16 == 0) &&
+                         (p.obs_elems % 4 == 0 || p.obs_mode == WURM_OBS_PARTIAL || p.obs_mode == WURM_OBS_POSITIONS ||
+                          p.obs_mode == WURM_OBS_NONE);
+    if (C % 4 == 0 && aligned) hipLaunchKernelGGL(grid_rollout_kernel<true>, grid, block, lds, stream, p);
+    else hipLaunchKernelGGL(grid_rollout_kernel<false>, grid, block, lds, stream, p);
+    return hipGetLastError();
+}
+
+} // namespace wurm

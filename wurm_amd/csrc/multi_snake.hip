@@ -923,7 +923,7 @@ __global__ __launch_bounds__(256) void multi_observe_kernel(MultiArgs p)
 // per launch instead of four times per iteration; per iteration only the actions are read and the outputs written.
 //   actions (T,K,N);  out_f32 (T,3,K,N) = rewards, food, sizes;  out_u8 (T,4,K,N) = dones, boost, snake_collision,
 //   edge_collision;  all_done (T,N);  obs (T,K,N,elems).
-__global__ __launch_bounds__(256) void multi_rollout_kernel(MultiArgs p)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void multi_rollout_kernel(MultiArgs p)
 {
     const int wave = (int)(threadIdx.x >> 6), wpb = (int)(blockDim.x >> 6);
     const long long env = (long long)blockIdx.x * wpb + wave;

@@ -14,8 +14,7 @@
 // for the general (irregular-state) orientation stencil.
 // rollout_kernel fuses T step+reset iterations with the env resident in registers; for well-formed start states it
 // carries head cell / length / orientation / food cell as scalars (fast_step) instead of re-deriving them.
-#include "wurm_device.hpp"
-#include "../../include/wurm_hip.h"
+#include "step_args.hpp"
 
 namespace wurm {
 
@@ -472,44 +471,6 @@ __device__ __forceinline__ void write_obs(const Env<CPL> &e, const Geo &g, int h
 
 // ------------------------------------------------------------------------------------------------ kernels
 
-struct StepArgs {
-    float *envs;
-    void *actions;
-    int act_dtype;
-    float *reward;
-    uint8_t *done, *selfc, *edgec;
-    float *obs;
-    int obs_mode, obs_n;
-    long long obs_elems;
-    long long N;
-    int S;
-    long long T;
-    int start_y, start_x;
-    u64 seed, call;
-    long long env_offset;
-    const int *inject_food;
-    const int *inject_reset;
-    const uint8_t *done_in;
-    int lds_per_wave;
-    // fused step (+ deferred / immediate reset): wurm_single_step_reset
-    float *obs_after;
-    uint8_t *done_copy;
-    const int *inject_pre_reset;
-    u64 pre_call;
-    int post_reset;
-};
-
-__device__ __forceinline__ long long load_action(const void *actions, int dtype, long long i)
-{
-    return dtype == WURM_ACT_I64 ? ((const long long *)actions)[i] : (long long)((const int *)actions)[i];
-}
-
-__device__ __forceinline__ void store_action(void *actions, int dtype, long long i, long long v)
-{
-    if (dtype == WURM_ACT_I64) ((long long *)actions)[i] = v;
-    else ((int *)actions)[i] = (int)v;
-}
-
 extern __shared__ __attribute__((aligned(16))) signed char wurm_lds[];
 
 template <int CPL, bool SNAKE>
@@ -537,6 +498,7 @@ __global__ __launch_bounds__(256) void step_kernel(StepArgs p)
         p.reward[env] = out.reward;
         p.done[env] = (uint8_t)out.done;
         p.edgec[env] = (uint8_t)out.edgec;
+        if (p.done_copy) p.done_copy[env] = (uint8_t)out.done;
     }
     if (p.obs_mode != WURM_OBS_NONE)
         write_obs<CPL, SNAKE>(e, g, out.headcell, p.obs + env * p.obs_elems, p.obs_mode, p.obs_n, lds);
@@ -944,6 +906,7 @@ __global__ __launch_bounds__(256) void rollout_kernel(StepArgs p)
     const int wave = uniform((int)(threadIdx.x >> 6)), wpb = (int)(blockDim.x >> 6);
     const long long env = (long long)blockIdx.x * wpb + wave;
     if (env >= p.N) return;
+    if (p.only_flagged && uniform((int)p.done[env]) != (int)GRID_SKIPPED) return; // the grid kernel rolled this env out
     signed char *lds = wurm_lds + wave * p.lds_per_wave;
     const Geo g = make_geo<CPL>(p.S);
     float *envp = p.envs + env * (SNAKE ? 3 : 2) * g.C;
@@ -1548,6 +1511,17 @@ static hipError_t launch_one(Kind kind, const StepArgs &p, dim3 grid, dim3 block
     case K_OBSERVE: hipLaunchKernelGGL((observe_kernel<CPL, SNAKE>), grid, block, lds, st, p); break;
     case K_FUSED: hipLaunchKernelGGL((fused_step_kernel<CPL, SNAKE>), grid, block, lds, st, p); break;
     case K_ROLLOUT:
+        if constexpr (SNAKE && CPL >= 4) {
+            if (grid_rollout_eligible(p)) {
+                // LDS-resident clock grid (grid_rollout.hip); then the generic kernel for the envs it could not take
+                hipError_t err = launch_grid_rollout(p, st);
+                if (err != hipSuccess) return err;
+                StepArgs q = p;
+                q.only_flagged = 1;
+                hipLaunchKernelGGL((rollout_kernel<CPL, SNAKE>), grid, block, lds, st, q);
+                break;
+            }
+        }
         if constexpr (SNAKE && CPL == 2) {
             const bool rng_mode = p.inject_food == nullptr && p.inject_reset == nullptr;
             if (rng_mode && p.S >= 9 && ((p.obs_mode == WURM_OBS_PARTIAL && p.obs_n <= 3) || p.obs_mode == WURM_OBS_NONE)) {
@@ -1727,7 +1701,9 @@ static int fused_entry(bool snake, const wurm_single_call *c, void *stream)
     p.inject_food = c->inject_food; p.inject_reset = c->inject_reset; p.done_in = c->pre_done;
     p.obs_after = c->obs_after; p.done_copy = c->done_copy; p.inject_pre_reset = c->inject_pre_reset;
     p.pre_call = c->pre_call; p.post_reset = c->post_reset;
-    return snake ? launch<true>(K_FUSED, p, stream) : launch<false>(K_FUSED, p, stream);
+    // nothing to rebuild and no second observation: the plain step kernel (lighter on registers for large grids)
+    const Kind kind = resets ? K_FUSED : K_STEP;
+    return snake ? launch<true>(kind, p, stream) : launch<false>(kind, p, stream);
 }
 
 int wurm_single_step_reset(const wurm_single_call *c, void *stream) { return fused_entry(true, c, stream); }

@@ -1,0 +1,55 @@
+// step_args.hpp — the kernel argument block and action accessors shared by the SingleSnake / SimpleGridworld
+// translation units (single_snake.hip, grid_rollout.hip).
+#pragma once
+
+#include "wurm_device.hpp"
+#include "../../include/wurm_hip.h"
+
+namespace wurm {
+
+struct StepArgs {
+    float *envs;
+    void *actions;
+    int act_dtype;
+    float *reward;
+    uint8_t *done, *selfc, *edgec;
+    float *obs;
+    int obs_mode, obs_n;
+    long long obs_elems;
+    long long N;
+    int S;
+    long long T;
+    int start_y, start_x;
+    u64 seed, call;
+    long long env_offset;
+    const int *inject_food;
+    const int *inject_reset;
+    const uint8_t *done_in;
+    int lds_per_wave;
+    // fused step (+ deferred / immediate reset): wurm_single_step_reset
+    float *obs_after;
+    uint8_t *done_copy;
+    const int *inject_pre_reset;
+    u64 pre_call;
+    int post_reset;
+    int only_flagged; // rollout_kernel: process only the envs the grid kernel marked GRID_SKIPPED in done[0][env]
+};
+
+__device__ __forceinline__ long long load_action(const void *actions, int dtype, long long i)
+{
+    return dtype == WURM_ACT_I64 ? ((const long long *)actions)[i] : (long long)((const int *)actions)[i];
+}
+
+__device__ __forceinline__ void store_action(void *actions, int dtype, long long i, long long v)
+{
+    if (dtype == WURM_ACT_I64) ((long long *)actions)[i] = v;
+    else ((int *)actions)[i] = (int)v;
+}
+
+// LDS-resident clock-grid rollout (grid_rollout.hip): true if it took the launch (SingleSnake, S >= 12).  Envs whose
+// state is outside its domain are left untouched and marked with done[0][env] = GRID_SKIPPED for the generic kernel.
+constexpr uint8_t GRID_SKIPPED = 0xFF;
+bool grid_rollout_eligible(const StepArgs &p);
+hipError_t launch_grid_rollout(const StepArgs &p, hipStream_t stream);
+
+} // namespace wurm
