@@ -11,6 +11,9 @@
 //   * the env's K body grids live in LDS as 16-bit cells [K][S*S] (bit 15 = "must be written back"), the food grid
 //     as bytes; lane l owns cells l + 64k of every grid, so HBM traffic is coalesced dword runs and every grid
 //     update is a conflict-free LDS access;
+//   * a body cell holds an EXPIRY CLOCK, not a value: value = max(ex - T_s, 0) with one clock T_s per snake.  "Every
+//     body cell of a mover decays by one" (:523-526 / :627-628) is T_s += 1, deleting a dead snake (:595-596 /
+//     :676-677) is T_s = CLOCK_DEAD — no pass over the grid; only the new head segment is written;
 //   * per-SNAKE scalars (head cell, length, done, orientation, reward ...) live one per lane in lanes 0..K-1, so
 //     the snake-level logic of all K snakes runs in parallel and exchanges values with shuffles / ballots;
 //   * cross-cell lookups (food under a head, bodies under a head) are single LDS reads at the head cell.
@@ -22,6 +25,11 @@ namespace wurm {
 
 constexpr unsigned short DIRTY = 0x8000u;
 constexpr unsigned short VMASK = 0x7fffu;
+constexpr int CLOCK_DEAD = 0x7fff;   // clock of a deleted snake: every cell of its grid reads 0
+#ifndef WURM_MULTI_CLOCK_REBASE
+#define WURM_MULTI_CLOCK_REBASE 0x3000
+#endif
+constexpr int CLOCK_REBASE = WURM_MULTI_CLOCK_REBASE; // rollout: re-base a snake's grid (ex -= T) past this clock
 
 struct MultiArgs {
     float *foods, *heads, *bodies;
@@ -53,7 +61,7 @@ struct MultiArgs {
     uint8_t *am_u8;
     long long T;          // rollout: number of fused step+reset iterations
     uint8_t *boost_state; // rollout: boost_this_step (N*K) written back at the end
-    int lds_per_wave, off_body, off_food, off_occ, off_img, off_col;
+    int lds_per_wave, off_body, off_food, off_occ, off_hmap, off_img, off_col;
 };
 
 struct Ctx {
@@ -61,9 +69,11 @@ struct Ctx {
     float rcpS;
     int *hcell;            // [K] head cell per snake (-1 = none)
     int *lmax;             // [K] max body value per snake
-    unsigned short *body;  // [K][C]
+    int *tclk;             // [K] clock per snake: body value = max(ex - tclk, 0)
+    unsigned short *body;  // [K][C] expiry clocks (low 15 bits) | DIRTY
     unsigned char *food;   // [C]
     unsigned char *occ;    // [C] scratch (reset: occupancy)
+    unsigned char *hmap;   // [C] head owner + 1 per cell, all-zero outside observe_full
     short *img;            // [3][C] env image (partial_n)
     float *colf;           // [K][4]: r, g, b, 1 + 0.5*boost
 };
@@ -82,15 +92,21 @@ __device__ __forceinline__ Ctx make_ctx(const MultiArgs &p, int wave)
     cx.rcpS = 1.0f / (float)p.S;
     cx.hcell = (int *)base;
     cx.lmax = (int *)(base + 4 * p.K);
+    cx.tclk = (int *)(base + 8 * p.K);
     cx.body = (unsigned short *)(base + p.off_body);
     cx.food = base + p.off_food;
     cx.occ = base + p.off_occ;
+    cx.hmap = base + p.off_hmap;
     cx.img = (short *)(base + p.off_img);
     cx.colf = (float *)(base + p.off_col);
     return cx;
 }
 
-__device__ __forceinline__ int BV(const Ctx &cx, int s, int c) { return cx.body[s * cx.C + c] & VMASK; }
+// body value of snake s at cell c
+__device__ __forceinline__ int BV(const Ctx &cx, int s, int c)
+{
+    return max((int)(cx.body[s * cx.C + c] & VMASK) - cx.tclk[s], 0);
+}
 
 // ------------------------------------------------------------------------------------------------ load / store
 
@@ -107,7 +123,9 @@ __device__ __forceinline__ u64 load_env(const Ctx &cx, const float *__restrict__
     if (lane < cx.K) {
         cx.hcell[lane] = -1;
         cx.lmax[lane] = 0;
+        cx.tclk[lane] = 0; // values are loaded as they are: ex = value
     }
+    for (int c = lane; c < C; c += 64) cx.hmap[c] = 0;
     wave_lds_sync();
     const float rcpC = 1.0f / (float)C;
     for (int base = 0; base < KC; base += 64 * LOAD_CHUNK) {
@@ -162,13 +180,14 @@ __device__ __forceinline__ void store_env(const Ctx &cx, float *__restrict__ foo
     const int C = cx.C, lane = cx.lane;
     for (int s = 0; s < cx.K; ++s) {
         float *bp = bodyp + (size_t)s * C, *hp = headp + (size_t)s * C;
-        int hs = cx.hcell[s];
+        const int hs = cx.hcell[s], T = cx.tclk[s];
 #pragma unroll 4
         for (int k = 0; k < cx.cpl; ++k) {
             int c = lane + 64 * k;
             if (c < C) {
-                unsigned short v = cx.body[s * C + c];
-                if (full || (v & DIRTY)) bp[c] = (float)(v & VMASK);
+                const unsigned short v = cx.body[s * C + c];
+                // changed since the load: written cells, and — once the clock has moved — every cell that held a value
+                if (full || (v & DIRTY) || (T != 0 && (v & VMASK))) bp[c] = (float)max((int)(v & VMASK) - T, 0);
                 if (full) hp[c] = (c == hs) ? 1.0f : 0.0f;
             }
         }
@@ -206,21 +225,8 @@ __device__ __forceinline__ void run_phase(const Ctx &cx, bool who, int dir, int 
     const bool ov = snake && hc >= 0 && cx.food[hc] != 0;
     wave_lds_sync();
     if (ov) cx.food[hc] = 0;
-    // decay the movers that did not eat (:523-526 / :627-628)
-    u64 m = ballot(who && !ov);
-    while (m) {
-        int s = first_bit(m);
-        m &= m - 1;
-        unsigned short *b = cx.body + s * C;
-#pragma unroll 4
-        for (int k = 0; k < cx.cpl; ++k) {
-            int c = lane + 64 * k;
-            if (c < C) {
-                int v = b[c] & VMASK;
-                if (v > 0) b[c] = (unsigned short)((v - 1) | DIRTY);
-            }
-        }
-    }
+    // decay the movers that did not eat (:523-526 / :627-628): their clock advances
+    if (who && !ov) cx.tclk[lane] += 1;
     if (who && ov) { // :527-529 / :629-631
         reward += 1.0f;
         foodcons += 1.0f;
@@ -244,7 +250,7 @@ __device__ __forceinline__ void run_phase(const Ctx &cx, bool who, int dir, int 
     // new head segment (:552-555 / :649-652)
     if (who && hc >= 0) {
         int v = BV(cx, lane, hc);
-        cx.body[lane * C + hc] = (unsigned short)(((v + L + (ov ? 1 : 0)) & VMASK) | DIRTY);
+        cx.body[lane * C + hc] = (unsigned short)(((cx.tclk[lane] + v + L + (ov ? 1 : 0)) & VMASK) | DIRTY);
     }
     if (who && ov) L += 1;
     // edge collisions (:560-562 / :657-659)
@@ -286,21 +292,38 @@ __device__ __forceinline__ void food_from_death(const Ctx &cx, bool done, bool h
 // delete done snakes (:595-596 / :676-677)
 __device__ __forceinline__ void delete_done(const Ctx &cx, bool done, bool &has_body, int &hc)
 {
-    const int C = cx.C, lane = cx.lane;
-    u64 m = ballot(lane < cx.K && done && has_body);
-    while (m) {
-        int s = first_bit(m);
-        m &= m - 1;
-        unsigned short *b = cx.body + s * C;
-        for (int k = 0; k < cx.cpl; ++k) {
-            int c = lane + 64 * k;
-            if (c < C && (b[c] & VMASK)) b[c] = DIRTY;
-        }
-    }
+    const int lane = cx.lane;
     if (lane < cx.K && done) {
+        if (has_body) cx.tclk[lane] = CLOCK_DEAD; // every cell of the grid now reads 0
         has_body = false;
         hc = -1;
     }
+    wave_lds_sync();
+}
+
+// keeps the 15-bit clocks of long-lived snakes away from the top of their range: ex -= T, T = 0 (values unchanged)
+__device__ __forceinline__ void rebase_clocks(const Ctx &cx)
+{
+    const int C = cx.C, lane = cx.lane;
+    const int myT = lane < cx.K ? cx.tclk[lane] : 0;
+    u64 m = ballot(lane < cx.K && myT > CLOCK_REBASE && myT < CLOCK_DEAD);
+    if (!m) return;
+    const u64 mine = m;
+    while (m) {
+        const int s = first_bit(m);
+        m &= m - 1;
+        unsigned short *b = cx.body + s * C;
+        const int T = cx.tclk[s];
+        for (int k = 0; k < cx.cpl; ++k) {
+            const int c = lane + 64 * k;
+            if (c < C) {
+                const unsigned short v = b[c];
+                if (v & VMASK) b[c] = (unsigned short)((v & DIRTY) | max((int)(v & VMASK) - T, 0));
+            }
+        }
+    }
+    wave_lds_sync();
+    if ((mine >> lane) & 1) cx.tclk[lane] = 0;
     wave_lds_sync();
 }
 
@@ -360,55 +383,66 @@ __device__ __forceinline__ int count_bits(const Ctx &cx, u64 bits)
 
 // ------------------------------------------------------------------------------------------------ observations
 
-// 'full' observation (_observe_agent :268-281 + _make_generic_rgb :175-192) of every agent from LDS
+// 'full' observation (_observe_agent :268-281 + _make_generic_rgb :175-192) of every agent from LDS.
+// Per row of 64 cells the class of each cell is worked out ONCE (K clock compares, head owner, food); what an agent
+// sees that has neither its head nor its body on the cell — border (0,0,0), somebody's head (0,0,192), somebody's body
+// (0,0,96), food (255,0,0), background (255,255,255) — is the same for every agent, so rows without any snake cell (most
+// of them) store the same three registers K times, and the per-agent priority chain runs only in rows that hold a
+// snake.  Stores take the scalar base of (agent, env) plus a 32-bit lane offset.
+__device__ __forceinline__ void store_rgb(float *base, u32 off0, u32 off1, u32 off2, float r, float g, float b)
+{
+    asm volatile("global_store_dword %0, %1, %6\n\tglobal_store_dword %2, %3, %6\n\tglobal_store_dword %4, %5, %6"
+                 : : "v"(off0), "v"(r), "v"(off1), "v"(g), "v"(off2), "v"(b), "s"(base) : "memory");
+}
+
 __device__ __forceinline__ void observe_full(const Ctx &cx, const MultiArgs &p, float *__restrict__ obs,
                                              long long env, int hc)
 {
     const int S = cx.S, C = cx.C, K = cx.K, lane = cx.lane;
-    // head owner per cell: occ[c] = 1 + snake index (consistent states have at most one head per cell)
-    for (int k = 0; k < cx.cpl; ++k) {
-        int c = lane + 64 * k;
-        if (c < C) cx.occ[c] = 0;
-    }
-    wave_lds_sync();
-    if (lane < K && hc >= 0) cx.occ[hc] = (unsigned char)(lane + 1);
+    // head owner per cell: hmap[c] = 1 + snake index (consistent states have at most one head per cell)
+    if (lane < K && hc >= 0) cx.hmap[hc] = (unsigned char)(lane + 1);
     wave_lds_sync();
     const float G1 = 192.0f / 255.0f, G2 = 96.0f / 255.0f;
+    // agent 0's observation of this env (wave-uniform: told to the compiler so that it lives in SGPRs)
+    float *const obs_env = (float *)uniform64((long long)(obs + env * p.obs_elems));
+    const long long agent_stride = p.N * p.obs_elems;    // to the next agent's
     for (int k = 0; k < cx.cpl; ++k) {
-        int c = lane + 64 * k;
-        if (c >= C) continue;
-        int y = div_size(c, cx.rcpS), x = c - y * S;
-        bool edge = y == 0 || x == 0 || y == S - 1 || x == S - 1;
-        u64 bm = 0;
-#pragma unroll 4
-        for (int s = 0; s < K; ++s) bm |= (u64)(BV(cx, s, c) > 0) << s;
-        int ho = (int)cx.occ[c] - 1;
-        bool fd = cx.food[c] != 0;
-        // What an agent sees that has neither its head nor its body on this cell: border (0,0,0), somebody's head
-        // (0,0,192), somebody's body (0,0,96), food (255,0,0), background (255,255,255).  Most (cell row, agent) pairs
-        // are of this kind, so the per-agent priority chain below runs only for rows where a lane holds that agent.
-        const bool snake_here = !edge && (ho >= 0 || bm != 0);
+        const int c = lane + 64 * k;
+        const bool valid = c < C;
+        const int cc = valid ? c : 0;
+        const int y = div_size(cc, cx.rcpS), x = cc - y * S;
+        const bool edge = y == 0 || x == 0 || y == S - 1 || x == S - 1;
+        u64 bm = 0; // bit s: snake s has body on this cell
+        for (int s = 0; s < K; ++s) bm |= (u64)((int)(cx.body[s * C + cc] & VMASK) > cx.tclk[s]) << s;
+        const int ho = (int)cx.hmap[cc] - 1;
+        const bool fd = cx.food[cc] != 0;
+        const bool snake_here = valid && !edge && (ho >= 0 || bm != 0);
         const float ro = (edge || snake_here) ? 0.0f : 1.0f;
         const float go = (edge || snake_here || fd) ? 0.0f : 1.0f;
         const float bo = edge ? 0.0f : (ho >= 0 ? G1 : (bm != 0 ? G2 : (fd ? 0.0f : 1.0f)));
+        const u32 o0 = (u32)cc * 4u, o1 = (u32)(C + cc) * 4u, o2 = (u32)(2 * C + cc) * 4u;
         const bool row_has_snake = ballot(snake_here) != 0;
-        for (int a = 0; a < K; ++a) {
-            float r = ro, g = go, b = bo;
-            if (row_has_snake) {
-                const bool mine = snake_here && (ho == a || ((bm >> a) & 1));
-                if (ballot(mine) != 0 && mine) {
-                    if (ho >= 0 && ho != a) { r = 0.0f; g = 0.0f; b = G1; }             // other head (0,0,192)
-                    else if (bm & ~(1ull << a)) { r = 0.0f; g = 0.0f; b = G2; }         // other body (0,0,96)
-                    else if (ho == a) { r = 0.0f; g = G1; b = 0.0f; }                   // own head (0,192,0)
-                    else { r = 0.0f; g = G2; b = 0.0f; }                                // own body (0,96,0)
+        float *base = obs_env;
+        if (valid) {
+            if (!row_has_snake) {
+                for (int a = 0; a < K; ++a, base += agent_stride) store_rgb(base, o0, o1, o2, ro, go, bo);
+            } else {
+                for (int a = 0; a < K; ++a, base += agent_stride) {
+                    float r = ro, g = go, b = bo;
+                    if (snake_here && (ho == a || ((bm >> a) & 1))) {
+                        // an agent with its own head or body on the cell: the reference's paint order
+                        if (ho >= 0 && ho != a) { r = 0.0f; g = 0.0f; b = G1; }             // other head (0,0,192)
+                        else if (bm & ~(1ull << a)) { r = 0.0f; g = 0.0f; b = G2; }         // other body (0,0,96)
+                        else if (ho == a) { r = 0.0f; g = G1; b = 0.0f; }                   // own head (0,192,0)
+                        else { r = 0.0f; g = G2; b = 0.0f; }                                // own body (0,96,0)
+                    }
+                    store_rgb(base, o0, o1, o2, r, g, b);
                 }
             }
-            float *o = obs + ((long long)a * p.N + env) * p.obs_elems;
-            o[c] = r;
-            o[C + c] = g;
-            o[2 * C + c] = b;
         }
     }
+    wave_lds_sync();
+    if (lane < K && hc >= 0) cx.hmap[hc] = 0;
     wave_lds_sync();
 }
 
@@ -538,20 +572,18 @@ __device__ __forceinline__ void multi_step_body(const Ctx &cx, const MultiArgs &
             else pay = u01(rng_words(p.seed, call, env_id, RNG_BOOST_COST, (u32)lane).w[0]) < p.cfg.boost_cost_prob;
         }
         u64 m = ballot(pay);
-        while (m) {
+        while (m) { // the tail cell (value 1) becomes food; the decay itself is the clock
             int s = first_bit(m);
             m &= m - 1;
-            unsigned short *b = cx.body + s * C;
+            const unsigned short *b = cx.body + s * C;
+            const int tail = cx.tclk[s] + 1;
             for (int k = 0; k < cx.cpl; ++k) {
                 int c = lane + 64 * k;
-                if (c < C) {
-                    int v = b[c] & VMASK;
-                    if (v == 1) cx.food[c] = 1;
-                    if (v > 0) b[c] = (unsigned short)((v - 1) | DIRTY);
-                }
+                if (c < C && (int)(b[c] & VMASK) == tail) cx.food[c] = 1;
             }
         }
         if (pay) {
+            cx.tclk[lane] += 1;
             reward -= 1.0f;
             L -= 1;
         }
@@ -766,8 +798,9 @@ __device__ __forceinline__ void multi_reset_grid(const Ctx &cx, const MultiArgs 
         for (int i = lane; i < K * C; i += 64) cx.body[i] = 0;
         for (int k = 0; k < cx.cpl; ++k) {
             int c = lane + 64 * k;
-            if (c < C) { cx.food[c] = 0; cx.occ[c] = 0; }
+            if (c < C) { cx.food[c] = 0; cx.occ[c] = 0; cx.hmap[c] = 0; }
         }
+        if (snake) cx.tclk[lane] = 0;
         wave_lds_sync();
         sn.hc = -1;
         for (int s = 0; s < K; ++s) { // _add_snake (:911-994), one snake after another
@@ -822,11 +855,13 @@ __device__ __forceinline__ void multi_reset_grid(const Ctx &cx, const MultiArgs 
             if (n > 0) cell = selected_cell(rank_select(cx, av, (int)mulhi_range(w.w[0], (u32)n)));
         }
         cell = uniform(cell);
-        // bodies[first] = new_bodies (:826): the dead snake's grid is replaced (it is all-zero in consistent states)
+        // bodies[first] = new_bodies (:826): the dead snake's grid is replaced (it reads all-zero in consistent
+        // states: its clock is CLOCK_DEAD) and its clock restarts
         for (int k = 0; k < cx.cpl; ++k) {
             int c = lane + 64 * k;
             if (c < C && (cx.body[f * C + c] & VMASK)) cx.body[f * C + c] = DIRTY;
         }
+        if (lane == f) cx.tclk[lane] = 0;
         wave_lds_sync();
         int h = place_snake(cx, f, cell, dnew);
         if (lane == f) {
@@ -964,6 +999,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void m
         }
         if (lane == 0) p.all_done[t * p.N + env] = (uint8_t)r.all_done;
         if (p.obs_mode != WURM_OBS_NONE) observe(cx, p, p.obs + t * KN * p.obs_elems, env, sn);
+        rebase_clocks(cx);
 
         // reset(dones['__all__']) (:771-836)
         if (snake && sn.done) sn.L = 0;           // deleted snakes have an all-zero body
@@ -1062,7 +1098,7 @@ __global__ void multi_colours_kernel(short *colours, long long N, int K, int fix
 static int multi_layout(MultiArgs &p, bool need_img)
 {
     const int C = p.S * p.S, K = p.K;
-    int off = 8 * K;                       // hcell, lmax
+    int off = 12 * K;                      // hcell, lmax, tclk
     p.off_col = off; off += 16 * K;        // colf
     off = (off + 15) & ~15;
     p.off_body = off; off += 2 * K * C;
@@ -1070,6 +1106,8 @@ static int multi_layout(MultiArgs &p, bool need_img)
     p.off_food = off; off += C;
     off = (off + 15) & ~15;
     p.off_occ = off; off += C;
+    off = (off + 15) & ~15;
+    p.off_hmap = off; off += C;
     off = (off + 15) & ~15;
     p.off_img = off; if (need_img) off += 6 * C;
     p.lds_per_wave = (off + 15) & ~15;
