@@ -61,7 +61,7 @@ struct MultiArgs {
     uint8_t *am_u8;
     long long T;          // rollout: number of fused step+reset iterations
     uint8_t *boost_state; // rollout: boost_this_step (N*K) written back at the end
-    int lds_per_wave, off_body, off_food, off_occ, off_hmap, off_img, off_col;
+    int lds_per_wave, off_body, off_food, off_occ, off_hmap, off_img, off_col, off_snap;
 };
 
 struct Ctx {
@@ -74,6 +74,7 @@ struct Ctx {
     unsigned char *food;   // [C]
     unsigned char *occ;    // [C] scratch (reset: occupancy)
     unsigned char *hmap;   // [C] head owner + 1 per cell, all-zero outside observe_full
+    unsigned short *snap;  // [C] observe_full_snap: class code per cell
     short *img;            // [3][C] env image (partial_n)
     float *colf;           // [K][4]: r, g, b, 1 + 0.5*boost
 };
@@ -97,6 +98,7 @@ __device__ __forceinline__ Ctx make_ctx(const MultiArgs &p, int wave)
     cx.food = base + p.off_food;
     cx.occ = base + p.off_occ;
     cx.hmap = base + p.off_hmap;
+    cx.snap = (unsigned short *)(base + (p.off_snap >= 0 ? p.off_snap : 0));
     cx.img = (short *)(base + p.off_img);
     cx.colf = (float *)(base + p.off_col);
     return cx;
@@ -446,6 +448,65 @@ __device__ __forceinline__ void observe_full(const Ctx &cx, const MultiArgs &p, 
     wave_lds_sync();
 }
 
+// 'full' observation of at most 8 snakes, agent-major.  With 4096 envs in flight the row-major order of observe_full
+// means ~49 000 concurrent 256-byte write streams (every row of 64 cells touches all K agents' regions, megabytes
+// apart); a pure store kernel in that order reaches 3.6 TB/s, agent by agent — one contiguous 3 * S * S float region
+// at a time per wave — 4.8 TB/s (tools/microbench/store_pattern.hip).  So the class of every cell is first written to
+// LDS as a 16-bit code (K clock compares, head owner, food, border: once per cell), then each agent's three planes are
+// produced from the codes:   code = body mask of snakes 0..7 | (head owner + 1) << 8 | food << 14 | border << 15
+// (Also tried, measured, dropped: issuing these stores in four parts between the phases of the NEXT step, so that the
+// store queue would drain while the wave computes — no gain: the waves of a launch stall on the store path together.)
+__device__ __forceinline__ void observe_full_snap(const Ctx &cx, const MultiArgs &p, float *__restrict__ obs,
+                                                  long long env, int hc)
+{
+    const int S = cx.S, C = cx.C, K = cx.K, lane = cx.lane;
+    if (lane < K && hc >= 0) cx.hmap[hc] = (unsigned char)(lane + 1);
+    wave_lds_sync();
+    for (int k = 0; k < cx.cpl; ++k) {
+        const int c = lane + 64 * k;
+        if (c < C) {
+            const int y = div_size(c, cx.rcpS), x = c - y * S;
+            const bool edge = y == 0 || x == 0 || y == S - 1 || x == S - 1;
+            u32 v = 0;
+            for (int s = 0; s < K; ++s) v |= (u32)((int)(cx.body[s * C + c] & VMASK) > cx.tclk[s]) << s;
+            v |= (u32)cx.hmap[c] << 8;
+            v |= (u32)(cx.food[c] != 0) << 14;
+            v |= (u32)edge << 15;
+            cx.snap[c] = (unsigned short)v;
+        }
+    }
+    wave_lds_sync();
+    if (lane < K && hc >= 0) cx.hmap[hc] = 0;
+    const float G1 = 192.0f / 255.0f, G2 = 96.0f / 255.0f;
+    float *const obs_env = (float *)uniform64((long long)(obs + env * p.obs_elems)); // agent 0's observation of this env
+    const long long agent_stride = p.N * p.obs_elems;
+    for (int a = 0; a < K; ++a) {
+        float *const base = obs_env + a * agent_stride;
+        for (int k = 0; k < cx.cpl; ++k) {
+            const int c = lane + 64 * k;
+            if (c < C) {
+                const u32 v = (u32)cx.snap[c];
+                const bool edge = (v >> 15) != 0, fd = ((v >> 14) & 1u) != 0;
+                const int ho = (int)((v >> 8) & 15u) - 1;
+                const u32 bm = v & 0xffu;
+                const bool snake_here = !edge && (ho >= 0 || bm != 0);
+                // border (0,0,0), somebody's head (0,0,192), somebody's body (0,0,96), food (255,0,0), background white
+                float r = (edge || snake_here) ? 0.0f : 1.0f;
+                float g = (edge || snake_here || fd) ? 0.0f : 1.0f;
+                float b = edge ? 0.0f : (ho >= 0 ? G1 : (bm != 0 ? G2 : (fd ? 0.0f : 1.0f)));
+                if (snake_here && (ho == a || ((bm >> a) & 1u))) { // own head or body here: the reference's paint order
+                    if (ho >= 0 && ho != a) { r = 0.0f; g = 0.0f; b = G1; }          // other head (0,0,192)
+                    else if (bm & ~(1u << a)) { r = 0.0f; g = 0.0f; b = G2; }         // other body (0,0,96)
+                    else if (ho == a) { r = 0.0f; g = G1; b = 0.0f; }                // own head (0,192,0)
+                    else { r = 0.0f; g = G2; b = 0.0f; }                             // own body (0,96,0)
+                }
+                store_rgb(base, (u32)c * 4u, (u32)(C + c) * 4u, (u32)(2 * C + c) * 4u, r, g, b);
+            }
+        }
+    }
+    wave_lds_sync();
+}
+
 // Per-snake state, one snake per lane (lanes 0..K-1), carried through a step / reset / rollout.
 struct Snake {
     int hc;           // head cell, -1 = none
@@ -519,7 +580,10 @@ __device__ __forceinline__ void observe_partial(const Ctx &cx, const MultiArgs &
 __device__ __forceinline__ void observe(const Ctx &cx, const MultiArgs &p, float *__restrict__ obs, long long env,
                                         const Snake &sn)
 {
-    if (p.obs_mode == WURM_OBS_DEFAULT) observe_full(cx, p, obs, env, sn.hc);
+    if (p.obs_mode == WURM_OBS_DEFAULT) {
+        if (p.off_snap >= 0) observe_full_snap(cx, p, obs, env, sn.hc);
+        else observe_full(cx, p, obs, env, sn.hc);
+    }
     else if (p.obs_mode == WURM_OBS_PARTIAL) observe_partial(cx, p, obs, env, sn);
 }
 
@@ -1095,7 +1159,7 @@ __global__ void multi_colours_kernel(short *colours, long long N, int K, int fix
 
 // ------------------------------------------------------------------------------------------------ host side
 
-static int multi_layout(MultiArgs &p, bool need_img)
+static int multi_layout(MultiArgs &p, bool need_img, bool need_snap)
 {
     const int C = p.S * p.S, K = p.K;
     int off = 12 * K;                      // hcell, lmax, tclk
@@ -1110,6 +1174,9 @@ static int multi_layout(MultiArgs &p, bool need_img)
     p.off_hmap = off; off += C;
     off = (off + 15) & ~15;
     p.off_img = off; if (need_img) off += 6 * C;
+    off = (off + 15) & ~15;
+    p.off_snap = -1;
+    if (need_snap) { p.off_snap = off; off += 2 * C; }
     p.lds_per_wave = (off + 15) & ~15;
     return p.lds_per_wave;
 }
@@ -1119,9 +1186,12 @@ enum MKind { MK_STEP, MK_RESET, MK_OBSERVE, MK_CHECK, MK_ROLLOUT };
 static int multi_launch(MKind kind, MultiArgs &p, void *stream)
 {
     if (p.N == 0) return WURM_OK;
-    const int lds = multi_layout(p, p.obs_mode == WURM_OBS_PARTIAL);
+    // 'full' observations of at most 8 snakes go through a per-cell class code in LDS (observe_full_snap)
+    const int lds = multi_layout(p, p.obs_mode == WURM_OBS_PARTIAL, p.obs_mode == WURM_OBS_DEFAULT && p.K <= 8);
     if (lds > 65536) return WURM_ERR_UNSUPPORTED;
-    int wpb = p.N <= 4096 ? 1 : 4;
+    // few envs: one wave per workgroup so that they spread over all 256 CUs; from 2048 envs on 4 waves per workgroup
+    // (8 workgroups per CU either way; the observation stream of 4096 envs measured ~5 % faster this way)
+    int wpb = p.N < 2048 ? 1 : 4;
     while (wpb > 1 && lds * wpb > 65536) wpb >>= 1;
     dim3 block(64 * wpb), grid((unsigned)((p.N + wpb - 1) / wpb));
     size_t shmem = kind == MK_CHECK ? 0 : (size_t)lds * wpb;
