@@ -2,15 +2,16 @@
 # Re-creates the artefacts under profiles/ on the GPU box (run through gpurun from the repo root):
 #   bash tools/collect_profiles.sh <tag>      ->  gpurun_out/profiles_<tag>/
 # rocprofv3 is always given the program itself after `--` and counters are collected in their own passes.
-TAG=${1:-r01}
+TAG=${1:-r02}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/profiles_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-# 1. the bench line (un-profiled)
+# 1. the bench line (un-profiled), exactly as the driver runs it, and with the defaults
 python3 $R/bench.py > $OUT/${TAG}_bench_cfg2.json 2> $OUT/bench.err
-# 2. kernel trace + stats of the same command (short form)
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o $TAG -- python3 $R/bench.py --steps 32768 --warmup 2048 --no-extra --no-cpu-baseline > $OUT/${TAG}_cfg2_rollout_bench_under_rocprof.json 2> $OUT/trace.err
+python3 $R/bench.py --steps 20 --warmup 5 --no-extra --no-cpu-baseline > $OUT/${TAG}_bench_cfg2_steps20.json 2>> $OUT/bench.err
+# 2. kernel trace + stats of the same command
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o $TAG -- python3 $R/bench.py --no-extra --no-cpu-baseline > $OUT/${TAG}_cfg2_rollout_bench_under_rocprof.json 2> $OUT/trace.err
 cp $(find $OUT/trace -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_cfg2_rollout_kernel_stats.csv
 cp $(find $OUT/trace -name "*domain_stats.csv" | head -1) $OUT/${TAG}_cfg2_rollout_domain_stats.csv
 # 3. HBM traffic: FETCH_SIZE and WRITE_SIZE in separate passes over the calibrated workload
@@ -19,12 +20,16 @@ for C in FETCH_SIZE WRITE_SIZE; do
 done
 python3 $R/tools/parse_pmc.py $(find $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE -name '*counter_collection.csv') > $OUT/${TAG}_pmc_fetch_write_summary.json
 python3 $R/tools/make_traffic_json.py $OUT/${TAG}_pmc_fetch_write_summary.json > $OUT/hbm_traffic.json
-# 4. instruction mix / wave cycles of the rollout kernel
+# 4. kernel durations of that workload (per kernel and grid size): the per-call kernels and the big-grid rollouts
+python3 $R/tools/trace_summary.py $(find $OUT/pmc_WRITE_SIZE -name "*kernel_trace.csv" | head -1) > $OUT/${TAG}_kernel_times_traffic_workload.txt
+# 5. instruction mix / wave cycles of the cfg2 rollout kernel and of the cfg4 MultiSnake rollout
 bash $R/tools/pmc_instmix.sh obs > /dev/null
 cp $R/gpurun_out/pmc_obs/summary.json $OUT/${TAG}_cfg2_rollout_instmix_pmc.json
-# 5. the other BASELINE shapes
+bash $R/tools/pmc_multi.sh > /dev/null
+cp $R/gpurun_out/pmc_multi_full/summary.json $OUT/${TAG}_multi_rollout_cfg4_full_instmix_pmc.json
+cp $R/gpurun_out/pmc_multi_none/summary.json $OUT/${TAG}_multi_rollout_cfg4_noobs_instmix_pmc.json
+# 6. the other BASELINE shapes
 python3 $R/tools/bench_configs.py > $OUT/${TAG}_percall_all_configs.jsonl 2>/dev/null
-python3 $R/tools/bench_rollout_configs.py > $OUT/${TAG}_rollout_single_configs.jsonl 2>/dev/null
-python3 $R/tools/bench_multi_rollout.py > $OUT/${TAG}_rollout_multi_configs.jsonl 2>/dev/null
+python3 $R/tools/bench_big.py > $OUT/${TAG}_big_configs.txt 2>/dev/null
 rm -rf $OUT/trace $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE
 ls -la $OUT

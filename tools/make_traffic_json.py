@@ -26,29 +26,38 @@ copy = find('__amd_rocclr_copyBuffer', 131072)
 
 
 def traffic(prefix, grid):
-    v = find(prefix, grid)
+    try:
+        v = find(prefix, grid)
+    except KeyError:
+        return None
     r = v['FETCH_SIZE']['mean'] * 1024 * read_factor
     w = v['WRITE_SIZE']['mean'] * 1024 * write_factor
     return {'read_bytes': r, 'write_bytes': w, 'total_bytes': r + w, 'launches': v['FETCH_SIZE']['launches']}
 
 
+def total(t):
+    return t['total_bytes'] if t else None
+
+
+detail = {
+    'rollout_512x9_chunk1024': traffic('void wurm::rollout_s9_kernel<4>', 32768),
+    'rollout_8192x9_chunk128': traffic('void wurm::rollout_s9_kernel<4>', 524288),
+    'rollout_cfg5_8192x36_default_chunk16': traffic('void wurm::(anonymous namespace)::grid_rollout_kernel<true>', 524288),
+    'multi_rollout_cfg4_4096x25_k4_full_chunk16': traffic('wurm::multi_rollout_kernel', 262144),
+    'fused_step_512x9_partial2': traffic('void wurm::fused_step_kernel<2, true>', 32768),
+    'fused_step_8192x9_partial2': traffic('void wurm::fused_step_kernel<2, true>', 524288),
+    'fused_step_65536x9_partial2': traffic('void wurm::fused_step_kernel<2, true>', 4194304),
+    'fused_step_8192x36_default': traffic('void wurm::fused_step_kernel<24, true>', 524288),
+}
 out = {
     '_calibration': {
         'read_factor_dword_per_lane': read_factor, 'write_factor_dword_per_lane': write_factor,
         'copy_1GiB_FETCH_SIZE_KiB': copy['FETCH_SIZE']['mean'], 'copy_1GiB_WRITE_SIZE_KiB': copy['WRITE_SIZE']['mean'],
         'note': 'FETCH_SIZE reads 1/2 of the true bytes for 16 B/lane copies AND for the kernels\' dword-per-lane '
                 'coalesced reads; WRITE_SIZE is exact for both.'},
-    'rollout_512x9_chunk1024': traffic('void wurm::rollout_s9_kernel<4>', 32768)['total_bytes'],
-    'rollout_8192x9_chunk128': traffic('void wurm::rollout_s9_kernel<4>', 524288)['total_bytes'],
-    'detail': {
-        'rollout_512x9_chunk1024': traffic('void wurm::rollout_s9_kernel<4>', 32768),
-        'rollout_8192x9_chunk128': traffic('void wurm::rollout_s9_kernel<4>', 524288),
-        'step_512x9_partial2': traffic('void wurm::step_kernel<2, true>', 32768),
-        'reset_512x9_partial2': traffic('void wurm::reset_kernel<2, true>', 32768),
-        'step_8192x9_partial2': traffic('void wurm::step_kernel<2, true>', 524288),
-        'reset_8192x9_partial2': traffic('void wurm::reset_kernel<2, true>', 524288),
-        'step_8192x36_default': traffic('void wurm::step_kernel<24, true>', 524288),
-        'reset_8192x36_default': traffic('void wurm::reset_kernel<24, true>', 524288),
-    },
+    # the keys bench.py looks up: rollout_<N>x<S>_chunk<steps per launch>
+    'rollout_512x9_chunk1024': total(detail['rollout_512x9_chunk1024']),
+    'rollout_8192x9_chunk128': total(detail['rollout_8192x9_chunk128']),
+    'detail': detail,
 }
 print(json.dumps(out, indent=1))

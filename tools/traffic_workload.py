@@ -5,8 +5,8 @@ MI355X_MICROARCH.md §HBM prescribes for gfx950 (FETCH_SIZE under-reports wide s
 widths must be calibrated in the kernel's own access pattern):
   * torch copy of 1 GiB        (16 B/lane streaming read + write)
   * wurm_single_check on a 1.02 GB state tensor (dword-per-lane coalesced reads — the env kernels' pattern)
-then the measured launches: rollout (cfg2 512 envs, cfg3-share 8192 envs), per-call step/reset (cfg2), and the
-36x36 step/reset (cfg5 shape)."""
+then the measured launches: rollouts (cfg2 512 envs, cfg3-share 8192 envs, cfg5 8192 x 36 x 36, cfg4 MultiSnake) and the
+per-call loop (one fused launch per iteration) at cfg2 / cfg3-share / cfg3 / cfg5."""
 import os
 import sys
 
@@ -38,19 +38,27 @@ for N, chunk in ((512, 1024), (8192, 128)):
     for c in range(0, chunk * 5, chunk):
         env.rollout(actions[c:c + chunk])
     torch.cuda.synchronize()
-# measured: per-call step/reset at cfg2 and cfg3-share
-for N in (512, 8192):
-    env = SingleSnake(num_envs=N, size=9, observation_mode='partial_2', device=dev, seed=0)
-    actions = torch.randint(4, (50, N), device=dev, dtype=torch.int64)
-    for t in range(50):
-        _, _, d, _ = env.step(actions[t])
-        env.reset(d)
-    torch.cuda.synchronize()
-# measured: cfg5 shape (8192 x 36 x 36, default RGB obs), per-call
+# measured: the big-grid rollouts — cfg5 (grid_rollout_kernel) and cfg4 (multi_rollout_kernel), 16 batch-steps per launch
 env = SingleSnake(num_envs=8192, size=36, observation_mode='default', device=dev, seed=0)
-actions = torch.randint(4, (20, 8192), device=dev, dtype=torch.int64)
-for t in range(20):
-    _, _, d, _ = env.step(actions[t])
-    env.reset(d)
+actions = torch.randint(4, (16 * 5, 8192), device=dev, dtype=torch.int64)
+for c in range(0, 16 * 5, 16):
+    env.rollout(actions[c:c + 16])
 torch.cuda.synchronize()
+del env, actions
+from wurm_amd.envs import MultiSnake  # noqa: E402
+env = MultiSnake(4096, 4, 25, device=dev, seed=0)
+actions = torch.randint(8, (16 * 5, 4, 4096), device=dev, dtype=torch.int64)
+for c in range(0, 16 * 5, 16):
+    env.rollout(actions[c:c + 16])
+torch.cuda.synchronize()
+del env, actions
+# measured: the per-call loop (one fused launch per `step(a); reset(done)` iteration) at cfg2, cfg3-share, cfg3, cfg5
+for N, S, mode in ((512, 9, 'partial_2'), (8192, 9, 'partial_2'), (65536, 9, 'partial_2'), (8192, 36, 'default')):
+    env = SingleSnake(num_envs=N, size=S, observation_mode=mode, device=dev, seed=0)
+    actions = torch.randint(4, (30, N), device=dev, dtype=torch.int64)
+    for t in range(30):
+        _, _, d, _ = env.step(actions[t])
+        env.reset(d, return_observations=False)
+    torch.cuda.synchronize()
+    del env, actions
 print('traffic workload done')

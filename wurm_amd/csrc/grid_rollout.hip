@@ -221,7 +221,7 @@ template <bool VEC>
 __global__ __launch_bounds__(256) void grid_rollout_kernel(StepArgs p)
 {
     const int wave = uniform((int)(threadIdx.x >> 6)), wpb = (int)(blockDim.x >> 6);
-    const long long env = (long long)blockIdx.x * wpb + wave;
+    const long long env = xcd_block(blockIdx.x, gridDim.x) * wpb + wave;
     if (env >= p.N) return;
     Grid g;
     g.S = p.S;

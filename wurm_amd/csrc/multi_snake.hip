@@ -716,7 +716,7 @@ __device__ __forceinline__ void multi_step_body(const Ctx &cx, const MultiArgs &
 __global__ __launch_bounds__(256) void multi_step_kernel(MultiArgs p)
 {
     const int wave = (int)(threadIdx.x >> 6), wpb = (int)(blockDim.x >> 6);
-    const long long env = (long long)blockIdx.x * wpb + wave;
+    const long long env = xcd_block(blockIdx.x, gridDim.x) * wpb + wave;
     if (env >= p.N) return;
     const Ctx cx = make_ctx(p, wave);
     const int C = cx.C, K = cx.K, lane = cx.lane;
@@ -943,7 +943,7 @@ __device__ __forceinline__ void multi_reset_grid(const Ctx &cx, const MultiArgs 
 __global__ __launch_bounds__(256) void multi_reset_kernel(MultiArgs p)
 {
     const int wave = (int)(threadIdx.x >> 6), wpb = (int)(blockDim.x >> 6);
-    const long long env = (long long)blockIdx.x * wpb + wave;
+    const long long env = xcd_block(blockIdx.x, gridDim.x) * wpb + wave;
     if (env >= p.N) return;
     const Ctx cx = make_ctx(p, wave);
     const int C = cx.C, K = cx.K, lane = cx.lane;
@@ -998,7 +998,7 @@ __global__ __launch_bounds__(256) void multi_reset_kernel(MultiArgs p)
 __global__ __launch_bounds__(256) void multi_observe_kernel(MultiArgs p)
 {
     const int wave = (int)(threadIdx.x >> 6), wpb = (int)(blockDim.x >> 6);
-    const long long env = (long long)blockIdx.x * wpb + wave;
+    const long long env = xcd_block(blockIdx.x, gridDim.x) * wpb + wave;
     if (env >= p.N) return;
     const Ctx cx = make_ctx(p, wave);
     const int C = cx.C, K = cx.K, lane = cx.lane;
@@ -1025,7 +1025,7 @@ __global__ __launch_bounds__(256) void multi_observe_kernel(MultiArgs p)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void multi_rollout_kernel(MultiArgs p)
 {
     const int wave = (int)(threadIdx.x >> 6), wpb = (int)(blockDim.x >> 6);
-    const long long env = (long long)blockIdx.x * wpb + wave;
+    const long long env = xcd_block(blockIdx.x, gridDim.x) * wpb + wave;
     if (env >= p.N) return;
     const Ctx cx = make_ctx(p, wave);
     const int C = cx.C, K = cx.K, lane = cx.lane;
@@ -1096,7 +1096,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void m
 __global__ __launch_bounds__(256) void multi_check_kernel(MultiArgs p)
 {
     const int wave = (int)(threadIdx.x >> 6), wpb = (int)(blockDim.x >> 6);
-    const long long env = (long long)blockIdx.x * wpb + wave;
+    const long long env = xcd_block(blockIdx.x, gridDim.x) * wpb + wave;
     if (env >= p.N) return;
     const int S = p.S, C = S * S, K = p.K, lane = (int)(threadIdx.x & 63u), cpl = (C + 63) >> 6;
     const float *foodp = p.foods + env * C;

@@ -239,7 +239,7 @@ void policy_rollout_kernel(PolicyArgs p)
 {
     constexpr int CPL = 2;
     static_assert(Policy<NOBS>::W2 <= 64, "one window cell per lane");
-    const long long env = blockIdx.x;
+    const long long env = xcd_block(blockIdx.x, gridDim.x);
     const Geo g = make_geo<CPL>(p.S);
     float *envp = p.envs + env * 3 * g.C;
     Env<CPL> e;
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NOBS <= 2 ? 
 void policy_rollout_s9_kernel(PolicyArgs p)
 {
     constexpr int CPL = 2, S = 9, E = Policy<NOBS>::E, W = Policy<NOBS>::W, W2 = Policy<NOBS>::W2;
-    const long long env = blockIdx.x;
+    const long long env = xcd_block(blockIdx.x, gridDim.x);
     const Geo g = make_geo<CPL>(S);
     const int lane = g.lane;
     float *envp = p.envs + env * 3 * (S * S);

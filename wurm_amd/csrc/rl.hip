@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void single_stats_kernel(const float *__restri
                                                            double *__restrict__ accum, long long N, int S)
 {
     const int wave = (int)(threadIdx.x >> 6), wpb = (int)(blockDim.x >> 6), lane = (int)(threadIdx.x & 63u);
-    const long long env = (long long)blockIdx.x * wpb + wave;
+    const long long env = xcd_block(blockIdx.x, gridDim.x) * wpb + wave;
     if (env >= N) return;
     const int C = S * S;
     const float *body = envs + env * 3 * C + 2 * C;

@@ -477,7 +477,7 @@ template <int CPL, bool SNAKE>
 __global__ __launch_bounds__(256) void step_kernel(StepArgs p)
 {
     const int wave = (int)(threadIdx.x >> 6), wpb = (int)(blockDim.x >> 6);
-    const long long env = (long long)blockIdx.x * wpb + wave;
+    const long long env = xcd_block(blockIdx.x, gridDim.x) * wpb + wave;
     if (env >= p.N) return;
     signed char *lds = wurm_lds + wave * p.lds_per_wave;
     const int NCH = SNAKE ? 3 : 2;
@@ -518,7 +518,7 @@ template <int CPL, bool SNAKE>
 __global__ __launch_bounds__(256) void fused_step_kernel(StepArgs p)
 {
     const int wave = (int)(threadIdx.x >> 6), wpb = (int)(blockDim.x >> 6);
-    const long long env = (long long)blockIdx.x * wpb + wave;
+    const long long env = xcd_block(blockIdx.x, gridDim.x) * wpb + wave;
     if (env >= p.N) return;
     signed char *lds = wurm_lds + wave * p.lds_per_wave;
     const int NCH = SNAKE ? 3 : 2;
@@ -567,7 +567,7 @@ template <int CPL, bool SNAKE>
 __global__ __launch_bounds__(256) void reset_kernel(StepArgs p)
 {
     const int wave = (int)(threadIdx.x >> 6), wpb = (int)(blockDim.x >> 6);
-    const long long env = (long long)blockIdx.x * wpb + wave;
+    const long long env = xcd_block(blockIdx.x, gridDim.x) * wpb + wave;
     if (env >= p.N) return;
     signed char *lds = wurm_lds + wave * p.lds_per_wave;
     const int NCH = SNAKE ? 3 : 2;
@@ -591,7 +591,7 @@ template <int CPL, bool SNAKE>
 __global__ __launch_bounds__(256) void observe_kernel(StepArgs p)
 {
     const int wave = (int)(threadIdx.x >> 6), wpb = (int)(blockDim.x >> 6);
-    const long long env = (long long)blockIdx.x * wpb + wave;
+    const long long env = xcd_block(blockIdx.x, gridDim.x) * wpb + wave;
     if (env >= p.N) return;
     signed char *lds = wurm_lds + wave * p.lds_per_wave;
     const int NCH = SNAKE ? 3 : 2;
@@ -904,7 +904,7 @@ template <int CPL, bool SNAKE, int OBSK = -1, bool INJ = true>
 __global__ __launch_bounds__(256) void rollout_kernel(StepArgs p)
 {
     const int wave = uniform((int)(threadIdx.x >> 6)), wpb = (int)(blockDim.x >> 6);
-    const long long env = (long long)blockIdx.x * wpb + wave;
+    const long long env = xcd_block(blockIdx.x, gridDim.x) * wpb + wave;
     if (env >= p.N) return;
     if (p.only_flagged && uniform((int)p.done[env]) != (int)GRID_SKIPPED) return; // the grid kernel rolled this env out
     signed char *lds = wurm_lds + wave * p.lds_per_wave;
@@ -991,7 +991,7 @@ __global__ __launch_bounds__(256) void rollout_lean_kernel(StepArgs p)
     constexpr int CPL = 2;
     static_assert(OBSK == WURM_OBS_PARTIAL || OBSK == WURM_OBS_NONE, "lean rollout: partial_n or no observation");
     const int wave = uniform((int)(threadIdx.x >> 6)), wpb = (int)(blockDim.x >> 6);
-    const long long env = (long long)blockIdx.x * wpb + wave;
+    const long long env = xcd_block(blockIdx.x, gridDim.x) * wpb + wave;
     if (env >= p.N) return;
     const Geo g = make_geo<CPL>(p.S);
     const int S = g.S, Sm2 = S - 2, lane = g.lane;
@@ -1221,7 +1221,7 @@ __global__ __launch_bounds__(256) void rollout_s9_kernel(StepArgs p)
     constexpr int CPL = 2, S = 9;
     static_assert(OBSK == WURM_OBS_PARTIAL || OBSK == WURM_OBS_NONE, "9x9 rollout: partial_n or no observation");
     const int wave = uniform((int)(threadIdx.x >> 6)), wpb = (int)(blockDim.x >> 6);
-    const long long env = (long long)blockIdx.x * wpb + wave;
+    const long long env = xcd_block(blockIdx.x, gridDim.x) * wpb + wave;
     if (env >= p.N) return;
     const Geo g = make_geo<CPL>(S);
     const int lane = g.lane;
@@ -1437,7 +1437,7 @@ __global__ __launch_bounds__(256) void check_kernel(const float *__restrict__ en
                                                     long long N, int S)
 {
     const int wave = (int)(threadIdx.x >> 6), wpb = (int)(blockDim.x >> 6);
-    const long long env = (long long)blockIdx.x * wpb + wave;
+    const long long env = xcd_block(blockIdx.x, gridDim.x) * wpb + wave;
     if (env >= N) return;
     const Geo g = make_geo<CPL>(S);
     const float *envp = envs + env * 3 * g.C;
@@ -1474,7 +1474,7 @@ __global__ __launch_bounds__(256) void orientations_kernel(const float *__restri
                                                            long long N, int S, int lds_per_wave)
 {
     const int wave = (int)(threadIdx.x >> 6), wpb = (int)(blockDim.x >> 6);
-    const long long env = (long long)blockIdx.x * wpb + wave;
+    const long long env = xcd_block(blockIdx.x, gridDim.x) * wpb + wave;
     if (env >= N) return;
     signed char *lds = wurm_lds + wave * lds_per_wave;
     const Geo g = make_geo<CPL>(S);

@@ -150,6 +150,19 @@ __device__ __forceinline__ void wave_lds_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Workgroup -> first env of the workgroup, XCD-aware.  The hardware deals workgroups to the 8 XCDs round-robin (workgroup
+// b runs on XCD b % 8) and every XCD has its own L2.  Neighbouring envs share cache lines: the 300-byte observation
+// records of 9 x 9 'partial_2' envs and their 972-byte state slabs are packed back to back, so with env = b the two halves
+// of almost every line are written from two different L2s and go to HBM as two partial-line writes (round 1 measured
+// WRITE_SIZE = 1.32 x the bytes stored).  Giving each XCD one CONTIGUOUS range of envs keeps both halves of a line in one
+// L2, where they merge before the write-back.  Pure relabelling: every random draw is keyed by the env id, not by the
+// workgroup, so results do not change.
+__device__ __forceinline__ long long xcd_block(unsigned b, unsigned nblocks)
+{
+    const unsigned q = nblocks >> 3; // workgroups per XCD; the nblocks % 8 stragglers keep their index
+    return b < 8u * q ? (long long)(b & 7u) * q + (b >> 3) : (long long)b;
+}
+
 // exact floor(c / S) for 0 <= c < 2^16, 1 <= S <= 256, via one fp32 multiply (rcpS = 1.0f / S)
 __device__ __forceinline__ int div_size(int c, float rcpS) { return (int)(((float)c + 0.5f) * rcpS); }
 
