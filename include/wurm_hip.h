@@ -156,6 +156,11 @@ int wurm_single_step_slot(wurm_single_call *c, const wurm_single_slabs *slabs, i
                           int actions_dtype, uint64_t call, int apply_pending, uint64_t pre_call, int want_obs_after,
                           void *stream);
 
+/* The same for SimpleGridworld (the self_collision plane of `flags` is not written). */
+int wurm_grid_step_slot(wurm_single_call *c, const wurm_single_slabs *slabs, int64_t slot, void *actions,
+                        int actions_dtype, uint64_t call, int apply_pending, uint64_t pre_call, int want_obs_after,
+                        void *stream);
+
 /* The acting half of the single-agent loop, experiments/main.py:207-212,227, T iterations in ONE launch:
  *   probs, value = model(state)            FeedforwardAgent, wurm/agents/feedforward.py:8-28: E -> 64 -> 64 -> {4, 1}
  *   action = Categorical(probs).sample()   main.py:208-210

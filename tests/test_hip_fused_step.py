@@ -252,3 +252,38 @@ def test_class_state_edits_and_odd_call_patterns():
             env.observation_mode = mode
     replay._eq(env.envs.cpu().numpy(), ref, 'final state', '-')
     env.check_consistency() if (oracle.single_check(ref) == 0).all() else None
+
+
+@pytest.mark.parametrize('lazy', [True, False])
+def test_gridworld_class_loop_equals_oracle_loop(lazy):
+    """SimpleGridworld through the same one-launch machinery (wurm_grid_step_slot): step / reset pairs with deferred and
+    eager resets, with and without the reset observation, reading env.envs in between."""
+    import torch
+    from oracle import oracle
+    from wurm_amd.envs import SimpleGridworld
+    N, S, T, seed, mode, start = 64, 9, 120, 21, 'default', (4, 4)
+    env = SimpleGridworld(N, S, observation_mode=mode, device='cuda:0', start_location=start, seed=seed, lazy_reset=lazy)
+    ref = np.zeros((N, 2, S, S), np.float32)
+    oracle.grid_reset(ref, np.ones(N, np.uint8), start, 'none', seed=seed, call=0)
+    replay._eq(env.envs.cpu().numpy(), ref, 'fresh envs', 0)
+    g = torch.Generator().manual_seed(4)
+    call = 1
+    for t in range(T):
+        a = torch.randint(4, (N,), generator=g)
+        a_dev, a_ref = a.cuda(), a.numpy().copy()
+        obs, r, d, info = env.step(a_dev)
+        o_ref, r_ref, d_ref, ec_ref = oracle.grid_step(ref, a_ref, mode, seed=seed, call=call)
+        want = (t // 7) % 2 == 0
+        back = env.reset(d) if want else env.reset(d, return_observations=False)
+        b_ref = oracle.grid_reset(ref, d_ref, start, mode, seed=seed, call=call + 1)
+        call += 2
+        replay._eq(a_dev.cpu().numpy(), a.numpy(), 'actions untouched', t)
+        replay._eq(obs.cpu().numpy(), o_ref, 'obs', t)
+        replay._eq(r.cpu().numpy()[:, 0], r_ref, 'reward', t)
+        replay._eq(d.cpu().numpy()[:, 0], d_ref, 'done', t)
+        replay._eq(info['edge_collision'].cpu().numpy(), ec_ref, 'edge_collision', t)
+        if want:
+            replay._eq(back.cpu().numpy(), b_ref, 'reset observation', t)
+        if t % 9 == 0:
+            replay._eq(env.envs.cpu().numpy(), ref, 'state', t)
+    replay._eq(env.envs.cpu().numpy(), ref, 'final state', T)

@@ -20,7 +20,7 @@ ACT_I64, ACT_I32 = 0, 1
 SYMBOLS = [
     'wurm_version', 'wurm_single_obs_elems', 'wurm_grid_obs_elems',
     'wurm_single_step', 'wurm_single_reset', 'wurm_single_observe', 'wurm_single_rollout', 'wurm_single_check',
-    'wurm_single_step_reset', 'wurm_grid_step_reset', 'wurm_single_step_slot',
+    'wurm_single_step_reset', 'wurm_grid_step_reset', 'wurm_single_step_slot', 'wurm_grid_step_slot',
     'wurm_grid_step', 'wurm_grid_reset', 'wurm_grid_observe', 'wurm_grid_rollout',
     'wurm_multi_obs_elems', 'wurm_multi_step', 'wurm_multi_reset', 'wurm_multi_observe', 'wurm_multi_check',
     'wurm_multi_rollout',
@@ -138,23 +138,24 @@ def _declare_prototypes(l):
         raise WurmHipError(f'{header}: no prototype found for {missing}')
 
 
-_step_slot = None
+_step_slot = {}
 
 
-def step_slot_fn():
-    """wurm_single_step_slot as the cheapest callable available: through the CPython shim wurm_amd/_fastcall (built
-    by `make`; ~1 us less host time per call than ctypes), else the ctypes function itself — same arguments, same
-    library, same kernels either way."""
-    global _step_slot
-    if _step_slot is None:
-        fn = lib().wurm_single_step_slot
+def step_slot_fn(name: str = 'wurm_single_step_slot'):
+    """wurm_single_step_slot / wurm_grid_step_slot as the cheapest callable available: through the CPython shim
+    wurm_amd/_fastcall (built by `make`; ~1 us less host time per call than ctypes), else the ctypes function itself —
+    same arguments, same library, same kernels either way."""
+    fn = _step_slot.get(name)
+    if fn is None:
+        cfn = getattr(lib(), name)
         try:
+            import functools
             from wurm_amd import _fastcall
-            _fastcall.bind(ctypes.cast(fn, ctypes.c_void_p).value)
-            _step_slot = _fastcall.step_slot
+            fn = functools.partial(_fastcall.step_slot, ctypes.cast(cfn, ctypes.c_void_p).value)
         except ImportError:
-            _step_slot = fn
-    return _step_slot
+            fn = cfn
+        _step_slot[name] = fn
+    return fn
 
 
 def check(rc: int, what: str):

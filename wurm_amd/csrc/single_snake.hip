@@ -1710,12 +1710,12 @@ int wurm_single_step_reset(const wurm_single_call *c, void *stream) { return fus
 
 int wurm_grid_step_reset(const wurm_single_call *c, void *stream) { return fused_entry(false, c, stream); }
 
-int wurm_single_step_slot(wurm_single_call *c, const wurm_single_slabs *s, int64_t slot, void *actions,
-                          int actions_dtype, uint64_t call, int apply_pending, uint64_t pre_call, int want_obs_after,
-                          void *stream)
+static int step_slot(bool snake, wurm_single_call *c, const wurm_single_slabs *s, int64_t slot, void *actions,
+                     int actions_dtype, uint64_t call, int apply_pending, uint64_t pre_call, int want_obs_after,
+                     void *stream)
 {
     if (!c || !s || slot < 0 || slot >= s->steps) return WURM_ERR_INVALID_ARG;
-    const int64_t N = c->num_envs, elems = obs_elems(true, c->obs_mode, c->obs_n, c->size);
+    const int64_t N = c->num_envs, elems = obs_elems(snake, c->obs_mode, c->obs_n, c->size);
     c->actions = actions;
     c->actions_dtype = actions_dtype;
     c->call = call;
@@ -1732,7 +1732,21 @@ int wurm_single_step_slot(wurm_single_call *c, const wurm_single_slabs *s, int64
     } else {
         c->pre_done = nullptr;
     }
-    return fused_entry(true, c, stream);
+    return fused_entry(snake, c, stream);
+}
+
+int wurm_single_step_slot(wurm_single_call *c, const wurm_single_slabs *s, int64_t slot, void *actions,
+                          int actions_dtype, uint64_t call, int apply_pending, uint64_t pre_call, int want_obs_after,
+                          void *stream)
+{
+    return step_slot(true, c, s, slot, actions, actions_dtype, call, apply_pending, pre_call, want_obs_after, stream);
+}
+
+int wurm_grid_step_slot(wurm_single_call *c, const wurm_single_slabs *s, int64_t slot, void *actions,
+                        int actions_dtype, uint64_t call, int apply_pending, uint64_t pre_call, int want_obs_after,
+                        void *stream)
+{
+    return step_slot(false, c, s, slot, actions, actions_dtype, call, apply_pending, pre_call, want_obs_after, stream);
 }
 
 int wurm_single_policy_rollout(float *envs, const float *obs0, const float *params, int64_t *actions, float *probs,

@@ -1,6 +1,7 @@
 """SimpleGridworld — drop-in for the reference's wurm.envs.SimpleGridworld (wurm/envs/simple_gridworld.py:15-271)
 on the gfx950 kernels of include/wurm_hip.h.  State `envs` is (num_envs, 2, size, size) fp32 = [food, agent].
-Deviations are the ones listed in wurm_amd/envs/single_snake.py."""
+Deviations are the ones listed in wurm_amd/envs/single_snake.py.  Per-call path: one launch per `step(a); reset(done)`
+iteration, see wurm_amd/envs/_fast_step.py."""
 from collections import namedtuple
 from typing import Tuple
 
@@ -8,14 +9,18 @@ import torch
 
 from wurm_amd import _lib
 from wurm_amd.constants import DEFAULT_DEVICE
-from wurm_amd.envs.single_snake import _draw_seed, _INT_TYPES
+from wurm_amd.envs._fast_step import FastStepMixin
+from wurm_amd.envs.single_snake import _draw_seed
 
 Spec = namedtuple('Spec', ['reward_threshold'])
 
 
-class SimpleGridworld(object):
+class SimpleGridworld(FastStepMixin):
     """Batched gridworld: the agent moves in the 4 cardinal directions, +1 reward on a food square (which then
     respawns), moving on to the border ring ends the episode (reference simple_gridworld.py:16-42)."""
+
+    _CHANNELS = 2
+    _STEP_SLOT = 'wurm_grid_step_slot'
 
     spec = Spec(float('inf'))
 
@@ -29,7 +34,8 @@ class SimpleGridworld(object):
                  manual_setup: bool = False,
                  verbose: int = 0,
                  seed: int = None,
-                 env_offset: int = 0):
+                 env_offset: int = 0,
+                 lazy_reset: bool = True):
         self.num_envs = num_envs
         self.size = size
         self.on_death = on_death
@@ -39,12 +45,12 @@ class SimpleGridworld(object):
         self.verbose = verbose
         self.seed = _draw_seed() if seed is None else int(seed)
         self.env_offset = int(env_offset)
-        self._call = 0
+        self.lazy_reset = bool(lazy_reset)
+        self._mode_cache = {}
+        self._fast_init()
 
         self.t = 0
 
-        self.envs = torch.zeros((num_envs, 2, size, size), device=self.device)
-        self.done = torch.zeros(num_envs, dtype=torch.bool, device=self.device)
         if not manual_setup:
             self._reset(torch.ones(num_envs, dtype=torch.bool, device=self.device), observe=False)
 
@@ -54,20 +60,27 @@ class SimpleGridworld(object):
         self.food_colour = torch.tensor((255, 0, 0), dtype=torch.short, device=self.device)
         self.edge_colour = torch.tensor((0, 0, 0), dtype=torch.short, device=self.device)
 
-    def _next_call(self, n: int = 1) -> int:
-        c = self._call
-        self._call += n
-        return c
+    def _lazy_supported(self) -> bool:
+        return self.size > 4 and self.start_location is not None
 
-    def _state(self) -> torch.Tensor:
-        e = self.envs
-        if e.shape != (self.num_envs, 2, self.size, self.size):
-            raise RuntimeError(f'env.envs has shape {tuple(e.shape)}, expected '
-                               f'{(self.num_envs, 2, self.size, self.size)}')
-        if e.dtype != torch.float32 or e.device != self.device or not e.is_contiguous():
-            e = e.to(device=self.device, dtype=torch.float32).contiguous()
-            self.envs = e
-        return e
+    def _configure_call(self, c):
+        sy, sx = self.start_location if self.start_location is not None else (-1, -1)
+        c.start_y, c.start_x = int(sy), int(sx)
+
+    def _launch_reset(self, envs, done, obs, m, n, call):
+        rc = _lib.call(self.device.index, _lib.lib().wurm_grid_reset, _lib.ptr(envs), _lib.ptr(done), _lib.ptr(obs), m, n,
+                       _lib.i64(self.num_envs), self.size, int(self.start_location[0]), int(self.start_location[1]),
+                       _lib.u64(self.seed), _lib.u64(call), _lib.i64(self.env_offset), None,
+                       _lib.stream_ptr(self.device.index))
+        _lib.check(rc, 'SimpleGridworld.reset')
+
+    def _mode_info(self, observation_mode: str):
+        info = self._mode_cache.get(observation_mode)
+        if info is None:
+            shape = self._obs_shape(observation_mode)
+            m, n = _lib.parse_obs_mode(observation_mode)
+            info = self._mode_cache[observation_mode] = (m, n, shape)
+        return info
 
     def _obs_shape(self, mode: str):
         N, S = self.num_envs, self.size
@@ -94,36 +107,10 @@ class SimpleGridworld(object):
         return (self._observe('default') * 255).round().short()
 
     def step(self, actions: torch.Tensor) -> (torch.Tensor, torch.Tensor, torch.Tensor, dict):
-        """reference :135-202 (actions are not modified)"""
-        if actions.dtype not in _INT_TYPES:
-            raise TypeError('actions Tensor must be an integer type i.e. '
-                            '{torch.ShortTensor, torch.IntTensor, torch.LongTensor}')
-
-        if actions.shape[0] != self.num_envs:
-            raise RuntimeError('Must have the same number of actions as environments.')
-
-        if actions.dtype == torch.short:
-            raise RuntimeError('scatter_(): Expected dtype int32/int64 for index')  # reference fails at :153
-
-        envs = self._state()
-        N = self.num_envs
-        act = actions
-        if act.device != self.device or not act.is_contiguous() or act.dim() != 1:
-            act = actions.to(self.device).reshape(N).contiguous()
-        shape = self._obs_shape(self.observation_mode)
-        m, n = _lib.parse_obs_mode(self.observation_mode)
-        obs = torch.empty(shape, dtype=torch.float32, device=self.device)
-        reward = torch.empty(N, dtype=torch.float32, device=self.device)
-        flags = torch.empty((2, N), dtype=torch.bool, device=self.device)
-        done, edge_collision = flags[0], flags[1]
-        rc = _lib.call(self.device.index, _lib.lib().wurm_grid_step, 
-            _lib.ptr(envs), _lib.ptr(act), _lib.ACT_I64 if act.dtype == torch.long else _lib.ACT_I32,
-            _lib.ptr(reward), _lib.ptr(done), _lib.ptr(edge_collision), _lib.ptr(obs), m, n, _lib.i64(N), self.size,
-            _lib.u64(self.seed), _lib.u64(self._next_call()), _lib.i64(self.env_offset), None, _lib.stream_ptr(self.device.index))
-        _lib.check(rc, 'SimpleGridworld.step')
-        info = {'edge_collision': edge_collision}
-        self.done = done
-        return obs, reward.unsqueeze(-1), done.unsqueeze(-1), info
+        """reference :135-202 (actions are not modified).  One launch; a reset(done) postponed by the previous iteration
+        (wurm_amd/envs/_fast_step.py) is applied in front of the transition."""
+        i = self._fast_step(actions, 'SimpleGridworld.step')
+        return self._v_obs[i], self._v_reward[i], self._last_done2, {'edge_collision': self._v_edgec[i]}
 
     def _reset(self, done: torch.Tensor, observe: bool = True):
         if self.size <= 4 or self.start_location is None:
@@ -139,17 +126,16 @@ class SimpleGridworld(object):
             obs = torch.empty(self._obs_shape(self.observation_mode), dtype=torch.float32, device=self.device)
         else:
             m, n, obs = _lib.OBS_NONE, 0, None
-        rc = _lib.call(self.device.index, _lib.lib().wurm_grid_reset, 
-            _lib.ptr(envs), _lib.ptr(done), _lib.ptr(obs), m, n, _lib.i64(self.num_envs), self.size,
-            int(self.start_location[0]), int(self.start_location[1]), _lib.u64(self.seed),
-            _lib.u64(self._next_call()), _lib.i64(self.env_offset), None, _lib.stream_ptr(self.device.index))
-        _lib.check(rc, 'SimpleGridworld.reset')
+        self._launch_reset(envs, done, obs, m, n, self._next_call())
         return obs
 
     def reset(self, done: torch.Tensor = None, return_observations: bool = True):
         """reference :225-245"""
         if done is None:
             done = self.done
+        handled, obs = self._try_lazy_reset(done, return_observations)
+        if handled:
+            return obs
         done = done.view((done.shape[0]))
         if done.dtype != torch.bool:
             done = done != 0
