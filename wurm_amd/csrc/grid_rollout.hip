@@ -217,12 +217,16 @@ __device__ __forceinline__ void grid_observe(const Grid &g, const StepView &s, f
     }
 }
 
-template <bool VEC>
-__global__ __launch_bounds__(256) void grid_rollout_kernel(StepArgs p)
+// carried wave-uniform scalars of one env
+struct Snk {
+    int hc, hy, hx; // head cell, row, column
+    int L, o;       // length, orientation
+    int food;       // food cell, -1 = none
+    int G, T;       // clocks: G = T + L
+};
+
+__device__ __forceinline__ Grid make_grid(const StepArgs &p, int wave)
 {
-    const int wave = uniform((int)(threadIdx.x >> 6)), wpb = (int)(blockDim.x >> 6);
-    const long long env = xcd_block(blockIdx.x, gridDim.x) * wpb + wave;
-    if (env >= p.N) return;
     Grid g;
     g.S = p.S;
     g.C = p.S * p.S;
@@ -230,11 +234,15 @@ __global__ __launch_bounds__(256) void grid_rollout_kernel(StepArgs p)
     g.lane = (int)(threadIdx.x & 63u);
     g.rcpS = 1.0f / (float)p.S;
     g.ex = (cell_t *)grid_lds_raw + wave * (g.iters * 256);
-    const int S = g.S, C = g.C, lane = g.lane;
-    float *envp = p.envs + env * 3 * C;
-    const u64 env_id = (u64)(p.env_offset + env);
+    return g;
+}
 
-    // ---- the state: fp32 [food, head, body] -> clock grid (T = 0: ex = body value), markers on ring and food
+// the state, fp32 [food, head, body] -> clock grid (T = 0: ex = body value), markers on ring and food.  false: the env
+// is outside the domain (see the head of this file) and must be left to the generic kernels.
+template <bool VEC>
+__device__ __forceinline__ bool grid_load(const Grid &g, const float *__restrict__ envp, Snk &s)
+{
+    const int S = g.S, C = g.C, lane = g.lane;
     int lmax = 0, counts = 0, myh = NO_CELL_G, myf = NO_CELL_G;
     bool bad_l = false;
     for (int it = 0; it < g.iters; ++it) {
@@ -291,20 +299,130 @@ __global__ __launch_bounds__(256) void grid_rollout_kernel(StepArgs p)
     packed = wave_sum_i32(packed);
     const int cellL = wave_min_i32(cL), cellN = wave_min_i32(cN);
     const bool ok = ballot(bad_l) == 0 && nhead == 1 && nfood <= 1 && L >= 2 && (packed & 0xffff) == 1 &&
-                    (packed >> 16) == 1 && cellL == hc && p.T <= (1ll << 26);
-    if (!uniform((int)ok)) { // outside the domain: rollout_kernel takes this env (second launch, only_flagged)
+                    (packed >> 16) == 1 && cellL == hc;
+    if (!uniform((int)ok)) return false;
+    const int hy = div_size(hc, g.rcpS), hx = hc - hy * S;
+    // orientation from the two newest cells, as orientation_of / fast_init (wurm/utils.py:36-65)
+    const int yN = div_size(cellN, g.rcpS), xN = cellN - yN * S;
+    const int dy = hy - yN, dx = hx - xN;
+    const int o = (dy == 0 && dx == 1) ? 1 : (dy == 1 && dx == 0) ? 2 : (dy == 0 && dx == -1) ? 3 : 0;
+    s.hc = uniform(hc); s.hy = uniform(hy); s.hx = uniform(hx); s.L = uniform(L); s.o = uniform(o);
+    s.food = uniform(food);
+    s.G = s.L;
+    s.T = 0;
+    return true;
+}
+
+// an empty grid: markers on the ring and the padding, 0 elsewhere; no snake, no food, all clocks at 0
+__device__ __forceinline__ void grid_clear(const Grid &g, Snk &s)
+{
+    for (int it = 0; it < g.iters; ++it) {
+        const int c0 = it * 256 + 4 * g.lane;
+        int4v e;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) e[j] = (c0 + j >= g.C || ring_cell(g, c0 + j)) ? EX_RING : 0;
+        write4(g.ex, c0, e);
+    }
+    s.hc = s.hy = s.hx = 0;
+    s.L = 0; s.o = 0; s.food = -1; s.G = 0; s.T = 0;
+    wave_lds_sync();
+}
+
+struct StepEv {
+    int a_out;   // sanitised action
+    bool eat, selfc, edgec;
+    int v;       // what the head ran into (the clock of the cell before the step)
+    int old_hc;  // head cell before the move
+};
+
+// one transition (single_snake.py:197-304; line references as step_core / fast_step).  a_small: the action if it is
+// one of 0..3 else -1; a_mod: action % 4 (C semantics).  use_inject: the food cell of an eating step is inject_cell.
+__device__ __forceinline__ void grid_step(const Grid &g, Snk &s, int a_small, int a_mod, bool use_inject,
+                                          int inject_cell, u64 seed, u64 call, u64 env_id, StepEv &ev)
+{
+    const int lane = g.lane;
+    const int a_out = s.o == a_small ? ((s.o + 2) & 3) : a_mod;                    // :221-222
+    const int ai = a_out & 3, dy = -tap_y(ai), dx = -tap_x(ai);
+    ev.old_hc = s.hc;
+    s.hy += dy; s.hx += dx; s.hc += dy * g.S + dx;                                 // :225-233 (the head was inside the ring)
+    s.o = (ai + 2) & 3;
+    const int v = uniform((int)g.ex[s.hc]);                                        // what the head runs into
+    const bool eat = v == EX_FOOD, edgec = v == EX_RING;                           // :242, :290-295
+    s.G += 1;
+    s.L += (int)eat;
+    s.T = s.G - s.L;                                                               // :246-249: no decay on the step that eats
+    const bool selfc = !eat && !edgec && v > s.T;                                  // :252
+    if (!edgec && lane == 0) g.ex[s.hc] = (cell_t)s.G;                             // :258-262 (a ring cell keeps its marker)
+    wave_lds_sync();
+    if (eat) {                                                                     // :270-282
+        if (use_inject) s.food = (inject_cell >= 0 && inject_cell < g.C && uniform((int)g.ex[inject_cell]) <= s.T) ? inject_cell : -1;
+        else s.food = grid_pick_free(g, s.T, rng_words(seed, call, env_id, RNG_FOOD, 0).w[0]);
+        if (s.food >= 0 && lane == 0) g.ex[s.food] = (cell_t)EX_FOOD;
+        wave_lds_sync();
+    }
+    ev.a_out = a_out; ev.eat = eat; ev.selfc = selfc; ev.edgec = edgec; ev.v = v;
+}
+
+// reset of one env (single_snake.py:322-387): the clock jumps past every live cell, then a 3-segment snake and food.
+// inj: nullable {seed_y, seed_x, direction, food_cell}
+__device__ __forceinline__ void grid_reset(const Grid &g, Snk &s, u64 seed, u64 call, u64 env_id, const int *inj)
+{
+    const int S = g.S, lane = g.lane;
+    wave_lds_sync();
+    s.T = s.G; // every clock of the dead snake is <= G: the grid is empty without touching it
+    if (s.food >= 0 && lane == 0) g.ex[s.food] = 0;
+    int sy, sx, d, fc = -1;
+    Words w;
+    w.w[0] = w.w[1] = w.w[2] = w.w[3] = 0;
+    if (inj) {
+        sy = uniform(inj[0]); sx = uniform(inj[1]); d = uniform(inj[2]); fc = uniform(inj[3]);
+    } else { // randint(4, S-4) twice, randint(4) (:358-359,366)
+        w = rng_words(seed, call, env_id, RNG_RESET, 0);
+        sy = 4 + (int)mulhi_range(w.w[0], (u32)(S - 8));
+        sx = 4 + (int)mulhi_range(w.w[1], (u32)(S - 8));
+        d = (int)(w.w[2] >> 30);
+    }
+    sy = uniform(sy); sx = uniform(sx); d = uniform(d);
+    s.hy = sy + tap_y(d); s.hx = sx + tap_x(d);
+    s.hc = s.hy * S + s.hx;
+    const int sc = sy * S + sx, tc = (sy - tap_y(d)) * S + sx - tap_x(d);
+    if (lane == 0) { // conv2d(seed, LENGTH_3_SNAKES[d]) (:372-376)
+        g.ex[tc] = (cell_t)(s.T + 1);
+        g.ex[sc] = (cell_t)(s.T + 2);
+        g.ex[s.hc] = (cell_t)(s.T + 3);
+    }
+    s.L = 3;
+    s.G = s.T + 3;
+    s.o = d;
+    wave_lds_sync();
+    if (inj) s.food = (fc >= 0 && fc < g.C && uniform((int)g.ex[fc]) <= s.T) ? fc : -1;
+    else s.food = grid_pick_free(g, s.T, w.w[3]);                                  // :384-385
+    if (s.food >= 0 && lane == 0) g.ex[s.food] = (cell_t)EX_FOOD;
+    wave_lds_sync();
+}
+
+__device__ __forceinline__ StepView view_of(const Snk &s, int head_body)
+{
+    StepView v;
+    v.hc = s.hc; v.hy = s.hy; v.hx = s.hx; v.food = s.food; v.T = s.T; v.G = s.G; v.head_body = head_body;
+    return v;
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void grid_rollout_kernel(StepArgs p)
+{
+    const int wave = uniform((int)(threadIdx.x >> 6)), wpb = (int)(blockDim.x >> 6);
+    const long long env = xcd_block(blockIdx.x, gridDim.x) * wpb + wave;
+    if (env >= p.N) return;
+    const Grid g = make_grid(p, wave);
+    const int lane = g.lane;
+    float *envp = p.envs + env * 3 * g.C;
+    const u64 env_id = (u64)(p.env_offset + env);
+    Snk s;
+    if (!grid_load<VEC>(g, envp, s)) { // outside the domain: rollout_kernel takes this env (second launch, only_flagged)
         if (lane == 0) p.done[env] = GRID_SKIPPED;
         return;
     }
-    int hy = div_size(hc, g.rcpS), hx = hc - hy * S;
-    int o;
-    {   // orientation from the two newest cells, as orientation_of / fast_init (wurm/utils.py:36-65)
-        const int yN = div_size(cellN, g.rcpS), xN = cellN - yN * S;
-        const int dy = hy - yN, dx = hx - xN;
-        o = (dy == 0 && dx == 1) ? 1 : (dy == 1 && dx == 0) ? 2 : (dy == 0 && dx == -1) ? 3 : 0;
-    }
-    hc = uniform(hc); hy = uniform(hy); hx = uniform(hx); L = uniform(L); o = uniform(o); food = uniform(food);
-    int G = L, T = 0; // G = T + L
 
     const bool inj_f = p.inject_food != nullptr, inj_r = p.inject_reset != nullptr;
     const long long obs_stride = p.N * p.obs_elems;
@@ -319,90 +437,31 @@ __global__ __launch_bounds__(256) void grid_rollout_kernel(StepArgs p)
         asm volatile("" : "+v"(my_a), "+v"(my_inj)); // retire the prefetch here, not in front of the first readlane
         const int my_small = (my_a >= 0 && my_a < 4) ? (int)my_a : -1, my_mod = (int)(my_a % 4);
         int my_out = 0, my_flags = 0; // of step t0 + lane: sanitised action; done | selfc << 1 | edgec << 2 | reward << 3
-        if (G > EX_REBASE) { // keep the 16-bit clocks away from the markers: ex -= T for the live cells, 0 for the rest
+        if (s.G > EX_REBASE) { // keep the 16-bit clocks away from the markers: ex -= T for the live cells, 0 for the rest
             for (int it = 0; it < g.iters; ++it) {
                 const int c0 = it * 256 + 4 * lane;
                 int4v e = read4(g.ex, c0);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) e[q] = e[q] >= EX_FOOD ? e[q] : max(e[q] - T, 0);
+                for (int q = 0; q < 4; ++q) e[q] = e[q] >= EX_FOOD ? e[q] : max(e[q] - s.T, 0);
                 write4(g.ex, c0, e);
             }
-            G -= T;
-            T = 0;
+            s.G -= s.T;
+            s.T = 0;
             wave_lds_sync();
         }
 
         for (int j = 0; j < nt; ++j, obs_t += obs_stride, call += 2) {
-            // ---- step (single_snake.py:197-304; line references as step_core / fast_step)
-            const int a_small = lane_value(my_small, j), a_mod = lane_value(my_mod, j);
-            const int a_out = o == a_small ? ((o + 2) & 3) : a_mod;                    // :221-222
-            const int ai = a_out & 3, dy = -tap_y(ai), dx = -tap_x(ai);
-            hy += dy; hx += dx; hc += dy * S + dx;                                     // :225-233 (the head was inside the ring)
-            o = (ai + 2) & 3;
-            const int v = uniform((int)g.ex[hc]);                                           // what the head runs into
-            const bool eat = v == EX_FOOD, edgec = v == EX_RING;                       // :242, :290-295
-            G += 1;
-            L += (int)eat;
-            T = G - L;                                                                 // :246-249: no decay on the step that eats
-            const bool selfc = !eat && !edgec && v > T;                                // :252
-            if (!edgec && lane == 0) g.ex[hc] = (cell_t)G;                                     // :258-262 (a ring cell keeps its marker)
-            wave_lds_sync();
-            if (eat) {                                                                 // :270-282
-                if (inj_f) {
-                    const int ic = lane_value(my_inj, j);
-                    food = (ic >= 0 && ic < C && uniform((int)g.ex[ic]) <= T) ? ic : -1;
-                } else {
-                    food = grid_pick_free(g, T, rng_words(p.seed, call, env_id, RNG_FOOD, 0).w[0]);
-                }
-                if (food >= 0 && lane == 0) g.ex[food] = (cell_t)EX_FOOD;
-                wave_lds_sync();
-            }
-            if (p.obs_mode != WURM_OBS_NONE) {
-                StepView s;
-                s.hc = hc; s.hy = hy; s.hx = hx; s.food = food; s.T = T; s.G = G;
-                s.head_body = L + (selfc ? v - T : 0);
-                grid_observe<VEC>(g, s, obs_t, p.obs_mode, p.obs_n);
-            }
+            StepEv ev;
+            grid_step(g, s, lane_value(my_small, j), lane_value(my_mod, j), inj_f, inj_f ? lane_value(my_inj, j) : -1,
+                      p.seed, call, env_id, ev);
+            if (p.obs_mode != WURM_OBS_NONE)
+                grid_observe<VEC>(g, view_of(s, s.L + (ev.selfc ? ev.v - s.T : 0)), obs_t, p.obs_mode, p.obs_n);
             if (lane == j) {
-                my_out = a_out;
-                my_flags = (int)(selfc | edgec) | ((int)selfc << 1) | ((int)edgec << 2) | ((int)eat << 3);
+                my_out = ev.a_out;
+                my_flags = (int)(ev.selfc | ev.edgec) | ((int)ev.selfc << 1) | ((int)ev.edgec << 2) | ((int)ev.eat << 3);
             }
-
-            // ---- reset of a finished env (single_snake.py:322-387)
-            if (selfc | edgec) {
-                wave_lds_sync();
-                T = G; // every clock of the dead snake is <= G: the grid is empty without touching it
-                if (food >= 0 && lane == 0) g.ex[food] = 0;
-                int sy, sx, d, fc = -1;
-                Words w;
-                w.w[0] = w.w[1] = w.w[2] = w.w[3] = 0;
-                if (inj_r) {
-                    const int *inj = p.inject_reset + ((t0 + j) * p.N + env) * 4;
-                    sy = uniform(inj[0]); sx = uniform(inj[1]); d = uniform(inj[2]); fc = uniform(inj[3]);
-                } else { // randint(4, S-4) twice, randint(4) (:358-359,366)
-                    w = rng_words(p.seed, call + 1ull, env_id, RNG_RESET, 0);
-                    sy = 4 + (int)mulhi_range(w.w[0], (u32)(S - 8));
-                    sx = 4 + (int)mulhi_range(w.w[1], (u32)(S - 8));
-                    d = (int)(w.w[2] >> 30);
-                }
-                sy = uniform(sy); sx = uniform(sx); d = uniform(d);
-                hy = sy + tap_y(d); hx = sx + tap_x(d);
-                hc = hy * S + hx;
-                const int sc = sy * S + sx, tc = (sy - tap_y(d)) * S + sx - tap_x(d);
-                if (lane == 0) { // conv2d(seed, LENGTH_3_SNAKES[d]) (:372-376)
-                    g.ex[tc] = (cell_t)(T + 1);
-                    g.ex[sc] = (cell_t)(T + 2);
-                    g.ex[hc] = (cell_t)(T + 3);
-                }
-                L = 3;
-                G = T + 3;
-                o = d;
-                wave_lds_sync();
-                if (inj_r) food = (fc >= 0 && fc < C && uniform((int)g.ex[fc]) <= T) ? fc : -1;
-                else food = grid_pick_free(g, T, w.w[3]);                               // :384-385
-                if (food >= 0 && lane == 0) g.ex[food] = (cell_t)EX_FOOD;
-                wave_lds_sync();
-            }
+            if (ev.selfc | ev.edgec)
+                grid_reset(g, s, p.seed, call + 1ull, env_id, inj_r ? p.inject_reset + ((t0 + j) * p.N + env) * 4 : nullptr);
         }
         if (lane < nt) {
             const long long i = my_t * p.N + env;
@@ -416,9 +475,84 @@ __global__ __launch_bounds__(256) void grid_rollout_kernel(StepArgs p)
 
     // ---- back to the reference layout (every done env was reset: the head is on the grid, inside the ring)
     wave_lds_sync();
-    StepView s;
-    s.hc = hc; s.hy = hy; s.hx = hx; s.food = food; s.T = T; s.G = G; s.head_body = L;
-    grid_observe<VEC>(g, s, envp, WURM_OBS_RAW, 0);
+    grid_observe<VEC>(g, view_of(s, s.L), envp, WURM_OBS_RAW, 0);
+}
+
+// ---------------------------------------------------------------------------------------------- per-call
+// fused_step_kernel (single_snake.hip) for grids >= 12 x 12 on the clock grid: [reset of the envs flagged in
+// p.done_in with call = p.pre_call], step (call = p.call), observation, [p.obs_after: the observation reset(done)
+// returns], [p.post_reset: the rebuilt state stored].  The state is read with 16-byte loads into LDS and only the
+// cells the step changed are written back: the decayed body cells, the two head cells, the food cells (a rebuilt env
+// is stored whole).  Envs outside the domain are flagged in done[env] for fused_step_kernel (second launch).
+template <bool VEC>
+__global__ __launch_bounds__(256) void grid_step_kernel(StepArgs p)
+{
+    const int wave = uniform((int)(threadIdx.x >> 6)), wpb = (int)(blockDim.x >> 6);
+    const long long env = xcd_block(blockIdx.x, gridDim.x) * wpb + wave;
+    if (env >= p.N) return;
+    const Grid g = make_grid(p, wave);
+    const int lane = g.lane, C = g.C;
+    float *envp = p.envs + env * 3 * C;
+    const u64 env_id = (u64)(p.env_offset + env);
+    Snk s;
+    const bool pre = p.done_in != nullptr && uniform((int)p.done_in[env]) != 0;
+    if (pre) {
+        grid_clear(g, s);
+        grid_reset(g, s, p.seed, p.pre_call, env_id, p.inject_pre_reset ? p.inject_pre_reset + env * 4 : nullptr);
+    } else if (!grid_load<VEC>(g, envp, s)) {
+        if (lane == 0) p.done[env] = GRID_SKIPPED;
+        return;
+    }
+    const long long a_in = uniform64(load_action(p.actions, p.act_dtype, env));
+    const bool inj_f = p.inject_food != nullptr;
+    const int inj_cell = inj_f ? uniform(p.inject_food[env]) : -1;
+    const int food0 = s.food, T0 = s.T;
+    StepEv ev;
+    grid_step(g, s, (a_in >= 0 && a_in < 4) ? (int)a_in : -1, (int)(a_in % 4), inj_f, inj_cell, p.seed, p.call, env_id, ev);
+    const bool done = ev.selfc | ev.edgec;
+    const int head_body = s.L + (ev.selfc ? ev.v - s.T : 0);
+    if (lane == 0) {
+        store_action(p.actions, p.act_dtype, env, (long long)ev.a_out);
+        p.selfc[env] = (uint8_t)ev.selfc;
+        p.reward[env] = ev.eat ? 1.0f : 0.0f;
+        p.done[env] = (uint8_t)done;
+        p.edgec[env] = (uint8_t)ev.edgec;
+        if (p.done_copy) p.done_copy[env] = (uint8_t)done;
+    }
+    if (p.obs_mode != WURM_OBS_NONE)
+        grid_observe<VEC>(g, view_of(s, head_body), p.obs + env * p.obs_elems, p.obs_mode, p.obs_n);
+
+    // ---- the post-step state back to HBM
+    const bool rebuild_after = done && p.post_reset;
+    if (!rebuild_after) {
+        if (pre) {
+            grid_observe<VEC>(g, view_of(s, head_body), envp, WURM_OBS_RAW, 0); // the env was rebuilt: everything changed
+        } else {
+            if (s.T != T0) { // the body decayed (:246-249): every cell that held a value holds one less
+                for (int it = 0; it < g.iters; ++it) {
+                    const int c0 = it * 256 + 4 * lane;
+                    const int4v e = read4(g.ex, c0);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (e[j] > T0 && e[j] < EX_FOOD && c0 + j != s.hc) envp[2 * C + c0 + j] = (float)max(e[j] - s.T, 0);
+                }
+            }
+            if (lane == 0) {
+                envp[C + ev.old_hc] = 0.0f;            // :225-233 the head moved
+                envp[C + s.hc] = 1.0f;
+                envp[2 * C + s.hc] = (float)head_body; // :258-262 (on the ring too: the reference grows the body there)
+                if (ev.eat) {                          // :270-282
+                    envp[food0] = 0.0f;
+                    if (s.food >= 0) envp[s.food] = 1.0f;
+                }
+            }
+        }
+    }
+    if (!p.post_reset && p.obs_after == nullptr) return;
+    if (done) grid_reset(g, s, p.seed, p.call + 1ull, env_id, p.inject_reset ? p.inject_reset + env * 4 : nullptr);
+    if (rebuild_after) grid_observe<VEC>(g, view_of(s, s.L), envp, WURM_OBS_RAW, 0);
+    if (p.obs_after != nullptr && p.obs_mode != WURM_OBS_NONE)
+        grid_observe<VEC>(g, view_of(s, done ? s.L : head_body), p.obs_after + env * p.obs_elems, p.obs_mode, p.obs_n);
 }
 
 } // namespace
@@ -426,6 +560,15 @@ __global__ __launch_bounds__(256) void grid_rollout_kernel(StepArgs p)
 bool grid_rollout_eligible(const StepArgs &p)
 {
     return p.S >= 12 && p.S <= 64 && p.T <= (1ll << 26);
+}
+
+bool grid_step_eligible(const StepArgs &p) { return p.S >= 12 && p.S <= 64; }
+
+static bool grid_aligned(const StepArgs &p)
+{
+    const bool plain = p.obs_mode == WURM_OBS_PARTIAL || p.obs_mode == WURM_OBS_POSITIONS || p.obs_mode == WURM_OBS_NONE;
+    return (p.S * p.S) % 4 == 0 && ((uintptr_t)p.envs % 16 == 0) && ((uintptr_t)p.obs % 16 == 0) &&
+           ((uintptr_t)p.obs_after % 16 == 0) && (p.obs_elems % 4 == 0 || plain);
 }
 
 hipError_t launch_grid_rollout(const StepArgs &p_in, hipStream_t stream)
@@ -444,11 +587,21 @@ hipError_t launch_grid_rollout(const StepArgs &p_in, hipStream_t stream)
     const size_t per_wave_target = (160u * 1024u / (unsigned)waves_per_cu) & ~255u;
     lds = std::min<size_t>(std::max(lds, per_wave_target * wpb), 64u * 1024u);
     (void)hipGetLastError();
-    const bool aligned = ((uintptr_t)p.envs % 16 == 0) && ((uintptr_t)p.obs % 16 == 0) &&
-                         (p.obs_elems % 4 == 0 || p.obs_mode == WURM_OBS_PARTIAL || p.obs_mode == WURM_OBS_POSITIONS ||
-                          p.obs_mode == WURM_OBS_NONE);
-    if (C % 4 == 0 && aligned) hipLaunchKernelGGL(grid_rollout_kernel<true>, grid, block, lds, stream, p);
+    if (grid_aligned(p)) hipLaunchKernelGGL(grid_rollout_kernel<true>, grid, block, lds, stream, p);
     else hipLaunchKernelGGL(grid_rollout_kernel<false>, grid, block, lds, stream, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_grid_step(const StepArgs &p_in, hipStream_t stream)
+{
+    StepArgs p = p_in;
+    const int C = p.S * p.S, iters = (C + 255) >> 8;
+    const int wpb = p.N <= 4096 ? 1 : 4;
+    dim3 block(64 * wpb), grid((unsigned)((p.N + wpb - 1) / wpb));
+    const size_t lds = (size_t)iters * 256 * sizeof(cell_t) * wpb; // one step per launch: as many waves per CU as fit
+    (void)hipGetLastError();
+    if (grid_aligned(p)) hipLaunchKernelGGL(grid_step_kernel<true>, grid, block, lds, stream, p);
+    else hipLaunchKernelGGL(grid_step_kernel<false>, grid, block, lds, stream, p);
     return hipGetLastError();
 }
 

@@ -15,6 +15,7 @@
 // rollout_kernel fuses T step+reset iterations with the env resident in registers; for well-formed start states it
 // carries head cell / length / orientation / food cell as scalars (fast_step) instead of re-deriving them.
 #include "step_args.hpp"
+#include <cstdlib>
 
 namespace wurm {
 
@@ -479,6 +480,7 @@ __global__ __launch_bounds__(256) void step_kernel(StepArgs p)
     const int wave = (int)(threadIdx.x >> 6), wpb = (int)(blockDim.x >> 6);
     const long long env = xcd_block(blockIdx.x, gridDim.x) * wpb + wave;
     if (env >= p.N) return;
+    if (p.only_flagged && uniform((int)p.done[env]) != (int)GRID_SKIPPED) return; // grid_step_kernel stepped this env
     signed char *lds = wurm_lds + wave * p.lds_per_wave;
     const int NCH = SNAKE ? 3 : 2;
     const Geo g = make_geo<CPL>(p.S);
@@ -520,6 +522,7 @@ __global__ __launch_bounds__(256) void fused_step_kernel(StepArgs p)
     const int wave = (int)(threadIdx.x >> 6), wpb = (int)(blockDim.x >> 6);
     const long long env = xcd_block(blockIdx.x, gridDim.x) * wpb + wave;
     if (env >= p.N) return;
+    if (p.only_flagged && uniform((int)p.done[env]) != (int)GRID_SKIPPED) return; // grid_step_kernel stepped this env
     signed char *lds = wurm_lds + wave * p.lds_per_wave;
     const int NCH = SNAKE ? 3 : 2;
     const Geo g = make_geo<CPL>(p.S);
@@ -1505,6 +1508,21 @@ template <int CPL, bool SNAKE>
 static hipError_t launch_one(Kind kind, const StepArgs &p, dim3 grid, dim3 block, size_t lds, hipStream_t st)
 {
     (void)hipGetLastError(); // drop any stale error left by earlier runtime calls of this thread
+    if constexpr (SNAKE && CPL >= 4) {
+        // large batches of large grids: the LDS clock-grid step (grid_rollout.hip: 16-byte loads, 34 VGPRs), then the
+        // generic kernel for the envs it could not take.  Small batches stay on one launch: they are latency-bound.
+        long long min_cells = 1ll << 20;
+        if (const char *e = getenv("WURM_GRID_STEP_MIN_CELLS")) min_cells = atoll(e); // tests force the path with 0
+        if ((kind == K_STEP || kind == K_FUSED) && grid_step_eligible(p) && p.N * (long long)p.S * p.S >= min_cells) {
+            hipError_t err = launch_grid_step(p, st);
+            if (err != hipSuccess) return err;
+            StepArgs q = p;
+            q.only_flagged = 1;
+            if (kind == K_STEP) hipLaunchKernelGGL((step_kernel<CPL, SNAKE>), grid, block, lds, st, q);
+            else hipLaunchKernelGGL((fused_step_kernel<CPL, SNAKE>), grid, block, lds, st, q);
+            return hipGetLastError();
+        }
+    }
     switch (kind) {
     case K_STEP: hipLaunchKernelGGL((step_kernel<CPL, SNAKE>), grid, block, lds, st, p); break;
     case K_RESET: hipLaunchKernelGGL((reset_kernel<CPL, SNAKE>), grid, block, lds, st, p); break;

@@ -51,5 +51,8 @@ __device__ __forceinline__ void store_action(void *actions, int dtype, long long
 constexpr uint8_t GRID_SKIPPED = 0xFF;
 bool grid_rollout_eligible(const StepArgs &p);
 hipError_t launch_grid_rollout(const StepArgs &p, hipStream_t stream);
+// the same for one per-call iteration (fused_step_kernel's contract)
+bool grid_step_eligible(const StepArgs &p);
+hipError_t launch_grid_step(const StepArgs &p, hipStream_t stream);
 
 } // namespace wurm
