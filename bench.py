@@ -203,7 +203,7 @@ def worker(args) -> int:
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    distributed = world > 1
+    distributed = 'WORLD_SIZE' in os.environ and 'RANK' in os.environ  # started by torchrun (even with one rank)
     dist = None
     if distributed:
         import torch.distributed as dist

@@ -248,7 +248,87 @@ struct StepOut {
     int headcell;     // head cell after the move, -1 if it left the grid
     float reward;
     int done, selfc, edgec;
+    int foodcell;     // small_step only: the food cell after the step (-1: none); -2: the generic path ran
 };
+
+// step_core for grids of at most 128 cells whose state is a well-formed snake (exactly one head, on the unique maximum
+// L >= 2 of the body channel; exactly one cell L - 1; at most one food cell; no negative values) — the state every
+// per-call step of a reset-after-done loop sees.  Same transition, but every wave-level quantity comes from BALLOTS of
+// per-lane compares (a v_cmp into an SGPR pair + s_bcnt1 / s_ff1) instead of DPP butterfly reductions: head and food
+// cells are the set bits of two masks, L is the body value under the head (one v_readlane), "unique maximum" is
+// popc(body == L) == 1 && no lane has body > L, the neck is the set bit of (body == L - 1).  PMC on round 1's
+// step_kernel<2> at 65 536 envs: 404 VALU + 237 SALU per env, six compiler-emitted DPP reductions (~20 instructions
+// each) among them, and the kernel was issue-bound at 2.1x the time its HBM traffic needs.  Returns false (nothing
+// touched) if the state is anything else; step_core then runs its general path.
+template <bool WRITE>
+__device__ __forceinline__ bool small_step(Env<2> &e, const Geo &g, float *__restrict__ envp, long long a_in, StepOut &out,
+                                           u64 seed, u64 call, u64 env_id, bool use_inject, int inject_cell)
+{
+    const int S = g.S, C = g.C, lane = g.lane;
+    const u64 H0 = ballot((e.head & 1) != 0), H1 = ballot((e.head & 2) != 0);
+    const u64 F0 = ballot((e.food & 1) != 0), F1 = ballot((e.food & 2) != 0);
+    if (popc64(H0) + popc64(H1) != 1 || popc64(F0) + popc64(F1) > 1) return false;
+    const int hc = H0 ? first_bit(H0) : 64 + first_bit(H1);
+    const int fc = F0 ? first_bit(F0) : (F1 ? 64 + first_bit(F1) : -1);
+    const int L = lane_value(hc < 64 ? e.body[0] : e.body[1], hc & 63);           // single_snake.py:210 snake_sizes
+    if (L < 2) return false;
+    const u64 above = ballot(e.body[0] > L || e.body[1] > L || e.body[0] < 0 || e.body[1] < 0);
+    const u64 M0 = ballot(e.body[0] == L), M1 = ballot(e.body[1] == L);
+    const u64 N0 = ballot(e.body[0] == L - 1), N1 = ballot(e.body[1] == L - 1);
+    if (above != 0 || popc64(M0) + popc64(M1) != 1 || popc64(N0) + popc64(N1) != 1) return false;
+    const int neck = N0 ? first_bit(N0) : 64 + first_bit(N1);
+    // orientation (wurm/utils.py:36-65) from the two newest cells, as orientation_of
+    const int hy = div_size(hc, g.rcpS), hx = hc - hy * S;
+    const int yN = div_size(neck, g.rcpS), xN = neck - yN * S;
+    const int dy = hy - yN, dx = hx - xN;
+    const int o = (dy == 0 && dx == 1) ? 1 : (dy == 1 && dx == 0) ? 2 : (dy == 0 && dx == -1) ? 3 : 0;
+    long long a = a_in;
+    if ((long long)o == a) a += 2;                                                  // :221-222
+    a = a % 4;
+    const int ai = (int)(((a % 4) + 4) % 4);
+    const int ny = hy - tap_y(ai), nx = hx - tap_x(ai);                            // :225-233
+    const bool inside = ny >= 0 && ny < S && nx >= 0 && nx < S;
+    const int nh = inside ? ny * S + nx : -1;
+    const bool EAT = inside && nh == fc;                                           // :242
+    const int under = inside ? lane_value(nh < 64 ? e.body[0] : e.body[1], nh & 63) : 0;
+    const bool SELFC = inside && (EAT ? under : max(under - 1, 0)) > 0;            // :252 (after the decay)
+    const int grow = L + (EAT ? 1 : 0);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int c = lane + 64 * k;
+        const int b0 = e.body[k];
+        int b = EAT ? b0 : max(b0 - 1, 0);                                         // :246-249
+        if (c == nh) b += grow;                                                    // :258-262
+        if (WRITE && b != b0) envp[2 * C + c] = (float)b;
+        e.body[k] = b;
+    }
+    if (WRITE && lane == 0) {
+        envp[C + hc] = 0.0f;
+        if (inside) envp[C + nh] = 1.0f;
+        if (EAT) envp[nh] = 0.0f;                                                  // :270-272
+    }
+    e.head = (inside && lane == (nh & 63)) ? (nh < 64 ? 1ull : 2ull) : 0ull;
+    if (EAT) {                                                                     // :277-282
+        e.food = 0;
+        u32 word = 0;
+        if (!use_inject) word = rng_words(seed, call, env_id, RNG_FOOD, 0).w[0];
+        add_food<2, true, WRITE>(e, g, envp, use_inject, inject_cell, word);
+    }
+    const bool EDGEC = !(inside && ny >= 1 && ny <= S - 2 && nx >= 1 && nx <= S - 2); // :290-295
+    out.action = a;
+    out.headcell = nh;
+    out.reward = EAT ? 1.0f : 0.0f;
+    out.selfc = SELFC;
+    out.edgec = EDGEC;
+    out.done = SELFC | EDGEC;
+    if (EAT) {
+        const u64 G0 = ballot((e.food & 1) != 0), G1 = ballot((e.food & 2) != 0);
+        out.foodcell = G0 ? first_bit(G0) : (G1 ? 64 + first_bit(G1) : -1);
+    } else {
+        out.foodcell = fc;
+    }
+    return true;
+}
 
 // One transition of one env held in registers.  WRITE: changed cells are written through to HBM as they are
 // produced (per-call kernels); !WRITE: registers only (rollout kernel).
@@ -257,6 +337,11 @@ __device__ __forceinline__ void step_core(Env<CPL> &e, const Geo &g, float *__re
                                           StepOut &out, u64 seed, u64 call, u64 env_id, bool use_inject,
                                           int inject_cell, signed char *lds)
 {
+    out.foodcell = -2;
+    if constexpr (SNAKE && CPL == 2 && WRITE) {
+        if (small_step<WRITE>(e, g, envp, a_in, out, seed, call, env_id, use_inject, inject_cell)) return;
+        out.foodcell = -2;
+    }
     const int S = g.S, C = g.C, lane = g.lane;
     long long a = a_in;
     int L = 0;
