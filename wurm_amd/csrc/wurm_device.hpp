@@ -89,13 +89,27 @@ constexpr int DPP_QUAD_XOR2 = 0x4E;        // quad_perm:[2,3,0,1]
 constexpr int DPP_ROW_HALF_MIRROR = 0x141; // lane i <-> 7-i within each 8
 constexpr int DPP_ROW_MIRROR = 0x140;      // lane i <-> 15-i within each 16
 
-// wave-wide max, result wave-uniform (SGPR): 4 DPP steps inside each 16-lane row, then 4 readlanes
+// Wave-wide reductions, result wave-uniform (SGPR): 4 DPP steps inside each 16-lane row, then 4 readlanes.
+// The butterfly is hand-written: for `v = op(v, dpp_row<..>(v))` the compiler emits v_mov + s_nop + v_mov_dpp + op per
+// step (~20 instructions per reduction), the DPP form of the op itself is one instruction per step.  Rules that keep it
+// safe (tools/microbench/reduce_test.hip exercises them, including partially active waves):
+//   * IN PLACE — destination = second source = %0.  With bound_ctrl:0 a lane whose DPP source lane is disabled by EXEC
+//     is not written at all; with a fresh destination register it would keep whatever that register held (for a
+//     minimum: possibly a small stale value, i.e. a wrong cell index), in place it keeps its own value, which is the
+//     identity of min / max and what __builtin_amdgcn_update_dpp(v, v, ...) gives;  for the SUM the untouched lane must
+//     contribute nothing twice, so sums are only taken with all lanes active (every call site is wave-uniform code);
+//   * s_nop 1 in front of every DPP read of a VGPR written by the previous VALU instruction (2 wait states on gfx9;
+//     the hazard recogniser does not look inside an asm block).
+#define WURM_DPP_BUTTERFLY(OP)                                                                         \
+    "s_nop 1\n\t" OP " %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"                  \
+    "s_nop 1\n\t" OP " %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"                  \
+    "s_nop 1\n\t" OP " %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"                      \
+    "s_nop 1\n\t" OP " %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"                           \
+    "s_nop 0"
+
 __device__ __forceinline__ int wave_max_i32(int v)
 {
-    v = max(v, dpp_row<DPP_QUAD_XOR1>(v));
-    v = max(v, dpp_row<DPP_QUAD_XOR2>(v));
-    v = max(v, dpp_row<DPP_ROW_HALF_MIRROR>(v));
-    v = max(v, dpp_row<DPP_ROW_MIRROR>(v));
+    asm(WURM_DPP_BUTTERFLY("v_max_i32_dpp") : "+v"(v));
     int r0 = __builtin_amdgcn_readlane(v, 0), r1 = __builtin_amdgcn_readlane(v, 16);
     int r2 = __builtin_amdgcn_readlane(v, 32), r3 = __builtin_amdgcn_readlane(v, 48);
     return max(max(r0, r1), max(r2, r3));
@@ -103,10 +117,7 @@ __device__ __forceinline__ int wave_max_i32(int v)
 
 __device__ __forceinline__ int wave_min_i32(int v)
 {
-    v = min(v, dpp_row<DPP_QUAD_XOR1>(v));
-    v = min(v, dpp_row<DPP_QUAD_XOR2>(v));
-    v = min(v, dpp_row<DPP_ROW_HALF_MIRROR>(v));
-    v = min(v, dpp_row<DPP_ROW_MIRROR>(v));
+    asm(WURM_DPP_BUTTERFLY("v_min_i32_dpp") : "+v"(v));
     int r0 = __builtin_amdgcn_readlane(v, 0), r1 = __builtin_amdgcn_readlane(v, 16);
     int r2 = __builtin_amdgcn_readlane(v, 32), r3 = __builtin_amdgcn_readlane(v, 48);
     return min(min(r0, r1), min(r2, r3));
@@ -114,10 +125,7 @@ __device__ __forceinline__ int wave_min_i32(int v)
 
 __device__ __forceinline__ int wave_sum_i32(int v)
 {
-    v += dpp_row<DPP_QUAD_XOR1>(v);
-    v += dpp_row<DPP_QUAD_XOR2>(v);
-    v += dpp_row<DPP_ROW_HALF_MIRROR>(v);
-    v += dpp_row<DPP_ROW_MIRROR>(v);
+    asm(WURM_DPP_BUTTERFLY("v_add_u32_dpp") : "+v"(v));
     return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) +
            __builtin_amdgcn_readlane(v, 48);
 }
