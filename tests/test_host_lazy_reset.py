@@ -1,0 +1,134 @@
+"""Host logic of the one-launch step path (wurm_amd/envs/_fast_step.py) WITHOUT a GPU: the C ABI is replaced by a
+recording stand-in (no compute), the env lives on CPU tensors, and the SEQUENCE of entry points, counters and flags the
+class hands to the library is checked for the call patterns a caller can produce — the contract the GPU tests then check
+for bit-exact results."""
+import ctypes
+
+import pytest
+import torch
+
+from wurm_amd import _lib
+
+
+class _Recorder(object):
+    """Stands in for libwurm_hip.so: every entry point records (name, selected arguments) and returns WURM_OK."""
+
+    def __init__(self):
+        self.calls = []
+
+    def wurm_single_reset(self, envs, done, obs, m, n, N, S, seed, call, off, inj, stream):
+        self.calls.append(('reset', dict(call=call, obs=obs is not None, mode=m)))
+        return 0
+
+    def wurm_single_observe(self, envs, obs, m, n, N, S, stream):
+        self.calls.append(('observe', dict(mode=m)))
+        return 0
+
+    def step_slot(self, c_addr, sl_addr, slot, actions, dtype, call, pending, pre_call, want_after, stream):
+        c = _lib.SingleCall.from_address(c_addr)
+        self.calls.append(('step', dict(slot=slot, call=call, pending=bool(pending), pre_call=pre_call,
+                                        want_after=bool(want_after), dtype=dtype, obs_mode=c.obs_mode, envs=c.envs)))
+        return 0
+
+
+@pytest.fixture
+def env_and_log(monkeypatch):
+    rec = _Recorder()
+    monkeypatch.setattr(_lib, 'lib', lambda: rec)
+    monkeypatch.setattr(_lib, 'require_device', lambda d: torch.device('cpu'))
+    monkeypatch.setattr(_lib, 'stream_ptr', lambda i=None: 0)
+    monkeypatch.setattr(_lib, 'call', lambda idx, fn, *a: fn(*a))
+    monkeypatch.setattr(_lib, 'accessors', lambda: ((lambda: -1), (lambda i: 0)))
+    monkeypatch.setattr(_lib, 'step_slot_fn', lambda name='wurm_single_step_slot': rec.step_slot)
+    from wurm_amd.envs import SingleSnake
+    env = SingleSnake(num_envs=8, size=9, observation_mode='partial_2', device='cpu', seed=5)
+    env._dev_index_override = True
+    rec.calls.clear()
+    return env, rec.calls
+
+
+def _step(env, a=None):
+    a = torch.zeros(8, dtype=torch.int64) if a is None else a
+    out = env.step(a)
+    env._dev_index = -1  # CPU tensors report device -1
+    return out
+
+
+def test_reset_with_the_steps_own_done_is_deferred_into_the_next_step(env_and_log):
+    env, log = env_and_log
+    obs, r, d, info = _step(env)
+    assert env.reset(d, return_observations=False) is None
+    assert [c[0] for c in log] == ['step']                      # no reset launch
+    _step(env)
+    s0, s1 = log[0][1], log[1][1]
+    assert not s0['pending'] and s1['pending'] and s1['pre_call'] == s0['call'] + 1 and s1['call'] == s0['call'] + 2
+    assert obs.shape == (8, 75) and r.shape == (8, 1) and d.shape == (8, 1) and d.dtype == torch.bool
+    assert set(info) == {'self_collision', 'edge_collision'}
+
+
+def test_reading_envs_flushes_the_postponed_reset(env_and_log):
+    env, log = env_and_log
+    _, _, d, _ = _step(env)
+    env.reset(d, return_observations=False)
+    _ = env.envs                                                # looks at the state
+    assert [c[0] for c in log] == ['step', 'reset'] and log[1][1]['call'] == log[0][1]['call'] + 1
+    assert not log[1][1]['obs']
+    _step(env)
+    assert not log[2][1]['pending']                             # nothing left to apply
+
+
+def test_reset_observation_moves_into_the_step_launch_once_asked_for(env_and_log):
+    env, log = env_and_log
+    _, _, d, _ = _step(env)
+    back = env.reset(d)                                         # first time: eager launch with an observation
+    assert back is not None and [c[0] for c in log] == ['step', 'reset'] and log[1][1]['obs']
+    _, _, d, _ = _step(env)
+    assert log[2][1]['want_after'] and not log[2][1]['pending']
+    back = env.reset(d)                                         # now served by the step launch, reset deferred
+    assert back is not None and len(log) == 3
+    _step(env)
+    assert log[3][1]['pending'] and log[3][1]['want_after']
+    env.reset(env.done, return_observations=False)              # env.done is the step's own flags too
+    _step(env)
+    assert log[4][1]['pending'] and not log[4][1]['want_after']
+
+
+def test_anything_else_is_an_eager_reset(env_and_log):
+    env, log = env_and_log
+    _, _, d, _ = _step(env)
+    env.reset(d.clone(), return_observations=False)             # another tensor object
+    _, _, d, _ = _step(env)
+    d[:] = False                                                # edited in place: version counter moved
+    env.reset(d, return_observations=False)
+    _, _, d, _ = _step(env)
+    env._observe('default')                                     # consumed nothing, but looked at the state
+    env.reset(d, return_observations=False)
+    names = [c[0] for c in log]
+    assert names == ['step', 'reset', 'step', 'reset', 'step', 'observe', 'reset']
+    assert not any(c[1]['pending'] for c in log if c[0] == 'step')
+    calls = [c[1]['call'] for c in log if 'call' in c[1]]
+    assert calls == sorted(calls) and len(set(calls)) == len(calls)   # one counter value per call, increasing
+
+
+def test_lazy_reset_can_be_switched_off_and_assignment_drops_the_pending_reset(env_and_log):
+    env, log = env_and_log
+    _, _, d, _ = _step(env)
+    env.reset(d, return_observations=False)
+    env.envs = torch.zeros(8, 3, 9, 9)                          # wholesale replacement: the postponed reset is void
+    _step(env)
+    assert [c[0] for c in log] == ['step', 'step'] and not log[1][1]['pending']
+    assert log[1][1]['envs'] == env.envs.data_ptr()
+    env.lazy_reset = False
+    _, _, d, _ = _step(env)
+    env.reset(d, return_observations=False)
+    assert log[-1][0] == 'reset'
+
+
+def test_argument_errors_match_the_reference(env_and_log):
+    env, _ = env_and_log
+    with pytest.raises(TypeError):
+        env.step(torch.zeros(8))
+    with pytest.raises(RuntimeError):
+        env.step(torch.zeros(7, dtype=torch.int64))
+    with pytest.raises(RuntimeError):
+        env.step(torch.zeros(8, dtype=torch.int16))
