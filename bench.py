@@ -408,7 +408,15 @@ def extra_measurements(device):
                  lambda c: (c, 8192), 4, 16, 6, 12 * 36 * 36,
                  'BASELINE configs[4]: SingleSnake 8192x36x36 default-RGB obs, fused rollout, 16 batch-steps per launch '
                  '(the launch writes the 15 552 B observation per env-step; SURVEY byte model of an unfused pair: 41 511 B)')
+    rollout_case('rollout_cfg5_8192x36_default_64steps',
+                 lambda: SingleSnake(8192, 36, observation_mode='default', device=device, seed=0),
+                 lambda c: (c, 8192), 4, 64, 4, 12 * 36 * 36,
+                 'BASELINE configs[4] as above with 64 batch-steps per launch (the state load / store and the launch are '
+                 'amortised over four times as many steps)')
     # (d) BASELINE configs[3]: MultiSnake 4096 x 25 x 25, 4 agents, constructor defaults ('full' obs)
+    rollout_case('multi_rollout_cfg4_4096x25_k4_full_64steps', lambda: MultiSnake(4096, 4, 25, device=device, seed=0),
+                 lambda c: (c, 4, 4096), 8, 64, 4, 12 * 4 * 25 * 25,
+                 'BASELINE configs[3] with 64 batch-steps per launch')
     rollout_case('multi_rollout_cfg4_4096x25_k4_full', lambda: MultiSnake(4096, 4, 25, device=device, seed=0),
                  lambda c: (c, 4, 4096), 8, 16, 6, 12 * 4 * 25 * 25,
                  'BASELINE configs[3]: MultiSnake 4096x25x25, 4 agents, defaults, step+observe+reset(__all__) per '

@@ -61,7 +61,7 @@ struct MultiArgs {
     uint8_t *am_u8;
     long long T;          // rollout: number of fused step+reset iterations
     uint8_t *boost_state; // rollout: boost_this_step (N*K) written back at the end
-    int lds_per_wave, off_body, off_food, off_occ, off_hmap, off_img, off_col, off_snap;
+    int lds_per_wave, off_body, off_food, off_occ, off_hmap, off_img, off_col, off_snap, off_acts;
 };
 
 struct Ctx {
@@ -75,6 +75,7 @@ struct Ctx {
     unsigned char *occ;    // [C] scratch (reset: occupancy)
     unsigned char *hmap;   // [C] head owner + 1 per cell, all-zero outside observe_full
     unsigned short *snap;  // [C] observe_full_snap: class code per cell
+    unsigned char *acts;   // [64][K] rollout: the actions of the current 64-step chunk (see multi_rollout_kernel)
     short *img;            // [3][C] env image (partial_n)
     float *colf;           // [K][4]: r, g, b, 1 + 0.5*boost
 };
@@ -99,6 +100,7 @@ __device__ __forceinline__ Ctx make_ctx(const MultiArgs &p, int wave)
     cx.occ = base + p.off_occ;
     cx.hmap = base + p.off_hmap;
     cx.snap = (unsigned short *)(base + (p.off_snap >= 0 ? p.off_snap : 0));
+    cx.acts = base + p.off_acts;
     cx.img = (short *)(base + p.off_img);
     cx.colf = (float *)(base + p.off_col);
     return cx;
@@ -456,8 +458,8 @@ __device__ __forceinline__ void observe_full(const Ctx &cx, const MultiArgs &p, 
 // produced from the codes:   code = body mask of snakes 0..7 | (head owner + 1) << 8 | food << 14 | border << 15
 // (Also tried, measured, dropped: issuing these stores in four parts between the phases of the NEXT step, so that the
 // store queue would drain while the wave computes — no gain: the waves of a launch stall on the store path together.)
-__device__ __forceinline__ void observe_full_snap(const Ctx &cx, const MultiArgs &p, float *__restrict__ obs,
-                                                  long long env, int hc)
+// class code of every cell of the env in LDS -> snap[] (executed by the wave that owns the env's state)
+__device__ __forceinline__ void snap_write(const Ctx &cx, int hc, unsigned short *snap)
 {
     const int S = cx.S, C = cx.C, K = cx.K, lane = cx.lane;
     if (lane < K && hc >= 0) cx.hmap[hc] = (unsigned char)(lane + 1);
@@ -472,20 +474,26 @@ __device__ __forceinline__ void observe_full_snap(const Ctx &cx, const MultiArgs
             v |= (u32)cx.hmap[c] << 8;
             v |= (u32)(cx.food[c] != 0) << 14;
             v |= (u32)edge << 15;
-            cx.snap[c] = (unsigned short)v;
+            snap[c] = (unsigned short)v;
         }
     }
     wave_lds_sync();
     if (lane < K && hc >= 0) cx.hmap[hc] = 0;
+    wave_lds_sync();
+}
+
+// the K agents' observations of one env from its class codes, agent by agent (any wave of the workgroup may run this)
+__device__ __forceinline__ void snap_emit(const Ctx &cx, const MultiArgs &p, float *obs_env, const unsigned short *snap)
+{
+    const int C = cx.C, K = cx.K, lane = cx.lane;
     const float G1 = 192.0f / 255.0f, G2 = 96.0f / 255.0f;
-    float *const obs_env = (float *)uniform64((long long)(obs + env * p.obs_elems)); // agent 0's observation of this env
     const long long agent_stride = p.N * p.obs_elems;
     for (int a = 0; a < K; ++a) {
         float *const base = obs_env + a * agent_stride;
         for (int k = 0; k < cx.cpl; ++k) {
             const int c = lane + 64 * k;
             if (c < C) {
-                const u32 v = (u32)cx.snap[c];
+                const u32 v = (u32)snap[c];
                 const bool edge = (v >> 15) != 0, fd = ((v >> 14) & 1u) != 0;
                 const int ho = (int)((v >> 8) & 15u) - 1;
                 const u32 bm = v & 0xffu;
@@ -504,6 +512,13 @@ __device__ __forceinline__ void observe_full_snap(const Ctx &cx, const MultiArgs
             }
         }
     }
+}
+
+__device__ __forceinline__ void observe_full_snap(const Ctx &cx, const MultiArgs &p, float *__restrict__ obs,
+                                                  long long env, int hc)
+{
+    snap_write(cx, hc, cx.snap);
+    snap_emit(cx, p, (float *)uniform64((long long)(obs + env * p.obs_elems)), cx.snap);
     wave_lds_sync();
 }
 
@@ -1022,13 +1037,36 @@ __global__ __launch_bounds__(256) void multi_observe_kernel(MultiArgs p)
 // per launch instead of four times per iteration; per iteration only the actions are read and the outputs written.
 //   actions (T,K,N);  out_f32 (T,3,K,N) = rewards, food, sizes;  out_u8 (T,4,K,N) = dones, boost, snake_collision,
 //   edge_collision;  all_done (T,N);  obs (T,K,N,elems).
+// TWO ('full' observations of at most 8 snakes): a workgroup is TWO waves for ONE env.  Wave 0 steps the env and leaves
+// the class codes of the stepped state in one of two LDS buffers; wave 1 turns the codes of step t into the ~120 stores
+// of its observation while wave 0 is already computing step t + 1; one s_barrier per step hands a buffer over.  The
+// transition (latency-bound LDS work) and the observation (store-bound) of a launch otherwise ADD UP — every wave is in
+// the same phase — and interleaving them inside one wave does not help (measured); two waves with their own
+// instruction streams do overlap.
+__device__ __forceinline__ void workgroup_handoff()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+template <bool TWO>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void multi_rollout_kernel(MultiArgs p)
 {
-    const int wave = (int)(threadIdx.x >> 6), wpb = (int)(blockDim.x >> 6);
-    const long long env = xcd_block(blockIdx.x, gridDim.x) * wpb + wave;
+    const int wave = uniform((int)(threadIdx.x >> 6)), wpb = TWO ? 1 : (int)(blockDim.x >> 6);
+    const long long env = xcd_block(blockIdx.x, gridDim.x) * wpb + (TWO ? 0 : wave);
     if (env >= p.N) return;
-    const Ctx cx = make_ctx(p, wave);
+    const Ctx cx = make_ctx(p, TWO ? 0 : wave);
     const int C = cx.C, K = cx.K, lane = cx.lane;
+    if (TWO && wave == 1) { // the writer: observation of step t from buffer t & 1, handed over by the barrier of step t
+        const long long KNw = (long long)K * p.N;
+        for (long long t = 0; t < p.T; ++t) {
+            workgroup_handoff();
+            snap_emit(cx, p, (float *)uniform64((long long)(p.obs + t * KNw * p.obs_elems + env * p.obs_elems)),
+                      cx.snap + (t & 1) * C);
+        }
+        return;
+    }
     const bool snake = lane < K;
     const u64 env_id = (u64)(p.env_offset + env);
     const long long agent = env * K + lane, KN = (long long)K * p.N;
@@ -1046,7 +1084,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void m
 
     for (long long t = 0; t < p.T; ++t) {
         const u64 call = p.call + 2ull * (u64)t;
-        const long long a = snake ? p.actions[t * KN + (long long)lane * p.N + env] : 0;
+        // Actions come from LDS, 64 steps at a time.  A global LOAD inside the step loop would queue behind the
+        // observation stores of the whole CU — the vector memory pipeline is in order — and every step would wait for
+        // the store backlog to drain: that, not the arithmetic, is why transition and observation time used to add up.
+        // Kept per action: a % 4 (C semantics, -3..3) and a > 3, which is all the step reads of it (:483-484).
+        if ((t & 63) == 0) {
+            const int nt = (int)min((long long)64, p.T - t);
+            wave_lds_sync();
+            for (int i = lane; i < nt * K; i += 64) {
+                const int j = i / K, sidx = i - j * K;
+                const long long av = p.actions[(t + j) * KN + (long long)sidx * p.N + env];
+                cx.acts[i] = (unsigned char)(((int)(av % 4) + 4) | (av > 3 ? 8 : 0));
+            }
+            wave_lds_sync();
+        }
+        long long a = 0;
+        if (snake) {
+            const int b = cx.acts[(int)(t & 63) * K + lane];
+            const int d4 = (b & 7) - 4;
+            a = (b & 8) ? 4 + d4 : d4; // same a % 4 and a > 3 as the caller's value (a > 3 implies a % 4 >= 0)
+        }
         StepRes r;
         multi_step_body(cx, p, env, env_id, call, a, sn, r, t * p.N * C, t * KN, t * p.N);
         if (snake) {
@@ -1062,7 +1119,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void m
             ob[3 * KN + am] = (uint8_t)r.edgecol;
         }
         if (lane == 0) p.all_done[t * p.N + env] = (uint8_t)r.all_done;
-        if (p.obs_mode != WURM_OBS_NONE) observe(cx, p, p.obs + t * KN * p.obs_elems, env, sn);
+        if (TWO) {
+            // buffer t & 1 is free: the writer finished with it before it arrived at the barrier of step t - 1
+            snap_write(cx, sn.hc, cx.snap + (t & 1) * C);
+            workgroup_handoff();
+        } else if (p.obs_mode != WURM_OBS_NONE) {
+            observe(cx, p, p.obs + t * KN * p.obs_elems, env, sn);
+        }
         rebase_clocks(cx);
 
         // reset(dones['__all__']) (:771-836)
@@ -1159,7 +1222,7 @@ __global__ void multi_colours_kernel(short *colours, long long N, int K, int fix
 
 // ------------------------------------------------------------------------------------------------ host side
 
-static int multi_layout(MultiArgs &p, bool need_img, bool need_snap)
+static int multi_layout(MultiArgs &p, bool need_img, int need_snap)
 {
     const int C = p.S * p.S, K = p.K;
     int off = 12 * K;                      // hcell, lmax, tclk
@@ -1176,7 +1239,8 @@ static int multi_layout(MultiArgs &p, bool need_img, bool need_snap)
     p.off_img = off; if (need_img) off += 6 * C;
     off = (off + 15) & ~15;
     p.off_snap = -1;
-    if (need_snap) { p.off_snap = off; off += 2 * C; }
+    if (need_snap) { p.off_snap = off; off += need_snap * ((2 * C + 15) & ~15); }
+    p.off_acts = off; off += 64 * K;
     p.lds_per_wave = (off + 15) & ~15;
     return p.lds_per_wave;
 }
@@ -1186,12 +1250,22 @@ enum MKind { MK_STEP, MK_RESET, MK_OBSERVE, MK_CHECK, MK_ROLLOUT };
 static int multi_launch(MKind kind, MultiArgs &p, void *stream)
 {
     if (p.N == 0) return WURM_OK;
-    // 'full' observations of at most 8 snakes go through a per-cell class code in LDS (observe_full_snap)
-    const int lds = multi_layout(p, p.obs_mode == WURM_OBS_PARTIAL, p.obs_mode == WURM_OBS_DEFAULT && p.K <= 8);
+    // 'full' observations of at most 8 snakes go through a per-cell class code in LDS (observe_full_snap); rollouts
+    // double-buffer it between a stepping and a writing wave (multi_rollout_kernel<true>)
+    const bool snap = p.obs_mode == WURM_OBS_DEFAULT && p.K <= 8;
+    const bool two = kind == MK_ROLLOUT && snap && p.T > 1;
+    const int lds = multi_layout(p, p.obs_mode == WURM_OBS_PARTIAL, snap ? (two ? 2 : 1) : 0);
     if (lds > 65536) return WURM_ERR_UNSUPPORTED;
     // few envs: one wave per workgroup so that they spread over all 256 CUs; from 2048 envs on 4 waves per workgroup
     // (8 workgroups per CU either way; the observation stream of 4096 envs measured ~5 % faster this way)
     int wpb = p.N < 2048 ? 1 : 4;
+    if (two) { // one env per workgroup of two waves
+        if (lds > 65536) return WURM_ERR_UNSUPPORTED;
+        dim3 block2(128), grid2((unsigned)p.N);
+        (void)hipGetLastError();
+        hipLaunchKernelGGL(multi_rollout_kernel<true>, grid2, block2, (size_t)lds, (hipStream_t)stream, p);
+        return hipGetLastError() == hipSuccess ? WURM_OK : WURM_ERR_HIP;
+    }
     while (wpb > 1 && lds * wpb > 65536) wpb >>= 1;
     dim3 block(64 * wpb), grid((unsigned)((p.N + wpb - 1) / wpb));
     size_t shmem = kind == MK_CHECK ? 0 : (size_t)lds * wpb;
@@ -1202,7 +1276,7 @@ static int multi_launch(MKind kind, MultiArgs &p, void *stream)
     case MK_RESET: hipLaunchKernelGGL(multi_reset_kernel, grid, block, shmem, st, p); break;
     case MK_OBSERVE: hipLaunchKernelGGL(multi_observe_kernel, grid, block, shmem, st, p); break;
     case MK_CHECK: hipLaunchKernelGGL(multi_check_kernel, grid, block, shmem, st, p); break;
-    case MK_ROLLOUT: hipLaunchKernelGGL(multi_rollout_kernel, grid, block, shmem, st, p); break;
+    case MK_ROLLOUT: hipLaunchKernelGGL(multi_rollout_kernel<false>, grid, block, shmem, st, p); break;
     }
     return hipGetLastError() == hipSuccess ? WURM_OK : WURM_ERR_HIP;
 }
