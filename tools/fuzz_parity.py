@@ -68,6 +68,57 @@ def fuzz_single(rng):
     return desc
 
 
+def fuzz_fused(rng):
+    """wurm_single_step_reset / wurm_grid_step_reset: random mixes of the two groupings ([postponed reset, step, observe]
+    and [step, observe, reset]), with and without the reset observation, an occasional iteration without any reset
+    (irregular states), hostile action values — against the oracle's step / reset pair with the same counters."""
+    grid = rng.rand() < 0.2
+    S = int(rng.choice([9, 9, 10, 11, 12, 14, 20, 25, 36, 48, 64]))
+    N = int(rng.randint(1, 70 if S <= 16 else 10))
+    T = int(rng.randint(5, 80 if S <= 16 else 30))
+    if grid:
+        mode = ['default', 'raw', 'positions', 'none'][rng.randint(4)]
+        start = (int(rng.randint(1, S - 1)), int(rng.randint(1, S - 1)))
+    else:
+        mode = ['default', 'raw', 'one_channel', 'positions', f'partial_{rng.randint(1, 7)}', 'none'][rng.randint(6)]
+        start = None
+    seed, off = int(rng.randint(1 << 30)), int(rng.randint(1 << 20))
+    desc = f'fused grid={grid} S={S} N={N} T={T} mode={mode} seed={seed} off={off}'
+    if os.environ.get('WURM_FUZZ_VERBOSE'):
+        print('start:', desc, flush=True)
+    o, h = OracleBackend(seed, off), HipBackend(seed, off)
+    C = 2 if grid else 3
+    eo = np.zeros((N, C, S, S), np.float32)
+    if grid:
+        o.grid_reset(eo, np.ones(N), start, 'none')
+    else:
+        o.single_reset(eo, np.ones(N), 'none')
+    eh = eo.copy()
+    call, prev, prev_call = 10, None, None
+    dtype = np.int64 if rng.rand() < 0.7 else np.int32
+    for t in range(T):
+        a = rng.randint(0, 4, N).astype(dtype)
+        if rng.rand() < 0.1:
+            a[rng.rand(N) < 0.3] = rng.randint(-9, 9)
+        ao, ah = a.copy(), a.copy()
+        style = rng.randint(4)  # 0: post reset, 1: pre (deferred) reset, 2: deferred + obs_after, 3: no reset at all
+        kw = dict(call=call, grid=start)
+        if style == 0:
+            kw.update(post_reset=True, want_obs_after=bool(rng.rand() < 0.5), pre_done=prev, pre_call=prev_call)
+        elif style in (1, 2):
+            kw.update(pre_done=prev, pre_call=prev_call, want_obs_after=(style == 2))
+        ro, rh = o.single_step_reset(eo, ao, mode, **kw), h.single_step_reset(eh, ah, mode, **kw)
+        same(ao, ah, f'{desc} actions t={t}'); same(eo, eh, f'{desc} state t={t} style={style}')
+        for k in ro:
+            same(ro[k], rh[k], f'{desc} {k} t={t} style={style}')
+        if style == 0 or style == 3:
+            prev, prev_call = None, None          # reset applied (0) or skipped altogether (3)
+        else:
+            prev, prev_call = ro['done'], call + 1  # the caller postponed reset(done): the next launch applies it
+        call += 2
+    return desc
+
+
 def fuzz_lean(rng):
     """The shapes the lean / 9x9 rollout kernels take: chained launches, tape lengths around the 64-step chunk, action
     values outside 0..3, an occasional per-call step without reset in between (irregular states -> generic path)."""
@@ -199,11 +250,11 @@ if __name__ == '__main__':
     ap.add_argument('--seed', type=int, default=0)
     args = ap.parse_args()
     rng = np.random.RandomState(args.seed)
-    t0, n, fails = time.time(), {'single': 0, 'lean': 0, 'policy': 0, 'grid': 0, 'multi': 0}, 0
+    t0, n, fails = time.time(), {'single': 0, 'fused': 0, 'lean': 0, 'policy': 0, 'grid': 0, 'multi': 0}, 0
     while time.time() - t0 < args.seconds:
-        kind = ['single', 'lean', 'policy', 'grid', 'multi'][rng.choice(5, p=[0.25, 0.2, 0.1, 0.05, 0.4])]
+        kind = ['single', 'fused', 'lean', 'policy', 'grid', 'multi'][rng.choice(6, p=[0.2, 0.2, 0.15, 0.05, 0.05, 0.35])]
         try:
-            {'single': fuzz_single, 'lean': fuzz_lean, 'policy': fuzz_policy, 'grid': fuzz_grid,
+            {'single': fuzz_single, 'fused': fuzz_fused, 'lean': fuzz_lean, 'policy': fuzz_policy, 'grid': fuzz_grid,
              'multi': fuzz_multi}[kind](rng)
             n[kind] += 1
         except AssertionError as e:
