@@ -266,6 +266,40 @@ int wurm_multi_step(float *foods, float *heads, float *bodies, uint8_t *dones, i
                     int size, const wurm_multi_config *cfg, uint64_t seed, uint64_t call, int64_t env_offset,
                     const wurm_multi_inject *inject, float *agent_major_f32, uint8_t *agent_major_u8, void *stream);
 
+/* Arguments of wurm_multi_step_reset: the pointers and sizes of wurm_multi_step (same meaning), plus the postponed
+ * reset.  A HOST struct of device pointers. */
+typedef struct wurm_multi_call {
+    float *foods, *heads, *bodies;
+    uint8_t *dones;
+    int64_t *orientations;
+    int16_t *colours;                 /* in/out when pre_done is given (re-rolled colours), else read ('partial_n')   */
+    const int64_t *actions;           /* (K,N)                                                                         */
+    uint8_t *boost_this_step;
+    float *rewards;
+    uint8_t *snake_collision, *edge_collision;
+    float *food_consumed, *sizes;
+    uint8_t *all_done;                /* out (N) = dones['__all__']                                                    */
+    uint8_t *all_done_copy;           /* nullable out (N): second copy of all_done                                     */
+    float *obs;
+    float *agent_major_f32;           /* nullable, as wurm_multi_step                                                  */
+    uint8_t *agent_major_u8;
+    const uint8_t *pre_done;          /* nullable in (N): wurm_multi_reset(done_env = pre_done, call = pre_call, no
+                                         observation) is applied to every env BEFORE the step                         */
+    const wurm_multi_inject *inject;            /* nullable: outcomes of the step                                      */
+    const wurm_multi_reset_inject *pre_inject;  /* nullable: outcomes of the reset in front of it                      */
+    int64_t num_envs, env_offset;
+    uint64_t seed, call, pre_call;
+    int num_snakes, size, obs_mode, obs_n;
+    wurm_multi_config cfg;
+} wurm_multi_call;
+
+/* One launch for one iteration of the caller loop of experiments/speeds.py:30-37 / tests/test_multi_snake_env.py:78-89,
+ *     obs, rewards, dones, info = env.step(actions);  env.reset(dones['__all__'])
+ * as [the reset the caller postponed, step, observe]: the host class defers reset(...) into the next step's launch and
+ * flushes it with wurm_multi_reset if the state is looked at in between.  Bit-identical to the wurm_multi_reset (without
+ * observation) / wurm_multi_step pair with the same counters.  pre_done = NULL: plain wurm_multi_step. */
+int wurm_multi_step_reset(const wurm_multi_call *c, void *stream);
+
 /* MultiSnake.reset (multi_snake.py:771-836): envs flagged in done_env (N bytes) are rebuilt (_create_envs
  * :996-1019: K snakes placed one after another on free cells away from everything, one food); colours of
  * snakes that are still dead are re-rolled (colour_random); respawn_any: the first dead snake of every env

@@ -305,6 +305,41 @@ def multi_step(self, st, actions, cfg, mode, inject=None):
                 size=size.cpu().numpy(), all_done=all_done.cpu().numpy())
 
 
+def multi_step_reset(self, st, actions, cfg, mode, call, pre_done=None, pre_call=0):
+    """wurm_multi_step_reset through the wurm_multi_call block: [wurm_multi_reset(pre_done, pre_call),] step(call)"""
+    import ctypes
+    N, _, S, _ = st['foods'].shape
+    K = st['heads'].shape[0] // N
+    m, n = _lib.parse_obs_mode(mode)
+    d = _multi_to_dev(self, st)
+    act = self._t(np.ascontiguousarray(actions, np.int64))
+    shape = _o.multi_obs_shape(mode, N, K, S)
+    obs = self._empty(shape, torch.float32) if shape else None
+    rewards, food, size = (self._empty((N * K,), torch.float32) for _ in range(3))
+    sc, ec = (self._empty((N * K,), torch.uint8) for _ in range(2))
+    all_done, copy = self._empty((N,), torch.uint8), self._empty((N,), torch.uint8)
+    am_f, am_b = self._empty((3, K, N), torch.float32), self._empty((4, K, N), torch.uint8)
+    pd = self._t((np.asarray(pre_done).reshape(N) != 0).astype(np.uint8)) if pre_done is not None else None
+    c = _lib.MultiCall()
+    for name in ('foods', 'heads', 'bodies', 'dones', 'orientations', 'colours', 'boost_this_step'):
+        setattr(c, name, d[name].data_ptr())
+    c.actions, c.rewards, c.snake_collision, c.edge_collision = act.data_ptr(), rewards.data_ptr(), sc.data_ptr(), ec.data_ptr()
+    c.food_consumed, c.sizes, c.all_done, c.all_done_copy = food.data_ptr(), size.data_ptr(), all_done.data_ptr(), copy.data_ptr()
+    c.obs, c.agent_major_f32, c.agent_major_u8 = _lib.ptr(obs), am_f.data_ptr(), am_b.data_ptr()
+    c.pre_done = _lib.ptr(pd)
+    c.num_envs, c.env_offset, c.seed, c.call, c.pre_call = N, self.env_offset, _lib.u64(self.seed), _lib.u64(call), _lib.u64(pre_call)
+    c.num_snakes, c.size, c.obs_mode, c.obs_n = K, S, m, n
+    c.cfg = _multi_cfg(K, cfg)
+    rc = self.lib.wurm_multi_step_reset(ctypes.addressof(c), self._stream())
+    _lib.check(rc, 'wurm_multi_step_reset')
+    torch.cuda.synchronize()
+    _multi_back(st, d)
+    assert torch.equal(copy, all_done), 'all_done_copy != all_done'
+    return dict(obs=obs.cpu().numpy() if obs is not None else None, rewards=rewards.cpu().numpy(),
+                snake_collision=sc.cpu().numpy(), edge_collision=ec.cpu().numpy(), food=food.cpu().numpy(),
+                size=size.cpu().numpy(), all_done=all_done.cpu().numpy())
+
+
 def multi_reset(self, st, done_env, cfg, inject=None, mode=None):
     import ctypes
     N, _, S, _ = st['foods'].shape
@@ -418,5 +453,5 @@ def multi_rollout(self, st, actions, cfg, mode, inject=None, reset_inject=None):
                 edge_collision=em(out_b[:, 3]), all_done=all_done.cpu().numpy())
 
 
-for _f in (multi_step, multi_reset, multi_observe, multi_check, multi_colours, orientations, multi_rollout):
+for _f in (multi_step, multi_step_reset, multi_reset, multi_observe, multi_check, multi_colours, orientations, multi_rollout):
     setattr(HipBackend, _f.__name__, _f)

@@ -1,0 +1,119 @@
+"""GPU parity of MultiSnake's one-launch iteration: wurm_multi_step_reset ([postponed reset,] step, observe) against the
+oracle's reset / step pair with the same counters, and the MultiSnake class whose reset(dones['__all__'],
+return_observations=False) is deferred into the next step's launch — including callers that look at or edit the state
+attributes in between, other masks, respawn_mode='any' and re-rolled colours.  Bit-exact everywhere."""
+import numpy as np
+import pytest
+
+from oracle import oracle as _o
+from tests.backends import OracleBackend
+from tests.test_hip_multi_vs_oracle import CFGS, _same, _same_state
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def hip():
+    from tests.hip_backend import HipBackend
+    return HipBackend
+
+
+@pytest.mark.parametrize('N,K,S,T,mode,cfg', [
+    (16, 4, 25, 60, 'full', 'default'),         # BASELINE cfg4 shape
+    (12, 4, 25, 80, 'partial_5', 'train'),      # respawn 'any', random_rate food
+    (10, 3, 10, 90, 'full', 'dense'),           # fixed colours, crowded
+    (9, 2, 12, 90, 'full', 'noboost'),
+    (7, 1, 5, 60, 'full', 'default'),
+])
+def test_postponed_reset_in_front_of_the_step(hip, N, K, S, T, mode, cfg):
+    cfg = CFGS[cfg]
+    rng = np.random.RandomState(K * S)
+    o, h = OracleBackend(seed=3, env_offset=11), hip(seed=3, env_offset=11)
+    so = _o.multi_empty_state(N, K, S)
+    so['colours'][...] = o.multi_colours(N, K, cfg['colour_mode'] == 'fixed', call=0)
+    o.call = 1
+    assert o.multi_reset(so, np.ones(N), cfg) == 0
+    sh = {k: v.copy() for k, v in so.items()}
+    call, prev, prev_call = 2, None, 0
+    deaths = 0
+    for t in range(T):
+        a = rng.randint(0, 8, size=(K, N)).astype(np.int64)
+        # oracle: the postponed reset (if any) with its counter, then the step with its own
+        if prev is not None:
+            o.call = prev_call
+            o.multi_reset(so, prev, cfg)
+        o.call = call
+        ro = o.multi_step(so, a, cfg, mode)
+        rh = h.multi_step_reset(sh, a, cfg, mode, call=call, pre_done=prev, pre_call=prev_call)
+        _same_state(so, sh, f'state t={t}')
+        for k in ro:
+            _same(ro[k], rh[k], f'{k} t={t}')
+        deaths += int(so['dones'].sum())
+        if t % 5 == 4:      # no reset this time: dead snakes are stepped again
+            prev = None
+        elif t % 7 == 3:    # an arbitrary mask
+            prev, prev_call = (rng.rand(N) < 0.3).astype(np.uint8), call + 1
+        else:
+            prev, prev_call = ro['all_done'], call + 1
+        call += 2
+    assert deaths > 0
+
+
+@pytest.mark.parametrize('lazy', [True, False])
+@pytest.mark.parametrize('cfg_name,mode', [('default', 'full'), ('train', 'partial_3')])
+def test_class_loop_equals_oracle_loop(lazy, cfg_name, mode):
+    import torch
+    from wurm_amd.envs import MultiSnake
+    cfg = CFGS[cfg_name]
+    N, K, S, T, seed = 24, 3, 14, 120, 99
+    env = MultiSnake(N, K, S, device='cuda:0', seed=seed, env_offset=7, observation_mode=mode, lazy_reset=lazy,
+                     boost=cfg['boost'], food_on_death_prob=cfg['food_on_death_prob'],
+                     boost_cost_prob=cfg['boost_cost_prob'], food_mode=cfg['food_mode'], food_rate=cfg['food_rate'],
+                     respawn_mode=cfg['respawn_mode'], reward_on_death=cfg['reward_on_death'],
+                     agent_colours=cfg['colour_mode'])
+    o = OracleBackend(seed=seed, env_offset=7)
+    st = _o.multi_empty_state(N, K, S)
+    st['colours'][...] = o.multi_colours(N, K, cfg['colour_mode'] == 'fixed', call=0)
+    o.call = 1
+    assert o.multi_reset(st, np.ones(N), cfg) == 0
+    g = torch.Generator().manual_seed(5)
+
+    def check_state(what):
+        _same(env.foods.cpu().numpy(), st['foods'], what + ' foods')
+        _same(env.heads.cpu().numpy(), st['heads'], what + ' heads')
+        _same(env.bodies.cpu().numpy(), st['bodies'], what + ' bodies')
+        _same(env.dones.cpu().numpy().astype(np.uint8), st['dones'], what + ' dones')
+        _same(env.orientations.cpu().numpy(), st['orientations'], what + ' orientations')
+        _same(env.agent_colours.cpu().numpy(), st['colours'], what + ' colours')
+
+    check_state('fresh')
+    for t in range(T):
+        a = torch.randint(8, (K, N), generator=g)
+        obs, rew, dones, info = env.step({f'agent_{i}': a[i].cuda() for i in range(K)})
+        r = o.multi_step(st, a.numpy(), cfg, mode)
+        for i in range(K):
+            _same(obs[f'agent_{i}'].cpu().numpy(), r['obs'][i], f'obs {i} t={t}')
+            _same(rew[f'agent_{i}'].cpu().numpy(), r['rewards'].reshape(N, K)[:, i], f'reward {i} t={t}')
+            _same(dones[f'agent_{i}'].cpu().numpy().astype(np.uint8), st['dones'].reshape(N, K)[:, i], f'done {i} t={t}')
+            _same(info[f'size_{i}'].cpu().numpy(), r['size'].reshape(N, K)[:, i], f'size {i} t={t}')
+        _same(dones['__all__'].cpu().numpy().astype(np.uint8), r['all_done'], f'all_done t={t}')
+        k = t % 6
+        if k == 4:          # the reference's default: the reset returns observations (eager)
+            back = env.reset(dones['__all__'])
+            o.multi_reset(st, r['all_done'], cfg, mode=mode)
+            for i in range(K):
+                _same(back[f'agent_{i}'].cpu().numpy(), o.last_reset_obs[i], f'reset obs {i} t={t}')
+        elif k == 5:        # another mask object
+            env.reset(dones['__all__'].clone(), return_observations=False)
+            o.multi_reset(st, r['all_done'], cfg)
+        else:               # deferred when lazy
+            assert env.reset(dones['__all__'], return_observations=False) is None
+            o.multi_reset(st, r['all_done'], cfg)
+        if k == 1:          # looking at the state applies the postponed reset
+            check_state(f't={t}')
+        if k == 2:          # ... and so does editing it
+            f = env.foods
+            f[0, 0, 1, 1] = 1.0
+            st['foods'][0, 0, 1, 1] = 1.0
+    check_state('final')
+    env.check_consistency() if (o.multi_check(st) == 0).all() else None

@@ -54,6 +54,8 @@ struct MultiArgs {
     int has_inj;
     const uint8_t *done_env;
     int *status;
+    u64 pre_call;            // multi_step_kernel: counter of the postponed reset applied in front of the step
+    uint8_t *all_done_copy;  // nullable: second copy of all_done (a buffer the caller cannot modify)
     wurm_multi_reset_inject rinj;
     int has_rinj;
     uint32_t *err;
@@ -728,6 +730,13 @@ __device__ __forceinline__ void multi_step_body(const Ctx &cx, const MultiArgs &
     wave_lds_sync();
 }
 
+// defined in the reset section below; multi_step_kernel applies a postponed reset in front of its transition
+__device__ __forceinline__ bool reroll_colour(const MultiArgs &p, long long agent, bool dead, u64 env_id, u64 call,
+                                              long long offA, Snake &sn);
+__device__ __forceinline__ void multi_reset_grid(const Ctx &cx, const MultiArgs &p, long long env, u64 env_id, u64 call,
+                                                 bool rebuild, bool respawn, Snake &sn, bool &orient_dirty,
+                                                 long long offA, long long offE);
+
 __global__ __launch_bounds__(256) void multi_step_kernel(MultiArgs p)
 {
     const int wave = (int)(threadIdx.x >> 6), wpb = (int)(blockDim.x >> 6);
@@ -747,8 +756,28 @@ __global__ __launch_bounds__(256) void multi_step_kernel(MultiArgs p)
     sn.done = snake ? p.dones[agent] != 0 : true;
     sn.orient = snake ? p.orientations[agent] : 0;
     sn.boosted = false;
-    load_colour(p, agent, snake && p.obs_mode == WURM_OBS_PARTIAL, sn);
     const int hc0 = sn.hc;
+    bool rebuilt = false;
+    if (p.done_env != nullptr) {
+        // the reset(done) the caller postponed (wurm_multi_step_reset): exactly multi_reset_kernel without observation,
+        // with its own counter, in front of the transition
+        const bool rebuild = uniform((int)p.done_env[env]) != 0;
+        if (rebuild) sn.done = false; // :798
+        load_colour(p, agent, snake, sn);
+        if (snake && reroll_colour(p, agent, sn.done, env_id, p.pre_call, 0, sn)) {
+            p.colours[agent * 3] = sn.col[0];
+            p.colours[agent * 3 + 1] = sn.col[1];
+            p.colours[agent * 3 + 2] = sn.col[2];
+        }
+        const bool respawn = p.cfg.respawn_any && ballot(snake && sn.done) != 0;
+        if (rebuild || respawn) {
+            bool orient_dirty = false;
+            multi_reset_grid(cx, p, env, env_id, p.pre_call, rebuild, respawn, sn, orient_dirty, 0, 0);
+        }
+        rebuilt = rebuild;
+    } else {
+        load_colour(p, agent, snake && p.obs_mode == WURM_OBS_PARTIAL, sn);
+    }
     const long long a = snake ? p.actions[(long long)lane * p.N + env] : 0;
     StepRes r;
     multi_step_body(cx, p, env, env_id, p.call, a, sn, r, 0, 0, 0);
@@ -774,9 +803,12 @@ __global__ __launch_bounds__(256) void multi_step_kernel(MultiArgs p)
             p.am_u8[3 * KN + am] = (uint8_t)r.edgecol;
         }
     }
-    if (lane == 0) p.all_done[env] = (uint8_t)r.all_done;
+    if (lane == 0) {
+        p.all_done[env] = (uint8_t)r.all_done;
+        if (p.all_done_copy) p.all_done_copy[env] = (uint8_t)r.all_done;
+    }
 
-    store_env(cx, foodp, headp, bodyp, fbits0, hc0, sn.hc, false);
+    store_env(cx, foodp, headp, bodyp, fbits0, hc0, sn.hc, rebuilt); // a rebuilt env is stored whole
     if (p.obs_mode != WURM_OBS_NONE) observe(cx, p, p.obs, env, sn);
 }
 
@@ -1330,6 +1362,32 @@ int wurm_multi_step(float *foods, float *heads, float *bodies, uint8_t *dones, i
     p.seed = seed; p.call = call; p.env_offset = env_offset;
     if (inject) { p.inj = *inject; p.has_inj = 1; }
     if (agent_major_f32 && agent_major_u8) { p.am_f32 = agent_major_f32; p.am_u8 = agent_major_u8; }
+    return multi_launch(MK_STEP, p, stream);
+}
+
+int wurm_multi_step_reset(const wurm_multi_call *c, void *stream)
+{
+    if (!c) return WURM_ERR_INVALID_ARG;
+    int rc = multi_check_args(c->num_envs, c->num_snakes, c->size, c->obs_mode, c->obs_n, c->obs);
+    if (rc) return rc;
+    if (c->num_envs > 0 && (!c->foods || !c->heads || !c->bodies || !c->dones || !c->orientations || !c->actions ||
+                            !c->boost_this_step || !c->rewards || !c->snake_collision || !c->edge_collision ||
+                            !c->food_consumed || !c->sizes || !c->all_done))
+        return WURM_ERR_INVALID_ARG;
+    if ((c->obs_mode == WURM_OBS_PARTIAL || c->pre_done) && c->num_envs > 0 && !c->colours) return WURM_ERR_INVALID_ARG;
+    if (c->pre_done && c->size < 5) return WURM_ERR_UNSUPPORTED;
+    MultiArgs p = {};
+    p.foods = c->foods; p.heads = c->heads; p.bodies = c->bodies; p.dones = c->dones;
+    p.orientations = (long long *)c->orientations; p.actions = (const long long *)c->actions; p.boost = c->boost_this_step;
+    p.rewards = c->rewards; p.snakecol = c->snake_collision; p.edgecol = c->edge_collision; p.foodcons = c->food_consumed;
+    p.sizes = c->sizes; p.all_done = c->all_done; p.all_done_copy = c->all_done_copy; p.colours = c->colours;
+    p.obs = c->obs; p.obs_mode = c->obs_mode; p.obs_n = c->obs_n;
+    p.obs_elems = multi_obs_elems(c->obs_mode, c->obs_n, c->size); p.N = c->num_envs; p.K = c->num_snakes; p.S = c->size;
+    p.cfg = c->cfg; p.seed = c->seed; p.call = c->call; p.env_offset = c->env_offset;
+    p.done_env = c->pre_done; p.pre_call = c->pre_call;
+    if (c->inject) { p.inj = *c->inject; p.has_inj = 1; }
+    if (c->pre_inject) { p.rinj = *c->pre_inject; p.has_rinj = 1; }
+    if (c->agent_major_f32 && c->agent_major_u8) { p.am_f32 = c->agent_major_f32; p.am_u8 = c->agent_major_u8; }
     return multi_launch(MK_STEP, p, stream);
 }
 

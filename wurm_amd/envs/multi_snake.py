@@ -12,6 +12,14 @@ changed after construction, as the reference allows.
 Deviations: see wurm_amd/envs/single_snake.py (bool masks, Philox RNG via `seed` / `env_offset`, GPU only); only
 `dtype=torch.float` is supported; a snake that finds no room during env creation stays dead instead of raising
 (the constructor checks and raises like the reference, `reset()` does not sync to check).
+
+Per-call path: `step` is one launch (wurm_multi_step_reset).  `reset(done, return_observations=False)` called with the very
+`dones['__all__']` the last `step` returned is DEFERRED into the next step's launch (`lazy_reset=True`, the default), with
+the RNG counter the eager call would have used — bit-identical results; the state attributes (`foods`, `heads`, `bodies`,
+`dones`, `orientations`, `agent_colours`) are properties that first apply a postponed reset, as does every method that
+looks at the state.  A reset whose observation is asked for (the reference's default) is executed at once: it has to
+write all K agents' observations a second time.  As for SingleSnake, a tensor alias taken before the deferred reset is
+the one thing that is not tracked.
 """
 import ctypes
 from collections import namedtuple, OrderedDict
@@ -28,8 +36,37 @@ Spec = namedtuple('Spec', ['reward_threshold'])
 _INT_TYPES = (torch.short, torch.int, torch.long)
 
 
+class _Flushing(object):
+    """State attribute of MultiSnake: reading or assigning it first applies a postponed reset(done)."""
+
+    def __init__(self, name):
+        self.slot = '_' + name
+
+    def __get__(self, obj, cls):
+        if obj is None:
+            return self
+        if obj._pending:
+            obj._flush()
+        return getattr(obj, self.slot)
+
+    def __set__(self, obj, value):
+        if obj._pending:
+            obj._flush()  # the reference applied the reset before this assignment; the other tensors still need it
+        obj._last_fresh = False
+        setattr(obj, self.slot, value)
+
+
 class MultiSnake(object):
     """Batched multi-agent snake environment (reference multi_snake.py:18-48)."""
+
+    _pending = False
+    _last_fresh = False
+    foods = _Flushing('foods')
+    heads = _Flushing('heads')
+    bodies = _Flushing('bodies')
+    dones = _Flushing('dones')
+    orientations = _Flushing('orientations')
+    agent_colours = _Flushing('agent_colours')
 
     spec = Spec(float('inf'))
     metadata = {
@@ -58,9 +95,18 @@ class MultiSnake(object):
                  render_args: dict = None,
                  agent_colours: str = 'random',
                  seed: int = None,
-                 env_offset: int = 0):
+                 env_offset: int = 0,
+                 lazy_reset: bool = True):
         self.num_envs = num_envs
         self.num_snakes = num_snakes
+        self.lazy_reset = bool(lazy_reset)
+        self._pend = None            # (N) bytes: the kernels' own copy of the last step's dones['__all__']
+        self._pend_call = 0
+        self._last_all_done = None   # the tensor the last step returned as dones['__all__']
+        self._last_version = -1
+        self._cfg_cache = (None, None)
+        self._mc = None              # persistent wurm_multi_call block
+        self._lifetimes_touched = False
         self.size = size
         self.initial_snake_length = initial_snake_length
         self.on_death = on_death
@@ -89,7 +135,7 @@ class MultiSnake(object):
         self.dones = torch.zeros(N * K, dtype=torch.bool, device=dev)
         self.boost_this_step = torch.zeros(N * K, dtype=torch.bool, device=dev)
         self.rewards = torch.zeros(N * K, dtype=torch.float, device=dev)
-        self.env_lifetimes = torch.zeros(N, dtype=torch.long, device=dev)
+        self._env_lifetimes = torch.zeros(N, dtype=torch.long, device=dev)
         self.snake_lifetimes = torch.zeros((N, K), dtype=torch.long, device=dev)
         self.orientations = torch.zeros(N * K, dtype=torch.long, device=dev)
         self.viewer = None
@@ -148,27 +194,50 @@ class MultiSnake(object):
     def _next_call(self, n: int = 1) -> int:
         c = self._call
         self._call += n
+        self._last_fresh = False
         return c
+
+    @property
+    def env_lifetimes(self) -> torch.Tensor:
+        """reference :106.  The reference never increments it (its use at :705 is dead code): as long as no
+        caller has asked for the tensor it is all zeros and `dones['__all__'] |= env_lifetimes > max_env_lifetime`
+        (:705) / `env_lifetimes[done] = 0` (:797) are skipped; once somebody has, both run as in the reference."""
+        self._lifetimes_touched = True
+        return self._env_lifetimes
+
+    @env_lifetimes.setter
+    def env_lifetimes(self, value):
+        self._lifetimes_touched = True
+        self._env_lifetimes = value
+
+    def _flush(self):
+        """Applies the postponed reset(done) now, with the ordinary reset kernel and the counter it was given."""
+        self._pending = False
+        self._launch_reset(self._pend, None, _lib.OBS_NONE, 0, self._pend_call, None)
 
     def _log(self, msg: str):
         if self.verbose > 0:
             print(msg)
 
     def _cfg(self) -> _lib.MultiConfig:
-        return _lib.multi_config(self.num_snakes, self.boost, self.food_on_death_prob, self.boost_cost_prob,
-                                 self.food_mode, self.food_rate, self.reward_on_death, self.respawn_mode,
-                                 self.colour_mode)
+        key = (self.boost, self.food_on_death_prob, self.boost_cost_prob, self.food_mode, self.food_rate,
+               self.reward_on_death, self.respawn_mode, self.colour_mode)
+        if self._cfg_cache[0] != key:  # dynamics attributes may be changed between calls (reference tests do)
+            self._cfg_cache = (key, _lib.multi_config(self.num_snakes, *key))
+        return self._cfg_cache[1]
 
     def _norm(self, name: str, shape, dtype):
         """State tensors may have been rebound by the caller: bring them to the layout the kernels read."""
-        t = getattr(self, name)
+        t = getattr(self, name)  # (a state attribute: applies a postponed reset first)
         if tuple(t.shape) != tuple(shape):
             raise RuntimeError(f'env.{name} has shape {tuple(t.shape)}, expected {tuple(shape)}')
         if t.dtype != dtype or t.device != self.device or not t.is_contiguous():
             if dtype == torch.bool and t.dtype != torch.bool:
                 t = t != 0
             t = t.to(device=self.device, dtype=dtype).contiguous()
+            fresh = self._last_fresh
             setattr(self, name, t)
+            self._last_fresh = fresh
         return t
 
     def _state(self):
@@ -263,6 +332,8 @@ class MultiSnake(object):
         N, K, S, dev = self.num_envs, self.num_snakes, self.size, self.device
         # reference :492: stack in dict order -> (K, N); the kernel reads agent i's action of env e at [i*N + e]
         stacked = torch.stack([v.reshape(N) for v in actions.values()]).to(device=dev, dtype=torch.long).contiguous()
+        pending = self._pending
+        self._pending = False  # consumed by this launch (the raw attributes below do not flush)
         foods, heads, bodies, dones, orientations, colours, _ = self._state()
         m, n, obs = self._obs_args(self.observation_mode)
 
@@ -271,13 +342,33 @@ class MultiSnake(object):
         am_f = torch.empty((3, K, N), dtype=torch.float32, device=dev)  # agent-major: rewards, food, sizes
         am_b = torch.empty((4, K, N), dtype=torch.bool, device=dev)     # agent-major: dones, boost, snake, edge
         all_done = torch.empty(N, dtype=torch.bool, device=dev)
-        cfg = self._cfg()
-        rc = _lib.call(self.device.index, _lib.lib().wurm_multi_step, 
-            _lib.ptr(foods), _lib.ptr(heads), _lib.ptr(bodies), _lib.ptr(dones), _lib.ptr(orientations),
-            _lib.ptr(stacked), _lib.ptr(bl[0]), _lib.ptr(fl[0]), _lib.ptr(bl[1]), _lib.ptr(bl[2]), _lib.ptr(fl[1]),
-            _lib.ptr(fl[2]), _lib.ptr(all_done), _lib.ptr(colours), _lib.ptr(obs), m, n, _lib.i64(N), K, S,
-            ctypes.byref(cfg), _lib.u64(self.seed), _lib.u64(self._next_call()), _lib.i64(self.env_offset), None,
-            _lib.ptr(am_f), _lib.ptr(am_b), _lib.stream_ptr(self.device.index))
+        c = self._mc
+        if c is None:
+            c = self._mc = _lib.MultiCall()
+            c.num_envs, c.env_offset, c.seed = N, self.env_offset, _lib.u64(self.seed)
+            c.num_snakes, c.size = K, S
+            self._pend = torch.zeros(N, dtype=torch.uint8, device=dev)
+            c.all_done_copy = self._pend.data_ptr()
+            self._mc_addr = ctypes.addressof(c)
+        c.foods, c.heads, c.bodies = foods.data_ptr(), heads.data_ptr(), bodies.data_ptr()
+        c.dones, c.orientations, c.colours = dones.data_ptr(), orientations.data_ptr(), colours.data_ptr()
+        c.actions = stacked.data_ptr()
+        p_fl, p_bl, nk = fl.data_ptr(), bl.data_ptr(), N * K
+        c.rewards, c.food_consumed, c.sizes = p_fl, p_fl + 4 * nk, p_fl + 8 * nk
+        c.boost_this_step, c.snake_collision, c.edge_collision = p_bl, p_bl + nk, p_bl + 2 * nk
+        c.all_done = all_done.data_ptr()
+        c.obs = _lib.ptr(obs)
+        c.agent_major_f32, c.agent_major_u8 = am_f.data_ptr(), am_b.data_ptr()
+        c.obs_mode, c.obs_n = m, n
+        c.cfg = self._cfg()
+        call = self._call
+        self._call = call + 1
+        c.call = call
+        if pending:
+            c.pre_done, c.pre_call = c.all_done_copy, self._pend_call
+        else:
+            c.pre_done = None
+        rc = _lib.call(dev.index, _lib.lib().wurm_multi_step_reset, self._mc_addr, _lib.stream_ptr(dev.index))
         _lib.check(rc, 'MultiSnake.step')
 
         self.boost_this_step = bl[0]
@@ -286,7 +377,9 @@ class MultiSnake(object):
         # reference :701-729 — per-agent dicts; the kernel wrote agent-major rows, so these are plain views
         agents = range(K)
         dones_out = {f'agent_{i}': am_b[0, i] for i in agents}
-        dones_out['__all__'] = all_done | (self.env_lifetimes > self.max_env_lifetime)  # :703-705
+        if self._lifetimes_touched:
+            all_done = all_done | (self._env_lifetimes > self.max_env_lifetime)  # :703-705
+        dones_out['__all__'] = all_done
         rewards = {f'agent_{i}': am_f[0, i] for i in agents}
 
         self.info = {}
@@ -296,6 +389,8 @@ class MultiSnake(object):
         self.info.update({f'boost_{i}': am_b[1, i] for i in agents})
         self.info.update({f'size_{i}': am_f[2, i] for i in agents})
 
+        self._last_all_done, self._last_version = all_done, all_done._version
+        self._last_fresh = not self._lifetimes_touched
         return self._obs_dict(obs), rewards, dones_out, self.info
 
     # ------------------------------------------------------------------ fused multi-step loop (extension)
@@ -332,7 +427,7 @@ class MultiSnake(object):
         _lib.check(rc, 'MultiSnake.rollout')
         if T > 0:
             self.rewards = out_f[-1, 0].t().reshape(-1)
-        self.env_lifetimes.zero_()
+        self._env_lifetimes.zero_()
         return {'observations': obs, 'rewards': out_f[:, 0], 'food': out_f[:, 1], 'size': out_f[:, 2],
                 'dones': out_b[:, 0], 'boost': out_b[:, 1], 'snake_collision': out_b[:, 2],
                 'edge_collision': out_b[:, 3], 'all_done': all_done}
@@ -359,17 +454,21 @@ class MultiSnake(object):
 
     # ------------------------------------------------------------------ reset
 
-    def _reset_kernel(self, done: torch.Tensor, observe: bool, want_status: bool = False):
+    def _launch_reset(self, done: torch.Tensor, obs, m, n, call, status):
         foods, heads, bodies, dones, orientations, colours, boost = self._state()
-        m, n, obs = self._obs_args(self.observation_mode if observe else None)
-        status = torch.zeros(1, dtype=torch.int32, device=self.device) if want_status else None
-        cfg = self._cfg()
-        rc = _lib.call(self.device.index, _lib.lib().wurm_multi_reset, 
+        rc = _lib.call(self.device.index, _lib.lib().wurm_multi_reset,
             _lib.ptr(foods), _lib.ptr(heads), _lib.ptr(bodies), _lib.ptr(dones), _lib.ptr(orientations),
             _lib.ptr(colours), _lib.ptr(done), _lib.ptr(status), _lib.ptr(boost), _lib.ptr(obs), m, n,
-            _lib.i64(self.num_envs), self.num_snakes, self.size, ctypes.byref(cfg), _lib.u64(self.seed),
-            _lib.u64(self._next_call()), _lib.i64(self.env_offset), None, _lib.stream_ptr(self.device.index))
+            _lib.i64(self.num_envs), self.num_snakes, self.size, ctypes.byref(self._cfg()), _lib.u64(self.seed),
+            _lib.u64(call), _lib.i64(self.env_offset), None, _lib.stream_ptr(self.device.index))
         _lib.check(rc, 'MultiSnake.reset')
+
+    def _reset_kernel(self, done: torch.Tensor, observe: bool, want_status: bool = False):
+        if self._pending:
+            self._flush()
+        m, n, obs = self._obs_args(self.observation_mode if observe else None)
+        status = torch.zeros(1, dtype=torch.int32, device=self.device) if want_status else None
+        self._launch_reset(done, obs, m, n, self._next_call(), status)
         if want_status:
             return int(status.item())
         return obs
@@ -380,9 +479,18 @@ class MultiSnake(object):
         Args:
             done: A 1D Tensor of length self.num_envs. A value of 1 means the corresponding environment needs to be
                 reset.  None: every env whose snakes are all dead.
+            return_observations: extension — pass False to skip the K observations the reference's callers discard.
+
+        Called with the very `dones['__all__']` the last `step` returned, nothing in between and
+        `return_observations=False`, the reset is postponed into the next step's launch (module docstring).
         """
         if self.initial_snake_length != 3:
             raise NotImplementedError('Only initial snake length = 3 has been implemented.')
+        if done is not None and done is self._last_all_done and self._last_fresh and self.lazy_reset and \
+                not return_observations and self.size >= 5 and done._version == self._last_version:
+            # env_lifetimes is all zeros here (nobody has asked for it): `env_lifetimes[done] = 0` (:797) is a no-op
+            self._pending, self._pend_call = True, self._next_call()
+            return None
         if done is None:
             done = self._norm('dones', (self.num_envs * self.num_snakes,), torch.bool) \
                 .view(self.num_envs, self.num_snakes).all(dim=1)
@@ -390,7 +498,7 @@ class MultiSnake(object):
         if done.dtype != torch.bool:
             done = done != 0
         done = done.to(self.device).contiguous()
-        self.env_lifetimes.masked_fill_(done, 0)  # :797
+        self._env_lifetimes.masked_fill_(done, 0)  # :797
         obs = self._reset_kernel(done, observe=return_observations)
         if return_observations:
             return self._obs_dict(obs)
@@ -408,7 +516,7 @@ class MultiSnake(object):
         colours = torch.zeros((num_envs * K, 3), dtype=torch.short, device=dev)
         ones = torch.ones(num_envs, dtype=torch.bool, device=dev)
         status = torch.zeros(1, dtype=torch.int32, device=dev)
-        cfg = self._cfg()
+        cfg = _lib.MultiConfig.from_buffer_copy(self._cfg())  # a copy: the cached block stays as it is
         cfg.respawn_any = 0
         rc = _lib.call(self.device.index, _lib.lib().wurm_multi_reset, 
             _lib.ptr(foods), _lib.ptr(heads), _lib.ptr(bodies), _lib.ptr(dones), _lib.ptr(orientations),
