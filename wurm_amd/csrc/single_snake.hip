@@ -1303,7 +1303,10 @@ __device__ __forceinline__ int keep_in_lane(int v, int value, u64 lanes)
     return v;
 }
 
-template <int OBSK>
+// INJ: the random outcomes (food cell of an eating step, seed cell / direction / food cell of a reset) come from
+// p.inject_food / p.inject_reset instead of Philox, so that the tapes recorded from the reference (tests/golden) run
+// through THIS kernel; the RNG instantiation is compiled without any of it.
+template <int OBSK, bool INJ = false>
 __global__ __launch_bounds__(256) void rollout_s9_kernel(StepArgs p)
 {
     constexpr int CPL = 2, S = 9;
@@ -1329,7 +1332,7 @@ __global__ __launch_bounds__(256) void rollout_s9_kernel(StepArgs p)
         lean = head_in && food_in && under_food == 0 && !ring_body;
     }
     if (!uniform((int)lean)) {
-        rollout_generic<CPL, true, OBSK, false>(p, env, envp, g, e, wurm_lds + wave * p.lds_per_wave);
+        rollout_generic<CPL, true, OBSK, INJ>(p, env, envp, g, e, wurm_lds + wave * p.lds_per_wave);
         return;
     }
 
@@ -1393,8 +1396,28 @@ __global__ __launch_bounds__(256) void rollout_s9_kernel(StepArgs p)
             my_mov23 = ent[2] | (ent[3] << 16);
         }
         const u64 my_call = p.call + 2ull * (u64)my_t; // step t uses call0 + 2t, its reset call0 + 2t + 1
-        const S9Reset my_reset = s9_reset_draw(p.seed, my_call + 1ull, env_id);
-        const int my_food = (int)rng_words(p.seed, my_call, env_id, RNG_FOOD, 0).w[0];
+        S9Reset my_reset;
+        int my_food; // RNG: the word the food cell is drawn with; INJ: the food code itself (-1: none)
+        if constexpr (INJ) {
+            // recorded outcomes of step t0 + lane, converted to cell codes 8 * row + column (reset_core's layout of inj[])
+            int sy = 4, sx = 4, d = 0, fc = -1, fe = -1;
+            if (lane < nt) {
+                const int *ir = p.inject_reset + (my_t * p.N + env) * 4;
+                sy = ir[0]; sx = ir[1]; d = ir[2]; fc = ir[3];
+                fe = p.inject_food[my_t * p.N + env];
+            }
+            asm volatile("" : "+v"(sy), "+v"(sx), "+v"(d), "+v"(fc), "+v"(fe)); // retire the loads before the step loop
+            d &= 3;
+            const int sc = sy * 8 + sx, dc = tap_y(d) * 8 + tap_x(d);
+            const int fcy = div_size(max(fc, 0), g.rcpS), fey = div_size(max(fe, 0), g.rcpS);
+            const int fcode = (fc >= 0 && fc < S * S) ? fcy * 8 + (fc - fcy * S) : -1;
+            my_reset.a = d | (fcode << 2);
+            my_reset.b = (sc + dc) | (sc << 7) | ((sc - dc) << 14);
+            my_food = (fe >= 0 && fe < S * S) ? fey * 8 + (fe - fey * S) : -1;
+        } else {
+            my_reset = s9_reset_draw(p.seed, my_call + 1ull, env_id);
+            my_food = (int)rng_words(p.seed, my_call, env_id, RNG_FOOD, 0).w[0];
+        }
         // what lane j keeps of step t0 + j: its move entry, whether it ate, self collision | edge collision << 1
         int my_rec = 0, my_ate = 0, my_fl = 0;
         {   // re-base the clocks so that they cannot overflow however long the tape is
@@ -1436,12 +1459,16 @@ __global__ __launch_bounds__(256) void rollout_s9_kernel(StepArgs p)
             if (__builtin_expect((((body | XF) >> (c & 63)) & 1) != 0, 0)) {
                 if (c == foodc) {                    // :270-282: K-th free interior cell in row-major order
                     my_ate = keep_in_lane(my_ate, 1, lane_j);
-                    const u64 fr = ~(occ | RING);
-                    const int n_free = popc64(fr);
-                    foodc = -1;
-                    if (n_free > 0) {
-                        const int K = (int)mulhi_range((u32)lane_value(my_food, j), (u32)n_free);
-                        foodc = first_bit(lane_mask((int)((fr >> lane) & 1) & (int)(rank_below(fr) == K)));
+                    if constexpr (INJ) {
+                        foodc = lane_value(my_food, j);
+                    } else {
+                        const u64 fr = ~(occ | RING);
+                        const int n_free = popc64(fr);
+                        foodc = -1;
+                        if (n_free > 0) {
+                            const int K = (int)mulhi_range((u32)lane_value(my_food, j), (u32)n_free);
+                            foodc = first_bit(lane_mask((int)((fr >> lane) & 1) & (int)(rank_below(fr) == K)));
+                        }
                     }
                     XF = RING | (foodc >= 0 ? 1ull << foodc : 0);
                 }
@@ -1494,7 +1521,7 @@ __global__ __launch_bounds__(256) void rollout_s9_kernel(StepArgs p)
                 const int ra = lane_value(my_reset.a, j), rb = lane_value(my_reset.b, j);
                 o16 = (ra & 3) << 4;
                 foodc = ra >> 2;
-                XF = RING | (1ull << foodc);
+                XF = INJ ? (RING | (foodc >= 0 ? 1ull << foodc : 0)) : (RING | (1ull << foodc));
                 c = rb & 127;
                 const int sc = (rb >> 7) & 127, tc = rb >> 14;
                 ex = lane == tc ? T + 1 : 0; ex = lane == sc ? T + 2 : ex; ex = lane == c ? T + 3 : ex;
@@ -1627,6 +1654,15 @@ static hipError_t launch_one(Kind kind, const StepArgs &p, dim3 grid, dim3 block
         }
         if constexpr (SNAKE && CPL == 2) {
             const bool rng_mode = p.inject_food == nullptr && p.inject_reset == nullptr;
+            if (p.inject_food != nullptr && p.inject_reset != nullptr && p.S == 9 &&
+                ((p.obs_mode == WURM_OBS_PARTIAL && p.obs_n <= 3) || p.obs_mode == WURM_OBS_NONE)) {
+                // recorded outcomes through the headline kernel itself
+                if (p.obs_mode == WURM_OBS_NONE)
+                    hipLaunchKernelGGL((rollout_s9_kernel<WURM_OBS_NONE, true>), grid, block, lds, st, p);
+                else
+                    hipLaunchKernelGGL((rollout_s9_kernel<WURM_OBS_PARTIAL, true>), grid, block, lds, st, p);
+                break;
+            }
             if (rng_mode && p.S >= 9 && ((p.obs_mode == WURM_OBS_PARTIAL && p.obs_n <= 3) || p.obs_mode == WURM_OBS_NONE)) {
                 if (p.S == 9 && p.obs_mode == WURM_OBS_NONE)
                     hipLaunchKernelGGL((rollout_s9_kernel<WURM_OBS_NONE>), grid, block, lds, st, p);
