@@ -40,14 +40,14 @@ def total(t):
 
 
 detail = {
-    'rollout_512x9_chunk1024': traffic('void wurm::rollout_s9_kernel<4>', 32768),
-    'rollout_8192x9_chunk128': traffic('void wurm::rollout_s9_kernel<4>', 524288),
+    'rollout_512x9_chunk1024': traffic('void wurm::rollout_s9_kernel<4', 32768),
+    'rollout_8192x9_chunk128': traffic('void wurm::rollout_s9_kernel<4', 524288),
     'rollout_cfg5_8192x36_default_chunk16': traffic('void wurm::(anonymous namespace)::grid_rollout_kernel<true>', 524288),
-    'multi_rollout_cfg4_4096x25_k4_full_chunk16': traffic('wurm::multi_rollout_kernel', 262144),
+    'multi_rollout_cfg4_4096x25_k4_full_chunk16': traffic('void wurm::multi_rollout_kernel<true>', 524288),
     'fused_step_512x9_partial2': traffic('void wurm::fused_step_kernel<2, true>', 32768),
     'fused_step_8192x9_partial2': traffic('void wurm::fused_step_kernel<2, true>', 524288),
     'fused_step_65536x9_partial2': traffic('void wurm::fused_step_kernel<2, true>', 4194304),
-    'fused_step_8192x36_default': traffic('void wurm::fused_step_kernel<24, true>', 524288),
+    'grid_step_8192x36_default': traffic('void wurm::(anonymous namespace)::grid_step_kernel<true>', 524288),
 }
 out = {
     '_calibration': {
