@@ -334,7 +334,7 @@ def worker(args) -> int:
             line['extra'] = extra_measurements(device)
         if n_gpus == 1 and not args.no_cpu_baseline:
             try:
-                line['cpu_baseline'] = cpu_baseline(512 if args.workload == 'cfg2' else 512,
+                line['cpu_baseline'] = cpu_baseline(512,
                                                     budget_s=0.5 if args.dry_run else 5.0)
             except Exception as e:  # the baseline is a reported extra: never lose the bench line over it
                 line['cpu_baseline'] = {'error': repr(e)}

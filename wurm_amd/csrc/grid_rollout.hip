@@ -582,8 +582,10 @@ hipError_t launch_grid_rollout(const StepArgs &p_in, hipStream_t stream)
     // configs[4], 16-step launches, median of 5 x 20 launches): 0.38-0.39 ms at 8-12 waves per CU, 0.39-0.46 ms with all
     // 32 resident — with every wave resident the launch runs in lockstep (all probing, then all storing) more often.
     // The effect is at the edge of the run-to-run noise; 12 is kept, WURM_GRID_WAVES_PER_CU overrides it.
-    int waves_per_cu = 12;
-    if (const char *e = getenv("WURM_GRID_WAVES_PER_CU")) waves_per_cu = std::max(1, atoi(e)); // tuning knob
+    static const int waves_per_cu = [] { // tuning knob, read once
+        const char *e = getenv("WURM_GRID_WAVES_PER_CU");
+        return e ? std::max(1, atoi(e)) : 12;
+    }();
     const size_t per_wave_target = (160u * 1024u / (unsigned)waves_per_cu) & ~255u;
     lds = std::min<size_t>(std::max(lds, per_wave_target * wpb), 64u * 1024u);
     (void)hipGetLastError();

@@ -1623,8 +1623,10 @@ static hipError_t launch_one(Kind kind, const StepArgs &p, dim3 grid, dim3 block
     if constexpr (SNAKE && CPL >= 4) {
         // large batches of large grids: the LDS clock-grid step (grid_rollout.hip: 16-byte loads, 34 VGPRs), then the
         // generic kernel for the envs it could not take.  Small batches stay on one launch: they are latency-bound.
-        long long min_cells = 1ll << 20;
-        if (const char *e = getenv("WURM_GRID_STEP_MIN_CELLS")) min_cells = atoll(e); // tests force the path with 0
+        static const long long min_cells = [] { // read once; tests force the path with WURM_GRID_STEP_MIN_CELLS=0
+            const char *e = getenv("WURM_GRID_STEP_MIN_CELLS");
+            return e ? atoll(e) : (1ll << 20);
+        }();
         if ((kind == K_STEP || kind == K_FUSED) && grid_step_eligible(p) && p.N * (long long)p.S * p.S >= min_cells) {
             hipError_t err = launch_grid_step(p, st);
             if (err != hipSuccess) return err;
