@@ -384,7 +384,12 @@ def extra_measurements(device):
                                 % (', return_observations=False' if kw else '')}
     del env, actions
 
-    def rollout_case(key, make_env, shape_actions, A, chunk, reps, obs_bytes, what):
+    try:
+        traffic_detail = json.load(open(os.path.join(ROOT, 'profiles', 'hbm_traffic.json'))).get('detail', {})
+    except Exception:
+        traffic_detail = {}
+
+    def rollout_case(key, make_env, shape_actions, A, chunk, reps, obs_bytes, what, traffic_key=None):
         env = make_env()
         acts = torch.randint(A, (reps + 1,) + shape_actions(chunk), device=device, dtype=torch.int64)
         it = iter(range(reps + 1))
@@ -394,6 +399,10 @@ def extra_measurements(device):
         out[key] = {'value': eps, 'unit': 'env-steps/s', 'ms_per_launch': dt * 1e3, 'batch_steps_per_launch': chunk,
                     'obs_write_GBs': obs_bytes * eps / 1e9, 'obs_write_frac_of_hbm_peak': obs_bytes * eps / 1e9 / HBM_PEAK_GBS,
                     'what': what}
+        t = traffic_detail.get(traffic_key) if traffic_key else None
+        if t:  # rocprofv3 FETCH_SIZE + WRITE_SIZE of exactly this launch shape (profiles/hbm_traffic.json)
+            out[key]['traffic_bytes_per_launch'] = t['total_bytes']
+            out[key]['frac_real'] = t['total_bytes'] / dt / 1e9 / HBM_PEAK_GBS
 
     # (b) one GPU's share of configs[2] (8192 envs) and all of configs[2] on one GPU
     rollout_case('rollout_8192', lambda: SingleSnake(8192, SIZE, observation_mode=OBS_MODE, device=device, seed=0),
@@ -407,7 +416,8 @@ def extra_measurements(device):
                  lambda: SingleSnake(8192, 36, observation_mode='default', device=device, seed=0),
                  lambda c: (c, 8192), 4, 16, 6, 12 * 36 * 36,
                  'BASELINE configs[4]: SingleSnake 8192x36x36 default-RGB obs, fused rollout, 16 batch-steps per launch '
-                 '(the launch writes the 15 552 B observation per env-step; SURVEY byte model of an unfused pair: 41 511 B)')
+                 '(the launch writes the 15 552 B observation per env-step; SURVEY byte model of an unfused pair: 41 511 B)',
+                 traffic_key='rollout_cfg5_8192x36_default_chunk16')
     rollout_case('rollout_cfg5_8192x36_default_64steps',
                  lambda: SingleSnake(8192, 36, observation_mode='default', device=device, seed=0),
                  lambda c: (c, 8192), 4, 64, 4, 12 * 36 * 36,
@@ -421,7 +431,8 @@ def extra_measurements(device):
                  lambda c: (c, 4, 4096), 8, 16, 6, 12 * 4 * 25 * 25,
                  'BASELINE configs[3]: MultiSnake 4096x25x25, 4 agents, defaults, step+observe+reset(__all__) per '
                  'batch-step, fused rollout, 16 batch-steps per launch (30 000 B of observations per env-step; SURVEY byte '
-                 'model of an unfused pair: 75 160 B; reference torch-CPU: 3 280 env-steps/s)')
+                 'model of an unfused pair: 75 160 B; reference torch-CPU: 3 280 env-steps/s)',
+                 traffic_key='multi_rollout_cfg4_4096x25_k4_full_chunk16')
     # (e) the acting loop with the policy inside the env kernel: MLP 75->64->64->{4,1} + sampling
     from wurm_amd.agents import FeedforwardAgent, pack_policy_params
     N, T, reps = 512, 256, 8

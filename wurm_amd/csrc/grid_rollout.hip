@@ -370,7 +370,8 @@ __device__ __forceinline__ void grid_reset(const Grid &g, Snk &s, u64 seed, u64 
     const int S = g.S, lane = g.lane;
     wave_lds_sync();
     s.T = s.G; // every clock of the dead snake is <= G: the grid is empty without touching it
-    if (s.food >= 0 && lane == 0) g.ex[s.food] = 0;
+    // the old food marker becomes a dead clock (1 <= T), not 0: "not 0" keeps meaning "has held something since the load"
+    if (s.food >= 0 && lane == 0) g.ex[s.food] = 1;
     int sy, sx, d, fc = -1;
     Words w;
     w.w[0] = w.w[1] = w.w[2] = w.w[3] = 0;
@@ -428,6 +429,8 @@ __global__ __launch_bounds__(256) void grid_rollout_kernel(StepArgs p)
     const long long obs_stride = p.N * p.obs_elems;
     float *obs_t = p.obs + env * p.obs_elems;
     u64 call = p.call; // step t uses call0 + 2t, its reset call0 + 2t + 1
+    const int hc0 = s.hc, food0 = s.food; // what HBM holds: for the sparse write-back at the end
+    bool rebased = false;
 
     for (long long t0 = 0; t0 < p.T; t0 += 64) {
         const int nt = (int)min((long long)64, p.T - t0);
@@ -447,6 +450,7 @@ __global__ __launch_bounds__(256) void grid_rollout_kernel(StepArgs p)
             }
             s.G -= s.T;
             s.T = 0;
+            rebased = true; // dead cells were zeroed: "ex != 0" no longer marks every cell that ever held a value
             wave_lds_sync();
         }
 
@@ -473,9 +477,33 @@ __global__ __launch_bounds__(256) void grid_rollout_kernel(StepArgs p)
         }
     }
 
-    // ---- back to the reference layout (every done env was reset: the head is on the grid, inside the ring)
+    // ---- back to the reference layout (every done env was reset: the head is on the grid, inside the ring).
+    // Only what may differ from HBM is written: a cell whose clock is not 0 has held a body value or the food since the
+    // load (clocks and markers only ever overwrite each other; nothing is cleared to 0 but by a re-base), the head and
+    // food planes hold a single 1 each.  After a re-base that bookkeeping is gone and the state is stored whole.
     wave_lds_sync();
-    grid_observe<VEC>(g, view_of(s, s.L), envp, WURM_OBS_RAW, 0);
+    if (rebased) {
+        grid_observe<VEC>(g, view_of(s, s.L), envp, WURM_OBS_RAW, 0);
+        return;
+    }
+    const int C = g.C;
+    for (int it = 0; it < g.iters; ++it) {
+        const int c0 = it * 256 + 4 * lane;
+        const int4v e = read4(g.ex, c0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (e[j] != 0 && e[j] != EX_RING) envp[2 * C + c0 + j] = e[j] == EX_FOOD ? 0.0f : (float)max(e[j] - s.T, 0);
+    }
+    if (lane == 0) {
+        if (hc0 != s.hc) {
+            envp[C + hc0] = 0.0f;
+            envp[C + s.hc] = 1.0f;
+        }
+        if (food0 != s.food) {
+            if (food0 >= 0) envp[food0] = 0.0f;
+            if (s.food >= 0) envp[s.food] = 1.0f;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------- per-call
