@@ -906,7 +906,7 @@ __device__ __forceinline__ void multi_reset_grid(const Ctx &cx, const MultiArgs 
     const int C = cx.C, K = cx.K, lane = cx.lane;
     const bool snake = lane < K;
     if (rebuild) { // _create_envs (:996-1019)
-        for (int i = lane; i < K * C; i += 64) cx.body[i] = 0;
+        for (int i = lane; i < K * C; i += 64) cx.body[i] &= DIRTY; // value 0; a cell that ever held one stays marked
         for (int k = 0; k < cx.cpl; ++k) {
             int c = lane + 64 * k;
             if (c < C) { cx.food[c] = 0; cx.occ[c] = 0; cx.hmap[c] = 0; }
@@ -1104,7 +1104,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void m
     const long long agent = env * K + lane, KN = (long long)K * p.N;
     float *foodp = p.foods + env * C, *headp = p.heads + env * K * C, *bodyp = p.bodies + env * K * C;
 
-    load_env(cx, foodp, headp, bodyp);
+    const u64 fbits0 = load_env(cx, foodp, headp, bodyp);
     Snake sn;
     sn.hc = snake ? cx.hcell[lane] : -1;
     sn.L = snake ? cx.lmax[lane] : 0;
@@ -1113,6 +1113,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void m
     sn.boosted = false;
     load_colour(p, agent, snake, sn);
     bool col_dirty = false;
+    const int hc0 = sn.hc; // what HBM holds: for the sparse write-back at the end
 
     for (long long t = 0; t < p.T; ++t) {
         const u64 call = p.call + 2ull * (u64)t;
@@ -1184,7 +1185,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void m
         cx.hcell[lane] = sn.hc;
     }
     wave_lds_sync();
-    store_env(cx, foodp, headp, bodyp, 0, -1, sn.hc, true);
+    // only what may differ from HBM: body cells that have held a value since the load (DIRTY survives deletions, rebuilds
+    // and re-bases), the head cell of each snake, food cells that changed
+    store_env(cx, foodp, headp, bodyp, fbits0, hc0, sn.hc, false);
 }
 
 // check_consistency (:733-769) -> per-env bitmask
