@@ -452,14 +452,18 @@ __device__ __forceinline__ void observe_full(const Ctx &cx, const MultiArgs &p, 
     wave_lds_sync();
 }
 
-// 'full' observation of at most 8 snakes, agent-major.  With 4096 envs in flight the row-major order of observe_full
+// 'full' observation of at most 10 snakes (experiments/speeds.py runs 10), agent-major.  With 4096 envs in flight the row-major order of observe_full
 // means ~49 000 concurrent 256-byte write streams (every row of 64 cells touches all K agents' regions, megabytes
 // apart); a pure store kernel in that order reaches 3.6 TB/s, agent by agent — one contiguous 3 * S * S float region
 // at a time per wave — 4.8 TB/s (tools/microbench/store_pattern.hip).  So the class of every cell is first written to
 // LDS as a 16-bit code (K clock compares, head owner, food, border: once per cell), then each agent's three planes are
-// produced from the codes:   code = body mask of snakes 0..7 | (head owner + 1) << 8 | food << 14 | border << 15
+// produced from the codes (layout: SNAP_OWNER_SHIFT below).
 // (Also tried, measured, dropped: issuing these stores in four parts between the phases of the NEXT step, so that the
 // store queue would drain while the wave computes — no gain: the waves of a launch stall on the store path together.)
+// 16-bit class code of a cell: body mask of snakes 0..9 | (head owner + 1) << 10 | food << 14 | border << 15
+constexpr int SNAP_OWNER_SHIFT = 10;
+constexpr int SNAP_MAX_SNAKES = 10; // 10 mask bits, and owner + 1 <= 11 fits the 4 owner bits
+
 // class code of every cell of the env in LDS -> snap[] (executed by the wave that owns the env's state)
 __device__ __forceinline__ void snap_write(const Ctx &cx, int hc, unsigned short *snap)
 {
@@ -473,7 +477,7 @@ __device__ __forceinline__ void snap_write(const Ctx &cx, int hc, unsigned short
             const bool edge = y == 0 || x == 0 || y == S - 1 || x == S - 1;
             u32 v = 0;
             for (int s = 0; s < K; ++s) v |= (u32)((int)(cx.body[s * C + c] & VMASK) > cx.tclk[s]) << s;
-            v |= (u32)cx.hmap[c] << 8;
+            v |= (u32)cx.hmap[c] << SNAP_OWNER_SHIFT;
             v |= (u32)(cx.food[c] != 0) << 14;
             v |= (u32)edge << 15;
             snap[c] = (unsigned short)v;
@@ -497,8 +501,8 @@ __device__ __forceinline__ void snap_emit(const Ctx &cx, const MultiArgs &p, flo
             if (c < C) {
                 const u32 v = (u32)snap[c];
                 const bool edge = (v >> 15) != 0, fd = ((v >> 14) & 1u) != 0;
-                const int ho = (int)((v >> 8) & 15u) - 1;
-                const u32 bm = v & 0xffu;
+                const int ho = (int)((v >> SNAP_OWNER_SHIFT) & 15u) - 1;
+                const u32 bm = v & ((1u << SNAP_OWNER_SHIFT) - 1u);
                 const bool snake_here = !edge && (ho >= 0 || bm != 0);
                 // border (0,0,0), somebody's head (0,0,192), somebody's body (0,0,96), food (255,0,0), background white
                 float r = (edge || snake_here) ? 0.0f : 1.0f;
@@ -1069,7 +1073,7 @@ __global__ __launch_bounds__(256) void multi_observe_kernel(MultiArgs p)
 // per launch instead of four times per iteration; per iteration only the actions are read and the outputs written.
 //   actions (T,K,N);  out_f32 (T,3,K,N) = rewards, food, sizes;  out_u8 (T,4,K,N) = dones, boost, snake_collision,
 //   edge_collision;  all_done (T,N);  obs (T,K,N,elems).
-// TWO ('full' observations of at most 8 snakes): a workgroup is TWO waves for ONE env.  Wave 0 steps the env and leaves
+// TWO ('full' observations of at most 10 snakes): a workgroup is TWO waves for ONE env.  Wave 0 steps the env and leaves
 // the class codes of the stepped state in one of two LDS buffers; wave 1 turns the codes of step t into the ~120 stores
 // of its observation while wave 0 is already computing step t + 1; one s_barrier per step hands a buffer over.  The
 // transition (latency-bound LDS work) and the observation (store-bound) of a launch otherwise ADD UP — every wave is in
@@ -1285,9 +1289,9 @@ enum MKind { MK_STEP, MK_RESET, MK_OBSERVE, MK_CHECK, MK_ROLLOUT };
 static int multi_launch(MKind kind, MultiArgs &p, void *stream)
 {
     if (p.N == 0) return WURM_OK;
-    // 'full' observations of at most 8 snakes go through a per-cell class code in LDS (observe_full_snap); rollouts
+    // 'full' observations of at most 10 snakes go through a per-cell class code in LDS (observe_full_snap); rollouts
     // double-buffer it between a stepping and a writing wave (multi_rollout_kernel<true>)
-    const bool snap = p.obs_mode == WURM_OBS_DEFAULT && p.K <= 8;
+    const bool snap = p.obs_mode == WURM_OBS_DEFAULT && p.K <= SNAP_MAX_SNAKES;
     const bool two = kind == MK_ROLLOUT && snap && p.T > 1;
     const int lds = multi_layout(p, p.obs_mode == WURM_OBS_PARTIAL, snap ? (two ? 2 : 1) : 0);
     if (lds > 65536) return WURM_ERR_UNSUPPORTED;
