@@ -300,6 +300,20 @@ typedef struct wurm_multi_call {
  * observation) / wurm_multi_step pair with the same counters.  pre_done = NULL: plain wurm_multi_step. */
 int wurm_multi_step_reset(const wurm_multi_call *c, void *stream);
 
+/* wurm_multi_step_reset for a host loop that keeps ONE call block alive (state pointers, sizes, seed, configuration,
+ * all_done_copy) and hands over only what changes from step to step; the output pointers of the block are filled from
+ * two packed buffers (so that the Python class allocates twice per step, not six times, and unbinds them into the
+ * per-agent dicts of multi_snake.py:701-729):
+ *   out_f32 (6*K*N floats): [0,KN) rewards, [KN,2KN) food_consumed, [2KN,3KN) sizes, env-major [env*K + i];
+ *                           then the same three agent-major, (3,K,N), [i*N + env]
+ *   out_u8 (7*K*N + N bytes): boost_this_step, snake_collision, edge_collision env-major; then agent-major (4,K,N)
+ *                           dones, boost, snake_collision, edge_collision; then all_done (N)
+ *   apply_pending != 0: the postponed reset with pre_done = c->all_done_copy (the previous step's all_done) and
+ *                           counter pre_call goes in front of the step.
+ * c->inject / c->pre_inject are used as they stand.  Bit-identical to wurm_multi_step_reset on the same pointers. */
+int wurm_multi_step_packed(wurm_multi_call *c, float *out_f32, uint8_t *out_u8, float *obs, const int64_t *actions,
+                           uint64_t call, int apply_pending, uint64_t pre_call, void *stream);
+
 /* MultiSnake.reset (multi_snake.py:771-836): envs flagged in done_env (N bytes) are rebuilt (_create_envs
  * :996-1019: K snakes placed one after another on free cells away from everything, one food); colours of
  * snakes that are still dead are re-rolled (colour_random); respawn_any: the first dead snake of every env

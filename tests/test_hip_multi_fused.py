@@ -89,13 +89,28 @@ def test_class_loop_equals_oracle_loop(lazy, cfg_name, mode):
     check_state('fresh')
     for t in range(T):
         a = torch.randint(8, (K, N), generator=g)
-        obs, rew, dones, info = env.step({f'agent_{i}': a[i].cuda() for i in range(K)})
+        if t % 2:           # separate tensors (stacked by the class) / rows of one tensor (used where they lie)
+            obs, rew, dones, info = env.step({f'agent_{i}': a[i].cuda() for i in range(K)})
+        else:
+            ac = a.cuda()
+            obs, rew, dones, info = env.step({f'agent_{i}': ac[i] for i in range(K)})
         r = o.multi_step(st, a.numpy(), cfg, mode)
         for i in range(K):
             _same(obs[f'agent_{i}'].cpu().numpy(), r['obs'][i], f'obs {i} t={t}')
             _same(rew[f'agent_{i}'].cpu().numpy(), r['rewards'].reshape(N, K)[:, i], f'reward {i} t={t}')
             _same(dones[f'agent_{i}'].cpu().numpy().astype(np.uint8), st['dones'].reshape(N, K)[:, i], f'done {i} t={t}')
             _same(info[f'size_{i}'].cpu().numpy(), r['size'].reshape(N, K)[:, i], f'size {i} t={t}')
+            _same(info[f'food_{i}'].cpu().numpy(), r['food'].reshape(N, K)[:, i], f'food {i} t={t}')
+            _same(info[f'snake_collision_{i}'].cpu().numpy().astype(np.uint8), r['snake_collision'].reshape(N, K)[:, i],
+                  f'snake collision {i} t={t}')
+            _same(info[f'edge_collision_{i}'].cpu().numpy().astype(np.uint8), r['edge_collision'].reshape(N, K)[:, i],
+                  f'edge collision {i} t={t}')
+            _same(info[f'boost_{i}'].cpu().numpy().astype(np.uint8), st['boost_this_step'].reshape(N, K)[:, i],
+                  f'boost {i} t={t}')
+        assert set(info) == {f'{k}_{i}' for k in ('snake_collision', 'edge_collision', 'food', 'boost', 'size')
+                             for i in range(K)}                                # the reference's keys (:485-487, :661-729)
+        _same(env.rewards.cpu().numpy(), r['rewards'], f'env.rewards t={t}')     # env-major attributes (:104-105)
+        _same(env.boost_this_step.cpu().numpy().astype(np.uint8), st['boost_this_step'], f'env.boost_this_step t={t}')
         _same(dones['__all__'].cpu().numpy().astype(np.uint8), r['all_done'], f'all_done t={t}')
         k = t % 6
         if k == 4:          # the reference's default: the reset returns observations (eager)

@@ -22,7 +22,7 @@ SYMBOLS = [
     'wurm_single_step', 'wurm_single_reset', 'wurm_single_observe', 'wurm_single_rollout', 'wurm_single_check',
     'wurm_single_step_reset', 'wurm_grid_step_reset', 'wurm_single_step_slot', 'wurm_grid_step_slot',
     'wurm_grid_step', 'wurm_grid_reset', 'wurm_grid_observe', 'wurm_grid_rollout',
-    'wurm_multi_obs_elems', 'wurm_multi_step', 'wurm_multi_step_reset', 'wurm_multi_reset', 'wurm_multi_observe', 'wurm_multi_check',
+    'wurm_multi_obs_elems', 'wurm_multi_step', 'wurm_multi_step_reset', 'wurm_multi_step_packed', 'wurm_multi_reset', 'wurm_multi_observe', 'wurm_multi_check',
     'wurm_multi_rollout',
     'wurm_multi_colours', 'wurm_orientations',
     'wurm_a2c_returns', 'wurm_a2c_returns_backward', 'wurm_single_stats', 'wurm_single_policy_rollout',
@@ -166,6 +166,21 @@ def step_slot_fn(name: str = 'wurm_single_step_slot'):
         except ImportError:
             fn = cfn
         _step_slot[name] = fn
+    return fn
+
+
+def multi_step_fn():
+    """wurm_multi_step_packed through the CPython shim when it is built, else the ctypes function (same arguments)."""
+    fn = _step_slot.get('wurm_multi_step_packed')
+    if fn is None:
+        cfn = lib().wurm_multi_step_packed
+        try:
+            import functools
+            from wurm_amd import _fastcall
+            fn = functools.partial(_fastcall.multi_step, ctypes.cast(cfn, ctypes.c_void_p).value)
+        except (ImportError, AttributeError):
+            fn = cfn
+        _step_slot['wurm_multi_step_packed'] = fn
     return fn
 
 

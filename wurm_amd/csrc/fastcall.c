@@ -1,4 +1,5 @@
-/* fastcall.c — a CPython shim for the one call that sits on the per-step path of the Python classes.
+/* fastcall.c — a CPython shim for the one call that sits on the per-step path of the Python classes
+ * (SingleSnake / SimpleGridworld: step_slot; MultiSnake: multi_step -> wurm_multi_step_packed).
  *
  * At 512 envs the loop of experiments/main.py:212-227 (`step(a); reset(done)` from Python) is bound by host time per
  * call, and a ctypes foreign call with ten arguments costs ~1.3 us of it; the same call through the CPython vectorcall
@@ -42,8 +43,40 @@ static PyObject *fast_step_slot(PyObject *self, PyObject *const *args, Py_ssize_
     return PyLong_FromLong(rc);
 }
 
+typedef int (*multi_step_fn)(void *call_block, float *out_f32, uint8_t *out_u8, float *obs, const int64_t *actions,
+                             uint64_t call, int apply_pending, uint64_t pre_call, void *stream);
+
+/* multi_step(function_addr, call_block_addr, out_f32, out_u8, obs, actions, call, apply_pending, pre_call, stream)
+ * -> int return code of wurm_multi_step_packed at function_addr */
+static PyObject *fast_multi_step(PyObject *self, PyObject *const *args, Py_ssize_t nargs)
+{
+    (void)self;
+    if (nargs != 10) {
+        PyErr_SetString(PyExc_TypeError, "multi_step takes exactly 10 arguments");
+        return NULL;
+    }
+    multi_step_fn fn = (multi_step_fn)PyLong_AsVoidPtr(args[0]);
+    void *blk = PyLong_AsVoidPtr(args[1]);
+    float *out_f32 = (float *)PyLong_AsVoidPtr(args[2]);
+    uint8_t *out_u8 = (uint8_t *)PyLong_AsVoidPtr(args[3]);
+    float *obs = (float *)PyLong_AsVoidPtr(args[4]);
+    const int64_t *actions = (const int64_t *)PyLong_AsVoidPtr(args[5]);
+    unsigned long long call = PyLong_AsUnsignedLongLong(args[6]);
+    int pending = PyObject_IsTrue(args[7]);
+    unsigned long long pre_call = PyLong_AsUnsignedLongLong(args[8]);
+    void *stream = PyLong_AsVoidPtr(args[9]);
+    if (PyErr_Occurred()) return NULL;
+    if (fn == NULL) {
+        PyErr_SetString(PyExc_RuntimeError, "wurm_amd._fastcall: null function address");
+        return NULL;
+    }
+    int rc = fn(blk, out_f32, out_u8, obs, actions, (uint64_t)call, pending, (uint64_t)pre_call, stream);
+    return PyLong_FromLong(rc);
+}
+
 static PyMethodDef fast_methods[] = {
     {"step_slot", (PyCFunction)(void (*)(void))fast_step_slot, METH_FASTCALL, "see fastcall.c"},
+    {"multi_step", (PyCFunction)(void (*)(void))fast_multi_step, METH_FASTCALL, "see fastcall.c"},
     {NULL, NULL, 0, NULL}};
 
 static struct PyModuleDef fast_module = {PyModuleDef_HEAD_INIT, "_fastcall", "per-step call shim (see fastcall.c)", -1,

@@ -1398,6 +1398,26 @@ int wurm_multi_step_reset(const wurm_multi_call *c, void *stream)
     return multi_launch(MK_STEP, p, stream);
 }
 
+int wurm_multi_step_packed(wurm_multi_call *c, float *out_f32, uint8_t *out_u8, float *obs, const int64_t *actions,
+                           uint64_t call, int apply_pending, uint64_t pre_call, void *stream)
+{
+    if (!c) return WURM_ERR_INVALID_ARG;
+    if (c->num_envs > 0 && (!out_f32 || !out_u8)) return WURM_ERR_INVALID_ARG;
+    if (apply_pending && !c->all_done_copy) return WURM_ERR_INVALID_ARG;
+    const long long KN = (long long)c->num_snakes * c->num_envs;
+    c->rewards = out_f32; c->food_consumed = out_f32 + KN; c->sizes = out_f32 + 2 * KN;
+    c->agent_major_f32 = out_f32 + 3 * KN;
+    c->boost_this_step = out_u8; c->snake_collision = out_u8 + KN; c->edge_collision = out_u8 + 2 * KN;
+    c->agent_major_u8 = out_u8 + 3 * KN;
+    c->all_done = out_u8 + 7 * KN;
+    c->obs = obs;
+    c->actions = actions;
+    c->call = call;
+    c->pre_done = apply_pending ? c->all_done_copy : nullptr;
+    c->pre_call = pre_call;
+    return wurm_multi_step_reset(c, stream);
+}
+
 int wurm_multi_reset(float *foods, float *heads, float *bodies, uint8_t *dones, int64_t *orientations,
                      int16_t *colours, const uint8_t *done_env, int32_t *status, const uint8_t *boost_this_step,
                      float *obs, int obs_mode, int obs_n, int64_t num_envs, int num_snakes, int size,

@@ -602,13 +602,8 @@ __global__ __launch_bounds__(256) void step_kernel(StepArgs p)
 // written whether or not the rebuilt state is stored (the deferred reset of the next launch recreates it from the
 // same counters).  p.done_copy (nullable): second copy of `done` in a buffer the caller cannot modify.
 template <int CPL, bool SNAKE>
-__global__ __launch_bounds__(256) void fused_step_kernel(StepArgs p)
+__device__ __forceinline__ void fused_step_env(const StepArgs &p, long long env, signed char *lds)
 {
-    const int wave = (int)(threadIdx.x >> 6), wpb = (int)(blockDim.x >> 6);
-    const long long env = xcd_block(blockIdx.x, gridDim.x) * wpb + wave;
-    if (env >= p.N) return;
-    if (p.only_flagged && uniform((int)p.done[env]) != (int)GRID_SKIPPED) return; // grid_step_kernel stepped this env
-    signed char *lds = wurm_lds + wave * p.lds_per_wave;
     const int NCH = SNAKE ? 3 : 2;
     const Geo g = make_geo<CPL>(p.S);
     float *envp = p.envs + env * NCH * g.C;
@@ -650,6 +645,20 @@ __global__ __launch_bounds__(256) void fused_step_kernel(StepArgs p)
     if (p.obs_after != nullptr && p.obs_mode != WURM_OBS_NONE)
         write_obs<CPL, SNAKE>(e, g, headcell, p.obs_after + env * p.obs_elems, p.obs_mode, p.obs_n, lds);
 }
+
+template <int CPL, bool SNAKE>
+__global__ __launch_bounds__(256) void fused_step_kernel(StepArgs p)
+{
+    const int wave = (int)(threadIdx.x >> 6), wpb = (int)(blockDim.x >> 6);
+    const long long env = xcd_block(blockIdx.x, gridDim.x) * wpb + wave;
+    if (env >= p.N) return;
+    if (p.only_flagged && uniform((int)p.done[env]) != (int)GRID_SKIPPED) return; // grid_step_kernel stepped this env
+    fused_step_env<CPL, SNAKE>(p, env, wurm_lds + wave * p.lds_per_wave);
+}
+
+} // namespace wurm
+#include "lane_step.hpp"
+namespace wurm {
 
 template <int CPL, bool SNAKE>
 __global__ __launch_bounds__(256) void reset_kernel(StepArgs p)
@@ -1636,6 +1645,16 @@ static hipError_t launch_one(Kind kind, const StepArgs &p, dim3 grid, dim3 block
             else hipLaunchKernelGGL((fused_step_kernel<CPL, SNAKE>), grid, block, lds, st, q);
             return hipGetLastError();
         }
+    }
+    if constexpr (SNAKE && CPL == 2) {
+        // large batches of small grids: one env per LANE (lane_step.hpp); envs outside its domain are stepped by the
+        // one-env-per-wave code inside the same launch
+        static const long long min_envs = [] { // read once; tests force the path with WURM_LANE_STEP_MIN_ENVS=0
+            const char *e = getenv("WURM_LANE_STEP_MIN_ENVS");
+            return e ? atoll(e) : 16384ll;
+        }();
+        if ((kind == K_STEP || kind == K_FUSED) && p.N >= min_envs && lane_step_eligible(p))
+            return launch_lane_step(p, st);
     }
     switch (kind) {
     case K_STEP: hipLaunchKernelGGL((step_kernel<CPL, SNAKE>), grid, block, lds, st, p); break;

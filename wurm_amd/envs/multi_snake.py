@@ -53,6 +53,7 @@ class _Flushing(object):
         if obj._pending:
             obj._flush()  # the reference applied the reset before this assignment; the other tensors still need it
         obj._last_fresh = False
+        obj._state_dirty = True  # step() re-validates the layout and re-reads the pointers
         setattr(obj, self.slot, value)
 
 
@@ -61,6 +62,8 @@ class MultiSnake(object):
 
     _pending = False
     _last_fresh = False
+    _state_dirty = True
+    _out_f = _out_b = _rewards_t = _boost_t = _mc_mode = None
     foods = _Flushing('foods')
     heads = _Flushing('heads')
     bodies = _Flushing('bodies')
@@ -210,6 +213,28 @@ class MultiSnake(object):
         self._lifetimes_touched = True
         self._env_lifetimes = value
 
+    @property
+    def rewards(self) -> torch.Tensor:
+        """reference :105/:478: (num_envs*num_snakes,) float, env-major — a view of the last step's output block"""
+        if self._rewards_t is None:
+            self._rewards_t = self._out_f.view(-1)[:self.num_envs * self.num_snakes]
+        return self._rewards_t
+
+    @rewards.setter
+    def rewards(self, value):
+        self._rewards_t = value
+
+    @property
+    def boost_this_step(self) -> torch.Tensor:
+        """reference :104: (num_envs*num_snakes,) env-major — a view of the last step's output block"""
+        if self._boost_t is None:
+            self._boost_t = self._out_b.view(-1)[:self.num_envs * self.num_snakes]
+        return self._boost_t
+
+    @boost_this_step.setter
+    def boost_this_step(self, value):
+        self._boost_t = value
+
     def _flush(self):
         """Applies the postponed reset(done) now, with the ordinary reset kernel and the counter it was given."""
         self._pending = False
@@ -330,18 +355,22 @@ class MultiSnake(object):
                 raise RuntimeError('Must have the same number of actions as environments.')
 
         N, K, S, dev = self.num_envs, self.num_snakes, self.size, self.device
-        # reference :492: stack in dict order -> (K, N); the kernel reads agent i's action of env e at [i*N + e]
-        stacked = torch.stack([v.reshape(N) for v in actions.values()]).to(device=dev, dtype=torch.long).contiguous()
+        # reference :492: stack in dict order -> (K, N); the kernel reads agent i's action of env e at [i*N + e].
+        # Rows of one (K, N) int64 tensor (e.g. `tape[t, i]`) are used where they lie.
+        vals = list(actions.values())
+        a0 = vals[0]
+        a_ptr = a0.data_ptr() if (a0.dtype is torch.long and a0.device == dev) else 0
+        if a_ptr:
+            row = 8 * N
+            for i, v in enumerate(vals):
+                if v.dtype is not torch.long or v.dim() != 1 or not v.is_contiguous() or v.data_ptr() != a_ptr + i * row:
+                    a_ptr = 0
+                    break
+        if not a_ptr:
+            vals = torch.stack([v.reshape(N) for v in vals]).to(device=dev, dtype=torch.long).contiguous()
+            a_ptr = vals.data_ptr()
         pending = self._pending
         self._pending = False  # consumed by this launch (the raw attributes below do not flush)
-        foods, heads, bodies, dones, orientations, colours, _ = self._state()
-        m, n, obs = self._obs_args(self.observation_mode)
-
-        fl = torch.empty((3, N * K), dtype=torch.float32, device=dev)   # rewards, food consumed, sizes (env-major)
-        bl = torch.empty((3, N * K), dtype=torch.bool, device=dev)      # boost_this_step, snake / edge collision
-        am_f = torch.empty((3, K, N), dtype=torch.float32, device=dev)  # agent-major: rewards, food, sizes
-        am_b = torch.empty((4, K, N), dtype=torch.bool, device=dev)     # agent-major: dones, boost, snake, edge
-        all_done = torch.empty(N, dtype=torch.bool, device=dev)
         c = self._mc
         if c is None:
             c = self._mc = _lib.MultiCall()
@@ -350,48 +379,65 @@ class MultiSnake(object):
             self._pend = torch.zeros(N, dtype=torch.uint8, device=dev)
             c.all_done_copy = self._pend.data_ptr()
             self._mc_addr = ctypes.addressof(c)
-        c.foods, c.heads, c.bodies = foods.data_ptr(), heads.data_ptr(), bodies.data_ptr()
-        c.dones, c.orientations, c.colours = dones.data_ptr(), orientations.data_ptr(), colours.data_ptr()
-        c.actions = stacked.data_ptr()
-        p_fl, p_bl, nk = fl.data_ptr(), bl.data_ptr(), N * K
-        c.rewards, c.food_consumed, c.sizes = p_fl, p_fl + 4 * nk, p_fl + 8 * nk
-        c.boost_this_step, c.snake_collision, c.edge_collision = p_bl, p_bl + nk, p_bl + 2 * nk
-        c.all_done = all_done.data_ptr()
-        c.obs = _lib.ptr(obs)
-        c.agent_major_f32, c.agent_major_u8 = am_f.data_ptr(), am_b.data_ptr()
-        c.obs_mode, c.obs_n = m, n
-        c.cfg = self._cfg()
+            self._mc_cfg = None
+            self._mc_fn = _lib.multi_step_fn()
+            self._get_device, self._get_stream = _lib.accessors()
+            ks = [str(i) for i in range(K)]
+            self._keys = tuple([p + k for k in ks] for p in ('agent_', 'snake_collision_', 'edge_collision_', 'food_',
+                                                             'boost_', 'size_'))
+        if self._state_dirty:
+            foods, heads, bodies, dones, orientations, colours, _ = self._state()
+            c.foods, c.heads, c.bodies = foods.data_ptr(), heads.data_ptr(), bodies.data_ptr()
+            c.dones, c.orientations, c.colours = dones.data_ptr(), orientations.data_ptr(), colours.data_ptr()
+            self._state_dirty = False
+        mode = self.observation_mode
+        if mode != self._mc_mode:
+            c.obs_mode, c.obs_n, o = self._obs_args(mode)
+            self._obs_shape, self._mc_mode = tuple(o.shape), mode
+        obs = torch.empty(self._obs_shape, dtype=torch.float32, device=dev)
+        cfg = self._cfg()
+        if cfg is not self._mc_cfg:
+            c.cfg = self._mc_cfg = cfg
+
+        # packed outputs (include/wurm_hip.h wurm_multi_step_packed): env-major blocks first, then agent-major rows
+        of = torch.empty((6 * K, N), dtype=torch.float32, device=dev)
+        ob = torch.empty((7 * K + 1, N), dtype=torch.bool, device=dev)
         call = self._call
         self._call = call + 1
-        c.call = call
-        if pending:
-            c.pre_done, c.pre_call = c.all_done_copy, self._pend_call
+        idx = dev.index
+        if self._get_device() != idx:  # a process driving several GPUs has another device current
+            rc = _lib.call(idx, self._mc_fn, self._mc_addr, of.data_ptr(), ob.data_ptr(), obs.data_ptr(), a_ptr, call,
+                           pending, self._pend_call, _lib.stream_ptr(idx))
         else:
-            c.pre_done = None
-        rc = _lib.call(dev.index, _lib.lib().wurm_multi_step_reset, self._mc_addr, _lib.stream_ptr(dev.index))
-        _lib.check(rc, 'MultiSnake.step')
+            rc = self._mc_fn(self._mc_addr, of.data_ptr(), ob.data_ptr(), obs.data_ptr(), a_ptr, call, pending,
+                             self._pend_call, self._get_stream(idx))
+        if rc:
+            _lib.check(rc, 'MultiSnake.step')
 
-        self.boost_this_step = bl[0]
-        self.rewards = fl[0]
+        self._out_f, self._out_b = of, ob          # env.rewards / env.boost_this_step are views of these, made on demand
+        self._rewards_t = self._boost_t = None
 
         # reference :701-729 — per-agent dicts; the kernel wrote agent-major rows, so these are plain views
-        agents = range(K)
-        dones_out = {f'agent_{i}': am_b[0, i] for i in agents}
+        rf, rb = of.unbind(0), ob.unbind(0)
+        k_agent, k_snake, k_edge, k_food, k_boost, k_size = self._keys
+        K3, K4, K5, K6, K7 = 3 * K, 4 * K, 5 * K, 6 * K, 7 * K
+        all_done = rb[K7]
+        dones_out = dict(zip(k_agent, rb[K3:K4]))
         if self._lifetimes_touched:
             all_done = all_done | (self._env_lifetimes > self.max_env_lifetime)  # :703-705
         dones_out['__all__'] = all_done
-        rewards = {f'agent_{i}': am_f[0, i] for i in agents}
+        rewards = dict(zip(k_agent, rf[K3:K4]))
 
-        self.info = {}
-        self.info.update({f'snake_collision_{i}': am_b[2, i] for i in agents})
-        self.info.update({f'edge_collision_{i}': am_b[3, i] for i in agents})
-        self.info.update({f'food_{i}': am_f[1, i] for i in agents})
-        self.info.update({f'boost_{i}': am_b[1, i] for i in agents})
-        self.info.update({f'size_{i}': am_f[2, i] for i in agents})
+        info = dict(zip(k_snake, rb[K5:K6]))
+        info.update(zip(k_edge, rb[K6:K7]))
+        info.update(zip(k_food, rf[K4:K5]))
+        info.update(zip(k_boost, rb[K4:K5]))
+        info.update(zip(k_size, rf[K5:K6]))
+        self.info = info
 
         self._last_all_done, self._last_version = all_done, all_done._version
         self._last_fresh = not self._lifetimes_touched
-        return self._obs_dict(obs), rewards, dones_out, self.info
+        return OrderedDict(zip(k_agent, obs.unbind(0))), rewards, dones_out, info
 
     # ------------------------------------------------------------------ fused multi-step loop (extension)
 
