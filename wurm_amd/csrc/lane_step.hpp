@@ -1,17 +1,19 @@
 // lane_step.hpp — the per-call SingleSnake step for LARGE batches of SMALL grids: ONE ENV PER LANE.
 //
 // fused_step_kernel<2> (one env per wave) spends 311 VALU + 310 SALU instructions per env at 9 x 9 and is issue bound:
-// 65 536 envs take ~49 us where their 93 MB of traffic need ~20 us (profiles/, DESIGN §7).  Almost all of those
-// instructions are per-env scalars computed by a whole wave.  Here a wave owns 64 CONSECUTIVE envs and works in two
-// alternating shapes:
-//   * cooperative, lanes = consecutive dwords of the 64-env block: the state (64 x 3 x S x S floats, one contiguous
-//     run) is read with 16-byte loads and the few non-zero elements are scattered into a per-env summary in LDS (head
+// 65 536 envs take ~49 us where their 93 MB of traffic need ~20 us (profiles/, DESIGN §4.8).  Almost all of those
+// instructions are per-env scalars computed by a whole wave.  Here a wave owns EPW = 16 CONSECUTIVE envs and works in
+// two alternating shapes:
+//   * cooperative, lanes = (env, cell) pairs of the block: the state (EPW x 3 x S x S floats, one contiguous run) is
+//     read with coalesced dword loads and the few non-zero elements are scattered into a per-env summary in LDS (head
 //     cell, food cell, position of every body value, a bit set of the body values present); the observation crops
-//     (64 x 3 x W x W floats, also one contiguous run) are produced the same way from per-env descriptors;
+//     (EPW x 3 x W x W floats, also one contiguous run) are produced from per-env descriptors by (env, window cell) pairs;
 //   * one env per lane: validation, orientation, move, eat / decay / grow, food respawn, reset draws — the code of
-//     small_step() with per-lane values, so its instructions are shared by 64 envs; the handful of cells that change
+//     small_step() with per-lane values, so its instructions are shared by EPW envs; the handful of cells that change
 //     (the body cells of a decaying snake, two head cells, the food) are written straight from the lanes, the per-env
 //     outputs (reward, done, flags, sanitised action) are coalesced stores.
+// EPW trades the per-wave cost of the per-lane phase against parallelism: the whole batch is resident at once, so the
+// launch takes as long as one wave (65 536 x 9 x 9: 64 envs per wave 82 us, 32: 34 us, 16: 29 us, 8: 31 us).
 // Domain: well-formed snakes (body values exactly 1..L once each, one head on L, at most one food) on 9 <= S <= 11
 // (S*S <= 128: occupancy is a 128-bit mask per lane), RNG mode, observation 'partial_n' or none, the contract of
 // fused_step_kernel without post_reset.  An env outside the domain is stepped by fused_step_env() — the one-env-per-wave
@@ -27,7 +29,7 @@ struct LaneArgs {
 };
 
 constexpr int LANE_VS = 132;  // bytes per env of the value -> cell table (33 dwords: lanes fall on distinct banks)
-constexpr int LANE_LOADS = 8; // 16-byte loads in flight per lane in the cooperative read
+constexpr int LANE_LOADS = 11; // (env, cell) pairs = 3 loads each in flight per lane in the cooperative read
 
 // per-wave LDS layout (bytes) for EPW envs per wave
 template <int EPW>
@@ -108,13 +110,13 @@ __device__ __forceinline__ LaneSnake lane_reset(u64 seed, u64 call, u64 env_id, 
 }
 
 // (2n+1)^2 crops of a block of envs, one contiguous run of nenv * 3 * W * W floats, from the descriptors in LDS
-template <int EPW>
+template <int EPW, int S>
 __device__ __forceinline__ void lane_observe(const LaneArgs &a, unsigned char *lds, int which, float *__restrict__ out,
                                              int nenv, int lane)
 {
     typedef LaneLds<EPW> Lds;
     const StepArgs &p = a.p;
-    const int S = p.S, n = p.obs_n, W = 2 * n + 1, W2 = W * W, E = 3 * W2;
+    const int n = p.obs_n, W = 2 * n + 1, W2 = W * W, E = 3 * W2;
     const float rcpW2 = 1.0f / (float)W2, rcpW = 1.0f / (float)W, rcpS = 1.0f / (float)S;
     const short *dh = (const short *)(lds + Lds::DESC + which * Lds::DESC_BYTES), *df = dh + EPW;
     const u64 *dB = (const u64 *)(dh + 2 * EPW);
@@ -146,7 +148,7 @@ __device__ __forceinline__ void lane_observe(const LaneArgs &a, unsigned char *l
 template <int CPL, bool SNAKE>
 __device__ __forceinline__ void fused_step_env(const StepArgs &p, long long env, signed char *lds);
 
-template <int EPW>
+template <int EPW, int S>
 __global__ __launch_bounds__(256) void lane_step_kernel(LaneArgs a)
 {
     typedef LaneLds<EPW> Lds;
@@ -156,7 +158,7 @@ __global__ __launch_bounds__(256) void lane_step_kernel(LaneArgs a)
     const long long env0 = ((long long)blockIdx.x * wpb + wave) * EPW;
     if (env0 >= p.N) return;
     unsigned char *lds = lane_lds + wave * Lds::BYTES;
-    const int S = p.S, C = S * S, C3 = 3 * C;
+    constexpr int C = S * S, C3 = 3 * C;
     const int nenv = (int)min((long long)EPW, p.N - env0);
     const long long env = env0 + lane;
     const bool mine = lane < nenv;
@@ -173,33 +175,35 @@ __global__ __launch_bounds__(256) void lane_step_kernel(LaneArgs a)
     {
         const float *base = p.envs + env0 * C3;
         const int pairs = nenv * C;
-        const float rcpC = 1.0f / (float)C;
+        int e = 0, cell = lane, idx = lane; // pair idx = e * C + cell; C > 63: a step of 64 wraps at most once
+        unsigned off = (unsigned)lane;      // e * C3 + cell
         for (int i0 = 0; i0 < pairs; i0 += 64 * LANE_LOADS) {
             float f[LANE_LOADS], h[LANE_LOADS], b[LANE_LOADS];
             int es[LANE_LOADS], cs[LANE_LOADS];
 #pragma unroll
-            for (int j = 0; j < LANE_LOADS; ++j) { // unconditional loads (index clamped), all in flight together
-                const int idx = min(i0 + lane + 64 * j, pairs - 1);
-                es[j] = div_size(idx, rcpC);
-                cs[j] = idx - es[j] * C;
-                const float *q = base + es[j] * C3 + cs[j];
-                f[j] = q[0];
-                h[j] = q[C];
-                b[j] = q[2 * C];
+            for (int j = 0; j < LANE_LOADS; ++j) { // unconditional loads (past the end: pair 0), all in flight together
+                es[j] = idx < pairs ? e : -1;
+                cs[j] = cell;
+                const unsigned o = idx < pairs ? off : 0u;
+                f[j] = base[o];
+                h[j] = base[o + C];
+                b[j] = base[o + 2 * C];
+                idx += 64; cell += 64; off += 64;
+                if (cell >= C) { cell -= C; ++e; off += 2 * C; }
             }
 #pragma unroll
             for (int j = 0; j < LANE_LOADS; ++j) {
-                if (i0 + lane + 64 * j >= pairs) continue;
-                const int e = es[j], cell = cs[j];
-                if (f[j] > 0.5f) { fpos[e] = (unsigned char)cell; atomicAdd(&stat[e], 1u << 16); }
-                if (h[j] > 0.5f) { hpos[e] = (unsigned char)cell; atomicAdd(&stat[e], 1u << 8); }
+                const int ej = es[j], cj = cs[j];
+                if (ej < 0) continue;
+                if (f[j] > 0.5f) { fpos[ej] = (unsigned char)cj; atomicAdd(&stat[ej], 1u << 16); }
+                if (h[j] > 0.5f) { hpos[ej] = (unsigned char)cj; atomicAdd(&stat[ej], 1u << 8); }
                 const int bi = __float2int_rn(b[j]); // body (single_snake.py:210): position of every value, values present
                 if (bi > 0 && bi < 128) {
-                    valpos[e * LANE_VS + bi] = (unsigned char)cell;
-                    atomicOr(&vm[(bi >> 5) * EPW + e], 1u << (bi & 31));
-                    atomicAdd(&stat[e], 1u);
+                    valpos[ej * LANE_VS + bi] = (unsigned char)cj;
+                    atomicOr(&vm[(bi >> 5) * EPW + ej], 1u << (bi & 31));
+                    atomicAdd(&stat[ej], 1u);
                 } else if (bi != 0) {
-                    atomicAdd(&stat[e], 1u << 24);
+                    atomicAdd(&stat[ej], 1u << 24);
                 }
             }
         }
@@ -238,7 +242,7 @@ __global__ __launch_bounds__(256) void lane_step_kernel(LaneArgs a)
     wave_lds_sync();
 
     // transition (small_step above, per lane)
-    const float rcpS = 1.0f / (float)S;
+    constexpr float rcpS = 1.0f / (float)S;
     long long act = 0;
     int nh = -1, grow = 0, dec = 0, fc_after = fc;
     bool EAT = false, SELFC = false, EDGEC = false, inside = false;
@@ -305,7 +309,7 @@ __global__ __launch_bounds__(256) void lane_step_kernel(LaneArgs a)
         const int s_nh = lane_value(nh, src), s_dec = lane_value(dec, src), s_grow = lane_value(grow, src);
         const int s_f = lane_value(fc_after, src);
         float *ep = p.envs + (env0 + src) * C3;
-        const float rcpC = 1.0f / (float)C;
+        constexpr float rcpC = 1.0f / (float)C;
         for (int i = lane; i < C3; i += 64) {
             const int ch = div_size(i, rcpC), cell = i - ch * C;
             float v;
@@ -346,8 +350,8 @@ __global__ __launch_bounds__(256) void lane_step_kernel(LaneArgs a)
             }
         }
         wave_lds_sync();
-        lane_observe<EPW>(a, lds, 0, p.obs + env0 * p.obs_elems, nenv, lane);
-        if (p.obs_after != nullptr) lane_observe<EPW>(a, lds, 1, p.obs_after + env0 * p.obs_elems, nenv, lane);
+        lane_observe<EPW, S>(a, lds, 0, p.obs + env0 * p.obs_elems, nenv, lane);
+        if (p.obs_after != nullptr) lane_observe<EPW, S>(a, lds, 1, p.obs_after + env0 * p.obs_elems, nenv, lane);
     }
 
     // ---- envs outside the domain: the one-env-per-wave code, which overwrites their crops and outputs
@@ -379,21 +383,15 @@ static hipError_t launch_lane_step(const StepArgs &p, hipStream_t stream)
             if (c < 64) a.int_lo |= 1ull << c;
             else a.int_hi |= 1ull << (c - 64);
         }
-    static const int epw = [] { // tuning knob, read once: envs per wave (16, 32 or 64)
-        const char *e = getenv("WURM_LANE_STEP_EPW");
-        return e ? atoi(e) : 16;
-    }();
+    constexpr int EPW = 16; // envs per wave; measured at 65 536 x 9 x 9: 8 -> 31 us, 16 -> 29 us, 32 -> 34 us, 64 -> 82 us
+    const int wpb = 4;
+    const long long waves = (p.N + EPW - 1) / EPW;
+    dim3 block(64 * wpb), grid((unsigned)((waves + wpb - 1) / wpb));
+    const size_t lds = (size_t)LaneLds<EPW>::BYTES * wpb;
     (void)hipGetLastError();
-    auto go = [&](auto kernel, int per_wave, int lds_bytes) {
-        const int wpb = 4;
-        const long long waves = (p.N + per_wave - 1) / per_wave;
-        dim3 block(64 * wpb), grid((unsigned)((waves + wpb - 1) / wpb));
-        hipLaunchKernelGGL(kernel, grid, block, (size_t)lds_bytes * wpb, stream, a);
-    };
-    if (epw == 64) go(lane_step_kernel<64>, 64, LaneLds<64>::BYTES);
-    else if (epw == 32) go(lane_step_kernel<32>, 32, LaneLds<32>::BYTES);
-    else if (epw == 8) go(lane_step_kernel<8>, 8, LaneLds<8>::BYTES);
-    else go(lane_step_kernel<16>, 16, LaneLds<16>::BYTES);
+    if (p.S == 9) hipLaunchKernelGGL((lane_step_kernel<EPW, 9>), grid, block, lds, stream, a);
+    else if (p.S == 10) hipLaunchKernelGGL((lane_step_kernel<EPW, 10>), grid, block, lds, stream, a);
+    else hipLaunchKernelGGL((lane_step_kernel<EPW, 11>), grid, block, lds, stream, a);
     return hipGetLastError();
 }
 

@@ -1194,35 +1194,50 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void m
     store_env(cx, foodp, headp, bodyp, fbits0, hc0, sn.hc, false);
 }
 
-// check_consistency (:733-769) -> per-env bitmask
+// check_consistency (:733-769) -> per-env bitmask.  Every plane is read once: the per-cell count of snakes (overlap test)
+// is kept in LDS, one byte per cell; a cell belongs to one lane, so plain read-modify-writes.
 __global__ __launch_bounds__(256) void multi_check_kernel(MultiArgs p)
 {
     const int wave = (int)(threadIdx.x >> 6), wpb = (int)(blockDim.x >> 6);
     const long long env = xcd_block(blockIdx.x, gridDim.x) * wpb + wave;
     if (env >= p.N) return;
     const int S = p.S, C = S * S, K = p.K, lane = (int)(threadIdx.x & 63u), cpl = (C + 63) >> 6;
+    unsigned char *cnt = wurm_multi_lds + (size_t)wave * p.lds_per_wave;
     const float *foodp = p.foods + env * C;
     uint32_t m = 0;
+    int badf = 0;
+    for (int k = 0; k < cpl; ++k) {
+        int c = lane + 64 * k;
+        if (c < C) {
+            const float f = foodp[c];
+            badf |= !(f == 0.0f || f == 1.0f);
+            cnt[c] = 0;
+        }
+    }
+    const bool bad_food = ballot(badf != 0) != 0;
+    bool any_alive = false;
     for (int s = 0; s < K; ++s) {
         const float *hp = p.heads + (env * K + s) * C, *bp = p.bodies + (env * K + s) * C;
         const bool dead = p.dones[env * K + s] != 0;
-        int badf = 0, hs = 0, bs = 0, bm = 0, hb = 0, hf = 0, nz = 0;
+        int hs = 0, bs = 0, bm = 0, hb = 0, hf = 0, nz = 0;
+#pragma unroll 4
         for (int k = 0; k < cpl; ++k) {
             int c = lane + 64 * k;
             if (c < C) {
-                float f = foodp[c], h = hp[c], b = bp[c];
-                int fi = __float2int_rn(f), hi = __float2int_rn(h), bi = __float2int_rn(b);
-                badf |= !(f == 0.0f || f == 1.0f);
-                hs += hi; bs += bi; hb += hi * bi; hf += hi * fi;
+                const float h = hp[c], b = bp[c];
+                const int hi = __float2int_rn(h), bi = __float2int_rn(b);
+                hs += hi; bs += bi; hb += hi * bi;
+                if (hi != 0) hf += hi * __float2int_rn(foodp[c]); // at the head cells only (one per snake)
                 bm = max(bm, bi);
                 nz |= (h != 0.0f) || (b != 0.0f);
+                if (b > 1e-6f) cnt[c] += 1;
             }
         }
         if (dead) {
             if (ballot(nz != 0)) m |= WURM_MCHK_DEAD_NONZERO;
             continue;
         }
-        if (ballot(badf != 0)) m |= WURM_CHK_FOOD_VALUE;
+        any_alive = true;
         hs = wave_sum_i32(hs); bs = wave_sum_i32(bs); hb = wave_sum_i32(hb); hf = wave_sum_i32(hf);
         bm = wave_max_i32(bm);
         if (hs != 1) m |= WURM_CHK_ONE_HEAD;
@@ -1232,14 +1247,11 @@ __global__ __launch_bounds__(256) void multi_check_kernel(MultiArgs p)
         if (!(bs >= 6)) m |= WURM_CHK_MIN_LENGTH;
         if (hf != 0) m |= WURM_CHK_HEAD_ON_FOOD;
     }
+    if (any_alive && bad_food) m |= WURM_CHK_FOOD_VALUE; // reported per living snake by the loop this replaces
     int over = 0;
     for (int k = 0; k < cpl; ++k) {
         int c = lane + 64 * k;
-        if (c < C) {
-            int cnt = 0;
-            for (int s = 0; s < K; ++s) cnt += p.bodies[(env * K + s) * C + c] > 1e-6f;
-            over |= cnt > 1;
-        }
+        if (c < C) over |= cnt[c] > 1;
     }
     if (ballot(over != 0)) m |= WURM_MCHK_OVERLAP;
     if (lane == 0) p.err[env] = m;
@@ -1293,7 +1305,8 @@ static int multi_launch(MKind kind, MultiArgs &p, void *stream)
     // double-buffer it between a stepping and a writing wave (multi_rollout_kernel<true>)
     const bool snap = p.obs_mode == WURM_OBS_DEFAULT && p.K <= SNAP_MAX_SNAKES;
     const bool two = kind == MK_ROLLOUT && snap && p.T > 1;
-    const int lds = multi_layout(p, p.obs_mode == WURM_OBS_PARTIAL, snap ? (two ? 2 : 1) : 0);
+    int lds = multi_layout(p, p.obs_mode == WURM_OBS_PARTIAL, snap ? (two ? 2 : 1) : 0);
+    if (kind == MK_CHECK) lds = p.lds_per_wave = (p.S * p.S + 15) & ~15; // the checker keeps one byte per cell
     if (lds > 65536) return WURM_ERR_UNSUPPORTED;
     // few envs: one wave per workgroup so that they spread over all 256 CUs; from 2048 envs on 4 waves per workgroup
     // (8 workgroups per CU either way; the observation stream of 4096 envs measured ~5 % faster this way)
@@ -1307,7 +1320,7 @@ static int multi_launch(MKind kind, MultiArgs &p, void *stream)
     }
     while (wpb > 1 && lds * wpb > 65536) wpb >>= 1;
     dim3 block(64 * wpb), grid((unsigned)((p.N + wpb - 1) / wpb));
-    size_t shmem = kind == MK_CHECK ? 0 : (size_t)lds * wpb;
+    size_t shmem = (size_t)lds * wpb;
     hipStream_t st = (hipStream_t)stream;
     (void)hipGetLastError();
     switch (kind) {
