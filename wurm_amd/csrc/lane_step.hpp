@@ -63,21 +63,6 @@ __device__ __forceinline__ bool mtest(const Mask128 &m, int c)
     return c < 64 ? (m.lo >> c) & 1 : (m.hi >> (c - 64)) & 1;
 }
 
-// index of the k-th (0-based) set bit of w; k < popc(w)
-__device__ __forceinline__ int nth_bit64(u64 w, int k)
-{
-    int pos = 0;
-    u32 x = (u32)w;
-    int c = __popc(x);
-    if (k >= c) { k -= c; pos = 32; x = (u32)(w >> 32); }
-#pragma unroll
-    for (int sh = 16; sh >= 1; sh >>= 1) {
-        c = __popc(x & ((1u << sh) - 1u));
-        if (k >= c) { k -= c; x >>= sh; pos += sh; }
-    }
-    return pos;
-}
-
 // the K-th free cell in row-major order, K = mulhi(word, n_free) (add_food above); -1 if nothing is free
 __device__ __forceinline__ int lane_pick_free(const Mask128 &fr, u32 word)
 {

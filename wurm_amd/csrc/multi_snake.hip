@@ -918,6 +918,28 @@ __device__ __forceinline__ void multi_reset_grid(const Ctx &cx, const MultiArgs 
         if (snake) cx.tclk[lane] = 0;
         wave_lds_sync();
         sn.hc = -1;
+        // RNG mode: the env is empty, so the occupancy is just the cells of the snakes placed so far — one 64-bit row
+        // mask per lane (lane r = row r) instead of the byte map: "3x3 neighbourhood empty" is a dilation (two shifts
+        // and the rows above / below), the count a popcount, the K-th free cell in row-major order a walk over the
+        // rows' counts.  Same cells as spawn_cells / count_bits / rank_select (measured: a rebuilt env took 52 000
+        // cycles of a 35 000-cycle step launch, and the launch waits for its slowest env).
+        const int S = cx.S;
+        u64 occ_row = 0;
+        auto pick = [&](u64 av, u32 word) -> int { // K-th set bit over the rows, K = mulhi(word, total)
+            const int cnt = popc64(av), n = wave_sum_i32(cnt);
+            if (n == 0) return -1;
+            int kth = (int)mulhi_range(word, (u32)n), r = 0;
+            for (; r < S - 1; ++r) {
+                const int c = lane_value(cnt, r);
+                if (kth < c) break;
+                kth -= c;
+            }
+            return r * S + nth_bit64((u64)lane_value64((long long)av, r), kth);
+        };
+        auto mark = [&](int cell) {
+            const int y = div_size(cell, cx.rcpS), x = cell - y * S;
+            if (lane == y) occ_row |= 1ull << x;
+        };
         for (int s = 0; s < K; ++s) { // _add_snake (:911-994), one snake after another
             int cell = -1, dnew = 0;
             if (p.has_rinj) {
@@ -926,13 +948,23 @@ __device__ __forceinline__ void multi_reset_grid(const Ctx &cx, const MultiArgs 
             } else {
                 Words w = rng_words(p.seed, call, env_id, RNG_SPAWN, (u32)s);
                 dnew = (int)(w.w[1] >> 30);
-                u64 av = spawn_cells(cx);
-                int n = count_bits(cx, av);
-                if (n > 0) cell = selected_cell(rank_select(cx, av, (int)mulhi_range(w.w[0], (u32)n)));
+                // available (:927-941): at least 2 from the border, nothing in the 3x3 neighbourhood
+                const u64 h = occ_row | (occ_row << 1) | (occ_row >> 1);
+                const u64 up = lane == 0 ? 0ull : (u64)__shfl_up((long long)h, 1);
+                const u64 dn = lane == 63 ? 0ull : (u64)__shfl_down((long long)h, 1);
+                const u64 cols = S >= 5 ? (((1ull << (S - 4)) - 1ull) << 2) : 0ull;
+                const u64 av = (lane >= 2 && lane <= S - 3) ? (~(h | up | dn) & cols) : 0ull;
+                cell = pick(av, w.w[0]);
             }
             cell = uniform(cell);
             if (cell < 0 && p.status && lane == 0) atomicAdd(p.status, 1); // the reference raises (:946-947)
             int h = place_snake(cx, s, cell, dnew);
+            if (cell >= 0 && !p.has_rinj) {
+                const int sy = div_size(cell, cx.rcpS), sx = cell - sy * S;
+                mark(cell);
+                mark((sy + tap_y(dnew)) * S + sx + tap_x(dnew));
+                mark((sy - tap_y(dnew)) * S + sx - tap_x(dnew));
+            }
             if (lane == s) {
                 sn.hc = h;
                 sn.L = h >= 0 ? 3 : 0;
@@ -944,13 +976,11 @@ __device__ __forceinline__ void multi_reset_grid(const Ctx &cx, const MultiArgs 
             if (p.has_rinj) {
                 int cell = p.rinj.create_food[offE + env];
                 if (cell >= 0 && cell < C && lane == 0) cx.food[cell] = 1;
-            } else {
-                u64 fr = free_cells(cx, sn.hc, 1);
-                int nf = count_bits(cx, fr);
-                if (nf > 0) {
-                    int k = rank_select(cx, fr, (int)mulhi_range(rng_words(p.seed, call, env_id, RNG_RESET, 0).w[3], (u32)nf));
-                    if (k >= 0) cx.food[lane + 64 * k] = 1;
-                }
+            } else { // free (:439-445): not on the border ring, nothing on it
+                const u64 cols = ((1ull << (S - 2)) - 1ull) << 1;
+                const u64 fr = (lane >= 1 && lane <= S - 2) ? (~occ_row & cols) : 0ull;
+                const int cell = pick(fr, rng_words(p.seed, call, env_id, RNG_RESET, 0).w[3]);
+                if (cell >= 0 && lane == 0) cx.food[cell] = 1;
             }
             wave_lds_sync();
         }

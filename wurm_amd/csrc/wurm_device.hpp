@@ -77,6 +77,21 @@ __device__ __forceinline__ int rank_below(u64 m)
     return (int)__builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
 }
 
+// index of the k-th (0-based) set bit of w; k < popc(w)
+__device__ __forceinline__ int nth_bit64(u64 w, int k)
+{
+    int pos = 0;
+    u32 x = (u32)w;
+    int c = __popc(x);
+    if (k >= c) { k -= c; pos = 32; x = (u32)(w >> 32); }
+#pragma unroll
+    for (int sh = 16; sh >= 1; sh >>= 1) {
+        c = __popc(x & ((1u << sh) - 1u));
+        if (k >= c) { k -= c; x >>= sh; pos += sh; }
+    }
+    return pos;
+}
+
 // DPP lane exchange inside a row of 16 lanes (VALU latency; no LDS round trip like ds_bpermute / __shfl).
 template <int CTRL>
 __device__ __forceinline__ int dpp_row(int v)
