@@ -384,6 +384,34 @@ def extra_measurements(device):
                                 % (', return_observations=False' if kw else '')}
     del env, actions
 
+    # (a') the same Python loop at BASELINE configs[2] whole (65 536 envs on one GPU: lane_step_kernel) and configs[3]
+    def per_call_case(key, env, step_args, reset_arg, T, what):
+        def it(t):
+            out_ = env.step(step_args(t))
+            env.reset(reset_arg(out_[2]), return_observations=False)
+        for t in range(10):
+            it(t)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for t in range(10, 10 + T):
+            it(t)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out[key] = {'value': env.num_envs * T / dt, 'unit': 'env-steps/s', 'us_per_batch_step': dt / T * 1e6, 'what': what}
+
+    N, T = 65536, 200
+    acts = torch.randint(4, (T + 10, N), device=device, dtype=torch.int64)
+    per_call_case('per_call_api_cfg3_65536', SingleSnake(N, SIZE, observation_mode=OBS_MODE, device=device, seed=0),
+                  lambda t: acts[t], lambda d: d, T,
+                  'BASELINE configs[2] whole on one GPU through `env.step(a); env.reset(d, return_observations=False)`')
+    N, K, T = 4096, 4, 100
+    acts = torch.randint(8, (T + 10, K, N), device=device, dtype=torch.int64)
+    keys = [f'agent_{i}' for i in range(K)]
+    per_call_case('per_call_api_cfg4_4096x25_k4', MultiSnake(N, K, 25, device=device, seed=0),
+                  lambda t: dict(zip(keys, acts[t].unbind(0))), lambda d: d['__all__'], T,
+                  "BASELINE configs[3] through `env.step(actions); env.reset(dones['__all__'], return_observations=False)`")
+    del acts
+
     try:
         traffic_detail = json.load(open(os.path.join(ROOT, 'profiles', 'hbm_traffic.json'))).get('detail', {})
     except Exception:

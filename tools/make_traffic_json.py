@@ -47,6 +47,8 @@ detail = {
     'fused_step_512x9_partial2': traffic('void wurm::fused_step_kernel<2, true>', 32768),
     'fused_step_8192x9_partial2': traffic('void wurm::fused_step_kernel<2, true>', 524288),
     'fused_step_65536x9_partial2': traffic('void wurm::fused_step_kernel<2, true>', 4194304),
+    'lane_step_65536x9_partial2': traffic('void wurm::lane_step_kernel<16, 9>', 262144),
+    'multi_step_cfg4_4096x25_k4_full': traffic('wurm::multi_step_kernel', 262144),
     'grid_step_8192x36_default': traffic('void wurm::(anonymous namespace)::grid_step_kernel<true>', 524288),
 }
 out = {

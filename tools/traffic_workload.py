@@ -6,7 +6,7 @@ widths must be calibrated in the kernel's own access pattern):
   * torch copy of 1 GiB        (16 B/lane streaming read + write)
   * wurm_single_check on a 1.02 GB state tensor (dword-per-lane coalesced reads — the env kernels' pattern)
 then the measured launches: rollouts (cfg2 512 envs, cfg3-share 8192 envs, cfg5 8192 x 36 x 36, cfg4 MultiSnake) and the
-per-call loop (one fused launch per iteration) at cfg2 / cfg3-share / cfg3 / cfg5."""
+per-call loop (one fused launch per iteration) at cfg2 / cfg3-share / cfg3 / cfg5 and MultiSnake cfg4."""
 import os
 import sys
 
@@ -61,4 +61,11 @@ for N, S, mode in ((512, 9, 'partial_2'), (8192, 9, 'partial_2'), (65536, 9, 'pa
         env.reset(d, return_observations=False)
     torch.cuda.synchronize()
     del env, actions
+# measured: the per-call MultiSnake loop at cfg4 (multi_step_kernel with the postponed reset in front)
+env = MultiSnake(4096, 4, 25, device=dev, seed=0)
+actions = torch.randint(8, (30, 4, 4096), device=dev, dtype=torch.int64)
+for t in range(30):
+    _, _, d, _ = env.step({f'agent_{i}': actions[t, i] for i in range(4)})
+    env.reset(d['__all__'], return_observations=False)
+torch.cuda.synchronize()
 print('traffic workload done')
