@@ -297,3 +297,31 @@ def test_rollout_equals_python_loop(api):
     for name in ('foods', 'heads', 'bodies', 'dones', 'orientations', 'agent_colours', 'boost_this_step'):
         assert torch.equal(getattr(a, name), getattr(b, name)), name
     b.check_consistency()
+
+
+def test_half_dtype(api):
+    """`dtype=torch.half` (reference :64): what the agents receive is half, computed as the reference's
+    `.to(dtype) / 255` (:281) would; the reference's own half path cannot step (the einsum at :640 mixes half and float
+    and raises), so the check is against the fp32 env: same trajectories, outputs equal to its outputs rounded once."""
+    kw = dict(num_envs=6, num_snakes=3, size=12, seed=5, observation_mode='partial_3', food_mode='random_rate')
+    a, b = api['MultiSnake'](**kw), api['MultiSnake'](dtype=torch.half, **kw)
+    assert b.foods.dtype == torch.float32  # the state stays fp32 (docstring)
+    tape = torch.randint(8, (12, 3, 6), device=DEVICE)
+    for t in range(8):
+        acts = {f'agent_{i}': tape[t, i] for i in range(3)}
+        oa, ra, da, ia = a.step(acts)
+        ob, rb, db, ib = b.step(acts)
+        for i in range(3):
+            assert ob[f'agent_{i}'].dtype == torch.half and torch.equal(ob[f'agent_{i}'], oa[f'agent_{i}'].half())
+            assert ib[f'size_{i}'].dtype == torch.half and torch.equal(ib[f'size_{i}'], ia[f'size_{i}'].half())
+            assert ib[f'food_{i}'].dtype == torch.half and torch.equal(ib[f'food_{i}'], ia[f'food_{i}'].half())
+            assert rb[f'agent_{i}'].dtype == torch.float32 and torch.equal(rb[f'agent_{i}'], ra[f'agent_{i}'])
+            assert torch.equal(db[f'agent_{i}'], da[f'agent_{i}'])
+        ba, bb = a.reset(da['__all__']), b.reset(db['__all__'])
+        assert all(bb[k].dtype == torch.half and torch.equal(bb[k], ba[k].half()) for k in ba)
+    ra, rb = a.rollout(tape[8:]), b.rollout(tape[8:])
+    assert rb['observations'].dtype == torch.half and torch.equal(rb['observations'], ra['observations'].half())
+    assert torch.equal(rb['size'], ra['size'].half()) and torch.equal(rb['rewards'], ra['rewards'])
+    assert torch.equal(a.bodies, b.bodies)
+    with pytest.raises(NotImplementedError):
+        api['MultiSnake'](num_envs=2, num_snakes=2, size=12, dtype=torch.double)

@@ -107,6 +107,7 @@ __device__ __forceinline__ void lane_observe(const LaneArgs &a, unsigned char *l
     const u64 *dB = (const u64 *)(dh + 2 * EPW);
     // lanes = (env, window cell) pairs: the cell is classified once and its three channel values are stored
     const int pairs = nenv * W2;
+    char *ob = (char *)out;
     for (int idx = lane; idx < pairs; idx += 64) {
         const int e = div_size(idx, rcpW2), w = idx - e * W2;
         const int wy = div_size(w, rcpW), wx = w - wy * W;
@@ -123,10 +124,10 @@ __device__ __forceinline__ void lane_observe(const LaneArgs &a, unsigned char *l
             else if ((bw >> (c & 63)) & 1) g = 127.0f / 255.0f;
             else r = g = b = 1.0f;
         }
-        float *o = out + e * E + w;
-        o[0] = r;
-        o[W2] = g;
-        o[2 * W2] = b;
+        const unsigned o = 4u * (unsigned)(e * E + w); // scalar base + 32-bit lane offset stores
+        *(float *)(ob + o) = r;
+        *(float *)(ob + o + 4u * (unsigned)W2) = g;
+        *(float *)(ob + o + 8u * (unsigned)W2) = b;
     }
 }
 
@@ -139,7 +140,8 @@ __global__ __launch_bounds__(256) void lane_step_kernel(LaneArgs a)
     typedef LaneLds<EPW> Lds;
     extern __shared__ __attribute__((aligned(16))) unsigned char lane_lds[];
     const StepArgs &p = a.p;
-    const int wave = (int)(threadIdx.x >> 6), wpb = (int)(blockDim.x >> 6), lane = (int)(threadIdx.x & 63u);
+    // the wave index through readfirstlane: per-wave pointers then live in SGPRs (scalar base + 32-bit lane offset loads)
+    const int wave = uniform((int)(threadIdx.x >> 6)), wpb = (int)(blockDim.x >> 6), lane = (int)(threadIdx.x & 63u);
     const long long env0 = ((long long)blockIdx.x * wpb + wave) * EPW;
     if (env0 >= p.N) return;
     unsigned char *lds = lane_lds + wave * Lds::BYTES;
@@ -158,10 +160,10 @@ __global__ __launch_bounds__(256) void lane_step_kernel(LaneArgs a)
 
     // ---- cooperative read: lanes = (env, cell) pairs of the block, three dwords each (food, head, body)
     {
-        const float *base = p.envs + env0 * C3;
+        const char *base = (const char *)(p.envs + env0 * C3);
         const int pairs = nenv * C;
         int e = 0, cell = lane, idx = lane; // pair idx = e * C + cell; C > 63: a step of 64 wraps at most once
-        unsigned off = (unsigned)lane;      // e * C3 + cell
+        unsigned off = 4u * (unsigned)lane; // byte offset of element e * C3 + cell (scalar base + 32-bit lane offset)
         for (int i0 = 0; i0 < pairs; i0 += 64 * LANE_LOADS) {
             float f[LANE_LOADS], h[LANE_LOADS], b[LANE_LOADS];
             int es[LANE_LOADS], cs[LANE_LOADS];
@@ -170,11 +172,12 @@ __global__ __launch_bounds__(256) void lane_step_kernel(LaneArgs a)
                 es[j] = idx < pairs ? e : -1;
                 cs[j] = cell;
                 const unsigned o = idx < pairs ? off : 0u;
-                f[j] = base[o];
-                h[j] = base[o + C];
-                b[j] = base[o + 2 * C];
-                idx += 64; cell += 64; off += 64;
-                if (cell >= C) { cell -= C; ++e; off += 2 * C; }
+                const char *q = base + o;
+                f[j] = *(const float *)q;
+                h[j] = *(const float *)(q + 4 * C);
+                b[j] = *(const float *)(q + 8 * C);
+                idx += 64; cell += 64; off += 256;
+                if (cell >= C) { cell -= C; ++e; off += 8 * C; }
             }
 #pragma unroll
             for (int j = 0; j < LANE_LOADS; ++j) {
@@ -251,7 +254,9 @@ __global__ __launch_bounds__(256) void lane_step_kernel(LaneArgs a)
         EDGEC = !(inside && ny >= 1 && ny <= S - 2 && nx >= 1 && nx <= S - 2);     // :290-295
     }
     // body: value v sits on valpos[v]; every one decays unless food was eaten, the new head cell grows
-    float *envp = p.envs + env * C3;
+    char *sb = (char *)(p.envs + env0 * C3);                 // scalar base of the block's state ...
+    const unsigned so = 4u * (unsigned)(lane * C3);           // ... + this lane's env (32-bit byte offsets)
+    auto put = [&](int elem, float v) { *(float *)(sb + (so + 4u * (unsigned)elem)) = v; };
     int under = 0;
     for (int v = 1; ballot(regular && v <= L) != 0; ++v) {
         if (regular && v <= L) {
@@ -259,23 +264,23 @@ __global__ __launch_bounds__(256) void lane_step_kernel(LaneArgs a)
             int nv = v - dec;
             if (cell == nh) { under = v; nv += grow; }
             if (nv > 0) mset(B, cell);
-            if (!pre && nv != v) envp[2 * C + cell] = (float)nv;
+            if (!pre && nv != v) put(2 * C + cell, (float)nv);
         }
     }
     if (regular) {
         SELFC = inside && under - dec > 0;                                         // :252 (after the decay)
         if (inside) mset(B, nh);
         if (!pre) {
-            if (inside && under == 0) envp[2 * C + nh] = (float)grow;
-            envp[C + hc] = 0.0f;
-            if (inside) envp[C + nh] = 1.0f;
+            if (inside && under == 0) put(2 * C + nh, (float)grow);
+            put(C + hc, 0.0f);
+            if (inside) put(C + nh, 1.0f);
         }
         if (EAT) {                                                                 // :270-282
             Mask128 fr = {interior.lo & ~B.lo, interior.hi & ~B.hi};
             fc_after = lane_pick_free(fr, rng_words(p.seed, p.call, env_id, RNG_FOOD, 0).w[0]);
             if (!pre) {
-                envp[nh] = 0.0f;
-                if (fc_after >= 0) envp[fc_after] = 1.0f;
+                put(nh, 0.0f);
+                if (fc_after >= 0) put(fc_after, 1.0f);
             }
         }
         const int done = SELFC | EDGEC;

@@ -9,8 +9,11 @@ reference's tests do, tests/test_multi_snake_env.py:21-47).  Dynamics attributes
 `boost_cost_prob`, `food_mode`, `food_rate`, `respawn_mode`, `reward_on_death`) are read at every call and may be
 changed after construction, as the reference allows.
 
-Deviations: see wurm_amd/envs/single_snake.py (bool masks, Philox RNG via `seed` / `env_offset`, GPU only); only
-`dtype=torch.float` is supported; a snake that finds no room during env creation stays dead instead of raising
+Deviations: see wurm_amd/envs/single_snake.py (bool masks, Philox RNG via `seed` / `env_offset`, GPU only);
+`dtype=torch.half` (reference :64, experiments/multiagent.py:124-129) is the type of what the env hands to the agents —
+observations, `info['food_i']`, `info['size_i']`, converted from the kernels' fp32 outputs (the same two roundings as
+the reference's `.to(dtype) / 255`, :281) — while the state tensors stay fp32 (every body value is an exact integer
+either way); a snake that finds no room during env creation stays dead instead of raising
 (the constructor checks and raises like the reference, `reset()` does not sync to check).
 
 Per-call path: `step` is one launch (wurm_multi_step_reset).  `reset(done, return_observations=False)` called with the very
@@ -115,9 +118,10 @@ class MultiSnake(object):
         self.on_death = on_death
         self.device = _lib.require_device(device)
         self.verbose = verbose
-        if dtype != torch.float:
-            raise NotImplementedError('wurm_amd.MultiSnake keeps its state in fp32 (dtype=torch.float) only')
+        if dtype not in (torch.float, torch.half):
+            raise NotImplementedError('wurm_amd.MultiSnake: dtype must be torch.float or torch.half')
         self.dtype = dtype
+        self._half = dtype == torch.half
         self.observation_mode = observation_mode
         if observation_mode.startswith('partial_'):
             self.observation_width = int(observation_mode.split('_')[1])
@@ -132,9 +136,9 @@ class MultiSnake(object):
             self.render_args = render_args
 
         N, K, S, dev = num_envs, num_snakes, size, self.device
-        self.foods = torch.zeros((N, 1, S, S), dtype=self.dtype, device=dev)
-        self.heads = torch.zeros((N * K, 1, S, S), dtype=self.dtype, device=dev)
-        self.bodies = torch.zeros((N * K, 1, S, S), dtype=self.dtype, device=dev)
+        self.foods = torch.zeros((N, 1, S, S), dtype=torch.float32, device=dev)    # fp32 whatever `dtype` (docstring)
+        self.heads = torch.zeros((N * K, 1, S, S), dtype=torch.float32, device=dev)
+        self.bodies = torch.zeros((N * K, 1, S, S), dtype=torch.float32, device=dev)
         self.dones = torch.zeros(N * K, dtype=torch.bool, device=dev)
         self.boost_this_step = torch.zeros(N * K, dtype=torch.bool, device=dev)
         self.rewards = torch.zeros(N * K, dtype=torch.float, device=dev)
@@ -287,6 +291,8 @@ class MultiSnake(object):
         return m, n, torch.empty(shape, dtype=torch.float32, device=self.device)
 
     def _obs_dict(self, obs: torch.Tensor) -> Dict[str, torch.Tensor]:
+        if self._half:
+            obs = obs.to(torch.half)
         return OrderedDict([(f'agent_{i}', o) for i, o in enumerate(obs.unbind(0))])
 
     # ------------------------------------------------------------------ colours / rendering (host side, torch ops)
@@ -430,9 +436,15 @@ class MultiSnake(object):
 
         info = dict(zip(k_snake, rb[K5:K6]))
         info.update(zip(k_edge, rb[K6:K7]))
-        info.update(zip(k_food, rf[K4:K5]))
+        if self._half:  # reference :477 / :724: food and size carry the env's dtype
+            rh = of[K4:].to(torch.half).unbind(0)
+            info.update(zip(k_food, rh[:K]))
+            info.update(zip(k_size, rh[K:]))
+            obs = obs.to(torch.half)
+        else:
+            info.update(zip(k_food, rf[K4:K5]))
+            info.update(zip(k_size, rf[K5:K6]))
         info.update(zip(k_boost, rb[K4:K5]))
-        info.update(zip(k_size, rf[K5:K6]))
         self.info = info
 
         self._last_all_done, self._last_version = all_done, all_done._version
@@ -474,7 +486,13 @@ class MultiSnake(object):
         if T > 0:
             self.rewards = out_f[-1, 0].t().reshape(-1)
         self._env_lifetimes.zero_()
-        return {'observations': obs, 'rewards': out_f[:, 0], 'food': out_f[:, 1], 'size': out_f[:, 2],
+        if self._half:
+            obs = obs.to(torch.half) if obs is not None else None
+            out_h = out_f[:, 1:].to(torch.half)
+            food, size = out_h[:, 0], out_h[:, 1]
+        else:
+            food, size = out_f[:, 1], out_f[:, 2]
+        return {'observations': obs, 'rewards': out_f[:, 0], 'food': food, 'size': size,
                 'dones': out_b[:, 0], 'boost': out_b[:, 1], 'snake_collision': out_b[:, 2],
                 'edge_collision': out_b[:, 3], 'all_done': all_done}
 
