@@ -281,6 +281,11 @@ typedef struct wurm_multi_call {
     uint8_t *all_done;                /* out (N) = dones['__all__']                                                    */
     uint8_t *all_done_copy;           /* nullable out (N): second copy of all_done                                     */
     float *obs;
+    float *obs_after;                 /* nullable out, shaped like obs: what wurm_multi_reset(done_env = all_done,
+                                         call = call + 1) would return — the observation of every agent after the
+                                         envs that just finished are rebuilt, dead snakes' colours re-rolled and
+                                         (respawn_any) one dead snake respawned.  Only written: that reset is NOT
+                                         applied to the state tensors (pass all_done_copy as the next pre_done)         */
     float *agent_major_f32;           /* nullable, as wurm_multi_step                                                  */
     uint8_t *agent_major_u8;
     const uint8_t *pre_done;          /* nullable in (N): wurm_multi_reset(done_env = pre_done, call = pre_call, no
@@ -303,7 +308,7 @@ int wurm_multi_step_reset(const wurm_multi_call *c, void *stream);
 /* wurm_multi_step_reset for a host loop that keeps ONE call block alive (state pointers, sizes, seed, configuration,
  * all_done_copy) and hands over only what changes from step to step; the output pointers of the block are filled from
  * two packed buffers (so that the Python class allocates twice per step, not six times, and unbinds them into the
- * per-agent dicts of multi_snake.py:701-729):
+ * per-agent dicts of multi_snake.py:701-729); obs_after (nullable) as in wurm_multi_call:
  *   out_f32 (6*K*N floats): [0,KN) rewards, [KN,2KN) food_consumed, [2KN,3KN) sizes, env-major [env*K + i];
  *                           then the same three agent-major, (3,K,N), [i*N + env]
  *   out_u8 (7*K*N + N bytes): boost_this_step, snake_collision, edge_collision env-major; then agent-major (4,K,N)
@@ -311,8 +316,8 @@ int wurm_multi_step_reset(const wurm_multi_call *c, void *stream);
  *   apply_pending != 0: the postponed reset with pre_done = c->all_done_copy (the previous step's all_done) and
  *                           counter pre_call goes in front of the step.
  * c->inject / c->pre_inject are used as they stand.  Bit-identical to wurm_multi_step_reset on the same pointers. */
-int wurm_multi_step_packed(wurm_multi_call *c, float *out_f32, uint8_t *out_u8, float *obs, const int64_t *actions,
-                           uint64_t call, int apply_pending, uint64_t pre_call, void *stream);
+int wurm_multi_step_packed(wurm_multi_call *c, float *out_f32, uint8_t *out_u8, float *obs, float *obs_after,
+                           const int64_t *actions, uint64_t call, int apply_pending, uint64_t pre_call, void *stream);
 
 /* MultiSnake.reset (multi_snake.py:771-836): envs flagged in done_env (N bytes) are rebuilt (_create_envs
  * :996-1019: K snakes placed one after another on free cells away from everything, one food); colours of

@@ -305,7 +305,7 @@ def multi_step(self, st, actions, cfg, mode, inject=None):
                 size=size.cpu().numpy(), all_done=all_done.cpu().numpy())
 
 
-def multi_step_reset(self, st, actions, cfg, mode, call, pre_done=None, pre_call=0):
+def multi_step_reset(self, st, actions, cfg, mode, call, pre_done=None, pre_call=0, want_obs_after=False):
     """wurm_multi_step_reset through the wurm_multi_call block: [wurm_multi_reset(pre_done, pre_call),] step(call)"""
     import ctypes
     N, _, S, _ = st['foods'].shape
@@ -315,6 +315,7 @@ def multi_step_reset(self, st, actions, cfg, mode, call, pre_done=None, pre_call
     act = self._t(np.ascontiguousarray(actions, np.int64))
     shape = _o.multi_obs_shape(mode, N, K, S)
     obs = self._empty(shape, torch.float32) if shape else None
+    obs_after = self._empty(shape, torch.float32) if (shape and want_obs_after) else None
     rewards, food, size = (self._empty((N * K,), torch.float32) for _ in range(3))
     sc, ec = (self._empty((N * K,), torch.uint8) for _ in range(2))
     all_done, copy = self._empty((N,), torch.uint8), self._empty((N,), torch.uint8)
@@ -326,6 +327,7 @@ def multi_step_reset(self, st, actions, cfg, mode, call, pre_done=None, pre_call
     c.actions, c.rewards, c.snake_collision, c.edge_collision = act.data_ptr(), rewards.data_ptr(), sc.data_ptr(), ec.data_ptr()
     c.food_consumed, c.sizes, c.all_done, c.all_done_copy = food.data_ptr(), size.data_ptr(), all_done.data_ptr(), copy.data_ptr()
     c.obs, c.agent_major_f32, c.agent_major_u8 = _lib.ptr(obs), am_f.data_ptr(), am_b.data_ptr()
+    c.obs_after = _lib.ptr(obs_after)
     c.pre_done = _lib.ptr(pd)
     c.num_envs, c.env_offset, c.seed, c.call, c.pre_call = N, self.env_offset, _lib.u64(self.seed), _lib.u64(call), _lib.u64(pre_call)
     c.num_snakes, c.size, c.obs_mode, c.obs_n = K, S, m, n
@@ -337,7 +339,8 @@ def multi_step_reset(self, st, actions, cfg, mode, call, pre_done=None, pre_call
     assert torch.equal(copy, all_done), 'all_done_copy != all_done'
     return dict(obs=obs.cpu().numpy() if obs is not None else None, rewards=rewards.cpu().numpy(),
                 snake_collision=sc.cpu().numpy(), edge_collision=ec.cpu().numpy(), food=food.cpu().numpy(),
-                size=size.cpu().numpy(), all_done=all_done.cpu().numpy())
+                size=size.cpu().numpy(), all_done=all_done.cpu().numpy(),
+                **({'obs_after': obs_after.cpu().numpy()} if obs_after is not None else {}))
 
 
 def multi_reset(self, st, done_env, cfg, inject=None, mode=None):

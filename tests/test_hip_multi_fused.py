@@ -44,10 +44,15 @@ def test_postponed_reset_in_front_of_the_step(hip, N, K, S, T, mode, cfg):
             o.multi_reset(so, prev, cfg)
         o.call = call
         ro = o.multi_step(so, a, cfg, mode)
-        rh = h.multi_step_reset(sh, a, cfg, mode, call=call, pre_done=prev, pre_call=prev_call)
+        rh = h.multi_step_reset(sh, a, cfg, mode, call=call, pre_done=prev, pre_call=prev_call, want_obs_after=(t % 3 != 2))
         _same_state(so, sh, f'state t={t}')
         for k in ro:
             _same(ro[k], rh[k], f'{k} t={t}')
+        if 'obs_after' in rh:  # what reset(all_done) with the next counter returns — computed, not applied
+            tmp = {k: v.copy() for k, v in so.items()}
+            o.call = call + 1
+            o.multi_reset(tmp, ro['all_done'], cfg, mode=mode)
+            _same(o.last_reset_obs, rh['obs_after'], f'obs_after t={t}')
         deaths += int(so['dones'].sum())
         if t % 5 == 4:      # no reset this time: dead snakes are stepped again
             prev = None
@@ -132,3 +137,47 @@ def test_class_loop_equals_oracle_loop(lazy, cfg_name, mode):
             st['foods'][0, 0, 1, 1] = 1.0
     check_state('final')
     env.check_consistency() if (o.multi_check(st) == 0).all() else None
+
+
+@pytest.mark.parametrize('cfg_name,mode', [('default', 'full'), ('train', 'partial_3'), ('dense', 'full')])
+def test_class_loop_with_reset_observations(cfg_name, mode):
+    """The reference's own call pattern, `obs, r, d, info = env.step(a); obs = env.reset(d['__all__'])` every iteration: the
+    first reset runs at once, later ones are served by the step launch (obs_after) and deferred."""
+    import torch
+    from wurm_amd.envs import MultiSnake
+    cfg = CFGS[cfg_name]
+    N, K, S, T, seed = 20, 3, 12, 100, 41
+    env = MultiSnake(N, K, S, device='cuda:0', seed=seed, env_offset=3, observation_mode=mode,
+                     boost=cfg['boost'], food_on_death_prob=cfg['food_on_death_prob'],
+                     boost_cost_prob=cfg['boost_cost_prob'], food_mode=cfg['food_mode'], food_rate=cfg['food_rate'],
+                     respawn_mode=cfg['respawn_mode'], reward_on_death=cfg['reward_on_death'],
+                     agent_colours=cfg['colour_mode'])
+    o = OracleBackend(seed=seed, env_offset=3)
+    st = _o.multi_empty_state(N, K, S)
+    st['colours'][...] = o.multi_colours(N, K, cfg['colour_mode'] == 'fixed', call=0)
+    o.call = 1
+    assert o.multi_reset(st, np.ones(N), cfg) == 0
+    g = torch.Generator().manual_seed(6)
+    served = 0
+    for t in range(T):
+        a = torch.randint(8, (K, N), generator=g)
+        ac = a.cuda()
+        obs, rew, dones, info = env.step({f'agent_{i}': ac[i] for i in range(K)})
+        r = o.multi_step(st, a.numpy(), cfg, mode)
+        for i in range(K):
+            _same(obs[f'agent_{i}'].cpu().numpy(), r['obs'][i], f'obs {i} t={t}')
+            _same(rew[f'agent_{i}'].cpu().numpy(), r['rewards'].reshape(N, K)[:, i], f'reward {i} t={t}')
+        _same(dones['__all__'].cpu().numpy().astype(np.uint8), r['all_done'], f'all_done t={t}')
+        served += env._obs_after is not None
+        back = env.reset(dones['__all__'])
+        o.multi_reset(st, r['all_done'], cfg, mode=mode)
+        for i in range(K):
+            _same(back[f'agent_{i}'].cpu().numpy(), o.last_reset_obs[i], f'reset obs {i} t={t}')
+        if t % 10 == 7:  # looking at the state applies the postponed reset
+            _same(env.bodies.cpu().numpy(), st['bodies'], f'bodies t={t}')
+            _same(env.agent_colours.cpu().numpy(), st['colours'], f'colours t={t}')
+            _same(env.dones.cpu().numpy().astype(np.uint8), st['dones'], f'dones t={t}')
+    assert served >= T - 2
+    _same(env.foods.cpu().numpy(), st['foods'], 'final foods')
+    _same(env.heads.cpu().numpy(), st['heads'], 'final heads')
+    _same(env.orientations.cpu().numpy(), st['orientations'], 'final orientations')

@@ -72,7 +72,7 @@ class MultiCall(ctypes.Structure):
     """wurm_multi_call of include/wurm_hip.h"""
     _fields_ = [(n, ctypes.c_void_p) for n in (
         'foods', 'heads', 'bodies', 'dones', 'orientations', 'colours', 'actions', 'boost_this_step', 'rewards',
-        'snake_collision', 'edge_collision', 'food_consumed', 'sizes', 'all_done', 'all_done_copy', 'obs',
+        'snake_collision', 'edge_collision', 'food_consumed', 'sizes', 'all_done', 'all_done_copy', 'obs', 'obs_after',
         'agent_major_f32', 'agent_major_u8', 'pre_done', 'inject', 'pre_inject')] + [
         ('num_envs', ctypes.c_int64), ('env_offset', ctypes.c_int64), ('seed', ctypes.c_uint64),
         ('call', ctypes.c_uint64), ('pre_call', ctypes.c_uint64), ('num_snakes', ctypes.c_int), ('size', ctypes.c_int),

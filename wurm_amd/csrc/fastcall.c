@@ -43,16 +43,16 @@ static PyObject *fast_step_slot(PyObject *self, PyObject *const *args, Py_ssize_
     return PyLong_FromLong(rc);
 }
 
-typedef int (*multi_step_fn)(void *call_block, float *out_f32, uint8_t *out_u8, float *obs, const int64_t *actions,
-                             uint64_t call, int apply_pending, uint64_t pre_call, void *stream);
+typedef int (*multi_step_fn)(void *call_block, float *out_f32, uint8_t *out_u8, float *obs, float *obs_after,
+                             const int64_t *actions, uint64_t call, int apply_pending, uint64_t pre_call, void *stream);
 
-/* multi_step(function_addr, call_block_addr, out_f32, out_u8, obs, actions, call, apply_pending, pre_call, stream)
- * -> int return code of wurm_multi_step_packed at function_addr */
+/* multi_step(function_addr, call_block_addr, out_f32, out_u8, obs, obs_after, actions, call, apply_pending, pre_call,
+ * stream) -> int return code of wurm_multi_step_packed at function_addr */
 static PyObject *fast_multi_step(PyObject *self, PyObject *const *args, Py_ssize_t nargs)
 {
     (void)self;
-    if (nargs != 10) {
-        PyErr_SetString(PyExc_TypeError, "multi_step takes exactly 10 arguments");
+    if (nargs != 11) {
+        PyErr_SetString(PyExc_TypeError, "multi_step takes exactly 11 arguments");
         return NULL;
     }
     multi_step_fn fn = (multi_step_fn)PyLong_AsVoidPtr(args[0]);
@@ -60,17 +60,18 @@ static PyObject *fast_multi_step(PyObject *self, PyObject *const *args, Py_ssize
     float *out_f32 = (float *)PyLong_AsVoidPtr(args[2]);
     uint8_t *out_u8 = (uint8_t *)PyLong_AsVoidPtr(args[3]);
     float *obs = (float *)PyLong_AsVoidPtr(args[4]);
-    const int64_t *actions = (const int64_t *)PyLong_AsVoidPtr(args[5]);
-    unsigned long long call = PyLong_AsUnsignedLongLong(args[6]);
-    int pending = PyObject_IsTrue(args[7]);
-    unsigned long long pre_call = PyLong_AsUnsignedLongLong(args[8]);
-    void *stream = PyLong_AsVoidPtr(args[9]);
+    float *obs_after = (float *)PyLong_AsVoidPtr(args[5]);
+    const int64_t *actions = (const int64_t *)PyLong_AsVoidPtr(args[6]);
+    unsigned long long call = PyLong_AsUnsignedLongLong(args[7]);
+    int pending = PyObject_IsTrue(args[8]);
+    unsigned long long pre_call = PyLong_AsUnsignedLongLong(args[9]);
+    void *stream = PyLong_AsVoidPtr(args[10]);
     if (PyErr_Occurred()) return NULL;
     if (fn == NULL) {
         PyErr_SetString(PyExc_RuntimeError, "wurm_amd._fastcall: null function address");
         return NULL;
     }
-    int rc = fn(blk, out_f32, out_u8, obs, actions, (uint64_t)call, pending, (uint64_t)pre_call, stream);
+    int rc = fn(blk, out_f32, out_u8, obs, obs_after, actions, (uint64_t)call, pending, (uint64_t)pre_call, stream);
     return PyLong_FromLong(rc);
 }
 

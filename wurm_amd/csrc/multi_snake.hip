@@ -43,6 +43,7 @@ struct MultiArgs {
     uint8_t *all_done;
     short *colours;
     float *obs;
+    float *obs_after;     // multi_step_kernel, nullable: the observation the caller's reset(all_done) will return
     int obs_mode, obs_n;
     long long obs_elems;
     long long N;
@@ -814,6 +815,19 @@ __global__ __launch_bounds__(256) void multi_step_kernel(MultiArgs p)
 
     store_env(cx, foodp, headp, bodyp, fbits0, hc0, sn.hc, rebuilt); // a rebuilt env is stored whole
     if (p.obs_mode != WURM_OBS_NONE) observe(cx, p, p.obs, env, sn);
+    if (p.obs_after == nullptr || p.obs_mode == WURM_OBS_NONE) return;
+    // what reset(dones['__all__']) returns (multi_reset_kernel with done_env = all_done, call + 1), on the LDS copy
+    // only: the caller postpones that reset into the next launch, which recreates it from the same counters
+    const bool rebuild_after = r.all_done;
+    if (rebuild_after) sn.done = false; // :798
+    // :800-803 the colours of snakes that are still dead are re-rolled (registers only; they matter to 'partial_n')
+    if (p.obs_mode == WURM_OBS_PARTIAL) reroll_colour(p, agent, snake && sn.done, env_id, p.call + 1ull, 0, sn);
+    const bool respawn_after = p.cfg.respawn_any && ballot(snake && sn.done) != 0;
+    if (rebuild_after || respawn_after) {
+        bool orient_dirty = false;
+        multi_reset_grid(cx, p, env, env_id, p.call + 1ull, rebuild_after, respawn_after, sn, orient_dirty, 0, 0);
+    }
+    observe(cx, p, p.obs_after, env, sn);
 }
 
 // ------------------------------------------------------------------------------------------------ reset
@@ -1425,13 +1439,14 @@ int wurm_multi_step_reset(const wurm_multi_call *c, void *stream)
                             !c->food_consumed || !c->sizes || !c->all_done))
         return WURM_ERR_INVALID_ARG;
     if ((c->obs_mode == WURM_OBS_PARTIAL || c->pre_done) && c->num_envs > 0 && !c->colours) return WURM_ERR_INVALID_ARG;
-    if (c->pre_done && c->size < 5) return WURM_ERR_UNSUPPORTED;
+    if ((c->pre_done || c->obs_after) && c->size < 5) return WURM_ERR_UNSUPPORTED;
+    if (c->obs_after && c->pre_inject) return WURM_ERR_UNSUPPORTED; // the reset behind obs_after draws from the RNG
     MultiArgs p = {};
     p.foods = c->foods; p.heads = c->heads; p.bodies = c->bodies; p.dones = c->dones;
     p.orientations = (long long *)c->orientations; p.actions = (const long long *)c->actions; p.boost = c->boost_this_step;
     p.rewards = c->rewards; p.snakecol = c->snake_collision; p.edgecol = c->edge_collision; p.foodcons = c->food_consumed;
     p.sizes = c->sizes; p.all_done = c->all_done; p.all_done_copy = c->all_done_copy; p.colours = c->colours;
-    p.obs = c->obs; p.obs_mode = c->obs_mode; p.obs_n = c->obs_n;
+    p.obs = c->obs; p.obs_after = c->obs_after; p.obs_mode = c->obs_mode; p.obs_n = c->obs_n;
     p.obs_elems = multi_obs_elems(c->obs_mode, c->obs_n, c->size); p.N = c->num_envs; p.K = c->num_snakes; p.S = c->size;
     p.cfg = c->cfg; p.seed = c->seed; p.call = c->call; p.env_offset = c->env_offset;
     p.done_env = c->pre_done; p.pre_call = c->pre_call;
@@ -1441,8 +1456,8 @@ int wurm_multi_step_reset(const wurm_multi_call *c, void *stream)
     return multi_launch(MK_STEP, p, stream);
 }
 
-int wurm_multi_step_packed(wurm_multi_call *c, float *out_f32, uint8_t *out_u8, float *obs, const int64_t *actions,
-                           uint64_t call, int apply_pending, uint64_t pre_call, void *stream)
+int wurm_multi_step_packed(wurm_multi_call *c, float *out_f32, uint8_t *out_u8, float *obs, float *obs_after,
+                           const int64_t *actions, uint64_t call, int apply_pending, uint64_t pre_call, void *stream)
 {
     if (!c) return WURM_ERR_INVALID_ARG;
     if (c->num_envs > 0 && (!out_f32 || !out_u8)) return WURM_ERR_INVALID_ARG;
@@ -1454,6 +1469,7 @@ int wurm_multi_step_packed(wurm_multi_call *c, float *out_f32, uint8_t *out_u8, 
     c->agent_major_u8 = out_u8 + 3 * KN;
     c->all_done = out_u8 + 7 * KN;
     c->obs = obs;
+    c->obs_after = obs_after;
     c->actions = actions;
     c->call = call;
     c->pre_done = apply_pending ? c->all_done_copy : nullptr;

@@ -20,9 +20,11 @@ Per-call path: `step` is one launch (wurm_multi_step_reset).  `reset(done, retur
 `dones['__all__']` the last `step` returned is DEFERRED into the next step's launch (`lazy_reset=True`, the default), with
 the RNG counter the eager call would have used — bit-identical results; the state attributes (`foods`, `heads`, `bodies`,
 `dones`, `orientations`, `agent_colours`) are properties that first apply a postponed reset, as does every method that
-looks at the state.  A reset whose observation is asked for (the reference's default) is executed at once: it has to
-write all K agents' observations a second time.  As for SingleSnake, a tensor alias taken before the deferred reset is
-the one thing that is not tracked.
+looks at the state.  A reset whose observation is asked for (the reference's default) is executed at once the first
+time; from then on the step launch also writes that observation (`obs_after`: the reset is applied to the on-chip copy
+of the env after the step's own observation, with the counter the eager call would use) and `reset` hands it out and
+is deferred like the other form.  As for SingleSnake, a tensor alias taken before the deferred reset is the one thing
+that is not tracked.
 """
 import ctypes
 from collections import namedtuple, OrderedDict
@@ -66,7 +68,8 @@ class MultiSnake(object):
     _pending = False
     _last_fresh = False
     _state_dirty = True
-    _out_f = _out_b = _rewards_t = _boost_t = _mc_mode = None
+    _out_f = _out_b = _rewards_t = _boost_t = _mc_mode = _obs_after = None
+    _want_after = False
     foods = _Flushing('foods')
     heads = _Flushing('heads')
     bodies = _Flushing('bodies')
@@ -401,6 +404,9 @@ class MultiSnake(object):
             c.obs_mode, c.obs_n, o = self._obs_args(mode)
             self._obs_shape, self._mc_mode = tuple(o.shape), mode
         obs = torch.empty(self._obs_shape, dtype=torch.float32, device=dev)
+        # a caller that reads what reset(dones['__all__']) returns gets it from this launch from now on (reset below)
+        after = torch.empty(self._obs_shape, dtype=torch.float32, device=dev) if self._want_after else None
+        a_after = after.data_ptr() if after is not None else 0
         cfg = self._cfg()
         if cfg is not self._mc_cfg:
             c.cfg = self._mc_cfg = cfg
@@ -412,15 +418,16 @@ class MultiSnake(object):
         self._call = call + 1
         idx = dev.index
         if self._get_device() != idx:  # a process driving several GPUs has another device current
-            rc = _lib.call(idx, self._mc_fn, self._mc_addr, of.data_ptr(), ob.data_ptr(), obs.data_ptr(), a_ptr, call,
-                           pending, self._pend_call, _lib.stream_ptr(idx))
+            rc = _lib.call(idx, self._mc_fn, self._mc_addr, of.data_ptr(), ob.data_ptr(), obs.data_ptr(), a_after, a_ptr,
+                           call, pending, self._pend_call, _lib.stream_ptr(idx))
         else:
-            rc = self._mc_fn(self._mc_addr, of.data_ptr(), ob.data_ptr(), obs.data_ptr(), a_ptr, call, pending,
+            rc = self._mc_fn(self._mc_addr, of.data_ptr(), ob.data_ptr(), obs.data_ptr(), a_after, a_ptr, call, pending,
                              self._pend_call, self._get_stream(idx))
         if rc:
             _lib.check(rc, 'MultiSnake.step')
 
         self._out_f, self._out_b = of, ob          # env.rewards / env.boost_this_step are views of these, made on demand
+        self._obs_after = after
         self._rewards_t = self._boost_t = None
 
         # reference :701-729 — per-agent dicts; the kernel wrote agent-major rows, so these are plain views
@@ -551,10 +558,17 @@ class MultiSnake(object):
         if self.initial_snake_length != 3:
             raise NotImplementedError('Only initial snake length = 3 has been implemented.')
         if done is not None and done is self._last_all_done and self._last_fresh and self.lazy_reset and \
-                not return_observations and self.size >= 5 and done._version == self._last_version:
+                self.size >= 5 and done._version == self._last_version:
             # env_lifetimes is all zeros here (nobody has asked for it): `env_lifetimes[done] = 0` (:797) is a no-op
-            self._pending, self._pend_call = True, self._next_call()
-            return None
+            if not return_observations:
+                self._want_after = False
+                self._pending, self._pend_call = True, self._next_call()
+                return None
+            if self._obs_after is not None:  # the step launch already wrote what this reset returns
+                obs, self._obs_after = self._obs_after, None
+                self._pending, self._pend_call = True, self._next_call()
+                return self._obs_dict(obs)
+            self._want_after = True          # from the next step on it does; this one runs at once
         if done is None:
             done = self._norm('dones', (self.num_envs * self.num_snakes,), torch.bool) \
                 .view(self.num_envs, self.num_snakes).all(dim=1)
