@@ -924,7 +924,12 @@ __device__ __forceinline__ void multi_reset_grid(const Ctx &cx, const MultiArgs 
     const int C = cx.C, K = cx.K, lane = cx.lane;
     const bool snake = lane < K;
     if (rebuild) { // _create_envs (:996-1019)
-        for (int i = lane; i < K * C; i += 64) cx.body[i] &= DIRTY; // value 0; a cell that ever held one stays marked
+        { // value 0; a cell that ever held one stays marked.  Four cells per access: the grids start on a 16-byte
+          // boundary and are followed by padding up to the next one, so the last access may run into the padding.
+            u64 *b8 = (u64 *)cx.body;
+            const u64 keep = (u64)DIRTY * 0x0001000100010001ull;
+            for (int i = lane; i < (K * C + 3) >> 2; i += 64) b8[i] &= keep;
+        }
         for (int k = 0; k < cx.cpl; ++k) {
             int c = lane + 64 * k;
             if (c < C) { cx.food[c] = 0; cx.occ[c] = 0; cx.hmap[c] = 0; }
@@ -954,13 +959,21 @@ __device__ __forceinline__ void multi_reset_grid(const Ctx &cx, const MultiArgs 
             const int y = div_size(cell, cx.rcpS), x = cell - y * S;
             if (lane == y) occ_row |= 1ull << x;
         };
+        // all the draws of the rebuild in one Philox evaluation: lane s < K takes the spawn block of snake s, lane K
+        // the block the food cell comes from (K = 64: there is no such lane, the food block is drawn on its own)
+        Words draws;
+        draws.w[0] = draws.w[1] = draws.w[2] = draws.w[3] = 0;
+        if (!p.has_rinj)
+            draws = rng_words(p.seed, call, env_id, lane < K ? RNG_SPAWN : RNG_RESET, lane < K ? (u32)lane : 0u);
         for (int s = 0; s < K; ++s) { // _add_snake (:911-994), one snake after another
             int cell = -1, dnew = 0;
             if (p.has_rinj) {
                 cell = p.rinj.create[(offA + env * K + s) * 2];
                 dnew = p.rinj.create[(offA + env * K + s) * 2 + 1];
             } else {
-                Words w = rng_words(p.seed, call, env_id, RNG_SPAWN, (u32)s);
+                Words w;
+                w.w[0] = (u32)lane_value((int)draws.w[0], s);
+                w.w[1] = (u32)lane_value((int)draws.w[1], s);
                 dnew = (int)(w.w[1] >> 30);
                 // available (:927-941): at least 2 from the border, nothing in the 3x3 neighbourhood
                 const u64 h = occ_row | (occ_row << 1) | (occ_row >> 1);
@@ -993,7 +1006,9 @@ __device__ __forceinline__ void multi_reset_grid(const Ctx &cx, const MultiArgs 
             } else { // free (:439-445): not on the border ring, nothing on it
                 const u64 cols = ((1ull << (S - 2)) - 1ull) << 1;
                 const u64 fr = (lane >= 1 && lane <= S - 2) ? (~occ_row & cols) : 0ull;
-                const int cell = pick(fr, rng_words(p.seed, call, env_id, RNG_RESET, 0).w[3]);
+                const u32 word = K < 64 ? (u32)lane_value((int)draws.w[3], K)
+                                        : rng_words(p.seed, call, env_id, RNG_RESET, 0).w[3];
+                const int cell = pick(fr, word);
                 if (cell >= 0 && lane == 0) cx.food[cell] = 1;
             }
             wave_lds_sync();
