@@ -2,7 +2,7 @@
 //
 // fused_step_kernel<2> (one env per wave) spends 311 VALU + 310 SALU instructions per env at 9 x 9 and is issue bound:
 // 65 536 envs take ~49 us where their 93 MB of traffic need ~20 us (profiles/).  Almost all of those
-// instructions are per-env scalars computed by a whole wave.  Here a wave owns EPW = 16 CONSECUTIVE envs and works in
+// instructions are per-env scalars computed by a whole wave.  Here a wave owns EPW (4, 8 or 16) CONSECUTIVE envs and works in
 // two alternating shapes:
 //   * cooperative, lanes = (env, cell) pairs of the block: the state (EPW x 3 x S x S floats, one contiguous run) is
 //     read with coalesced dword loads and the few non-zero elements are scattered into a per-env summary in LDS (head
@@ -13,7 +13,8 @@
 //     (the body cells of a decaying snake, two head cells, the food) are written straight from the lanes, the per-env
 //     outputs (reward, done, flags, sanitised action) are coalesced stores.
 // EPW trades the per-wave cost of the per-lane phase against parallelism: the whole batch is resident at once, so the
-// launch takes as long as one wave (65 536 x 9 x 9: 64 envs per wave 82 us, 32: 34 us, 16: 29 us, 8: 31 us).
+// launch takes as long as one wave (65 536 x 9 x 9: 64 envs per wave 82 us, 32: 34 us, 16: 26 us); smaller batches take
+// 8 or 4 envs per wave (launch_lane_step).
 // Domain: well-formed snakes (body values exactly 1..L once each, one head on L, at most one food) on 9 <= S <= 11
 // (S*S <= 128: occupancy is a 128-bit mask per lane), RNG mode, observation 'partial_n' or none, the contract of
 // fused_step_kernel without post_reset.  An env outside the domain is stepped by fused_step_env() — the one-env-per-wave
@@ -373,15 +374,24 @@ static hipError_t launch_lane_step(const StepArgs &p, hipStream_t stream)
             if (c < 64) a.int_lo |= 1ull << c;
             else a.int_hi |= 1ull << (c - 64);
         }
-    constexpr int EPW = 16; // envs per wave; measured at 65 536 x 9 x 9: 8 -> 31 us, 16 -> 29 us, 32 -> 34 us, 64 -> 82 us
-    const int wpb = 4;
-    const long long waves = (p.N + EPW - 1) / EPW;
-    dim3 block(64 * wpb), grid((unsigned)((waves + wpb - 1) / wpb));
-    const size_t lds = (size_t)LaneLds<EPW>::BYTES * wpb;
+    // Envs per wave.  The whole batch is resident at once, so a launch takes as long as ONE wave: fewer envs per wave
+    // = more, shorter waves, but the per-lane phase is paid once per wave.  Measured (9 x 9 partial_2, us per launch;
+    // the one-env-per-wave kernel in brackets): 8192 envs 9.2 / 10.8 / 13.9 at 4 / 8 / 16 envs per wave [9.6],
+    // 16 384: 11.2 / 12.0 / 14.9 [15.1], 32 768: 17.4 / 15.6 / 17.6 [26.6], 65 536: 28.7 / 27.3 / 26.0 [48.3].
+    const int epw = p.N >= 49152 ? 16 : (p.N >= 24576 ? 8 : 4);
     (void)hipGetLastError();
-    if (p.S == 9) hipLaunchKernelGGL((lane_step_kernel<EPW, 9>), grid, block, lds, stream, a);
-    else if (p.S == 10) hipLaunchKernelGGL((lane_step_kernel<EPW, 10>), grid, block, lds, stream, a);
-    else hipLaunchKernelGGL((lane_step_kernel<EPW, 11>), grid, block, lds, stream, a);
+    auto go = [&](auto k9, auto k10, auto k11, int epw, int lds_per_wave) {
+        const int wpb = p.N <= 8192 ? 1 : 4;
+        const long long waves = (p.N + epw - 1) / epw;
+        dim3 block(64 * wpb), grid((unsigned)((waves + wpb - 1) / wpb));
+        const size_t lds = (size_t)lds_per_wave * wpb;
+        if (p.S == 9) hipLaunchKernelGGL(k9, grid, block, lds, stream, a);
+        else if (p.S == 10) hipLaunchKernelGGL(k10, grid, block, lds, stream, a);
+        else hipLaunchKernelGGL(k11, grid, block, lds, stream, a);
+    };
+    if (epw == 4) go(lane_step_kernel<4, 9>, lane_step_kernel<4, 10>, lane_step_kernel<4, 11>, 4, LaneLds<4>::BYTES);
+    else if (epw == 8) go(lane_step_kernel<8, 9>, lane_step_kernel<8, 10>, lane_step_kernel<8, 11>, 8, LaneLds<8>::BYTES);
+    else go(lane_step_kernel<16, 9>, lane_step_kernel<16, 10>, lane_step_kernel<16, 11>, 16, LaneLds<16>::BYTES);
     return hipGetLastError();
 }
 

@@ -1651,7 +1651,7 @@ static hipError_t launch_one(Kind kind, const StepArgs &p, dim3 grid, dim3 block
         // one-env-per-wave code inside the same launch
         static const long long min_envs = [] { // read once; tests force the path with WURM_LANE_STEP_MIN_ENVS=0
             const char *e = getenv("WURM_LANE_STEP_MIN_ENVS");
-            return e ? atoll(e) : 16384ll;
+            return e ? atoll(e) : 12288ll;
         }();
         if ((kind == K_STEP || kind == K_FUSED) && p.N >= min_envs && lane_step_eligible(p))
             return launch_lane_step(p, st);
