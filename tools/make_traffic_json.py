@@ -42,6 +42,9 @@ def total(t):
 detail = {
     'rollout_512x9_chunk1024': traffic('void wurm::rollout_s9_kernel<4', 32768),
     'rollout_8192x9_chunk128': traffic('void wurm::rollout_s9_kernel<4', 524288),
+    'rollout_16384x9_chunk128': traffic('void wurm::rollout_s9_kernel<4', 1048576),
+    'rollout_32768x9_chunk64': traffic('void wurm::rollout_s9_kernel<4', 2097152),
+    'rollout_65536x9_chunk64': traffic('void wurm::rollout_s9_kernel<4', 4194304),
     'rollout_cfg5_8192x36_default_chunk16': traffic('void wurm::(anonymous namespace)::grid_rollout_kernel<true>', 524288),
     'multi_rollout_cfg4_4096x25_k4_full_chunk16': traffic('void wurm::multi_rollout_kernel<true>', 524288),
     'fused_step_512x9_partial2': traffic('void wurm::fused_step_kernel<2, true>', 32768),
@@ -60,6 +63,9 @@ out = {
     # the keys bench.py looks up: rollout_<N>x<S>_chunk<steps per launch>
     'rollout_512x9_chunk1024': total(detail['rollout_512x9_chunk1024']),
     'rollout_8192x9_chunk128': total(detail['rollout_8192x9_chunk128']),
+    'rollout_16384x9_chunk128': total(detail['rollout_16384x9_chunk128']),
+    'rollout_32768x9_chunk64': total(detail['rollout_32768x9_chunk64']),
+    'rollout_65536x9_chunk64': total(detail['rollout_65536x9_chunk64']),
     'detail': detail,
 }
 print(json.dumps(out, indent=1))

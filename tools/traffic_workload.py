@@ -32,7 +32,7 @@ torch.cuda.synchronize()
 del big
 
 # measured: rollouts
-for N, chunk in ((512, 1024), (8192, 128)):
+for N, chunk in ((512, 1024), (8192, 128), (16384, 128), (32768, 64), (65536, 64)):  # bench.py's shapes at 1..8 GPUs
     env = SingleSnake(num_envs=N, size=9, observation_mode='partial_2', device=dev, seed=0)
     actions = torch.randint(4, (chunk * 5, N), device=dev, dtype=torch.int64)
     for c in range(0, chunk * 5, chunk):
