@@ -798,7 +798,16 @@ __global__ __launch_bounds__(256) void multi_step_kernel(MultiArgs p)
     const long long agent = env * K + lane;
     float *foodp = p.foods + env * C, *headp = p.heads + env * K * C, *bodyp = p.bodies + env * K * C;
 
-    const u64 fbits0 = load_env(cx, foodp, headp, bodyp);
+    // An env the postponed reset rebuilds is not read at all (as in multi_reset_kernel): the launch is one round of waves
+    // and ends with its slowest env, and a rebuilt env — rebuild + whole-env store — is the slowest already.
+    const bool rebuild = p.done_env != nullptr && uniform((int)p.done_env[env]) != 0;
+    u64 fbits0 = 0;
+    if (!rebuild) {
+        fbits0 = load_env(cx, foodp, headp, bodyp);
+    } else {
+        if (snake) { cx.hcell[lane] = -1; cx.lmax[lane] = 0; cx.tclk[lane] = 0; } // the rest: multi_reset_grid(rebuild)
+        wave_lds_sync();
+    }
     Snake sn;
     sn.hc = snake ? cx.hcell[lane] : -1;
     sn.L = snake ? cx.lmax[lane] : 0;
@@ -810,7 +819,6 @@ __global__ __launch_bounds__(256) void multi_step_kernel(MultiArgs p)
     if (p.done_env != nullptr) {
         // the reset(done) the caller postponed (wurm_multi_step_reset): exactly multi_reset_kernel without observation,
         // with its own counter, in front of the transition
-        const bool rebuild = uniform((int)p.done_env[env]) != 0;
         if (rebuild) sn.done = false; // :798
         load_colour(p, agent, snake, sn);
         if (snake && reroll_colour(p, agent, sn.done, env_id, p.pre_call, 0, sn)) {
