@@ -113,6 +113,7 @@ __device__ __forceinline__ void lane_observe(const LaneArgs &a, unsigned char *l
         const int e = div_size(idx, rcpW2), w = idx - e * W2;
         const int wy = div_size(w, rcpW), wx = w - wy * W;
         const int h = dh[e];
+        if (h < -1) continue; // an env outside the domain: fused_step_env() writes its crop, nothing is stored here
         const int hy = div_size(max(h, 0), rcpS), hx = h - hy * S;
         const int y = hy - n + wy, x = hx - n + wx;
         float r = 0.0f, g = 0.0f, b = 0.0f; // zero padding (single_snake.py:179), the border ring, no head
@@ -317,7 +318,7 @@ __global__ __launch_bounds__(256) void lane_step_kernel(LaneArgs a)
         short *dh = (short *)(lds + Lds::DESC), *df = dh + EPW;
         u64 *dB = (u64 *)(dh + 2 * EPW);
         if (mine) {
-            dh[lane] = (short)(regular ? nh : -1);
+            dh[lane] = (short)(regular ? nh : -2);
             df[lane] = (short)fc_after;
             dB[lane] = B.lo;
             dB[EPW + lane] = B.hi;
@@ -325,7 +326,7 @@ __global__ __launch_bounds__(256) void lane_step_kernel(LaneArgs a)
         if (p.obs_after != nullptr) { // what reset(done) returns: done envs rebuilt with call + 1 (not stored here)
             short *ah = (short *)(lds + Lds::DESC + Lds::DESC_BYTES), *af = ah + EPW;
             u64 *aB = (u64 *)(ah + 2 * EPW);
-            int h2 = regular ? nh : -1, f2 = fc_after;
+            int h2 = regular ? nh : -2, f2 = fc_after;
             Mask128 B2 = B;
             if (regular && (SELFC || EDGEC)) {
                 const LaneSnake r = lane_reset(p.seed, p.call + 1ull, env_id, S, interior);
@@ -345,7 +346,7 @@ __global__ __launch_bounds__(256) void lane_step_kernel(LaneArgs a)
         if (p.obs_after != nullptr) lane_observe<EPW, S>(a, lds, 1, p.obs_after + env0 * p.obs_elems, nenv, lane);
     }
 
-    // ---- envs outside the domain: the one-env-per-wave code, which overwrites their crops and outputs
+    // ---- envs outside the domain: the one-env-per-wave code writes their state, crops and outputs (nothing above did)
     u64 odd = ballot(mine && !regular);
     if (odd != 0) {
         wave_lds_sync();
