@@ -24,6 +24,9 @@ def hip():
     (10, 3, 10, 90, 'full', 'dense'),           # fixed colours, crowded
     (9, 2, 12, 90, 'full', 'noboost'),
     (7, 1, 5, 60, 'full', 'default'),
+    (6, 10, 36, 40, 'full', 'train'),           # experiments/speeds.py shape: one env per workgroup
+    (5, 4, 48, 30, 'full', 'default'),
+    (4, 5, 40, 30, 'none', 'dense'),
 ])
 def test_postponed_reset_in_front_of_the_step(hip, N, K, S, T, mode, cfg):
     cfg = CFGS[cfg]
@@ -139,14 +142,15 @@ def test_class_loop_equals_oracle_loop(lazy, cfg_name, mode):
     env.check_consistency() if (o.multi_check(st) == 0).all() else None
 
 
-@pytest.mark.parametrize('cfg_name,mode', [('default', 'full'), ('train', 'partial_3'), ('dense', 'full')])
-def test_class_loop_with_reset_observations(cfg_name, mode):
+@pytest.mark.parametrize('cfg_name,mode,shape', [('default', 'full', (20, 3, 12, 100)), ('train', 'partial_3', (20, 3, 12, 100)),
+                                                 ('dense', 'full', (20, 3, 12, 100)), ('train', 'full', (6, 10, 36, 40))])
+def test_class_loop_with_reset_observations(cfg_name, mode, shape):
     """The reference's own call pattern, `obs, r, d, info = env.step(a); obs = env.reset(d['__all__'])` every iteration: the
     first reset runs at once, later ones are served by the step launch (obs_after) and deferred."""
     import torch
     from wurm_amd.envs import MultiSnake
     cfg = CFGS[cfg_name]
-    N, K, S, T, seed = 20, 3, 12, 100, 41
+    (N, K, S, T), seed = shape, 41
     env = MultiSnake(N, K, S, device='cuda:0', seed=seed, env_offset=3, observation_mode=mode,
                      boost=cfg['boost'], food_on_death_prob=cfg['food_on_death_prob'],
                      boost_cost_prob=cfg['boost_cost_prob'], food_mode=cfg['food_mode'], food_rate=cfg['food_rate'],

@@ -49,6 +49,9 @@ CFGS = {
     (8, 6, 14, 100, 'partial_2', 'dense'),
     (9, 3, 10, 100, 'full', 'noboost'),
     (3, 10, 36, 40, 'partial_3', 'train'),     # experiments/speeds.py shape (10 agents, 36x36)
+    (4, 10, 36, 40, 'full', 'train'),          # ... with its own observation: one env per WORKGROUP (multi_step_wg_kernel)
+    (5, 4, 48, 30, 'full', 'default'),         # 18 KB of grids per env: the workgroup kernel as well
+    (3, 3, 64, 24, 'full', 'dense'),
     (5, 1, 9, 60, 'full', 'dense'),
     (7, 1, 5, 60, 'full', 'default'),          # the smallest grid the reference can populate (seed rows 2..S-3)
     (7, 1, 6, 60, 'partial_1', 'train'),

@@ -490,13 +490,13 @@ __device__ __forceinline__ void snap_write(const Ctx &cx, int hc, unsigned short
 }
 
 // the K agents' observations of one env from its class codes, agent by agent (any wave of the workgroup may run this)
-__device__ __forceinline__ void snap_emit(const Ctx &cx, const MultiArgs &p, float *obs_env, const unsigned short *snap)
+__device__ __forceinline__ void snap_emit_agent(const Ctx &cx, const MultiArgs &p, float *obs_env,
+                                                const unsigned short *snap, int a)
 {
-    const int C = cx.C, K = cx.K, lane = cx.lane;
+    const int C = cx.C, lane = cx.lane;
     const float G1 = 192.0f / 255.0f, G2 = 96.0f / 255.0f;
-    const long long agent_stride = p.N * p.obs_elems;
-    for (int a = 0; a < K; ++a) {
-        float *const base = obs_env + a * agent_stride;
+    {
+        float *const base = obs_env + a * (p.N * p.obs_elems);
         for (int k = 0; k < cx.cpl; ++k) {
             const int c = lane + 64 * k;
             if (c < C) {
@@ -519,6 +519,11 @@ __device__ __forceinline__ void snap_emit(const Ctx &cx, const MultiArgs &p, flo
             }
         }
     }
+}
+
+__device__ __forceinline__ void snap_emit(const Ctx &cx, const MultiArgs &p, float *obs_env, const unsigned short *snap)
+{
+    for (int a = 0; a < cx.K; ++a) snap_emit_agent(cx, p, obs_env, snap, a);
 }
 
 __device__ __forceinline__ void observe_full_snap(const Ctx &cx, const MultiArgs &p, float *__restrict__ obs,
@@ -786,39 +791,23 @@ __device__ __forceinline__ void multi_reset_grid(const Ctx &cx, const MultiArgs 
                                                  bool rebuild, bool respawn, Snake &sn, bool &orient_dirty,
                                                  long long offA, long long offE);
 
-__global__ __launch_bounds__(256) void multi_step_kernel(MultiArgs p)
+// The part of the per-call step between the load and the store of the env (LDS state ready, hcell / lmax / tclk set):
+// [the reset(done) the caller postponed, exactly multi_reset_kernel without observation, with its own counter,] the
+// transition, and the per-agent outputs.  Runs on ONE wave.  hc0: the head cells HBM holds (sparse write-back).
+__device__ __forceinline__ void step_middle(const Ctx &cx, const MultiArgs &p, long long env, bool rebuild, Snake &sn,
+                                            StepRes &r, int &hc0)
 {
-    const int wave = (int)(threadIdx.x >> 6), wpb = (int)(blockDim.x >> 6);
-    const long long env = xcd_block(blockIdx.x, gridDim.x) * wpb + wave;
-    if (env >= p.N) return;
-    const Ctx cx = make_ctx(p, wave);
-    const int C = cx.C, K = cx.K, lane = cx.lane;
+    const int K = cx.K, lane = cx.lane;
     const bool snake = lane < K;
     const u64 env_id = (u64)(p.env_offset + env);
     const long long agent = env * K + lane;
-    float *foodp = p.foods + env * C, *headp = p.heads + env * K * C, *bodyp = p.bodies + env * K * C;
-
-    // An env the postponed reset rebuilds is not read at all (as in multi_reset_kernel): the launch is one round of waves
-    // and ends with its slowest env, and a rebuilt env — rebuild + whole-env store — is the slowest already.
-    const bool rebuild = p.done_env != nullptr && uniform((int)p.done_env[env]) != 0;
-    u64 fbits0 = 0;
-    if (!rebuild) {
-        fbits0 = load_env(cx, foodp, headp, bodyp);
-    } else {
-        if (snake) { cx.hcell[lane] = -1; cx.lmax[lane] = 0; cx.tclk[lane] = 0; } // the rest: multi_reset_grid(rebuild)
-        wave_lds_sync();
-    }
-    Snake sn;
     sn.hc = snake ? cx.hcell[lane] : -1;
     sn.L = snake ? cx.lmax[lane] : 0;
     sn.done = snake ? p.dones[agent] != 0 : true;
     sn.orient = snake ? p.orientations[agent] : 0;
     sn.boosted = false;
-    const int hc0 = sn.hc;
-    bool rebuilt = false;
+    hc0 = sn.hc;
     if (p.done_env != nullptr) {
-        // the reset(done) the caller postponed (wurm_multi_step_reset): exactly multi_reset_kernel without observation,
-        // with its own counter, in front of the transition
         if (rebuild) sn.done = false; // :798
         load_colour(p, agent, snake, sn);
         if (snake && reroll_colour(p, agent, sn.done, env_id, p.pre_call, 0, sn)) {
@@ -831,12 +820,10 @@ __global__ __launch_bounds__(256) void multi_step_kernel(MultiArgs p)
             bool orient_dirty = false;
             multi_reset_grid(cx, p, env, env_id, p.pre_call, rebuild, respawn, sn, orient_dirty, 0, 0);
         }
-        rebuilt = rebuild;
     } else {
         load_colour(p, agent, snake && p.obs_mode == WURM_OBS_PARTIAL, sn);
     }
     const long long a = snake ? p.actions[(long long)lane * p.N + env] : 0;
-    StepRes r;
     multi_step_body(cx, p, env, env_id, p.call, a, sn, r, 0, 0, 0);
 
     // outputs (:701-729)
@@ -864,22 +851,184 @@ __global__ __launch_bounds__(256) void multi_step_kernel(MultiArgs p)
         p.all_done[env] = (uint8_t)r.all_done;
         if (p.all_done_copy) p.all_done_copy[env] = (uint8_t)r.all_done;
     }
+}
 
-    store_env(cx, foodp, headp, bodyp, fbits0, hc0, sn.hc, rebuilt); // a rebuilt env is stored whole
-    if (p.obs_mode != WURM_OBS_NONE) observe(cx, p, p.obs, env, sn);
-    if (p.obs_after == nullptr || p.obs_mode == WURM_OBS_NONE) return;
-    // what reset(dones['__all__']) returns (multi_reset_kernel with done_env = all_done, call + 1), on the LDS copy
-    // only: the caller postpones that reset into the next launch, which recreates it from the same counters
+// What reset(dones['__all__']) will do (multi_reset_kernel with done_env = all_done, call + 1), applied to the LDS copy
+// only: the caller postpones that reset into the next launch, which recreates it from the same counters.  ONE wave.
+__device__ __forceinline__ void reset_for_obs_after(const Ctx &cx, const MultiArgs &p, long long env, Snake &sn,
+                                                    const StepRes &r)
+{
+    const bool snake = cx.lane < cx.K;
+    const u64 env_id = (u64)(p.env_offset + env);
     const bool rebuild_after = r.all_done;
     if (rebuild_after) sn.done = false; // :798
     // :800-803 the colours of snakes that are still dead are re-rolled (registers only; they matter to 'partial_n')
-    if (p.obs_mode == WURM_OBS_PARTIAL) reroll_colour(p, agent, snake && sn.done, env_id, p.call + 1ull, 0, sn);
+    if (p.obs_mode == WURM_OBS_PARTIAL)
+        reroll_colour(p, env * cx.K + cx.lane, snake && sn.done, env_id, p.call + 1ull, 0, sn);
     const bool respawn_after = p.cfg.respawn_any && ballot(snake && sn.done) != 0;
     if (rebuild_after || respawn_after) {
         bool orient_dirty = false;
         multi_reset_grid(cx, p, env, env_id, p.call + 1ull, rebuild_after, respawn_after, sn, orient_dirty, 0, 0);
     }
+}
+
+__global__ __launch_bounds__(256) void multi_step_kernel(MultiArgs p)
+{
+    const int wave = (int)(threadIdx.x >> 6), wpb = (int)(blockDim.x >> 6);
+    const long long env = xcd_block(blockIdx.x, gridDim.x) * wpb + wave;
+    if (env >= p.N) return;
+    const Ctx cx = make_ctx(p, wave);
+    const int C = cx.C, K = cx.K, lane = cx.lane;
+    const bool snake = lane < K;
+    float *foodp = p.foods + env * C, *headp = p.heads + env * K * C, *bodyp = p.bodies + env * K * C;
+
+    // An env the postponed reset rebuilds is not read at all (as in multi_reset_kernel): the launch is one round of waves
+    // and ends with its slowest env, and a rebuilt env — rebuild + whole-env store — is the slowest already.
+    const bool rebuild = p.done_env != nullptr && uniform((int)p.done_env[env]) != 0;
+    u64 fbits0 = 0;
+    if (!rebuild) {
+        fbits0 = load_env(cx, foodp, headp, bodyp);
+    } else {
+        if (snake) { cx.hcell[lane] = -1; cx.lmax[lane] = 0; cx.tclk[lane] = 0; } // the rest: multi_reset_grid(rebuild)
+        wave_lds_sync();
+    }
+    Snake sn;
+    StepRes r;
+    int hc0;
+    step_middle(cx, p, env, rebuild, sn, r, hc0);
+    store_env(cx, foodp, headp, bodyp, fbits0, hc0, sn.hc, rebuild); // a rebuilt env is stored whole
+    if (p.obs_mode != WURM_OBS_NONE) observe(cx, p, p.obs, env, sn);
+    if (p.obs_after == nullptr || p.obs_mode == WURM_OBS_NONE) return;
+    reset_for_obs_after(cx, p, env, sn, r);
     observe(cx, p, p.obs_after, env, sn);
+}
+
+// ---- one env per WORKGROUP.  With 10 snakes on 36 x 36 (experiments/speeds.py) an env's grids take 33 KB of LDS: one
+// wave per SIMD, and multi_step_kernel spends 445 us on 1.1 GB with nothing to overlap the load, the transition and the
+// stores.  Here the four waves of a workgroup share ONE env: all of them copy it in, turn it into class codes and write
+// it back (flat over the K * S * S cells; the K agents' observations go out one agent per wave), wave 0 alone runs the
+// transition in between.  Same LDS layout, same device functions for everything that is not a plain copy.
+__device__ __forceinline__ u64 wg_load_env(const Ctx &cx, const float *__restrict__ foodp, const float *__restrict__ headp,
+                                           const float *__restrict__ bodyp, int tid, int nth)
+{
+    const int C = cx.C, KC = cx.K * C;
+    if (tid < cx.K) {
+        cx.hcell[tid] = -1;
+        cx.lmax[tid] = 0;
+        cx.tclk[tid] = 0;
+    }
+    for (int c = tid; c < C; c += nth) cx.hmap[c] = 0;
+    __syncthreads();
+    const float rcpC = 1.0f / (float)C;
+    constexpr int CH = 8;
+    for (int base = 0; base < KC; base += nth * CH) {
+        float hv[CH], bv[CH];
+#pragma unroll
+        for (int j = 0; j < CH; ++j) { // unconditional loads (index clamped into the env), all in flight together
+            const int i = min(base + tid + nth * j, KC - 1);
+            hv[j] = headp[i];
+            bv[j] = bodyp[i];
+        }
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            const int i = base + tid + nth * j;
+            if (i < KC) {
+                const int bi = __float2int_rn(bv[j]);
+                cx.body[i] = (unsigned short)(bi != 0 ? ((bi & VMASK) | DIRTY) : 0);
+                if (hv[j] > 0.5f || bi > 0) { // rare: a head cell or a body cell
+                    const int s = div_size(i, rcpC);
+                    if (hv[j] > 0.5f) cx.hcell[s] = i - s * C;
+                    if (bi > 0) atomicMax(&cx.lmax[s], bi);
+                }
+            }
+        }
+    }
+    u64 fbits = 0; // bit k: food at cell tid + nth * k
+    for (int k = 0, c = tid; c < C; ++k, c += nth) {
+        const int f = foodp[c] > 0.5f;
+        cx.food[c] = (unsigned char)f;
+        fbits |= (u64)f << k;
+    }
+    return fbits;
+}
+
+__device__ __forceinline__ void wg_store_env(const Ctx &cx, float *__restrict__ foodp, float *__restrict__ headp,
+                                             float *__restrict__ bodyp, u64 fbits0, bool full, int tid, int nth)
+{
+    const int C = cx.C, KC = cx.K * C;
+    const float rcpC = 1.0f / (float)C;
+    for (int i = tid; i < KC; i += nth) {
+        const unsigned short v = cx.body[i];
+        const int s = div_size(i, rcpC), T = cx.tclk[s];
+        // changed since the load: written cells, and — once the clock has moved — every cell that held a value
+        if (full || (v & DIRTY) || (T != 0 && (v & VMASK))) bodyp[i] = (float)max((int)(v & VMASK) - T, 0);
+        if (full) headp[i] = (i - s * C == cx.hcell[s]) ? 1.0f : 0.0f;
+    }
+    for (int k = 0, c = tid; c < C; ++k, c += nth) {
+        const int f = cx.food[c] != 0;
+        if (full || f != (int)((fbits0 >> k) & 1)) foodp[c] = f ? 1.0f : 0.0f;
+    }
+}
+
+// 'full' observation of the env in LDS by the whole workgroup: class codes (cells over all threads), then one agent
+// per wave.  cx.hcell holds the head cells.  Ends with a barrier (the codes and the head map may be rewritten after it).
+__device__ __forceinline__ void wg_observe_snap(const Ctx &cx, const MultiArgs &p, float *obs, long long env, int tid,
+                                                int nth, int wave)
+{
+    const int S = cx.S, C = cx.C, K = cx.K;
+    int hc = -1;
+    if (tid < K) {
+        hc = cx.hcell[tid];
+        if (hc >= 0) cx.hmap[hc] = (unsigned char)(tid + 1);
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += nth) {
+        const int y = div_size(c, cx.rcpS), x = c - y * S;
+        const bool edge = y == 0 || x == 0 || y == S - 1 || x == S - 1;
+        u32 v = 0;
+        for (int s = 0; s < K; ++s) v |= (u32)((int)(cx.body[s * C + c] & VMASK) > cx.tclk[s]) << s;
+        v |= (u32)cx.hmap[c] << SNAP_OWNER_SHIFT;
+        v |= (u32)(cx.food[c] != 0) << 14;
+        v |= (u32)edge << 15;
+        cx.snap[c] = (unsigned short)v;
+    }
+    __syncthreads();
+    if (tid < K && hc >= 0) cx.hmap[hc] = 0;
+    float *obs_env = (float *)uniform64((long long)(obs + env * p.obs_elems));
+    for (int a = wave; a < K; a += nth >> 6) snap_emit_agent(cx, p, obs_env, cx.snap, a);
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void multi_step_wg_kernel(MultiArgs p)
+{
+    const int tid = (int)threadIdx.x, nth = (int)blockDim.x, wave = uniform(tid >> 6);
+    const long long env = xcd_block(blockIdx.x, gridDim.x);
+    if (env >= p.N) return; // the whole workgroup: the barriers below see every wave or none
+    const Ctx cx = make_ctx(p, 0);
+    const int C = cx.C, K = cx.K, lane = cx.lane;
+    float *foodp = p.foods + env * C, *headp = p.heads + env * K * C, *bodyp = p.bodies + env * K * C;
+    const bool rebuild = p.done_env != nullptr && p.done_env[env] != 0;
+    u64 fbits0 = 0;
+    if (!rebuild) fbits0 = wg_load_env(cx, foodp, headp, bodyp, tid, nth);
+    else if (tid < K) { cx.hcell[tid] = -1; cx.lmax[tid] = 0; cx.tclk[tid] = 0; }
+    __syncthreads();
+    Snake sn;
+    StepRes r;
+    int hc0 = -1;
+    if (wave == 0) step_middle(cx, p, env, rebuild, sn, r, hc0);
+    __syncthreads();
+    wg_store_env(cx, foodp, headp, bodyp, fbits0, rebuild, tid, nth);
+    if (wave == 0 && !rebuild && lane < K && sn.hc != hc0) { // the head cells that moved
+        float *hp = headp + (size_t)lane * C;
+        if (hc0 >= 0) hp[hc0] = 0.0f;
+        if (sn.hc >= 0) hp[sn.hc] = 1.0f;
+    }
+    if (p.obs_mode == WURM_OBS_NONE) return;
+    wg_observe_snap(cx, p, p.obs, env, tid, nth, wave);
+    if (p.obs_after == nullptr) return;
+    if (wave == 0) reset_for_obs_after(cx, p, env, sn, r);
+    __syncthreads();
+    wg_observe_snap(cx, p, p.obs_after, env, tid, nth, wave);
 }
 
 // ------------------------------------------------------------------------------------------------ reset
@@ -1427,6 +1576,12 @@ static int multi_launch(MKind kind, MultiArgs &p, void *stream)
         dim3 block2(128), grid2((unsigned)p.N);
         (void)hipGetLastError();
         hipLaunchKernelGGL(multi_rollout_kernel<true>, grid2, block2, (size_t)lds, (hipStream_t)stream, p);
+        return hipGetLastError() == hipSuccess ? WURM_OK : WURM_ERR_HIP;
+    }
+    if (kind == MK_STEP && lds * 4 > 65536 && (snap || p.obs_mode == WURM_OBS_NONE)) {
+        // an env too large for four per workgroup: one env per workgroup of four waves (multi_step_wg_kernel)
+        (void)hipGetLastError();
+        hipLaunchKernelGGL(multi_step_wg_kernel, dim3((unsigned)p.N), dim3(256), (size_t)lds, (hipStream_t)stream, p);
         return hipGetLastError() == hipSuccess ? WURM_OK : WURM_ERR_HIP;
     }
     while (wpb > 1 && lds * wpb > 65536) wpb >>= 1;
