@@ -513,10 +513,8 @@ class MultiSnake(object):
                                          _lib.ptr(err), _lib.i64(self.num_envs), self.num_snakes, self.size,
                                          _lib.stream_ptr(self.device.index))
         _lib.check(rc, 'MultiSnake.check_consistency')
-        from wurm_amd.utils import _raise_for
-        bits = (err.unsqueeze(-1) >> torch.arange(10, device=self.device, dtype=torch.int32)) & 1
-        present = bits.any(dim=0).cpu().tolist()
-        mask = sum((1 << i) for i, p in enumerate(present) if p)
+        from wurm_amd.utils import _raise_for, _or_reduce
+        mask = _or_reduce(err, 10)
         _raise_for(mask & 0x7f, one_food=False)
         if mask & 0x100:
             raise RuntimeError('An environment contains overlapping snakes')

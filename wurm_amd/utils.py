@@ -96,9 +96,12 @@ def env_consistency(envs: torch.Tensor):
     _raise_for(_or_reduce(consistency_mask(envs)), one_food=True)
 
 
-def _or_reduce(mask: torch.Tensor) -> int:
-    # OR over envs of an 8-bit mask: one sync, like the reference's torch.all(...) calls
-    bits = (mask.unsqueeze(-1) >> torch.arange(8, device=mask.device, dtype=torch.int32)) & 1
+def _or_reduce(mask: torch.Tensor, nbits: int = 8) -> int:
+    # OR over envs of a bit mask.  The usual answer is 0: one `any()` (one small kernel, one sync — the reference's
+    # checks sync several times) settles that; only a failing batch pays for the per-bit reduction
+    if not bool(mask.any()):
+        return 0
+    bits = (mask.unsqueeze(-1) >> torch.arange(nbits, device=mask.device, dtype=torch.int32)) & 1
     present = bits.any(dim=0).cpu().tolist()
     return sum((1 << i) for i, p in enumerate(present) if p)
 
