@@ -1325,6 +1325,82 @@ __global__ __launch_bounds__(256) void multi_observe_kernel(MultiArgs p)
     observe(cx, p, p.obs, env, sn);
 }
 
+// ---- reset and _observe of large envs, one env per workgroup (see multi_step_wg_kernel)
+__global__ __launch_bounds__(256) void multi_reset_wg_kernel(MultiArgs p)
+{
+    const int tid = (int)threadIdx.x, nth = (int)blockDim.x, wave = uniform(tid >> 6);
+    const long long env = xcd_block(blockIdx.x, gridDim.x);
+    if (env >= p.N) return;
+    const Ctx cx = make_ctx(p, 0);
+    const int C = cx.C, K = cx.K, lane = cx.lane;
+    const bool snake = wave == 0 && lane < K;
+    const u64 env_id = (u64)(p.env_offset + env);
+    const long long agent = env * K + lane;
+    float *foodp = p.foods + env * C, *headp = p.heads + env * K * C, *bodyp = p.bodies + env * K * C;
+    const bool rebuild = p.done_env[env] != 0;
+    const bool want_obs = p.obs_mode != WURM_OBS_NONE;
+    // every thread works out whether a snake is (still) dead: the workgroup decides together whether there is work
+    bool any_dead = false;
+    if (!rebuild)
+        for (int sidx = 0; sidx < K; ++sidx) any_dead |= p.dones[env * K + sidx] != 0;
+    const bool respawn = p.cfg.respawn_any && any_dead;
+    Snake sn;
+    sn.hc = -1;
+    sn.L = 0;
+    sn.done = snake ? p.dones[agent] != 0 : false;
+    if (rebuild) sn.done = false; // :798
+    sn.orient = 0;
+    sn.boosted = false;
+    if (wave == 0) {
+        load_colour(p, agent, snake && (want_obs || p.cfg.colour_random), sn);
+        if (snake && reroll_colour(p, agent, sn.done, env_id, p.call, 0, sn)) {
+            p.colours[agent * 3] = sn.col[0];
+            p.colours[agent * 3 + 1] = sn.col[1];
+            p.colours[agent * 3 + 2] = sn.col[2];
+        }
+    }
+    if (!rebuild && !respawn && !want_obs) return;
+    u64 fbits0 = 0;
+    if (!rebuild) fbits0 = wg_load_env(cx, foodp, headp, bodyp, tid, nth);
+    else if (tid < K) { cx.hcell[tid] = -1; cx.lmax[tid] = 0; cx.tclk[tid] = 0; }
+    __syncthreads();
+    int hc0 = -1;
+    if (wave == 0) {
+        if (!rebuild) {
+            sn.hc = snake ? cx.hcell[lane] : -1;
+            sn.L = snake ? cx.lmax[lane] : 0;
+            hc0 = sn.hc;
+        }
+        bool orient_dirty = false;
+        multi_reset_grid(cx, p, env, env_id, p.call, rebuild, respawn, sn, orient_dirty, 0, 0);
+        if (snake) {
+            if (rebuild || respawn) p.dones[agent] = (uint8_t)sn.done;
+            if (orient_dirty) p.orientations[agent] = sn.orient;
+        }
+    }
+    __syncthreads();
+    if (rebuild || respawn) {
+        wg_store_env(cx, foodp, headp, bodyp, fbits0, rebuild, tid, nth);
+        if (snake && !rebuild && sn.hc != hc0) {
+            float *hp = headp + (size_t)lane * C;
+            if (hc0 >= 0) hp[hc0] = 0.0f;
+            if (sn.hc >= 0) hp[sn.hc] = 1.0f;
+        }
+    }
+    if (want_obs) wg_observe_snap(cx, p, p.obs, env, tid, nth, wave);
+}
+
+__global__ __launch_bounds__(256) void multi_observe_wg_kernel(MultiArgs p)
+{
+    const int tid = (int)threadIdx.x, nth = (int)blockDim.x, wave = uniform(tid >> 6);
+    const long long env = xcd_block(blockIdx.x, gridDim.x);
+    if (env >= p.N) return;
+    const Ctx cx = make_ctx(p, 0);
+    wg_load_env(cx, p.foods + env * cx.C, p.heads + env * cx.K * cx.C, p.bodies + env * cx.K * cx.C, tid, nth);
+    __syncthreads();
+    wg_observe_snap(cx, p, p.obs, env, tid, nth, wave);
+}
+
 // ------------------------------------------------------------------------------------------------ rollout
 
 // T fused iterations of the caller loop of experiments/speeds.py:30-37 / tests/test_multi_snake_env.py:78-89:
@@ -1578,10 +1654,14 @@ static int multi_launch(MKind kind, MultiArgs &p, void *stream)
         hipLaunchKernelGGL(multi_rollout_kernel<true>, grid2, block2, (size_t)lds, (hipStream_t)stream, p);
         return hipGetLastError() == hipSuccess ? WURM_OK : WURM_ERR_HIP;
     }
-    if (kind == MK_STEP && lds * 4 > 65536 && (snap || p.obs_mode == WURM_OBS_NONE)) {
+    if ((kind == MK_STEP || kind == MK_RESET || (kind == MK_OBSERVE && snap)) && lds * 4 > 65536 &&
+        (snap || p.obs_mode == WURM_OBS_NONE)) {
         // an env too large for four per workgroup: one env per workgroup of four waves (multi_step_wg_kernel)
         (void)hipGetLastError();
-        hipLaunchKernelGGL(multi_step_wg_kernel, dim3((unsigned)p.N), dim3(256), (size_t)lds, (hipStream_t)stream, p);
+        const dim3 g((unsigned)p.N), b(256);
+        if (kind == MK_STEP) hipLaunchKernelGGL(multi_step_wg_kernel, g, b, (size_t)lds, (hipStream_t)stream, p);
+        else if (kind == MK_RESET) hipLaunchKernelGGL(multi_reset_wg_kernel, g, b, (size_t)lds, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL(multi_observe_wg_kernel, g, b, (size_t)lds, (hipStream_t)stream, p);
         return hipGetLastError() == hipSuccess ? WURM_OK : WURM_ERR_HIP;
     }
     while (wpb > 1 && lds * wpb > 65536) wpb >>= 1;
