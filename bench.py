@@ -404,6 +404,18 @@ def extra_measurements(device):
     per_call_case('per_call_api_cfg3_65536', SingleSnake(N, SIZE, observation_mode=OBS_MODE, device=device, seed=0),
                   lambda t: acts[t], lambda d: d, T,
                   'BASELINE configs[2] whole on one GPU through `env.step(a); env.reset(d, return_observations=False)`')
+    N, T = 8192, 200
+    acts = torch.randint(4, (T + 10, N), device=device, dtype=torch.int64)
+    per_call_case('per_call_api_cfg5_8192x36_default', SingleSnake(N, 36, observation_mode='default', device=device, seed=0),
+                  lambda t: acts[t], lambda d: d, T,
+                  'BASELINE configs[4] through `env.step(a); env.reset(d, return_observations=False)`')
+    from wurm_amd.envs import SimpleGridworld
+    N, T = 64, 2000
+    acts = torch.randint(4, (T + 10, N), device=device, dtype=torch.int64)
+    per_call_case('per_call_api_cfg1_gridworld_64x9',
+                  SimpleGridworld(N, 9, start_location=(4, 4), observation_mode='default', device=device, seed=0),
+                  lambda t: acts[t], lambda d: d, T,
+                  'BASELINE configs[0] (SimpleGridworld 64 x 9 x 9, default observation) on the GPU, same loop')
     N, K, T = 4096, 4, 100
     acts = torch.randint(8, (T + 10, K, N), device=device, dtype=torch.int64)
     keys = [f'agent_{i}' for i in range(K)]

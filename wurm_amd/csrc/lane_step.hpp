@@ -30,7 +30,6 @@ struct LaneArgs {
 };
 
 constexpr int LANE_VS = 132;  // bytes per env of the value -> cell table (33 dwords: lanes fall on distinct banks)
-constexpr int LANE_LOADS = 11; // (env, cell) pairs = 3 loads each in flight per lane in the cooperative read
 
 // per-wave LDS layout (bytes) for EPW envs per wave
 template <int EPW>
@@ -161,6 +160,7 @@ __global__ __launch_bounds__(256) void lane_step_kernel(LaneArgs a)
     wave_lds_sync();
 
     // ---- cooperative read: lanes = (env, cell) pairs of the block, three dwords each (food, head, body)
+    constexpr int LANE_LOADS = EPW >= 16 ? 11 : 8; // pairs (= 3 loads each) in flight per lane: EPW * C / 64 pairs in all
     {
         const char *base = (const char *)(p.envs + env0 * C3);
         const int pairs = nenv * C;
