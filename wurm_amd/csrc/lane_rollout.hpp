@@ -1,0 +1,556 @@
+// lane_rollout.hpp — the fused rollout (T iterations of `step(a[t]); reset(done)`) for LARGE batches of 9 x 9 SingleSnake
+// envs: ONE ENV PER LANE.
+//
+// rollout_s9_kernel (one env per wave) spends a whole wave's 30 SALU + 28 VALU + 3 stores on every env-step; with 8 192 or
+// 65 536 envs resident it is bound by instruction issue at 0.40-0.44 of the HBM peak although it moves no byte twice
+// (profiles/r02_cfg2_rollout_instmix_pmc.json).  Here a wave owns EPW consecutive envs (EPW = 4 ... 64) and
+// works on CHUNKS of TC = 64 / EPW steps, so that every lane is one (step, env) PAIR of the chunk wherever the work is
+// not inherently serial:
+//   (1) pair lanes: the action of (t, env) -> sanitise inputs; both Philox blocks of (t, env) — the food draw and the
+//       complete would-be reset, in closed form as in rollout_s9_kernel — into an LDS record;
+//   (2) env lanes (lanes 0 .. EPW-1), TC steps one after another: the transition of single_snake.py:197-304 on per-lane
+//       state — a 64-bit occupancy mask over cell codes 8 * row + column, the body as a QUEUE OF MOVES (2 bits per
+//       segment, 96 bits: the tail cell is found by popping the oldest move, so "every body cell decays" costs nothing per
+//       cell), head / tail codes, length, orientation, food code; food respawn = n-th set bit of `interior & ~occupied`;
+//       reset = unpacking the precomputed draw.  Each step leaves a 12-byte record of the stepped (pre-reset) state;
+//   (3) pair lanes: record -> the 5 x 5 window of the occupancy mask around the head (one 64-bit shift), window planes
+//       "value is 1" / "value is 127/255" for the three channels, compacted to 75 bits in the crop's own (c, y, x) order
+//       and OR-ed into the chunk's flat bit string in LDS; the per-step outputs (sanitised action, reward, done and its
+//       two causes) go out as coalesced stores;
+//   (4) all lanes, 19 iterations per chunk: 16-byte group j of the chunk's crops (EPW * 300 contiguous bytes per step) =
+//       one aligned nibble of each flat bit string -> one 16-byte read of a 256-entry table of float4 -> one
+//       global_store_dwordx4, 1 KB per wave instruction, no address arithmetic.
+// The state is read once (cooperatively: three coalesced dword loads per (env, cell) pair, non-zero elements scattered into
+// a per-env value -> cell table) and written once per launch.
+// Domain: S = 9, observation 'partial_2' or none; snakes whose body values are exactly 1..L once each on edge-adjacent
+// interior cells with the head on L and at most one food on a free interior cell (closed under step + reset).  Any other
+// env is left alone and rolled out by rollout_generic — the one-env-per-wave code — at the end of the same launch.
+// INJ: recorded random outcomes instead of Philox (tests/golden tapes through this kernel).
+#pragma once
+
+#include <type_traits>
+
+namespace wurm {
+
+constexpr int LR_C = 81, LR_C3 = 243, LR_E = 75; // cells, state floats and crop floats per env
+constexpr int LR_VS = 68;                        // bytes per env of the value -> cell table (17 dwords)
+constexpr int LR_BM = 84;                        // bytes per env of the body map written back (21 dwords)
+constexpr int LR_TAB = 4096 + 656;               // workgroup tables: 256 x float4, 81 x u64 window-interior masks
+
+// per-wave LDS (bytes)
+template <int EPW>
+struct LaneRollLds {
+    static constexpr int IO = 0;                           // uint4 [64]   step inputs of pair (s, e), then its state record
+    static constexpr int BITS = IO + 1024;                 // u32 [2][152] flat bit strings: value is 1 / value is 127/255
+    static constexpr int SCR = BITS + 2 * 608;             // start / end of launch scratch (and rollout_generic's class map)
+    static constexpr int VM = SCR;                         // u32 [2][EPW] bit set of body values present
+    static constexpr int STAT = VM + 8 * EPW;              // u32 [EPW]    count | heads << 8 | foods << 16 | bad << 24
+    static constexpr int HPOS = STAT + 4 * EPW;            // u8  [EPW]
+    static constexpr int FPOS = HPOS + EPW;                // u8  [EPW]
+    static constexpr int VALPOS = FPOS + EPW;              // u8  [EPW][LR_VS]
+    static constexpr int START_END = VALPOS + EPW * LR_VS;
+    static constexpr int BMAP = SCR;                       // u8  [EPW][LR_BM] body values by cell (end of launch)
+    static constexpr int HC = BMAP + EPW * LR_BM;          // s16 [EPW] head cell (-1: env not written back)
+    static constexpr int FC = HC + 2 * EPW;                // s16 [EPW] food cell (-1: none)
+    static constexpr int END_END = FC + 2 * EPW;
+    static constexpr int BYTES = ((START_END > END_END ? START_END : END_END) + 15) & ~15;
+    static_assert(BYTES - SCR >= 96, "scratch must hold rollout_generic's class map");
+};
+
+// row / column / code step of move index ai (= sanitised action & 3): -TAP[ai] (single_snake.py:225-233)
+__device__ __forceinline__ int lr_dcode(int ai) { return (int)(signed char)(0x01F8FF08u >> (8 * ai)); } // +8, -1, -8, +1
+__device__ __forceinline__ int lr_dy(int ai) { return (int)(signed char)(0x00FF0001u >> (8 * ai)); }    // +1, 0, -1, 0
+__device__ __forceinline__ int lr_dx(int ai) { return (int)(signed char)(0x0100FF00u >> (8 * ai)); }    // 0, -1, 0, +1
+
+// rows of 5 bits at byte stride (window layout, bit 8 i + j) -> 25 contiguous bits (bit 5 i + j)
+__device__ __forceinline__ u32 lr_compact(u32 lo, u32 hi)
+{
+    return (lo & 31u) | ((lo >> 3) & (31u << 5)) | ((lo >> 6) & (31u << 10)) | ((lo >> 9) & (31u << 15)) | ((hi & 31u) << 20);
+}
+
+// Per-lane state of one env (plain scalars, passed by reference — kept out of a struct: the compiler turns a select
+// between adjacent struct members into an indexed load and then keeps the whole struct in scratch): occ = occupancy over
+// cell codes 8 * row + column, q0..q2 = the body as a queue of moves (newest in bits 0-1 of q0), c / tc = head / tail codes,
+// L = length, o = orientation, food = food code (-1: none), act = the env is in the kernel's domain.
+constexpr u64 LR_RING = 0x01010101010101FFull; // codes of the border ring, modulo 64 (row 0 / 8: 0..8, columns 0 / 8: 8 r)
+constexpr u64 LR_INTERIOR = ~LR_RING;          // codes 8 r + c, r, c in 1..7
+
+// One transition (single_snake.py:197-304) and, for a finished env, the reset that follows it (:322-387).
+// in:  x = action bits (the action if it is 0..3 else 7 | (action % 4 & 7) << 3), y = would-be reset, z = food word;
+// out: x, y = occupancy of the stepped state, z = head code before the move | sanitised action << 8,
+//      w = food code + 1 | ate << 8 | self collision << 9 | edge collision << 10 | valid << 15
+template <bool INJ>
+__device__ __forceinline__ uint4 lr_transition(u64 &occ, u32 &q0, u32 &q1, u32 &q2, int &c, int &tc, int &L, int &o, int &food,
+                                               const bool act, const uint4 &cur)
+{
+    u32 rz = 0, rw = 0;
+    u64 occ_rec = 0;
+    if (act) {
+        const int a_small = (int)(cur.x & 7u), a_mod = ((int)(cur.x << 26)) >> 29;
+        const int a_out = o == a_small ? (o ^ 2) : a_mod;        // :221-222
+        const int ai = a_out & 3;
+        const int cn = c + lr_dcode(ai), cb = cn & 63;               // :225-233
+        const bool eat = cn == food;                                 // :242
+        const int pos = 2 * L - 4;                                   // the oldest move
+        const u32 qs = pos < 32 ? q0 : (pos < 64 ? q1 : q2);
+        const int m = (int)((qs >> (pos & 31)) & 3u);
+        const u64 occ_d = eat ? occ : occ & ~(1ull << tc);     // :246-249 (only the tail cell expires)
+        tc = eat ? tc : tc + lr_dcode(m);
+        const u32 selfc = (u32)(occ_d >> cb) & 1u;                      // :252
+        const u32 edge = (u32)(LR_RING >> cb) & 1u;                     // :290-295
+        q2 = (q2 << 2) | (q1 >> 30); q1 = (q1 << 2) | (q0 >> 30); q0 = (q0 << 2) | (u32)ai;
+        occ = occ_d | (1ull << cb);                                  // :258-262
+        L += eat ? 1 : 0;
+        const int c_prev = c;
+        c = cn;
+        o = ai ^ 2;
+        if (eat) {                                                      // :270-282
+            if constexpr (INJ) {
+                food = (int)cur.z - 1;
+            } else {
+                const u64 fr = LR_INTERIOR & ~occ;
+                const int n_free = __popcll(fr);
+                food = n_free ? nth_bit64(fr, (int)mulhi_range(cur.z, (u32)n_free)) : -1;
+            }
+        }
+        occ_rec = occ;
+        rz = (u32)c_prev | (((u32)a_out & 0xffu) << 8);
+        rw = (u32)(food + 1) | ((u32)eat << 8) | (selfc << 9) | (edge << 10) | 0x8000u;
+        if (selfc | edge) {                                             // :322-387
+            const u32 r = cur.y;
+            const int hc = (int)(r & 127u), sc = (int)((r >> 7) & 127u), d = (int)((r >> 21) & 3u);
+            tc = (int)((r >> 14) & 127u);
+            c = hc; o = d; L = 3;
+            food = (int)((r >> 23) & 127u) - 1;
+            occ = (1ull << hc) | (1ull << sc) | (1ull << tc);
+            q0 = (u32)((d ^ 2) * 5); q1 = 0; q2 = 0;
+        }
+    }
+    return make_uint4((u32)occ_rec, (u32)(occ_rec >> 32), rz, rw);
+}
+
+// an env outside the domain: the one-env-per-wave rollout, whole wave
+template <int OBSK, bool INJ>
+__device__ __forceinline__ void lane_rollout_fallback(const StepArgs &p, long long env, signed char *lds)
+{
+    const Geo g = make_geo<2>(9);
+    float *envp = p.envs + env * LR_C3;
+    Env<2> e;
+    load_state<2, true>(envp, g, e);
+    rollout_generic<2, true, OBSK, INJ>(p, env, envp, g, e, lds);
+}
+
+template <int EPW, int OBSK, bool INJ>
+__global__ __launch_bounds__(256) void lane_rollout_kernel(StepArgs p)
+{
+    typedef LaneRollLds<EPW> Lds;
+    static_assert(EPW == 4 || EPW == 8 || EPW == 16 || EPW == 32 || EPW == 64, "envs per wave");
+    static_assert(OBSK == WURM_OBS_PARTIAL || OBSK == WURM_OBS_NONE, "lane rollout: partial_2 or no observation");
+    constexpr int TC = 64 / EPW;                  // steps per chunk
+    constexpr int LOG_EPW = EPW == 4 ? 2 : EPW == 8 ? 3 : EPW == 16 ? 4 : EPW == 32 ? 5 : 6;
+    constexpr int GS = EPW * LR_E / 4;            // 16-byte groups per step of the wave's crops
+    constexpr int SUPER = 16;                     // chunks per batch of action loads
+    constexpr int S = 9;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lr_lds[];
+    const int wave = uniform((int)(threadIdx.x >> 6)), wpb = (int)(blockDim.x >> 6), lane = (int)(threadIdx.x & 63u);
+
+    // ---- workgroup tables
+    float4 *tab = (float4 *)lr_lds;               // nibble pair -> four floats
+    u64 *wint = (u64 *)(lr_lds + 4096);           // head (row, column) -> window cells that lie inside the border ring
+    for (int i = (int)threadIdx.x; i < 256; i += (int)blockDim.x) {
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = ((i >> j) & 1) ? 1.0f : ((i >> (4 + j)) & 1) ? 127.0f / 255.0f : 0.0f;
+        tab[i] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+    for (int i = (int)threadIdx.x; i < LR_C; i += (int)blockDim.x) {
+        const int hy = i / S, hx = i - hy * S;
+        u64 m = 0;
+        for (int wy = 0; wy < 5; ++wy)
+            for (int wx = 0; wx < 5; ++wx)
+                if ((unsigned)(hy - 2 + wy - 1) < 7u && (unsigned)(hx - 2 + wx - 1) < 7u) m |= 1ull << (8 * wy + wx);
+        wint[i] = m;
+    }
+    __syncthreads();
+
+    const long long env0 = (xcd_block(blockIdx.x, gridDim.x) * wpb + wave) * EPW;
+    if (env0 >= p.N) return;
+    unsigned char *lds = lr_lds + LR_TAB + wave * Lds::BYTES;
+    const int nenv = (int)min((long long)EPW, p.N - env0);
+    const bool mine = lane < nenv;                // env lanes: lane e owns env0 + e
+    const int ps = lane >> LOG_EPW, pe = lane & (EPW - 1); // pair lanes: step ps of the chunk, env env0 + pe
+
+    // ---- cooperative read of the state: lanes = (env, cell) pairs of the block, three dwords each (food, head, body)
+    u32 *vm = (u32 *)(lds + Lds::VM), *stat = (u32 *)(lds + Lds::STAT);
+    unsigned char *hpos = lds + Lds::HPOS, *fpos = lds + Lds::FPOS, *valpos = lds + Lds::VALPOS;
+    if (lane < EPW) { vm[lane] = 0; vm[EPW + lane] = 0; stat[lane] = 0; }
+    wave_lds_sync();
+    {
+        constexpr int LOADS = 9;
+        const char *base = (const char *)(p.envs + env0 * LR_C3);
+        const int pairs = nenv * LR_C;
+        int e = 0, cell = lane, idx = lane;
+        unsigned off = 4u * (unsigned)lane;
+        for (int i0 = 0; i0 < pairs; i0 += 64 * LOADS) {
+            float f[LOADS], h[LOADS], b[LOADS];
+            int es[LOADS], cs[LOADS];
+#pragma unroll
+            for (int j = 0; j < LOADS; ++j) {
+                es[j] = idx < pairs ? e : -1;
+                cs[j] = cell;
+                const char *q = base + (idx < pairs ? off : 0u);
+                f[j] = *(const float *)q;
+                h[j] = *(const float *)(q + 4 * LR_C);
+                b[j] = *(const float *)(q + 8 * LR_C);
+                idx += 64; cell += 64; off += 256;
+                if (cell >= LR_C) { cell -= LR_C; ++e; off += 8 * LR_C; }
+            }
+#pragma unroll
+            for (int j = 0; j < LOADS; ++j) {
+                const int ej = es[j], cj = cs[j];
+                if (ej < 0) continue;
+                if (f[j] > 0.5f) { fpos[ej] = (unsigned char)cj; atomicAdd(&stat[ej], 1u << 16); }
+                if (h[j] > 0.5f) { hpos[ej] = (unsigned char)cj; atomicAdd(&stat[ej], 1u << 8); }
+                const int bi = __float2int_rn(b[j]);
+                if (bi > 0 && bi < 64) {
+                    valpos[ej * LR_VS + bi] = (unsigned char)cj;
+                    atomicOr(&vm[(bi >> 5) * EPW + ej], 1u << (bi & 31));
+                    atomicAdd(&stat[ej], 1u);
+                } else if (bi != 0) {
+                    atomicAdd(&stat[ej], 1u << 24);
+                }
+            }
+        }
+    }
+    wave_lds_sync();
+
+    // ---- env lanes: validation, and the state as occupancy mask + queue of moves
+    u64 occ = 0;
+    u32 q0 = 0, q1 = 0, q2 = 0;
+    int c = 0, tc = 0, L = 0, o = 0, food = -1;
+    bool act = false;
+    if (mine) {
+        const u32 st = stat[lane];
+        const int cnt = (int)(st & 0xffu), nhd = (int)((st >> 8) & 0xffu), nfd = (int)((st >> 16) & 0xffu);
+        const u64 vset = (u64)vm[lane] | ((u64)vm[EPW + lane] << 32);
+        L = vset ? 63 - __clzll((long long)vset) : 0;
+        act = (st >> 24) == 0 && nhd == 1 && nfd <= 1 && L >= 2 && cnt == L && vset == (2ull << L) - 2ull;
+        if (act) act = (int)valpos[lane * LR_VS + L] == (int)hpos[lane];
+        if (act && nfd) {
+            const int fc = fpos[lane], fy = fc / S, fx = fc - fy * S;
+            act = (unsigned)(fy - 1) < 7u && (unsigned)(fx - 1) < 7u;
+            food = fy * 8 + fx;
+        }
+    }
+    {
+        int prev = 0;
+        for (int v = 1; ballot(act && v <= L) != 0; ++v) {
+            if (act && v <= L) {
+                const int cell = valpos[lane * LR_VS + v], y = cell / S, x = cell - y * S;
+                const int code = y * 8 + x;
+                if (!((unsigned)(y - 1) < 7u && (unsigned)(x - 1) < 7u)) act = false;
+                occ |= 1ull << (code & 63);
+                if (v == 1) {
+                    tc = code;
+                } else {
+                    const int d = code - prev;
+                    const int m = d == 8 ? 0 : d == -1 ? 1 : d == -8 ? 2 : d == 1 ? 3 : -1;
+                    if (m < 0) act = false;
+                    q2 = (q2 << 2) | (q1 >> 30); q1 = (q1 << 2) | (q0 >> 30); q0 = (q0 << 2) | (u32)(m & 3);
+                }
+                prev = code;
+            }
+        }
+        c = prev;
+        o = (int)(q0 & 3u) ^ 2;                       // head = neck + TAP[o], the last move was -TAP[o ^ 2]
+        if (act && food >= 0 && ((occ >> food) & 1)) act = false;
+    }
+    const u64 odd = ballot(mine && !act);             // envs outside the domain: rollout_generic below
+    wave_lds_sync();
+
+    // ---- the chunks
+    uint4 *io = (uint4 *)(lds + Lds::IO);
+    u32 *bits = (u32 *)(lds + Lds::BITS);
+    const u64 env_id = (u64)(p.env_offset + env0 + pe); // of the pair lane
+    const bool pair_env = pe < nenv;
+    float *obs_c = p.obs + env0 * LR_E;               // crops of the chunk's first step, this wave's envs
+    const unsigned obs_step_bytes = (unsigned)(p.N * (LR_E * 4)); // (the launcher keeps TC * N * 300 below 2^32)
+
+    // Actions: one load per chunk and pair lane, SUPER chunks at a time and one batch AHEAD (loads and stores share vmcnt
+    // and retire in order: the wait for a batch issued a whole super-chunk earlier only drains the last few stores, and the
+    // chunk loop itself never waits on memory).  Unconditional loads (index clamped into the tape) so that all of a batch
+    // are in flight together.
+    const long long a_last = p.T * p.N - 1;
+    long long av[SUPER];
+    auto load_batch = [&](long long t_first) { // the dtype test outside the unrolled loads: SUPER loads back to back
+        if (p.act_dtype == WURM_ACT_I64) {
+#pragma unroll
+            for (int k = 0; k < SUPER; ++k)
+                av[k] = ((const long long *)p.actions)[min((t_first + (long long)k * TC + ps) * p.N + env0 + pe, a_last)];
+        } else {
+            int a32[SUPER];
+#pragma unroll
+            for (int k = 0; k < SUPER; ++k)
+                a32[k] = ((const int *)p.actions)[min((t_first + (long long)k * TC + ps) * p.N + env0 + pe, a_last)];
+#pragma unroll
+            for (int k = 0; k < SUPER; ++k) av[k] = (long long)a32[k];
+        }
+    };
+    load_batch(0);
+
+    for (long long T0 = 0; T0 < p.T; T0 += SUPER * TC) {
+        // 4 bits per action: the action if it is 0..3, else 8 | (action % 4 & 7) (single_snake.py:221-222 needs "equals the
+        // orientation" and the C remainder)
+        u64 apk = 0;
+#pragma unroll
+        for (int k = 0; k < SUPER; ++k) {
+            const long long a = av[k];
+            const u32 code = (a >= 0 && a < 4) ? (u32)a : (8u | ((u32)(int)(a % 4) & 7u));
+            apk |= (u64)code << (4 * k);
+        }
+        if (T0 + SUPER * TC < p.T) load_batch(T0 + SUPER * TC);
+
+        for (int k = 0; k < SUPER; ++k) {
+            const long long t0 = T0 + (long long)k * TC;
+            if (t0 >= p.T) break;
+            const int nt = (int)min((long long)TC, p.T - t0);
+            const long long t = t0 + ps;
+            const bool pv = pair_env && ps < nt;
+            const long long oi = t * p.N + env0 + pe;  // index of the pair's per-step outputs
+
+            // (1) pair lanes: step inputs
+            uint4 rec; // first the inputs of pair (ps, pe), then the record of its stepped state
+            {
+                const u32 acode = (u32)(apk >> (4 * k)) & 15u;
+                const u32 a_small = (acode & 8u) ? 7u : acode, a_mod = acode & 7u;
+                const u64 call = p.call + 2ull * (u64)t; // step t uses call0 + 2t, its reset call0 + 2t + 1
+                u32 rpack, fword;
+                if constexpr (INJ) {
+                    int sy = 4, sx = 4, d = 0, fc = -1, fe = -1;
+                    if (pv) {
+                        const int *ir = p.inject_reset + oi * 4;
+                        sy = ir[0]; sx = ir[1]; d = ir[2]; fc = ir[3];
+                        fe = p.inject_food[oi];
+                    }
+                    d &= 3;
+                    const int sc = sy * 8 + sx, dc = tap_y(d) * 8 + tap_x(d);
+                    const int fcy = max(fc, 0) / S, fey = max(fe, 0) / S;
+                    const int fcode = (fc >= 0 && fc < LR_C) ? fcy * 8 + (fc - fcy * S) : -1;
+                    const int ecode = (fe >= 0 && fe < LR_C) ? fey * 8 + (fe - fey * S) : -1;
+                    rpack = (u32)((sc + dc) | (sc << 7) | ((sc - dc) << 14) | (d << 21)) | ((u32)(fcode + 1) << 23);
+                    fword = (u32)(ecode + 1);
+                } else {
+                    const S9Reset r = s9_reset_draw(p.seed, call + 1ull, env_id);
+                    rpack = (u32)r.b | ((u32)(r.a & 3) << 21) | ((u32)((r.a >> 2) + 1) << 23);
+                    fword = rng_words(p.seed, call, env_id, RNG_FOOD, 0).w[0];
+                }
+                rec = make_uint4(a_small | (a_mod << 3), rpack, fword, 0u);
+            }
+
+            // (2) env lanes: TC transitions (single_snake.py:197-304, then the reset of :322-387 for a finished env).
+            // in: x = action bits, y = would-be reset, z = food word;  out: occupancy, head code before the move |
+            // sanitised action << 8, food code + 1 | ate << 8 | self collision << 9 | edge collision << 10 | valid << 15
+            if constexpr (EPW == 64) {
+                rec = lr_transition<INJ>(occ, q0, q1, q2, c, tc, L, o, food, act, rec);              // pair lane == env lane: the record never leaves its registers
+            } else {
+                io[lane] = rec;
+                wave_lds_sync();
+                if (lane < EPW) {
+                    uint4 in = io[lane];
+                    for (int s2 = 0; s2 < nt; ++s2) {
+                        const uint4 cur = in;
+                        if (s2 + 1 < nt) in = io[(s2 + 1) * EPW + lane];
+                        io[s2 * EPW + lane] = lr_transition<INJ>(occ, q0, q1, q2, c, tc, L, o, food, act, cur);
+                    }
+                }
+            }
+            if (OBSK == WURM_OBS_PARTIAL) { // clear the flat bit strings (the previous chunk's reads are done: LDS is in order)
+#pragma unroll
+                for (int i = lane; i < 2 * 152; i += 64) bits[i] = 0;
+            }
+            wave_lds_sync();
+            if constexpr (EPW != 64) rec = io[lane];
+
+            // (3) pair lanes: outputs of (t, env) and its crop as bit planes
+            {
+                const u32 rz = rec.z, rw = rec.w;
+                const bool valid = pv && (rw & 0x8000u) != 0;
+                if (valid) {
+                    store_action(p.actions, p.act_dtype, oi, (long long)(int)(signed char)(rz >> 8));
+                    p.reward[oi] = (rw & 0x100u) ? 1.0f : 0.0f;
+                    p.done[oi] = (uint8_t)((rw & 0x600u) != 0);
+                    p.selfc[oi] = (uint8_t)((rw >> 9) & 1u);
+                    p.edgec[oi] = (uint8_t)((rw >> 10) & 1u);
+                }
+                if (OBSK == WURM_OBS_PARTIAL && valid) {
+                    // crop of the stepped state (single_snake.py:166-193): a window cell that is off the grid or on the
+                    // ring is (0,0,0); food (1,0,0), head (0,1,0), body (0,127/255,0), background (1,1,1)
+                    const int cp = (int)(rz & 63u), ai = (int)((rz >> 8) & 3u);
+                    const int hy = (cp >> 3) + lr_dy(ai), hx = (cp & 7) + lr_dx(ai); // the head, also when it is on the ring
+                    const int sh = 8 * hy + hx - 18;              // window bit 8 i + j <-> code sh + 8 i + j
+                    const u64 oc = (u64)rec.x | ((u64)rec.y << 32);
+                    const u64 V = sh >= 0 ? oc >> sh : oc << (-sh);
+                    const u64 W = wint[hy * S + hx];
+                    const int fpos_w = (int)(rw & 127u) - 1 - sh;
+                    const u64 F = (rw & 127u) != 0 && (unsigned)fpos_w < 40u ? (1ull << fpos_w) & W : 0ull;
+                    const u64 R = W & ~V;                         // free or food: red
+                    const u64 B = R & ~F;                         // free: blue (and green)
+                    const u64 CENTRE = 1ull << 18;
+                    const u64 G1 = B | (W & CENTRE);              // green 1: free, or the head inside the ring
+                    const u64 GH = V & W & ~CENTRE;               // green 127/255: body
+                    const u32 r25 = lr_compact((u32)R, (u32)(R >> 32)), b25 = lr_compact((u32)B, (u32)(B >> 32));
+                    const u32 g25 = lr_compact((u32)G1, (u32)(G1 >> 32)), h25 = lr_compact((u32)GH, (u32)(GH >> 32));
+                    // 75 bits in (c, y, x) order, shifted to bit 75 * pair of the flat strings (dword w of "value is 1" at
+                    // bits[2 w], of "value is 127/255" at bits[2 w + 1]: one 8-byte read gets both in phase 4)
+                    const u32 d0 = r25 | (g25 << 25), d1 = (g25 >> 7) | (b25 << 18), d2 = b25 >> 14;
+                    const u32 e0 = h25 << 25, e1 = h25 >> 7;
+                    const int bit = LR_E * lane, w0 = bit >> 5, sb = bit & 31;
+                    const u64 x01 = ((u64)d0 << sb), x12 = (((u64)d2 << 32) | d1) << sb;
+                    const u64 y01 = ((u64)e0 << sb), y1 = ((u64)e1 << sb);
+                    u32 *P = bits + 2 * w0;
+                    atomicOr(&P[0], (u32)x01);
+                    atomicOr(&P[2], (u32)(x01 >> 32) | (u32)x12);
+                    atomicOr(&P[4], (u32)(x12 >> 32));
+                    atomicOr(&P[6], (u32)(((u64)d2 << sb) >> 32));
+                    atomicOr(&P[1], (u32)y01);
+                    atomicOr(&P[3], (u32)(y01 >> 32) | (u32)y1);
+                    atomicOr(&P[5], (u32)(y1 >> 32));
+                }
+            }
+
+            // (4) all lanes: the chunk's crops, 16 bytes per lane and instruction — staged so that the 19 reads of the bit
+            // strings, the 19 table reads and the 19 stores are each in flight together (a lone wave pays one LDS round
+            // trip per stage, not per group)
+            if (OBSK == WURM_OBS_PARTIAL) {
+                wave_lds_sync();
+                if (nenv == EPW && nt == TC) {
+                    const int shn = (lane & 7) * 4;
+                    const uint2 *b2 = (const uint2 *)bits + (lane >> 3);
+                    char *ob = (char *)obs_c;
+                    // one straight-line block (no per-group branch): the scheduler keeps the reads of the bit strings, the
+                    // table reads and the stores of several groups in flight (no local arrays: they would go to scratch)
+#pragma unroll
+                    for (int i = 0; i < 19; ++i) {
+                        const uint2 w = b2[8 * i];
+                        const float4 v = tab[((w.x >> shn) & 15u) | (((w.y >> shn) & 15u) << 4)];
+                        const int j = 64 * i + lane;               // group j = floats 4 j .. 4 j + 3 of the chunk
+                        const unsigned s = EPW == 64 ? 0u : ((unsigned)j * (unsigned)(((1 << 20) + GS - 1) / GS)) >> 20; // j / GS
+                        const unsigned off = s * obs_step_bytes + 16u * ((unsigned)j - s * (unsigned)GS);
+                        if (i < 18 || lane < 48) *(float4 *)(ob + off) = v; // 1200 groups
+                    }
+                } else { // the ragged last wave, the last chunk of a tape that is not a multiple of TC: float by float
+                    for (int f = lane; f < 64 * LR_E; f += 64) {
+                        const int pr = f / LR_E, k2 = f - pr * LR_E, s = pr >> LOG_EPW, e = pr & (EPW - 1);
+                        if (s < nt && e < nenv) {
+                            const u32 w1 = bits[2 * (f >> 5)], wh = bits[2 * (f >> 5) + 1];
+                            const float v = ((w1 >> (f & 31)) & 1u) ? 1.0f : ((wh >> (f & 31)) & 1u) ? 127.0f / 255.0f : 0.0f;
+                            obs_c[(long long)s * p.N * LR_E + e * LR_E + k2] = v;
+                        }
+                    }
+                }
+            }
+            obs_c += (long long)TC * p.N * LR_E;
+        }
+    }
+    wave_lds_sync();
+
+    // ---- write the state back: body values by cell from the queue, then the block's slabs with coalesced stores
+    {
+        unsigned char *bm = lds + Lds::BMAP;
+        short *hcs = (short *)(lds + Lds::HC), *fcs = (short *)(lds + Lds::FC);
+        for (int i = lane; i < EPW * LR_BM / 4; i += 64) ((u32 *)bm)[i] = 0;
+        wave_lds_sync();
+        if (lane < EPW) {
+            hcs[lane] = (short)(act ? (c >> 3) * S + (c & 7) : -1);
+            fcs[lane] = (short)(food >= 0 ? (food >> 3) * S + (food & 7) : -1);
+        }
+        {
+            int code = c;
+            u32 w0 = q0, w1 = q1, w2 = q2;
+            for (int v = L; ballot(act && v >= 1) != 0; --v) {
+                if (act && v >= 1) {
+                    bm[lane * LR_BM + (code >> 3) * S + (code & 7)] = (unsigned char)v;
+                    code -= lr_dcode((int)(w0 & 3u));
+                    w0 = (w0 >> 2) | (w1 << 30); w1 = (w1 >> 2) | (w2 << 30); w2 >>= 2;
+                }
+            }
+        }
+        wave_lds_sync();
+        float *sb = p.envs + env0 * LR_C3;
+        const int total = nenv * LR_C3;
+        for (int i = lane; i < total; i += 64) {
+            const int e = i / LR_C3, r = i - e * LR_C3, ch = r / LR_C, cell = r - ch * LR_C;
+            const int hc = hcs[e];
+            if (hc < 0) continue; // outside the domain: untouched
+            const float v = ch == 0 ? (cell == (int)fcs[e] ? 1.0f : 0.0f)
+                          : ch == 1 ? (cell == hc ? 1.0f : 0.0f) : (float)bm[e * LR_BM + cell];
+            sb[i] = v;
+        }
+    }
+
+    // ---- envs outside the domain: the one-env-per-wave code, whole wave per env (it reads and writes their state,
+    // action tape, outputs and crops itself; nothing above touched them except crop bytes, which it overwrites)
+    if (odd != 0) {
+        __threadfence();
+        wave_lds_sync();
+        for (u64 m = odd; m != 0; m &= m - 1)
+            lane_rollout_fallback<OBSK, INJ>(p, env0 + first_bit(m), (signed char *)(lds + Lds::SCR));
+    }
+}
+
+bool lane_rollout_eligible(const StepArgs &p)
+{
+    if (p.S != 9 || p.only_flagged) return false;
+    if (p.obs_mode != WURM_OBS_NONE && !(p.obs_mode == WURM_OBS_PARTIAL && p.obs_n == 2)) return false;
+    if ((p.inject_food == nullptr) != (p.inject_reset == nullptr)) return false;
+    return true;
+}
+
+// envs per wave: 0 = automatic.  Tests and the tuning sweep force it with WURM_LANE_ROLLOUT_EPW (read per launch).
+static int lane_rollout_epw(long long N)
+{
+    if (const char *e = getenv("WURM_LANE_ROLLOUT_EPW")) {
+        const int v = atoi(e);
+        if (v == 4 || v == 8 || v == 16 || v == 32 || v == 64) return v;
+    }
+    // measured (tools/tune_lane_rollout.py, profiles/r03_tune_lane_rollout.jsonl): 8 192 envs 8 per wave, 16 384 and 32 768: 16,
+    // 65 536: 16 or 32 (64 per wave = one wave per SIMD: nothing covers its LDS round trips)
+    return N >= 40960 ? 32 : N >= 12288 ? 16 : N >= 6144 ? 8 : 4;
+}
+
+// the kernel addresses the crops of a chunk (64 / epw steps) with 32-bit byte offsets
+static int lane_rollout_epw_checked(long long N)
+{
+    int epw = lane_rollout_epw(N);
+    while (epw < 64 && (64 / epw) * N * (LR_E * 4) >= (1ll << 32)) epw *= 2;
+    return epw;
+}
+
+template <int OBSK>
+static hipError_t launch_lane_rollout_obs(const StepArgs &p, hipStream_t stream)
+{
+    const bool inj = p.inject_food != nullptr;
+    const int epw = inj ? 16 : lane_rollout_epw_checked(p.N);
+    const long long waves = (p.N + epw - 1) / epw;
+    const int wpb = waves >= 2048 ? 4 : 1;
+    dim3 block(64 * wpb), grid((unsigned)((waves + wpb - 1) / wpb));
+    (void)hipGetLastError();
+    auto go = [&](auto kernel, int lds_per_wave) {
+        hipLaunchKernelGGL(kernel, grid, block, (size_t)(LR_TAB + lds_per_wave * wpb), stream, p);
+    };
+    if (inj) go(lane_rollout_kernel<16, OBSK, true>, LaneRollLds<16>::BYTES);
+    else if (epw == 4) go(lane_rollout_kernel<4, OBSK, false>, LaneRollLds<4>::BYTES);
+    else if (epw == 8) go(lane_rollout_kernel<8, OBSK, false>, LaneRollLds<8>::BYTES);
+    else if (epw == 16) go(lane_rollout_kernel<16, OBSK, false>, LaneRollLds<16>::BYTES);
+    else if (epw == 32) go(lane_rollout_kernel<32, OBSK, false>, LaneRollLds<32>::BYTES);
+    else go(lane_rollout_kernel<64, OBSK, false>, LaneRollLds<64>::BYTES);
+    return hipGetLastError();
+}
+
+hipError_t launch_lane_rollout(const StepArgs &p, hipStream_t stream)
+{
+    return p.obs_mode == WURM_OBS_NONE ? launch_lane_rollout_obs<WURM_OBS_NONE>(p, stream)
+                                       : launch_lane_rollout_obs<WURM_OBS_PARTIAL>(p, stream);
+}
+
+} // namespace wurm

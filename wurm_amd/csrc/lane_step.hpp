@@ -355,6 +355,7 @@ __global__ __launch_bounds__(256) void lane_step_kernel(LaneArgs a)
     }
 }
 
+#ifndef WURM_SINGLE_SNAKE_DEVICE_CODE_ONLY
 static bool lane_step_eligible(const StepArgs &p)
 {
     if (p.S < 9 || p.S * p.S > 128) return false;
@@ -395,5 +396,6 @@ static hipError_t launch_lane_step(const StepArgs &p, hipStream_t stream)
     else go(lane_step_kernel<16, 9>, lane_step_kernel<16, 10>, lane_step_kernel<16, 11>, 16, LaneLds<16>::BYTES);
     return hipGetLastError();
 }
+#endif // WURM_SINGLE_SNAKE_DEVICE_CODE_ONLY
 
 } // namespace wurm

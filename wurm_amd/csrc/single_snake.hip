@@ -1612,6 +1612,7 @@ __global__ __launch_bounds__(256) void orientations_kernel(const float *__restri
     if (g.lane == 0) out[env] = o;
 }
 
+#ifndef WURM_SINGLE_SNAKE_DEVICE_CODE_ONLY // lane_rollout.hip includes this file for the device code above only
 // ------------------------------------------------------------------------------------------------ host side
 
 enum Kind { K_STEP, K_RESET, K_OBSERVE, K_ROLLOUT, K_FUSED };
@@ -1674,6 +1675,11 @@ static hipError_t launch_one(Kind kind, const StepArgs &p, dim3 grid, dim3 block
             }
         }
         if constexpr (SNAKE && CPL == 2) {
+            // large batches of 9 x 9: one env per LANE (lane_rollout.hpp); envs outside its domain are rolled out by the
+            // one-env-per-wave code inside the same launch
+            // (threshold read per launch: a rollout launch is long, and the tests switch it with WURM_LANE_ROLLOUT_MIN_ENVS)
+            const char *lane_env = getenv("WURM_LANE_ROLLOUT_MIN_ENVS");
+            if (p.N >= (lane_env ? atoll(lane_env) : 6144ll) && lane_rollout_eligible(p)) return launch_lane_rollout(p, st);
             const bool rng_mode = p.inject_food == nullptr && p.inject_reset == nullptr;
             if (p.inject_food != nullptr && p.inject_reset != nullptr && p.S == 9 &&
                 ((p.obs_mode == WURM_OBS_PARTIAL && p.obs_n <= 3) || p.obs_mode == WURM_OBS_NONE)) {
@@ -2048,3 +2054,7 @@ int wurm_grid_rollout(float *envs, const void *actions, int actions_dtype, float
 }
 
 } // extern "C"
+
+#else
+} // namespace wurm
+#endif // WURM_SINGLE_SNAKE_DEVICE_CODE_ONLY

@@ -55,4 +55,9 @@ hipError_t launch_grid_rollout(const StepArgs &p, hipStream_t stream);
 bool grid_step_eligible(const StepArgs &p);
 hipError_t launch_grid_step(const StepArgs &p, hipStream_t stream);
 
+// one-env-per-LANE rollout for large batches of 9 x 9 SingleSnake (lane_rollout.hip / lane_rollout.hpp); envs outside its
+// domain are rolled out by the one-env-per-wave code inside the same launch
+bool lane_rollout_eligible(const StepArgs &p);
+hipError_t launch_lane_rollout(const StepArgs &p, hipStream_t stream);
+
 } // namespace wurm
