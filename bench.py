@@ -21,6 +21,10 @@ episode statistics.  `python bench.py --gpus N` with N > 1 STARTS ITS OWN N RANK
 line; when the driver has already started the ranks (WORLD_SIZE / RANK in the environment) this process is one of them.
   --workload cfg2 : 512 envs per GPU (weak scaling; the default and the headline)
   --workload cfg3 : BASELINE configs[2] — 65 536 envs in total, split 65 536/N per rank (strong scaling)
+Whatever the workload, the line also carries `cfg3_strong_scaling`: BASELINE configs[2] (65 536 envs split over the N
+ranks, the multi-GPU configuration north_star names) timed with the same barrier / max-over-ranks protocol right after
+the headline region — so that a `--gpus N` sweep of the default command measures the batch split, not only the
+communication-free weak scaling of 512 envs per GPU.
 """
 import argparse
 import json
@@ -37,7 +41,9 @@ if ROOT not in sys.path:
 SIZE = 9
 OBS_MODE = 'partial_2'
 OBS_ELEMS = 75
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s measured achievable
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+HBM_ACHIEVABLE_GBS = 6300.0  # what a float4 copy reaches on this part (same guide)
+LANE_ROLLOUT_MIN_ENVS = 6144  # from here on rollouts of 9 x 9 run one env per LANE (wurm_amd/csrc/lane_rollout.hpp)
 MAX_TAPE_BLOCKS = 160  # distinct (chunk, N) action blocks kept in HBM; longer runs cycle through them
 
 
@@ -229,21 +235,6 @@ def worker(args) -> int:
         scaling = 'strong'
         chunk = args.chunk or (64 if N > 16384 else 128)
 
-    blocks = min(W + K, MAX_TAPE_BLOCKS)
-    if args.dry_run:
-        env, tape = None, None
-    else:
-        from wurm_amd.envs import SingleSnake
-        env = SingleSnake(num_envs=N, size=SIZE, observation_mode=OBS_MODE, device=device, seed=0, env_offset=offset)
-        gen = torch.Generator(device=device).manual_seed(1000 + rank)
-        tape = torch.randint(4, (blocks, chunk, N), generator=gen, device=device, dtype=torch.int64)
-
-    def launch(i):
-        if args.dry_run:
-            time.sleep(0.001)
-            return None
-        return env.rollout(tape[i % blocks])
-
     def barrier():
         if distributed:
             dist.barrier()
@@ -252,40 +243,67 @@ def worker(args) -> int:
         if not args.dry_run:
             torch.cuda.synchronize()
 
-    for i in range(W):
-        launch(i)
-    sync()
-    barrier()
-    sync()
-    events = []
-    t0 = time.perf_counter()
-    for i in range(W, W + K):
+    def timed_region(N, offset, chunk, K, W):
+        """W untimed + exactly K timed rollout launches of (chunk, N) bracketed by barrier + synchronize on both sides;
+        returns (max-over-ranks seconds, env-steps of all ranks, HIP-event average launch seconds on this rank, blocks)"""
+        blocks = min(W + K, MAX_TAPE_BLOCKS)
         if args.dry_run:
-            launch(i)
-            continue
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        launch(i)
-        e1.record()
-        events.append((e0, e1))
-    sync()
-    barrier()
-    sync()
-    elapsed = time.perf_counter() - t0
+            env, tape = None, None
+        else:
+            from wurm_amd.envs import SingleSnake
+            env = SingleSnake(num_envs=N, size=SIZE, observation_mode=OBS_MODE, device=device, seed=0, env_offset=offset)
+            gen = torch.Generator(device=device).manual_seed(1000 + rank)
+            tape = torch.randint(4, (blocks, chunk, N), generator=gen, device=device, dtype=torch.int64)
 
-    t = torch.tensor([elapsed, float(N * chunk * K)], dtype=torch.float64, device=device)
-    if distributed:
-        dist.all_reduce(t[:1], op=dist.ReduceOp.MAX)
-        dist.all_reduce(t[1:], op=dist.ReduceOp.SUM)
-    elapsed, total_env_steps = float(t[0].item()), float(t[1].item())
+        def launch(i):
+            if args.dry_run:
+                time.sleep(0.001)
+                return None
+            return env.rollout(tape[i % blocks])
+
+        for i in range(W):
+            launch(i)
+        sync()
+        barrier()
+        sync()
+        events = []
+        t0 = time.perf_counter()
+        for i in range(W, W + K):
+            if args.dry_run:
+                launch(i)
+                continue
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            launch(i)
+            e1.record()
+            events.append((e0, e1))
+        sync()
+        barrier()
+        sync()
+        elapsed = time.perf_counter() - t0
+        t = torch.tensor([elapsed, float(N * chunk * K)], dtype=torch.float64, device=device)
+        if distributed:
+            dist.all_reduce(t[:1], op=dist.ReduceOp.MAX)
+            dist.all_reduce(t[1:], op=dist.ReduceOp.SUM)
+        avg = sum(e0.elapsed_time(e1) for e0, e1 in events) * 1e-3 / len(events) if events else float(t[0].item()) / K
+        del env, tape
+        return float(t[0].item()), float(t[1].item()), avg, blocks
+
+    elapsed, total_env_steps, avg_launch_s, blocks = timed_region(N, offset, chunk, K, W)
+
+    # BASELINE configs[2] split over the ranks, same protocol (see the module docstring)
+    g3 = 65536
+    off3, n3 = shard_range(g3, rank, n_gpus)
+    chunk3 = 64 if n3 > 16384 else 128
+    k3, w3 = (K, W) if args.workload == 'cfg3' else (min(K, 20), 3)
+    if args.workload == 'cfg3' and (args.num_envs in (None, g3)) and args.chunk in (None, chunk3):
+        el3, tot3, avg3 = elapsed, total_env_steps, avg_launch_s
+    else:
+        el3, tot3, avg3, _ = timed_region(n3, off3, chunk3, k3, w3)
 
     rc = 0
     if rank == 0:
         per = algorithmic_bytes_per_env_step(SIZE, OBS_ELEMS)
-        if events:
-            avg_launch_s = sum(e0.elapsed_time(e1) for e0, e1 in events) * 1e-3 / len(events)
-        else:
-            avg_launch_s = elapsed / K
         bytes_per_launch = per * N * chunk
         achieved = bytes_per_launch / avg_launch_s / 1e9
         traffic, frac_real = None, None
@@ -297,7 +315,10 @@ def worker(args) -> int:
                 traffic = None
         if traffic:
             frac_real = traffic / avg_launch_s / 1e9 / HBM_PEAK_GBS
-        kernel = 'wurm::rollout_s9_kernel<4> (9x9 SingleSnake, partial_n crop, RNG mode; one wave per env)'
+        lane = N >= LANE_ROLLOUT_MIN_ENVS
+        kernel = ('wurm::lane_rollout_kernel<EPW, partial> (9x9 SingleSnake, partial_2 crop, RNG mode; one env per LANE, '
+                  'wurm_amd/csrc/lane_rollout.hpp)') if lane else \
+            'wurm::rollout_s9_kernel<4> (9x9 SingleSnake, partial_n crop, RNG mode; one wave per env)'
         line = {
             'metric': 'env_steps_per_s', 'value': total_env_steps / elapsed, 'unit': 'env-steps/s',
             'n_gpus': n_gpus, 'steps': K, 'warmup': W, 'ms_per_step': elapsed / K * 1e3,
@@ -316,17 +337,29 @@ def worker(args) -> int:
                        'world_size': world, 'backend': (dist.get_backend() if distributed else None),
                        'state_dtype': 'fp32 NCHW (exact integers)',
                        'action_tape_blocks': blocks},
-            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+            # cfg2 (512 lone waves on 1024 SIMDs) is bound by how fast ONE wave issues instructions, not by HBM: `frac` is
+            # a statement about the SURVEY byte model of an unfused step / reset pair, `frac_real` about HBM utilisation
+            'roofline': {'bound': 'hbm' if lane else 'issue', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
+                         'peak_achievable': HBM_ACHIEVABLE_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'frac_real': frac_real,
                          'kernel': kernel, 'avg_launch_ms': avg_launch_s * 1e3,
                          'algorithmic_bytes_per_env_step': per, 'env_steps_per_launch': N * chunk,
-                         'limiter': 'instruction issue' if N <= 1024 else 'instruction issue / observation stores',
+                         'limiter': 'observation stores (HBM)' if lane else 'instruction issue of one wave per env',
                          'note': '`achieved` prices the launch at the SURVEY §8(d) bytes of an UNFUSED step/reset pair; '
                                  '`traffic` (rocprofv3 FETCH_SIZE + WRITE_SIZE per launch of this exact shape, '
                                  'profiles/hbm_traffic.json) and `frac_real` are what the fused kernel really moves — '
-                                 'far less, because the env state never leaves the registers between steps. 512 envs '
-                                 'are 512 lone waves on 1024 SIMDs: the kernel is bound by one wave\'s instruction '
-                                 'issue rate, not by HBM (DESIGN.md §4.4)'},
+                                 'far less, because the env state never leaves the chip between steps. ' +
+                                 ('Batches of 6 144 envs and more run one env per lane and are bound by the observation '
+                                  'store stream (DESIGN.md §4.9).' if lane else
+                                  '512 envs are 512 lone waves on 1024 SIMDs: the kernel is bound by one wave\'s '
+                                  'instruction issue rate, not by HBM (DESIGN.md §4.4).')},
+            'cfg3_strong_scaling': {
+                'value': tot3 / el3, 'unit': 'env-steps/s', 'scaling': 'strong', 'global_num_envs': g3,
+                'num_envs_per_gpu': n3, 'batch_steps_per_launch': chunk3, 'steps': k3, 'warmup': w3,
+                'ms_per_step': el3 / k3 * 1e3, 'avg_launch_ms': avg3 * 1e3,
+                'obs_and_outputs_GBs_this_rank': (4 * OBS_ELEMS + 23) * n3 * chunk3 / avg3 / 1e9,
+                'what': 'BASELINE configs[2]: SingleSnake 65 536 x 9 x 9 partial_2 split over the ranks (shard_range, no '
+                        'data-path collective), same barrier + max-over-ranks protocol as the headline'},
         }
         if args.dry_run:
             line['dry_run'] = True
@@ -368,7 +401,9 @@ def extra_measurements(device):
     N, T = 512, 4000
     env = SingleSnake(num_envs=N, size=SIZE, observation_mode=OBS_MODE, device=device, seed=0)
     actions = torch.randint(4, (T + 400, N), device=device, dtype=torch.int64)
-    for variant, kw in (('per_call_api_512', {'return_observations': False}), ('per_call_api_512_reset_obs', {})):
+    # `per_call_api_512` is the reference's own call form (SingleSnake.reset always returns its observation,
+    # single_snake.py:322-342; experiments/main.py:212-227 discards it); the keyword form is this build's extension
+    for variant, kw in (('per_call_api_512', {}), ('per_call_api_512_no_reset_obs', {'return_observations': False})):
         for t in range(400):
             _, _, d, _ = env.step(actions[t])
             env.reset(d, **kw)
@@ -385,10 +420,12 @@ def extra_measurements(device):
     del env, actions
 
     # (a') the same Python loop at BASELINE configs[2] whole (65 536 envs on one GPU: lane_step_kernel) and configs[3]
-    def per_call_case(key, env, step_args, reset_arg, T, what):
+    def per_call_case(key, env, step_args, reset_arg, T, what, reset_kw={'return_observations': False}, check=False):
         def it(t):
             out_ = env.step(step_args(t))
-            env.reset(reset_arg(out_[2]), return_observations=False)
+            env.reset(reset_arg(out_[2]), **reset_kw)
+            if check:
+                env.check_consistency()
         for t in range(10):
             it(t)
         torch.cuda.synchronize()
@@ -398,6 +435,15 @@ def extra_measurements(device):
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         out[key] = {'value': env.num_envs * T / dt, 'unit': 'env-steps/s', 'us_per_batch_step': dt / T * 1e6, 'what': what}
+        t = traffic_detail.get(key)
+        if t:  # rocprofv3 FETCH_SIZE + WRITE_SIZE of one iteration's launches (profiles/hbm_traffic.json)
+            out[key]['traffic_bytes_per_batch_step'] = t['total_bytes']
+            out[key]['frac_real'] = t['total_bytes'] / (dt / T) / 1e9 / HBM_PEAK_GBS
+
+    try:
+        traffic_detail = json.load(open(os.path.join(ROOT, 'profiles', 'hbm_traffic.json'))).get('detail', {})
+    except Exception:
+        traffic_detail = {}
 
     N, T = 65536, 200
     acts = torch.randint(4, (T + 10, N), device=device, dtype=torch.int64)
@@ -422,12 +468,30 @@ def extra_measurements(device):
     per_call_case('per_call_api_cfg4_4096x25_k4', MultiSnake(N, K, 25, device=device, seed=0),
                   lambda t: dict(zip(keys, acts[t].unbind(0))), lambda d: d['__all__'], T,
                   "BASELINE configs[3] through `env.step(actions); env.reset(dones['__all__'], return_observations=False)`")
-    del acts
+    # (a'') the MultiSnake variants the reference itself runs: tests/test_multi_snake_env.py:100-104 (training dynamics,
+    # `partial_5` crops; SURVEY §8(d) "additionally") and experiments/speeds.py:10-44 (10 agents on 36 x 36, respawn 'any',
+    # `step; reset(done['__all__']); check_consistency()` — the reference's own benchmark loop, reset observation included)
+    def cfg4prime():
+        return MultiSnake(4096, 4, 25, device=device, seed=0, respawn_mode='any', food_mode='random_rate',
+                          boost_cost_prob=0.25, observation_mode='partial_5', food_on_death_prob=0.33, food_rate=2.5e-4)
 
-    try:
-        traffic_detail = json.load(open(os.path.join(ROOT, 'profiles', 'hbm_traffic.json'))).get('detail', {})
-    except Exception:
-        traffic_detail = {}
+    def speeds_env():
+        return MultiSnake(4096, 10, 36, device=device, seed=0, boost=True, respawn_mode='any')
+    per_call_case('per_call_api_cfg4prime_4096x25_k4_partial5', cfg4prime(),
+                  lambda t: dict(zip(keys, acts[t].unbind(0))), lambda d: d['__all__'], T,
+                  "MultiSnake 4096x25x25 K=4 with the reference's training dynamics (tests/test_multi_snake_env.py:100-104: "
+                  "respawn 'any', random_rate food, partial_5), `env.step(a); env.reset(d['__all__'], return_observations=False)`")
+    N, K, T = 4096, 10, 30
+    acts = torch.randint(8, (T + 10, K, N), device=device, dtype=torch.int64)
+    keys10 = [f'agent_{i}' for i in range(K)]
+    per_call_case('per_call_api_speeds_4096x36_k10', speeds_env(),
+                  lambda t: dict(zip(keys10, acts[t].unbind(0))), lambda d: d['__all__'], T,
+                  "experiments/speeds.py shape (4096 x 36 x 36, 10 agents), `step; reset(d['__all__'], return_observations=False)`")
+    per_call_case('speeds_py_loop_4096x36_k10', speeds_env(),
+                  lambda t: dict(zip(keys10, acts[t].unbind(0))), lambda d: d['__all__'], T,
+                  "experiments/speeds.py:30-38 as written: `step(actions); reset(done['__all__']); check_consistency()` "
+                  '(the reset returns its 10 observations, the checker runs every step)', reset_kw={}, check=True)
+    del acts
 
     def rollout_case(key, make_env, shape_actions, A, chunk, reps, obs_bytes, what, traffic_key=None):
         env = make_env()
@@ -473,6 +537,14 @@ def extra_measurements(device):
                  'batch-step, fused rollout, 16 batch-steps per launch (30 000 B of observations per env-step; SURVEY byte '
                  'model of an unfused pair: 75 160 B; reference torch-CPU: 3 280 env-steps/s)',
                  traffic_key='multi_rollout_cfg4_4096x25_k4_full_chunk16')
+    rollout_case('multi_rollout_cfg4prime_4096x25_k4_partial5', cfg4prime, lambda c: (c, 4, 4096), 8, 16, 6, 12 * 4 * 11 * 11,
+                 "MultiSnake 4096x25x25 K=4, training dynamics (respawn 'any', random_rate food) and partial_5 crops "
+                 '(tests/test_multi_snake_env.py:100-104), fused rollout, 16 batch-steps per launch',
+                 traffic_key='multi_rollout_cfg4prime_4096x25_k4_partial5_chunk16')
+    rollout_case('multi_rollout_speeds_4096x36_k10', speeds_env, lambda c: (c, 10, 4096), 8, 4, 4, 12 * 10 * 36 * 36,
+                 "experiments/speeds.py shape: MultiSnake 4096x36x36, 10 agents, respawn 'any', 'full' observations "
+                 '(155 520 B per env-step), fused rollout, 4 batch-steps per launch',
+                 traffic_key='multi_rollout_speeds_4096x36_k10_chunk4')
     # (e) the acting loop with the policy inside the env kernel: MLP 75->64->64->{4,1} + sampling
     from wurm_amd.agents import FeedforwardAgent, pack_policy_params
     N, T, reps = 512, 256, 8

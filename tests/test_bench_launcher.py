@@ -30,12 +30,17 @@ def test_gpus_2_spawns_two_ranks():
     per_launch = d['config']['env_steps_per_launch_per_gpu']
     assert abs(d['value'] - 2 * 3 * per_launch / (d['ms_per_step'] * 1e-3 * 3)) / d['value'] < 1e-6
     assert 'cpu_baseline' not in d and 'extra' not in d
+    # BASELINE configs[2] split over the two ranks rides along with the weak-scaling headline
+    c3 = d['cfg3_strong_scaling']
+    assert c3['global_num_envs'] == 65536 and c3['num_envs_per_gpu'] == 32768 and c3['scaling'] == 'strong'
+    assert c3['value'] > 0 and c3['steps'] == 3
 
 
 def test_cfg3_is_split_over_the_ranks():
     d = _run('--gpus', '2', '--dry-run', '--steps', '2', '--warmup', '0', '--workload', 'cfg3')
     assert d['config']['global_num_envs'] == 65536 and d['config']['num_envs_per_gpu'] == 32768
     assert d['scaling'] == 'strong' and d['config']['baseline_config'] == 'BASELINE.json configs[2]'
+    assert abs(d['cfg3_strong_scaling']['value'] - d['value']) / d['value'] < 1e-9   # the same region, not timed twice
 
 
 def test_single_process_default_and_cpu_baseline_legs():

@@ -287,3 +287,101 @@ def test_gridworld_class_loop_equals_oracle_loop(lazy):
         if t % 9 == 0:
             replay._eq(env.envs.cpu().numpy(), ref, 'state', t)
     replay._eq(env.envs.cpu().numpy(), ref, 'final state', T)
+
+
+def test_alias_taken_before_the_deferred_reset_is_the_one_documented_deviation():
+    """DESIGN.md §5 deviation 9: a tensor alias of `env.envs` taken BEFORE `step(a); reset(d)` shows the un-reset state
+    until the next step or the next look at the attribute (which is what the reference's callers do:
+    experiments/main.py:215,273 re-read `env.envs`); with lazy_reset=False the alias is exact at once."""
+    import torch
+    from oracle import oracle
+    from wurm_amd.envs import SingleSnake
+    N, S, seed = 64, 9, 13
+    g = torch.Generator().manual_seed(3)
+    for lazy in (True, False):
+        env = SingleSnake(N, S, observation_mode='partial_2', device='cuda:0', seed=seed, lazy_reset=lazy)
+        ref = _oracle_loop_env(N, S, seed)
+        call = 1
+        for t in range(40):   # until some env has finished
+            a = torch.randint(4, (N,), generator=g)
+            alias = env.envs                                  # taken before the iteration
+            obs, r, d, info = env.step(a.cuda())
+            _, _, d_ref, _, _ = oracle.single_step(ref, a.numpy().copy(), 'partial_2', seed=seed, call=call)
+            pre_reset = ref.copy()
+            env.reset(d, return_observations=False)
+            oracle.single_reset(ref, d_ref, 'none', seed=seed, call=call + 1)
+            call += 2
+            if d_ref.any():
+                if lazy:   # the alias still shows the stepped, un-reset state ...
+                    replay._eq(alias.cpu().numpy(), pre_reset, 'alias before the flush', t)
+                replay._eq(env.envs.cpu().numpy(), ref, 'the attribute', t)   # ... the attribute never does ...
+                assert alias is env.envs
+                replay._eq(alias.cpu().numpy(), ref, 'alias after the flush', t)  # ... and reading it brings the alias up to date
+                break
+        else:
+            raise AssertionError('no env finished in 40 steps')
+
+
+def test_state_edited_between_step_and_reset_is_observed_by_the_reset():
+    """`step(a); env.envs[i] = ...; obs = env.reset(done)`: the observation the step launch pre-computed for the reset is
+    stale once the caller has been handed the state; the reset must observe the edited state, as the reference does."""
+    import torch
+    from oracle import oracle
+    from wurm_amd.envs import SingleSnake
+    N, S, seed, mode = 32, 9, 9, 'partial_2'
+    env = SingleSnake(N, S, observation_mode=mode, device='cuda:0', seed=seed)
+    ref = _oracle_loop_env(N, S, seed)
+    g = torch.Generator().manual_seed(8)
+    call = 1
+    for t in range(30):
+        a = torch.randint(4, (N,), generator=g)
+        obs, r, d, info = env.step(a.cuda())
+        _, _, d_ref, _, _ = oracle.single_step(ref, a.numpy().copy(), mode, seed=seed, call=call)
+        if t % 3 == 2:        # move env 0's food next to nothing in particular: any visible edit will do
+            e = env.envs
+            e[:, 0] = 0
+            e[:, 0, 1, 1] = 1
+            ref[:, 0] = 0
+            ref[:, 0, 1, 1] = 1
+        back = env.reset(d)
+        b_ref = oracle.single_reset(ref, d_ref, mode, seed=seed, call=call + 1)
+        call += 2
+        replay._eq(back.cpu().numpy(), b_ref, 'reset observation', t)
+    replay._eq(env.envs.cpu().numpy(), ref, 'final state', '-')
+
+
+def test_class_loop_under_inference_mode_and_with_awkward_action_tensors():
+    """torch.inference_mode() (no version counters: resets run eagerly), actions as a strided view / (N,1) / on the CPU:
+    the loop runs and equals the oracle's"""
+    import torch
+    from oracle import oracle
+    from wurm_amd.envs import SingleSnake
+    N, S, seed, mode = 48, 9, 4, 'partial_2'
+    env = SingleSnake(N, S, observation_mode=mode, device='cuda:0', seed=seed)
+    ref = _oracle_loop_env(N, S, seed)
+    g = torch.Generator().manual_seed(5)
+    call = 1
+    for t in range(60):
+        a = torch.randint(4, (N,), generator=g)
+        a_ref = a.numpy().copy()
+        kind = t % 4
+        ctx = torch.inference_mode() if t >= 30 else torch.no_grad()
+        with ctx:
+            if kind == 0:
+                a_in = a.cuda()
+            elif kind == 1:
+                a_in = torch.stack([a, a], dim=1).cuda()[:, 0]      # strided view
+            elif kind == 2:
+                a_in = a.cuda().view(N, 1)
+            else:
+                a_in = a.clone()                                      # CPU tensor
+            obs, r, d, info = env.step(a_in)
+            o_ref, r_ref, d_ref, _, _ = oracle.single_step(ref, a_ref, mode, seed=seed, call=call)
+            back = env.reset(d)
+            b_ref = oracle.single_reset(ref, d_ref, mode, seed=seed, call=call + 1)
+        call += 2
+        replay._eq(obs.cpu().numpy(), o_ref, 'obs', t)
+        replay._eq(a_in.cpu().numpy().reshape(N), a_ref, 'sanitised actions', t)
+        replay._eq(d.cpu().numpy()[:, 0], d_ref, 'done', t)
+        replay._eq(back.cpu().numpy(), b_ref, 'reset observation', t)
+    replay._eq(env.envs.cpu().numpy(), ref, 'final state', '-')

@@ -182,3 +182,15 @@ def test_full_size_rollout_equals_per_call_loop(hip):
         h2.single_reset(e2, d, 'none')
     _same(e1, e2, 'final state')
     _same(a1, a2, 'sanitised actions')
+
+
+def test_the_launch_bench_py_times_512x1024(hip):
+    """exactly the launch the driver's `python bench.py` times — rollout_s9_kernel<partial>, 512 envs x 1 024 batch-steps,
+    RNG mode, one wave per 64-thread workgroup — against the oracle on every output of every env-step"""
+    N, S, T = 512, 9, 1024
+    rng = np.random.RandomState(0)
+    o, h = OracleBackend(seed=0), hip(seed=0)
+    envs = _fresh(o, N, S)
+    o.call = h.call = 1
+    out = _compare_rollout(o, h, envs, rng.randint(0, 4, size=(T, N)).astype(np.int64), 'partial_2')
+    assert out['done'].sum() > 50000

@@ -185,3 +185,60 @@ def test_class_loop_with_reset_observations(cfg_name, mode, shape):
     _same(env.foods.cpu().numpy(), st['foods'], 'final foods')
     _same(env.heads.cpu().numpy(), st['heads'], 'final heads')
     _same(env.orientations.cpu().numpy(), st['orientations'], 'final orientations')
+
+
+def test_alias_taken_before_the_deferred_reset_is_the_one_documented_deviation():
+    """DESIGN.md §5 deviation 9 for MultiSnake: aliases of `foods / heads / bodies` taken before `step; reset(all_done,
+    return_observations=False)` show the un-reset state until the next step or the next look at an attribute."""
+    import torch
+    from wurm_amd.envs import MultiSnake
+    cfg = CFGS['default']
+    N, K, S, seed = 32, 2, 10, 17
+    env = MultiSnake(N, K, S, device='cuda:0', seed=seed, observation_mode='full')
+    o = OracleBackend(seed=seed)
+    st = _o.multi_empty_state(N, K, S)
+    st['colours'][...] = o.multi_colours(N, K, cfg['colour_mode'] == 'fixed', call=0)
+    o.call = 1
+    assert o.multi_reset(st, np.ones(N), cfg) == 0
+    g = torch.Generator().manual_seed(2)
+    for t in range(200):
+        a = torch.randint(8, (K, N), generator=g)
+        bodies_alias, foods_alias = env.bodies, env.foods           # taken before the iteration
+        ac = a.cuda()
+        _, _, dones, _ = env.step({f'agent_{i}': ac[i] for i in range(K)})
+        r = o.multi_step(st, a.numpy(), cfg, 'full')
+        pre = {k: st[k].copy() for k in ('bodies', 'foods')}
+        assert env.reset(dones['__all__'], return_observations=False) is None
+        o.multi_reset(st, r['all_done'], cfg)
+        if r['all_done'].any():
+            _same(bodies_alias.cpu().numpy(), pre['bodies'], 'alias before the flush: un-reset bodies')
+            _same(foods_alias.cpu().numpy(), pre['foods'], 'alias before the flush: un-reset foods')
+            _same(env.bodies.cpu().numpy(), st['bodies'], 'the attribute')
+            _same(bodies_alias.cpu().numpy(), st['bodies'], 'alias after the flush')
+            _same(foods_alias.cpu().numpy(), st['foods'], 'alias after the flush')
+            return
+    raise AssertionError('no env finished in 200 steps')
+
+
+def test_class_loop_under_inference_mode():
+    import torch
+    from wurm_amd.envs import MultiSnake
+    cfg = CFGS['default']
+    N, K, S, seed = 16, 2, 10, 23
+    env = MultiSnake(N, K, S, device='cuda:0', seed=seed, observation_mode='full')
+    o = OracleBackend(seed=seed)
+    st = _o.multi_empty_state(N, K, S)
+    st['colours'][...] = o.multi_colours(N, K, cfg['colour_mode'] == 'fixed', call=0)
+    o.call = 1
+    assert o.multi_reset(st, np.ones(N), cfg) == 0
+    g = torch.Generator().manual_seed(3)
+    with torch.inference_mode():
+        for t in range(40):
+            a = torch.randint(8, (K, N), generator=g)
+            ac = a.cuda()
+            obs, _, dones, _ = env.step({f'agent_{i}': ac[i] for i in range(K)})
+            r = o.multi_step(st, a.numpy(), cfg, 'full')
+            _same(obs['agent_0'].cpu().numpy(), r['obs'][0], f'obs t={t}')
+            env.reset(dones['__all__'], return_observations=bool(t % 2))
+            o.multi_reset(st, r['all_done'], cfg)
+    _same(env.bodies.cpu().numpy(), st['bodies'], 'final bodies')

@@ -24,34 +24,68 @@ class _Recorder(object):
         self.calls.append(('observe', dict(mode=m)))
         return 0
 
+    fail_next = False
+
     def step_slot(self, c_addr, sl_addr, slot, actions, dtype, call, pending, pre_call, want_after, stream):
+        if self.fail_next:
+            self.fail_next = False
+            return -3
         c = _lib.SingleCall.from_address(c_addr)
         self.calls.append(('step', dict(slot=slot, call=call, pending=bool(pending), pre_call=pre_call,
                                         want_after=bool(want_after), dtype=dtype, obs_mode=c.obs_mode, envs=c.envs)))
         return 0
 
 
-@pytest.fixture
-def env_and_log(monkeypatch):
+_STEP_SLOT_T = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
+                                ctypes.c_int, ctypes.c_uint64, ctypes.c_int, ctypes.c_uint64, ctypes.c_int, ctypes.c_void_p)
+
+
+class _CSlot(object):
+    """the recorder's step_slot behind a real C function pointer, as wurm_amd._fastcall.Stepper needs it"""
+
+    def __init__(self, rec):
+        self._cb = _STEP_SLOT_T(lambda c, sl, slot, a, dt, call, pend, pre, want, st: rec.step_slot(c, sl, slot, a, dt, call,
+                                                                                              pend, pre, want, st))
+        self.c_address = ctypes.cast(self._cb, ctypes.c_void_p).value
+
+    def __call__(self, *args):
+        return self._cb(*args)
+
+
+def _have_c_stepper():
+    try:
+        from wurm_amd import _fastcall
+        return hasattr(_fastcall, 'Stepper')
+    except ImportError:
+        return False
+
+
+@pytest.fixture(params=['python', 'c'])
+def env_and_log(monkeypatch, request):
+    """the env on CPU tensors over a recording stand-in of the library, once with the Python step machine (PyStepper) and
+    once with the C one (wurm_amd._fastcall.Stepper calling the recorder through a C function pointer)"""
+    if request.param == 'c' and not _have_c_stepper():
+        pytest.skip('wurm_amd/_fastcall is not built')
     rec = _Recorder()
+    slot = _CSlot(rec) if request.param == 'c' else rec.step_slot
     monkeypatch.setattr(_lib, 'lib', lambda: rec)
     monkeypatch.setattr(_lib, 'require_device', lambda d: torch.device('cpu'))
     monkeypatch.setattr(_lib, 'stream_ptr', lambda i=None: 0)
     monkeypatch.setattr(_lib, 'call', lambda idx, fn, *a: fn(*a))
     monkeypatch.setattr(_lib, 'accessors', lambda: ((lambda: -1), (lambda i: 0)))
-    monkeypatch.setattr(_lib, 'step_slot_fn', lambda name='wurm_single_step_slot': rec.step_slot)
+    monkeypatch.setattr(_lib, 'step_slot_fn', lambda name='wurm_single_step_slot': slot)
     from wurm_amd.envs import SingleSnake
+    from wurm_amd.envs._fast_step import PyStepper
     env = SingleSnake(num_envs=8, size=9, observation_mode='partial_2', device='cpu', seed=5)
-    env._dev_index_override = True
+    assert isinstance(env._fs, PyStepper) == (request.param == 'python')
     rec.calls.clear()
+    env._rec = rec
     return env, rec.calls
 
 
 def _step(env, a=None):
     a = torch.zeros(8, dtype=torch.int64) if a is None else a
-    out = env.step(a)
-    env._dev_index = -1  # CPU tensors report device -1
-    return out
+    return env.step(a)
 
 
 def test_reset_with_the_steps_own_done_is_deferred_into_the_next_step(env_and_log):
@@ -122,6 +156,68 @@ def test_lazy_reset_can_be_switched_off_and_assignment_drops_the_pending_reset(e
     _, _, d, _ = _step(env)
     env.reset(d, return_observations=False)
     assert log[-1][0] == 'reset'
+
+
+def test_an_edited_done_costs_one_eager_reset_not_the_rest_of_the_slab(env_and_log):
+    """the steps of a slab share one version counter: after an in-place edit the deferral resumes with the next step"""
+    env, log = env_and_log
+    _, _, d, _ = _step(env)
+    d[0] = True
+    env.reset(d, return_observations=False)                     # eager: the flags are no longer the kernel's own copy
+    _, _, d, _ = _step(env)
+    env.reset(d, return_observations=False)                     # deferred again
+    _step(env)
+    assert [c[0] for c in log] == ['step', 'reset', 'step', 'step'] and log[3][1]['pending']
+
+
+def test_step_and_reset_under_inference_mode(env_and_log):
+    """tensors allocated under torch.inference_mode() have no version counter: resets run eagerly, nothing raises"""
+    env, log = env_and_log
+    with torch.inference_mode():
+        for _ in range(3):
+            _, _, d, _ = _step(env)
+            assert env.reset(d) is not None
+    assert [c[0] for c in log] == ['step', 'reset'] * 3
+
+
+def test_editing_the_state_between_step_and_reset_drops_the_precomputed_observation(env_and_log):
+    env, log = env_and_log
+    _, _, d, _ = _step(env)
+    env.reset(d)                                                # asks for the reset observation: eager the first time
+    _, _, d, _ = _step(env)                                     # this launch pre-computes it ...
+    assert log[-1][1]['want_after']
+    env.envs[0, 0, 4, 4] = 1                                    # ... but the caller edits the state it was computed from
+    n = len(log)
+    assert env.reset(d) is not None
+    assert [c[0] for c in log[n:]] == ['reset'] and log[-1][1]['obs']   # observed after the edit, as the reference would
+
+
+def test_done_attribute_is_the_last_steps_flags_unless_assigned_since(env_and_log):
+    env, log = env_and_log
+    _, _, d, _ = _step(env)
+    assert env.done.shape == (8,) and env.done.data_ptr() == d.data_ptr()
+    mine = torch.ones(8, dtype=torch.bool)
+    env.done = mine
+    assert env.done is mine
+    env.reset()                                                 # uses the assigned tensor: eager
+    assert log[-1][0] == 'reset'
+    _, _, d2, _ = _step(env)
+    assert env.done.data_ptr() == d2.data_ptr()                 # a step overwrites the attribute, as in the reference
+
+
+def test_a_failed_launch_consumes_nothing(env_and_log):
+    env, log = env_and_log
+    _, _, d, _ = _step(env)
+    env.reset(d, return_observations=False)
+    call, slot = env._fs.call, env._fs.slot
+    c = _lib.SingleCall.from_address(ctypes.addressof(env._c))
+    envs_ptr = c.envs
+    env._rec.fail_next = True
+    with pytest.raises(Exception):
+        _step(env)
+    assert env._fs.pending and env._fs.call == call and env._fs.slot == slot and c.envs == envs_ptr
+    _step(env)                                                   # the postponed reset is still applied
+    assert log[-1][1]['pending']
 
 
 def test_argument_errors_match_the_reference(env_and_log):

@@ -96,7 +96,8 @@ class WurmHipError(RuntimeError):
 
 def build(force: bool = False) -> str:
     """Compiles wurm_amd/csrc/*.hip for gfx950 into wurm_amd/libwurm_hip.so (hipcc cross-compiles without a GPU)."""
-    cmd = ['make', '-j4', '-C', CSRC] + (['-B'] if force else [])
+    import sys
+    cmd = ['make', '-j4', '-C', CSRC, 'PYTHON=' + sys.executable] + (['-B'] if force else [])
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise WurmHipError('building libwurm_hip.so failed:\n' + r.stdout[-4000:] + r.stderr[-4000:])
@@ -152,20 +153,29 @@ def _declare_prototypes(l):
 _step_slot = {}
 
 
-def step_slot_fn(name: str = 'wurm_single_step_slot'):
-    """wurm_single_step_slot / wurm_grid_step_slot as the cheapest callable available: through the CPython shim
-    wurm_amd/_fastcall (built by `make`; ~1 us less host time per call than ctypes), else the ctypes function itself —
-    same arguments, same library, same kernels either way."""
-    fn = _step_slot.get(name)
-    if fn is None:
-        cfn = getattr(lib(), name)
+class _SlotFn(object):
+    """wurm_single_step_slot / wurm_grid_step_slot as a Python callable (through the CPython shim wurm_amd/_fastcall when
+    it is built, else ctypes) that also carries the C address of the entry point for wurm_amd._fastcall.Stepper."""
+
+    def __init__(self, cfn):
+        self.c_address = ctypes.cast(cfn, ctypes.c_void_p).value
         try:
             import functools
             from wurm_amd import _fastcall
-            fn = functools.partial(_fastcall.step_slot, ctypes.cast(cfn, ctypes.c_void_p).value)
+            self._call = functools.partial(_fastcall.step_slot, self.c_address)
         except ImportError:
-            fn = cfn
-        _step_slot[name] = fn
+            self._call = cfn
+
+    def __call__(self, *args):
+        return self._call(*args)
+
+
+def step_slot_fn(name: str = 'wurm_single_step_slot'):
+    """The per-step entry point `name` of libwurm_hip.so (see _SlotFn) — same arguments, same library, same kernels
+    whichever way it ends up being called."""
+    fn = _step_slot.get(name)
+    if fn is None:
+        fn = _step_slot[name] = _SlotFn(getattr(lib(), name))
     return fn
 
 

@@ -75,6 +75,260 @@ static PyObject *fast_multi_step(PyObject *self, PyObject *const *args, Py_ssize
     return PyLong_FromLong(rc);
 }
 
+/* ------------------------------------------------------------------------------------------------ Stepper
+ * The bodies of `env.step(actions)` and of the deferred `env.reset(done)` of SingleSnake / SimpleGridworld
+ * (wurm_amd/envs/_fast_step.py describes the protocol; PyStepper there is the same logic in Python and the specification
+ * of this type).  The loop being served is experiments/main.py:212-227 of the reference,
+ *     obs, reward, done, info = env.step(action); env.reset(done)
+ * which at 512 envs is bound by host time per iteration: here one iteration costs a handful of C-API calls on the
+ * action tensor, one launch, and two prebuilt objects handed back.
+ */
+#include <structmember.h>
+
+typedef struct {
+    PyObject_HEAD
+    step_slot_fn fn;
+    void *blk, *slabs;
+    long long slot, R, num_envs, dev_index, slab_version;
+    unsigned long long call, pend_call, steps;
+    char ok, pending, last_fresh, want_obs_after, lazy_ok;
+    PyObject *outs, *done2s, *obs_afters;         /* per slot of the current slab: output tuple, (N,1) done, reset obs */
+    PyObject *last_done2, *done_view, *obs_after; /* of the last step */
+    PyObject *get_device, *get_stream;            /* torch's current-device / raw-stream accessors */
+    PyObject *dt_i64, *dt_i32, *dt_i16;
+} Stepper;
+
+static PyObject *s_dtype, *s_data_ptr, *s_get_device, *s_dim, *s_is_contiguous, *s_version, *s_size, *s_zero;
+
+static void set_obj(PyObject **slot, PyObject *v)
+{
+    PyObject *old = *slot;
+    Py_INCREF(v);
+    *slot = v;
+    Py_XDECREF(old);
+}
+
+static int stepper_init(Stepper *self, PyObject *args, PyObject *kwds)
+{
+    (void)kwds;
+    PyObject *fn, *blk, *slabs, *gd, *gs, *d64, *d32, *d16;
+    if (!PyArg_ParseTuple(args, "OOOOOOOO", &fn, &blk, &slabs, &gd, &gs, &d64, &d32, &d16)) return -1;
+    self->fn = (step_slot_fn)PyLong_AsVoidPtr(fn);
+    self->blk = PyLong_AsVoidPtr(blk);
+    self->slabs = PyLong_AsVoidPtr(slabs);
+    if (PyErr_Occurred()) return -1;
+    if (self->fn == NULL) {
+        PyErr_SetString(PyExc_RuntimeError, "wurm_amd._fastcall.Stepper: null function address");
+        return -1;
+    }
+    set_obj(&self->get_device, gd); set_obj(&self->get_stream, gs);
+    set_obj(&self->dt_i64, d64); set_obj(&self->dt_i32, d32); set_obj(&self->dt_i16, d16);
+    set_obj(&self->outs, Py_None); set_obj(&self->done2s, Py_None); set_obj(&self->obs_afters, Py_None);
+    set_obj(&self->last_done2, Py_None); set_obj(&self->done_view, Py_None); set_obj(&self->obs_after, Py_None);
+    self->slot = self->R = 0;
+    self->slab_version = -1;
+    self->call = self->pend_call = self->steps = 0;
+    self->ok = self->pending = self->last_fresh = self->want_obs_after = self->lazy_ok = 0;
+    return 0;
+}
+
+static int stepper_traverse(Stepper *self, visitproc visit, void *arg)
+{
+    Py_VISIT(self->outs); Py_VISIT(self->done2s); Py_VISIT(self->obs_afters);
+    Py_VISIT(self->last_done2); Py_VISIT(self->done_view); Py_VISIT(self->obs_after);
+    Py_VISIT(self->get_device); Py_VISIT(self->get_stream);
+    Py_VISIT(self->dt_i64); Py_VISIT(self->dt_i32); Py_VISIT(self->dt_i16);
+    return 0;
+}
+
+static int stepper_clear(Stepper *self)
+{
+    Py_CLEAR(self->outs); Py_CLEAR(self->done2s); Py_CLEAR(self->obs_afters);
+    Py_CLEAR(self->last_done2); Py_CLEAR(self->done_view); Py_CLEAR(self->obs_after);
+    Py_CLEAR(self->get_device); Py_CLEAR(self->get_stream);
+    Py_CLEAR(self->dt_i64); Py_CLEAR(self->dt_i32); Py_CLEAR(self->dt_i16);
+    return 0;
+}
+
+static void stepper_dealloc(Stepper *self)
+{
+    PyObject_GC_UnTrack(self);
+    stepper_clear(self);
+    Py_TYPE(self)->tp_free((PyObject *)self);
+}
+
+/* result of a no-argument method as a C long; -2 with an exception set on failure (the methods used return >= -1) */
+static long method_long(PyObject *obj, PyObject *name)
+{
+    PyObject *r = PyObject_CallMethodNoArgs(obj, name);
+    if (!r) return -2;
+    long v = PyLong_Check(r) ? PyLong_AsLong(r) : (long)PyObject_IsTrue(r);
+    Py_DECREF(r);
+    return v;
+}
+
+/* step(actions) -> the prebuilt output tuple of this step;  None: the caller has to prepare something first (new slab,
+ * state tensor to re-validate, actions on another device / not a contiguous vector, another device current) and call
+ * again;  a non-zero int: the entry point's error code.  Argument errors are raised as the reference raises them
+ * (single_snake.py:198-203; int16 passes its check and fails in scatter_ at :229). */
+static PyObject *stepper_step(Stepper *self, PyObject *actions)
+{
+    PyObject *dt = PyObject_GetAttr(actions, s_dtype);
+    if (!dt) return NULL;
+    int code;
+    if (dt == self->dt_i64) code = 0;
+    else if (dt == self->dt_i32) code = 1;
+    else {
+        const int is16 = dt == self->dt_i16;
+        Py_DECREF(dt);
+        if (is16) PyErr_SetString(PyExc_RuntimeError, "scatter_(): Expected dtype int32/int64 for index");
+        else PyErr_SetString(PyExc_TypeError, "actions Tensor must be an integer type i.e. "
+                                              "{torch.ShortTensor, torch.IntTensor, torch.LongTensor}");
+        return NULL;
+    }
+    Py_DECREF(dt);
+    PyObject *n0 = PyObject_CallMethodOneArg(actions, s_size, s_zero); /* (len() of a tensor is a Python-level method) */
+    if (!n0) return NULL;
+    const long long n = PyLong_AsLongLong(n0);
+    Py_DECREF(n0);
+    if (n == -1 && PyErr_Occurred()) return NULL;
+    if (n != self->num_envs) {
+        PyErr_SetString(PyExc_RuntimeError, "Must have the same number of actions as environments.");
+        return NULL;
+    }
+    const long long i = self->slot;
+    if (!self->ok || i >= self->R || (self->want_obs_after && self->obs_afters == Py_None)) Py_RETURN_NONE;
+    long v = method_long(actions, s_get_device);
+    if (v == -2) return NULL;
+    if ((long long)v != self->dev_index) Py_RETURN_NONE;
+    v = method_long(actions, s_dim);
+    if (v == -2) return NULL;
+    if (v != 1) Py_RETURN_NONE;
+    v = method_long(actions, s_is_contiguous);
+    if (v == -2) return NULL;
+    if (!v) Py_RETURN_NONE;
+    PyObject *cur = PyObject_CallNoArgs(self->get_device);
+    if (!cur) return NULL;
+    const long cur_dev = PyLong_AsLong(cur);
+    Py_DECREF(cur);
+    if (cur_dev == -1 && PyErr_Occurred()) return NULL;
+    if ((long long)cur_dev != self->dev_index) Py_RETURN_NONE; /* kernels launch on the current device */
+    PyObject *idx = PyLong_FromLongLong(self->dev_index);
+    if (!idx) return NULL;
+    PyObject *st = PyObject_CallOneArg(self->get_stream, idx);
+    Py_DECREF(idx);
+    if (!st) return NULL;
+    void *stream = PyLong_AsVoidPtr(st);
+    Py_DECREF(st);
+    if (PyErr_Occurred()) return NULL;
+    PyObject *pp = PyObject_CallMethodNoArgs(actions, s_data_ptr);
+    if (!pp) return NULL;
+    void *aptr = PyLong_AsVoidPtr(pp);
+    Py_DECREF(pp);
+    if (PyErr_Occurred()) return NULL;
+
+    const int rc = self->fn(self->blk, self->slabs, (int64_t)i, aptr, code, (uint64_t)self->call, self->pending,
+                            (uint64_t)self->pend_call, self->want_obs_after, stream);
+    if (rc) return PyLong_FromLong(rc); /* nothing consumed: the counter, the postponed reset and the slot stay */
+    self->call += 1;
+    self->steps += 1;
+    self->pending = 0;
+    self->slot = i + 1;
+    set_obj(&self->last_done2, PyList_GET_ITEM(self->done2s, i));
+    set_obj(&self->done_view, Py_None);
+    self->last_fresh = 1;
+    set_obj(&self->obs_after, self->want_obs_after ? PyList_GET_ITEM(self->obs_afters, i) : Py_None);
+    PyObject *out = PyList_GET_ITEM(self->outs, i);
+    Py_INCREF(out);
+    return out;
+}
+
+/* reset_lazy(done, return_observations) -> what reset(done) returns if the reset could be postponed into the next
+ * step's launch (None, or the observation the last step's launch already wrote), else NotImplemented */
+static PyObject *stepper_reset_lazy(Stepper *self, PyObject *const *args, Py_ssize_t nargs)
+{
+    if (nargs != 2) {
+        PyErr_SetString(PyExc_TypeError, "reset_lazy takes exactly 2 arguments");
+        return NULL;
+    }
+    PyObject *done = args[0];
+    const int want = PyObject_IsTrue(args[1]);
+    if (want < 0) return NULL;
+    if (self->last_fresh && self->lazy_ok &&
+        (done == self->last_done2 || (self->done_view != Py_None && done == self->done_view))) {
+        long long ver = -1;
+        PyObject *vo = PyObject_GetAttr(done, s_version);
+        if (vo) {
+            ver = PyLong_AsLongLong(vo);
+            Py_DECREF(vo);
+            if (ver == -1 && PyErr_Occurred()) { PyErr_Clear(); ver = -1; }
+        } else {
+            PyErr_Clear(); /* inference tensors do not track versions: cannot prove `done` is unmodified */
+        }
+        if (ver >= 0 && ver == self->slab_version) {
+            if (!want) {
+                self->want_obs_after = 0;
+                self->pending = 1; self->pend_call = self->call; self->call += 1; self->last_fresh = 0;
+                Py_RETURN_NONE;
+            }
+            if (self->obs_after != Py_None) {
+                PyObject *obs = self->obs_after; /* reference handed over */
+                Py_INCREF(Py_None);
+                self->obs_after = Py_None;
+                self->pending = 1; self->pend_call = self->call; self->call += 1; self->last_fresh = 0;
+                return obs;
+            }
+            self->want_obs_after = 1; /* from the next step on, the step launch also writes this observation */
+        } else if (ver >= 0) {
+            self->slab_version = ver; /* an in-place edit of one step's flags costs one eager reset, not the slab's rest */
+        }
+    }
+    Py_INCREF(Py_NotImplemented);
+    return Py_NotImplemented;
+}
+
+static PyMemberDef stepper_members[] = {
+    {"slot", T_LONGLONG, offsetof(Stepper, slot), 0, NULL},
+    {"R", T_LONGLONG, offsetof(Stepper, R), 0, NULL},
+    {"num_envs", T_LONGLONG, offsetof(Stepper, num_envs), 0, NULL},
+    {"dev_index", T_LONGLONG, offsetof(Stepper, dev_index), 0, NULL},
+    {"slab_version", T_LONGLONG, offsetof(Stepper, slab_version), 0, NULL},
+    {"call", T_ULONGLONG, offsetof(Stepper, call), 0, NULL},
+    {"pend_call", T_ULONGLONG, offsetof(Stepper, pend_call), 0, NULL},
+    {"steps", T_ULONGLONG, offsetof(Stepper, steps), 0, NULL},
+    {"ok", T_BOOL, offsetof(Stepper, ok), 0, NULL},
+    {"pending", T_BOOL, offsetof(Stepper, pending), 0, NULL},
+    {"last_fresh", T_BOOL, offsetof(Stepper, last_fresh), 0, NULL},
+    {"want_obs_after", T_BOOL, offsetof(Stepper, want_obs_after), 0, NULL},
+    {"lazy_ok", T_BOOL, offsetof(Stepper, lazy_ok), 0, NULL},
+    {"outs", T_OBJECT, offsetof(Stepper, outs), 0, NULL},
+    {"done2s", T_OBJECT, offsetof(Stepper, done2s), 0, NULL},
+    {"obs_afters", T_OBJECT, offsetof(Stepper, obs_afters), 0, NULL},
+    {"last_done2", T_OBJECT, offsetof(Stepper, last_done2), 0, NULL},
+    {"done_view", T_OBJECT, offsetof(Stepper, done_view), 0, NULL},
+    {"obs_after", T_OBJECT, offsetof(Stepper, obs_after), 0, NULL},
+    {NULL, 0, 0, 0, NULL}};
+
+static PyMethodDef stepper_methods[] = {
+    {"step", (PyCFunction)stepper_step, METH_O, "see fastcall.c"},
+    {"reset_lazy", (PyCFunction)(void (*)(void))stepper_reset_lazy, METH_FASTCALL, "see fastcall.c"},
+    {NULL, NULL, 0, NULL}};
+
+static PyTypeObject StepperType = {
+    PyVarObject_HEAD_INIT(NULL, 0)
+    .tp_name = "wurm_amd._fastcall.Stepper",
+    .tp_basicsize = sizeof(Stepper),
+    .tp_flags = Py_TPFLAGS_DEFAULT | Py_TPFLAGS_HAVE_GC,
+    .tp_doc = "per-step state machine of SingleSnake / SimpleGridworld (see fastcall.c)",
+    .tp_new = PyType_GenericNew,
+    .tp_init = (initproc)stepper_init,
+    .tp_dealloc = (destructor)stepper_dealloc,
+    .tp_traverse = (traverseproc)stepper_traverse,
+    .tp_clear = (inquiry)stepper_clear,
+    .tp_members = stepper_members,
+    .tp_methods = stepper_methods,
+};
+
 static PyMethodDef fast_methods[] = {
     {"step_slot", (PyCFunction)(void (*)(void))fast_step_slot, METH_FASTCALL, "see fastcall.c"},
     {"multi_step", (PyCFunction)(void (*)(void))fast_multi_step, METH_FASTCALL, "see fastcall.c"},
@@ -83,4 +337,25 @@ static PyMethodDef fast_methods[] = {
 static struct PyModuleDef fast_module = {PyModuleDef_HEAD_INIT, "_fastcall", "per-step call shim (see fastcall.c)", -1,
                                          fast_methods, NULL, NULL, NULL, NULL};
 
-PyMODINIT_FUNC PyInit__fastcall(void) { return PyModule_Create(&fast_module); }
+PyMODINIT_FUNC PyInit__fastcall(void)
+{
+    s_dtype = PyUnicode_InternFromString("dtype");
+    s_data_ptr = PyUnicode_InternFromString("data_ptr");
+    s_get_device = PyUnicode_InternFromString("get_device");
+    s_dim = PyUnicode_InternFromString("dim");
+    s_is_contiguous = PyUnicode_InternFromString("is_contiguous");
+    s_version = PyUnicode_InternFromString("_version");
+    s_size = PyUnicode_InternFromString("size");
+    s_zero = PyLong_FromLong(0);
+    if (!s_size || !s_zero || !s_dtype || !s_data_ptr || !s_get_device || !s_dim || !s_is_contiguous || !s_version) return NULL;
+    if (PyType_Ready(&StepperType) < 0) return NULL;
+    PyObject *m = PyModule_Create(&fast_module);
+    if (!m) return NULL;
+    Py_INCREF(&StepperType);
+    if (PyModule_AddObject(m, "Stepper", (PyObject *)&StepperType) < 0) {
+        Py_DECREF(&StepperType);
+        Py_DECREF(m);
+        return NULL;
+    }
+    return m;
+}

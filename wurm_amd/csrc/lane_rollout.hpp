@@ -35,6 +35,7 @@ namespace wurm {
 constexpr int LR_C = 81, LR_C3 = 243, LR_E = 75; // cells, state floats and crop floats per env
 constexpr int LR_VS = 68;                        // bytes per env of the value -> cell table (17 dwords)
 constexpr int LR_BM = 84;                        // bytes per env of the body map written back (21 dwords)
+constexpr int LR_QCAP = 512;                     // entries of the non-zero queue (drained when fewer than 256 are free)
 constexpr int LR_TAB = 4096 + 656;               // workgroup tables: 256 x float4, 81 x u64 window-interior masks
 
 // per-wave LDS (bytes)
@@ -48,11 +49,14 @@ struct LaneRollLds {
     static constexpr int HPOS = STAT + 4 * EPW;            // u8  [EPW]
     static constexpr int FPOS = HPOS + EPW;                // u8  [EPW]
     static constexpr int VALPOS = FPOS + EPW;              // u8  [EPW][LR_VS]
-    static constexpr int START_END = VALPOS + EPW * LR_VS;
-    static constexpr int BMAP = SCR;                       // u8  [EPW][LR_BM] body values by cell (end of launch)
+    static constexpr int QUEUE = (VALPOS + EPW * LR_VS + 7) & ~7; // u64 [LR_QCAP] non-zero elements found by the state read
+    static constexpr int START_END = QUEUE + 8 * LR_QCAP;
+    static constexpr int BMAP = SCR;                       // u8  [EPW][LR_BM] body values by cell (end of launch, slow path)
     static constexpr int HC = BMAP + EPW * LR_BM;          // s16 [EPW] head cell (-1: env not written back)
     static constexpr int FC = HC + 2 * EPW;                // s16 [EPW] food cell (-1: none)
-    static constexpr int END_END = FC + 2 * EPW;
+    static constexpr int SLAB = SCR;                       // u8  [EPW * 243] the block's state, one byte per float (fast path)
+    static constexpr int END_SLOW = FC + 2 * EPW, END_FAST = SLAB + EPW * LR_C3 + 16;
+    static constexpr int END_END = END_SLOW > END_FAST ? END_SLOW : END_FAST;
     static constexpr int BYTES = ((START_END > END_END ? START_END : END_END) + 15) & ~15;
     static_assert(BYTES - SCR >= 96, "scratch must hold rollout_generic's class map");
 };
@@ -165,10 +169,13 @@ __global__ __launch_bounds__(256) void lane_rollout_kernel(StepArgs p)
     }
     for (int i = (int)threadIdx.x; i < LR_C; i += (int)blockDim.x) {
         const int hy = i / S, hx = i - hy * S;
+        // window column j shows grid column hx - 2 + j: inside the ring for max(0, 3 - hx) <= j <= min(4, 9 - hx); rows alike
+        const int j0 = max(0, 3 - hx), j1 = min(4, 9 - hx);
+        const u64 cols = j1 >= j0 ? (u64)(((2u << j1) - 1u) & ~((1u << j0) - 1u)) : 0ull;
         u64 m = 0;
+#pragma unroll
         for (int wy = 0; wy < 5; ++wy)
-            for (int wx = 0; wx < 5; ++wx)
-                if ((unsigned)(hy - 2 + wy - 1) < 7u && (unsigned)(hx - 2 + wx - 1) < 7u) m |= 1ull << (8 * wy + wx);
+            if ((unsigned)(hy - 2 + wy - 1) < 7u) m |= cols << (8 * wy);
         wint[i] = m;
     }
     __syncthreads();
@@ -180,12 +187,93 @@ __global__ __launch_bounds__(256) void lane_rollout_kernel(StepArgs p)
     const bool mine = lane < nenv;                // env lanes: lane e owns env0 + e
     const int ps = lane >> LOG_EPW, pe = lane & (EPW - 1); // pair lanes: step ps of the chunk, env env0 + pe
 
+    // Actions: one load per chunk and pair lane, SUPER chunks at a time and one batch AHEAD (loads and stores share vmcnt
+    // and retire in order: the wait for a batch issued a whole super-chunk earlier only drains the last few stores, and the
+    // chunk loop itself never waits on memory).  Unconditional loads (index clamped into the tape) so that all of a batch
+    // are in flight together.
+    const long long a_last = p.T * p.N - 1;
+    long long av[SUPER];
+    auto load_batch = [&](long long t_first) { // the dtype test outside the unrolled loads: SUPER loads back to back
+        if (p.act_dtype == WURM_ACT_I64) {
+#pragma unroll
+            for (int k = 0; k < SUPER; ++k)
+                av[k] = ((const long long *)p.actions)[min((t_first + (long long)k * TC + ps) * p.N + env0 + pe, a_last)];
+        } else {
+            int a32[SUPER];
+#pragma unroll
+            for (int k = 0; k < SUPER; ++k)
+                a32[k] = ((const int *)p.actions)[min((t_first + (long long)k * TC + ps) * p.N + env0 + pe, a_last)];
+#pragma unroll
+            for (int k = 0; k < SUPER; ++k) av[k] = (long long)a32[k];
+        }
+    };
+    load_batch(0);
+
     // ---- cooperative read of the state: lanes = (env, cell) pairs of the block, three dwords each (food, head, body)
     u32 *vm = (u32 *)(lds + Lds::VM), *stat = (u32 *)(lds + Lds::STAT);
     unsigned char *hpos = lds + Lds::HPOS, *fpos = lds + Lds::FPOS, *valpos = lds + Lds::VALPOS;
     if (lane < EPW) { vm[lane] = 0; vm[EPW + lane] = 0; stat[lane] = 0; }
     wave_lds_sync();
-    {
+    const bool whole = nenv == EPW && (((size_t)p.envs) & 15u) == 0; // full block, 16-byte aligned (env0 is a multiple of 4)
+    if (whole) {
+        // The block as EPW * 243 / 4 float4.  About 2 % of the elements are non-zero: each wave-wide slot (j, k) compacts
+        // its non-zero (element index, value) pairs into a queue with one ballot + prefix count, and the queue is decoded
+        // 64 entries at a time — so the division-heavy decode runs once per 64 non-zero elements, not once per slot.
+        constexpr int N4 = EPW * LR_C3 / 4, B4 = 16; // B4 loads in flight per lane
+        const float4 *base4 = (const float4 *)(p.envs + env0 * LR_C3);
+        u64 *queue = (u64 *)(lds + Lds::QUEUE);
+        int qn = 0; // wave-uniform
+        auto drain = [&]() {
+            wave_lds_sync();
+            for (int i = lane; i < qn; i += 64) {
+                const u64 ent = queue[i];
+                const float val = __uint_as_float((u32)ent);
+                const int f = (int)(ent >> 32), ej = f / LR_C3, r = f - ej * LR_C3, ch = r / LR_C, cj = r - ch * LR_C;
+                if (ch == 0) {
+                    if (val > 0.5f) { fpos[ej] = (unsigned char)cj; atomicAdd(&stat[ej], 1u << 16); }
+                } else if (ch == 1) {
+                    if (val > 0.5f) { hpos[ej] = (unsigned char)cj; atomicAdd(&stat[ej], 1u << 8); }
+                } else {
+                    const int bi = __float2int_rn(val);
+                    if (bi > 0 && bi < 64) {
+                        valpos[ej * LR_VS + bi] = (unsigned char)cj;
+                        atomicOr(&vm[(bi >> 5) * EPW + ej], 1u << (bi & 31));
+                        atomicAdd(&stat[ej], 1u);
+                    } else if (bi != 0) {
+                        atomicAdd(&stat[ej], 1u << 24);
+                    }
+                }
+            }
+            wave_lds_sync();
+            qn = 0;
+        };
+        for (int i0 = 0; i0 < N4; i0 += 64 * B4) {
+            float x[B4], y[B4], z[B4], w[B4];
+#pragma unroll
+            for (int j = 0; j < B4; ++j) {
+                const int g = i0 + 64 * j + lane;
+                const float4 v = base4[min(g, N4 - 1)];
+                x[j] = v.x; y[j] = v.y; z[j] = v.z; w[j] = v.w;
+            }
+#pragma unroll
+            for (int j = 0; j < B4; ++j) {
+                const int g = i0 + 64 * j + lane;
+                if (i0 + 64 * j >= N4) break;
+                if (qn > LR_QCAP - 256) drain();
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float val = k == 0 ? x[j] : k == 1 ? y[j] : k == 2 ? z[j] : w[j];
+                    const bool nz = g < N4 && val != 0.0f;
+                    const u64 m = ballot(nz);
+                    if (m != 0) {
+                        if (nz) queue[qn + rank_below(m)] = ((u64)(u32)(4 * g + k) << 32) | (u64)__float_as_uint(val);
+                        qn += popc64(m);
+                    }
+                }
+            }
+        }
+        drain();
+    } else {
         constexpr int LOADS = 9;
         const char *base = (const char *)(p.envs + env0 * LR_C3);
         const int pairs = nenv * LR_C;
@@ -275,28 +363,6 @@ __global__ __launch_bounds__(256) void lane_rollout_kernel(StepArgs p)
     const bool pair_env = pe < nenv;
     float *obs_c = p.obs + env0 * LR_E;               // crops of the chunk's first step, this wave's envs
     const unsigned obs_step_bytes = (unsigned)(p.N * (LR_E * 4)); // (the launcher keeps TC * N * 300 below 2^32)
-
-    // Actions: one load per chunk and pair lane, SUPER chunks at a time and one batch AHEAD (loads and stores share vmcnt
-    // and retire in order: the wait for a batch issued a whole super-chunk earlier only drains the last few stores, and the
-    // chunk loop itself never waits on memory).  Unconditional loads (index clamped into the tape) so that all of a batch
-    // are in flight together.
-    const long long a_last = p.T * p.N - 1;
-    long long av[SUPER];
-    auto load_batch = [&](long long t_first) { // the dtype test outside the unrolled loads: SUPER loads back to back
-        if (p.act_dtype == WURM_ACT_I64) {
-#pragma unroll
-            for (int k = 0; k < SUPER; ++k)
-                av[k] = ((const long long *)p.actions)[min((t_first + (long long)k * TC + ps) * p.N + env0 + pe, a_last)];
-        } else {
-            int a32[SUPER];
-#pragma unroll
-            for (int k = 0; k < SUPER; ++k)
-                a32[k] = ((const int *)p.actions)[min((t_first + (long long)k * TC + ps) * p.N + env0 + pe, a_last)];
-#pragma unroll
-            for (int k = 0; k < SUPER; ++k) av[k] = (long long)a32[k];
-        }
-    };
-    load_batch(0);
 
     for (long long T0 = 0; T0 < p.T; T0 += SUPER * TC) {
         // 4 bits per action: the action if it is 0..3, else 8 | (action % 4 & 7) (single_snake.py:221-222 needs "equals the
@@ -454,8 +520,35 @@ __global__ __launch_bounds__(256) void lane_rollout_kernel(StepArgs p)
     }
     wave_lds_sync();
 
-    // ---- write the state back: body values by cell from the queue, then the block's slabs with coalesced stores
-    {
+    // ---- write the state back.  Fast path (full block, every env in the domain): the block as one byte per float in LDS —
+    // zeroed, the food / head cells and the body values (walking the queue from the head) scattered by the env lanes —
+    // then 4 bytes -> float4 per lane and instruction.
+    if (whole && odd == 0) {
+        constexpr int N4 = EPW * LR_C3 / 4;
+        u32 *slab = (u32 *)(lds + Lds::SLAB);
+        unsigned char *sb8 = (unsigned char *)slab;
+        for (int i = lane; i < N4 + 4; i += 64) slab[i] = 0;
+        wave_lds_sync();
+        if (lane < EPW) {
+            unsigned char *my = sb8 + lane * LR_C3;
+            if (food >= 0) my[(food >> 3) * S + (food & 7)] = 1;
+            my[LR_C + (c >> 3) * S + (c & 7)] = 1;
+            int code = c;
+            u32 w0 = q0, w1 = q1, w2 = q2;
+            for (int v = L; v >= 1; --v) {
+                my[2 * LR_C + (code >> 3) * S + (code & 7)] = (unsigned char)v;
+                code -= lr_dcode((int)(w0 & 3u));
+                w0 = (w0 >> 2) | (w1 << 30); w1 = (w1 >> 2) | (w2 << 30); w2 >>= 2;
+            }
+        }
+        wave_lds_sync();
+        float4 *out4 = (float4 *)(p.envs + env0 * LR_C3);
+#pragma unroll 4
+        for (int g = lane; g < N4; g += 64) {
+            const u32 b = slab[g];
+            out4[g] = make_float4((float)(b & 0xffu), (float)((b >> 8) & 0xffu), (float)((b >> 16) & 0xffu), (float)(b >> 24));
+        }
+    } else {
         unsigned char *bm = lds + Lds::BMAP;
         short *hcs = (short *)(lds + Lds::HC), *fcs = (short *)(lds + Lds::FC);
         for (int i = lane; i < EPW * LR_BM / 4; i += 64) ((u32 *)bm)[i] = 0;

@@ -5,19 +5,24 @@ time per call, not by the GPU, so:
   * `step` is ONE launch (wurm_single_step_slot / wurm_grid_step_slot, include/wurm_hip.h) described by a persistent
     argument block; the tensors it returns are carved from slabs that hold the next few dozen steps' worth of FRESH
     outputs (a slab is never written twice: it is dropped once used up and lives as long as any tensor handed out from
-    it), and the call itself goes through the CPython shim wurm_amd/_fastcall instead of ctypes;
+    it) and are handed back as one PREBUILT tuple per slot;
   * `reset(done)` with the very `done` that `step` just returned is DEFERRED (`lazy_reset=True`, the default): the next
     `step` rebuilds those envs in front of its own transition, in the same launch, with the RNG counter the eager call
     would have used — bit-identical results.  Anything that looks at the state in between (`env.envs`, `_observe`,
     `check_consistency`, `rollout`, `render`, another `reset`) first flushes the postponed reset with the ordinary reset
     kernel, so `env.envs` always is what the reference would show.  If the caller reads the observation `reset(done)`
-    returns, the step launch writes that one too (the observation of every env once the finished ones are rebuilt).
+    returns (the reference's `reset` always returns it, single_snake.py:322-342), the step launch writes that one too
+    (the observation of every env once the finished ones are rebuilt).
     The one thing that is not tracked is a tensor alias taken BEFORE the deferred reset
-    (`e = env.envs; env.step(a); env.reset(d); e[...]`): read the attribute again, or pass `lazy_reset=False`.
+    (`e = env.envs; env.step(a); env.reset(d); e[...]` shows the un-reset state until the next step or the next look at
+    `env.envs`): read the attribute again, or pass `lazy_reset=False` (DESIGN.md §5 deviation 9, tests/test_hip_fused_step.py);
+  * the bodies of `step` and of the deferred `reset` are a small state machine, `Stepper`: in C where the extension
+    wurm_amd/_fastcall is built (wurm_amd/csrc/fastcall.c), else `PyStepper` below — the same logic, and the
+    specification of the C type (tests/test_host_lazy_reset.py drives both through the same call patterns).
 
 The host class provides: num_envs, size, device, seed, env_offset, observation_mode, lazy_reset, _CHANNELS,
 _STEP_SLOT (entry point name), _mode_info(mode) -> (mode code, n, obs shape), _lazy_supported(), _launch_reset(envs,
-done, obs, mode code, n, call), _configure_call(block).
+done, obs, mode code, n, call), _configure_call(block), _make_out(i) -> what step returns for slot i.
 """
 import ctypes
 
@@ -26,31 +31,154 @@ import torch
 from wurm_amd import _lib
 
 
+class PyStepper(object):
+    """Pure-Python twin of wurm_amd._fastcall.Stepper (same attributes, same methods, same results).
+
+    `fn` is a callable fn(call_block_addr, slabs_addr, slot, actions_ptr, actions_dtype, call, apply_pending, pre_call,
+    want_obs_after, stream) -> return code: the ctypes function, or a recording stand-in in the host tests."""
+
+    def __init__(self, fn, blk, slabs, get_device, get_stream, dt_i64, dt_i32, dt_i16):
+        self.fn, self.blk, self.slabs = fn, blk, slabs
+        self.get_device, self.get_stream = get_device, get_stream
+        self.dt_i64, self.dt_i32, self.dt_i16 = dt_i64, dt_i32, dt_i16
+        self.slot = self.R = self.num_envs = self.dev_index = 0
+        self.slab_version = -1
+        self.call = self.pend_call = self.steps = 0
+        self.ok = self.pending = self.last_fresh = self.want_obs_after = self.lazy_ok = False
+        self.outs = self.done2s = self.obs_afters = None
+        self.last_done2 = self.done_view = self.obs_after = None
+
+    def step(self, actions):
+        """The prebuilt output tuple of this step; None: the caller has to prepare something first (new slab, state tensor
+        to re-validate, actions on another device / not a contiguous vector, another device current) and call again; a
+        non-zero int: the entry point's error code.  Argument errors as the reference raises them
+        (single_snake.py:198-203; int16 passes its check and then fails in scatter_ at :229)."""
+        dt = actions.dtype
+        if dt is self.dt_i64:
+            code = 0  # _lib.ACT_I64
+        elif dt is self.dt_i32:
+            code = 1  # _lib.ACT_I32
+        elif dt is self.dt_i16:
+            raise RuntimeError('scatter_(): Expected dtype int32/int64 for index')
+        else:
+            raise TypeError('actions Tensor must be an integer type i.e. '
+                            '{torch.ShortTensor, torch.IntTensor, torch.LongTensor}')
+        if actions.size(0) != self.num_envs:
+            raise RuntimeError('Must have the same number of actions as environments.')
+        i = self.slot
+        if not self.ok or i >= self.R or (self.want_obs_after and self.obs_afters is None):
+            return None
+        idx = self.dev_index
+        if actions.get_device() != idx or actions.dim() != 1 or not actions.is_contiguous():
+            return None
+        if self.get_device() != idx:  # kernels launch on the current device
+            return None
+        rc = self.fn(self.blk, self.slabs, i, actions.data_ptr(), code, self.call, self.pending, self.pend_call,
+                     self.want_obs_after, self.get_stream(idx))
+        if rc:
+            return int(rc)  # nothing consumed: the counter, the postponed reset and the slot stay
+        self.call += 1
+        self.steps += 1
+        self.pending = False
+        self.slot = i + 1
+        self.last_done2 = self.done2s[i]
+        self.done_view = None
+        self.last_fresh = True
+        self.obs_after = self.obs_afters[i] if self.want_obs_after else None
+        return self.outs[i]
+
+    def reset_lazy(self, done, return_observations):
+        """What reset(done) returns if the reset could be postponed into the next step's launch (None, or the observation
+        the last step's launch already wrote), else NotImplemented."""
+        if self.last_fresh and self.lazy_ok and (done is self.last_done2 or
+                                                 (self.done_view is not None and done is self.done_view)):
+            try:
+                ver = done._version
+            except RuntimeError:  # inference tensors do not track versions: cannot prove `done` is unmodified
+                ver = -1
+            if ver >= 0 and ver == self.slab_version:
+                if not return_observations:
+                    self.want_obs_after = False
+                    self.pending, self.pend_call, self.last_fresh = True, self.call, False
+                    self.call += 1
+                    return None
+                if self.obs_after is not None:
+                    obs, self.obs_after = self.obs_after, None
+                    self.pending, self.pend_call, self.last_fresh = True, self.call, False
+                    self.call += 1
+                    return obs
+                self.want_obs_after = True  # from the next step on, the step launch also writes this observation
+            elif ver >= 0:
+                self.slab_version = ver  # an in-place edit of one step's flags costs one eager reset, not the slab's rest
+        return NotImplemented
+
+
+def _make_stepper(name, blk_addr, slabs_addr):
+    """C Stepper over the entry point's address when wurm_amd/_fastcall is built and the entry point is a real C function;
+    else PyStepper over whatever callable _lib.step_slot_fn hands out (ctypes function / test stand-in)."""
+    get_device, get_stream = _lib.accessors()
+    fn = _lib.step_slot_fn(name)
+    addr = getattr(fn, 'c_address', None)
+    if addr is not None:
+        try:
+            from wurm_amd import _fastcall
+            return _fastcall.Stepper(addr, blk_addr, slabs_addr, get_device, get_stream, torch.int64, torch.int32,
+                                     torch.int16)
+        except (ImportError, AttributeError):
+            pass
+    return PyStepper(fn, blk_addr, slabs_addr, get_device, get_stream, torch.int64, torch.int32, torch.int16)
+
+
 class FastStepMixin(object):
     def _fast_init(self):
-        self._call = 0
-        self._pending = False          # a reset is postponed; its flags are in self._pend, its counter in _pend_call
+        N = self.num_envs
+        c = self._c = _lib.SingleCall()
+        c.num_envs, c.env_offset, c.seed, c.size = N, self.env_offset, _lib.u64(self.seed), self.size
+        self._sl = _lib.SingleSlabs()
+        self._fs = _make_stepper(self._STEP_SLOT, ctypes.addressof(c), ctypes.addressof(self._sl))
+        self._fs.num_envs = N
+        self._fs.dev_index = -1 if self.device.index is None else self.device.index
+        self._get_device = _lib.accessors()[0]
         self._pend = None              # (N) bytes: the kernels' own copy of the last step's `done`
-        self._pend_call = 0
-        self._last_done2 = None        # the (N,1) `done` the last step returned
-        self._done = None              # env.done: its (N) view (made on first use) or whatever the caller assigned
-        self._done_from_step = False
-        self._slab_version = -1
-        self._last_fresh = False       # no call since that step has consumed an RNG counter or changed the state
-        self._obs_after = None         # what reset(done) will return, if the last step produced it
-        self._want_obs_after = False   # adaptive: callers that read reset()'s observation get it from the step launch
-        self._R = self._slot = 0       # output slabs (see _new_slab)
         self._slab_mode = None
-        self._v_obs_after = None
-        self._c = None
-        self._envs = torch.zeros((self.num_envs, self._CHANNELS, self.size, self.size), device=self.device)
-        self._envs_ok = self._envs
-        self._done = torch.zeros(self.num_envs, dtype=torch.bool, device=self.device)
+        self._envs = torch.zeros((N, self._CHANNELS, self.size, self.size), device=self.device)
+        self._envs_ok = None           # the state tensor that has been validated (None: validate before the next launch)
+        # env.done: what the caller (or the constructor / rollout) assigned, valid until the next step overwrites it
+        self._done, self._done_stamp = torch.zeros(N, dtype=torch.bool, device=self.device), 0
+
+    # state of the step machine that other methods of the classes read and write
+    _call = property(lambda self: self._fs.call, lambda self, v: setattr(self._fs, 'call', v))
+    _pending = property(lambda self: self._fs.pending, lambda self, v: setattr(self._fs, 'pending', v))
+    _pend_call = property(lambda self: self._fs.pend_call, lambda self, v: setattr(self._fs, 'pend_call', v))
+    _last_fresh = property(lambda self: self._fs.last_fresh, lambda self, v: setattr(self._fs, 'last_fresh', v))
+
+    @property
+    def observation_mode(self) -> str:
+        return self._observation_mode
+
+    @observation_mode.setter
+    def observation_mode(self, value: str):
+        self._observation_mode = value
+        fs = getattr(self, '_fs', None)
+        if fs is not None:
+            fs.ok = False  # the next step builds output slabs of the new shape
+
+    @property
+    def lazy_reset(self) -> bool:
+        return self._lazy_reset
+
+    @lazy_reset.setter
+    def lazy_reset(self, value: bool):
+        self._lazy_reset = bool(value)
+        fs = getattr(self, '_fs', None)
+        if fs is not None:
+            fs.lazy_ok = self._lazy_reset and self._lazy_supported()
 
     def _next_call(self, n: int = 1) -> int:
-        c = self._call
-        self._call += n
-        self._last_fresh = False  # the counter the last step's `obs_after` assumed for its reset is gone
+        fs = self._fs
+        c = fs.call
+        fs.call = c + n
+        fs.last_fresh = False  # the counter the last step's `obs_after` assumed for its reset is gone
         return c
 
     # ------------------------------------------------------------------ state
@@ -58,29 +186,37 @@ class FastStepMixin(object):
     @property
     def envs(self) -> torch.Tensor:
         """The state tensor, caller-visible and caller-mutable as in the reference (tests/test_single_snake_env.py:54,
-        experiments/main.py:215,273).  Reading it applies a postponed reset."""
-        if self._pending:
+        experiments/main.py:215,273).  Reading it applies a postponed reset; the caller may edit what it gets, so an
+        observation the last step's launch pre-computed for `reset(done)` is dropped (that reset then runs eagerly)."""
+        fs = self._fs
+        if fs.pending:
             self._flush()
+        fs.obs_after = None
         return self._envs
 
     @envs.setter
     def envs(self, value: torch.Tensor):
         # the reference would have applied reset(done) to the OLD tensor before this assignment replaced it
-        self._pending = False
-        self._last_fresh = False
+        fs = self._fs
+        fs.pending = False
+        fs.last_fresh = False
+        fs.ok = False
+        self._envs_ok = None
         self._envs = value
 
     def _flush(self):
         """Applies the postponed reset(done) now, with the ordinary reset kernel and the counter it was given."""
-        self._pending = False
-        self._launch_reset(self._checked(self._envs), self._pend, None, _lib.OBS_NONE, 0, self._pend_call)
+        fs = self._fs
+        self._launch_reset(self._checked(self._envs), self._pend, None, _lib.OBS_NONE, 0, fs.pend_call)
+        fs.pending = False  # (only once the launch is known to have been accepted)
 
     def _state(self) -> torch.Tensor:
         """The state tensor, validated, with any postponed reset applied; the caller is about to change it or to
         consume an RNG counter."""
-        if self._pending:
+        fs = self._fs
+        if fs.pending:
             self._flush()
-        self._last_fresh = False
+        fs.last_fresh = False
         return self._checked(self._envs)
 
     def _checked(self, e: torch.Tensor) -> torch.Tensor:
@@ -94,128 +230,114 @@ class FastStepMixin(object):
             e = e.to(device=self.device, dtype=torch.float32).contiguous()
             self._envs = e
         self._envs_ok = e
-        if self._c is not None:
-            self._c.envs = e.data_ptr()
+        self._c.envs = e.data_ptr()
         return e
 
     @property
     def done(self) -> torch.Tensor:
-        """(num_envs,) bool — the `done` of the last step (the reference assigns `self.done = done` in step)."""
-        d = self._done
+        """(num_envs,) bool — the `done` of the last step (the reference assigns `self.done = done` in step), or whatever
+        was assigned to the attribute since."""
+        fs = self._fs
+        if self._done_stamp == fs.steps:
+            if self._done is None:  # after a rollout: every finished env was reset (made on first use: no fill kernel per launch)
+                self._done = torch.zeros(self.num_envs, dtype=torch.bool, device=self.device)
+            return self._done
+        self._done = None  # a step has run since the assignment
+        d = fs.done_view
         if d is None:  # the 1-D view of what the last step returned, made on first use
-            d = self._done = self._last_done2.view(self.num_envs)
-            self._done_from_step = True
+            d = fs.done_view = fs.last_done2.view(self.num_envs)
         return d
 
     @done.setter
     def done(self, value: torch.Tensor):
-        self._done, self._done_from_step = value, False
+        self._done, self._done_stamp = value, self._fs.steps
+
+    def _done_all_false(self):
+        """env.done after a fused rollout (every finished env has been reset)"""
+        self._done, self._done_stamp = None, self._fs.steps
 
     # ------------------------------------------------------------------ step
 
     def _new_slab(self):
         """Fresh output tensors for the next R steps in a few allocations (instead of four per step): R observations,
-        R (N,1) rewards, 3 x R flag vectors (wurm_single_slabs).  A slab is never written twice; it is released when the
-        last tensor carved from it is."""
+        R (N,1) rewards, 3 x R flag vectors (wurm_single_slabs), and the R tuples `step` returns.  A slab is never written
+        twice; it is released when the last tensor carved from it is."""
         N = self.num_envs
+        fs = self._fs
         m, n, shape = self._mode_info(self.observation_mode)
         elems = int(torch.Size(shape).numel()) // max(N, 1)
         per_step = N * (4 * elems + 4 + 3)
         R = max(1, min(64, (32 << 20) // max(per_step, 1)))
         dev = self.device
+        want_after = bool(fs.want_obs_after)
         obs = torch.empty((R,) + tuple(shape), dtype=torch.float32, device=dev)
         reward = torch.empty((R, N, 1), dtype=torch.float32, device=dev)
         flags = torch.empty((3, R, N), dtype=torch.bool, device=dev)
-        obs_after = torch.empty((R,) + tuple(shape), dtype=torch.float32, device=dev) if self._want_obs_after else None
+        obs_after = torch.empty((R,) + tuple(shape), dtype=torch.float32, device=dev) if want_after else None
         self._v_obs, self._v_reward = obs.unbind(0), reward.unbind(0)
         self._v_done2 = flags[0].unsqueeze(-1).unbind(0)
         self._v_selfc, self._v_edgec = flags[1].unbind(0), flags[2].unbind(0)
-        self._v_obs_after = obs_after.unbind(0) if obs_after is not None else None
-        self._slab_version = flags._version
-        self._R, self._slot = R, 0
-        if self._c is None:
-            c = self._c = _lib.SingleCall()
-            c.num_envs, c.env_offset, c.seed, c.size = N, self.env_offset, _lib.u64(self.seed), self.size
+        if self._pend is None:
             self._pend = torch.zeros(N, dtype=torch.uint8, device=dev)
-            c.done_copy = self._pend.data_ptr()
-            self._sl = _lib.SingleSlabs()
-            self._c_addr, self._sl_addr = ctypes.addressof(c), ctypes.addressof(self._sl)
-            self._fn = _lib.step_slot_fn(self._STEP_SLOT)
-            self._get_device, self._get_stream = _lib.accessors()
-            self._dev_index = dev.index
-            c.envs = self._checked(self._envs).data_ptr()
+            self._c.done_copy = self._pend.data_ptr()
         self._configure_call(self._c)
         self._c.obs_mode, self._c.obs_n = m, n
         sl = self._sl
         sl.obs, sl.reward, sl.flags, sl.steps = obs.data_ptr(), reward.data_ptr(), flags.data_ptr(), R
         sl.obs_after = obs_after.data_ptr() if obs_after is not None else None
         self._slab_mode = self.observation_mode
+        try:
+            fs.slab_version = flags._version
+        except RuntimeError:   # allocated under torch.inference_mode(): no version counters, so no deferral (eager resets)
+            fs.slab_version = -1
+        fs.outs = [self._make_out(i) for i in range(R)]
+        fs.done2s = list(self._v_done2)
+        fs.obs_afters = list(obs_after.unbind(0)) if obs_after is not None else None
+        fs.R, fs.slot = R, 0
+        fs.lazy_ok = self._lazy_reset and self._lazy_supported()
 
     def _fast_step(self, actions: torch.Tensor, what: str):
-        """One launch: [postponed reset] + step + observation (+ the observation reset(done) will return).  Returns the
-        slot index of the outputs in the current slab."""
-        dt = actions.dtype
-        if dt is torch.int64:
-            code = 0  # _lib.ACT_I64
-        elif dt is torch.int32:
-            code = 1  # _lib.ACT_I32
-        elif dt is torch.short:
-            # the reference passes its own dtype check and then fails inside scatter_ (single_snake.py:229)
-            raise RuntimeError('scatter_(): Expected dtype int32/int64 for index')
-        else:
-            raise TypeError('actions Tensor must be an integer type i.e. '
-                            '{torch.ShortTensor, torch.IntTensor, torch.LongTensor}')
-        N = self.num_envs
-        if actions.size(0) != N:
-            raise RuntimeError('Must have the same number of actions as environments.')
-        i = self._slot
-        if i >= self._R or self._slab_mode != self.observation_mode or \
-                (self._want_obs_after and self._v_obs_after is None):
-            self._new_slab()
-            i = 0
-        self._slot = i + 1
-        idx = self._dev_index
-        act = actions
-        if act.get_device() != idx or act.dim() != 1 or not act.is_contiguous():
-            act = actions.to(self.device).reshape(N).contiguous()
-        e = self._envs
-        if e is not self._envs_ok:
-            e = self._checked(e)
-        call = self._call
-        self._call = call + 1
-        pending = self._pending
-        if pending:
-            self._pending = False
-        want_after = self._want_obs_after
-        if self._get_device() != idx:  # a process driving several GPUs has another device current
-            rc = _lib.call(idx, self._fn, self._c_addr, self._sl_addr, i, act.data_ptr(), code, call, pending,
-                           self._pend_call, want_after, _lib.stream_ptr(idx))
-        else:
-            rc = self._fn(self._c_addr, self._sl_addr, i, act.data_ptr(), code, call, pending, self._pend_call,
-                          want_after, self._get_stream(idx))
-        if rc:
-            _lib.check(rc, what)
-        if act is not actions:
-            actions.copy_(act.view_as(actions))  # SingleSnake sanitises actions in place (single_snake.py:222)
-        self._last_done2 = self._v_done2[i]
-        self._done = None
-        self._last_fresh = True
-        self._obs_after = self._v_obs_after[i] if want_after else None
-        return i
+        """`step`: one launch — [postponed reset] + step + observation (+ the observation reset(done) will return)."""
+        fs = self._fs
+        out = fs.step(actions)
+        if out.__class__ is tuple:
+            return out
+        return self._slow_step(actions, out, what)
+
+    def _slow_step(self, actions: torch.Tensor, out, what: str):
+        """What the step machine could not do by itself (it returned None), or an error code of the entry point."""
+        fs = self._fs
+        if out is None:
+            if fs.slot >= fs.R or self._slab_mode != self.observation_mode or \
+                    (fs.want_obs_after and fs.obs_afters is None):
+                self._new_slab()
+            e = self._envs
+            if e is not self._envs_ok:
+                self._checked(e)
+            fs.ok = True
+            idx = fs.dev_index
+            act = actions
+            if act.get_device() != idx or act.dim() != 1 or not act.is_contiguous():
+                act = actions.to(self.device).reshape(self.num_envs).contiguous()
+            if self._get_device() != idx:
+                with torch.cuda.device(idx):  # a process driving several GPUs has another device current
+                    out = fs.step(act)
+            else:
+                out = fs.step(act)
+            if out.__class__ is tuple:
+                if act is not actions:
+                    actions.copy_(act.view_as(actions))  # SingleSnake sanitises actions in place (single_snake.py:222)
+                return out
+        if out is None:
+            raise RuntimeError(f'{what}: the step machine refused a prepared call')  # not reachable
+        _lib.check(int(out), what)
+        raise RuntimeError(f'{what}: unexpected return {out!r}')
 
     # ------------------------------------------------------------------ reset
 
     def _try_lazy_reset(self, done: torch.Tensor, return_observations: bool):
         """(True, obs) if reset(done) could be postponed into the next step's launch, else (False, None)."""
-        if self._last_fresh and (done is self._last_done2 or (self._done_from_step and done is self._done)) and \
-                self.lazy_reset and self._lazy_supported() and done._version == self._slab_version:
-            if not return_observations:
-                self._want_obs_after = False
-                self._pending, self._pend_call, self._last_fresh = True, self._next_call(), False
-                return True, None
-            if self._obs_after is not None:
-                obs, self._obs_after = self._obs_after, None
-                self._pending, self._pend_call, self._last_fresh = True, self._next_call(), False
-                return True, obs
-            self._want_obs_after = True  # from the next step on, the step launch also writes this observation
-        return False, None
+        obs = self._fs.reset_lazy(done, return_observations)
+        if obs is NotImplemented:
+            return False, None
+        return True, obs

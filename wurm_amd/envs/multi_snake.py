@@ -41,6 +41,15 @@ Spec = namedtuple('Spec', ['reward_threshold'])
 _INT_TYPES = (torch.short, torch.int, torch.long)
 
 
+def _version_of(t: torch.Tensor) -> int:
+    """the tensor's version counter, or -1 where there is none (tensors made under torch.inference_mode()): the deferred
+    reset needs it to prove that the flags it was handed are still the kernel's own"""
+    try:
+        return t._version
+    except RuntimeError:
+        return -1
+
+
 class _Flushing(object):
     """State attribute of MultiSnake: reading or assigning it first applies a postponed reset(done)."""
 
@@ -52,6 +61,7 @@ class _Flushing(object):
             return self
         if obj._pending:
             obj._flush()
+        obj._obs_after = None  # the caller may edit what it gets: reset(done) then observes again instead of reusing it
         return getattr(obj, self.slot)
 
     def __set__(self, obj, value):
@@ -380,51 +390,55 @@ class MultiSnake(object):
             a_ptr = vals.data_ptr()
         pending = self._pending
         self._pending = False  # consumed by this launch (the raw attributes below do not flush)
-        c = self._mc
-        if c is None:
-            c = self._mc = _lib.MultiCall()
-            c.num_envs, c.env_offset, c.seed = N, self.env_offset, _lib.u64(self.seed)
-            c.num_snakes, c.size = K, S
-            self._pend = torch.zeros(N, dtype=torch.uint8, device=dev)
-            c.all_done_copy = self._pend.data_ptr()
-            self._mc_addr = ctypes.addressof(c)
-            self._mc_cfg = None
-            self._mc_fn = _lib.multi_step_fn()
-            self._get_device, self._get_stream = _lib.accessors()
-            ks = [str(i) for i in range(K)]
-            self._keys = tuple([p + k for k in ks] for p in ('agent_', 'snake_collision_', 'edge_collision_', 'food_',
-                                                             'boost_', 'size_'))
-        if self._state_dirty:
-            foods, heads, bodies, dones, orientations, colours, _ = self._state()
-            c.foods, c.heads, c.bodies = foods.data_ptr(), heads.data_ptr(), bodies.data_ptr()
-            c.dones, c.orientations, c.colours = dones.data_ptr(), orientations.data_ptr(), colours.data_ptr()
-            self._state_dirty = False
-        mode = self.observation_mode
-        if mode != self._mc_mode:
-            c.obs_mode, c.obs_n, o = self._obs_args(mode)
-            self._obs_shape, self._mc_mode = tuple(o.shape), mode
-        obs = torch.empty(self._obs_shape, dtype=torch.float32, device=dev)
-        # a caller that reads what reset(dones['__all__']) returns gets it from this launch from now on (reset below)
-        after = torch.empty(self._obs_shape, dtype=torch.float32, device=dev) if self._want_after else None
-        a_after = after.data_ptr() if after is not None else 0
-        cfg = self._cfg()
-        if cfg is not self._mc_cfg:
-            c.cfg = self._mc_cfg = cfg
-
-        # packed outputs (include/wurm_hip.h wurm_multi_step_packed): env-major blocks first, then agent-major rows
-        of = torch.empty((6 * K, N), dtype=torch.float32, device=dev)
-        ob = torch.empty((7 * K + 1, N), dtype=torch.bool, device=dev)
         call = self._call
-        self._call = call + 1
-        idx = dev.index
-        if self._get_device() != idx:  # a process driving several GPUs has another device current
-            rc = _lib.call(idx, self._mc_fn, self._mc_addr, of.data_ptr(), ob.data_ptr(), obs.data_ptr(), a_after, a_ptr,
-                           call, pending, self._pend_call, _lib.stream_ptr(idx))
-        else:
-            rc = self._mc_fn(self._mc_addr, of.data_ptr(), ob.data_ptr(), obs.data_ptr(), a_after, a_ptr, call, pending,
-                             self._pend_call, self._get_stream(idx))
-        if rc:
-            _lib.check(rc, 'MultiSnake.step')
+        try:  # if anything below raises, the postponed reset and the counter are still owed
+            c = self._mc
+            if c is None:
+                c = self._mc = _lib.MultiCall()
+                c.num_envs, c.env_offset, c.seed = N, self.env_offset, _lib.u64(self.seed)
+                c.num_snakes, c.size = K, S
+                self._pend = torch.zeros(N, dtype=torch.uint8, device=dev)
+                c.all_done_copy = self._pend.data_ptr()
+                self._mc_addr = ctypes.addressof(c)
+                self._mc_cfg = None
+                self._mc_fn = _lib.multi_step_fn()
+                self._get_device, self._get_stream = _lib.accessors()
+                ks = [str(i) for i in range(K)]
+                self._keys = tuple([p + k for k in ks] for p in ('agent_', 'snake_collision_', 'edge_collision_', 'food_',
+                                                                 'boost_', 'size_'))
+            if self._state_dirty:
+                foods, heads, bodies, dones, orientations, colours, _ = self._state()
+                c.foods, c.heads, c.bodies = foods.data_ptr(), heads.data_ptr(), bodies.data_ptr()
+                c.dones, c.orientations, c.colours = dones.data_ptr(), orientations.data_ptr(), colours.data_ptr()
+                self._state_dirty = False
+            mode = self.observation_mode
+            if mode != self._mc_mode:
+                c.obs_mode, c.obs_n, o = self._obs_args(mode)
+                self._obs_shape, self._mc_mode = tuple(o.shape), mode
+            obs = torch.empty(self._obs_shape, dtype=torch.float32, device=dev)
+            # a caller that reads what reset(dones['__all__']) returns gets it from this launch from now on (reset below)
+            after = torch.empty(self._obs_shape, dtype=torch.float32, device=dev) if self._want_after else None
+            a_after = after.data_ptr() if after is not None else 0
+            cfg = self._cfg()
+            if cfg is not self._mc_cfg:
+                c.cfg = self._mc_cfg = cfg
+
+            # packed outputs (include/wurm_hip.h wurm_multi_step_packed): env-major blocks first, then agent-major rows
+            of = torch.empty((6 * K, N), dtype=torch.float32, device=dev)
+            ob = torch.empty((7 * K + 1, N), dtype=torch.bool, device=dev)
+            self._call = call + 1
+            idx = dev.index
+            if self._get_device() != idx:  # a process driving several GPUs has another device current
+                rc = _lib.call(idx, self._mc_fn, self._mc_addr, of.data_ptr(), ob.data_ptr(), obs.data_ptr(), a_after, a_ptr,
+                               call, pending, self._pend_call, _lib.stream_ptr(idx))
+            else:
+                rc = self._mc_fn(self._mc_addr, of.data_ptr(), ob.data_ptr(), obs.data_ptr(), a_after, a_ptr, call, pending,
+                                 self._pend_call, self._get_stream(idx))
+            if rc:
+                _lib.check(rc, 'MultiSnake.step')
+        except BaseException:
+            self._pending, self._call = pending, call
+            raise
 
         self._out_f, self._out_b = of, ob          # env.rewards / env.boost_this_step are views of these, made on demand
         self._obs_after = after
@@ -454,7 +468,7 @@ class MultiSnake(object):
         info.update(zip(k_boost, rb[K4:K5]))
         self.info = info
 
-        self._last_all_done, self._last_version = all_done, all_done._version
+        self._last_all_done, self._last_version = all_done, _version_of(all_done)
         self._last_fresh = not self._lifetimes_touched
         return OrderedDict(zip(k_agent, obs.unbind(0))), rewards, dones_out, info
 
@@ -556,7 +570,7 @@ class MultiSnake(object):
         if self.initial_snake_length != 3:
             raise NotImplementedError('Only initial snake length = 3 has been implemented.')
         if done is not None and done is self._last_all_done and self._last_fresh and self.lazy_reset and \
-                self.size >= 5 and done._version == self._last_version:
+                self.size >= 5 and self._last_version >= 0 and _version_of(done) == self._last_version:
             # env_lifetimes is all zeros here (nobody has asked for it): `env_lifetimes[done] = 0` (:797) is a no-op
             if not return_observations:
                 self._want_after = False

@@ -109,8 +109,10 @@ class SimpleGridworld(FastStepMixin):
     def step(self, actions: torch.Tensor) -> (torch.Tensor, torch.Tensor, torch.Tensor, dict):
         """reference :135-202 (actions are not modified).  One launch; a reset(done) postponed by the previous iteration
         (wurm_amd/envs/_fast_step.py) is applied in front of the transition."""
-        i = self._fast_step(actions, 'SimpleGridworld.step')
-        return self._v_obs[i], self._v_reward[i], self._last_done2, {'edge_collision': self._v_edgec[i]}
+        return self._fast_step(actions, 'SimpleGridworld.step')
+
+    def _make_out(self, i: int):
+        return self._v_obs[i], self._v_reward[i], self._v_done2[i], {'edge_collision': self._v_edgec[i]}
 
     def _reset(self, done: torch.Tensor, observe: bool = True):
         if self.size <= 4 or self.start_location is None:
@@ -168,7 +170,7 @@ class SimpleGridworld(FastStepMixin):
             _lib.i64(T), int(self.start_location[0]), int(self.start_location[1]), _lib.u64(self.seed),
             _lib.u64(self._next_call(2 * T)), _lib.i64(self.env_offset), None, None, _lib.stream_ptr(self.device.index))
         _lib.check(rc, 'SimpleGridworld.rollout')
-        self.done = torch.zeros(N, dtype=torch.bool, device=self.device)
+        self._done_all_false()
         return {'observations': obs, 'rewards': reward, 'dones': flags[0], 'edge_collision': flags[1]}
 
     def _consistent(self):

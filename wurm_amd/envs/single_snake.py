@@ -158,9 +158,12 @@ class SingleSnake(FastStepMixin):
         """reference :197-304.  `actions` is sanitised in place (reverse moves become forward moves).  One launch:
         a reset(done) postponed by the previous iteration (wurm_amd/envs/_fast_step.py) is applied in front of the
         transition."""
-        i = self._fast_step(actions, 'SingleSnake.step')
-        return self._v_obs[i], self._v_reward[i], self._last_done2, {'self_collision': self._v_selfc[i],
-                                                                      'edge_collision': self._v_edgec[i]}
+        return self._fast_step(actions, 'SingleSnake.step')
+
+    def _make_out(self, i: int):
+        """what `step` returns for slot i of the current output slab (built once per slab)"""
+        return (self._v_obs[i], self._v_reward[i], self._v_done2[i],
+                {'self_collision': self._v_selfc[i], 'edge_collision': self._v_edgec[i]})
 
     # ------------------------------------------------------------------ reset
 
@@ -248,7 +251,7 @@ class SingleSnake(FastStepMixin):
             _lib.i64(N), self.size, _lib.i64(T), _lib.u64(self.seed), _lib.u64(self._next_call(2 * T)),
             _lib.i64(self.env_offset), None, None, _lib.stream_ptr(self.device.index))
         _lib.check(rc, 'SingleSnake.rollout')
-        self.done = torch.zeros(N, dtype=torch.bool, device=self.device)  # every done env was reset
+        self._done_all_false()  # every done env was reset
         return {'observations': obs, 'rewards': reward, 'dones': flags[0], 'self_collision': flags[1],
                 'edge_collision': flags[2]}
 
@@ -293,7 +296,7 @@ class SingleSnake(FastStepMixin):
         _lib.check(rc, 'SingleSnake.policy_rollout')
         if check and T > 0 and bool(status.any()):
             raise RuntimeError('policy_rollout: some envs are not well-formed snakes (status != 0); they were left untouched')
-        self.done = torch.zeros(N, dtype=torch.bool, device=dev)  # every done env was reset
+        self._done_all_false()  # every done env was reset
         return {'actions': actions, 'probs': probs, 'values': values, 'rewards': reward, 'dones': flags[0],
                 'self_collision': flags[1], 'edge_collision': flags[2], 'observations': obs,
                 'state': obs[-1] if T > 0 else state.reshape(shape), 'status': status}
