@@ -137,3 +137,19 @@ def test_multi_rollout_equals_loop(hip, N, K, S, T, mode, cfg):
         _same(ro[k], rh[k], k)
     _same_state(so, sh, 'final state')
     assert ro['dones'].sum() > 0
+
+
+@pytest.mark.parametrize('N,K,S,T,mode,cfg', [
+    (6, 32, 36, 12, 'full', 'train'),       # 90 KB of grids per env: the kernels are opted into > 64 KB of LDS
+    (5, 24, 36, 12, 'partial_3', 'train'),  # 75 KB with the env image of partial_n
+    (4, 12, 64, 10, 'full', 'default'),     # 12 snakes on 64 x 64: 112 KB
+])
+def test_envs_larger_than_64kb_of_lds(hip, N, K, S, T, mode, cfg):
+    """One env's grids must fit a CU's LDS: up to 64 KB as before, up to 160 KB with the kernels' opt-in."""
+    test_multi_step_reset_loop(hip, N, K, S, T, mode, cfg)
+
+
+def test_env_beyond_160kb_is_unsupported(hip):
+    from wurm_amd.envs import MultiSnake
+    with pytest.raises(NotImplementedError):
+        MultiSnake(2, 40, 64, device='cuda:0', seed=1)   # 2 x 40 x 4096 bytes of body clocks alone

@@ -2,7 +2,7 @@
 # Re-creates the artefacts under profiles/ on the GPU box (run through gpurun from the repo root):
 #   bash tools/collect_profiles.sh <tag>      ->  gpurun_out/profiles_<tag>/
 # rocprofv3 is always given the program itself after `--` and counters are collected in their own passes.
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/profiles_$TAG
 mkdir -p $OUT
@@ -23,8 +23,13 @@ python3 $R/tools/make_traffic_json.py $OUT/${TAG}_pmc_fetch_write_summary.json >
 # 4. kernel durations of that workload (per kernel and grid size): the per-call kernels and the big-grid rollouts
 python3 $R/tools/trace_summary.py $(find $OUT/pmc_WRITE_SIZE -name "*kernel_trace.csv" | head -1) > $OUT/${TAG}_kernel_times_traffic_workload.txt
 # 5. instruction mix / wave cycles of the cfg2 rollout kernel and of the cfg4 MultiSnake rollout
-bash $R/tools/pmc_instmix.sh obs > /dev/null
-cp $R/gpurun_out/pmc_obs/summary.json $OUT/${TAG}_cfg2_rollout_instmix_pmc.json
+bash $R/tools/pmc_instmix.sh obs 512 256 > /dev/null
+cp $R/gpurun_out/pmc_obs_512/summary.json $OUT/${TAG}_cfg2_rollout_instmix_pmc.json
+# ... and of the one-env-per-lane rollout at the cfg3 shapes (8 192 envs per GPU, all 65 536 on one GPU)
+bash $R/tools/pmc_instmix.sh obs 8192 128 > /dev/null
+cp $R/gpurun_out/pmc_obs_8192/summary.json $OUT/${TAG}_lane_rollout_8192_instmix_pmc.json
+bash $R/tools/pmc_instmix.sh obs 65536 64 > /dev/null
+cp $R/gpurun_out/pmc_obs_65536/summary.json $OUT/${TAG}_lane_rollout_65536_instmix_pmc.json
 bash $R/tools/pmc_multi.sh > /dev/null
 cp $R/gpurun_out/pmc_multi_full/summary.json $OUT/${TAG}_multi_rollout_cfg4_full_instmix_pmc.json
 cp $R/gpurun_out/pmc_multi_none/summary.json $OUT/${TAG}_multi_rollout_cfg4_noobs_instmix_pmc.json

@@ -9,11 +9,24 @@ import sys
 s = json.load(open(sys.argv[1]))
 
 
-def find(prefix, grid):
-    for k, v in s.items():
-        if k.startswith(prefix) and k.endswith(f'grid={grid}'):
-            return v
-    raise KeyError((prefix, grid))
+def find(prefix, grid, part=None):
+    """the summary entry of the kernel whose name starts with `prefix` at that grid size (threads); part = (i, n): the i-th
+    of n equal runs of launches in dispatch order — tools/traffic_workload.py launches one kernel at one grid size for
+    more than one configuration (MultiSnake 4 x 25 x 25 and 10 x 36 x 36, both 4096 envs)"""
+    hits = [(k, v) for k, v in s.items() if k.startswith(prefix) and k.endswith(f'|grid={grid}')]
+    if len(hits) != 1:
+        raise KeyError((prefix, grid, [k for k, _ in hits]))
+    v = hits[0][1]
+    if part is None:
+        return v
+    i, n = part
+    out = {}
+    for c, x in v.items():
+        vals = x['values']
+        m = len(vals) // n
+        sub = vals[i * m:(i + 1) * m]
+        out[c] = {'launches': len(sub), 'mean': sum(sub) / len(sub), 'min': min(sub), 'max': max(sub)}
+    return out
 
 
 known_read = 65536 * 3 * 36 * 36 * 4  # bytes read by check_kernel<24> over the 65536 x 36 x 36 state
@@ -25,9 +38,9 @@ write_factor = known_write / (calw['WRITE_SIZE']['mean'] * 1024)
 copy = find('__amd_rocclr_copyBuffer', 131072)
 
 
-def traffic(prefix, grid):
+def traffic(prefix, grid, part=None):
     try:
-        v = find(prefix, grid)
+        v = find(prefix, grid, part)
     except KeyError:
         return None
     r = v['FETCH_SIZE']['mean'] * 1024 * read_factor
@@ -41,17 +54,22 @@ def total(t):
 
 detail = {
     'rollout_512x9_chunk1024': traffic('void wurm::rollout_s9_kernel<4', 32768),
-    'rollout_8192x9_chunk128': traffic('void wurm::rollout_s9_kernel<4', 524288),
-    'rollout_16384x9_chunk128': traffic('void wurm::rollout_s9_kernel<4', 1048576),
-    'rollout_32768x9_chunk64': traffic('void wurm::rollout_s9_kernel<4', 2097152),
-    'rollout_65536x9_chunk64': traffic('void wurm::rollout_s9_kernel<4', 4194304),
+    # one env per LANE from 6 144 envs on (lane_rollout.hpp): 8 / 16 / 16 / 32 envs per wave at these batch sizes
+    'rollout_8192x9_chunk128': traffic('void wurm::lane_rollout_kernel<8, 4, false>', 65536),
+    'rollout_16384x9_chunk128': traffic('void wurm::lane_rollout_kernel<16, 4, false>', 65536),
+    'rollout_32768x9_chunk64': traffic('void wurm::lane_rollout_kernel<16, 4, false>', 131072),
+    'rollout_65536x9_chunk64': traffic('void wurm::lane_rollout_kernel<32, 4, false>', 131072),
     'rollout_cfg5_8192x36_default_chunk16': traffic('void wurm::(anonymous namespace)::grid_rollout_kernel<true>', 524288),
-    'multi_rollout_cfg4_4096x25_k4_full_chunk16': traffic('void wurm::multi_rollout_kernel<true>', 524288),
+    'multi_rollout_cfg4_4096x25_k4_full_chunk16': traffic('void wurm::multi_rollout_kernel<true>', 524288, (0, 2)),
+    'multi_rollout_speeds_4096x36_k10_chunk4': traffic('void wurm::multi_rollout_kernel<true>', 524288, (1, 2)),
+    'multi_rollout_cfg4prime_4096x25_k4_partial5_chunk16': traffic('void wurm::multi_rollout_kernel<false>', 262144),
     'fused_step_512x9_partial2': traffic('void wurm::fused_step_kernel<2, true>', 32768),
     'fused_step_8192x9_partial2': traffic('void wurm::fused_step_kernel<2, true>', 524288),
     'fused_step_65536x9_partial2': traffic('void wurm::fused_step_kernel<2, true>', 4194304),
     'lane_step_65536x9_partial2': traffic('void wurm::lane_step_kernel<16, 9>', 262144),
-    'multi_step_cfg4_4096x25_k4_full': traffic('wurm::multi_step_kernel', 262144),
+    'multi_step_cfg4_4096x25_k4_full': traffic('wurm::multi_step_kernel', 262144, (3, 5)),  # dispatch order: 20 launches of cfg4', then 30 of cfg4
+    'per_call_api_cfg4prime_4096x25_k4_partial5': traffic('wurm::multi_step_kernel', 262144, (0, 5)),
+    'per_call_api_speeds_4096x36_k10': traffic('wurm::multi_step_wg_kernel', 1048576),
     'grid_step_8192x36_default': traffic('void wurm::(anonymous namespace)::grid_step_kernel<true>', 524288),
 }
 out = {

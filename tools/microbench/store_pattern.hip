@@ -29,8 +29,25 @@ __global__ __launch_bounds__(256) void k(float *out, int T, long long N)
             for (int a = 0; a < K; ++a) { float *b = o + a * as; for (int kk = 0; kk < cpl; ++kk) { int c = lane + 64 * kk; if (c < C) { b[c] = v; b[C + c] = v; b[2 * C + c] = v; } } }
         } else if (MODE == 2) {
             for (int a = 0; a < K; ++a) { float *b = o + a * as; for (int i = lane; i < E; i += 64) b[i] = v; }
-        } else {
+        } else if (MODE == 3) {
             for (int a = 0; a < K; ++a) { float *b = o + a * as; for (int i = 4 * lane; i < E; i += 256) { if (i + 3 < E) *(vf4 *)(b + i) = vf4{v, v, v, v}; else for (int j = i; j < E; ++j) b[j] = v; } }
+        } else if (MODE == 4) {
+            // x4 on absolute 16-byte boundaries: head floats up to the boundary and tail floats as dword stores
+            for (int a = 0; a < K; ++a) {
+                float *b = o + a * as;
+                const int h = (int)(((16 - ((size_t)b & 15)) & 15) >> 2);       // floats before the first boundary
+                if (lane < h) b[lane] = v;
+                const int n4 = (E - h) >> 2;
+                for (int i = lane; i < n4; i += 64) *(vf4 *)(b + h + 4 * i) = vf4{v, v, v, v};
+                const int t0 = h + 4 * n4;
+                if (t0 + lane < E) b[t0 + lane] = v;
+            }
+        } else {
+            // 4 waves of a workgroup = 4 consecutive envs: wave w writes AGENT w's regions of all four envs (30 000 contiguous,
+            // 16-byte aligned bytes), x4
+            const long long env0 = (long long)blockIdx.x * 4;
+            float *b = out + (((long long)t * K + wave) * N + env0) * E;
+            for (int i = lane; i < 4 * E / 4; i += 64) *(vf4 *)(b + 4 * i) = vf4{v, v, v, v};
         }
     }
 }
@@ -52,12 +69,17 @@ static void run(const char *name, float *buf, int T, long long N, int wpb)
 int main()
 {
     const long long N = 4096; const int T = 16;
-    float *buf; hipMalloc(&buf, 4ull * 7500 * T * N);
+    float *buf; hipMalloc(&buf, 4ull * 7500 * 64 * N);
     for (int wpb : {1, 4}) {
         run<0>("rows", buf, T, N, wpb);
         run<1>("agents", buf, T, N, wpb);
         run<2>("planes", buf, T, N, wpb);
         run<3>("x4", buf, T, N, wpb);
+        run<4>("x4peel", buf, T, N, wpb);
     }
+    run<5>("x4by4env", buf, T, N, 4);
+    run<5>("x4by4env", buf, 64, N, 4);
+    run<4>("x4peel", buf, 64, N, 4);
+    run<1>("agents", buf, 64, N, 4);
     return 0;
 }

@@ -14,8 +14,11 @@ for path in sys.argv[1:]:
             if 'wurm::' not in name and 'copy' not in name.lower() and 'elementwise' not in name:
                 continue
             key = f"{name[:90]}|grid={row.get('Grid_Size', row.get('Grid_Size_X', '?'))}"
-            acc[key][row['Counter_Name']].append(float(row['Counter_Value']))
+            acc[key][row['Counter_Name']].append((int(row.get('Dispatch_Id', 0)), float(row['Counter_Value'])))
 out = {}
 for key, counters in acc.items():
-    out[key] = {c: {'launches': len(v), 'mean': sum(v) / len(v), 'min': min(v), 'max': max(v)} for c, v in counters.items()}
+    out[key] = {}
+    for c, dv in counters.items():
+        v = [x for _, x in sorted(dv)]  # in dispatch order: tools/make_traffic_json.py splits runs of one kernel by position
+        out[key][c] = {'launches': len(v), 'mean': sum(v) / len(v), 'min': min(v), 'max': max(v), 'values': v}
 print(json.dumps(out, indent=1))

@@ -52,6 +52,29 @@ for c in range(0, 16 * 5, 16):
     env.rollout(actions[c:c + 16])
 torch.cuda.synchronize()
 del env, actions
+# measured: the MultiSnake variants the reference itself runs — training dynamics with partial_5 crops
+# (tests/test_multi_snake_env.py:100-104) and the experiments/speeds.py shape (10 agents on 36 x 36) — rollout and per call
+def cfg4prime():
+    return MultiSnake(4096, 4, 25, device=dev, seed=0, respawn_mode='any', food_mode='random_rate', boost_cost_prob=0.25,
+                      observation_mode='partial_5', food_on_death_prob=0.33, food_rate=2.5e-4)
+
+
+def speeds_env():
+    return MultiSnake(4096, 10, 36, device=dev, seed=0, boost=True, respawn_mode='any')
+
+
+for make, K, chunk in ((cfg4prime, 4, 16), (speeds_env, 10, 4)):
+    env = make()
+    actions = torch.randint(8, (chunk * 5, K, 4096), device=dev, dtype=torch.int64)
+    for c in range(0, chunk * 5, chunk):
+        env.rollout(actions[c:c + chunk])
+    torch.cuda.synchronize()
+    env = make()
+    for t in range(20):
+        _, _, d, _ = env.step({f'agent_{i}': actions[t, i] for i in range(K)})
+        env.reset(d['__all__'], return_observations=False)
+    torch.cuda.synchronize()
+    del env, actions
 # measured: the per-call loop (one fused launch per `step(a); reset(done)` iteration) at cfg2, cfg3-share, cfg3, cfg5
 for N, S, mode in ((512, 9, 'partial_2'), (8192, 9, 'partial_2'), (65536, 9, 'partial_2'), (8192, 36, 'default')):
     env = SingleSnake(num_envs=N, size=S, observation_mode=mode, device=dev, seed=0)

@@ -1532,6 +1532,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void m
 
 // check_consistency (:733-769) -> per-env bitmask.  Every plane is read once: the per-cell count of snakes (overlap test)
 // is kept in LDS, one byte per cell; a cell belongs to one lane, so plain read-modify-writes.
+// The env's planes are walked as ITEMS of (snake, 8 rows of 64 cells), double-buffered in registers: the 16 loads of item
+// i + 1 are in flight while item i is reduced (round 2 issued a snake's loads, waited, reduced, and only then touched the
+// next snake: five dependent memory round trips per env at K = 4, 2.6 TB/s).
+constexpr int MCHK_U = 8;
+
+__device__ __forceinline__ void mchk_load(const float *__restrict__ hp, const float *__restrict__ bp, int k0, int lane, int C,
+                                          float (&h)[MCHK_U], float (&b)[MCHK_U])
+{
+#pragma unroll
+    for (int j = 0; j < MCHK_U; ++j) {
+        const int c = lane + 64 * (k0 + j);
+        const bool in = c < C;
+        h[j] = in ? hp[c] : 0.0f;
+        b[j] = in ? bp[c] : 0.0f;
+    }
+}
+
 __global__ __launch_bounds__(256) void multi_check_kernel(MultiArgs p)
 {
     const int wave = (int)(threadIdx.x >> 6), wpb = (int)(blockDim.x >> 6);
@@ -1540,6 +1557,10 @@ __global__ __launch_bounds__(256) void multi_check_kernel(MultiArgs p)
     const int S = p.S, C = S * S, K = p.K, lane = (int)(threadIdx.x & 63u), cpl = (C + 63) >> 6;
     unsigned char *cnt = wurm_multi_lds + (size_t)wave * p.lds_per_wave;
     const float *foodp = p.foods + env * C;
+    const float *heads = p.heads + env * K * C, *bodies = p.bodies + env * K * C;
+    const int nchunk = (cpl + MCHK_U - 1) / MCHK_U, nitems = K * nchunk;
+    float hA[MCHK_U], bA[MCHK_U], hB[MCHK_U], bB[MCHK_U];
+    mchk_load(heads, bodies, 0, lane, C, hA, bA); // item 0 is in flight while the food plane is checked
     uint32_t m = 0;
     int badf = 0;
     for (int k = 0; k < cpl; ++k) {
@@ -1552,36 +1573,48 @@ __global__ __launch_bounds__(256) void multi_check_kernel(MultiArgs p)
     }
     const bool bad_food = ballot(badf != 0) != 0;
     bool any_alive = false;
-    for (int s = 0; s < K; ++s) {
-        const float *hp = p.heads + (env * K + s) * C, *bp = p.bodies + (env * K + s) * C;
-        const bool dead = p.dones[env * K + s] != 0;
-        int hs = 0, bs = 0, bm = 0, hb = 0, hf = 0, nz = 0;
-#pragma unroll 4
-        for (int k = 0; k < cpl; ++k) {
-            int c = lane + 64 * k;
+    int hs = 0, bs = 0, bm = 0, hb = 0, hf = 0, nz = 0; // per-lane partials of the current snake
+    auto reduce_item = [&](int item, const float (&h)[MCHK_U], const float (&b)[MCHK_U]) {
+        const int s = item / nchunk, k0 = (item - s * nchunk) * MCHK_U;
+#pragma unroll
+        for (int j = 0; j < MCHK_U; ++j) {
+            const int c = lane + 64 * (k0 + j);
             if (c < C) {
-                const float h = hp[c], b = bp[c];
-                const int hi = __float2int_rn(h), bi = __float2int_rn(b);
+                const int hi = __float2int_rn(h[j]), bi = __float2int_rn(b[j]);
                 hs += hi; bs += bi; hb += hi * bi;
                 if (hi != 0) hf += hi * __float2int_rn(foodp[c]); // at the head cells only (one per snake)
                 bm = max(bm, bi);
-                nz |= (h != 0.0f) || (b != 0.0f);
-                if (b > 1e-6f) cnt[c] += 1;
+                nz |= (h[j] != 0.0f) || (b[j] != 0.0f);
+                if (b[j] > 1e-6f) cnt[c] += 1;
             }
         }
-        if (dead) {
-            if (ballot(nz != 0)) m |= WURM_MCHK_DEAD_NONZERO;
-            continue;
+        if (k0 + MCHK_U >= cpl) { // the snake's last item: its verdict
+            const bool dead = p.dones[env * K + s] != 0;
+            if (dead) {
+                if (ballot(nz != 0)) m |= WURM_MCHK_DEAD_NONZERO;
+            } else {
+                any_alive = true;
+                const int t_hs = wave_sum_i32(hs), t_bs = wave_sum_i32(bs), t_hb = wave_sum_i32(hb), t_hf = wave_sum_i32(hf);
+                const int t_bm = wave_max_i32(bm);
+                if (t_hs != 1) m |= WURM_CHK_ONE_HEAD;
+                if (!(t_bs > 0)) m |= WURM_CHK_HAS_SNAKE;
+                if (t_bm != t_hb) m |= WURM_CHK_HEAD_AT_END;
+                if (2 * t_bs != t_bm * (t_bm + 1)) m |= WURM_CHK_BODY_RANGE;
+                if (!(t_bs >= 6)) m |= WURM_CHK_MIN_LENGTH;
+                if (t_hf != 0) m |= WURM_CHK_HEAD_ON_FOOD;
+            }
+            hs = bs = bm = hb = hf = nz = 0;
         }
-        any_alive = true;
-        hs = wave_sum_i32(hs); bs = wave_sum_i32(bs); hb = wave_sum_i32(hb); hf = wave_sum_i32(hf);
-        bm = wave_max_i32(bm);
-        if (hs != 1) m |= WURM_CHK_ONE_HEAD;
-        if (!(bs > 0)) m |= WURM_CHK_HAS_SNAKE;
-        if (bm != hb) m |= WURM_CHK_HEAD_AT_END;
-        if (2 * bs != bm * (bm + 1)) m |= WURM_CHK_BODY_RANGE;
-        if (!(bs >= 6)) m |= WURM_CHK_MIN_LENGTH;
-        if (hf != 0) m |= WURM_CHK_HEAD_ON_FOOD;
+    };
+    auto issue = [&](int item, float (&h)[MCHK_U], float (&b)[MCHK_U]) {
+        const int s = item / nchunk, k0 = (item - s * nchunk) * MCHK_U;
+        mchk_load(heads + s * C, bodies + s * C, k0, lane, C, h, b);
+    };
+    for (int it = 0; it < nitems; it += 2) {
+        if (it + 1 < nitems) issue(it + 1, hB, bB);
+        reduce_item(it, hA, bA);
+        if (it + 2 < nitems) issue(it + 2, hA, bA);
+        if (it + 1 < nitems) reduce_item(it + 1, hB, bB);
     }
     if (any_alive && bad_food) m |= WURM_CHK_FOOD_VALUE; // reported per living snake by the loop this replaces
     int over = 0;
@@ -1634,6 +1667,15 @@ static int multi_layout(MultiArgs &p, bool need_img, int need_snap)
 
 enum MKind { MK_STEP, MK_RESET, MK_OBSERVE, MK_CHECK, MK_ROLLOUT };
 
+constexpr int LDS_MAX_BYTES = 160 * 1024; // per workgroup on CDNA4 (MI355X_MICROARCH.md)
+
+// dynamic LDS beyond the default 64 KB of a launch needs the kernel's opt-in
+static bool allow_lds(const void *kernel, size_t bytes)
+{
+    if (bytes <= 65536) return true;
+    return hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess;
+}
+
 static int multi_launch(MKind kind, MultiArgs &p, void *stream)
 {
     if (p.N == 0) return WURM_OK;
@@ -1643,14 +1685,17 @@ static int multi_launch(MKind kind, MultiArgs &p, void *stream)
     const bool two = kind == MK_ROLLOUT && snap && p.T > 1;
     int lds = multi_layout(p, p.obs_mode == WURM_OBS_PARTIAL, snap ? (two ? 2 : 1) : 0);
     if (kind == MK_CHECK) lds = p.lds_per_wave = (p.S * p.S + 15) & ~15; // the checker keeps one byte per cell
-    if (lds > 65536) return WURM_ERR_UNSUPPORTED;
+    // One env's grids must fit the LDS of a CU.  Up to 64 KB is the default limit of a launch; beyond it the kernel is
+    // opted into CDNA4's 160 KB per workgroup (one env per CU at a time, e.g. 32 snakes on 36 x 36: 90 KB).  Larger envs
+    // (2 K S^2 + 3 S^2 bytes and change > 160 KB, e.g. S = 64 with K > 18) are UNSUPPORTED (DESIGN.md §5 deviation 10).
+    if (lds > LDS_MAX_BYTES) return WURM_ERR_UNSUPPORTED;
     // few envs: one wave per workgroup so that they spread over all 256 CUs; from 2048 envs on 4 waves per workgroup
     // (8 workgroups per CU either way; the observation stream of 4096 envs measured ~5 % faster this way)
     int wpb = p.N < 2048 ? 1 : 4;
     if (two) { // one env per workgroup of two waves
-        if (lds > 65536) return WURM_ERR_UNSUPPORTED;
         dim3 block2(128), grid2((unsigned)p.N);
         (void)hipGetLastError();
+        if (!allow_lds((const void *)multi_rollout_kernel<true>, (size_t)lds)) return WURM_ERR_HIP;
         hipLaunchKernelGGL(multi_rollout_kernel<true>, grid2, block2, (size_t)lds, (hipStream_t)stream, p);
         return hipGetLastError() == hipSuccess ? WURM_OK : WURM_ERR_HIP;
     }
@@ -1659,6 +1704,9 @@ static int multi_launch(MKind kind, MultiArgs &p, void *stream)
         // an env too large for four per workgroup: one env per workgroup of four waves (multi_step_wg_kernel)
         (void)hipGetLastError();
         const dim3 g((unsigned)p.N), b(256);
+        const void *kf = kind == MK_STEP ? (const void *)multi_step_wg_kernel
+                       : kind == MK_RESET ? (const void *)multi_reset_wg_kernel : (const void *)multi_observe_wg_kernel;
+        if (!allow_lds(kf, (size_t)lds)) return WURM_ERR_HIP;
         if (kind == MK_STEP) hipLaunchKernelGGL(multi_step_wg_kernel, g, b, (size_t)lds, (hipStream_t)stream, p);
         else if (kind == MK_RESET) hipLaunchKernelGGL(multi_reset_wg_kernel, g, b, (size_t)lds, (hipStream_t)stream, p);
         else hipLaunchKernelGGL(multi_observe_wg_kernel, g, b, (size_t)lds, (hipStream_t)stream, p);
@@ -1669,6 +1717,11 @@ static int multi_launch(MKind kind, MultiArgs &p, void *stream)
     size_t shmem = (size_t)lds * wpb;
     hipStream_t st = (hipStream_t)stream;
     (void)hipGetLastError();
+    const void *kf = kind == MK_STEP ? (const void *)multi_step_kernel
+                   : kind == MK_RESET ? (const void *)multi_reset_kernel
+                   : kind == MK_OBSERVE ? (const void *)multi_observe_kernel
+                   : kind == MK_CHECK ? (const void *)multi_check_kernel : (const void *)multi_rollout_kernel<false>;
+    if (!allow_lds(kf, shmem)) return WURM_ERR_HIP;
     switch (kind) {
     case MK_STEP: hipLaunchKernelGGL(multi_step_kernel, grid, block, shmem, st, p); break;
     case MK_RESET: hipLaunchKernelGGL(multi_reset_kernel, grid, block, shmem, st, p); break;
