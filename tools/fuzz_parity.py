@@ -153,6 +153,64 @@ def fuzz_lean(rng):
     return desc
 
 
+def fuzz_lane(rng):
+    """The one-env-per-LANE rollout (lane_rollout.hpp), forced at small batch sizes: random envs-per-wave, ragged batches,
+    tape lengths around the chunk / action-batch sizes, hostile action values, chained launches, un-reset envs and
+    hand-edited states between launches (they must fall back to the generic path inside the launch)."""
+    epw = int(rng.choice([4, 8, 16, 32, 64]))
+    N = int(rng.choice([1, 3, epw - 1, epw, epw + 1, 2 * epw + 5, 3 * epw, 200]))
+    mode = ['partial_2', 'partial_2', 'partial_2', 'none'][rng.randint(4)]
+    seed, off = int(rng.randint(1 << 30)), int(rng.randint(1 << 40))
+    desc = f'lane epw={epw} N={N} mode={mode} seed={seed} off={off}'
+    if os.environ.get('WURM_FUZZ_VERBOSE'):
+        print('start:', desc, flush=True)
+    o, h = OracleBackend(seed, off), HipBackend(seed, off)
+    S = 9
+    eo, eh = np.zeros((N, 3, S, S), np.float32), np.zeros((N, 3, S, S), np.float32)
+    o.single_reset(eo, np.ones(N), 'none'); h.single_reset(eh, np.ones(N), 'none')
+    o.call = h.call = int(rng.randint(1 << 50))
+    old = {k: os.environ.get(k) for k in ('WURM_LANE_ROLLOUT_MIN_ENVS', 'WURM_LANE_ROLLOUT_EPW')}
+    os.environ['WURM_LANE_ROLLOUT_MIN_ENVS'], os.environ['WURM_LANE_ROLLOUT_EPW'] = '0', str(epw)
+    try:
+        tc = 64 // epw
+        for launch in range(int(rng.randint(1, 4))):
+            T = int(rng.choice([1, 2, tc - 1, tc, tc + 1, 16 * tc - 1, 16 * tc, 16 * tc + 1, 30, 64, 100, 200]))
+            T = max(T, 1)
+            dtype = np.int64 if rng.rand() < 0.7 else np.int32
+            a = rng.randint(0, 4, (T, N)).astype(dtype)
+            if rng.rand() < 0.3:
+                wild = rng.rand(T, N) < 0.2
+                a[wild] = rng.randint(-50, 50, int(wild.sum()))
+            ao, ah = a.copy(), a.copy()
+            ro, rh = o.single_rollout(eo, ao, mode), h.single_rollout(eh, ah, mode)
+            for k in ro:
+                same(ro[k], rh[k], f'{desc} launch {launch} T={T} {k}')
+            same(ao, ah, f'{desc} launch {launch} actions'); same(eo, eh, f'{desc} launch {launch} state')
+            r = rng.rand()
+            if r < 0.25:   # leave some envs done-but-not-reset for the next launch
+                a1 = rng.randint(0, 4, N).astype(np.int64)
+                for _ in range(int(rng.randint(1, 6))):
+                    o.single_step(eo, a1.copy(), 'none'); h.single_step(eh, a1.copy(), 'none')
+                same(eo, eh, f'{desc} un-reset steps')
+            elif r < 0.4:  # hand-edit a few envs: extra food, head wiped, body value removed
+                for e in rng.randint(0, N, size=min(N, 3)):
+                    kind = rng.randint(3)
+                    if kind == 0:
+                        eo[e, 0, rng.randint(1, 8), rng.randint(1, 8)] = 1
+                    elif kind == 1:
+                        eo[e, 1] = 0
+                    else:
+                        eo[e, 2][eo[e, 2] == 2] = 0
+                eh[...] = eo
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    return desc
+
+
 def fuzz_policy(rng):
     S, n = int(rng.choice([9, 9, 10, 11])), int(rng.randint(0, 4))
     N, T = int(rng.choice([1, 5, 33, 64, 100])), int(rng.choice([1, 7, 64, 65, 130]))
@@ -244,26 +302,61 @@ def fuzz_multi(rng):
     return desc
 
 
+FAMILIES = {'single': fuzz_single, 'fused': fuzz_fused, 'lean': fuzz_lean, 'lane': fuzz_lane, 'policy': fuzz_policy,
+            'grid': fuzz_grid, 'multi': fuzz_multi}
+WEIGHTS = {'single': 0.17, 'fused': 0.17, 'lean': 0.1, 'lane': 0.16, 'policy': 0.05, 'grid': 0.05, 'multi': 0.3}
+
+
+def library_sha256():
+    import hashlib
+    from wurm_amd import _lib
+    return hashlib.sha256(open(_lib.LIB_PATH, 'rb').read()).hexdigest()
+
+
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
     ap.add_argument('--seconds', type=float, default=60)
     ap.add_argument('--seed', type=int, default=0)
+    ap.add_argument('--summary', default=None,
+                    help='append a JSON record of this run (library sha256, seed, cases per family, forced thresholds, '
+                         'mismatches) to this file, e.g. profiles/r03_fuzz_summary.json')
     args = ap.parse_args()
     rng = np.random.RandomState(args.seed)
-    t0, n, fails = time.time(), {'single': 0, 'fused': 0, 'lean': 0, 'policy': 0, 'grid': 0, 'multi': 0}, 0
+    kinds = list(FAMILIES)
+    t0, n, fails, messages = time.time(), {k: 0 for k in kinds}, 0, []
     while time.time() - t0 < args.seconds:
-        kind = ['single', 'fused', 'lean', 'policy', 'grid', 'multi'][rng.choice(6, p=[0.2, 0.2, 0.15, 0.05, 0.05, 0.35])]
+        kind = kinds[rng.choice(len(kinds), p=[WEIGHTS[k] for k in kinds])]
         try:
-            {'single': fuzz_single, 'fused': fuzz_fused, 'lean': fuzz_lean, 'policy': fuzz_policy, 'grid': fuzz_grid,
-             'multi': fuzz_multi}[kind](rng)
+            FAMILIES[kind](rng)
             n[kind] += 1
         except AssertionError as e:
             fails += 1
+            messages.append(str(e)[:600])
             print('MISMATCH:', str(e)[:600])
         except Exception:
             fails += 1
+            messages.append(traceback.format_exc()[-600:])
             traceback.print_exc()
         if fails >= 5:
             break
-    print(f'fuzz done: {n} cases, {fails} failures, {time.time() - t0:.0f} s')
+    elapsed = time.time() - t0
+    print(f'fuzz done: {n} cases, {fails} failures, {elapsed:.0f} s')
+    if args.summary:
+        import json
+        rec = {'library_sha256': library_sha256(), 'seed': args.seed, 'seconds': round(elapsed, 1), 'cases': n,
+               'total_cases': sum(n.values()), 'mismatches': fails, 'messages': messages,
+               'forced_thresholds': {k: os.environ[k] for k in ('WURM_LANE_STEP_MIN_ENVS', 'WURM_GRID_STEP_MIN_CELLS',
+                                                                 'WURM_LANE_ROLLOUT_MIN_ENVS', 'WURM_LANE_ROLLOUT_EPW')
+                                     if k in os.environ},
+               'bar': 'bit-exact HIP (C ABI) vs oracle on every output of every step'}
+        runs = []
+        if os.path.exists(args.summary):
+            try:
+                runs = json.load(open(args.summary))['runs']
+            except Exception:
+                runs = []
+        runs.append(rec)
+        json.dump({'what': 'tools/fuzz_parity.py runs on the GPU box (one record per run)', 'runs': runs,
+                   'total_cases': sum(r['total_cases'] for r in runs),
+                   'total_mismatches': sum(r['mismatches'] for r in runs)}, open(args.summary, 'w'), indent=1)
     sys.exit(1 if fails else 0)
