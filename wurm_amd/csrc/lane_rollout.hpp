@@ -30,12 +30,13 @@
 
 #include <type_traits>
 
+#include "lane_load.hpp"
+
 namespace wurm {
 
 constexpr int LR_C = 81, LR_C3 = 243, LR_E = 75; // cells, state floats and crop floats per env
 constexpr int LR_VS = 68;                        // bytes per env of the value -> cell table (17 dwords)
 constexpr int LR_BM = 84;                        // bytes per env of the body map written back (21 dwords)
-constexpr int LR_QCAP = 512;                     // entries of the non-zero queue (drained when fewer than 256 are free)
 constexpr int LR_TAB = 4096 + 656;               // workgroup tables: 256 x float4, 81 x u64 window-interior masks
 
 // per-wave LDS (bytes)
@@ -50,7 +51,7 @@ struct LaneRollLds {
     static constexpr int FPOS = HPOS + EPW;                // u8  [EPW]
     static constexpr int VALPOS = FPOS + EPW;              // u8  [EPW][LR_VS]
     static constexpr int QUEUE = (VALPOS + EPW * LR_VS + 7) & ~7; // u64 [LR_QCAP] non-zero elements found by the state read
-    static constexpr int START_END = QUEUE + 8 * LR_QCAP;
+    static constexpr int START_END = QUEUE + 8 * LANE_QCAP;
     static constexpr int BMAP = SCR;                       // u8  [EPW][LR_BM] body values by cell (end of launch, slow path)
     static constexpr int HC = BMAP + EPW * LR_BM;          // s16 [EPW] head cell (-1: env not written back)
     static constexpr int FC = HC + 2 * EPW;                // s16 [EPW] food cell (-1: none)
@@ -216,63 +217,8 @@ __global__ __launch_bounds__(256) void lane_rollout_kernel(StepArgs p)
     wave_lds_sync();
     const bool whole = nenv == EPW && (((size_t)p.envs) & 15u) == 0; // full block, 16-byte aligned (env0 is a multiple of 4)
     if (whole) {
-        // The block as EPW * 243 / 4 float4.  About 2 % of the elements are non-zero: each wave-wide slot (j, k) compacts
-        // its non-zero (element index, value) pairs into a queue with one ballot + prefix count, and the queue is decoded
-        // 64 entries at a time — so the division-heavy decode runs once per 64 non-zero elements, not once per slot.
-        constexpr int N4 = EPW * LR_C3 / 4, B4 = 16; // B4 loads in flight per lane
-        const float4 *base4 = (const float4 *)(p.envs + env0 * LR_C3);
-        u64 *queue = (u64 *)(lds + Lds::QUEUE);
-        int qn = 0; // wave-uniform
-        auto drain = [&]() {
-            wave_lds_sync();
-            for (int i = lane; i < qn; i += 64) {
-                const u64 ent = queue[i];
-                const float val = __uint_as_float((u32)ent);
-                const int f = (int)(ent >> 32), ej = f / LR_C3, r = f - ej * LR_C3, ch = r / LR_C, cj = r - ch * LR_C;
-                if (ch == 0) {
-                    if (val > 0.5f) { fpos[ej] = (unsigned char)cj; atomicAdd(&stat[ej], 1u << 16); }
-                } else if (ch == 1) {
-                    if (val > 0.5f) { hpos[ej] = (unsigned char)cj; atomicAdd(&stat[ej], 1u << 8); }
-                } else {
-                    const int bi = __float2int_rn(val);
-                    if (bi > 0 && bi < 64) {
-                        valpos[ej * LR_VS + bi] = (unsigned char)cj;
-                        atomicOr(&vm[(bi >> 5) * EPW + ej], 1u << (bi & 31));
-                        atomicAdd(&stat[ej], 1u);
-                    } else if (bi != 0) {
-                        atomicAdd(&stat[ej], 1u << 24);
-                    }
-                }
-            }
-            wave_lds_sync();
-            qn = 0;
-        };
-        for (int i0 = 0; i0 < N4; i0 += 64 * B4) {
-            float x[B4], y[B4], z[B4], w[B4];
-#pragma unroll
-            for (int j = 0; j < B4; ++j) {
-                const int g = i0 + 64 * j + lane;
-                const float4 v = base4[min(g, N4 - 1)];
-                x[j] = v.x; y[j] = v.y; z[j] = v.z; w[j] = v.w;
-            }
-#pragma unroll
-            for (int j = 0; j < B4; ++j) {
-                const int g = i0 + 64 * j + lane;
-                if (i0 + 64 * j >= N4) break;
-                if (qn > LR_QCAP - 256) drain();
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const float val = k == 0 ? x[j] : k == 1 ? y[j] : k == 2 ? z[j] : w[j];
-                    const bool nz = g < N4 && val != 0.0f;
-                    const u64 m = ballot(nz);
-                    if (m != 0) {
-                        if (nz) queue[qn + rank_below(m)] = ((u64)(u32)(4 * g + k) << 32) | (u64)__float_as_uint(val);
-                        qn += popc64(m);
-                    }
-                }
-            }
-        }
-        drain();
+        lane_load_block<EPW, LR_C, 2, LR_VS>(p.envs + env0 * LR_C3, lane, vm, stat, hpos, fpos, valpos,
+                                             (u64 *)(lds + Lds::QUEUE));
     } else {
         constexpr int LOADS = 9;
         const char *base = (const char *)(p.envs + env0 * LR_C3);

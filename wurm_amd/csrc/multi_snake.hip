@@ -549,7 +549,11 @@ struct StepRes {
     bool snakecol, edgecol, all_done;
 };
 
-// 'partial_n' observation (:289-332): env image (_get_env_images :194-227) into LDS, then one crop per agent
+// 'partial_n' observation (:289-332): the crop of the env image (_get_env_images :194-227) around each living head.
+// Round 2 rendered the whole image into LDS (8 bytes per cell) and cropped it; the K windows hold K (2n+1)^2 cells —
+// 484 against the image's 625 at K = 4, 25 x 25, partial_5 — so the pixels are now computed for the (agent, window cell)
+// PAIRS directly, 64 per pass with no idle lanes: no image buffer (5 KB of LDS per env less: 4096 envs of cfg4' are
+// resident in one round instead of 1.33), no image write + read, the same pixel function of the cell as before.
 __device__ __forceinline__ void observe_partial(const Ctx &cx, const MultiArgs &p, float *__restrict__ obs,
                                                 long long env, const Snake &sn)
 {
@@ -558,14 +562,14 @@ __device__ __forceinline__ void observe_partial(const Ctx &cx, const MultiArgs &
         cx.colf[lane * 4 + 0] = (float)sn.col[0];
         cx.colf[lane * 4 + 1] = (float)sn.col[1];
         cx.colf[lane * 4 + 2] = (float)sn.col[2];
-        cx.colf[lane * 4 + 3] = 1.0f + 0.5f * (sn.boosted ? 1.0f : 0.0f); // :198
+        // :198 the brightening of a boosting snake; the SIGN carries "this observer is dead" (zeros, :320-323)
+        cx.colf[lane * 4 + 3] = (1.0f + 0.5f * (sn.boosted ? 1.0f : 0.0f)) * (sn.done ? -1.0f : 1.0f);
         cx.hcell[lane] = sn.hc;
     }
     wave_lds_sync();
     // Which snakes are on a cell: four snakes per pass with their clocks and head cells in registers, so that the body
     // reads of one cell are independent LDS loads issued together; only the snakes found there enter the colour sum
-    // (in ascending index, the reference's summation order :201-205).  The pixel goes to LDS as one 8-byte record
-    // {r, g, b, 0} of shorts.  (Measured at 4096 x 25 x 25 x 4: this pass was 11.6 us of a 30 us step.)
+    // (in ascending index, the reference's summation order :201-205).
     int tk[4], hk[4];
     auto four = [&](int s0) {
 #pragma unroll
@@ -576,65 +580,55 @@ __device__ __forceinline__ void observe_partial(const Ctx &cx, const MultiArgs &
         }
     };
     four(0);
-    typedef short short4v __attribute__((ext_vector_type(4)));
-    short4v *img4 = (short4v *)cx.img;
-    for (int k = 0; k < cx.cpl; ++k) {
-        int c = lane + 64 * k;
-        if (c >= C) continue;
-        int y = div_size(c, cx.rcpS), x = c - y * S;
-        float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;
-        for (int s0 = 0; s0 < K; s0 += 4) {
-            if (K > 4) four(s0); // more than four snakes: the registers are re-filled per pass
-            unsigned short bv[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) bv[j] = cx.body[min(s0 + j, K - 1) * C + c];
-            u32 mb = 0, mh = 0;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                mb |= (u32)((int)(bv[j] & VMASK) > tk[j]) << j;
-                mh |= (u32)(hk[j] == c) << j;
-            }
-            for (u32 m = mb | mh; m; m &= m - 1) {
-                const int j = __ffs((int)m) - 1, s = s0 + j;
-                // :197 `body.float() * 1/3 + head.float() * 1/3`: 1.0f / 3.0f is the correctly rounded quotient the two
-                // IEEE divisions gave; a snake that is not on the cell adds inten = 0, i.e. nothing, to each channel
-                const float third = 1.0f / 3.0f;
-                float inten = (((mb >> j) & 1u) ? third : 0.0f) + (((mh >> j) & 1u) ? third : 0.0f);
-                inten *= cx.colf[s * 4 + 3];
-                a0 += inten * cx.colf[s * 4 + 0];
-                a1 += inten * cx.colf[s * 4 + 1];
-                a2 += inten * cx.colf[s * 4 + 2];
-            }
-        }
-        int r = (int)a0, g = (int)a1, b = (int)a2; // :206 .short() truncates
-        if (cx.food[c]) r += 255;                   // :208-209
-        if (r == 0 && g == 0 && b == 0) r = g = b = 255; // :214-219
-        if (y == 0 || x == 0 || y == S - 1 || x == S - 1) r = g = b = 0; // :225
-        short4v px = {(short)r, (short)g, (short)b, 0};
-        img4[c] = px;
-    }
-    wave_lds_sync();
-    const int W = 2 * n + 1, W2 = W * W;
-    const float rcpW = 1.0f / (float)W;
-    for (int a = 0; a < K; ++a) {
-        const int h = lane_value(sn.hc, a);
-        const bool dead = lane_value((int)sn.done, a) != 0;
+    const int W = 2 * n + 1, W2 = W * W, pairs = K * W2;
+    const float rcpW = 1.0f / (float)W, rcpW2 = 1.0f / (float)W2;
+    const long long agent_stride = p.N * p.obs_elems;
+    float *const o_env = obs + env * p.obs_elems;
+    for (int idx = lane; idx < pairs; idx += 64) {
+        const int a = div_size(idx, rcpW2), w = idx - a * W2;
+        const int wy = div_size(w, rcpW), wx = w - wy * W;
+        const int h = cx.colf[a * 4 + 3] < 0.0f ? -1 : cx.hcell[a];
         const int hy = h >= 0 ? div_size(h, cx.rcpS) : 0, hx = h - hy * S;
-        float *o = obs + ((long long)a * p.N + env) * p.obs_elems;
-        for (int w = lane; w < W2; w += 64) { // one window cell per lane: its three channel values
-            const int wy = div_size(w, rcpW), wx = w - wy * W;
-            const int y = hy - n + wy, x = hx - n + wx;
-            float r = 0.0f, g = 0.0f, b = 0.0f; // dead snakes (:320-323) and the zero padding (:302)
-            if (!dead && h >= 0 && y >= 0 && y < S && x >= 0 && x < S) {
-                const short4v px = img4[y * S + x];
-                r = (float)px.x / 255.0f;
-                g = (float)px.y / 255.0f;
-                b = (float)px.z / 255.0f;
+        const int y = hy - n + wy, x = hx - n + wx;
+        float r = 0.0f, g = 0.0f, b = 0.0f; // dead snakes (:320-323) and the zero padding (:302)
+        if (h >= 0 && y >= 0 && y < S && x >= 0 && x < S) {
+            const int c = y * S + x;
+            float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;
+            for (int s0 = 0; s0 < K; s0 += 4) {
+                if (K > 4) four(s0); // more than four snakes: the registers are re-filled per pass
+                unsigned short bv[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bv[j] = cx.body[min(s0 + j, K - 1) * C + c];
+                u32 mb = 0, mh = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    mb |= (u32)((int)(bv[j] & VMASK) > tk[j]) << j;
+                    mh |= (u32)(hk[j] == c) << j;
+                }
+                for (u32 m = mb | mh; m; m &= m - 1) {
+                    const int j = __ffs((int)m) - 1, s = s0 + j;
+                    // :197 `body.float() * 1/3 + head.float() * 1/3`: 1.0f / 3.0f is the correctly rounded quotient the
+                    // two IEEE divisions gave; a snake that is not on the cell adds inten = 0, i.e. nothing
+                    const float third = 1.0f / 3.0f;
+                    float inten = (((mb >> j) & 1u) ? third : 0.0f) + (((mh >> j) & 1u) ? third : 0.0f);
+                    inten *= fabsf(cx.colf[s * 4 + 3]);
+                    a0 += inten * cx.colf[s * 4 + 0];
+                    a1 += inten * cx.colf[s * 4 + 1];
+                    a2 += inten * cx.colf[s * 4 + 2];
+                }
             }
-            o[w] = r;
-            o[W2 + w] = g;
-            o[2 * W2 + w] = b;
+            int ri = (int)a0, gi = (int)a1, bi = (int)a2;     // :206 .short() truncates
+            if (cx.food[c]) ri += 255;                          // :208-209
+            if (ri == 0 && gi == 0 && bi == 0) ri = gi = bi = 255; // :214-219
+            if (y == 0 || x == 0 || y == S - 1 || x == S - 1) ri = gi = bi = 0; // :225
+            r = (float)ri / 255.0f;
+            g = (float)gi / 255.0f;
+            b = (float)bi / 255.0f;
         }
+        float *o = o_env + (long long)a * agent_stride;
+        o[w] = r;
+        o[W2 + w] = g;
+        o[2 * W2 + w] = b;
     }
     wave_lds_sync();
 }
@@ -1656,7 +1650,7 @@ static int multi_layout(MultiArgs &p, bool need_img, int need_snap)
     off = (off + 15) & ~15;
     p.off_hmap = off; off += C;
     off = (off + 15) & ~15;
-    p.off_img = off; if (need_img) off += 8 * C; // {r, g, b, 0} shorts per cell
+    p.off_img = off; (void)need_img;        // (round 2 kept the env image of partial_n here: 8 bytes per cell)
     off = (off + 15) & ~15;
     p.off_snap = -1;
     if (need_snap) { p.off_snap = off; off += need_snap * ((2 * C + 15) & ~15); }
