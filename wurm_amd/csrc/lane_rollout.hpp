@@ -50,8 +50,8 @@ struct LaneRollLds {
     static constexpr int HPOS = STAT + 4 * EPW;            // u8  [EPW]
     static constexpr int FPOS = HPOS + EPW;                // u8  [EPW]
     static constexpr int VALPOS = FPOS + EPW;              // u8  [EPW][LR_VS]
-    static constexpr int QUEUE = (VALPOS + EPW * LR_VS + 7) & ~7; // u64 [LR_QCAP] non-zero elements found by the state read
-    static constexpr int START_END = QUEUE + 8 * LANE_QCAP;
+    static constexpr int QUEUE = (VALPOS + EPW * LR_VS + 15) & ~15; // non-zero float4s found by the state read (lane_load.hpp)
+    static constexpr int START_END = QUEUE + LANE_QUEUE_BYTES;
     static constexpr int BMAP = SCR;                       // u8  [EPW][LR_BM] body values by cell (end of launch, slow path)
     static constexpr int HC = BMAP + EPW * LR_BM;          // s16 [EPW] head cell (-1: env not written back)
     static constexpr int FC = HC + 2 * EPW;                // s16 [EPW] food cell (-1: none)
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256) void lane_rollout_kernel(StepArgs p)
     const bool whole = nenv == EPW && (((size_t)p.envs) & 15u) == 0; // full block, 16-byte aligned (env0 is a multiple of 4)
     if (whole) {
         lane_load_block<EPW, LR_C, 2, LR_VS>(p.envs + env0 * LR_C3, lane, vm, stat, hpos, fpos, valpos,
-                                             (u64 *)(lds + Lds::QUEUE));
+                                             lds + Lds::QUEUE);
     } else {
         constexpr int LOADS = 9;
         const char *base = (const char *)(p.envs + env0 * LR_C3);

@@ -43,8 +43,8 @@ struct LaneLds {
     static constexpr int DESC = FPOS + EPW;               // 2 x { short h[EPW], short f[EPW], u64 B[2][EPW] }
     static constexpr int DESC_BYTES = 20 * EPW;
     static constexpr int VALPOS = DESC + 2 * DESC_BYTES;  // u8  [EPW][LANE_VS]
-    static constexpr int QUEUE = (VALPOS + EPW * LANE_VS + 7) & ~7; // u64 [LANE_QCAP] non-zero elements of the state read
-    static constexpr int BYTES = (QUEUE + 8 * LANE_QCAP + 15) & ~15;
+    static constexpr int QUEUE = (VALPOS + EPW * LANE_VS + 15) & ~15; // non-zero float4s of the state read (lane_load.hpp)
+    static constexpr int BYTES = (QUEUE + LANE_QUEUE_BYTES + 15) & ~15;
 };
 
 struct Mask128 {
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256) void lane_step_kernel(LaneArgs a)
     // an odd base address) lanes = (env, cell) pairs, three dwords each (food, head, body)
     constexpr int LANE_LOADS = EPW >= 16 ? 11 : 8; // pairs (= 3 loads each) in flight per lane: EPW * C / 64 pairs in all
     if (nenv == EPW && (((size_t)p.envs) & 15u) == 0) {
-        lane_load_block<EPW, C, 4, LANE_VS>(p.envs + env0 * C3, lane, vm, stat, hpos, fpos, valpos, (u64 *)(lds + Lds::QUEUE));
+        lane_load_block<EPW, C, 4, LANE_VS>(p.envs + env0 * C3, lane, vm, stat, hpos, fpos, valpos, lds + Lds::QUEUE);
     } else
     {
         const char *base = (const char *)(p.envs + env0 * C3);

@@ -1526,10 +1526,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void m
 
 // check_consistency (:733-769) -> per-env bitmask.  Every plane is read once: the per-cell count of snakes (overlap test)
 // is kept in LDS, one byte per cell; a cell belongs to one lane, so plain read-modify-writes.
-// The env's planes are walked as ITEMS of (snake, 8 rows of 64 cells), double-buffered in registers: the 16 loads of item
+// The env's planes are walked as ITEMS of (snake, 11 rows of 64 cells), double-buffered in registers: the 16 loads of item
 // i + 1 are in flight while item i is reduced (round 2 issued a snake's loads, waited, reduced, and only then touched the
 // next snake: five dependent memory round trips per env at K = 4, 2.6 TB/s).
-constexpr int MCHK_U = 8;
+constexpr int MCHK_U = 11; // 25 x 25: a snake is one item, 36 x 36: two (11 + 10 rows)
 
 __device__ __forceinline__ void mchk_load(const float *__restrict__ hp, const float *__restrict__ bp, int k0, int lane, int C,
                                           float (&h)[MCHK_U], float (&b)[MCHK_U])
