@@ -12,7 +12,7 @@
 typedef float vf4 __attribute__((ext_vector_type(4)));
 typedef float vf3 __attribute__((ext_vector_type(3)));
 
-enum { COOP_X4 = 0, COOP_DWORD = 1, LANE_X4 = 2 };
+enum { COOP_X4 = 0, COOP_DWORD = 1, LANE_X4 = 2, COOP_X4_NT = 3 };
 
 template <int MODE, int EPW, int VALU>
 __global__ __launch_bounds__(64) void k(float *out, long long N, int T, int shift)
@@ -28,7 +28,7 @@ __global__ __launch_bounds__(64) void k(float *out, long long N, int T, int shif
         for (int i = 0; i < VALU; i += 8)
             asm volatile("v_add_f32 %0, %0, 1.0\n\tv_add_f32 %0, %0, 1.0\n\tv_add_f32 %0, %0, 1.0\n\tv_add_f32 %0, %0, 1.0\n\t"
                          "v_add_f32 %0, %0, 1.0\n\tv_add_f32 %0, %0, 1.0\n\tv_add_f32 %0, %0, 1.0\n\tv_add_f32 %0, %0, 1.0" : "+v"(v));
-        if (MODE == COOP_X4) {
+        if (MODE == COOP_X4 || MODE == COOP_X4_NT) {
             constexpr int GS = EPW * 75 / 4; // 16-byte groups per step
 #pragma unroll
             for (int i = 0; i < 19; ++i) {
@@ -37,7 +37,7 @@ __global__ __launch_bounds__(64) void k(float *out, long long N, int T, int shif
                     const int s = j / GS, r = j - s * GS;
                     char *q = ob + ((long long)(t0 + s) * N + env0) * 300 + 16 * r;
                     vf4 x = {v, v, v, v};
-                    *(vf4 *)q = x;
+                    if (MODE == COOP_X4_NT) __builtin_nontemporal_store(x, (vf4 *)q); else *(vf4 *)q = x;
                 }
             }
         } else if (MODE == COOP_DWORD) {
@@ -89,6 +89,10 @@ int main()
         const int T = N >= 32768 ? 64 : 128;
         printf("---- N = %lld\n", N);
         run<COOP_X4, 64, 0>("coop_x4", buf, N, T);
+        run<COOP_X4_NT, 64, 0>("coop_x4_nt", buf, N, T);
+        run<COOP_X4_NT, 32, 0>("coop_x4_nt", buf, N, T);
+        run<COOP_X4_NT, 8, 0>("coop_x4_nt", buf, N, T);
+        run<COOP_X4_NT, 32, 700>("coop_x4_nt", buf, N, T);
         run<COOP_X4, 64, 0>("coop_x4+4", buf, N, T, 1);
         run<COOP_X4, 32, 0>("coop_x4", buf, N, T);
         run<COOP_X4, 16, 0>("coop_x4", buf, N, T);
