@@ -122,6 +122,11 @@ typedef struct wurm_single_call {
     int actions_dtype, obs_mode, obs_n, size;
     int post_reset;                  /* != 0: envs that finished are rebuilt (call + 1) and STORED after `obs`   */
     int start_y, start_x;            /* SimpleGridworld start location (simple_gridworld.py:254-262)             */
+    void *resident;                  /* nullable in/out, SingleSnake only: wurm_single_resident_bytes() bytes the
+                                        caller owns — a compact mirror of `envs` that the step reads INSTEAD of envs
+                                        and keeps current (envs itself is still written every call)               */
+    int resident_valid;              /* != 0: nothing but calls that were given `resident` has written envs since
+                                        the mirror was last maintained; 0: it is rebuilt from envs first          */
 } wurm_single_call;
 
 /* One launch for one iteration of the caller loop of tests/test_single_snake_env.py:24-31 /
@@ -132,6 +137,15 @@ typedef struct wurm_single_call {
  * launch and flushes it with wurm_single_reset if the state is looked at in between, so `envs` is always what the
  * reference would show.  Bit-identical to the wurm_single_step / wurm_single_reset pair with the same counters. */
 int wurm_single_step_reset(const wurm_single_call *c, void *stream);
+
+/* Size in bytes of the mirror of wurm_single_call.resident for this batch, 0 if the shape is not served by it (then pass
+ * resident = NULL).  Served: size 9, observation none or partial_2, num_envs >= a threshold below which the launch is
+ * latency-bound anyway (WURM_RESIDENT_MIN_ENVS, default 4096).  With the mirror the per-call step of a large batch
+ * does not read the (N,3,9,9) state at all (wurm_amd/csrc/lane_resident.hpp).  Protocol: a call of
+ * wurm_single_step_reset with `resident` given leaves the mirror current unless it had inject_* / post_reset set;
+ * wurm_single_step_slot maintains c->resident_valid itself after each call, the caller only CLEARS it whenever anything
+ * else writes `envs` (another entry point, the caller's own code). */
+int64_t wurm_single_resident_bytes(int64_t num_envs, int size, int obs_mode, int obs_n);
 
 /* The same for SimpleGridworld (simple_gridworld.py:135-202,225-268). */
 int wurm_grid_step_reset(const wurm_single_call *c, void *stream);

@@ -84,8 +84,11 @@ class HipBackend(object):
         return obs.cpu().numpy() if obs is not None else None
 
     def single_step_reset(self, envs, actions, mode, call, pre_done=None, pre_call=None, post_reset=False,
-                          want_obs_after=False, inject_food=None, inject_reset=None, inject_pre_reset=None, grid=None):
-        """wurm_single_step_reset / wurm_grid_step_reset through the wurm_single_call argument block"""
+                          want_obs_after=False, inject_food=None, inject_reset=None, inject_pre_reset=None, grid=None,
+                          resident=None):
+        """wurm_single_step_reset / wurm_grid_step_reset through the wurm_single_call argument block.
+        resident: a dict the caller keeps across calls ({'valid': 0 | 1}; the mirror buffer is created in it): the call is
+        given wurm_single_call.resident / resident_valid, and 'valid' is set as the protocol of the header says"""
         N, _, S, _ = envs.shape
         m, n = _lib.parse_obs_mode(mode)
         e, a = self._t(envs), self._t(actions)
@@ -105,10 +108,17 @@ class HipBackend(object):
         c.pre_call = _lib.u64(pre_call if pre_call is not None else 0)
         c.actions_dtype, c.obs_mode, c.obs_n, c.size, c.post_reset = self._act(a), m, n, S, int(bool(post_reset))
         c.start_y, c.start_x = (-1, -1) if grid is None else grid
+        if resident is not None:
+            if resident.get('buf') is None or resident['buf'].numel() != 32 * N:
+                resident['buf'], resident['valid'] = self._empty((32 * N,), torch.uint8), 0
+            c.resident, c.resident_valid = _lib.ptr(resident['buf']), int(resident.get('valid', 0))
         import ctypes
         fn = self.lib.wurm_single_step_reset if grid is None else self.lib.wurm_grid_step_reset
         rc = fn(ctypes.addressof(c), self._stream())
         _lib.check(rc, 'wurm_single_step_reset')
+        if resident is not None:
+            resident['valid'] = int(inject_food is None and inject_reset is None and inject_pre_reset is None and
+                                    not post_reset and S == 9 and (m == _lib.OBS_NONE or (m == _lib.OBS_PARTIAL and n == 2)))
         torch.cuda.synchronize()
         envs[...] = e.cpu().numpy()
         actions[...] = a.cpu().numpy()

@@ -25,14 +25,23 @@ class _Recorder(object):
         return 0
 
     fail_next = False
+    mirror_bytes_per_env = 32
+
+    def wurm_single_resident_bytes(self, N, S, m, n):
+        return self.mirror_bytes_per_env * int(getattr(N, 'value', N))
 
     def step_slot(self, c_addr, sl_addr, slot, actions, dtype, call, pending, pre_call, want_after, stream):
+        c = _lib.SingleCall.from_address(c_addr)
         if self.fail_next:
             self.fail_next = False
+            if c.resident:
+                c.resident_valid = 0
             return -3
-        c = _lib.SingleCall.from_address(c_addr)
         self.calls.append(('step', dict(slot=slot, call=call, pending=bool(pending), pre_call=pre_call,
-                                        want_after=bool(want_after), dtype=dtype, obs_mode=c.obs_mode, envs=c.envs)))
+                                        want_after=bool(want_after), dtype=dtype, obs_mode=c.obs_mode, envs=c.envs,
+                                        mirror=bool(c.resident), mirror_valid=bool(c.resident_valid))))
+        if c.resident:  # what wurm_single_step_slot does: the mirror is current after a launch that was given it
+            c.resident_valid = 1
         return 0
 
 
@@ -228,3 +237,93 @@ def test_argument_errors_match_the_reference(env_and_log):
         env.step(torch.zeros(7, dtype=torch.int64))
     with pytest.raises(RuntimeError):
         env.step(torch.zeros(8, dtype=torch.int16))
+
+
+def _steps(log):
+    return [c[1] for c in log if c[0] == 'step']
+
+
+def test_the_mirror_is_built_once_in_the_plain_loop(env_and_log):
+    """wurm_single_call.resident: the step launch keeps the compact mirror of the state current; nothing in the loop of
+    experiments/main.py:212-227 (step, deferred reset in either form, a new output slab) makes it stale"""
+    env, log = env_and_log
+    for t in range(70):  # 64 steps per slab
+        _, _, d, _ = _step(env)
+        if t < 35:
+            env.reset(d)
+        else:
+            env.reset(d, return_observations=False)
+    st = _steps(log)
+    assert all(s['mirror'] for s in st)
+    # (the very first reset(d) that wants its observation runs eagerly, test_reset_observation_moves_into_the_step_launch...)
+    assert [s['mirror_valid'] for s in st] == [False, False] + [True] * 68
+
+
+def test_everything_else_that_writes_the_state_makes_the_mirror_stale(env_and_log):
+    env, log = env_and_log
+    _step(env); _step(env)
+    assert _steps(log)[-1]['mirror_valid']
+    env.reset(torch.ones(8, dtype=torch.bool), return_observations=False)   # an eager reset
+    _step(env)
+    assert not _steps(log)[-1]['mirror_valid']
+    _, _, d, _ = _step(env)
+    assert _steps(log)[-1]['mirror_valid']
+    env.reset(d, return_observations=False)                                  # postponed ...
+    env.check_consistency() if False else env._observe('default')          # ... and flushed by a look at the state
+    _step(env)
+    assert not _steps(log)[-1]['mirror_valid']
+    _step(env)
+    env.envs = torch.zeros(8, 3, 9, 9)                                       # a new state tensor
+    _step(env)
+    assert not _steps(log)[-1]['mirror_valid']
+    _step(env)
+    assert _steps(log)[-1]['mirror_valid']
+    env._rec.fail_next = True                                                # a launch that failed: rebuilt next time
+    with pytest.raises(Exception):
+        _step(env)
+    _step(env)
+    assert not _steps(log)[-1]['mirror_valid']
+
+
+def test_a_state_tensor_the_caller_holds_is_watched_for_in_place_edits(env_and_log):
+    env, log = env_and_log
+    _step(env)
+    e = env.envs                     # reading alone changes nothing ...
+    _step(env)
+    assert _steps(log)[-1]['mirror_valid']
+    _step(env)
+    e[0, 0, 3, 3] = 1.0              # ... an in-place edit, at any later time, does: the next step rebuilds the mirror
+    _step(env)
+    assert not _steps(log)[-1]['mirror_valid']
+    _step(env)
+    assert _steps(log)[-1]['mirror_valid']
+    e.view(-1)[5:7].zero_()          # through a view as well (views share the version counter)
+    _step(env)
+    assert not _steps(log)[-1]['mirror_valid']
+    t2 = torch.zeros(8, 3, 9, 9)
+    env.envs = t2                    # a tensor handed in is held by the caller too
+    _step(env); _step(env)
+    assert _steps(log)[-1]['mirror_valid']
+    t2[1, 2, 4, 4] = 2.0
+    _step(env)
+    assert not _steps(log)[-1]['mirror_valid']
+
+
+def test_a_state_tensor_without_version_counter_switches_the_mirror_off(env_and_log):
+    env, log = env_and_log
+    _step(env)
+    assert _steps(log)[-1]['mirror']
+    with torch.inference_mode():
+        env.envs = torch.zeros(8, 3, 9, 9)   # an inference tensor: edits could not be seen
+    _step(env)
+    assert not _steps(log)[-1]['mirror']
+    _step(env)
+    assert not _steps(log)[-1]['mirror']
+
+
+def test_no_mirror_for_shapes_the_library_does_not_serve(env_and_log):
+    env, log = env_and_log
+    env._rec.mirror_bytes_per_env = 0
+    env.observation_mode = 'default'         # (the recorder decides; the library serves size 9, partial_2 / none)
+    _step(env)
+    assert not _steps(log)[-1]['mirror']

@@ -1,5 +1,6 @@
+"""Fixed per-launch cost of the fused rollout: time per launch against the tape length (SingleSnake N x 9 x 9 partial_2)."""
 import json, os, sys
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from wurm_amd.envs import SingleSnake
 dev = torch.device('cuda:0')

@@ -94,6 +94,8 @@ typedef struct {
     char ok, pending, last_fresh, want_obs_after, lazy_ok;
     PyObject *outs, *done2s, *obs_afters;         /* per slot of the current slab: output tuple, (N,1) done, reset obs */
     PyObject *last_done2, *done_view, *obs_after; /* of the last step */
+    PyObject *watch;                              /* a tensor the caller may edit in place (the state), or None ... */
+    long long watch_version;                      /* ... and its version counter when last looked at */
     PyObject *get_device, *get_stream;            /* torch's current-device / raw-stream accessors */
     PyObject *dt_i64, *dt_i32, *dt_i16;
 } Stepper;
@@ -125,6 +127,8 @@ static int stepper_init(Stepper *self, PyObject *args, PyObject *kwds)
     set_obj(&self->dt_i64, d64); set_obj(&self->dt_i32, d32); set_obj(&self->dt_i16, d16);
     set_obj(&self->outs, Py_None); set_obj(&self->done2s, Py_None); set_obj(&self->obs_afters, Py_None);
     set_obj(&self->last_done2, Py_None); set_obj(&self->done_view, Py_None); set_obj(&self->obs_after, Py_None);
+    set_obj(&self->watch, Py_None);
+    self->watch_version = -1;
     self->slot = self->R = 0;
     self->slab_version = -1;
     self->call = self->pend_call = self->steps = 0;
@@ -135,7 +139,7 @@ static int stepper_init(Stepper *self, PyObject *args, PyObject *kwds)
 static int stepper_traverse(Stepper *self, visitproc visit, void *arg)
 {
     Py_VISIT(self->outs); Py_VISIT(self->done2s); Py_VISIT(self->obs_afters);
-    Py_VISIT(self->last_done2); Py_VISIT(self->done_view); Py_VISIT(self->obs_after);
+    Py_VISIT(self->last_done2); Py_VISIT(self->done_view); Py_VISIT(self->obs_after); Py_VISIT(self->watch);
     Py_VISIT(self->get_device); Py_VISIT(self->get_stream);
     Py_VISIT(self->dt_i64); Py_VISIT(self->dt_i32); Py_VISIT(self->dt_i16);
     return 0;
@@ -144,7 +148,7 @@ static int stepper_traverse(Stepper *self, visitproc visit, void *arg)
 static int stepper_clear(Stepper *self)
 {
     Py_CLEAR(self->outs); Py_CLEAR(self->done2s); Py_CLEAR(self->obs_afters);
-    Py_CLEAR(self->last_done2); Py_CLEAR(self->done_view); Py_CLEAR(self->obs_after);
+    Py_CLEAR(self->last_done2); Py_CLEAR(self->done_view); Py_CLEAR(self->obs_after); Py_CLEAR(self->watch);
     Py_CLEAR(self->get_device); Py_CLEAR(self->get_stream);
     Py_CLEAR(self->dt_i64); Py_CLEAR(self->dt_i32); Py_CLEAR(self->dt_i16);
     return 0;
@@ -168,7 +172,7 @@ static long method_long(PyObject *obj, PyObject *name)
 }
 
 /* step(actions) -> the prebuilt output tuple of this step;  None: the caller has to prepare something first (new slab,
- * state tensor to re-validate, actions on another device / not a contiguous vector, another device current) and call
+ * state tensor to re-validate or edited in place, actions on another device / not a contiguous vector, another device current) and call
  * again;  a non-zero int: the entry point's error code.  Argument errors are raised as the reference raises them
  * (single_snake.py:198-203; int16 passes its check and fails in scatter_ at :229). */
 static PyObject *stepper_step(Stepper *self, PyObject *actions)
@@ -198,6 +202,18 @@ static PyObject *stepper_step(Stepper *self, PyObject *actions)
     }
     const long long i = self->slot;
     if (!self->ok || i >= self->R || (self->want_obs_after && self->obs_afters == Py_None)) Py_RETURN_NONE;
+    if (self->watch != NULL && self->watch != Py_None) { /* the state tensor edited in place since the caller took it: the caller re-validates */
+        long long ver = -1;
+        PyObject *vo = PyObject_GetAttr(self->watch, s_version);
+        if (vo) {
+            ver = PyLong_AsLongLong(vo);
+            Py_DECREF(vo);
+            if (ver == -1 && PyErr_Occurred()) PyErr_Clear();
+        } else {
+            PyErr_Clear();
+        }
+        if (ver != self->watch_version) Py_RETURN_NONE;
+    }
     long v = method_long(actions, s_get_device);
     if (v == -2) return NULL;
     if ((long long)v != self->dev_index) Py_RETURN_NONE;
@@ -307,6 +323,8 @@ static PyMemberDef stepper_members[] = {
     {"last_done2", T_OBJECT, offsetof(Stepper, last_done2), 0, NULL},
     {"done_view", T_OBJECT, offsetof(Stepper, done_view), 0, NULL},
     {"obs_after", T_OBJECT, offsetof(Stepper, obs_after), 0, NULL},
+    {"watch", T_OBJECT, offsetof(Stepper, watch), 0, NULL},
+    {"watch_version", T_LONGLONG, offsetof(Stepper, watch_version), 0, NULL},
     {NULL, 0, 0, 0, NULL}};
 
 static PyMethodDef stepper_methods[] = {

@@ -84,7 +84,8 @@ constexpr u64 LR_INTERIOR = ~LR_RING;          // codes 8 r + c, r, c in 1..7
 // in:  x = action bits (the action if it is 0..3 else 7 | (action % 4 & 7) << 3), y = would-be reset, z = food word;
 // out: x, y = occupancy of the stepped state, z = head code before the move | sanitised action << 8,
 //      w = food code + 1 | ate << 8 | self collision << 9 | edge collision << 10 | valid << 15
-template <bool INJ>
+// RESET = false: the step alone (the per-call kernel of lane_resident.hpp rebuilds finished envs in the NEXT launch)
+template <bool INJ, bool RESET = true>
 __device__ __forceinline__ uint4 lr_transition(u64 &occ, u32 &q0, u32 &q1, u32 &q2, int &c, int &tc, int &L, int &o, int &food,
                                                const bool act, const uint4 &cur)
 {
@@ -121,7 +122,7 @@ __device__ __forceinline__ uint4 lr_transition(u64 &occ, u32 &q0, u32 &q1, u32 &
         occ_rec = occ;
         rz = (u32)c_prev | (((u32)a_out & 0xffu) << 8);
         rw = (u32)(food + 1) | ((u32)eat << 8) | (selfc << 9) | (edge << 10) | 0x8000u;
-        if (selfc | edge) {                                             // :322-387
+        if (RESET && (selfc | edge)) {                                  // :322-387
             const u32 r = cur.y;
             const int hc = (int)(r & 127u), sc = (int)((r >> 7) & 127u), d = (int)((r >> 21) & 3u);
             tc = (int)((r >> 14) & 127u);
@@ -134,34 +135,11 @@ __device__ __forceinline__ uint4 lr_transition(u64 &occ, u32 &q0, u32 &q1, u32 &
     return make_uint4((u32)occ_rec, (u32)(occ_rec >> 32), rz, rw);
 }
 
-// an env outside the domain: the one-env-per-wave rollout, whole wave
-template <int OBSK, bool INJ>
-__device__ __forceinline__ void lane_rollout_fallback(const StepArgs &p, long long env, signed char *lds)
+// workgroup tables (LR_TAB bytes): tab[i] = the four floats of nibble pair i (low nibble: "value is 1", high nibble: "value
+// is 127/255"); wint[head cell] = the cells of the 5 x 5 window (bit 8 i + j) that lie inside the border ring
+__device__ __forceinline__ void lr_build_tables(float4 *tab, u64 *wint)
 {
-    const Geo g = make_geo<2>(9);
-    float *envp = p.envs + env * LR_C3;
-    Env<2> e;
-    load_state<2, true>(envp, g, e);
-    rollout_generic<2, true, OBSK, INJ>(p, env, envp, g, e, lds);
-}
-
-template <int EPW, int OBSK, bool INJ>
-__global__ __launch_bounds__(256) void lane_rollout_kernel(StepArgs p)
-{
-    typedef LaneRollLds<EPW> Lds;
-    static_assert(EPW == 4 || EPW == 8 || EPW == 16 || EPW == 32 || EPW == 64, "envs per wave");
-    static_assert(OBSK == WURM_OBS_PARTIAL || OBSK == WURM_OBS_NONE, "lane rollout: partial_2 or no observation");
-    constexpr int TC = 64 / EPW;                  // steps per chunk
-    constexpr int LOG_EPW = EPW == 4 ? 2 : EPW == 8 ? 3 : EPW == 16 ? 4 : EPW == 32 ? 5 : 6;
-    constexpr int GS = EPW * LR_E / 4;            // 16-byte groups per step of the wave's crops
-    constexpr int SUPER = 16;                     // chunks per batch of action loads
     constexpr int S = 9;
-    extern __shared__ __attribute__((aligned(16))) unsigned char lr_lds[];
-    const int wave = uniform((int)(threadIdx.x >> 6)), wpb = (int)(blockDim.x >> 6), lane = (int)(threadIdx.x & 63u);
-
-    // ---- workgroup tables
-    float4 *tab = (float4 *)lr_lds;               // nibble pair -> four floats
-    u64 *wint = (u64 *)(lr_lds + 4096);           // head (row, column) -> window cells that lie inside the border ring
     for (int i = (int)threadIdx.x; i < 256; i += (int)blockDim.x) {
         float v[4];
 #pragma unroll
@@ -179,49 +157,29 @@ __global__ __launch_bounds__(256) void lane_rollout_kernel(StepArgs p)
             if ((unsigned)(hy - 2 + wy - 1) < 7u) m |= cols << (8 * wy);
         wint[i] = m;
     }
-    __syncthreads();
+}
 
-    const long long env0 = (xcd_block(blockIdx.x, gridDim.x) * wpb + wave) * EPW;
-    if (env0 >= p.N) return;
-    unsigned char *lds = lr_lds + LR_TAB + wave * Lds::BYTES;
-    const int nenv = (int)min((long long)EPW, p.N - env0);
-    const bool mine = lane < nenv;                // env lanes: lane e owns env0 + e
-    const int ps = lane >> LOG_EPW, pe = lane & (EPW - 1); // pair lanes: step ps of the chunk, env env0 + pe
-
-    // Actions: one load per chunk and pair lane, SUPER chunks at a time and one batch AHEAD (loads and stores share vmcnt
-    // and retire in order: the wait for a batch issued a whole super-chunk earlier only drains the last few stores, and the
-    // chunk loop itself never waits on memory).  Unconditional loads (index clamped into the tape) so that all of a batch
-    // are in flight together.
-    const long long a_last = p.T * p.N - 1;
-    long long av[SUPER];
-    auto load_batch = [&](long long t_first) { // the dtype test outside the unrolled loads: SUPER loads back to back
-        if (p.act_dtype == WURM_ACT_I64) {
-#pragma unroll
-            for (int k = 0; k < SUPER; ++k)
-                av[k] = ((const long long *)p.actions)[min((t_first + (long long)k * TC + ps) * p.N + env0 + pe, a_last)];
-        } else {
-            int a32[SUPER];
-#pragma unroll
-            for (int k = 0; k < SUPER; ++k)
-                a32[k] = ((const int *)p.actions)[min((t_first + (long long)k * TC + ps) * p.N + env0 + pe, a_last)];
-#pragma unroll
-            for (int k = 0; k < SUPER; ++k) av[k] = (long long)a32[k];
-        }
-    };
-    load_batch(0);
-
+// The state of a block of EPW consecutive envs (`block` = its first float), read cooperatively — lanes = (env, cell) pairs,
+// the few non-zero elements scattered into a per-env value -> cell table in LDS — then, per env lane: validation and the
+// state as occupancy mask + queue of moves.  act = the env is in the domain (header of this file).
+template <int EPW>
+__device__ __forceinline__ void lr_read_block(const float *block, const bool whole, const int nenv, const int lane,
+                                              unsigned char *lds, u64 &occ, u32 &q0, u32 &q1, u32 &q2, int &c, int &tc, int &L,
+                                              int &o, int &food, bool &act)
+{
+    typedef LaneRollLds<EPW> Lds;
+    constexpr int S = 9;
     // ---- cooperative read of the state: lanes = (env, cell) pairs of the block, three dwords each (food, head, body)
     u32 *vm = (u32 *)(lds + Lds::VM), *stat = (u32 *)(lds + Lds::STAT);
     unsigned char *hpos = lds + Lds::HPOS, *fpos = lds + Lds::FPOS, *valpos = lds + Lds::VALPOS;
     if (lane < EPW) { vm[lane] = 0; vm[EPW + lane] = 0; stat[lane] = 0; }
     wave_lds_sync();
-    const bool whole = nenv == EPW && (((size_t)p.envs) & 15u) == 0; // full block, 16-byte aligned (env0 is a multiple of 4)
     if (whole) {
-        lane_load_block<EPW, LR_C, 2, LR_VS>(p.envs + env0 * LR_C3, lane, vm, stat, hpos, fpos, valpos,
+        lane_load_block<EPW, LR_C, 2, LR_VS>(block, lane, vm, stat, hpos, fpos, valpos,
                                              lds + Lds::QUEUE);
     } else {
         constexpr int LOADS = 9;
-        const char *base = (const char *)(p.envs + env0 * LR_C3);
+        const char *base = (const char *)(block);
         const int pairs = nenv * LR_C;
         int e = 0, cell = lane, idx = lane;
         unsigned off = 4u * (unsigned)lane;
@@ -259,10 +217,8 @@ __global__ __launch_bounds__(256) void lane_rollout_kernel(StepArgs p)
     wave_lds_sync();
 
     // ---- env lanes: validation, and the state as occupancy mask + queue of moves
-    u64 occ = 0;
-    u32 q0 = 0, q1 = 0, q2 = 0;
-    int c = 0, tc = 0, L = 0, o = 0, food = -1;
-    bool act = false;
+    occ = 0; q0 = q1 = q2 = 0; c = tc = L = o = 0; food = -1; act = false;
+    const bool mine = lane < nenv;
     if (mine) {
         const u32 st = stat[lane];
         const int cnt = (int)(st & 0xffu), nhd = (int)((st >> 8) & 0xffu), nfd = (int)((st >> 16) & 0xffu);
@@ -299,6 +255,75 @@ __global__ __launch_bounds__(256) void lane_rollout_kernel(StepArgs p)
         o = (int)(q0 & 3u) ^ 2;                       // head = neck + TAP[o], the last move was -TAP[o ^ 2]
         if (act && food >= 0 && ((occ >> food) & 1)) act = false;
     }
+}
+
+// an env outside the domain: the one-env-per-wave rollout, whole wave
+template <int OBSK, bool INJ>
+__device__ __forceinline__ void lane_rollout_fallback(const StepArgs &p, long long env, signed char *lds)
+{
+    const Geo g = make_geo<2>(9);
+    float *envp = p.envs + env * LR_C3;
+    Env<2> e;
+    load_state<2, true>(envp, g, e);
+    rollout_generic<2, true, OBSK, INJ>(p, env, envp, g, e, lds);
+}
+
+template <int EPW, int OBSK, bool INJ>
+__global__ __launch_bounds__(256) void lane_rollout_kernel(StepArgs p)
+{
+    typedef LaneRollLds<EPW> Lds;
+    static_assert(EPW == 4 || EPW == 8 || EPW == 16 || EPW == 32 || EPW == 64, "envs per wave");
+    static_assert(OBSK == WURM_OBS_PARTIAL || OBSK == WURM_OBS_NONE, "lane rollout: partial_2 or no observation");
+    constexpr int TC = 64 / EPW;                  // steps per chunk
+    constexpr int LOG_EPW = EPW == 4 ? 2 : EPW == 8 ? 3 : EPW == 16 ? 4 : EPW == 32 ? 5 : 6;
+    constexpr int GS = EPW * LR_E / 4;            // 16-byte groups per step of the wave's crops
+    constexpr int SUPER = 16;                     // chunks per batch of action loads
+    constexpr int S = 9;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lr_lds[];
+    const int wave = uniform((int)(threadIdx.x >> 6)), wpb = (int)(blockDim.x >> 6), lane = (int)(threadIdx.x & 63u);
+
+    // ---- workgroup tables
+    float4 *tab = (float4 *)lr_lds;               // nibble pair -> four floats
+    u64 *wint = (u64 *)(lr_lds + 4096);           // head (row, column) -> window cells that lie inside the border ring
+    lr_build_tables(tab, wint);
+    __syncthreads();
+
+    const long long env0 = (xcd_block(blockIdx.x, gridDim.x) * wpb + wave) * EPW;
+    if (env0 >= p.N) return;
+    unsigned char *lds = lr_lds + LR_TAB + wave * Lds::BYTES;
+    const int nenv = (int)min((long long)EPW, p.N - env0);
+    const bool mine = lane < nenv;                // env lanes: lane e owns env0 + e
+    const int ps = lane >> LOG_EPW, pe = lane & (EPW - 1); // pair lanes: step ps of the chunk, env env0 + pe
+
+    // Actions: one load per chunk and pair lane, SUPER chunks at a time and one batch AHEAD (loads and stores share vmcnt
+    // and retire in order: the wait for a batch issued a whole super-chunk earlier only drains the last few stores, and the
+    // chunk loop itself never waits on memory).  Unconditional loads (index clamped into the tape) so that all of a batch
+    // are in flight together.
+    const long long a_last = p.T * p.N - 1;
+    long long av[SUPER];
+    auto load_batch = [&](long long t_first) { // the dtype test outside the unrolled loads: SUPER loads back to back
+        if (p.act_dtype == WURM_ACT_I64) {
+#pragma unroll
+            for (int k = 0; k < SUPER; ++k)
+                av[k] = ((const long long *)p.actions)[min((t_first + (long long)k * TC + ps) * p.N + env0 + pe, a_last)];
+        } else {
+            int a32[SUPER];
+#pragma unroll
+            for (int k = 0; k < SUPER; ++k)
+                a32[k] = ((const int *)p.actions)[min((t_first + (long long)k * TC + ps) * p.N + env0 + pe, a_last)];
+#pragma unroll
+            for (int k = 0; k < SUPER; ++k) av[k] = (long long)a32[k];
+        }
+    };
+    load_batch(0);
+
+    // ---- the state: cooperative read, validation, occupancy mask + queue of moves per env lane
+    u64 occ = 0;
+    u32 q0 = 0, q1 = 0, q2 = 0;
+    int c = 0, tc = 0, L = 0, o = 0, food = -1;
+    bool act = false;
+    const bool whole = nenv == EPW && (((size_t)p.envs) & 15u) == 0; // full block, 16-byte aligned (env0 is a multiple of 4)
+    lr_read_block<EPW>(p.envs + env0 * LR_C3, whole, nenv, lane, lds, occ, q0, q1, q2, c, tc, L, o, food, act);
     const u64 odd = ballot(mine && !act);             // envs outside the domain: rollout_generic below
     wave_lds_sync();
 

@@ -153,6 +153,8 @@ __global__ __launch_bounds__(256) void lane_step_kernel(LaneArgs a)
     const int nenv = (int)min((long long)EPW, p.N - env0);
     const long long env = env0 + lane;
     const bool mine = lane < nenv;
+    WURM_TL_DECL;
+    WURM_TL(0); // entry
 
     u32 *vm = (u32 *)(lds + Lds::VM), *stat = (u32 *)(lds + Lds::STAT);
     unsigned char *hpos = lds + Lds::HPOS, *fpos = lds + Lds::FPOS, *valpos = lds + Lds::VALPOS;
@@ -208,6 +210,7 @@ __global__ __launch_bounds__(256) void lane_step_kernel(LaneArgs a)
     }
     wave_lds_sync();
 
+    WURM_TL(1); // state read
     // ---- one env per lane
     const Mask128 interior = {a.int_lo, a.int_hi};
     const u64 env_id = (u64)(p.env_offset + env);
@@ -239,6 +242,7 @@ __global__ __launch_bounds__(256) void lane_step_kernel(LaneArgs a)
     }
     wave_lds_sync();
 
+    WURM_TL(2); // validated
     // transition (small_step above, per lane)
     constexpr float rcpS = 1.0f / (float)S;
     long long act = 0;
@@ -263,6 +267,7 @@ __global__ __launch_bounds__(256) void lane_step_kernel(LaneArgs a)
         grow = L + (EAT ? 1 : 0);                                                  // :258-262
         EDGEC = !(inside && ny >= 1 && ny <= S - 2 && nx >= 1 && nx <= S - 2);     // :290-295
     }
+    WURM_TL(3); // action loaded, move decided
     // body: value v sits on valpos[v]; every one decays unless food was eaten, the new head cell grows
     char *sb = (char *)(p.envs + env0 * C3);                 // scalar base of the block's state ...
     const unsigned so = 4u * (unsigned)(lane * C3);           // ... + this lane's env (32-bit byte offsets)
@@ -302,6 +307,7 @@ __global__ __launch_bounds__(256) void lane_step_kernel(LaneArgs a)
         if (p.done_copy) p.done_copy[env] = (uint8_t)done;
     }
 
+    WURM_TL(4); // changed cells and outputs stored
     // a rebuilt env is stored whole (its old contents are unrelated): cooperative, one env at a time
     for (u64 m = ballot(pre); m != 0; m &= m - 1) {
         const int src = first_bit(m);
@@ -321,6 +327,7 @@ __global__ __launch_bounds__(256) void lane_step_kernel(LaneArgs a)
         }
     }
 
+    WURM_TL(5); // rebuilt envs stored
     // ---- observations: descriptors per env, then the crops of the whole block
     if (p.obs_mode == WURM_OBS_PARTIAL) {
         short *dh = (short *)(lds + Lds::DESC), *df = dh + EPW;
@@ -354,6 +361,8 @@ __global__ __launch_bounds__(256) void lane_step_kernel(LaneArgs a)
         if (p.obs_after != nullptr) lane_observe<EPW, S>(a, lds, 1, p.obs_after + env0 * p.obs_elems, nenv, lane);
     }
 
+    WURM_TL(6); // crops issued; WURM_TL_STORE: drained
+    if (p.obs_mode == WURM_OBS_PARTIAL) WURM_TL_STORE(p.obs + env0 * p.obs_elems, lane);
     // ---- envs outside the domain: the one-env-per-wave code writes their state, crops and outputs (nothing above did)
     u64 odd = ballot(mine && !regular);
     if (odd != 0) {

@@ -1845,8 +1845,10 @@ int wurm_single_rollout(float *envs, void *actions, int actions_dtype, float *re
     return launch<true>(K_ROLLOUT, p, stream);
 }
 
-static int fused_entry(bool snake, const wurm_single_call *c, void *stream)
+// *mirror_current (nullable): whether c->resident describes envs once this call has run
+static int fused_entry(bool snake, const wurm_single_call *c, void *stream, int *mirror_current = nullptr)
 {
+    if (mirror_current) *mirror_current = 0;
     if (!c) return WURM_ERR_INVALID_ARG;
     int rc = check_common(snake, c->envs, c->num_envs, c->size, c->obs, c->obs_mode, c->obs_n, c->actions_dtype);
     if (rc) return rc;
@@ -1867,9 +1869,24 @@ static int fused_entry(bool snake, const wurm_single_call *c, void *stream)
     p.inject_food = c->inject_food; p.inject_reset = c->inject_reset; p.done_in = c->pre_done;
     p.obs_after = c->obs_after; p.done_copy = c->done_copy; p.inject_pre_reset = c->inject_pre_reset;
     p.pre_call = c->pre_call; p.post_reset = c->post_reset;
+    if (snake && c->resident != nullptr && N > 0 && lane_resident_eligible(p)) {
+        // the caller keeps a compact mirror of the state: the step reads that instead of envs (lane_resident.hpp)
+        p.lds_per_wave = ((p.S * p.S + 15) / 16) * 16;
+        if (launch_lane_resident(p, c->resident, c->resident_valid != 0, (hipStream_t)stream) != hipSuccess) return WURM_ERR_HIP;
+        if (mirror_current) *mirror_current = 1;
+        return WURM_OK;
+    }
     // nothing to rebuild and no second observation: the plain step kernel (lighter on registers for large grids)
     const Kind kind = resets ? K_FUSED : K_STEP;
     return snake ? launch<true>(kind, p, stream) : launch<false>(kind, p, stream);
+}
+
+int64_t wurm_single_resident_bytes(int64_t num_envs, int size, int obs_mode, int obs_n)
+{
+    const char *e = getenv("WURM_RESIDENT_MIN_ENVS");
+    const long long min_envs = e ? atoll(e) : 4096ll;
+    if (num_envs <= 0 || num_envs < min_envs || !lane_resident_shape(size, obs_mode, obs_n)) return 0;
+    return num_envs * 32;
 }
 
 int wurm_single_step_reset(const wurm_single_call *c, void *stream) { return fused_entry(true, c, stream); }
@@ -1898,7 +1915,10 @@ static int step_slot(bool snake, wurm_single_call *c, const wurm_single_slabs *s
     } else {
         c->pre_done = nullptr;
     }
-    return fused_entry(snake, c, stream);
+    int current = 0;
+    const int rc = fused_entry(snake, c, stream, &current);
+    if (c->resident) c->resident_valid = (rc == WURM_OK && current) ? 1 : 0;
+    return rc;
 }
 
 int wurm_single_step_slot(wurm_single_call *c, const wurm_single_slabs *s, int64_t slot, void *actions,

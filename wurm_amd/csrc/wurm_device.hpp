@@ -194,4 +194,27 @@ __device__ __forceinline__ int div_size(int c, float rcpS) { return (int)(((floa
 __device__ __forceinline__ int tap_y(int i) { return i == 0 ? -1 : (i == 2 ? 1 : 0); }
 __device__ __forceinline__ int tap_x(int i) { return i == 1 ? 1 : (i == 3 ? -1 : 0); }
 
+// In-kernel timeline (tools/kernel_timeline.py): a build with -DWURM_TIMELINE (make -C wurm_amd/csrc timeline ->
+// libwurm_hip_timeline.so, loaded with WURM_HIP_LIBRARY=...) stamps s_memtime at up to eight points of the per-call
+// lane kernels and overwrites the first 64 bytes of the wave's own observation block with the stamps once its stores have
+// drained.  Scalars, not an array (an array would live in scratch).  In the shipped build the macros are empty.
+#ifdef WURM_TIMELINE
+#define WURM_TL_DECL unsigned long long tl_0 = 0, tl_1 = 0, tl_2 = 0, tl_3 = 0, tl_4 = 0, tl_5 = 0, tl_6 = 0, tl_7 = 0
+#define WURM_TL(k) tl_##k = __builtin_amdgcn_s_memtime()
+#define WURM_TL_STORE(ptr, lane)                                                                                         \
+    do {                                                                                                                 \
+        __builtin_amdgcn_s_waitcnt(0);                                                                                   \
+        WURM_TL(7);                                                                                                      \
+        unsigned long long *tl_o = (unsigned long long *)(ptr);                                                          \
+        if ((lane) == 0) {                                                                                               \
+            tl_o[0] = tl_0; tl_o[1] = tl_1; tl_o[2] = tl_2; tl_o[3] = tl_3;                                              \
+            tl_o[4] = tl_4; tl_o[5] = tl_5; tl_o[6] = tl_6; tl_o[7] = tl_7;                                              \
+        }                                                                                                                \
+    } while (0)
+#else
+#define WURM_TL_DECL
+#define WURM_TL(k)
+#define WURM_TL_STORE(ptr, lane)
+#endif
+
 } // namespace wurm

@@ -47,10 +47,11 @@ class PyStepper(object):
         self.ok = self.pending = self.last_fresh = self.want_obs_after = self.lazy_ok = False
         self.outs = self.done2s = self.obs_afters = None
         self.last_done2 = self.done_view = self.obs_after = None
+        self.watch, self.watch_version = None, -1  # a tensor the caller may edit in place, and its version when last looked at
 
     def step(self, actions):
         """The prebuilt output tuple of this step; None: the caller has to prepare something first (new slab, state tensor
-        to re-validate, actions on another device / not a contiguous vector, another device current) and call again; a
+        to re-validate or edited in place, actions on another device / not a contiguous vector, another device current) and call again; a
         non-zero int: the entry point's error code.  Argument errors as the reference raises them
         (single_snake.py:198-203; int16 passes its check and then fails in scatter_ at :229)."""
         dt = actions.dtype
@@ -68,6 +69,14 @@ class PyStepper(object):
         i = self.slot
         if not self.ok or i >= self.R or (self.want_obs_after and self.obs_afters is None):
             return None
+        w = self.watch
+        if w is not None:
+            try:
+                ver = w._version
+            except RuntimeError:
+                ver = -1
+            if ver != self.watch_version:
+                return None  # the state tensor has been edited in place since the caller took it
         idx = self.dev_index
         if actions.get_device() != idx or actions.dim() != 1 or not actions.is_contiguous():
             return None
@@ -145,6 +154,10 @@ class FastStepMixin(object):
         self._envs_ok = None           # the state tensor that has been validated (None: validate before the next launch)
         # env.done: what the caller (or the constructor / rollout) assigned, valid until the next step overwrites it
         self._done, self._done_stamp = torch.zeros(N, dtype=torch.bool, device=self.device), 0
+        # compact mirror of the state the step launch reads instead of `envs` (wurm_single_call.resident; large 9 x 9
+        # batches).  The library marks it current after each step launch; everything else that writes the state clears
+        # the mark (_touch); a state tensor the caller got hold of is watched for in-place edits through its version counter
+        self._mirror, self._mirror_key, self._mirror_off = None, None, False
 
     # state of the step machine that other methods of the classes read and write
     _call = property(lambda self: self._fs.call, lambda self, v: setattr(self._fs, 'call', v))
@@ -192,6 +205,7 @@ class FastStepMixin(object):
         if fs.pending:
             self._flush()
         fs.obs_after = None
+        self._watch(self._envs)
         return self._envs
 
     @envs.setter
@@ -203,10 +217,13 @@ class FastStepMixin(object):
         fs.ok = False
         self._envs_ok = None
         self._envs = value
+        self._touch()
+        self._watch(value)
 
     def _flush(self):
         """Applies the postponed reset(done) now, with the ordinary reset kernel and the counter it was given."""
         fs = self._fs
+        self._touch()
         self._launch_reset(self._checked(self._envs), self._pend, None, _lib.OBS_NONE, 0, fs.pend_call)
         fs.pending = False  # (only once the launch is known to have been accepted)
 
@@ -217,7 +234,49 @@ class FastStepMixin(object):
         if fs.pending:
             self._flush()
         fs.last_fresh = False
+        self._touch()
         return self._checked(self._envs)
+
+    def _touch(self):
+        """something other than the step launch is about to write the state: the mirror is rebuilt by the next step"""
+        self._c.resident_valid = 0
+
+    def _watch(self, t):
+        """The caller holds the state tensor `t` from now on and may edit it in place at any time: every step compares its
+        version counter (in-place torch ops bump it) and rebuilds the mirror after a change.  Tensors without version
+        counters (made under torch.inference_mode()) cannot be watched: no mirror from then on."""
+        fs = self._fs
+        try:
+            fs.watch, fs.watch_version = t, t._version
+        except (RuntimeError, AttributeError):
+            fs.watch, fs.watch_version = None, -1
+            self._mirror_off, self._mirror, self._mirror_key = True, None, None
+            self._c.resident, self._c.resident_valid = None, 0
+
+    def _mirror_sync(self):
+        """the step machine saw another version of the watched state tensor: the mirror is stale"""
+        fs = self._fs
+        w = fs.watch
+        if w is not None:
+            try:
+                ver = w._version
+            except RuntimeError:
+                ver = -1
+            if ver != fs.watch_version:
+                self._touch()
+                self._watch(w)
+
+    def _setup_mirror(self, m: int, n: int):
+        key = (m, n)
+        if key == self._mirror_key:
+            return
+        self._mirror_key = key
+        nbytes = 0
+        if self._CHANNELS == 3 and not self._mirror_off:
+            nbytes = int(_lib.lib().wurm_single_resident_bytes(_lib.i64(self.num_envs), self.size, m, n))
+        self._mirror = torch.empty(nbytes, dtype=torch.uint8, device=self.device) if nbytes > 0 else None
+        self._c.resident = self._mirror.data_ptr() if self._mirror is not None else None
+        self._c.resident_valid = 0
 
     def _checked(self, e: torch.Tensor) -> torch.Tensor:
         if e is self._envs_ok:
@@ -231,6 +290,7 @@ class FastStepMixin(object):
             self._envs = e
         self._envs_ok = e
         self._c.envs = e.data_ptr()
+        self._touch()
         return e
 
     @property
@@ -267,7 +327,7 @@ class FastStepMixin(object):
         m, n, shape = self._mode_info(self.observation_mode)
         elems = int(torch.Size(shape).numel()) // max(N, 1)
         per_step = N * (4 * elems + 4 + 3)
-        R = max(1, min(64, (32 << 20) // max(per_step, 1)))
+        R = max(1, min(64, (256 << 20) // max(per_step, 1)))  # (65 536 x 9 x 9 'partial_2': 20 MB per step)
         dev = self.device
         want_after = bool(fs.want_obs_after)
         obs = torch.empty((R,) + tuple(shape), dtype=torch.float32, device=dev)
@@ -282,6 +342,7 @@ class FastStepMixin(object):
             self._c.done_copy = self._pend.data_ptr()
         self._configure_call(self._c)
         self._c.obs_mode, self._c.obs_n = m, n
+        self._setup_mirror(m, n)
         sl = self._sl
         sl.obs, sl.reward, sl.flags, sl.steps = obs.data_ptr(), reward.data_ptr(), flags.data_ptr(), R
         sl.obs_after = obs_after.data_ptr() if obs_after is not None else None
@@ -308,6 +369,7 @@ class FastStepMixin(object):
         """What the step machine could not do by itself (it returned None), or an error code of the entry point."""
         fs = self._fs
         if out is None:
+            self._mirror_sync()
             if fs.slot >= fs.R or self._slab_mode != self.observation_mode or \
                     (fs.want_obs_after and fs.obs_afters is None):
                 self._new_slab()
