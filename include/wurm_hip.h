@@ -127,6 +127,9 @@ typedef struct wurm_single_call {
                                         and keeps current (envs itself is still written every call)               */
     int resident_valid;              /* != 0: nothing but calls that were given `resident` has written envs since
                                         the mirror was last maintained; 0: it is rebuilt from envs first          */
+    int resident_lazy;               /* != 0: the step does not write envs at all; envs is brought up to date by
+                                        wurm_single_resident_flush (call it before anything else reads or writes
+                                        envs, and before clearing resident_valid)                                 */
 } wurm_single_call;
 
 /* One launch for one iteration of the caller loop of tests/test_single_snake_env.py:24-31 /
@@ -144,8 +147,14 @@ int wurm_single_step_reset(const wurm_single_call *c, void *stream);
  * does not read the (N,3,9,9) state at all (wurm_amd/csrc/lane_resident.hpp).  Protocol: a call of
  * wurm_single_step_reset with `resident` given leaves the mirror current unless it had inject_* / post_reset set;
  * wurm_single_step_slot maintains c->resident_valid itself after each call, the caller only CLEARS it whenever anything
- * else writes `envs` (another entry point, the caller's own code). */
+ * else writes `envs` (another entry point, the caller's own code).  A call that cannot use the mirror (inject_* /
+ * post_reset) flushes a lazy mirror into envs first by itself. */
 int64_t wurm_single_resident_bytes(int64_t num_envs, int size, int obs_mode, int obs_n);
+
+/* resident_lazy: writes envs from the mirror (every env the mirror describes, whole; the others — states outside the
+ * lane kernels' domain, which the step keeps in envs itself — are left as they are).  A no-op returning WURM_OK unless
+ * c->resident, c->resident_lazy and c->resident_valid are all set.  Leaves the mirror valid. */
+int wurm_single_resident_flush(const wurm_single_call *c, void *stream);
 
 /* The same for SimpleGridworld (simple_gridworld.py:135-202,225-268). */
 int wurm_grid_step_reset(const wurm_single_call *c, void *stream);

@@ -88,10 +88,17 @@ class HipBackend(object):
                           resident=None):
         """wurm_single_step_reset / wurm_grid_step_reset through the wurm_single_call argument block.
         resident: a dict the caller keeps across calls ({'valid': 0 | 1}; the mirror buffer is created in it): the call is
-        given wurm_single_call.resident / resident_valid, and 'valid' is set as the protocol of the header says"""
+        given wurm_single_call.resident / resident_valid, and 'valid' is set as the protocol of the header says.  With
+        resident['lazy'] the device copy of the state is kept in the dict across calls (the step does not write it) and is
+        written out (wurm_single_resident_flush) and copied back into `envs` only when resident['sync'] is true"""
         N, _, S, _ = envs.shape
         m, n = _lib.parse_obs_mode(mode)
-        e, a = self._t(envs), self._t(actions)
+        lazy = resident is not None and bool(resident.get('lazy'))
+        if lazy and resident.get('valid') and resident.get('envs_dev') is not None:
+            e = resident['envs_dev']  # stale by design; the mirror describes the state
+        else:
+            e = self._t(envs)
+        a = self._t(actions)
         shape = (_o.single_obs_shape if grid is None else _o.grid_obs_shape)(mode, N, S)
         obs = self._empty(shape, torch.float32) if shape else None
         obs_after = self._empty(shape, torch.float32) if (shape and want_obs_after) else None
@@ -112,6 +119,7 @@ class HipBackend(object):
             if resident.get('buf') is None or resident['buf'].numel() != 32 * N:
                 resident['buf'], resident['valid'] = self._empty((32 * N,), torch.uint8), 0
             c.resident, c.resident_valid = _lib.ptr(resident['buf']), int(resident.get('valid', 0))
+            c.resident_lazy = int(lazy)
         import ctypes
         fn = self.lib.wurm_single_step_reset if grid is None else self.lib.wurm_grid_step_reset
         rc = fn(ctypes.addressof(c), self._stream())
@@ -119,8 +127,14 @@ class HipBackend(object):
         if resident is not None:
             resident['valid'] = int(inject_food is None and inject_reset is None and inject_pre_reset is None and
                                     not post_reset and S == 9 and (m == _lib.OBS_NONE or (m == _lib.OBS_PARTIAL and n == 2)))
+            if lazy:
+                resident['envs_dev'] = e
+                c.resident_valid = resident['valid']
+                if resident.get('sync', True):
+                    _lib.check(self.lib.wurm_single_resident_flush(ctypes.addressof(c), self._stream()), 'flush')
         torch.cuda.synchronize()
-        envs[...] = e.cpu().numpy()
+        if not lazy or resident.get('sync', True):
+            envs[...] = e.cpu().numpy()
         actions[...] = a.cpu().numpy()
         assert torch.equal(copy, done), 'done_copy != done'
         return dict(obs=obs.cpu().numpy() if obs is not None else None, reward=reward.cpu().numpy(),

@@ -15,6 +15,7 @@ class _Recorder(object):
 
     def __init__(self):
         self.calls = []
+        self.flushes = []
 
     def wurm_single_reset(self, envs, done, obs, m, n, N, S, seed, call, off, inj, stream):
         self.calls.append(('reset', dict(call=call, obs=obs is not None, mode=m)))
@@ -30,6 +31,12 @@ class _Recorder(object):
     def wurm_single_resident_bytes(self, N, S, m, n):
         return self.mirror_bytes_per_env * int(getattr(N, 'value', N))
 
+    def wurm_single_resident_flush(self, c_addr, stream):
+        c = _lib.SingleCall.from_address(c_addr)
+        assert c.resident and c.resident_lazy and c.resident_valid  # (the library would do nothing otherwise)
+        self.flushes.append(len(self.calls))   # kept apart from `calls`: position in the call sequence
+        return 0
+
     def step_slot(self, c_addr, sl_addr, slot, actions, dtype, call, pending, pre_call, want_after, stream):
         c = _lib.SingleCall.from_address(c_addr)
         if self.fail_next:
@@ -39,7 +46,8 @@ class _Recorder(object):
             return -3
         self.calls.append(('step', dict(slot=slot, call=call, pending=bool(pending), pre_call=pre_call,
                                         want_after=bool(want_after), dtype=dtype, obs_mode=c.obs_mode, envs=c.envs,
-                                        mirror=bool(c.resident), mirror_valid=bool(c.resident_valid))))
+                                        mirror=bool(c.resident), mirror_valid=bool(c.resident_valid),
+                                        lazy=bool(c.resident_lazy))))
         if c.resident:  # what wurm_single_step_slot does: the mirror is current after a launch that was given it
             c.resident_valid = 1
         return 0
@@ -327,3 +335,44 @@ def test_no_mirror_for_shapes_the_library_does_not_serve(env_and_log):
     env.observation_mode = 'default'         # (the recorder decides; the library serves size 9, partial_2 / none)
     _step(env)
     assert not _steps(log)[-1]['mirror']
+
+
+def test_a_lazy_mirror_is_written_out_before_anything_else_looks_at_the_state(env_and_log):
+    """wurm_single_call.resident_lazy: the step launches do not write `envs`; whatever else reads or writes the state is
+    preceded by wurm_single_resident_flush — once — and the caller getting hold of the tensor ends the lazy form"""
+    env, log = env_and_log
+    rec = env._rec
+    for _ in range(3):
+        _, _, d, _ = _step(env)
+        env.reset(d, return_observations=False)
+    assert all(s['lazy'] for s in _steps(log)) and rec.flushes == []
+    env._observe('default')                      # flush, (postponed) reset, observe
+    assert rec.flushes == [3] and [c[0] for c in log[3:]] == ['reset', 'observe']
+    env._observe('default')                      # envs are current now: no second flush
+    assert rec.flushes == [3]
+    _step(env)
+    assert _steps(log)[-1]['lazy'] and not _steps(log)[-1]['mirror_valid']
+    _step(env)
+    n = len(log)
+    e = env.envs                                 # written out, handed out, eager from now on
+    assert rec.flushes == [3, n]
+    _step(env)
+    assert not _steps(log)[-1]['lazy'] and _steps(log)[-1]['mirror_valid']   # (writing out leaves the mirror current)
+    env._observe('default')
+    assert rec.flushes == [3, n]                 # nothing to write out in the eager form
+    del e
+
+
+def test_replacing_the_state_tensor_writes_a_lazy_mirror_out_to_the_old_one_first(env_and_log):
+    env, log = env_and_log
+    rec = env._rec
+    _step(env); _step(env)
+    old_ptr = env._c.envs
+    seen = []
+    orig = rec.wurm_single_resident_flush
+    rec.wurm_single_resident_flush = lambda c_addr, stream: (seen.append(_lib.SingleCall.from_address(c_addr).envs),
+                                                            orig(c_addr, stream))[1]
+    env.envs = torch.zeros(8, 3, 9, 9)
+    assert seen == [old_ptr]
+    _step(env)
+    assert not _steps(log)[-1]['lazy'] and not _steps(log)[-1]['mirror_valid'] and _steps(log)[-1]['envs'] != old_ptr

@@ -59,7 +59,9 @@ def test_basic_movement(api):
 
 
 def test_eat_food(api):
-    env = api['SingleSnake'](num_envs=1, size=size, manual_setup=True)
+    # seed pinned (extension keyword): the reference's test leaves the respawned food to the global RNG and fails when it
+    # lands on one of the two cells the snake crosses next (about 1 run in 50)
+    env = api['SingleSnake'](num_envs=1, size=size, manual_setup=True, seed=2019)
     env.envs = api['get_test_env'](size, 'up').to(DEVICE)
     actions = torch.Tensor([0, 3, 3, 0, 0]).unsqueeze(1).long().to(DEVICE)
     initial_size = api['body'](env.envs).max()

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""A few per-call step / reset launches (SingleSnake N x 9 x 9 partial_2; N from argv, default 65536) — PMC target."""
+"""A few per-call step / reset launches (SingleSnake N x 9 x 9 partial_2; N from argv, default 65536; second argument
+`ref`: reset(done) returns its observation as in the reference, default: it does not) — PMC / kernel-trace target."""
 import os
 import sys
 
@@ -12,6 +13,6 @@ env = SingleSnake(num_envs=N, size=9, observation_mode='partial_2', device='cuda
 a = torch.randint(4, (400, N), device='cuda')
 for t in range(400):
     _, _, d, _ = env.step(a[t])
-    env.reset(d, return_observations=False)
+    env.reset(d, return_observations=(len(sys.argv) > 2 and sys.argv[2] == 'ref'))
 torch.cuda.synchronize()
 print('done')

@@ -21,7 +21,7 @@ ACT_I64, ACT_I32 = 0, 1
 SYMBOLS = [
     'wurm_version', 'wurm_single_obs_elems', 'wurm_grid_obs_elems',
     'wurm_single_step', 'wurm_single_reset', 'wurm_single_observe', 'wurm_single_rollout', 'wurm_single_check',
-    'wurm_single_step_reset', 'wurm_single_resident_bytes', 'wurm_grid_step_reset', 'wurm_single_step_slot', 'wurm_grid_step_slot',
+    'wurm_single_step_reset', 'wurm_single_resident_bytes', 'wurm_single_resident_flush', 'wurm_grid_step_reset', 'wurm_single_step_slot', 'wurm_grid_step_slot',
     'wurm_grid_step', 'wurm_grid_reset', 'wurm_grid_observe', 'wurm_grid_rollout',
     'wurm_multi_obs_elems', 'wurm_multi_step', 'wurm_multi_step_reset', 'wurm_multi_step_packed', 'wurm_multi_reset', 'wurm_multi_observe', 'wurm_multi_check',
     'wurm_multi_rollout',
@@ -40,7 +40,8 @@ class SingleCall(ctypes.Structure):
                 ('seed', ctypes.c_uint64), ('call', ctypes.c_uint64), ('pre_call', ctypes.c_uint64),
                 ('actions_dtype', ctypes.c_int), ('obs_mode', ctypes.c_int), ('obs_n', ctypes.c_int),
                 ('size', ctypes.c_int), ('post_reset', ctypes.c_int), ('start_y', ctypes.c_int),
-                ('start_x', ctypes.c_int), ('resident', ctypes.c_void_p), ('resident_valid', ctypes.c_int)]
+                ('start_x', ctypes.c_int), ('resident', ctypes.c_void_p), ('resident_valid', ctypes.c_int),
+                ('resident_lazy', ctypes.c_int)]
 
 
 class SingleSlabs(ctypes.Structure):

@@ -11,6 +11,9 @@
 // other entry point can be called in between.  The caller says whether the mirror is current (wurm_single_call.
 // resident_valid: nobody else has written `envs` since the last call that maintained it); if not, a build kernel
 // recreates it from `envs` first (the cooperative read + validation of lane_rollout.hpp).
+// LAZY (wurm_single_call.resident_lazy): `envs` is not written at all — the ~12 scattered 4-byte stores per env are what
+// the eager form's waves spend 40-55 % of their life on — and is brought up to date from the mirror by
+// lane_resident_flush_kernel (wurm_single_resident_flush) before anything else looks at it.
 //
 // One env per lane for the transition; crops of the post-step state (`obs`) and, when asked for, of the state after the
 // finished envs are rebuilt (`obs_after`, what reset(done) returns) as (which, env) pair lanes -> bit planes -> flat bit
@@ -28,7 +31,8 @@ namespace wurm {
 
 // The mirror: two planes of N uint4.
 //   plane 0 [env]: occupancy lo, hi, q0, q1
-//   plane 1 [env]: q2, head code | tail code << 7 | length << 14 | orientation << 21 | (food code + 1) << 23, flags, 0
+//   plane 1 [env]: q2, head code | tail code << 7 | length << 14 | orientation << 21 | (food code + 1) << 23, flags,
+//                  head row | head column << 4 (true coordinates: the code of a head on the border ring is ambiguous)
 constexpr u32 RES_ACT = 1u;       // the env is in the lane kernels' domain and the record describes it
 constexpr u32 RES_TERMINAL = 2u;  // the last step finished the env: the record is void unless the next call rebuilds it
 constexpr int RES_BYTES = 32;
@@ -59,7 +63,88 @@ __global__ __launch_bounds__(256) void lane_resident_build_kernel(ResidentArgs a
         const u32 pk = (u32)(c & 127) | ((u32)(tc & 127) << 7) | ((u32)(L & 127) << 14) | ((u32)(o & 3) << 21) |
                        ((u32)((food + 1) & 127) << 23);
         a.res[env0 + lane] = make_uint4((u32)occ, (u32)(occ >> 32), q0, q1);
-        a.res[p.N + env0 + lane] = make_uint4(q2, pk, act ? RES_ACT : 0u, 0u);
+        a.res[p.N + env0 + lane] = make_uint4(q2, pk, act ? RES_ACT : 0u, (u32)(c >> 3) | ((u32)(c & 7) << 4));
+    }
+}
+
+// `envs` of ONE env from its record, whole wave (uniform arguments): body values by walking the queue from the head —
+// a cell the walk visits twice (the snake ran into itself: single_snake.py:252-262 adds the new head's value on top of
+// what the cell held) gets the sum.  For the finished env that is stepped again without its reset, LAZY form.
+__device__ __forceinline__ void res_materialise_env(float *ep, int lane, u32 w0, u32 w1, u32 w2, int L, int hy, int hx, int fidx)
+{
+    constexpr int S = 9, C = LR_C;
+    int v0 = 0, v1 = 0; // body values of cells lane and lane + 64
+    int y = hy, x = hx;
+    for (int v = L; v >= 1; --v) {
+        const int cell = y * S + x;
+        if (cell == lane) v0 += v;
+        if (cell == lane + 64) v1 += v;
+        const int m = (int)(w0 & 3u);
+        y -= lr_dy(m); x -= lr_dx(m);
+        w0 = (w0 >> 2) | (w1 << 30); w1 = (w1 >> 2) | (w2 << 30); w2 >>= 2;
+    }
+    const int hcell = hy * S + hx;
+    ep[lane] = lane == fidx ? 1.0f : 0.0f;
+    ep[C + lane] = lane == hcell ? 1.0f : 0.0f;
+    ep[2 * C + lane] = (float)v0;
+    if (lane + 64 < C) {
+        ep[lane + 64] = lane + 64 == fidx ? 1.0f : 0.0f;
+        ep[C + lane + 64] = lane + 64 == hcell ? 1.0f : 0.0f;
+        ep[2 * C + lane + 64] = (float)v1;
+    }
+}
+
+// `envs` from the mirror (LAZY form): every env whose record describes it (RES_ACT) is written whole; the others are the
+// ones the one-env-per-wave code steps on `envs` itself, which is current for them.
+template <int EPW>
+__global__ __launch_bounds__(256) void lane_resident_flush_kernel(ResidentArgs a)
+{
+    constexpr int S = 9, N4 = EPW * LR_C3 / 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char res_lds[];
+    const StepArgs &p = a.p;
+    const int wave = uniform((int)(threadIdx.x >> 6)), wpb = (int)(blockDim.x >> 6), lane = (int)(threadIdx.x & 63u);
+    const long long env0 = ((long long)blockIdx.x * wpb + wave) * EPW;
+    if (env0 >= p.N) return;
+    const int nenv = (int)min((long long)EPW, p.N - env0);
+    u32 *slab = (u32 *)(res_lds + wave * (EPW * LR_C3 + 16)); // the block's state, one byte per float
+    unsigned char *sb8 = (unsigned char *)slab;
+    uint4 r0 = make_uint4(0, 0, 0, 0), r1 = r0;
+    if (lane < nenv) {
+        r0 = a.res[env0 + lane];
+        r1 = a.res[p.N + env0 + lane];
+    }
+    for (int i = lane; i < N4 + 4; i += 64) slab[i] = 0;
+    wave_lds_sync();
+    const bool actf = lane < nenv && (r1.z & RES_ACT) != 0;
+    if (actf) {
+        unsigned char *my = sb8 + lane * LR_C3;
+        const int L = (int)((r1.y >> 14) & 127u), food = (int)((r1.y >> 23) & 127u) - 1;
+        int y = (int)(r1.w & 15u), x = (int)((r1.w >> 4) & 15u);
+        if (food >= 0) my[(food >> 3) * S + (food & 7)] = 1;
+        my[LR_C + y * S + x] = 1;
+        u32 w0 = r0.z, w1 = r0.w, w2 = r1.x;
+        for (int v = L; v >= 1; --v) {
+            my[2 * LR_C + y * S + x] += (unsigned char)v;
+            const int m = (int)(w0 & 3u);
+            y -= lr_dy(m); x -= lr_dx(m);
+            w0 = (w0 >> 2) | (w1 << 30); w1 = (w1 >> 2) | (w2 << 30); w2 >>= 2;
+        }
+    }
+    const u64 am = ballot(actf);
+    wave_lds_sync();
+    if (nenv == EPW && am == (EPW == 64 ? ~0ull : (1ull << EPW) - 1ull) && (((size_t)p.envs) & 15u) == 0) {
+        float4 *out4 = (float4 *)(p.envs + env0 * LR_C3);
+#pragma unroll 4
+        for (int g = lane; g < N4; g += 64) {
+            const u32 b = slab[g];
+            out4[g] = make_float4((float)(b & 0xffu), (float)((b >> 8) & 0xffu), (float)((b >> 16) & 0xffu), (float)(b >> 24));
+        }
+    } else {
+        float *sb = p.envs + env0 * LR_C3;
+        for (int i = lane; i < nenv * LR_C3; i += 64) {
+            const int e = i / LR_C3;
+            if ((am >> e) & 1ull) sb[i] = (float)sb8[i];
+        }
     }
 }
 
@@ -71,8 +156,9 @@ struct ResLds {
     static constexpr int BYTES = SCR + 128;
 };
 
-// EPW envs per wave; NW = 2: crops of `obs` and of `obs_after` (EPW * 2 <= 64 pair lanes), NW = 1: `obs` only
-template <int EPW, int NW, int OBSK>
+// EPW envs per wave; NW = 2: crops of `obs` and of `obs_after` (EPW * 2 <= 64 pair lanes), NW = 1: `obs` only; LAZY: `envs`
+// is left alone
+template <int EPW, int NW, int OBSK, bool LAZY>
 __global__ __launch_bounds__(256) void lane_resident_step_kernel(ResidentArgs a)
 {
     static_assert(EPW == 16 || EPW == 32 || EPW == 64, "envs per wave");
@@ -167,12 +253,13 @@ __global__ __launch_bounds__(256) void lane_resident_step_kernel(ResidentArgs a)
         const u32 pk = (u32)(c & 127) | ((u32)(tc & 127) << 7) | ((u32)(L & 127) << 14) | ((u32)(o & 3) << 21) |
                        ((u32)((food + 1) & 127) << 23);
         a.res[env] = make_uint4((u32)occ, (u32)(occ >> 32), q0, q1);
-        a.res[p.N + env] = make_uint4(q2, pk, act ? (RES_ACT | (fin ? RES_TERMINAL : 0u)) : (r1.z & ~RES_ACT), 0u);
+        a.res[p.N + env] = make_uint4(q2, pk, act ? (RES_ACT | (fin ? RES_TERMINAL : 0u)) : (r1.z & ~RES_ACT),
+                                      act ? ((u32)ny | ((u32)nx << 4)) : r1.w);
     }
 
     WURM_TL(3); // outputs and mirror stored
     // ---- `envs`: the elements that change (single_snake.py:246-282), straight from the env lanes
-    {
+    if (!LAZY) {
         char *sb = (char *)(p.envs + env0 * C3);
         const unsigned so = 4u * (unsigned)(lane * C3);
         auto put = [&](int elem, float v) { *(float *)(sb + (so + 4u * (unsigned)elem)) = v; };
@@ -311,6 +398,16 @@ __global__ __launch_bounds__(256) void lane_resident_step_kernel(ResidentArgs a)
     // ---- envs outside the domain: the one-env-per-wave code reads and writes their state, outputs and crops itself
     // (nothing above touched them except crop bytes, which it overwrites)
     if (odd != 0) {
+        if (LAZY) { // a finished env that is stepped again without its reset: `envs` has to show its last state first
+            for (u64 m = ballot(mine && (r1.z & (RES_ACT | RES_TERMINAL)) == (RES_ACT | RES_TERMINAL) && !pre); m != 0; m &= m - 1) {
+                const int src = first_bit(m);
+                const int fd = (int)((lane_value((int)r1.y, src) >> 23) & 127) - 1;
+                res_materialise_env(p.envs + (env0 + src) * C3, lane, (u32)lane_value((int)r0.z, src),
+                                    (u32)lane_value((int)r0.w, src), (u32)lane_value((int)r1.x, src),
+                                    (lane_value((int)r1.y, src) >> 14) & 127, lane_value((int)r1.w, src) & 15,
+                                    (lane_value((int)r1.w, src) >> 4) & 15, fd >= 0 ? (fd >> 3) * S + (fd & 7) : -1);
+            }
+        }
         __threadfence();
         wave_lds_sync();
         for (u64 m = odd; m != 0; m &= m - 1)
@@ -334,7 +431,22 @@ bool lane_resident_eligible(const StepArgs &p)
     return true;
 }
 
-hipError_t launch_lane_resident(const StepArgs &p, void *resident, bool valid, hipStream_t stream)
+hipError_t launch_lane_resident_flush(const StepArgs &p, void *resident, hipStream_t stream)
+{
+    ResidentArgs a;
+    a.p = p;
+    a.res = (uint4 *)resident;
+    constexpr int EPW = 16;
+    const long long waves = (p.N + EPW - 1) / EPW;
+    const int wpb = waves >= 1024 ? 4 : 1;
+    dim3 block(64 * wpb), grid((unsigned)((waves + wpb - 1) / wpb));
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(lane_resident_flush_kernel<EPW>, grid, block, (size_t)((EPW * LR_C3 + 16) * wpb), stream, a);
+    return hipGetLastError();
+}
+
+template <bool LAZY>
+static hipError_t launch_lane_resident_form(const StepArgs &p, void *resident, bool valid, hipStream_t stream)
 {
     ResidentArgs a;
     a.p = p;
@@ -363,18 +475,24 @@ hipError_t launch_lane_resident(const StepArgs &p, void *resident, bool valid, h
         hipLaunchKernelGGL(kernel, grid, block, (size_t)(LR_TAB + ResLds::BYTES * wpb), stream, a);
     };
     if (!crops) {
-        if (epw == 16) go(lane_resident_step_kernel<16, 1, WURM_OBS_NONE>, 16);
-        else if (epw == 32) go(lane_resident_step_kernel<32, 1, WURM_OBS_NONE>, 32);
-        else go(lane_resident_step_kernel<64, 1, WURM_OBS_NONE>, 64);
+        if (epw == 16) go(lane_resident_step_kernel<16, 1, WURM_OBS_NONE, LAZY>, 16);
+        else if (epw == 32) go(lane_resident_step_kernel<32, 1, WURM_OBS_NONE, LAZY>, 32);
+        else go(lane_resident_step_kernel<64, 1, WURM_OBS_NONE, LAZY>, 64);
     } else if (nw == 1) {
-        if (epw == 16) go(lane_resident_step_kernel<16, 1, WURM_OBS_PARTIAL>, 16);
-        else if (epw == 32) go(lane_resident_step_kernel<32, 1, WURM_OBS_PARTIAL>, 32);
-        else go(lane_resident_step_kernel<64, 1, WURM_OBS_PARTIAL>, 64);
+        if (epw == 16) go(lane_resident_step_kernel<16, 1, WURM_OBS_PARTIAL, LAZY>, 16);
+        else if (epw == 32) go(lane_resident_step_kernel<32, 1, WURM_OBS_PARTIAL, LAZY>, 32);
+        else go(lane_resident_step_kernel<64, 1, WURM_OBS_PARTIAL, LAZY>, 64);
     } else {
-        if (epw == 16) go(lane_resident_step_kernel<16, 2, WURM_OBS_PARTIAL>, 16);
-        else go(lane_resident_step_kernel<32, 2, WURM_OBS_PARTIAL>, 32);
+        if (epw == 16) go(lane_resident_step_kernel<16, 2, WURM_OBS_PARTIAL, LAZY>, 16);
+        else go(lane_resident_step_kernel<32, 2, WURM_OBS_PARTIAL, LAZY>, 32);
     }
     return hipGetLastError();
+}
+
+hipError_t launch_lane_resident(const StepArgs &p, void *resident, bool valid, bool lazy, hipStream_t stream)
+{
+    return lazy ? launch_lane_resident_form<true>(p, resident, valid, stream)
+                : launch_lane_resident_form<false>(p, resident, valid, stream);
 }
 
 } // namespace wurm

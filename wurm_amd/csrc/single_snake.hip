@@ -1845,10 +1845,11 @@ int wurm_single_rollout(float *envs, void *actions, int actions_dtype, float *re
     return launch<true>(K_ROLLOUT, p, stream);
 }
 
-// *mirror_current (nullable): whether c->resident describes envs once this call has run
-static int fused_entry(bool snake, const wurm_single_call *c, void *stream, int *mirror_current = nullptr)
+// *mirror_state (nullable): 1 = c->resident describes the state once this call has run, 0 = another path wrote envs (the
+// mirror is stale), -1 = nothing was launched
+static int fused_entry(bool snake, const wurm_single_call *c, void *stream, int *mirror_state = nullptr)
 {
-    if (mirror_current) *mirror_current = 0;
+    if (mirror_state) *mirror_state = -1;
     if (!c) return WURM_ERR_INVALID_ARG;
     int rc = check_common(snake, c->envs, c->num_envs, c->size, c->obs, c->obs_mode, c->obs_n, c->actions_dtype);
     if (rc) return rc;
@@ -1869,16 +1870,35 @@ static int fused_entry(bool snake, const wurm_single_call *c, void *stream, int 
     p.inject_food = c->inject_food; p.inject_reset = c->inject_reset; p.done_in = c->pre_done;
     p.obs_after = c->obs_after; p.done_copy = c->done_copy; p.inject_pre_reset = c->inject_pre_reset;
     p.pre_call = c->pre_call; p.post_reset = c->post_reset;
-    if (snake && c->resident != nullptr && N > 0 && lane_resident_eligible(p)) {
-        // the caller keeps a compact mirror of the state: the step reads that instead of envs (lane_resident.hpp)
+    if (snake && c->resident != nullptr && N > 0) {
         p.lds_per_wave = ((p.S * p.S + 15) / 16) * 16;
-        if (launch_lane_resident(p, c->resident, c->resident_valid != 0, (hipStream_t)stream) != hipSuccess) return WURM_ERR_HIP;
-        if (mirror_current) *mirror_current = 1;
-        return WURM_OK;
+        if (lane_resident_eligible(p)) {
+            // the caller keeps a compact mirror of the state: the step reads that instead of envs (lane_resident.hpp)
+            if (launch_lane_resident(p, c->resident, c->resident_valid != 0, c->resident_lazy != 0, (hipStream_t)stream) !=
+                hipSuccess)
+                return WURM_ERR_HIP;
+            if (mirror_state) *mirror_state = 1;
+            return WURM_OK;
+        }
+        // this call cannot use the mirror: a lazy one is written out to envs before the ordinary kernels read them
+        if (c->resident_lazy && c->resident_valid && p.S == 9 &&
+            launch_lane_resident_flush(p, c->resident, (hipStream_t)stream) != hipSuccess)
+            return WURM_ERR_HIP;
     }
+    if (mirror_state) *mirror_state = 0;
     // nothing to rebuild and no second observation: the plain step kernel (lighter on registers for large grids)
     const Kind kind = resets ? K_FUSED : K_STEP;
     return snake ? launch<true>(kind, p, stream) : launch<false>(kind, p, stream);
+}
+
+int wurm_single_resident_flush(const wurm_single_call *c, void *stream)
+{
+    if (!c) return WURM_ERR_INVALID_ARG;
+    if (!c->resident || !c->resident_lazy || !c->resident_valid || c->num_envs <= 0) return WURM_OK;
+    if (!c->envs || c->size != 9) return WURM_ERR_INVALID_ARG;
+    StepArgs p = {};
+    p.envs = c->envs; p.N = c->num_envs; p.S = c->size;
+    return launch_lane_resident_flush(p, c->resident, (hipStream_t)stream) == hipSuccess ? WURM_OK : WURM_ERR_HIP;
 }
 
 int64_t wurm_single_resident_bytes(int64_t num_envs, int size, int obs_mode, int obs_n)
@@ -1915,9 +1935,9 @@ static int step_slot(bool snake, wurm_single_call *c, const wurm_single_slabs *s
     } else {
         c->pre_done = nullptr;
     }
-    int current = 0;
-    const int rc = fused_entry(snake, c, stream, &current);
-    if (c->resident) c->resident_valid = (rc == WURM_OK && current) ? 1 : 0;
+    int mirror = -1;
+    const int rc = fused_entry(snake, c, stream, &mirror);
+    if (c->resident && mirror >= 0) c->resident_valid = (rc == WURM_OK && mirror == 1) ? 1 : 0;
     return rc;
 }
 

@@ -25,6 +25,7 @@ _STEP_SLOT (entry point name), _mode_info(mode) -> (mode code, n, obs shape), _l
 done, obs, mode code, n, call), _configure_call(block), _make_out(i) -> what step returns for slot i.
 """
 import ctypes
+import os
 
 import torch
 
@@ -158,6 +159,7 @@ class FastStepMixin(object):
         # batches).  The library marks it current after each step launch; everything else that writes the state clears
         # the mark (_touch); a state tensor the caller got hold of is watched for in-place edits through its version counter
         self._mirror, self._mirror_key, self._mirror_off = None, None, False
+        self._lazy_mirror = os.environ.get('WURM_RESIDENT_LAZY', '1') != '0'
 
     # state of the step machine that other methods of the classes read and write
     _call = property(lambda self: self._fs.call, lambda self, v: setattr(self._fs, 'call', v))
@@ -205,6 +207,7 @@ class FastStepMixin(object):
         if fs.pending:
             self._flush()
         fs.obs_after = None
+        self._write_out()  # (lazy mirror: the step launches have not been writing `envs`; eager from now on, _watch)
         self._watch(self._envs)
         return self._envs
 
@@ -215,9 +218,9 @@ class FastStepMixin(object):
         fs.pending = False
         fs.last_fresh = False
         fs.ok = False
+        self._touch()  # (a lazy mirror is written out to the tensor that is being replaced, which is still ours here)
         self._envs_ok = None
         self._envs = value
-        self._touch()
         self._watch(value)
 
     def _flush(self):
@@ -238,14 +241,25 @@ class FastStepMixin(object):
         return self._checked(self._envs)
 
     def _touch(self):
-        """something other than the step launch is about to write the state: the mirror is rebuilt by the next step"""
+        """Something other than the step launch is about to look at the state or to write it: a lazy mirror is written
+        out to `envs` first (the step launches have not been writing them), and the next step rebuilds the mirror."""
+        self._write_out()
         self._c.resident_valid = 0
+
+    def _write_out(self):
+        """`envs` from a lazy mirror (which stays current)"""
+        c = self._c
+        if c.resident_valid and c.resident and c.resident_lazy:
+            rc = _lib.call(self.device.index, _lib.lib().wurm_single_resident_flush, ctypes.addressof(c),
+                           _lib.stream_ptr(self.device.index))
+            _lib.check(rc, 'wurm_single_resident_flush')
 
     def _watch(self, t):
         """The caller holds the state tensor `t` from now on and may edit it in place at any time: every step compares its
         version counter (in-place torch ops bump it) and rebuilds the mirror after a change.  Tensors without version
         counters (made under torch.inference_mode()) cannot be watched: no mirror from then on."""
         fs = self._fs
+        self._c.resident_lazy = 0  # the caller may READ it at any time as well: the step launches write `envs` from now on
         try:
             fs.watch, fs.watch_version = t, t._version
         except (RuntimeError, AttributeError):
@@ -277,6 +291,9 @@ class FastStepMixin(object):
         self._mirror = torch.empty(nbytes, dtype=torch.uint8, device=self.device) if nbytes > 0 else None
         self._c.resident = self._mirror.data_ptr() if self._mirror is not None else None
         self._c.resident_valid = 0
+        # lazy (the step launches do not write `envs`, _touch() brings them up to date) as long as the caller has never
+        # got hold of the state tensor
+        self._c.resident_lazy = int(self._mirror is not None and self._fs.watch is None and self._lazy_mirror)
 
     def _checked(self, e: torch.Tensor) -> torch.Tensor:
         if e is self._envs_ok:
@@ -290,7 +307,7 @@ class FastStepMixin(object):
             self._envs = e
         self._envs_ok = e
         self._c.envs = e.data_ptr()
-        self._touch()
+        self._c.resident_valid = 0  # another tensor (its setter already dealt with a lazy mirror of the old one)
         return e
 
     @property
