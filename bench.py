@@ -435,7 +435,8 @@ def extra_measurements(device):
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         out[key] = {'value': env.num_envs * T / dt, 'unit': 'env-steps/s', 'us_per_batch_step': dt / T * 1e6, 'what': what}
-        t = traffic_detail.get(key)
+        t = traffic_detail.get({'per_call_api_cfg3_65536': 'resident_step_65536x9_partial2_reset_obs',
+                                'per_call_api_cfg3_65536_no_reset_obs': 'resident_step_65536x9_partial2'}.get(key, key))
         if t:  # rocprofv3 FETCH_SIZE + WRITE_SIZE of one iteration's launches (profiles/hbm_traffic.json)
             out[key]['traffic_bytes_per_batch_step'] = t['total_bytes']
             out[key]['frac_real'] = t['total_bytes'] / (dt / T) / 1e9 / HBM_PEAK_GBS
@@ -445,11 +446,31 @@ def extra_measurements(device):
     except Exception:
         traffic_detail = {}
 
+    # BASELINE configs[2] whole on one GPU.  As for 512 envs, the plain key is the reference's own call form (reset(d) returns
+    # its observation); from 4096 envs of 9 x 9 the step runs on the resident mirror of the state
+    # (wurm_amd/csrc/lane_resident.hpp) — `_no_mirror` switches it off (lane_step_kernel, what rounds 2 measured)
     N, T = 65536, 200
     acts = torch.randint(4, (T + 10, N), device=device, dtype=torch.int64)
     per_call_case('per_call_api_cfg3_65536', SingleSnake(N, SIZE, observation_mode=OBS_MODE, device=device, seed=0),
                   lambda t: acts[t], lambda d: d, T,
-                  'BASELINE configs[2] whole on one GPU through `env.step(a); env.reset(d, return_observations=False)`')
+                  'BASELINE configs[2] whole on one GPU through `env.step(a); env.reset(d)` (resident mirror, lazy)', reset_kw={})
+    per_call_case('per_call_api_cfg3_65536_no_reset_obs', SingleSnake(N, SIZE, observation_mode=OBS_MODE, device=device, seed=0),
+                  lambda t: acts[t], lambda d: d, T,
+                  'the same through `env.step(a); env.reset(d, return_observations=False)`')
+    os.environ['WURM_RESIDENT_MIN_ENVS'] = str(10 ** 9)
+    try:
+        per_call_case('per_call_api_cfg3_65536_no_mirror', SingleSnake(N, SIZE, observation_mode=OBS_MODE, device=device, seed=0),
+                      lambda t: acts[t], lambda d: d, T,
+                      '`env.step(a); env.reset(d)` with the mirror switched off (WURM_RESIDENT_MIN_ENVS): lane_step_kernel '
+                      'reads the whole (N,3,9,9) state every call', reset_kw={})
+    finally:
+        os.environ.pop('WURM_RESIDENT_MIN_ENVS')
+    # algorithmic bytes of one resident step launch: two crops of 300 B per env, the mirror read and written (2 x 32 B),
+    # action in and out (16 B), reward + 4 flag bytes + the postponed reset's flag (9 B)
+    for key, per_env in (('per_call_api_cfg3_65536', 600 + 64 + 16 + 9), ('per_call_api_cfg3_65536_no_reset_obs', 300 + 64 + 16 + 9)):
+        e = out[key]
+        e['algorithmic_bytes_per_batch_step'] = per_env * N
+        e['frac_algorithmic'] = per_env * N / (e['us_per_batch_step'] * 1e-6) / 1e9 / HBM_PEAK_GBS
     N, T = 8192, 200
     acts = torch.randint(4, (T + 10, N), device=device, dtype=torch.int64)
     per_call_case('per_call_api_cfg5_8192x36_default', SingleSnake(N, 36, observation_mode='default', device=device, seed=0),

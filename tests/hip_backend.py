@@ -133,7 +133,7 @@ class HipBackend(object):
                 if resident.get('sync', True):
                     _lib.check(self.lib.wurm_single_resident_flush(ctypes.addressof(c), self._stream()), 'flush')
         torch.cuda.synchronize()
-        if not lazy or resident.get('sync', True):
+        if not lazy or resident.get('sync', True) or not resident['valid']:  # (not valid: the call wrote envs itself)
             envs[...] = e.cpu().numpy()
         actions[...] = a.cpu().numpy()
         assert torch.equal(copy, done), 'done_copy != done'

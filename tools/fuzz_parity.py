@@ -119,6 +119,72 @@ def fuzz_fused(rng):
     return desc
 
 
+def fuzz_resident(rng):
+    """wurm_single_step_reset on the resident mirror (wurm_single_call.resident, lane_resident.hpp), eager and lazy: random
+    batch sizes around the envs-per-wave settings, deferred resets with and without the reset observation, iterations
+    without any reset (finished envs stepped again), hostile actions, hand-edited states and calls that cannot use the
+    mirror (post_reset) in between; `envs` compared whenever the lazy form writes them out."""
+    S = 9
+    N = int(rng.choice([1, 3, 15, 16, 17, 31, 33, 63, 64, 65, 100, 129, 200, 257]))
+    T = int(rng.randint(5, 70))
+    mode = 'partial_2' if rng.rand() < 0.8 else 'none'
+    lazy = bool(rng.rand() < 0.6)
+    epw = int(rng.choice([0, 16, 32, 64]))
+    seed, off = int(rng.randint(1 << 30)), int(rng.randint(1 << 20))
+    desc = f'resident N={N} T={T} mode={mode} lazy={lazy} epw={epw} seed={seed} off={off}'
+    if os.environ.get('WURM_FUZZ_VERBOSE'):
+        print('start:', desc, flush=True)
+    if epw:
+        os.environ['WURM_RESIDENT_EPW'] = str(epw)
+    else:
+        os.environ.pop('WURM_RESIDENT_EPW', None)
+    try:
+        o, h = OracleBackend(seed, off), HipBackend(seed, off)
+        eo = np.zeros((N, 3, S, S), np.float32)
+        o.single_reset(eo, np.ones(N), 'none')
+        eh = eo.copy()
+        mirror = {'valid': 0, 'lazy': lazy}
+        call, prev, prev_call = 10, None, None
+        dtype = np.int64 if rng.rand() < 0.7 else np.int32
+        for t in range(T):
+            a = rng.randint(0, 4, N).astype(dtype)
+            if rng.rand() < 0.1:
+                a[rng.rand(N) < 0.3] = rng.randint(-9, 9)
+            ao, ah = a.copy(), a.copy()
+            style = int(rng.choice([0, 1, 1, 2, 2, 2, 3]))  # 0: post reset (no mirror), 1 / 2: deferred (+ obs_after), 3: none
+            edit = rng.rand() < 0.08
+            mirror['sync'] = bool(not lazy or edit or rng.rand() < 0.3 or t == T - 1)
+            kw = dict(call=call)
+            if style == 0:
+                kw.update(post_reset=True, want_obs_after=bool(rng.rand() < 0.5), pre_done=prev, pre_call=prev_call)
+            elif style in (1, 2):
+                kw.update(pre_done=prev, pre_call=prev_call, want_obs_after=(style == 2))
+            ro = o.single_step_reset(eo, ao, mode, **kw)
+            rh = h.single_step_reset(eh, ah, mode, resident=mirror, **kw)
+            same(ao, ah, f'{desc} actions t={t}')
+            if mirror['sync'] or style == 0:
+                same(eo, eh, f'{desc} state t={t} style={style}')
+            for k in ro:
+                same(ro[k], rh[k], f'{desc} {k} t={t} style={style}')
+            if style == 0 or style == 3:
+                prev, prev_call = None, None
+            else:
+                prev, prev_call = ro['done'], call + 1
+            if edit:  # the caller edits the state (and says so): an extra food, a food removed, a body value broken
+                i = int(rng.randint(N))
+                eo[i, 0, int(rng.randint(1, 8)), int(rng.randint(1, 8))] = 1
+                if rng.rand() < 0.5:
+                    eo[int(rng.randint(N)), 0] = 0
+                if rng.rand() < 0.3:
+                    eo[int(rng.randint(N)), 2, int(rng.randint(1, 8)), int(rng.randint(1, 8))] += 2
+                eh[...] = eo
+                mirror['valid'] = 0
+            call += 2
+    finally:
+        os.environ.pop('WURM_RESIDENT_EPW', None)
+    return desc
+
+
 def fuzz_lean(rng):
     """The shapes the lean / 9x9 rollout kernels take: chained launches, tape lengths around the 64-step chunk, action
     values outside 0..3, an occasional per-call step without reset in between (irregular states -> generic path)."""
@@ -169,7 +235,8 @@ def fuzz_lane(rng):
     eo, eh = np.zeros((N, 3, S, S), np.float32), np.zeros((N, 3, S, S), np.float32)
     o.single_reset(eo, np.ones(N), 'none'); h.single_reset(eh, np.ones(N), 'none')
     o.call = h.call = int(rng.randint(1 << 50))
-    old = {k: os.environ.get(k) for k in ('WURM_LANE_ROLLOUT_MIN_ENVS', 'WURM_LANE_ROLLOUT_EPW')}
+    old = {k: os.environ.get(k) for k in ('WURM_LANE_ROLLOUT_MIN_ENVS', 'WURM_LANE_ROLLOUT_EPW',
+                                                                 'WURM_RESIDENT_MIN_ENVS')}
     os.environ['WURM_LANE_ROLLOUT_MIN_ENVS'], os.environ['WURM_LANE_ROLLOUT_EPW'] = '0', str(epw)
     try:
         tc = 64 // epw
@@ -302,9 +369,10 @@ def fuzz_multi(rng):
     return desc
 
 
-FAMILIES = {'single': fuzz_single, 'fused': fuzz_fused, 'lean': fuzz_lean, 'lane': fuzz_lane, 'policy': fuzz_policy,
-            'grid': fuzz_grid, 'multi': fuzz_multi}
-WEIGHTS = {'single': 0.17, 'fused': 0.17, 'lean': 0.1, 'lane': 0.16, 'policy': 0.05, 'grid': 0.05, 'multi': 0.3}
+FAMILIES = {'single': fuzz_single, 'fused': fuzz_fused, 'resident': fuzz_resident, 'lean': fuzz_lean, 'lane': fuzz_lane,
+            'policy': fuzz_policy, 'grid': fuzz_grid, 'multi': fuzz_multi}
+WEIGHTS = {'single': 0.14, 'fused': 0.14, 'resident': 0.14, 'lean': 0.08, 'lane': 0.14, 'policy': 0.04, 'grid': 0.04,
+           'multi': 0.28}
 
 
 def library_sha256():
@@ -346,7 +414,8 @@ if __name__ == '__main__':
         rec = {'library_sha256': library_sha256(), 'seed': args.seed, 'seconds': round(elapsed, 1), 'cases': n,
                'total_cases': sum(n.values()), 'mismatches': fails, 'messages': messages,
                'forced_thresholds': {k: os.environ[k] for k in ('WURM_LANE_STEP_MIN_ENVS', 'WURM_GRID_STEP_MIN_CELLS',
-                                                                 'WURM_LANE_ROLLOUT_MIN_ENVS', 'WURM_LANE_ROLLOUT_EPW')
+                                                                 'WURM_LANE_ROLLOUT_MIN_ENVS', 'WURM_LANE_ROLLOUT_EPW',
+                                                                 'WURM_RESIDENT_MIN_ENVS')
                                      if k in os.environ},
                'bar': 'bit-exact HIP (C ABI) vs oracle on every output of every step'}
         runs = []

@@ -67,6 +67,10 @@ detail = {
     'fused_step_8192x9_partial2': traffic('void wurm::fused_step_kernel<2, true>', 524288),
     'fused_step_65536x9_partial2': traffic('void wurm::fused_step_kernel<2, true>', 4194304),
     'lane_step_65536x9_partial2': traffic('void wurm::lane_step_kernel<16, 9>', 262144),
+    # the per-call step on the resident mirror (lane_resident.hpp, lazy form): without / with the reset observation
+    'resident_step_8192x9_partial2': traffic('void wurm::lane_resident_step_kernel<32, 1, 4, true>', 16384),
+    'resident_step_65536x9_partial2': traffic('void wurm::lane_resident_step_kernel<64, 1, 4, true>', 65536),
+    'resident_step_65536x9_partial2_reset_obs': traffic('void wurm::lane_resident_step_kernel<32, 2, 4, true>', 131072),
     'multi_step_cfg4_4096x25_k4_full': traffic('wurm::multi_step_kernel', 262144, (3, 5)),  # dispatch order: 20 launches of cfg4', then 30 of cfg4
     'per_call_api_cfg4prime_4096x25_k4_partial5': traffic('wurm::multi_step_kernel', 262144, (0, 5)),
     'per_call_api_speeds_4096x36_k10': traffic('wurm::multi_step_wg_kernel', 1048576),

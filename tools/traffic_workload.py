@@ -75,15 +75,24 @@ for make, K, chunk in ((cfg4prime, 4, 16), (speeds_env, 10, 4)):
         env.reset(d['__all__'], return_observations=False)
     torch.cuda.synchronize()
     del env, actions
-# measured: the per-call loop (one fused launch per `step(a); reset(done)` iteration) at cfg2, cfg3-share, cfg3, cfg5
-for N, S, mode in ((512, 9, 'partial_2'), (8192, 9, 'partial_2'), (65536, 9, 'partial_2'), (8192, 36, 'default')):
+# measured: the per-call loop (one fused launch per `step(a); reset(done)` iteration) at cfg2, cfg3-share, cfg3, cfg5.
+# From 4096 envs of 9 x 9 the step runs on the resident mirror (lane_resident.hpp): first as shipped — without the reset
+# observation, then in the reference form at 65 536 — then with the mirror switched off (lane_step_kernel / fused_step_kernel)
+import os
+def percall(N, S, mode, reset_obs=False):
     env = SingleSnake(num_envs=N, size=S, observation_mode=mode, device=dev, seed=0)
     actions = torch.randint(4, (30, N), device=dev, dtype=torch.int64)
     for t in range(30):
         _, _, d, _ = env.step(actions[t])
-        env.reset(d, return_observations=False)
+        env.reset(d, return_observations=reset_obs)
     torch.cuda.synchronize()
-    del env, actions
+for N, S, mode in ((512, 9, 'partial_2'), (8192, 9, 'partial_2'), (65536, 9, 'partial_2'), (8192, 36, 'default')):
+    percall(N, S, mode)
+percall(65536, 9, 'partial_2', reset_obs=True)
+os.environ['WURM_RESIDENT_MIN_ENVS'] = str(10 ** 9)
+percall(8192, 9, 'partial_2')
+percall(65536, 9, 'partial_2')
+os.environ.pop('WURM_RESIDENT_MIN_ENVS')
 # measured: the per-call MultiSnake loop at cfg4 (multi_step_kernel with the postponed reset in front)
 env = MultiSnake(4096, 4, 25, device=dev, seed=0)
 actions = torch.randint(8, (30, 4, 4096), device=dev, dtype=torch.int64)
