@@ -33,6 +33,18 @@ cp $R/gpurun_out/pmc_obs_65536/summary.json $OUT/${TAG}_lane_rollout_65536_instm
 bash $R/tools/pmc_multi.sh > /dev/null
 cp $R/gpurun_out/pmc_multi_full/summary.json $OUT/${TAG}_multi_rollout_cfg4_full_instmix_pmc.json
 cp $R/gpurun_out/pmc_multi_none/summary.json $OUT/${TAG}_multi_rollout_cfg4_noobs_instmix_pmc.json
+# ... and of the per-call step on the resident mirror at 65 536 envs (reference form, and without the reset observation)
+bash $R/tools/pmc_percall.sh 65536 ref > /dev/null
+cp $R/gpurun_out/pmc_percall/summary.json $OUT/${TAG}_percall_65536x9_resident_ref_instmix_pmc.json
+bash $R/tools/pmc_percall.sh 65536 noobs > /dev/null
+cp $R/gpurun_out/pmc_percall/summary.json $OUT/${TAG}_percall_65536x9_resident_noobs_instmix_pmc.json
+# 5b. in-kernel timelines (needs `make -C wurm_amd/csrc timeline`) and the per-call loop with / without the mirror
+if [ -f $R/wurm_amd/libwurm_hip_timeline.so ]; then
+  for K in "--kernel lane_step" "--kernel resident --form ref" "--kernel resident --form noobs" "--kernel resident --form noobs --epw 16"; do
+    WURM_HIP_LIBRARY=$R/wurm_amd/libwurm_hip_timeline.so python3 $R/tools/kernel_timeline.py $K 2>/dev/null | grep -v amdgpu.ids >> $OUT/${TAG}_kernel_timeline.txt
+  done
+fi
+python3 $R/tools/percall_sweep.py 2>/dev/null | grep -v amdgpu.ids > $OUT/${TAG}_percall_sweep.txt
 # 6. the other BASELINE shapes
 python3 $R/tools/bench_configs.py > $OUT/${TAG}_percall_all_configs.jsonl 2>/dev/null
 python3 $R/tools/bench_big.py > $OUT/${TAG}_big_configs.txt 2>/dev/null
