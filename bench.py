@@ -436,7 +436,9 @@ def extra_measurements(device):
         dt = time.perf_counter() - t0
         out[key] = {'value': env.num_envs * T / dt, 'unit': 'env-steps/s', 'us_per_batch_step': dt / T * 1e6, 'what': what}
         t = traffic_detail.get({'per_call_api_cfg3_65536': 'resident_step_65536x9_partial2_reset_obs',
-                                'per_call_api_cfg3_65536_no_reset_obs': 'resident_step_65536x9_partial2'}.get(key, key))
+                                'per_call_api_cfg3_65536_no_reset_obs': 'resident_step_65536x9_partial2',
+                                'per_call_api_cfg5_8192x36_default': 'grid_step_8192x36_default',
+                                'per_call_api_cfg5_8192x36_default_no_mirror': 'grid_step_8192x36_default_no_mirror'}.get(key, key))
         if t:  # rocprofv3 FETCH_SIZE + WRITE_SIZE of one iteration's launches (profiles/hbm_traffic.json)
             out[key]['traffic_bytes_per_batch_step'] = t['total_bytes']
             out[key]['frac_real'] = t['total_bytes'] / (dt / T) / 1e9 / HBM_PEAK_GBS
@@ -475,7 +477,15 @@ def extra_measurements(device):
     acts = torch.randint(4, (T + 10, N), device=device, dtype=torch.int64)
     per_call_case('per_call_api_cfg5_8192x36_default', SingleSnake(N, 36, observation_mode='default', device=device, seed=0),
                   lambda t: acts[t], lambda d: d, T,
-                  'BASELINE configs[4] through `env.step(a); env.reset(d, return_observations=False)`')
+                  'BASELINE configs[4] through `env.step(a); env.reset(d, return_observations=False)` (clock grids kept in the '
+                  'resident mirror, lazy: grid_rollout.hip)')
+    os.environ['WURM_RESIDENT_MIN_ENVS'] = str(10 ** 9)
+    try:
+        per_call_case('per_call_api_cfg5_8192x36_default_no_mirror',
+                      SingleSnake(N, 36, observation_mode='default', device=device, seed=0), lambda t: acts[t], lambda d: d, T,
+                      'the same with the mirror switched off: the step reads the (N,3,36,36) fp32 state every call')
+    finally:
+        os.environ.pop('WURM_RESIDENT_MIN_ENVS')
     from wurm_amd.envs import SimpleGridworld
     N, T = 64, 2000
     acts = torch.randint(4, (T + 10, N), device=device, dtype=torch.int64)

@@ -142,9 +142,10 @@ typedef struct wurm_single_call {
 int wurm_single_step_reset(const wurm_single_call *c, void *stream);
 
 /* Size in bytes of the mirror of wurm_single_call.resident for this batch, 0 if the shape is not served by it (then pass
- * resident = NULL).  Served: size 9, observation none or partial_2, num_envs >= a threshold below which the launch is
- * latency-bound anyway (WURM_RESIDENT_MIN_ENVS, default 4096).  With the mirror the per-call step of a large batch
- * does not read the (N,3,9,9) state at all (wurm_amd/csrc/lane_resident.hpp).  Protocol: a call of
+ * resident = NULL).  Served: size 9 with observation none or partial_2 from 4096 envs on (32 bytes per env,
+ * wurm_amd/csrc/lane_resident.hpp), and 12 <= size <= 64 with any observation from 2^20 cells in the batch on (the 16-bit
+ * clock grid of the LDS step + 48 bytes per env, grid_rollout.hip); WURM_RESIDENT_MIN_ENVS replaces both thresholds by
+ * a number of envs.  With the mirror the per-call step of a large batch does not read the (N,3,S,S) state at all.  Protocol: a call of
  * wurm_single_step_reset with `resident` given leaves the mirror current unless it had inject_* / post_reset set;
  * wurm_single_step_slot maintains c->resident_valid itself after each call, the caller only CLEARS it whenever anything
  * else writes `envs` (another entry point, the caller's own code).  A call that cannot use the mirror (inject_* /

@@ -116,8 +116,9 @@ class HipBackend(object):
         c.actions_dtype, c.obs_mode, c.obs_n, c.size, c.post_reset = self._act(a), m, n, S, int(bool(post_reset))
         c.start_y, c.start_x = (-1, -1) if grid is None else grid
         if resident is not None:
-            if resident.get('buf') is None or resident['buf'].numel() != 32 * N:
-                resident['buf'], resident['valid'] = self._empty((32 * N,), torch.uint8), 0
+            nbytes = 32 * N if S == 9 else N * ((((S * S + 255) >> 8) * 512) + 48)  # (lane_resident.hpp / grid_rollout.hip)
+            if resident.get('buf') is None or resident['buf'].numel() != nbytes:
+                resident['buf'], resident['valid'] = self._empty((nbytes,), torch.uint8), 0
             c.resident, c.resident_valid = _lib.ptr(resident['buf']), int(resident.get('valid', 0))
             c.resident_lazy = int(lazy)
         import ctypes
@@ -126,7 +127,8 @@ class HipBackend(object):
         _lib.check(rc, 'wurm_single_step_reset')
         if resident is not None:
             resident['valid'] = int(inject_food is None and inject_reset is None and inject_pre_reset is None and
-                                    not post_reset and S == 9 and (m == _lib.OBS_NONE or (m == _lib.OBS_PARTIAL and n == 2)))
+                                    not post_reset and grid is None and
+                                    ((S == 9 and (m == _lib.OBS_NONE or (m == _lib.OBS_PARTIAL and n == 2))) or 12 <= S <= 64))
             if lazy:
                 resident['envs_dev'] = e
                 c.resident_valid = resident['valid']

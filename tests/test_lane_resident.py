@@ -289,6 +289,140 @@ def test_inference_mode_state_tensor_cannot_be_watched():
             assert torch.equal(o1, o2)
 
 
+@pytest.mark.parametrize('lazy', [False, True])
+@pytest.mark.parametrize('S,N,mode,T', [
+    (12, 70, 'default', 80),
+    (12, 33, 'partial_3', 80),
+    (14, 40, 'one_channel', 60),     # S^2 not a multiple of four: the unaligned instantiation
+    (20, 24, 'positions', 60),
+    (25, 9, 'raw', 50),
+    (36, 12, 'default', 50),
+    (36, 6, 'none', 40),
+    (64, 3, 'partial_6', 30),
+])
+def test_abi_grid_mirror(hip, S, N, mode, T, lazy):
+    """12 x 12 and larger: grid_step_kernel keeps its clock grids in the mirror (grid_rollout.hip) — every observation mode,
+    eager and lazy, postponed resets, un-reset finished envs (they leave the domain), hand-edited states (the caller says so),
+    other entry points in between"""
+    rng = np.random.RandomState(S * 100 + N)
+    o, h = OracleBackend(seed=13, env_offset=77), hip(seed=13, env_offset=77)
+    eo = np.zeros((N, 3, S, S), np.float32)
+    o.single_reset(eo, np.ones(N, np.uint8), 'none')
+    eh = eo.copy()
+    prev = None
+    deaths = 0
+    mirror = {'valid': 0, 'lazy': lazy}
+    for t in range(T):
+        a = rng.randint(-3, 9, size=N).astype(np.int64 if t % 2 else np.int32)
+        if t % 3:  # mostly straight ahead, so that snakes live long enough to eat now and then
+            a = np.where(rng.rand(N) < 0.7, 0, a).astype(a.dtype)
+        ao, ah = a.copy(), a.copy()
+        kw = dict(call=1 + 2 * t, pre_done=prev, pre_call=2 * t, want_obs_after=(t % 3 != 1))
+        mirror['sync'] = not lazy or t % 5 == 4 or t % 9 == 5 or t % 11 == 7 or t == T - 1
+        ro = o.single_step_reset(eo, ao, mode, **kw)
+        rh = h.single_step_reset(eh, ah, mode, resident=mirror, **kw)
+        assert mirror['valid'] == 1
+        _same(ah, ao, f'actions t={t}')
+        if mirror['sync']:
+            _same(eh, eo, f'state t={t}')
+        _cmp(ro, rh, t)
+        deaths += int(ro['done'].sum())
+        prev = ro['done'] if t % 4 != 3 else None
+        if t % 9 == 5:
+            eo[0, 0, 2, 2] = 1
+            eo[1 % N, 0] = 0
+            eo[2 % N, 2, 4, 4] = eo[2 % N, 2].max()
+            eh[...] = eo
+            mirror['valid'] = 0
+        if t % 11 == 7:
+            some = (rng.rand(N) < 0.2).astype(np.uint8)
+            o.call = h.call = 100000 + t
+            o.single_reset(eo, some, 'none')
+            h.single_reset(eh, some, 'none')
+            _same(eh, eo, f'eager reset t={t}')
+            mirror['valid'] = 0
+    assert deaths > 0
+
+
+def test_abi_grid_mirror_clock_rebase(hip):
+    """the 16-bit clocks of a mirrored grid are re-based before they reach the markers (EX_REBASE = 0xc000 in
+    grid_rollout.hip): a record is planted with its clocks just below the threshold and stepped across it"""
+    import torch
+    S, N = 12, 4
+    o, h = OracleBackend(seed=3), hip(seed=3)
+    eo = np.zeros((N, 3, S, S), np.float32)
+    o.single_reset(eo, np.ones(N, np.uint8), 'none')
+    eh = eo.copy()
+    mirror = {'valid': 0, 'lazy': True, 'sync': True}
+    a0 = np.zeros(N, np.int64)
+    ro = o.single_step_reset(eo, a0.copy(), 'default', call=1)
+    rh = h.single_step_reset(eh, a0.copy(), 'default', call=1, resident=mirror)
+    _cmp(ro, rh, 0)
+    # shift every live clock, T and G of the mirror by the same amount: the same state, later on the clock
+    iters = (S * S + 255) >> 8
+    buf = mirror['buf']
+    grids = buf[:N * iters * 512].view(torch.int16).view(N, iters * 256)
+    recs = buf[N * iters * 512:].view(torch.int32).view(N, 12)
+    shift = 0xc000 - 40
+    g32 = grids.to(torch.int32) & 0xffff
+    T_ = recs[:, 7].clone()
+    live = (g32 > T_[:, None]) & (g32 < 0xfffe)
+    g32 = torch.where(live, g32 + shift, g32)
+    grids.copy_(g32.to(torch.int16))
+    recs[:, 6] += shift
+    recs[:, 7] += shift
+    prev = ro['done']
+    rng = np.random.RandomState(0)
+    for t in range(1, 120):
+        a = rng.randint(0, 4, size=N).astype(np.int64)
+        ao, ah = a.copy(), a.copy()
+        kw = dict(call=1 + 2 * t, pre_done=prev, pre_call=2 * t, want_obs_after=True)
+        ro = o.single_step_reset(eo, ao, 'default', **kw)
+        rh = h.single_step_reset(eh, ah, 'default', resident=mirror, **kw)
+        _same(eh, eo, f'state t={t}')
+        _cmp(ro, rh, t)
+        prev = ro['done']
+    assert int((recs[:, 6] & 0xffffffff).max()) < 0xc000 + 8   # G came back down
+
+
+@pytest.mark.parametrize('mode', ['default', 'partial_3'])
+def test_host_loop_grid_mirror_matches_the_path_without(mode):
+    import torch
+    N, S, T, seed = 96, 16, 70, 4
+    res = []
+    for min_envs in (0, 10 ** 9):
+        with knobs(WURM_RESIDENT_MIN_ENVS=min_envs):
+            from wurm_amd.envs import SingleSnake
+            env = SingleSnake(N, S, observation_mode=mode, device='cuda:0', seed=seed)
+            g = torch.Generator(device='cuda:0').manual_seed(2)
+            acts = torch.randint(-1, 5, (T, N), generator=g, device='cuda:0')
+            outs = []
+            alias = None
+            for t in range(T):
+                a = acts[t].clone()
+                obs, r, d, info = env.step(a)
+                assert (env._mirror is not None) == (min_envs == 0)
+                back = env.reset(d) if t % 2 else env.reset(d, return_observations=False)
+                outs.append([x.clone() for x in (obs, r, d, info['self_collision'], info['edge_collision'], a)] +
+                            ([back.clone()] if back is not None else []))
+                if t % 10 == 9:
+                    outs.append([env._observe('raw')])
+                if t == 30:
+                    alias = env.envs
+                if t in (35, 50):
+                    alias[3, 0] = 0
+                    alias[3, 0, 1 + t % 7, 3] = 1
+                if t == 40:
+                    env.rollout(acts[:4].clone())
+            outs.append([env.envs.clone()])
+            res.append(outs)
+    assert len(res[0]) == len(res[1])
+    for i, (x, y) in enumerate(zip(*res)):
+        assert len(x) == len(y)
+        for j, (u, v) in enumerate(zip(x, y)):
+            assert torch.equal(u, v), (i, j)
+
+
 @pytest.mark.parametrize('N', [4096, 40000])
 def test_at_the_natural_threshold(N):
     """as shipped (mirror from 4096 envs): the oracle follows single envs of the batch by their global id"""

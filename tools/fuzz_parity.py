@@ -124,14 +124,18 @@ def fuzz_resident(rng):
     batch sizes around the envs-per-wave settings, deferred resets with and without the reset observation, iterations
     without any reset (finished envs stepped again), hostile actions, hand-edited states and calls that cannot use the
     mirror (post_reset) in between; `envs` compared whenever the lazy form writes them out."""
-    S = 9
-    N = int(rng.choice([1, 3, 15, 16, 17, 31, 33, 63, 64, 65, 100, 129, 200, 257]))
+    S = int(rng.choice([9, 9, 9, 12, 14, 20, 25, 36]))
+    if S == 9:    # lane_resident.hpp: 32 bytes per env
+        N = int(rng.choice([1, 3, 15, 16, 17, 31, 33, 63, 64, 65, 100, 129, 200, 257]))
+        mode = 'partial_2' if rng.rand() < 0.8 else 'none'
+    else:         # grid_rollout.hip: the clock grid + a record per env, every observation mode
+        N = int(rng.randint(1, 24))
+        mode = ['default', 'raw', 'one_channel', 'positions', f'partial_{rng.randint(1, 7)}', 'none'][rng.randint(6)]
     T = int(rng.randint(5, 70))
-    mode = 'partial_2' if rng.rand() < 0.8 else 'none'
     lazy = bool(rng.rand() < 0.6)
     epw = int(rng.choice([0, 16, 32, 64]))
     seed, off = int(rng.randint(1 << 30)), int(rng.randint(1 << 20))
-    desc = f'resident N={N} T={T} mode={mode} lazy={lazy} epw={epw} seed={seed} off={off}'
+    desc = f'resident S={S} N={N} T={T} mode={mode} lazy={lazy} epw={epw} seed={seed} off={off}'
     if os.environ.get('WURM_FUZZ_VERBOSE'):
         print('start:', desc, flush=True)
     if epw:
@@ -172,11 +176,11 @@ def fuzz_resident(rng):
                 prev, prev_call = ro['done'], call + 1
             if edit:  # the caller edits the state (and says so): an extra food, a food removed, a body value broken
                 i = int(rng.randint(N))
-                eo[i, 0, int(rng.randint(1, 8)), int(rng.randint(1, 8))] = 1
+                eo[i, 0, int(rng.randint(1, S - 1)), int(rng.randint(1, S - 1))] = 1
                 if rng.rand() < 0.5:
                     eo[int(rng.randint(N)), 0] = 0
                 if rng.rand() < 0.3:
-                    eo[int(rng.randint(N)), 2, int(rng.randint(1, 8)), int(rng.randint(1, 8))] += 2
+                    eo[int(rng.randint(N)), 2, int(rng.randint(1, S - 1)), int(rng.randint(1, S - 1))] += 2
                 eh[...] = eo
                 mirror['valid'] = 0
             call += 2

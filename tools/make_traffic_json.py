@@ -74,7 +74,9 @@ detail = {
     'multi_step_cfg4_4096x25_k4_full': traffic('wurm::multi_step_kernel', 262144, (3, 5)),  # dispatch order: 20 launches of cfg4', then 30 of cfg4
     'per_call_api_cfg4prime_4096x25_k4_partial5': traffic('wurm::multi_step_kernel', 262144, (0, 5)),
     'per_call_api_speeds_4096x36_k10': traffic('wurm::multi_step_wg_kernel', 1048576),
-    'grid_step_8192x36_default': traffic('void wurm::(anonymous namespace)::grid_step_kernel<true>', 524288),
+    # dispatch order: 30 launches on the resident mirror (lazy: the fp32 state is neither read nor written), then 30 without
+    'grid_step_8192x36_default': traffic('void wurm::(anonymous namespace)::grid_step_kernel<true>', 524288, (0, 2)),
+    'grid_step_8192x36_default_no_mirror': traffic('void wurm::(anonymous namespace)::grid_step_kernel<true>', 524288, (1, 2)),
 }
 out = {
     '_calibration': {

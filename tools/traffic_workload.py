@@ -92,6 +92,7 @@ percall(65536, 9, 'partial_2', reset_obs=True)
 os.environ['WURM_RESIDENT_MIN_ENVS'] = str(10 ** 9)
 percall(8192, 9, 'partial_2')
 percall(65536, 9, 'partial_2')
+percall(8192, 36, 'default')   # grid_step_kernel a second time: the first 30 launches kept their grids in the mirror
 os.environ.pop('WURM_RESIDENT_MIN_ENVS')
 # measured: the per-call MultiSnake loop at cfg4 (multi_step_kernel with the postponed reset in front)
 env = MultiSnake(4096, 4, 25, device=dev, seed=0)

@@ -409,6 +409,59 @@ __device__ __forceinline__ StepView view_of(const Snk &s, int head_body)
     return v;
 }
 
+// ---- the caller's mirror of the state (wurm_single_call.resident for S >= 12): per env the clock grid as it sits in
+// LDS (iters * 256 cells of 16 bits) and a 48-byte record — what grid_load would produce, kept between calls so that the
+// per-call step does not read 12 S^2 bytes of fp32 to find one snake.  Plane 0: grids [N][iters * 256]; plane 1: records.
+constexpr int MR_INTS = 12;   // hc, hy, hx, L, o, food, G, T, head_body, flags, -, -
+constexpr int MR_ACT = 1;     // the record and the grid describe the env (else: envs is authoritative for it)
+constexpr int MR_TERMINAL = 2; // the last step finished the env: outside the domain unless the next call rebuilds it
+
+__device__ __forceinline__ cell_t *mirror_grid(const StepArgs &p, const Grid &g, long long env)
+{
+    return (cell_t *)p.resident + env * (long long)(g.iters * 256);
+}
+__device__ __forceinline__ int *mirror_rec(const StepArgs &p, const Grid &g, long long env)
+{
+    return (int *)((cell_t *)p.resident + p.N * (long long)(g.iters * 256)) + env * MR_INTS;
+}
+
+// mirror -> LDS / LDS -> mirror: 8 bytes per lane and instruction, the layout is the same on both sides
+__device__ __forceinline__ void mirror_load_grid(const Grid &g, const cell_t *src)
+{
+    for (int it0 = 0; it0 < g.iters; it0 += 8) {
+        uint2 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            v[j] = *(const uint2 *)(src + min(it0 + j, g.iters - 1) * 256 + 4 * g.lane);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (it0 + j < g.iters) *(uint2 *)(g.ex + (it0 + j) * 256 + 4 * g.lane) = v[j];
+    }
+    wave_lds_sync();
+}
+__device__ __forceinline__ void mirror_store_grid(const Grid &g, cell_t *dst)
+{
+    wave_lds_sync();
+    for (int it = 0; it < g.iters; ++it)
+        *(uint2 *)(dst + it * 256 + 4 * g.lane) = *(const uint2 *)(g.ex + it * 256 + 4 * g.lane);
+}
+__device__ __forceinline__ void mirror_store_rec(const Grid &g, int *rec, const Snk &s, int head_body, int flags)
+{
+    const int lane = g.lane;
+    const int v = lane == 0 ? s.hc : lane == 1 ? s.hy : lane == 2 ? s.hx : lane == 3 ? s.L : lane == 4 ? s.o
+                : lane == 5 ? s.food : lane == 6 ? s.G : lane == 7 ? s.T : lane == 8 ? head_body : lane == 9 ? flags : 0;
+    if (lane < MR_INTS) rec[lane] = v;
+}
+// returns the flags; s and head_body from the record
+__device__ __forceinline__ int mirror_load_rec(const Grid &g, const int *rec, Snk &s, int &head_body)
+{
+    const int v = g.lane < MR_INTS ? rec[g.lane] : 0;
+    s.hc = lane_value(v, 0); s.hy = lane_value(v, 1); s.hx = lane_value(v, 2); s.L = lane_value(v, 3);
+    s.o = lane_value(v, 4); s.food = lane_value(v, 5); s.G = lane_value(v, 6); s.T = lane_value(v, 7);
+    head_body = lane_value(v, 8);
+    return lane_value(v, 9);
+}
+
 template <bool VEC>
 __global__ __launch_bounds__(256) void grid_rollout_kernel(StepArgs p)
 {
@@ -524,12 +577,36 @@ __global__ __launch_bounds__(256) void grid_step_kernel(StepArgs p)
     const u64 env_id = (u64)(p.env_offset + env);
     Snk s;
     const bool pre = p.done_in != nullptr && uniform((int)p.done_in[env]) != 0;
+    const bool mirrored = p.resident != nullptr;
+    const bool lazy = mirrored && p.resident_lazy != 0;
+    cell_t *mgrid = mirrored ? mirror_grid(p, g, env) : nullptr;
+    int *mrec = mirrored ? mirror_rec(p, g, env) : nullptr;
+    bool whole = true; // the mirror's grid has to be stored whole (else: the cells this step changed)
     if (pre) {
         grid_clear(g, s);
         grid_reset(g, s, p.seed, p.pre_call, env_id, p.inject_pre_reset ? p.inject_pre_reset + env * 4 : nullptr);
-    } else if (!grid_load<VEC>(g, envp, s)) {
-        if (lane == 0) p.done[env] = GRID_SKIPPED;
-        return;
+    } else {
+        int flags = 0, hb = 0;
+        if (mirrored && p.resident_valid) flags = mirror_load_rec(g, mrec, s, hb);
+        if ((flags & (MR_ACT | MR_TERMINAL)) == MR_ACT) {
+            mirror_load_grid(g, mgrid);
+            whole = false;
+        } else if (flags & MR_ACT) {
+            // finished by the last step and not rebuilt: outside the domain.  The generic kernel steps it on envs (second
+            // launch) — which the lazy form has not been writing: its last state goes out first
+            if (lazy) {
+                mirror_load_grid(g, mgrid);
+                grid_observe<VEC>(g, view_of(s, hb), envp, WURM_OBS_RAW, 0);
+            }
+            if (lane == 0) { mrec[9] = 0; p.done[env] = GRID_SKIPPED; }
+            return;
+        } else if (!grid_load<VEC>(g, envp, s)) {
+            if (lane == 0) {
+                if (mirrored) mrec[9] = 0;
+                p.done[env] = GRID_SKIPPED;
+            }
+            return;
+        }
     }
     const long long a_in = uniform64(load_action(p.actions, p.act_dtype, env));
     const bool inj_f = p.inject_food != nullptr;
@@ -552,7 +629,7 @@ __global__ __launch_bounds__(256) void grid_step_kernel(StepArgs p)
 
     // ---- the post-step state back to HBM
     const bool rebuild_after = done && p.post_reset;
-    if (!rebuild_after) {
+    if (!rebuild_after && !lazy) {
         if (pre) {
             grid_observe<VEC>(g, view_of(s, head_body), envp, WURM_OBS_RAW, 0); // the env was rebuilt: everything changed
         } else {
@@ -576,11 +653,50 @@ __global__ __launch_bounds__(256) void grid_step_kernel(StepArgs p)
             }
         }
     }
+    if (mirrored) { // (never with post_reset: grid_resident_eligible)
+        if (s.G > EX_REBASE) { // keep the 16-bit clocks away from the markers (as the rollout does between chunks)
+            wave_lds_sync();
+            for (int it = 0; it < g.iters; ++it) {
+                const int c0 = it * 256 + 4 * lane;
+                int4v e = read4(g.ex, c0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) e[q] = e[q] >= EX_FOOD ? e[q] : max(e[q] - s.T, 0);
+                write4(g.ex, c0, e);
+            }
+            s.G -= s.T;
+            s.T = 0;
+            whole = true;
+        }
+        if (whole) {
+            mirror_store_grid(g, mgrid);
+        } else if (lane == 0) { // what grid_step wrote: the clock of the new head cell, the marker of a respawned food
+            if (!ev.edgec) mgrid[s.hc] = (cell_t)s.G;
+            if (ev.eat && s.food >= 0) mgrid[s.food] = (cell_t)EX_FOOD;
+        }
+        mirror_store_rec(g, mrec, s, head_body, MR_ACT | (done ? MR_TERMINAL : 0));
+        wave_lds_sync();
+    }
     if (!p.post_reset && p.obs_after == nullptr) return;
     if (done) grid_reset(g, s, p.seed, p.call + 1ull, env_id, p.inject_reset ? p.inject_reset + env * 4 : nullptr);
     if (rebuild_after) grid_observe<VEC>(g, view_of(s, s.L), envp, WURM_OBS_RAW, 0);
     if (p.obs_after != nullptr && p.obs_mode != WURM_OBS_NONE)
         grid_observe<VEC>(g, view_of(s, done ? s.L : head_body), p.obs_after + env * p.obs_elems, p.obs_mode, p.obs_n);
+}
+
+// envs from the mirror (lazy form): every env its record describes is written whole
+template <bool VEC>
+__global__ __launch_bounds__(256) void grid_flush_kernel(StepArgs p)
+{
+    const int wave = uniform((int)(threadIdx.x >> 6)), wpb = (int)(blockDim.x >> 6);
+    const long long env = xcd_block(blockIdx.x, gridDim.x) * wpb + wave;
+    if (env >= p.N) return;
+    const Grid g = make_grid(p, wave);
+    Snk s;
+    int hb = 0;
+    const int flags = mirror_load_rec(g, mirror_rec(p, g, env), s, hb);
+    if (!(flags & MR_ACT)) return;
+    mirror_load_grid(g, mirror_grid(p, g, env));
+    grid_observe<VEC>(g, view_of(s, hb), p.envs + env * 3 * g.C, WURM_OBS_RAW, 0);
 }
 
 } // namespace
@@ -591,6 +707,17 @@ bool grid_rollout_eligible(const StepArgs &p)
 }
 
 bool grid_step_eligible(const StepArgs &p) { return p.S >= 12 && p.S <= 64; }
+
+bool grid_resident_eligible(const StepArgs &p)
+{
+    return grid_step_eligible(p) && !p.inject_food && !p.inject_reset && !p.inject_pre_reset && !p.post_reset && !p.only_flagged;
+}
+
+long long grid_resident_bytes(long long N, int S)
+{
+    const long long iters = ((long long)S * S + 255) >> 8;
+    return N * (iters * 256 * (long long)sizeof(cell_t) + MR_INTS * 4);
+}
 
 static bool grid_aligned(const StepArgs &p)
 {
@@ -632,6 +759,19 @@ hipError_t launch_grid_step(const StepArgs &p_in, hipStream_t stream)
     (void)hipGetLastError();
     if (grid_aligned(p)) hipLaunchKernelGGL(grid_step_kernel<true>, grid, block, lds, stream, p);
     else hipLaunchKernelGGL(grid_step_kernel<false>, grid, block, lds, stream, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_grid_resident_flush(const StepArgs &p_in, hipStream_t stream)
+{
+    StepArgs p = p_in;
+    const int C = p.S * p.S, iters = (C + 255) >> 8;
+    const int wpb = p.N <= 4096 ? 1 : 4;
+    dim3 block(64 * wpb), grid((unsigned)((p.N + wpb - 1) / wpb));
+    const size_t lds = (size_t)iters * 256 * sizeof(cell_t) * wpb;
+    (void)hipGetLastError();
+    if (C % 4 == 0 && (uintptr_t)p.envs % 16 == 0) hipLaunchKernelGGL(grid_flush_kernel<true>, grid, block, lds, stream, p);
+    else hipLaunchKernelGGL(grid_flush_kernel<false>, grid, block, lds, stream, p);
     return hipGetLastError();
 }
 

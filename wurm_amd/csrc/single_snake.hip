@@ -1637,7 +1637,8 @@ static hipError_t launch_one(Kind kind, const StepArgs &p, dim3 grid, dim3 block
             const char *e = getenv("WURM_GRID_STEP_MIN_CELLS");
             return e ? atoll(e) : (1ll << 20);
         }();
-        if ((kind == K_STEP || kind == K_FUSED) && grid_step_eligible(p) && p.N * (long long)p.S * p.S >= min_cells) {
+        if ((kind == K_STEP || kind == K_FUSED) && grid_step_eligible(p) &&
+            (p.N * (long long)p.S * p.S >= min_cells || p.resident != nullptr)) { // (a mirror is kept by this kernel only)
             hipError_t err = launch_grid_step(p, st);
             if (err != hipSuccess) return err;
             StepArgs q = p;
@@ -1880,10 +1881,22 @@ static int fused_entry(bool snake, const wurm_single_call *c, void *stream, int 
             if (mirror_state) *mirror_state = 1;
             return WURM_OK;
         }
+        if (grid_resident_eligible(p)) {
+            // 12 x 12 and larger: the LDS clock-grid step keeps its grids in the mirror (grid_rollout.hip)
+            p.resident = c->resident;
+            p.resident_valid = c->resident_valid != 0;
+            p.resident_lazy = c->resident_lazy != 0;
+            rc = launch<true>(resets ? K_FUSED : K_STEP, p, stream);
+            if (mirror_state) *mirror_state = rc == WURM_OK ? 1 : 0;
+            return rc;
+        }
         // this call cannot use the mirror: a lazy one is written out to envs before the ordinary kernels read them
-        if (c->resident_lazy && c->resident_valid && p.S == 9 &&
-            launch_lane_resident_flush(p, c->resident, (hipStream_t)stream) != hipSuccess)
-            return WURM_ERR_HIP;
+        if (c->resident_lazy && c->resident_valid) {
+            hipError_t err = hipSuccess;
+            if (p.S == 9) err = launch_lane_resident_flush(p, c->resident, (hipStream_t)stream);
+            else if (grid_step_eligible(p)) { StepArgs q = p; q.resident = c->resident; err = launch_grid_resident_flush(q, (hipStream_t)stream); }
+            if (err != hipSuccess) return WURM_ERR_HIP;
+        }
     }
     if (mirror_state) *mirror_state = 0;
     // nothing to rebuild and no second observation: the plain step kernel (lighter on registers for large grids)
@@ -1895,18 +1908,29 @@ int wurm_single_resident_flush(const wurm_single_call *c, void *stream)
 {
     if (!c) return WURM_ERR_INVALID_ARG;
     if (!c->resident || !c->resident_lazy || !c->resident_valid || c->num_envs <= 0) return WURM_OK;
-    if (!c->envs || c->size != 9) return WURM_ERR_INVALID_ARG;
+    if (!c->envs) return WURM_ERR_INVALID_ARG;
     StepArgs p = {};
-    p.envs = c->envs; p.N = c->num_envs; p.S = c->size;
-    return launch_lane_resident_flush(p, c->resident, (hipStream_t)stream) == hipSuccess ? WURM_OK : WURM_ERR_HIP;
+    p.envs = c->envs; p.N = c->num_envs; p.S = c->size; p.resident = c->resident;
+    hipError_t err;
+    if (c->size == 9) err = launch_lane_resident_flush(p, c->resident, (hipStream_t)stream);
+    else if (grid_step_eligible(p)) err = launch_grid_resident_flush(p, (hipStream_t)stream);
+    else return WURM_ERR_INVALID_ARG;
+    return err == hipSuccess ? WURM_OK : WURM_ERR_HIP;
 }
 
 int64_t wurm_single_resident_bytes(int64_t num_envs, int size, int obs_mode, int obs_n)
 {
+    if (num_envs <= 0) return 0;
     const char *e = getenv("WURM_RESIDENT_MIN_ENVS");
-    const long long min_envs = e ? atoll(e) : 4096ll;
-    if (num_envs <= 0 || num_envs < min_envs || !lane_resident_shape(size, obs_mode, obs_n)) return 0;
-    return num_envs * 32;
+    if (lane_resident_shape(size, obs_mode, obs_n)) // 9 x 9: 32 bytes per env (lane_resident.hpp)
+        return num_envs >= (e ? atoll(e) : 4096ll) ? num_envs * 32 : 0;
+    StepArgs p = {};
+    p.S = size;
+    if (grid_step_eligible(p) && obs_elems(true, obs_mode, obs_n, size) >= 0) { // 12 x 12 and larger: grid + record per env
+        const bool big = e ? num_envs >= atoll(e) : num_envs * (long long)size * size >= (1ll << 20);
+        return big ? grid_resident_bytes(num_envs, size) : 0;
+    }
+    return 0;
 }
 
 int wurm_single_step_reset(const wurm_single_call *c, void *stream) { return fused_entry(true, c, stream); }

@@ -33,6 +33,10 @@ struct StepArgs {
     u64 pre_call;
     int post_reset;
     int only_flagged; // rollout_kernel: process only the envs the grid kernel marked GRID_SKIPPED in done[0][env]
+    // grid_step_kernel: the caller's compact mirror of the state (wurm_single_call.resident, S >= 12: the clock grids
+    // and the per-env scalars as the kernel holds them), nullable; valid: it describes envs; lazy: envs are not written
+    void *resident;
+    int resident_valid, resident_lazy;
 };
 
 __device__ __forceinline__ long long load_action(const void *actions, int dtype, long long i)
@@ -65,5 +69,9 @@ bool lane_resident_shape(int S, int obs_mode, int obs_n);
 bool lane_resident_eligible(const StepArgs &p);
 hipError_t launch_lane_resident(const StepArgs &p, void *resident, bool valid, bool lazy, hipStream_t stream);
 hipError_t launch_lane_resident_flush(const StepArgs &p, void *resident, hipStream_t stream);
+// the same for grids of 12 x 12 and larger (grid_rollout.hip: grid_step_kernel reads / maintains p.resident)
+bool grid_resident_eligible(const StepArgs &p);
+long long grid_resident_bytes(long long N, int S);
+hipError_t launch_grid_resident_flush(const StepArgs &p, hipStream_t stream);
 
 } // namespace wurm
