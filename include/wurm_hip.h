@@ -320,6 +320,14 @@ typedef struct wurm_multi_call {
     uint64_t seed, call, pre_call;
     int num_snakes, size, obs_mode, obs_n;
     wurm_multi_config cfg;
+    void *resident;                   /* nullable in/out: wurm_multi_resident_bytes() bytes the caller owns — a compact
+                                         mirror of foods / heads / bodies that the step reads INSTEAD of them and keeps
+                                         current (dones, orientations, colours are always read and written in place)      */
+    int resident_valid;               /* != 0: nothing but calls that were given `resident` has written foods / heads /
+                                         bodies since the mirror was last maintained; 0: the step reads them            */
+    int resident_lazy;                /* != 0: the step does not write foods / heads / bodies; wurm_multi_resident_flush
+                                         brings them up to date (before anything else reads or writes them, and before
+                                         resident_valid is cleared)                                                     */
 } wurm_multi_call;
 
 /* One launch for one iteration of the caller loop of experiments/speeds.py:30-37 / tests/test_multi_snake_env.py:78-89,
@@ -342,6 +350,16 @@ int wurm_multi_step_reset(const wurm_multi_call *c, void *stream);
  * c->inject / c->pre_inject are used as they stand.  Bit-identical to wurm_multi_step_reset on the same pointers. */
 int wurm_multi_step_packed(wurm_multi_call *c, float *out_f32, uint8_t *out_u8, float *obs, float *obs_after,
                            const int64_t *actions, uint64_t call, int apply_pending, uint64_t pre_call, void *stream);
+
+/* The mirror of wurm_multi_call.resident: per env the 16-bit clock grids of the K bodies, the food grid as bytes and three
+ * ints per snake — (2 K + 1) S^2 bytes and change instead of (1 + 2 K) S^2 fp32 read every call
+ * (wurm_amd/csrc/multi_snake.hip).  Returns its size in bytes, 0 if it is not offered for this batch (fewer than 2^20
+ * cells num_envs * num_snakes * size^2; WURM_RESIDENT_MIN_ENVS replaces that by a number of envs).  Protocol as for
+ * wurm_single_call.resident: wurm_multi_step_packed sets c->resident_valid after a launch that maintained the mirror
+ * (not with inject / pre_inject: such a call writes a lazy mirror out first and steps the fp32 state), the caller clears it
+ * whenever anything else writes the state — after wurm_multi_resident_flush if the mirror is lazy. */
+int64_t wurm_multi_resident_bytes(int64_t num_envs, int num_snakes, int size);
+int wurm_multi_resident_flush(const wurm_multi_call *c, void *stream);
 
 /* MultiSnake.reset (multi_snake.py:771-836): envs flagged in done_env (N bytes) are rebuilt (_create_envs
  * :996-1019: K snakes placed one after another on free cells away from everything, one food); colours of

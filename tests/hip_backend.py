@@ -331,13 +331,20 @@ def multi_step(self, st, actions, cfg, mode, inject=None):
                 size=size.cpu().numpy(), all_done=all_done.cpu().numpy())
 
 
-def multi_step_reset(self, st, actions, cfg, mode, call, pre_done=None, pre_call=0, want_obs_after=False):
-    """wurm_multi_step_reset through the wurm_multi_call block: [wurm_multi_reset(pre_done, pre_call),] step(call)"""
+def multi_step_reset(self, st, actions, cfg, mode, call, pre_done=None, pre_call=0, want_obs_after=False, resident=None):
+    """wurm_multi_step_reset through the wurm_multi_call block: [wurm_multi_reset(pre_done, pre_call),] step(call).
+    resident: a dict the caller keeps across calls ({'valid': 0 | 1, 'lazy': bool, 'sync': bool}): the call is given
+    wurm_multi_call.resident; with 'lazy' the device copy of the state lives in the dict and foods / heads / bodies are
+    written out (wurm_multi_resident_flush) and copied back into `st` only when 'sync' is true"""
     import ctypes
     N, _, S, _ = st['foods'].shape
     K = st['heads'].shape[0] // N
     m, n = _lib.parse_obs_mode(mode)
-    d = _multi_to_dev(self, st)
+    lazy = resident is not None and bool(resident.get('lazy'))
+    if lazy and resident.get('valid') and resident.get('dev') is not None:
+        d = resident['dev']  # foods / heads / bodies stale by design; the small arrays are always current
+    else:
+        d = _multi_to_dev(self, st)
     act = self._t(np.ascontiguousarray(actions, np.int64))
     shape = _o.multi_obs_shape(mode, N, K, S)
     obs = self._empty(shape, torch.float32) if shape else None
@@ -358,10 +365,30 @@ def multi_step_reset(self, st, actions, cfg, mode, call, pre_done=None, pre_call
     c.num_envs, c.env_offset, c.seed, c.call, c.pre_call = N, self.env_offset, _lib.u64(self.seed), _lib.u64(call), _lib.u64(pre_call)
     c.num_snakes, c.size, c.obs_mode, c.obs_n = K, S, m, n
     c.cfg = _multi_cfg(K, cfg)
+    if resident is not None:
+        nbytes = int(self.lib.wurm_multi_resident_bytes(_lib.i64(N), K, S))
+        assert nbytes > 0, 'set WURM_RESIDENT_MIN_ENVS=0 for small batches'
+        if resident.get('buf') is None or resident['buf'].numel() != nbytes:
+            resident['buf'], resident['valid'] = self._empty((nbytes,), torch.uint8), 0
+        c.resident, c.resident_valid, c.resident_lazy = resident['buf'].data_ptr(), int(resident.get('valid', 0)), int(lazy)
     rc = self.lib.wurm_multi_step_reset(ctypes.addressof(c), self._stream())
     _lib.check(rc, 'wurm_multi_step_reset')
+    synced = True
+    if resident is not None:
+        resident['valid'] = 1
+        if lazy:
+            resident['dev'] = d
+            c.resident_valid = 1
+            synced = bool(resident.get('sync', True))
+            if synced:
+                _lib.check(self.lib.wurm_multi_resident_flush(ctypes.addressof(c), self._stream()), 'flush')
     torch.cuda.synchronize()
-    _multi_back(st, d)
+    if synced:
+        _multi_back(st, d)
+    else:  # the small state arrays are written by every launch
+        for k in st:
+            if k not in ('foods', 'heads', 'bodies'):
+                st[k][...] = d[k].cpu().numpy()
     assert torch.equal(copy, all_done), 'all_done_copy != all_done'
     return dict(obs=obs.cpu().numpy() if obs is not None else None, rewards=rewards.cpu().numpy(),
                 snake_collision=sc.cpu().numpy(), edge_collision=ec.cpu().numpy(), food=food.cpu().numpy(),

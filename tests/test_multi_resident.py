@@ -1,0 +1,275 @@
+"""MultiSnake's per-call step on a resident mirror of foods / heads / bodies (wurm_multi_call.resident; the LDS image of
+the env's grids kept between calls, wurm_amd/csrc/multi_snake.hip): eager and lazy, one env per wave and one env per
+workgroup, every dynamics configuration of the parity suite.
+
+(a) through the C ABI: the oracle follows [postponed reset,] step over many iterations while foods / heads / bodies are
+    written out only now and then (lazy), with iterations without any reset, arbitrary reset masks, hand-edited states
+    (the caller clears resident_valid) and other entry points in between;
+(b) through the host class: the reference's loops with the mirror forced on against the oracle, state attributes read,
+    edited in place through an alias, and replaced in between; long-lived snakes crossing the clock re-base;
+(c) in a child process with WURM_RESIDENT_MIN_ENVS=0 the MultiSnake parity suites as a whole."""
+import contextlib
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from oracle import oracle as _o
+from tests.backends import OracleBackend
+from tests.test_hip_multi_vs_oracle import CFGS, _same, _same_state
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope='module')
+def hip():
+    from tests.hip_backend import HipBackend
+    return HipBackend
+
+
+@contextlib.contextmanager
+def knobs(**kw):
+    old = {k: os.environ.get(k) for k in kw}
+    for k, v in kw.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = str(v)
+    try:
+        yield
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+@pytest.mark.parametrize('lazy', [False, True])
+@pytest.mark.parametrize('N,K,S,T,mode,cfg', [
+    (16, 4, 25, 60, 'full', 'default'),         # BASELINE cfg4 shape
+    (12, 4, 25, 80, 'partial_5', 'train'),      # respawn 'any', random_rate food
+    (10, 3, 10, 90, 'full', 'dense'),           # fixed colours, crowded
+    (9, 2, 12, 90, 'full', 'noboost'),
+    (7, 1, 5, 60, 'full', 'default'),
+    (6, 10, 36, 40, 'full', 'train'),           # experiments/speeds.py shape: one env per workgroup
+    (5, 4, 48, 30, 'full', 'default'),
+    (4, 5, 40, 30, 'none', 'dense'),
+])
+def test_abi_postponed_reset_and_step_on_the_mirror(hip, N, K, S, T, mode, cfg, lazy):
+    cfg = CFGS[cfg]
+    rng = np.random.RandomState(K * S)
+    o, h = OracleBackend(seed=3, env_offset=11), hip(seed=3, env_offset=11)
+    so = _o.multi_empty_state(N, K, S)
+    so['colours'][...] = o.multi_colours(N, K, cfg['colour_mode'] == 'fixed', call=0)
+    o.call = 1
+    assert o.multi_reset(so, np.ones(N), cfg) == 0
+    sh = {k: v.copy() for k, v in so.items()}
+    call, prev, prev_call = 2, None, 0
+    deaths = 0
+    mirror = {'valid': 0, 'lazy': lazy}
+    with knobs(WURM_RESIDENT_MIN_ENVS=0):
+        for t in range(T):
+            a = rng.randint(0, 8, size=(K, N)).astype(np.int64)
+            if prev is not None:
+                o.call = prev_call
+                o.multi_reset(so, prev, cfg)
+            o.call = call
+            ro = o.multi_step(so, a, cfg, mode)
+            edit = t % 13 == 6
+            other = t % 17 == 9
+            mirror['sync'] = not lazy or edit or other or t % 4 == 3 or t == T - 1
+            rh = h.multi_step_reset(sh, a, cfg, mode, call=call, pre_done=prev, pre_call=prev_call,
+                                    want_obs_after=(t % 3 != 2), resident=mirror)
+            if mirror['sync']:
+                _same_state(so, sh, f'state t={t}')
+            else:
+                for k in ('dones', 'orientations', 'colours', 'boost_this_step'):
+                    _same(so[k], sh[k], f'{k} t={t}')
+            for k in ro:
+                _same(ro[k], rh[k], f'{k} t={t}')
+            if 'obs_after' in rh:
+                tmp = {k: v.copy() for k, v in so.items()}
+                o.call = call + 1
+                o.multi_reset(tmp, ro['all_done'], cfg, mode=mode)
+                _same(o.last_reset_obs, rh['obs_after'], f'obs_after t={t}')
+            deaths += int(so['dones'].sum())
+            if t % 5 == 4:      # no reset this time: dead snakes are stepped again
+                prev = None
+            elif t % 7 == 3:    # an arbitrary mask
+                prev, prev_call = (rng.rand(N) < 0.3).astype(np.uint8), call + 1
+            else:
+                prev, prev_call = ro['all_done'], call + 1
+            call += 2
+            if edit:            # the caller edits the state (and says so): a food appears, one disappears
+                so['foods'][0, 0, 2, 2] = 1
+                so['foods'][(t // 13) % N, 0] *= 0
+                for k in ('foods',):
+                    sh[k][...] = so[k]
+                mirror['valid'] = 0
+            if other:           # another entry point writes the state in between: an eager reset of a few envs
+                some = (rng.rand(N) < 0.3).astype(np.uint8)
+                o.call = h.call = 50000 + t
+                o.multi_reset(so, some, cfg)
+                h.multi_reset(sh, some, cfg)
+                _same_state(so, sh, f'eager reset t={t}')
+                mirror['valid'] = 0
+    assert deaths > 0
+
+
+def _class_env(N, K, S, seed, mode, cfg, **kw):
+    from wurm_amd.envs import MultiSnake
+    return MultiSnake(N, K, S, device='cuda:0', seed=seed, env_offset=7, observation_mode=mode,
+                      boost=cfg['boost'], food_on_death_prob=cfg['food_on_death_prob'],
+                      boost_cost_prob=cfg['boost_cost_prob'], food_mode=cfg['food_mode'], food_rate=cfg['food_rate'],
+                      respawn_mode=cfg['respawn_mode'], reward_on_death=cfg['reward_on_death'],
+                      agent_colours=cfg['colour_mode'], **kw)
+
+
+@pytest.mark.parametrize('cfg_name,mode,shape', [('default', 'full', (24, 4, 14, 150)), ('train', 'partial_3', (20, 3, 12, 150)),
+                                                 ('dense', 'full', (20, 3, 12, 120)), ('train', 'full', (6, 10, 36, 50))])
+def test_class_loop_on_the_lazy_mirror_against_the_oracle(cfg_name, mode, shape):
+    """nobody looks at the state for many iterations (the lazy form all the way), then it is read, edited through the alias,
+    and one tensor is replaced; outputs every step and the state at those points against the oracle"""
+    import torch
+    cfg = CFGS[cfg_name]
+    (N, K, S, T), seed = shape, 23
+    with knobs(WURM_RESIDENT_MIN_ENVS=0):
+        env = _class_env(N, K, S, seed, mode, cfg)
+        o = OracleBackend(seed=seed, env_offset=7)
+        st = _o.multi_empty_state(N, K, S)
+        st['colours'][...] = o.multi_colours(N, K, cfg['colour_mode'] == 'fixed', call=0)
+        o.call = 1
+        assert o.multi_reset(st, np.ones(N), cfg) == 0
+        g = torch.Generator().manual_seed(5)
+
+        def check_state(what):
+            _same(env.foods.cpu().numpy(), st['foods'], what + ' foods')
+            _same(env.heads.cpu().numpy(), st['heads'], what + ' heads')
+            _same(env.bodies.cpu().numpy(), st['bodies'], what + ' bodies')
+            _same(env.dones.cpu().numpy().astype(np.uint8), st['dones'], what + ' dones')
+            _same(env.orientations.cpu().numpy(), st['orientations'], what + ' orientations')
+
+        alias = None
+        for t in range(T):
+            a = torch.randint(8, (K, N), generator=g)
+            ac = a.cuda()
+            obs, rew, dones, info = env.step({f'agent_{i}': ac[i] for i in range(K)})
+            assert env._mirror is not None
+            r = o.multi_step(st, a.numpy(), cfg, mode)
+            for i in range(K):
+                _same(obs[f'agent_{i}'].cpu().numpy(), r['obs'][i], f'obs {i} t={t}')
+                _same(rew[f'agent_{i}'].cpu().numpy(), r['rewards'].reshape(N, K)[:, i], f'reward {i} t={t}')
+                _same(info[f'size_{i}'].cpu().numpy(), r['size'].reshape(N, K)[:, i], f'size {i} t={t}')
+            _same(dones['__all__'].cpu().numpy().astype(np.uint8), r['all_done'], f'all_done t={t}')
+            if t % 3 == 2:
+                back = env.reset(dones['__all__'])
+                o.multi_reset(st, r['all_done'], cfg, mode=mode)
+                for i in range(K):
+                    _same(back[f'agent_{i}'].cpu().numpy(), o.last_reset_obs[i], f'reset obs {i} t={t}')
+            else:
+                env.reset(dones['__all__'], return_observations=False)
+                o.multi_reset(st, r['all_done'], cfg)
+            if t < T // 2:
+                assert env._mc.resident_lazy == 1   # (resident_valid drops whenever a reset runs eagerly: alternating forms)
+            if t == T // 2:
+                check_state(f't={t}')            # the first look: written out, eager from now on
+                assert env._mc.resident_lazy == 0
+                alias = env.foods
+            if t in (T // 2 + 5, T // 2 + 20):   # in-place edits through the alias, found by the version counter
+                alias[1, 0, 3, 3] = 1.0
+                st['foods'][1, 0, 3, 3] = 1.0
+            if t == T // 2 + 30:                 # a state tensor is replaced
+                nb = env.bodies.clone()
+                env.bodies = nb
+            if t == T - 10:
+                env.check_consistency() if (o.multi_check(st) == 0).all() else None
+        check_state('final')
+
+
+def test_long_lived_snakes_cross_the_clock_rebase():
+    """a small WURM_MULTI_CLOCK_REBASE cannot be set at run time, so the snakes are kept alive long enough instead: two
+    snakes circling for 0x3000 + steps would take too long — the record's clocks are moved forward by hand"""
+    import torch
+    from tests.test_hip_multi_vs_oracle import CFGS as _C
+    cfg = _C['noboost']
+    N, K, S, seed = 6, 2, 12, 4
+    with knobs(WURM_RESIDENT_MIN_ENVS=0):
+        env = _class_env(N, K, S, seed, 'full', cfg)
+        o = OracleBackend(seed=seed, env_offset=7)
+        st = _o.multi_empty_state(N, K, S)
+        st['colours'][...] = o.multi_colours(N, K, cfg['colour_mode'] == 'fixed', call=0)
+        o.call = 1
+        assert o.multi_reset(st, np.ones(N), cfg) == 0
+        g = torch.Generator().manual_seed(9)
+
+        def one(t):
+            a = torch.randint(4, (K, N), generator=g)
+            ac = a.cuda()
+            obs, rew, dones, info = env.step({f'agent_{i}': ac[i] for i in range(K)})
+            r = o.multi_step(st, a.numpy(), cfg, 'full')
+            for i in range(K):
+                _same(obs[f'agent_{i}'].cpu().numpy(), r['obs'][i], f'obs {i} t={t}')
+            env.reset(dones['__all__'], return_observations=False)
+            o.multi_reset(st, r['all_done'], cfg)
+
+        for t in range(5):
+            one(t)
+        # the mirror: [body u16 K*C | food u8 C | tclk, hc, L per snake] per env; move every live clock and tclk forward
+        C = S * S
+        nb, nf = (2 * K * C + 15) // 16 * 16, (C + 15) // 16 * 16
+        per = nb + nf + (12 * K + 15) // 16 * 16
+        m = env._mirror.view(N, per)
+        body = m[:, :nb].contiguous().view(torch.int16)[:, :K * C].to(torch.int32).view(N, K, C)
+        sc = m[:, nb + nf:nb + nf + 12 * K].contiguous().view(torch.int32).view(N, 3 * K)
+        tclk = sc[:, :K].clone()
+        alive = tclk < 0x7000
+        shift = 0x3000 - 10
+        live = (body > tclk[:, :, None]) & alive[:, :, None]
+        body = torch.where(live, body + shift, body)
+        tclk = torch.where(alive, tclk + shift, tclk)
+        m[:, :nb].view(torch.int16)[:, :K * C] = body.view(N, K * C).to(torch.int16)
+        sc[:, :K] = tclk
+        m[:, nb + nf:nb + nf + 12 * K] = sc.contiguous().view(torch.uint8).view(N, 12 * K)
+        for t in range(5, 60):
+            one(t)
+        sc = m[:, nb + nf:nb + nf + 12 * K].contiguous().view(torch.int32).view(N, 3 * K)
+        assert int(sc[:, :K][sc[:, :K] < 0x7000].max()) < 0x3000 + 4     # re-based
+        _same(env.bodies.cpu().numpy(), st['bodies'], 'final bodies')
+        _same(env.foods.cpu().numpy(), st['foods'], 'final foods')
+        _same(env.heads.cpu().numpy(), st['heads'], 'final heads')
+
+
+def test_inference_mode_state_cannot_be_watched():
+    import torch
+    cfg = CFGS['default']
+    with knobs(WURM_RESIDENT_MIN_ENVS=0):
+        with torch.inference_mode():
+            env = _class_env(8, 2, 12, 3, 'full', cfg)
+            a = {f'agent_{i}': torch.zeros(8, dtype=torch.long, device='cuda:0') for i in range(2)}
+            env.step(a)
+            assert env._mirror is not None
+            f = env.foods                     # no version counter: no mirror from now on
+            assert env._mirror is None and not env._mc.resident
+            f[0, 0, 5, 5] = 1.0
+            ref = _class_env(8, 2, 12, 3, 'full', cfg)
+            ref.step(a)
+            ref.foods[0, 0, 5, 5] = 1.0
+            o1, o2 = env.step(a)[0], ref.step(a)[0]
+            for k in o1:
+                assert torch.equal(o1[k], o2[k])
+
+
+def test_multi_parity_suites_on_the_mirror():
+    if os.environ.get('WURM_RESIDENT_MIN_ENVS') == '0':
+        pytest.skip('already inside the forced run')
+    env = dict(os.environ, WURM_RESIDENT_MIN_ENVS='0')
+    r = subprocess.run([sys.executable, '-m', 'pytest', '-x', '-q', '-m', 'gpu', '-p', 'no:cacheprovider',
+                        'tests/test_hip_multi_fused.py', 'tests/test_kat_multi_snake.py', 'tests/test_hip_multi_vs_oracle.py',
+                        'tests/test_hip_golden.py', 'tests/test_recording.py'],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]

@@ -23,7 +23,7 @@ SYMBOLS = [
     'wurm_single_step', 'wurm_single_reset', 'wurm_single_observe', 'wurm_single_rollout', 'wurm_single_check',
     'wurm_single_step_reset', 'wurm_single_resident_bytes', 'wurm_single_resident_flush', 'wurm_grid_step_reset', 'wurm_single_step_slot', 'wurm_grid_step_slot',
     'wurm_grid_step', 'wurm_grid_reset', 'wurm_grid_observe', 'wurm_grid_rollout',
-    'wurm_multi_obs_elems', 'wurm_multi_step', 'wurm_multi_step_reset', 'wurm_multi_step_packed', 'wurm_multi_reset', 'wurm_multi_observe', 'wurm_multi_check',
+    'wurm_multi_obs_elems', 'wurm_multi_step', 'wurm_multi_step_reset', 'wurm_multi_step_packed', 'wurm_multi_resident_bytes', 'wurm_multi_resident_flush', 'wurm_multi_reset', 'wurm_multi_observe', 'wurm_multi_check',
     'wurm_multi_rollout',
     'wurm_multi_colours', 'wurm_orientations',
     'wurm_a2c_returns', 'wurm_a2c_returns_backward', 'wurm_single_stats', 'wurm_single_policy_rollout',
@@ -78,7 +78,8 @@ class MultiCall(ctypes.Structure):
         'agent_major_f32', 'agent_major_u8', 'pre_done', 'inject', 'pre_inject')] + [
         ('num_envs', ctypes.c_int64), ('env_offset', ctypes.c_int64), ('seed', ctypes.c_uint64),
         ('call', ctypes.c_uint64), ('pre_call', ctypes.c_uint64), ('num_snakes', ctypes.c_int), ('size', ctypes.c_int),
-        ('obs_mode', ctypes.c_int), ('obs_n', ctypes.c_int), ('cfg', MultiConfig)]
+        ('obs_mode', ctypes.c_int), ('obs_n', ctypes.c_int), ('cfg', MultiConfig), ('resident', ctypes.c_void_p),
+        ('resident_valid', ctypes.c_int), ('resident_lazy', ctypes.c_int)]
 
 
 def multi_config(num_snakes, boost, food_on_death_prob, boost_cost_prob, food_mode, food_rate, reward_on_death,

@@ -65,6 +65,10 @@ struct MultiArgs {
     long long T;          // rollout: number of fused step+reset iterations
     uint8_t *boost_state; // rollout: boost_this_step (N*K) written back at the end
     int lds_per_wave, off_body, off_food, off_occ, off_hmap, off_img, off_col, off_snap, off_acts;
+    // per-call step: the caller's compact mirror of foods / heads / bodies (wurm_multi_call.resident), nullable; valid: it
+    // describes them; lazy: the step does not write them
+    unsigned char *resident;
+    int resident_valid, resident_lazy;
 };
 
 struct Ctx {
@@ -181,20 +185,23 @@ __device__ __forceinline__ u64 load_env(const Ctx &cx, const float *__restrict__
 }
 
 // LDS -> HBM: body cells flagged DIRTY, the two head cells that changed, food cells that changed.
+// t0_in_lmax: the clocks the snakes had when the env was loaded are in cx.lmax (a state that came from the mirror keeps
+// its clocks between calls); else they were 0 (load_env).
 __device__ __forceinline__ void store_env(const Ctx &cx, float *__restrict__ foodp, float *__restrict__ headp,
-                                          float *__restrict__ bodyp, u64 fbits0, int hc0, int hc, bool full)
+                                          float *__restrict__ bodyp, u64 fbits0, int hc0, int hc, bool full,
+                                          bool t0_in_lmax = false)
 {
     const int C = cx.C, lane = cx.lane;
     for (int s = 0; s < cx.K; ++s) {
         float *bp = bodyp + (size_t)s * C, *hp = headp + (size_t)s * C;
-        const int hs = cx.hcell[s], T = cx.tclk[s];
+        const int hs = cx.hcell[s], T = cx.tclk[s], T0 = t0_in_lmax ? cx.lmax[s] : 0;
 #pragma unroll 4
         for (int k = 0; k < cx.cpl; ++k) {
             int c = lane + 64 * k;
             if (c < C) {
                 const unsigned short v = cx.body[s * C + c];
                 // changed since the load: written cells, and — once the clock has moved — every cell that held a value
-                if (full || (v & DIRTY) || (T != 0 && (v & VMASK))) bp[c] = (float)max((int)(v & VMASK) - T, 0);
+                if (full || (v & DIRTY) || (T != T0 && (int)(v & VMASK) > T0)) bp[c] = (float)max((int)(v & VMASK) - T, 0);
                 if (full) hp[c] = (c == hs) ? 1.0f : 0.0f;
             }
         }
@@ -211,6 +218,115 @@ __device__ __forceinline__ void store_env(const Ctx &cx, float *__restrict__ foo
             if (full || f != (int)((fbits0 >> k) & 1)) foodp[c] = f ? 1.0f : 0.0f;
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------ the mirror
+// wurm_multi_call.resident: per env the LDS image of its grids — the K body grids as 16-bit expiry clocks (without the
+// DIRTY bits), the food grid as bytes, and per snake its clock, head cell and length — kept by the caller between calls,
+// so that the per-call step copies (2 K + 1) S^2 bytes into LDS instead of reading and converting (1 + 2 K) S^2 fp32.
+// Any state load_env accepts is representable (the image IS what load_env produces), so there is no domain and no fallback.
+__host__ __device__ __forceinline__ int mirror_body_bytes(int K, int C) { return (2 * K * C + 15) & ~15; }
+__host__ __device__ __forceinline__ int mirror_food_bytes(int C) { return (C + 15) & ~15; }
+__host__ __device__ __forceinline__ long long mirror_env_bytes(int K, int C)
+{
+    return (long long)mirror_body_bytes(K, C) + mirror_food_bytes(C) + ((12 * K + 15) & ~15);
+}
+
+// mirror -> LDS by `nth` threads (tid 0..nth-1; nth = 64: one wave, then `sync` is a wave-level LDS fence).  Returns the
+// thread's food bits in load_env's layout (bit k = food at cell tid + nth * k).  hcell / lmax / tclk as load_env leaves
+// them (lmax = the snake's length).
+template <typename Sync>
+__device__ __forceinline__ u64 mirror_load(const Ctx &cx, const unsigned char *__restrict__ m, int tid, int nth, Sync sync)
+{
+    const int C = cx.C, K = cx.K, nb = mirror_body_bytes(K, C) >> 4, nf = mirror_food_bytes(C) >> 4;
+    const uint4 *mb = (const uint4 *)m, *mf = (const uint4 *)(m + mirror_body_bytes(K, C));
+    const int *ms = (const int *)(m + mirror_body_bytes(K, C) + mirror_food_bytes(C));
+    // (the grids start on 16-byte boundaries in LDS and are followed by padding up to the next one: multi_layout)
+    uint4 *lb = (uint4 *)cx.body, *lf = (uint4 *)cx.food;
+    for (int i0 = 0; i0 < nb; i0 += 8 * nth) {
+        uint4 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = mb[min(i0 + tid + j * nth, nb - 1)];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (i0 + tid + j * nth < nb) lb[i0 + tid + j * nth] = v[j];
+    }
+    for (int i = tid; i < nf; i += nth) lf[i] = mf[i];
+    if (tid < K) {
+        cx.tclk[tid] = ms[tid];
+        cx.hcell[tid] = ms[K + tid];
+        cx.lmax[tid] = ms[2 * K + tid];
+    }
+    for (int c = tid; c < C; c += nth) cx.hmap[c] = 0;
+    sync();
+    u64 fbits = 0;
+    for (int k = 0, c = tid; c < C; ++k, c += nth) fbits |= (u64)(cx.food[c] != 0) << k;
+    return fbits;
+}
+
+// LDS -> mirror (the DIRTY bits stay behind: they mean "written since the load from fp32").  hc / L: the snake's head
+// cell and length as of now (threads 0..K-1).
+// sparse: the grids came from this mirror in this launch — only the body cells written since (DIRTY) and the food cells
+// that differ from fbits0 (mirror_load's return value) are stored.
+template <typename Sync>
+__device__ __forceinline__ void mirror_store(const Ctx &cx, unsigned char *__restrict__ m, int tid, int nth, int hc, int L,
+                                             Sync sync, bool sparse = false, u64 fbits0 = 0)
+{
+    const int C = cx.C, K = cx.K, nb = mirror_body_bytes(K, C) >> 4, nf = mirror_food_bytes(C) >> 4;
+    uint4 *mb = (uint4 *)m, *mf = (uint4 *)(m + mirror_body_bytes(K, C));
+    int *ms = (int *)(m + mirror_body_bytes(K, C) + mirror_food_bytes(C));
+    const uint4 *lb = (const uint4 *)cx.body, *lf = (const uint4 *)cx.food;
+    sync();
+    const u32 keep = (u32)VMASK * 0x00010001u, dirty = (u32)DIRTY * 0x00010001u;
+    if (sparse) {
+        unsigned short *mb16 = (unsigned short *)m;
+        unsigned char *mf8 = m + mirror_body_bytes(K, C);
+        for (int i = tid; i < nb; i += nth) {
+            const uint4 v = lb[i];
+            if (((v.x | v.y | v.z | v.w) & dirty) == 0) continue;
+            const u32 w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (w[q] & (u32)DIRTY) mb16[8 * i + 2 * q] = (unsigned short)(w[q] & VMASK);
+                if (w[q] & ((u32)DIRTY << 16)) mb16[8 * i + 2 * q + 1] = (unsigned short)((w[q] >> 16) & VMASK);
+            }
+        }
+        for (int k = 0, c = tid; c < C; ++k, c += nth) {
+            const int f = cx.food[c] != 0;
+            if (f != (int)((fbits0 >> k) & 1)) mf8[c] = (unsigned char)f;
+        }
+    } else {
+        for (int i = tid; i < nb; i += nth) {
+            uint4 v = lb[i];
+            v.x &= keep; v.y &= keep; v.z &= keep; v.w &= keep;
+            mb[i] = v;
+        }
+        for (int i = tid; i < nf; i += nth) mf[i] = lf[i];
+    }
+    if (tid < K) {
+        ms[tid] = cx.tclk[tid];
+        ms[K + tid] = hc;
+        ms[2 * K + tid] = L;
+    }
+}
+
+// foods / heads / bodies from the mirror (lazy form), no LDS: one workgroup per env
+__global__ __launch_bounds__(256) void multi_flush_kernel(MultiArgs p)
+{
+    const long long env = blockIdx.x;
+    const int C = p.S * p.S, K = p.K, KC = K * C, tid = (int)threadIdx.x, nth = (int)blockDim.x;
+    const unsigned char *m = p.resident + env * mirror_env_bytes(K, C);
+    const unsigned short *mb = (const unsigned short *)m;
+    const unsigned char *mf = m + mirror_body_bytes(K, C);
+    const int *ms = (const int *)(m + mirror_body_bytes(K, C) + mirror_food_bytes(C));
+    float *foodp = p.foods + env * C, *headp = p.heads + env * KC, *bodyp = p.bodies + env * KC;
+    const float rcpC = 1.0f / (float)C;
+    for (int i = tid; i < KC; i += nth) {
+        const int s = div_size(i, rcpC);
+        bodyp[i] = (float)max((int)(mb[i] & VMASK) - ms[s], 0);
+        headp[i] = (i - s * C == ms[K + s]) ? 1.0f : 0.0f;
+    }
+    for (int c = tid; c < C; c += nth) foodp[c] = mf[c] ? 1.0f : 0.0f;
 }
 
 // ------------------------------------------------------------------------------------------------ step pieces
@@ -309,12 +425,12 @@ __device__ __forceinline__ void delete_done(const Ctx &cx, bool done, bool &has_
 }
 
 // keeps the 15-bit clocks of long-lived snakes away from the top of their range: ex -= T, T = 0 (values unchanged)
-__device__ __forceinline__ void rebase_clocks(const Ctx &cx)
+__device__ __forceinline__ bool rebase_clocks(const Ctx &cx)
 {
     const int C = cx.C, lane = cx.lane;
     const int myT = lane < cx.K ? cx.tclk[lane] : 0;
     u64 m = ballot(lane < cx.K && myT > CLOCK_REBASE && myT < CLOCK_DEAD);
-    if (!m) return;
+    if (!m) return false;
     const u64 mine = m;
     while (m) {
         const int s = first_bit(m);
@@ -332,6 +448,7 @@ __device__ __forceinline__ void rebase_clocks(const Ctx &cx)
     wave_lds_sync();
     if ((mine >> lane) & 1) cx.tclk[lane] = 0;
     wave_lds_sync();
+    return true;
 }
 
 // bit k set <=> cell lane + 64k is interior and has no food, head or body on it (:439-445, :393-399)
@@ -879,18 +996,35 @@ __global__ __launch_bounds__(256) void multi_step_kernel(MultiArgs p)
     // An env the postponed reset rebuilds is not read at all (as in multi_reset_kernel): the launch is one round of waves
     // and ends with its slowest env, and a rebuilt env — rebuild + whole-env store — is the slowest already.
     const bool rebuild = p.done_env != nullptr && uniform((int)p.done_env[env]) != 0;
+    const bool mirrored = p.resident != nullptr, lazy = mirrored && p.resident_lazy != 0;
+    const bool from_mirror = mirrored && p.resident_valid != 0;
+    unsigned char *mp = mirrored ? p.resident + env * mirror_env_bytes(K, C) : nullptr;
+    auto fence = [] { wave_lds_sync(); };
     u64 fbits0 = 0;
     if (!rebuild) {
-        fbits0 = load_env(cx, foodp, headp, bodyp);
+        fbits0 = from_mirror ? mirror_load(cx, mp, lane, 64, fence) : load_env(cx, foodp, headp, bodyp);
     } else {
         if (snake) { cx.hcell[lane] = -1; cx.lmax[lane] = 0; cx.tclk[lane] = 0; } // the rest: multi_reset_grid(rebuild)
         wave_lds_sync();
     }
+    const int t0 = snake ? cx.tclk[lane] : 0; // the clocks as loaded (0 unless the state came from the mirror)
     Snake sn;
     StepRes r;
     int hc0;
     step_middle(cx, p, env, rebuild, sn, r, hc0);
-    store_env(cx, foodp, headp, bodyp, fbits0, hc0, sn.hc, rebuild); // a rebuilt env is stored whole
+    if (!lazy) {
+        if (from_mirror) { // (step_middle has read the lengths out of lmax)
+            if (snake) cx.lmax[lane] = t0;
+            wave_lds_sync();
+        }
+        store_env(cx, foodp, headp, bodyp, fbits0, hc0, sn.hc, rebuild, from_mirror); // a rebuilt env is stored whole
+    }
+    if (mirrored) {
+        const bool rebased = rebase_clocks(cx); // the clocks stay with the mirror from call to call
+        mirror_store(cx, mp, lane, 64, sn.hc, (snake && !sn.done) ? sn.L : 0, fence, // (a deleted snake's body reads all-zero)
+                     from_mirror && !rebuild && !rebased, fbits0);
+        wave_lds_sync();
+    }
     if (p.obs_mode != WURM_OBS_NONE) observe(cx, p, p.obs, env, sn);
     if (p.obs_after == nullptr || p.obs_mode == WURM_OBS_NONE) return;
     reset_for_obs_after(cx, p, env, sn, r);
@@ -947,15 +1081,16 @@ __device__ __forceinline__ u64 wg_load_env(const Ctx &cx, const float *__restric
 }
 
 __device__ __forceinline__ void wg_store_env(const Ctx &cx, float *__restrict__ foodp, float *__restrict__ headp,
-                                             float *__restrict__ bodyp, u64 fbits0, bool full, int tid, int nth)
+                                             float *__restrict__ bodyp, u64 fbits0, bool full, int tid, int nth,
+                                             bool t0_in_lmax = false)
 {
     const int C = cx.C, KC = cx.K * C;
     const float rcpC = 1.0f / (float)C;
     for (int i = tid; i < KC; i += nth) {
         const unsigned short v = cx.body[i];
-        const int s = div_size(i, rcpC), T = cx.tclk[s];
+        const int s = div_size(i, rcpC), T = cx.tclk[s], T0 = t0_in_lmax ? cx.lmax[s] : 0;
         // changed since the load: written cells, and — once the clock has moved — every cell that held a value
-        if (full || (v & DIRTY) || (T != 0 && (v & VMASK))) bodyp[i] = (float)max((int)(v & VMASK) - T, 0);
+        if (full || (v & DIRTY) || (T != T0 && (int)(v & VMASK) > T0)) bodyp[i] = (float)max((int)(v & VMASK) - T, 0);
         if (full) headp[i] = (i - s * C == cx.hcell[s]) ? 1.0f : 0.0f;
     }
     for (int k = 0, c = tid; c < C; ++k, c += nth) {
@@ -1002,20 +1137,42 @@ __global__ __launch_bounds__(256) void multi_step_wg_kernel(MultiArgs p)
     const int C = cx.C, K = cx.K, lane = cx.lane;
     float *foodp = p.foods + env * C, *headp = p.heads + env * K * C, *bodyp = p.bodies + env * K * C;
     const bool rebuild = p.done_env != nullptr && p.done_env[env] != 0;
+    const bool mirrored = p.resident != nullptr, lazy = mirrored && p.resident_lazy != 0;
+    const bool from_mirror = mirrored && p.resident_valid != 0;
+    unsigned char *mp = mirrored ? p.resident + env * mirror_env_bytes(K, C) : nullptr;
+    auto barrier = [] { __syncthreads(); };
     u64 fbits0 = 0;
-    if (!rebuild) fbits0 = wg_load_env(cx, foodp, headp, bodyp, tid, nth);
+    if (!rebuild) fbits0 = from_mirror ? mirror_load(cx, mp, tid, nth, barrier) : wg_load_env(cx, foodp, headp, bodyp, tid, nth);
     else if (tid < K) { cx.hcell[tid] = -1; cx.lmax[tid] = 0; cx.tclk[tid] = 0; }
     __syncthreads();
+    const int t0 = tid < K ? cx.tclk[tid] : 0;
     Snake sn;
     StepRes r;
     int hc0 = -1;
     if (wave == 0) step_middle(cx, p, env, rebuild, sn, r, hc0);
     __syncthreads();
-    wg_store_env(cx, foodp, headp, bodyp, fbits0, rebuild, tid, nth);
-    if (wave == 0 && !rebuild && lane < K && sn.hc != hc0) { // the head cells that moved
-        float *hp = headp + (size_t)lane * C;
-        if (hc0 >= 0) hp[hc0] = 0.0f;
-        if (sn.hc >= 0) hp[sn.hc] = 1.0f;
+    if (!lazy) {
+        if (from_mirror) {
+            if (tid < K) cx.lmax[tid] = t0;
+            __syncthreads();
+        }
+        wg_store_env(cx, foodp, headp, bodyp, fbits0, rebuild, tid, nth, from_mirror);
+        if (wave == 0 && !rebuild && lane < K && sn.hc != hc0) { // the head cells that moved
+            float *hp = headp + (size_t)lane * C;
+            if (hc0 >= 0) hp[hc0] = 0.0f;
+            if (sn.hc >= 0) hp[sn.hc] = 1.0f;
+        }
+    }
+    if (mirrored) {
+        if (wave == 0 && rebase_clocks(cx) && lane == 0) cx.hmap[0] = 1; // (the head map is all-zero here: a flag for the others)
+        __syncthreads();
+        const bool rebased = cx.hmap[0] != 0;
+        __syncthreads();
+        if (tid == 0) cx.hmap[0] = 0;
+        // (threads 0..K-1 are lanes of wave 0: they hold the snakes' head cells and lengths)
+        mirror_store(cx, mp, tid, nth, sn.hc, (tid < K && !sn.done) ? sn.L : 0, barrier, from_mirror && !rebuild && !rebased,
+                     fbits0);
+        __syncthreads();
     }
     if (p.obs_mode == WURM_OBS_NONE) return;
     wg_observe_snap(cx, p, p.obs, env, tid, nth, wave);
@@ -1802,7 +1959,38 @@ int wurm_multi_step_reset(const wurm_multi_call *c, void *stream)
     if (c->inject) { p.inj = *c->inject; p.has_inj = 1; }
     if (c->pre_inject) { p.rinj = *c->pre_inject; p.has_rinj = 1; }
     if (c->agent_major_f32 && c->agent_major_u8) { p.am_f32 = c->agent_major_f32; p.am_u8 = c->agent_major_u8; }
+    if (c->resident && c->num_envs > 0) {
+        if (!c->inject && !c->pre_inject) {
+            p.resident = (unsigned char *)c->resident;
+            p.resident_valid = c->resident_valid != 0;
+            p.resident_lazy = c->resident_lazy != 0;
+        } else if (c->resident_lazy && c->resident_valid) { // recorded outcomes step the fp32 state: write the mirror out first
+            rc = wurm_multi_resident_flush(c, stream);
+            if (rc) return rc;
+        }
+    }
     return multi_launch(MK_STEP, p, stream);
+}
+
+int64_t wurm_multi_resident_bytes(int64_t num_envs, int num_snakes, int size)
+{
+    if (num_envs <= 0 || num_snakes < 1 || num_snakes > 64 || size < 5 || size > 64) return 0;
+    const char *e = getenv("WURM_RESIDENT_MIN_ENVS");
+    const bool big = e ? num_envs >= atoll(e) : num_envs * (long long)num_snakes * size * size >= (1ll << 20);
+    return big ? num_envs * mirror_env_bytes(num_snakes, size * size) : 0;
+}
+
+int wurm_multi_resident_flush(const wurm_multi_call *c, void *stream)
+{
+    if (!c) return WURM_ERR_INVALID_ARG;
+    if (!c->resident || !c->resident_lazy || !c->resident_valid || c->num_envs <= 0) return WURM_OK;
+    if (!c->foods || !c->heads || !c->bodies) return WURM_ERR_INVALID_ARG;
+    MultiArgs p = {};
+    p.foods = c->foods; p.heads = c->heads; p.bodies = c->bodies; p.N = c->num_envs; p.K = c->num_snakes; p.S = c->size;
+    p.resident = (unsigned char *)c->resident;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(multi_flush_kernel, dim3((unsigned)p.N), dim3(256), 0, (hipStream_t)stream, p);
+    return hipGetLastError() == hipSuccess ? WURM_OK : WURM_ERR_HIP;
 }
 
 int wurm_multi_step_packed(wurm_multi_call *c, float *out_f32, uint8_t *out_u8, float *obs, float *obs_after,
@@ -1823,7 +2011,9 @@ int wurm_multi_step_packed(wurm_multi_call *c, float *out_f32, uint8_t *out_u8, 
     c->call = call;
     c->pre_done = apply_pending ? c->all_done_copy : nullptr;
     c->pre_call = pre_call;
-    return wurm_multi_step_reset(c, stream);
+    const int rc = wurm_multi_step_reset(c, stream);
+    if (c->resident) c->resident_valid = (rc == WURM_OK && !c->inject && !c->pre_inject) ? 1 : 0;
+    return rc;
 }
 
 int wurm_multi_reset(float *foods, float *heads, float *bodies, uint8_t *dones, int64_t *orientations,

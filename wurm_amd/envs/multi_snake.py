@@ -27,6 +27,7 @@ is deferred like the other form.  As for SingleSnake, a tensor alias taken befor
 that is not tracked.
 """
 import ctypes
+import os
 from collections import namedtuple, OrderedDict
 from typing import Dict, Optional, Tuple
 
@@ -62,14 +63,25 @@ class _Flushing(object):
         if obj._pending:
             obj._flush()
         obj._obs_after = None  # the caller may edit what it gets: reset(done) then observes again instead of reusing it
-        return getattr(obj, self.slot)
+        t = getattr(obj, self.slot)
+        if self.slot in _MIRRORED:
+            obj._escape(t)     # the caller holds a state tensor from now on (resident mirror: written out, watched)
+        return t
 
     def __set__(self, obj, value):
         if obj._pending:
             obj._flush()  # the reference applied the reset before this assignment; the other tensors still need it
+        if self.slot in _MIRRORED:
+            obj._touch()   # (a lazy mirror is written out to the tensors as they are before one of them is replaced)
         obj._last_fresh = False
         obj._state_dirty = True  # step() re-validates the layout and re-reads the pointers
         setattr(obj, self.slot, value)
+        if self.slot in _MIRRORED:
+            obj._escape(value)
+
+
+_MIRRORED = ('_foods', '_heads', '_bodies')  # what wurm_multi_call.resident mirrors
+_SLOTS = _MIRRORED + ('_dones', '_orientations', '_agent_colours')
 
 
 class MultiSnake(object):
@@ -78,6 +90,10 @@ class MultiSnake(object):
     _pending = False
     _last_fresh = False
     _state_dirty = True
+    _mirror = None          # the compact mirror of foods / heads / bodies the step launch reads instead of them
+    _mirror_off = False
+    _lazy_mirror = os.environ.get('WURM_RESIDENT_LAZY', '1') != '0'
+    _watched = ()           # (tensor, version) of state tensors the caller holds: in-place edits make the mirror stale
     _out_f = _out_b = _rewards_t = _boost_t = _mc_mode = _obs_after = None
     _want_after = False
     foods = _Flushing('foods')
@@ -149,9 +165,10 @@ class MultiSnake(object):
             self.render_args = render_args
 
         N, K, S, dev = num_envs, num_snakes, size, self.device
-        self.foods = torch.zeros((N, 1, S, S), dtype=torch.float32, device=dev)    # fp32 whatever `dtype` (docstring)
-        self.heads = torch.zeros((N * K, 1, S, S), dtype=torch.float32, device=dev)
-        self.bodies = torch.zeros((N * K, 1, S, S), dtype=torch.float32, device=dev)
+        # (the raw slots: the class's own tensors are not "held by the caller" until an attribute is read or assigned)
+        self._foods = torch.zeros((N, 1, S, S), dtype=torch.float32, device=dev)    # fp32 whatever `dtype` (docstring)
+        self._heads = torch.zeros((N * K, 1, S, S), dtype=torch.float32, device=dev)
+        self._bodies = torch.zeros((N * K, 1, S, S), dtype=torch.float32, device=dev)
         self.dones = torch.zeros(N * K, dtype=torch.bool, device=dev)
         self.boost_this_step = torch.zeros(N * K, dtype=torch.bool, device=dev)
         self.rewards = torch.zeros(N * K, dtype=torch.float, device=dev)
@@ -257,6 +274,51 @@ class MultiSnake(object):
         self._pending = False
         self._launch_reset(self._pend, None, _lib.OBS_NONE, 0, self._pend_call, None)
 
+    # ---- the resident mirror (include/wurm_hip.h: wurm_multi_call.resident; protocol as in envs/_fast_step.py)
+
+    def _write_out(self):
+        """foods / heads / bodies from a lazy mirror (which stays current)"""
+        c = self._mc
+        if c is not None and c.resident and c.resident_lazy and c.resident_valid:
+            rc = _lib.call(self.device.index, _lib.lib().wurm_multi_resident_flush, self._mc_addr,
+                           _lib.stream_ptr(self.device.index))
+            _lib.check(rc, 'wurm_multi_resident_flush')
+
+    def _touch(self):
+        """something other than the step launch is about to read or write the state tensors"""
+        self._write_out()
+        if self._mc is not None:
+            self._mc.resident_valid = 0
+
+    def _escape(self, t):
+        """The caller holds the state tensor `t` from now on: it is brought up to date, written by every step (no lazy form
+        any more) and watched for in-place edits through its version counter; without one (inference tensors) no mirror."""
+        self._write_out()
+        if self._mc is not None:
+            self._mc.resident_lazy = 0
+        self._lazy_mirror = False
+        ver = _version_of(t) if isinstance(t, torch.Tensor) else -1
+        if ver < 0:
+            self._mirror_off, self._mirror = True, None
+            if self._mc is not None:
+                self._mc.resident, self._mc.resident_valid = None, 0
+            return
+        self._watched = tuple((x, v) for x, v in self._watched if x is not t) + ((t, ver),)
+
+    def _watch_ok(self) -> bool:
+        """False (and the mirror marked stale) if a watched tensor has been edited in place since the last look"""
+        ok = True
+        for x, v in self._watched:
+            if _version_of(x) != v:
+                ok = False
+        if not ok:
+            self._touch()
+            self._watched = tuple((x, _version_of(x)) for x, _ in self._watched)
+            if any(v < 0 for _, v in self._watched):
+                self._mirror_off, self._mirror, self._watched = True, None, ()
+                self._mc.resident, self._mc.resident_valid = None, 0
+        return ok
+
     def _log(self, msg: str):
         if self.verbose > 0:
             print(msg)
@@ -270,19 +332,36 @@ class MultiSnake(object):
 
     def _norm(self, name: str, shape, dtype):
         """State tensors may have been rebound by the caller: bring them to the layout the kernels read."""
-        t = getattr(self, name)  # (a state attribute: applies a postponed reset first)
+        if self._pending:
+            self._flush()
+        raw = '_' + name in _SLOTS
+        t = getattr(self, '_' + name if raw else name)  # (the raw slot: the class's own use hands out no alias)
         if tuple(t.shape) != tuple(shape):
             raise RuntimeError(f'env.{name} has shape {tuple(t.shape)}, expected {tuple(shape)}')
         if t.dtype != dtype or t.device != self.device or not t.is_contiguous():
             if dtype == torch.bool and t.dtype != torch.bool:
                 t = t != 0
             t = t.to(device=self.device, dtype=dtype).contiguous()
-            fresh = self._last_fresh
-            setattr(self, name, t)
-            self._last_fresh = fresh
+            if raw:  # (not through the descriptor: nobody else holds the normalised copy)
+                setattr(self, '_' + name, t)
+                self._state_dirty = True
+                if '_' + name in _MIRRORED and self._mc is not None:
+                    self._mc.resident_valid = 0
+            else:
+                fresh = self._last_fresh
+                setattr(self, name, t)
+                self._last_fresh = fresh
         return t
 
     def _state(self):
+        """the state tensors, normalised, a postponed reset applied; the caller is about to read or write them with another
+        entry point (the step launch uses _step_state)"""
+        if self._pending:
+            self._flush()
+        self._touch()
+        return self._step_state()
+
+    def _step_state(self):
         N, K, S = self.num_envs, self.num_snakes, self.size
         return (self._norm('foods', (N, 1, S, S), torch.float32), self._norm('heads', (N * K, 1, S, S), torch.float32),
                 self._norm('bodies', (N * K, 1, S, S), torch.float32), self._norm('dones', (N * K,), torch.bool),
@@ -406,8 +485,17 @@ class MultiSnake(object):
                 ks = [str(i) for i in range(K)]
                 self._keys = tuple([p + k for k in ks] for p in ('agent_', 'snake_collision_', 'edge_collision_', 'food_',
                                                                  'boost_', 'size_'))
+                # the resident mirror of foods / heads / bodies (large batches): the launch reads it instead of them;
+                # lazy (they are not written either) as long as the caller has never got hold of one of them
+                nbytes = 0 if self._mirror_off else int(_lib.lib().wurm_multi_resident_bytes(_lib.i64(N), K, S))
+                if nbytes > 0:
+                    self._mirror = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+                    c.resident, c.resident_valid = self._mirror.data_ptr(), 0
+                    c.resident_lazy = int(self._lazy_mirror and not self._watched)
+            if self._watched:
+                self._watch_ok()
             if self._state_dirty:
-                foods, heads, bodies, dones, orientations, colours, _ = self._state()
+                foods, heads, bodies, dones, orientations, colours, _ = self._step_state()
                 c.foods, c.heads, c.bodies = foods.data_ptr(), heads.data_ptr(), bodies.data_ptr()
                 c.dones, c.orientations, c.colours = dones.data_ptr(), orientations.data_ptr(), colours.data_ptr()
                 self._state_dirty = False
