@@ -438,6 +438,8 @@ def extra_measurements(device):
         t = traffic_detail.get({'per_call_api_cfg3_65536': 'resident_step_65536x9_partial2_reset_obs',
                                 'per_call_api_cfg3_65536_no_reset_obs': 'resident_step_65536x9_partial2',
                                 'per_call_api_cfg5_8192x36_default': 'grid_step_8192x36_default',
+                                'per_call_api_cfg4_4096x25_k4': 'multi_step_cfg4_4096x25_k4_full',
+                                'per_call_api_cfg4_4096x25_k4_no_mirror': 'multi_step_cfg4_4096x25_k4_full_no_mirror',
                                 'per_call_api_cfg5_8192x36_default_no_mirror': 'grid_step_8192x36_default_no_mirror'}.get(key, key))
         if t:  # rocprofv3 FETCH_SIZE + WRITE_SIZE of one iteration's launches (profiles/hbm_traffic.json)
             out[key]['traffic_bytes_per_batch_step'] = t['total_bytes']
@@ -498,7 +500,15 @@ def extra_measurements(device):
     keys = [f'agent_{i}' for i in range(K)]
     per_call_case('per_call_api_cfg4_4096x25_k4', MultiSnake(N, K, 25, device=device, seed=0),
                   lambda t: dict(zip(keys, acts[t].unbind(0))), lambda d: d['__all__'], T,
-                  "BASELINE configs[3] through `env.step(actions); env.reset(dones['__all__'], return_observations=False)`")
+                  "BASELINE configs[3] through `env.step(actions); env.reset(dones['__all__'], return_observations=False)` "
+                  '(grids kept in the resident mirror, lazy: multi_snake.hip)')
+    os.environ['WURM_RESIDENT_MIN_ENVS'] = str(10 ** 9)
+    try:
+        per_call_case('per_call_api_cfg4_4096x25_k4_no_mirror', MultiSnake(N, K, 25, device=device, seed=0),
+                      lambda t: dict(zip(keys, acts[t].unbind(0))), lambda d: d['__all__'], T,
+                      'the same with the mirror switched off: the step reads foods / heads / bodies (92 MB of fp32) every call')
+    finally:
+        os.environ.pop('WURM_RESIDENT_MIN_ENVS')
     # (a'') the MultiSnake variants the reference itself runs: tests/test_multi_snake_env.py:100-104 (training dynamics,
     # `partial_5` crops; SURVEY §8(d) "additionally") and experiments/speeds.py:10-44 (10 agents on 36 x 36, respawn 'any',
     # `step; reset(done['__all__']); check_consistency()` — the reference's own benchmark loop, reset observation included)

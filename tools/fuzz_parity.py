@@ -373,10 +373,81 @@ def fuzz_multi(rng):
     return desc
 
 
+def fuzz_multi_resident(rng):
+    """wurm_multi_step_reset on the resident mirror (wurm_multi_call.resident), eager and lazy: random K / S (one env per
+    wave and per workgroup), dynamics and observation modes; postponed resets with the step's own mask, arbitrary masks, no
+    reset at all; the fp32 state compared whenever the lazy form writes it out; hand-edited food in between."""
+    S = int(rng.choice([8, 10, 12, 14, 18, 25, 30, 36, 44]))
+    K = int(rng.choice([1, 2, 2, 3, 4, 4, 5, 8, 10, 16]))
+    while 2 * K * S * S + 8 * S * S > 60000:
+        K = max(1, K // 2)
+    N, T = int(rng.randint(1, 20 if S <= 18 else 6)), int(rng.randint(5, 60 if S <= 18 else 25))
+    mode = ['full', f'partial_{rng.randint(1, 6)}', 'none'][rng.randint(3)]
+    cfg = dict(boost=bool(rng.rand() < 0.8), food_on_death_prob=float(rng.choice([0.0, 0.2, 0.5, 0.9, 1.0])),
+               boost_cost_prob=float(rng.choice([0.0, 0.25, 0.5, 1.0])), food_mode=['only_one', 'random_rate'][rng.randint(2)],
+               food_rate=float(rng.choice([5e-4, 5e-3, 5e-2])), reward_on_death=float(rng.choice([-1, -2, 0])),
+               respawn_mode=['all', 'any'][rng.randint(2)], colour_mode=['random', 'fixed'][rng.randint(2)])
+    lazy = bool(rng.rand() < 0.6)
+    seed, off = int(rng.randint(1 << 30)), int(rng.randint(1 << 20))
+    desc = f'multi_resident S={S} K={K} N={N} T={T} mode={mode} lazy={lazy} seed={seed} off={off} cfg={cfg}'
+    if os.environ.get('WURM_FUZZ_VERBOSE'):
+        print('start:', desc, flush=True)
+    old = os.environ.get('WURM_RESIDENT_MIN_ENVS')
+    os.environ['WURM_RESIDENT_MIN_ENVS'] = '0'
+    try:
+        o, h = OracleBackend(seed, off), HipBackend(seed, off)
+        so = _o.multi_empty_state(N, K, S)
+        so['colours'][...] = o.multi_colours(N, K, cfg['colour_mode'] == 'fixed', call=0)
+        o.call = 1
+        o.multi_reset(so, np.ones(N), cfg)
+        sh = {k: v.copy() for k, v in so.items()}
+        mirror = {'valid': 0, 'lazy': lazy}
+        call, prev, prev_call = 2, None, 0
+        for t in range(T):
+            a = rng.randint(0, 8, size=(K, N)).astype(np.int64)
+            if prev is not None:
+                o.call = prev_call
+                o.multi_reset(so, prev, cfg)
+            o.call = call
+            ro = o.multi_step(so, a, cfg, mode)
+            edit = rng.rand() < 0.06
+            mirror['sync'] = bool(not lazy or edit or rng.rand() < 0.3 or t == T - 1)
+            rh = h.multi_step_reset(sh, a, cfg, mode, call=call, pre_done=prev, pre_call=prev_call,
+                                    want_obs_after=bool(rng.rand() < 0.5) and mode != 'none', resident=mirror)
+            for k in so:
+                if mirror['sync'] or k not in ('foods', 'heads', 'bodies'):
+                    same(so[k], sh[k], f'{desc} state {k} t={t}')
+            for k in ro:
+                same(ro[k], rh[k], f'{desc} {k} t={t}')
+            if 'obs_after' in rh:
+                tmp = {k: v.copy() for k, v in so.items()}
+                o.call = call + 1
+                o.multi_reset(tmp, ro['all_done'], cfg, mode=mode)
+                same(o.last_reset_obs, rh['obs_after'], f'{desc} obs_after t={t}')
+            u = rng.rand()
+            if u < 0.15:
+                prev = None
+            elif u < 0.3:
+                prev, prev_call = (rng.rand(N) < 0.3).astype(np.uint8), call + 1
+            else:
+                prev, prev_call = ro['all_done'], call + 1
+            call += 2
+            if edit:
+                so['foods'][int(rng.randint(N)), 0, int(rng.randint(1, S - 1)), int(rng.randint(1, S - 1))] = 1
+                sh['foods'][...] = so['foods']
+                mirror['valid'] = 0
+    finally:
+        if old is None:
+            os.environ.pop('WURM_RESIDENT_MIN_ENVS', None)
+        else:
+            os.environ['WURM_RESIDENT_MIN_ENVS'] = old
+    return desc
+
+
 FAMILIES = {'single': fuzz_single, 'fused': fuzz_fused, 'resident': fuzz_resident, 'lean': fuzz_lean, 'lane': fuzz_lane,
-            'policy': fuzz_policy, 'grid': fuzz_grid, 'multi': fuzz_multi}
-WEIGHTS = {'single': 0.14, 'fused': 0.14, 'resident': 0.14, 'lean': 0.08, 'lane': 0.14, 'policy': 0.04, 'grid': 0.04,
-           'multi': 0.28}
+            'policy': fuzz_policy, 'grid': fuzz_grid, 'multi': fuzz_multi, 'multi_resident': fuzz_multi_resident}
+WEIGHTS = {'single': 0.13, 'fused': 0.13, 'resident': 0.13, 'lean': 0.07, 'lane': 0.13, 'policy': 0.03, 'grid': 0.04,
+           'multi': 0.2, 'multi_resident': 0.14}
 
 
 def library_sha256():

@@ -71,8 +71,11 @@ detail = {
     'resident_step_8192x9_partial2': traffic('void wurm::lane_resident_step_kernel<32, 1, 4, true>', 16384),
     'resident_step_65536x9_partial2': traffic('void wurm::lane_resident_step_kernel<64, 1, 4, true>', 65536),
     'resident_step_65536x9_partial2_reset_obs': traffic('void wurm::lane_resident_step_kernel<32, 2, 4, true>', 131072),
-    'multi_step_cfg4_4096x25_k4_full': traffic('wurm::multi_step_kernel', 262144, (3, 5)),  # dispatch order: 20 launches of cfg4', then 30 of cfg4
-    'per_call_api_cfg4prime_4096x25_k4_partial5': traffic('wurm::multi_step_kernel', 262144, (0, 5)),
+    # dispatch order of multi_step_kernel at this grid: 20 launches of cfg4', 20 of cfg4 (both on the resident mirror, lazy),
+    # 20 of cfg4 with the mirror switched off; the second ten of each
+    'multi_step_cfg4_4096x25_k4_full': traffic('wurm::multi_step_kernel', 262144, (3, 6)),
+    'multi_step_cfg4_4096x25_k4_full_no_mirror': traffic('wurm::multi_step_kernel', 262144, (5, 6)),
+    'per_call_api_cfg4prime_4096x25_k4_partial5': traffic('wurm::multi_step_kernel', 262144, (1, 6)),
     'per_call_api_speeds_4096x36_k10': traffic('wurm::multi_step_wg_kernel', 1048576),
     # dispatch order: 30 launches on the resident mirror (lazy: the fp32 state is neither read nor written), then 30 without
     'grid_step_8192x36_default': traffic('void wurm::(anonymous namespace)::grid_step_kernel<true>', 524288, (0, 2)),

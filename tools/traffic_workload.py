@@ -95,10 +95,15 @@ percall(65536, 9, 'partial_2')
 percall(8192, 36, 'default')   # grid_step_kernel a second time: the first 30 launches kept their grids in the mirror
 os.environ.pop('WURM_RESIDENT_MIN_ENVS')
 # measured: the per-call MultiSnake loop at cfg4 (multi_step_kernel with the postponed reset in front)
-env = MultiSnake(4096, 4, 25, device=dev, seed=0)
-actions = torch.randint(8, (30, 4, 4096), device=dev, dtype=torch.int64)
-for t in range(30):
-    _, _, d, _ = env.step({f'agent_{i}': actions[t, i] for i in range(4)})
-    env.reset(d['__all__'], return_observations=False)
-torch.cuda.synchronize()
+# — 20 launches on the resident mirror of foods / heads / bodies (lazy), then 20 with it switched off
+for mirror in (True, False):
+    if not mirror:
+        os.environ['WURM_RESIDENT_MIN_ENVS'] = str(10 ** 9)
+    env = MultiSnake(4096, 4, 25, device=dev, seed=0)
+    actions = torch.randint(8, (20, 4, 4096), device=dev, dtype=torch.int64)
+    for t in range(20):
+        _, _, d, _ = env.step({f'agent_{i}': actions[t, i] for i in range(4)})
+        env.reset(d['__all__'], return_observations=False)
+    torch.cuda.synchronize()
+os.environ.pop('WURM_RESIDENT_MIN_ENVS')
 print('traffic workload done')
