@@ -376,3 +376,42 @@ def test_replacing_the_state_tensor_writes_a_lazy_mirror_out_to_the_old_one_firs
     assert seen == [old_ptr]
     _step(env)
     assert not _steps(log)[-1]['lazy'] and not _steps(log)[-1]['mirror_valid'] and _steps(log)[-1]['envs'] != old_ptr
+
+
+def test_a_look_that_only_reads_keeps_the_mirror_and_the_second_one_ends_the_lazy_form(env_and_log):
+    """_observe / check_consistency read the state with another kernel: a lazy mirror is written out for them but stays
+    current; a caller that keeps doing that (the reference's loops check consistency every step) gets the eager form"""
+    env, log = env_and_log
+    rec = env._rec
+    _step(env); _step(env)
+    env._observe('default')
+    assert rec.flushes == [2]
+    _step(env)
+    assert _steps(log)[-1]['mirror_valid'] and _steps(log)[-1]['lazy']
+    env._observe('default')
+    assert len(rec.flushes) == 2
+    _step(env)
+    assert _steps(log)[-1]['mirror_valid'] and not _steps(log)[-1]['lazy']
+    env._observe('default')
+    assert len(rec.flushes) == 2          # eager: nothing to write out
+    _step(env)
+    assert _steps(log)[-1]['mirror_valid']
+
+
+def test_a_loop_that_invalidates_the_mirror_every_step_loses_it(env_and_log):
+    """eager resets after (nearly) every step: the mirror would be rebuilt every step for nothing"""
+    env, log = env_and_log
+    for t in range(12):
+        _step(env)
+        env.reset(torch.ones(8, dtype=torch.bool), return_observations=False)   # not the step's own flags: eager
+    assert _steps(log)[0]['mirror'] and not _steps(log)[-1]['mirror']
+    # ... but an occasional one does not cost it
+    env2_log_start = len(log)
+    from wurm_amd.envs import SingleSnake
+    e2 = SingleSnake(num_envs=8, size=9, observation_mode='partial_2', device='cpu', seed=5)
+    for t in range(200):
+        _, _, d, _ = _step(e2)
+        e2.reset(d, return_observations=False)
+        if t % 20 == 19:
+            e2.reset(torch.ones(8, dtype=torch.bool), return_observations=False)
+    assert all(s['mirror'] for s in _steps(log)[env2_log_start + 1:])

@@ -160,6 +160,7 @@ class FastStepMixin(object):
         # the mark (_touch); a state tensor the caller got hold of is watched for in-place edits through its version counter
         self._mirror, self._mirror_key, self._mirror_off = None, None, False
         self._lazy_mirror = os.environ.get('WURM_RESIDENT_LAZY', '1') != '0'
+        self._write_outs = self._touches = self._mirror_step0 = 0
 
     # state of the step machine that other methods of the classes read and write
     _call = property(lambda self: self._fs.call, lambda self, v: setattr(self._fs, 'call', v))
@@ -230,21 +231,32 @@ class FastStepMixin(object):
         self._launch_reset(self._checked(self._envs), self._pend, None, _lib.OBS_NONE, 0, fs.pend_call)
         fs.pending = False  # (only once the launch is known to have been accepted)
 
-    def _state(self) -> torch.Tensor:
+    def _state(self, write: bool = True) -> torch.Tensor:
         """The state tensor, validated, with any postponed reset applied; the caller is about to change it or to
-        consume an RNG counter."""
+        consume an RNG counter (write=False: it only reads it with another kernel — the mirror stays current)."""
         fs = self._fs
         if fs.pending:
             self._flush()
         fs.last_fresh = False
-        self._touch()
+        if write:
+            self._touch()
+        else:
+            self._write_out()
         return self._checked(self._envs)
 
     def _touch(self):
         """Something other than the step launch is about to look at the state or to write it: a lazy mirror is written
         out to `envs` first (the step launches have not been writing them), and the next step rebuilds the mirror."""
         self._write_out()
-        self._c.resident_valid = 0
+        c = self._c
+        if c.resident_valid and c.resident:
+            # a loop in which (nearly) every step is followed by something that writes the state some other way — an eager
+            # reset, a rollout — rebuilds the mirror every step for nothing: switch it off for this env object
+            self._touches += 1
+            if self._touches >= 8 and 2 * self._touches >= self._fs.steps - self._mirror_step0:
+                self._mirror_off, self._mirror, self._mirror_key = True, None, None
+                c.resident = None
+        c.resident_valid = 0
 
     def _write_out(self):
         """`envs` from a lazy mirror (which stays current)"""
@@ -253,6 +265,11 @@ class FastStepMixin(object):
             rc = _lib.call(self.device.index, _lib.lib().wurm_single_resident_flush, ctypes.addressof(c),
                            _lib.stream_ptr(self.device.index))
             _lib.check(rc, 'wurm_single_resident_flush')
+            # a caller that keeps looking at the state (check_consistency() every step, experiments/main.py:214-215) pays
+            # a whole-state write per look in the lazy form: from the second one on the steps write `envs` themselves
+            self._write_outs += 1
+            if self._write_outs >= 2:
+                c.resident_lazy = 0
 
     def _watch(self, t):
         """The caller holds the state tensor `t` from now on and may edit it in place at any time: every step compares its
@@ -289,11 +306,13 @@ class FastStepMixin(object):
         if self._CHANNELS == 3 and not self._mirror_off:
             nbytes = int(_lib.lib().wurm_single_resident_bytes(_lib.i64(self.num_envs), self.size, m, n))
         self._mirror = torch.empty(nbytes, dtype=torch.uint8, device=self.device) if nbytes > 0 else None
+        self._touches, self._mirror_step0 = 0, self._fs.steps
         self._c.resident = self._mirror.data_ptr() if self._mirror is not None else None
         self._c.resident_valid = 0
         # lazy (the step launches do not write `envs`, _touch() brings them up to date) as long as the caller has never
         # got hold of the state tensor
-        self._c.resident_lazy = int(self._mirror is not None and self._fs.watch is None and self._lazy_mirror)
+        self._c.resident_lazy = int(self._mirror is not None and self._fs.watch is None and self._lazy_mirror and
+                                    self._write_outs < 2)
 
     def _checked(self, e: torch.Tensor) -> torch.Tensor:
         if e is self._envs_ok:

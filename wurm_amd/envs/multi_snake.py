@@ -94,6 +94,7 @@ class MultiSnake(object):
     _mirror_off = False
     _lazy_mirror = os.environ.get('WURM_RESIDENT_LAZY', '1') != '0'
     _watched = ()           # (tensor, version) of state tensors the caller holds: in-place edits make the mirror stale
+    _write_outs = _touches = _steps = 0
     _out_f = _out_b = _rewards_t = _boost_t = _mc_mode = _obs_after = None
     _want_after = False
     foods = _Flushing('foods')
@@ -283,12 +284,27 @@ class MultiSnake(object):
             rc = _lib.call(self.device.index, _lib.lib().wurm_multi_resident_flush, self._mc_addr,
                            _lib.stream_ptr(self.device.index))
             _lib.check(rc, 'wurm_multi_resident_flush')
+            # a caller that keeps looking at the state (experiments/speeds.py:30-38: check_consistency() every step) pays a
+            # whole-state write per look in the lazy form: from the second one on the steps write the tensors themselves
+            self._write_outs += 1
+            if self._write_outs >= 2:
+                c.resident_lazy = 0
+                self._lazy_mirror = False
 
     def _touch(self):
         """something other than the step launch is about to read or write the state tensors"""
         self._write_out()
-        if self._mc is not None:
-            self._mc.resident_valid = 0
+        c = self._mc
+        if c is not None:
+            if c.resident and c.resident_valid:
+                # a loop in which (nearly) every step is followed by something that writes the state some other way (an
+                # eager reset: experiments/speeds.py's check_consistency() flushes the postponed one every step) rebuilds
+                # the mirror every step for nothing: switch it off for this env object
+                self._touches += 1
+                if self._touches >= 8 and 2 * self._touches >= self._steps:
+                    self._mirror_off, self._mirror = True, None
+                    c.resident = None
+            c.resident_valid = 0
 
     def _escape(self, t):
         """The caller holds the state tensor `t` from now on: it is brought up to date, written by every step (no lazy form
@@ -353,12 +369,15 @@ class MultiSnake(object):
                 self._last_fresh = fresh
         return t
 
-    def _state(self):
-        """the state tensors, normalised, a postponed reset applied; the caller is about to read or write them with another
-        entry point (the step launch uses _step_state)"""
+    def _state(self, write: bool = True):
+        """the state tensors, normalised, a postponed reset applied; the caller is about to write them with another entry
+        point, or (write=False) only to read them — then the mirror stays current (the step launch uses _step_state)"""
         if self._pending:
             self._flush()
-        self._touch()
+        if write:
+            self._touch()
+        else:
+            self._write_out()
         return self._step_state()
 
     def _step_state(self):
@@ -400,7 +419,7 @@ class MultiSnake(object):
     def _get_env_images(self) -> torch.Tensor:
         """reference :194-227 — (N,3,S,S) int16 image of every env; not on the step path (used by render())."""
         N, K, S = self.num_envs, self.num_snakes, self.size
-        foods, heads, bodies, dones, _, colours, boost = self._state()
+        foods, heads, bodies, dones, _, colours, boost = self._state(write=False)
         inten = bodies.gt(EPS).float() * 1 / 3 + heads.gt(EPS).float() * 1 / 3
         inten = (inten * (1 + 0.5 * boost.float())[:, None, None, None]).squeeze(1)
         img = (inten[:, None] * colours.float()[:, :, None, None]).reshape(N, K, 3, S, S).sum(dim=1).short()
@@ -426,7 +445,7 @@ class MultiSnake(object):
         if mode is None:
             mode = self.observation_mode
         m, n, obs = self._obs_args(mode)
-        foods, heads, bodies, dones, _, colours, boost = self._state()
+        foods, heads, bodies, dones, _, colours, boost = self._state(write=False)
         rc = _lib.call(self.device.index, _lib.lib().wurm_multi_observe, _lib.ptr(foods), _lib.ptr(heads), _lib.ptr(bodies), _lib.ptr(dones),
                                            _lib.ptr(boost), _lib.ptr(colours), _lib.ptr(obs), m, n,
                                            _lib.i64(self.num_envs), self.num_snakes, self.size, _lib.stream_ptr(self.device.index))
@@ -492,6 +511,7 @@ class MultiSnake(object):
                     self._mirror = torch.empty(nbytes, dtype=torch.uint8, device=dev)
                     c.resident, c.resident_valid = self._mirror.data_ptr(), 0
                     c.resident_lazy = int(self._lazy_mirror and not self._watched)
+            self._steps += 1
             if self._watched:
                 self._watch_ok()
             if self._state_dirty:
@@ -609,7 +629,7 @@ class MultiSnake(object):
 
     def check_consistency(self):
         """reference :733-769: raises RuntimeError if any env is inconsistent"""
-        foods, heads, bodies, dones, _, _, _ = self._state()
+        foods, heads, bodies, dones, _, _, _ = self._state(write=False)
         err = torch.empty(self.num_envs, dtype=torch.int32, device=self.device)
         rc = _lib.call(self.device.index, _lib.lib().wurm_multi_check, _lib.ptr(foods), _lib.ptr(heads), _lib.ptr(bodies), _lib.ptr(dones),
                                          _lib.ptr(err), _lib.i64(self.num_envs), self.num_snakes, self.size,

@@ -141,7 +141,7 @@ class SingleSnake(FastStepMixin):
     def _observe(self, observation_mode: str = 'default') -> torch.Tensor:
         """reference :130-195"""
         m, n, shape = self._mode_info(observation_mode)
-        envs = self._state()
+        envs = self._state(write=False)
         obs = torch.empty(shape, dtype=torch.float32, device=self.device)
         rc = _lib.call(self.device.index, _lib.lib().wurm_single_observe, _lib.ptr(envs), _lib.ptr(obs), m, n, _lib.i64(self.num_envs),
                                             self.size, _lib.stream_ptr(self.device.index))
@@ -306,7 +306,7 @@ class SingleSnake(FastStepMixin):
     def check_consistency(self):
         """wurm.utils.env_consistency on self.envs (reference wurm/utils.py:167-178)."""
         from wurm_amd.utils import env_consistency
-        env_consistency(self._state())
+        env_consistency(self._state(write=False))
 
     # ------------------------------------------------------------------ rendering (host side)
 
