@@ -77,26 +77,45 @@ def _have_c_stepper():
         return False
 
 
-@pytest.fixture(params=['python', 'c'])
+def _torchinfo_addresses():
+    """the real tensor-facts helper of wurm_amd/libwurm_torchinfo.so (it works on CPU tensors) with stand-ins for the two
+    that ask the HIP runtime: current device -1 (as the patched accessor), stream 0"""
+    import os
+    path = os.path.join(os.path.dirname(_lib.__file__), 'libwurm_torchinfo.so')
+    if not os.path.exists(path):
+        return None
+    l = ctypes.PyDLL(path)
+    keep = (l, ctypes.CFUNCTYPE(ctypes.c_void_p, ctypes.c_int)(lambda idx: 0), ctypes.CFUNCTYPE(ctypes.c_int)(lambda: -1))
+    return keep, (ctypes.cast(l.wurm_torch_tensor_info, ctypes.c_void_p).value,
+                  ctypes.cast(keep[1], ctypes.c_void_p).value, ctypes.cast(keep[2], ctypes.c_void_p).value)
+
+
+@pytest.fixture(params=['python', 'c', 'c+torchinfo'])
 def env_and_log(monkeypatch, request):
     """the env on CPU tensors over a recording stand-in of the library, once with the Python step machine (PyStepper) and
     once with the C one (wurm_amd._fastcall.Stepper calling the recorder through a C function pointer)"""
-    if request.param == 'c' and not _have_c_stepper():
+    if request.param != 'python' and not _have_c_stepper():
         pytest.skip('wurm_amd/_fastcall is not built')
+    helpers = _torchinfo_addresses() if request.param == 'c+torchinfo' else None
+    if request.param == 'c+torchinfo' and helpers is None:
+        pytest.skip('wurm_amd/libwurm_torchinfo.so is not built')
     rec = _Recorder()
-    slot = _CSlot(rec) if request.param == 'c' else rec.step_slot
+    slot = _CSlot(rec) if request.param != 'python' else rec.step_slot
     monkeypatch.setattr(_lib, 'lib', lambda: rec)
     monkeypatch.setattr(_lib, 'require_device', lambda d: torch.device('cpu'))
     monkeypatch.setattr(_lib, 'stream_ptr', lambda i=None: 0)
     monkeypatch.setattr(_lib, 'call', lambda idx, fn, *a: fn(*a))
     monkeypatch.setattr(_lib, 'accessors', lambda: ((lambda: -1), (lambda i: 0)))
     monkeypatch.setattr(_lib, 'step_slot_fn', lambda name='wurm_single_step_slot': slot)
+    # (the real helpers ask the HIP runtime for the device and the stream: stand-ins, or the generic attribute path)
+    monkeypatch.setattr(_lib, 'torch_helpers', lambda: helpers[1] if helpers else None)
     from wurm_amd.envs import SingleSnake
     from wurm_amd.envs._fast_step import PyStepper
     env = SingleSnake(num_envs=8, size=9, observation_mode='partial_2', device='cpu', seed=5)
     assert isinstance(env._fs, PyStepper) == (request.param == 'python')
     rec.calls.clear()
     env._rec = rec
+    env._keep = helpers
     return env, rec.calls
 
 

@@ -257,6 +257,27 @@ def _torch_accessors():
         _get_device = torch.cuda.current_device
 
 
+_torchinfo = None
+
+
+def torch_helpers():
+    """(tensor_info, raw_stream, current_device) addresses of wurm_amd/libwurm_torchinfo.so (csrc/torchinfo.cpp: facts about
+    a tensor and torch's current device / stream straight from ATen), or None if that optional helper is not built."""
+    global _torchinfo
+    if _torchinfo is None:
+        _torchinfo = False
+        path = os.path.join(_HERE, 'libwurm_torchinfo.so')
+        if os.path.exists(path) and os.environ.get('WURM_TORCHINFO', '1') != '0':
+            try:
+                import torch  # noqa: F401  (its libraries first: the helper links against them)
+                l = ctypes.PyDLL(path)
+                _torchinfo = (l, tuple(ctypes.cast(getattr(l, n), ctypes.c_void_p).value for n in
+                                       ('wurm_torch_tensor_info', 'wurm_torch_raw_stream', 'wurm_torch_current_device')))
+            except (OSError, AttributeError):
+                _torchinfo = False
+    return _torchinfo[1] if _torchinfo else None
+
+
 def accessors():
     """(current-device getter, raw-stream getter) for callers that inline `call` / `stream_ptr` on a hot path"""
     if _get_raw_stream is None:

@@ -85,9 +85,18 @@ static PyObject *fast_multi_step(PyObject *self, PyObject *const *args, Py_ssize
  */
 #include <structmember.h>
 
+/* wurm_amd/csrc/torchinfo.cpp (optional): the facts about `actions` straight from the at::Tensor */
+typedef struct wurm_tensor_info { void *ptr; long long size0; int dtype, dim, contiguous, device; } wurm_tensor_info;
+typedef int (*tensor_info_fn)(PyObject *, wurm_tensor_info *);
+typedef void *(*raw_stream_fn)(int);
+typedef int (*current_device_fn)(void);
+
 typedef struct {
     PyObject_HEAD
     step_slot_fn fn;
+    tensor_info_fn tinfo;      /* all three or none */
+    raw_stream_fn raw_stream;
+    current_device_fn cur_dev;
     void *blk, *slabs;
     long long slot, R, num_envs, dev_index, slab_version;
     unsigned long long call, pend_call, steps;
@@ -113,9 +122,16 @@ static void set_obj(PyObject **slot, PyObject *v)
 static int stepper_init(Stepper *self, PyObject *args, PyObject *kwds)
 {
     (void)kwds;
-    PyObject *fn, *blk, *slabs, *gd, *gs, *d64, *d32, *d16;
-    if (!PyArg_ParseTuple(args, "OOOOOOOO", &fn, &blk, &slabs, &gd, &gs, &d64, &d32, &d16)) return -1;
+    PyObject *fn, *blk, *slabs, *gd, *gs, *d64, *d32, *d16, *ti = NULL, *rs = NULL, *cd = NULL;
+    if (!PyArg_ParseTuple(args, "OOOOOOOO|OOO", &fn, &blk, &slabs, &gd, &gs, &d64, &d32, &d16, &ti, &rs, &cd)) return -1;
     self->fn = (step_slot_fn)PyLong_AsVoidPtr(fn);
+    self->tinfo = NULL; self->raw_stream = NULL; self->cur_dev = NULL;
+    if (ti && rs && cd && ti != Py_None && rs != Py_None && cd != Py_None) { /* addresses of torchinfo.cpp's helpers */
+        self->tinfo = (tensor_info_fn)PyLong_AsVoidPtr(ti);
+        self->raw_stream = (raw_stream_fn)PyLong_AsVoidPtr(rs);
+        self->cur_dev = (current_device_fn)PyLong_AsVoidPtr(cd);
+        if (!self->tinfo || !self->raw_stream || !self->cur_dev) { self->tinfo = NULL; self->raw_stream = NULL; self->cur_dev = NULL; }
+    }
     self->blk = PyLong_AsVoidPtr(blk);
     self->slabs = PyLong_AsVoidPtr(slabs);
     if (PyErr_Occurred()) return -1;
@@ -175,8 +191,48 @@ static long method_long(PyObject *obj, PyObject *name)
  * state tensor to re-validate or edited in place, actions on another device / not a contiguous vector, another device current) and call
  * again;  a non-zero int: the entry point's error code.  Argument errors are raised as the reference raises them
  * (single_snake.py:198-203; int16 passes its check and fails in scatter_ at :229). */
+static PyObject *stepper_finish(Stepper *self, long long i, int rc);
+
 static PyObject *stepper_step(Stepper *self, PyObject *actions)
 {
+    wurm_tensor_info ti;
+    if (self->tinfo && self->tinfo(actions, &ti) == 0 && ti.dim >= 1) {
+        /* the same checks, in the same order, on the facts torchinfo.cpp read from the at::Tensor (ScalarType: Short = 2,
+         * Int = 3, Long = 4); anything that is not a tensor of at least one dimension takes the generic path below */
+        int code;
+        if (ti.dtype == 4) code = 0;
+        else if (ti.dtype == 3) code = 1;
+        else {
+            if (ti.dtype == 2) PyErr_SetString(PyExc_RuntimeError, "scatter_(): Expected dtype int32/int64 for index");
+            else PyErr_SetString(PyExc_TypeError, "actions Tensor must be an integer type i.e. "
+                                                  "{torch.ShortTensor, torch.IntTensor, torch.LongTensor}");
+            return NULL;
+        }
+        if (ti.size0 != self->num_envs) {
+            PyErr_SetString(PyExc_RuntimeError, "Must have the same number of actions as environments.");
+            return NULL;
+        }
+        const long long i = self->slot;
+        if (!self->ok || i >= self->R || (self->want_obs_after && self->obs_afters == Py_None)) Py_RETURN_NONE;
+        if (self->watch != NULL && self->watch != Py_None) {
+            long long ver = -1;
+            PyObject *vo = PyObject_GetAttr(self->watch, s_version);
+            if (vo) {
+                ver = PyLong_AsLongLong(vo);
+                Py_DECREF(vo);
+                if (ver == -1 && PyErr_Occurred()) PyErr_Clear();
+            } else {
+                PyErr_Clear();
+            }
+            if (ver != self->watch_version) Py_RETURN_NONE;
+        }
+        if ((long long)ti.device != self->dev_index || ti.dim != 1 || !ti.contiguous) Py_RETURN_NONE;
+        if ((long long)self->cur_dev() != self->dev_index) Py_RETURN_NONE; /* kernels launch on the current device */
+        void *stream = self->raw_stream((int)self->dev_index);
+        const int rc = self->fn(self->blk, self->slabs, (int64_t)i, ti.ptr, code, (uint64_t)self->call, self->pending,
+                                (uint64_t)self->pend_call, self->want_obs_after, stream);
+        return stepper_finish(self, i, rc);
+    }
     PyObject *dt = PyObject_GetAttr(actions, s_dtype);
     if (!dt) return NULL;
     int code;
@@ -245,6 +301,12 @@ static PyObject *stepper_step(Stepper *self, PyObject *actions)
 
     const int rc = self->fn(self->blk, self->slabs, (int64_t)i, aptr, code, (uint64_t)self->call, self->pending,
                             (uint64_t)self->pend_call, self->want_obs_after, stream);
+    return stepper_finish(self, i, rc);
+}
+
+/* bookkeeping after the launch of slot i */
+static PyObject *stepper_finish(Stepper *self, long long i, int rc)
+{
     if (rc) return PyLong_FromLong(rc); /* nothing consumed: the counter, the postponed reset and the slot stay */
     self->call += 1;
     self->steps += 1;

@@ -132,8 +132,9 @@ def _make_stepper(name, blk_addr, slabs_addr):
     if addr is not None:
         try:
             from wurm_amd import _fastcall
+            helpers = _lib.torch_helpers() or (None, None, None)
             return _fastcall.Stepper(addr, blk_addr, slabs_addr, get_device, get_stream, torch.int64, torch.int32,
-                                     torch.int16)
+                                     torch.int16, *helpers)
         except (ImportError, AttributeError):
             pass
     return PyStepper(fn, blk_addr, slabs_addr, get_device, get_stream, torch.int64, torch.int32, torch.int16)
