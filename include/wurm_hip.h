@@ -328,6 +328,11 @@ typedef struct wurm_multi_call {
     int resident_lazy;                /* != 0: the step does not write foods / heads / bodies; wurm_multi_resident_flush
                                          brings them up to date (before anything else reads or writes them, and before
                                          resident_valid is cleared)                                                     */
+    uint32_t *check_mask;             /* nullable out (N): wurm_multi_check's mask of the post-step state, computed from
+                                         the on-chip image inside the step launch — for an env whose image came from the
+                                         mirror or from a rebuild; 0xffffffff = not computed (the env was read from the
+                                         fp32 tensors, which can hold more than the image: run wurm_multi_check)         */
+    uint32_t *check_mask_after;       /* nullable out (N), with obs_after: the same for the state obs_after observes   */
 } wurm_multi_call;
 
 /* One launch for one iteration of the caller loop of experiments/speeds.py:30-37 / tests/test_multi_snake_env.py:78-89,

@@ -371,6 +371,11 @@ def multi_step_reset(self, st, actions, cfg, mode, call, pre_done=None, pre_call
         if resident.get('buf') is None or resident['buf'].numel() != nbytes:
             resident['buf'], resident['valid'] = self._empty((nbytes,), torch.uint8), 0
         c.resident, c.resident_valid, c.resident_lazy = resident['buf'].data_ptr(), int(resident.get('valid', 0)), int(lazy)
+        masks = self._empty((2, N), torch.int32)
+        masks.fill_(-7)
+        c.check_mask = masks[0].data_ptr()
+        c.check_mask_after = masks[1].data_ptr() if obs_after is not None else None
+        resident['masks'] = masks
     rc = self.lib.wurm_multi_step_reset(ctypes.addressof(c), self._stream())
     _lib.check(rc, 'wurm_multi_step_reset')
     synced = True

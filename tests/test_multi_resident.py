@@ -191,6 +191,147 @@ def test_class_loop_on_the_lazy_mirror_against_the_oracle(cfg_name, mode, shape)
         check_state('final')
 
 
+# ------------------------------------------------------------------ check_consistency inside the step launch
+
+@pytest.mark.parametrize('cfg_name,mode,shape', [('default', 'full', (24, 4, 14, 120)), ('train', 'partial_3', (20, 3, 12, 120)),
+                                                 ('dense', 'full', (20, 3, 12, 100)), ('train', 'full', (6, 10, 36, 40))])
+@pytest.mark.parametrize('reset_obs', [True, False])
+def test_check_consistency_from_the_step_launch(cfg_name, mode, shape, reset_obs):
+    """experiments/speeds.py:30-38 — `step; reset(done['__all__']); check_consistency()` every iteration: the masks come out
+    of the step launch (no pass over the fp32 tensors, the postponed reset stays postponed) and equal the oracle's checker
+    on the oracle's state, env by env"""
+    import torch
+    cfg = CFGS[cfg_name]
+    (N, K, S, T), seed = shape, 31
+    with knobs(WURM_RESIDENT_MIN_ENVS=0):
+        env = _class_env(N, K, S, seed, mode, cfg)
+        o = OracleBackend(seed=seed, env_offset=7)
+        st = _o.multi_empty_state(N, K, S)
+        st['colours'][...] = o.multi_colours(N, K, cfg['colour_mode'] == 'fixed', call=0)
+        o.call = 1
+        assert o.multi_reset(st, np.ones(N), cfg) == 0
+        g = torch.Generator().manual_seed(5)
+        from_launch = 0
+        for t in range(T):
+            a = torch.randint(8, (K, N), generator=g)
+            ac = a.cuda()
+            obs, rew, dones, info = env.step({f'agent_{i}': ac[i] for i in range(K)})
+            r = o.multi_step(st, a.numpy(), cfg, mode)
+            for i in range(K):
+                _same(obs[f'agent_{i}'].cpu().numpy(), r['obs'][i], f'obs {i} t={t}')
+            if reset_obs:
+                env.reset(dones['__all__'])
+                o.multi_reset(st, r['all_done'], cfg, mode=mode)
+            else:
+                env.reset(dones['__all__'], return_observations=False)
+                o.multi_reset(st, r['all_done'], cfg)
+            want = o.multi_check(st).astype(np.int64)
+            m = env._step_check_mask()
+            if m is not None:
+                got = m.cpu().numpy().astype(np.int64)
+                known = got != -1
+                _same(got[known], want[known], f'mask t={t}')
+                from_launch += int(known.all())
+                assert reset_obs or bool((known | (r['all_done'] != 0)).all())
+            launches_before = env._steps
+            if (want == 0).all():
+                env.check_consistency()
+            else:
+                with pytest.raises(RuntimeError):
+                    env.check_consistency()
+            assert env._steps == launches_before
+        # (without the reset observation the launch cannot vouch for envs the postponed reset rebuilds: those iterations
+        # run the checker over the tensors)
+        assert from_launch > (T // 2 if reset_obs else 0), from_launch
+        if reset_obs:
+            assert env._pending            # the checker never forced the postponed reset out
+
+
+def _mirror_views(buf, N, K, S):
+    import torch
+    C = S * S
+    nb, nf = (2 * K * C + 15) // 16 * 16, (C + 15) // 16 * 16
+    per = nb + nf + (12 * K + 15) // 16 * 16
+    m = buf.view(N, per)
+    return m, nb, nf
+
+
+@pytest.mark.parametrize('K,S', [(3, 12), (10, 36)])
+def test_abi_masks_of_a_planted_inconsistent_image_equal_the_checker(hip, K, S):
+    """the dynamics keep every invariant, so non-zero masks are planted: the mirror is edited by hand (an overlap, a hole in
+    a body, food under a head, a segment above the head's value), written out, and stepped — by the oracle from the fp32
+    tensors, by the library from the image; outputs, state and masks must agree"""
+    import torch
+    cfg = CFGS['noboost']
+    N, C = 12, S * S
+    rng = np.random.RandomState(7)
+    o, h = OracleBackend(seed=5, env_offset=3), hip(seed=5, env_offset=3)
+    so = _o.multi_empty_state(N, K, S)
+    so['colours'][...] = o.multi_colours(N, K, cfg['colour_mode'] == 'fixed', call=0)
+    o.call = 1
+    assert o.multi_reset(so, np.ones(N), cfg) == 0
+    sh = {k: v.copy() for k, v in so.items()}
+    mirror = {'valid': 0, 'lazy': True, 'sync': True}
+    seen = 0
+    with knobs(WURM_RESIDENT_MIN_ENVS=0):
+        call = 2
+        for t in range(40):
+            a = rng.randint(0, 4, size=(K, N)).astype(np.int64)
+            if t % 4 == 2:  # plant: edit the image, write it out, adopt what it says as the common state
+                m, nb, nf = _mirror_views(mirror['buf'], N, K, S)
+                body = m[:, :nb].contiguous().view(torch.int16)[:, :K * C].clone().view(N, K, C)
+                food = m[:, nb:nb + C].clone()
+                sc = m[:, nb + nf:nb + nf + 12 * K].contiguous().view(torch.int32).view(N, 3, K)
+                tclk, hc = sc[:, 0], sc[:, 1]
+                for e in range(N):
+                    kind = (e + t) % 4
+                    s0 = int(rng.randint(K))
+                    live = (body[e, s0].to(torch.int32) > tclk[e, s0]) & (tclk[e, s0] < 0x7000)
+                    cells = torch.nonzero(live).flatten()
+                    if len(cells) < 3:
+                        continue
+                    order = torch.argsort(body[e, s0][cells].to(torch.int32))
+                    mid = int(cells[order[len(cells) // 2]])            # a middle segment: still there after the next decay
+                    if kind == 0 and K > 1:      # overlap: another living snake gets a segment on that cell
+                        s1 = (s0 + 1) % K
+                        if int(tclk[e, s1]) < 0x7000:
+                            body[e, s1, mid] = int(tclk[e, s1]) + 3
+                    elif kind == 1:              # a hole in the body
+                        body[e, s0, mid] = 0
+                    elif kind == 2:              # a middle segment larger than the head's: the head is not at the end
+                        Ls = sc[:, 2]
+                        body[e, s0, mid] = int(tclk[e, s0]) + int(Ls[e, s0]) + 2
+                        Ls[e, s0] += 2           # (the image's length slot is the largest body value, as load_env derives it)
+                m[:, :nb].view(torch.int16)[:, :K * C] = body.view(N, K * C)
+                m[:, nb:nb + C] = food
+                m[:, nb + nf:nb + nf + 12 * K] = sc.contiguous().view(N, 3 * K).view(torch.uint8).view(N, 12 * K)
+                # write the edited image out through the library and take it as the state of both sides
+                import ctypes
+                from wurm_amd import _lib
+                blk = _lib.MultiCall()
+                d = mirror['dev']
+                blk.foods, blk.heads, blk.bodies = d['foods'].data_ptr(), d['heads'].data_ptr(), d['bodies'].data_ptr()
+                blk.num_envs, blk.num_snakes, blk.size = N, K, S
+                blk.resident, blk.resident_valid, blk.resident_lazy = mirror['buf'].data_ptr(), 1, 1
+                _lib.check(h.lib.wurm_multi_resident_flush(ctypes.addressof(blk), h._stream()), 'flush')
+                torch.cuda.synchronize()
+                for k in ('foods', 'heads', 'bodies'):
+                    sh[k][...] = d[k].cpu().numpy()
+                    so[k][...] = sh[k]
+            o.call = call
+            ro = o.multi_step(so, a, cfg, 'full')
+            rh = h.multi_step_reset(sh, a, cfg, 'full', call=call, resident=mirror)
+            _same_state(so, sh, f'state t={t}')
+            for k in ro:
+                _same(ro[k], rh[k], f'{k} t={t}')
+            want = o.multi_check(so).astype(np.int64)
+            got = mirror['masks'][0].cpu().numpy().astype(np.int64)
+            _same(got, want, f'mask t={t}')   # (t = 0: read from fp32 planes that hold nothing the image cannot)
+            seen += int((want != 0).sum())
+            call += 2
+    assert seen > 0
+
+
 def test_long_lived_snakes_cross_the_clock_rebase():
     """a small WURM_MULTI_CLOCK_REBASE cannot be set at run time, so the snakes are kept alive long enough instead: two
     snakes circling for 0x3000 + steps would take too long — the record's clocks are moved forward by hand"""

@@ -79,7 +79,8 @@ class MultiCall(ctypes.Structure):
         ('num_envs', ctypes.c_int64), ('env_offset', ctypes.c_int64), ('seed', ctypes.c_uint64),
         ('call', ctypes.c_uint64), ('pre_call', ctypes.c_uint64), ('num_snakes', ctypes.c_int), ('size', ctypes.c_int),
         ('obs_mode', ctypes.c_int), ('obs_n', ctypes.c_int), ('cfg', MultiConfig), ('resident', ctypes.c_void_p),
-        ('resident_valid', ctypes.c_int), ('resident_lazy', ctypes.c_int)]
+        ('resident_valid', ctypes.c_int), ('resident_lazy', ctypes.c_int), ('check_mask', ctypes.c_void_p),
+        ('check_mask_after', ctypes.c_void_p)]
 
 
 def multi_config(num_snakes, boost, food_on_death_prob, boost_cost_prob, food_mode, food_rate, reward_on_death,

@@ -60,6 +60,7 @@ struct MultiArgs {
     wurm_multi_reset_inject rinj;
     int has_rinj;
     uint32_t *err;
+    uint32_t *err_after;  // step kernels: the mask of the state reset_for_obs_after leaves (with obs_after), nullable
     float *am_f32;
     uint8_t *am_u8;
     long long T;          // rollout: number of fused step+reset iterations
@@ -127,10 +128,14 @@ __device__ __forceinline__ int BV(const Ctx &cx, int s, int c)
 // alone with its latency at 16 waves/CU: few large batches of loads, not many small ones).
 constexpr int LOAD_CHUNK = 16;
 
+// plain (nullable out, wave-uniform): the planes held nothing the LDS image cannot represent — food and head values 0 / 1,
+// at most one head per snake, body values integers in 0 .. 0x7fff — so lds_check sees all there is to check.
 __device__ __forceinline__ u64 load_env(const Ctx &cx, const float *__restrict__ foodp,
-                                        const float *__restrict__ headp, const float *__restrict__ bodyp)
+                                        const float *__restrict__ headp, const float *__restrict__ bodyp,
+                                        bool *plain = nullptr)
 {
     const int C = cx.C, lane = cx.lane, KC = cx.K * C;
+    int odd = 0, nheads = 0;
     if (lane < cx.K) {
         cx.hcell[lane] = -1;
         cx.lmax[lane] = 0;
@@ -155,6 +160,8 @@ __device__ __forceinline__ u64 load_env(const Ctx &cx, const float *__restrict__
             if (i < KC) {
                 const int bi = __float2int_rn(bv[j]);
                 cx.body[i] = (unsigned short)(bi != 0 ? ((bi & VMASK) | DIRTY) : 0);
+                odd |= (int)((hv[j] != 0.0f && hv[j] != 1.0f) || bv[j] != (float)bi || bi < 0 || bi > (int)VMASK);
+                nheads += (int)(hv[j] > 0.5f);
                 if (hv[j] > 0.5f || bi > 0) { // rare: a head cell or a body cell
                     const int s = div_size(i, rcpC);
                     if (hv[j] > 0.5f) cx.hcell[s] = i - s * C;
@@ -177,10 +184,13 @@ __device__ __forceinline__ u64 load_env(const Ctx &cx, const float *__restrict__
                 const int f = fv[j] > 0.5f;
                 cx.food[c] = (unsigned char)f;
                 fbits |= (u64)f << (k0 + j);
+                odd |= (int)(fv[j] != 0.0f && fv[j] != 1.0f);
             }
         }
     }
     wave_lds_sync();
+    if (plain) // as many heads as snakes that have one <=> nobody has two
+        *plain = ballot(odd != 0) == 0 && wave_sum_i32(nheads) == popc64(ballot(lane < cx.K && cx.hcell[lane] >= 0));
     return fbits;
 }
 
@@ -902,6 +912,69 @@ __device__ __forceinline__ void multi_reset_grid(const Ctx &cx, const MultiArgs 
                                                  bool rebuild, bool respawn, Snake &sn, bool &orient_dirty,
                                                  long long offA, long long offE);
 
+// check_consistency (:733-769) of the env as it sits in LDS — the masks of multi_check_kernel, for an image that came from
+// the mirror or from a rebuild (16-bit clocks, one head cell per snake, food bytes 0 / 1: what the fp32 planes could
+// additionally hold — several heads, fractional values — cannot occur there).  ONE wave; sn = the snakes' scalars.
+__device__ __forceinline__ uint32_t lds_check(const Ctx &cx, const Snake &sn)
+{
+    const int C = cx.C, K = cx.K, lane = cx.lane;
+    // lane l owns cells 8 l .. 8 l + 7 of every run of 512: one 16-byte LDS read per run and snake.  The body grids start
+    // on a 16-byte boundary (multi_layout) and snake s's at 2 s C bytes behind it: aligned for every s only if C is a
+    // multiple of 8 — else the cells are read one by one
+    const int runs = (C + 511) >> 9;
+    const bool wide = (C & 7) == 0;
+    uint32_t m = 0;
+    u64 occ = 0; // bit 8 r + j: cell 512 r + 8 lane + j holds a body value of a snake seen so far (runs <= 8: C <= 4096)
+    int over = 0;
+    for (int s = 0; s < K; ++s) {
+        const int T = cx.tclk[s], hc = lane_value(sn.hc, s);
+        const bool dead = lane_value((int)sn.done, s) != 0;
+        const unsigned short *b = cx.body + s * C;
+        int bs = 0, bm = 0;
+        for (int r = 0; r < runs; ++r) {
+            const int c0 = 512 * r + 8 * lane;
+            u32 w[4] = {0, 0, 0, 0};
+            if (wide) {
+                if (c0 < C) {
+                    const uint4 q = *(const uint4 *)(b + c0);
+                    w[0] = q.x; w[1] = q.y; w[2] = q.z; w[3] = q.w;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (c0 + j < C) w[j >> 1] |= (u32)b[c0 + j] << (16 * (j & 1));
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int v = max((int)((w[j >> 1] >> (16 * (j & 1))) & VMASK) - T, 0);
+                bs += v;
+                bm = max(bm, v);
+                const u64 bit = 1ull << (8 * r + j);
+                if (v > 0) {
+                    over |= (int)((occ & bit) != 0);
+                    occ |= bit;
+                }
+            }
+        }
+        const int t_bs = wave_sum_i32(bs), t_bm = wave_max_i32(bm);
+        if (dead) {
+            if (t_bs > 0 || hc >= 0) m |= WURM_MCHK_DEAD_NONZERO;
+        } else {
+            const int t_hb = hc >= 0 ? BV(cx, s, hc) : 0, t_hf = hc >= 0 ? (int)cx.food[hc] : 0;
+            if (hc < 0) m |= WURM_CHK_ONE_HEAD;
+            if (!(t_bs > 0)) m |= WURM_CHK_HAS_SNAKE;
+            if (t_bm != t_hb) m |= WURM_CHK_HEAD_AT_END;
+            if (2 * t_bs != t_bm * (t_bm + 1)) m |= WURM_CHK_BODY_RANGE;
+            if (!(t_bs >= 6)) m |= WURM_CHK_MIN_LENGTH;
+            if (t_hf != 0) m |= WURM_CHK_HEAD_ON_FOOD;
+        }
+    }
+    if (ballot(over != 0)) m |= WURM_MCHK_OVERLAP;
+    return m;
+}
+
+constexpr uint32_t MCHK_NOT_COMPUTED = 0xffffffffu; // read from fp32 planes that hold what the image cannot: run multi_check_kernel
+
 // The part of the per-call step between the load and the store of the env (LDS state ready, hcell / lmax / tclk set):
 // [the reset(done) the caller postponed, exactly multi_reset_kernel without observation, with its own counter,] the
 // transition, and the per-agent outputs.  Runs on ONE wave.  hc0: the head cells HBM holds (sparse write-back).
@@ -966,7 +1039,8 @@ __device__ __forceinline__ void step_middle(const Ctx &cx, const MultiArgs &p, l
 
 // What reset(dones['__all__']) will do (multi_reset_kernel with done_env = all_done, call + 1), applied to the LDS copy
 // only: the caller postpones that reset into the next launch, which recreates it from the same counters.  ONE wave.
-__device__ __forceinline__ void reset_for_obs_after(const Ctx &cx, const MultiArgs &p, long long env, Snake &sn,
+// Returns whether the env was rebuilt or a snake respawned (else the grids are as the step left them).
+__device__ __forceinline__ bool reset_for_obs_after(const Ctx &cx, const MultiArgs &p, long long env, Snake &sn,
                                                     const StepRes &r)
 {
     const bool snake = cx.lane < cx.K;
@@ -981,6 +1055,7 @@ __device__ __forceinline__ void reset_for_obs_after(const Ctx &cx, const MultiAr
         bool orient_dirty = false;
         multi_reset_grid(cx, p, env, env_id, p.call + 1ull, rebuild_after, respawn_after, sn, orient_dirty, 0, 0);
     }
+    return rebuild_after || respawn_after;
 }
 
 __global__ __launch_bounds__(256) void multi_step_kernel(MultiArgs p)
@@ -1001,8 +1076,10 @@ __global__ __launch_bounds__(256) void multi_step_kernel(MultiArgs p)
     unsigned char *mp = mirrored ? p.resident + env * mirror_env_bytes(K, C) : nullptr;
     auto fence = [] { wave_lds_sync(); };
     u64 fbits0 = 0;
+    bool plain = false; // read from the fp32 planes, which held nothing the image cannot represent
     if (!rebuild) {
-        fbits0 = from_mirror ? mirror_load(cx, mp, lane, 64, fence) : load_env(cx, foodp, headp, bodyp);
+        fbits0 = from_mirror ? mirror_load(cx, mp, lane, 64, fence)
+                             : load_env(cx, foodp, headp, bodyp, p.err != nullptr ? &plain : nullptr);
     } else {
         if (snake) { cx.hcell[lane] = -1; cx.lmax[lane] = 0; cx.tclk[lane] = 0; } // the rest: multi_reset_grid(rebuild)
         wave_lds_sync();
@@ -1012,6 +1089,12 @@ __global__ __launch_bounds__(256) void multi_step_kernel(MultiArgs p)
     StepRes r;
     int hc0;
     step_middle(cx, p, env, rebuild, sn, r, hc0);
+    const bool clean = from_mirror || rebuild || plain; // lds_check sees everything there is to check
+    uint32_t m_step = MCHK_NOT_COMPUTED;
+    if (p.err != nullptr) {
+        if (clean) m_step = lds_check(cx, sn);
+        if (lane == 0) p.err[env] = m_step;
+    }
     if (!lazy) {
         if (from_mirror) { // (step_middle has read the lengths out of lmax)
             if (snake) cx.lmax[lane] = t0;
@@ -1027,7 +1110,11 @@ __global__ __launch_bounds__(256) void multi_step_kernel(MultiArgs p)
     }
     if (p.obs_mode != WURM_OBS_NONE) observe(cx, p, p.obs, env, sn);
     if (p.obs_after == nullptr || p.obs_mode == WURM_OBS_NONE) return;
-    reset_for_obs_after(cx, p, env, sn, r);
+    const bool touched = reset_for_obs_after(cx, p, env, sn, r);
+    if (p.err_after != nullptr) {
+        if (touched) m_step = clean ? lds_check(cx, sn) : MCHK_NOT_COMPUTED; // (else: the state the first mask describes)
+        if (lane == 0) p.err_after[env] = m_step;
+    }
     observe(cx, p, p.obs_after, env, sn);
 }
 
@@ -1036,10 +1123,12 @@ __global__ __launch_bounds__(256) void multi_step_kernel(MultiArgs p)
 // stores.  Here the four waves of a workgroup share ONE env: all of them copy it in, turn it into class codes and write
 // it back (flat over the K * S * S cells; the K agents' observations go out one agent per wave), wave 0 alone runs the
 // transition in between.  Same LDS layout, same device functions for everything that is not a plain copy.
+// plain: as load_env's (nullable out, the same in every thread)
 __device__ __forceinline__ u64 wg_load_env(const Ctx &cx, const float *__restrict__ foodp, const float *__restrict__ headp,
-                                           const float *__restrict__ bodyp, int tid, int nth)
+                                           const float *__restrict__ bodyp, int tid, int nth, bool *plain = nullptr)
 {
     const int C = cx.C, KC = cx.K * C;
+    int odd = 0, nheads = 0;
     if (tid < cx.K) {
         cx.hcell[tid] = -1;
         cx.lmax[tid] = 0;
@@ -1063,6 +1152,8 @@ __device__ __forceinline__ u64 wg_load_env(const Ctx &cx, const float *__restric
             if (i < KC) {
                 const int bi = __float2int_rn(bv[j]);
                 cx.body[i] = (unsigned short)(bi != 0 ? ((bi & VMASK) | DIRTY) : 0);
+                odd |= (int)((hv[j] != 0.0f && hv[j] != 1.0f) || bv[j] != (float)bi || bi < 0 || bi > (int)VMASK);
+                nheads += (int)(hv[j] > 0.5f);
                 if (hv[j] > 0.5f || bi > 0) { // rare: a head cell or a body cell
                     const int s = div_size(i, rcpC);
                     if (hv[j] > 0.5f) cx.hcell[s] = i - s * C;
@@ -1073,9 +1164,22 @@ __device__ __forceinline__ u64 wg_load_env(const Ctx &cx, const float *__restric
     }
     u64 fbits = 0; // bit k: food at cell tid + nth * k
     for (int k = 0, c = tid; c < C; ++k, c += nth) {
-        const int f = foodp[c] > 0.5f;
+        const float fv = foodp[c];
+        const int f = fv > 0.5f;
         cx.food[c] = (unsigned char)f;
         fbits |= (u64)f << k;
+        odd |= (int)(fv != 0.0f && fv != 1.0f);
+    }
+    if (plain) { // (the colour slots are free until step_middle loads them: a counter for the heads seen by all threads)
+        int *cnt = (int *)cx.colf;
+        if (tid == 0) *cnt = 0;
+        __syncthreads();
+        if (nheads) atomicAdd(cnt, nheads);
+        const int any_odd = __syncthreads_or(odd);
+        int with_head = 0;
+        for (int s2 = 0; s2 < cx.K; ++s2) with_head += (int)(cx.hcell[s2] >= 0);
+        *plain = !any_odd && *cnt == with_head;
+        __syncthreads();
     }
     return fbits;
 }
@@ -1142,7 +1246,9 @@ __global__ __launch_bounds__(256) void multi_step_wg_kernel(MultiArgs p)
     unsigned char *mp = mirrored ? p.resident + env * mirror_env_bytes(K, C) : nullptr;
     auto barrier = [] { __syncthreads(); };
     u64 fbits0 = 0;
-    if (!rebuild) fbits0 = from_mirror ? mirror_load(cx, mp, tid, nth, barrier) : wg_load_env(cx, foodp, headp, bodyp, tid, nth);
+    bool plain = false;
+    if (!rebuild) fbits0 = from_mirror ? mirror_load(cx, mp, tid, nth, barrier)
+                                       : wg_load_env(cx, foodp, headp, bodyp, tid, nth, p.err != nullptr ? &plain : nullptr);
     else if (tid < K) { cx.hcell[tid] = -1; cx.lmax[tid] = 0; cx.tclk[tid] = 0; }
     __syncthreads();
     const int t0 = tid < K ? cx.tclk[tid] : 0;
@@ -1150,6 +1256,12 @@ __global__ __launch_bounds__(256) void multi_step_wg_kernel(MultiArgs p)
     StepRes r;
     int hc0 = -1;
     if (wave == 0) step_middle(cx, p, env, rebuild, sn, r, hc0);
+    const bool clean = from_mirror || rebuild || plain;
+    uint32_t m_step = MCHK_NOT_COMPUTED;
+    if (wave == 0 && p.err != nullptr) {
+        if (clean) m_step = lds_check(cx, sn);
+        if (lane == 0) p.err[env] = m_step;
+    }
     __syncthreads();
     if (!lazy) {
         if (from_mirror) {
@@ -1177,7 +1289,13 @@ __global__ __launch_bounds__(256) void multi_step_wg_kernel(MultiArgs p)
     if (p.obs_mode == WURM_OBS_NONE) return;
     wg_observe_snap(cx, p, p.obs, env, tid, nth, wave);
     if (p.obs_after == nullptr) return;
-    if (wave == 0) reset_for_obs_after(cx, p, env, sn, r);
+    if (wave == 0) {
+        const bool touched = reset_for_obs_after(cx, p, env, sn, r);
+        if (p.err_after != nullptr) {
+            if (touched) m_step = clean ? lds_check(cx, sn) : MCHK_NOT_COMPUTED;
+            if (lane == 0) p.err_after[env] = m_step;
+        }
+    }
     __syncthreads();
     wg_observe_snap(cx, p, p.obs_after, env, tid, nth, wave);
 }
@@ -1959,6 +2077,8 @@ int wurm_multi_step_reset(const wurm_multi_call *c, void *stream)
     if (c->inject) { p.inj = *c->inject; p.has_inj = 1; }
     if (c->pre_inject) { p.rinj = *c->pre_inject; p.has_rinj = 1; }
     if (c->agent_major_f32 && c->agent_major_u8) { p.am_f32 = c->agent_major_f32; p.am_u8 = c->agent_major_u8; }
+    p.err = c->check_mask;
+    p.err_after = c->check_mask_after;
     if (c->resident && c->num_envs > 0) {
         if (!c->inject && !c->pre_inject) {
             p.resident = (unsigned char *)c->resident;

@@ -63,6 +63,7 @@ class _Flushing(object):
         if obj._pending:
             obj._flush()
         obj._obs_after = None  # the caller may edit what it gets: reset(done) then observes again instead of reusing it
+        obj._chk_fresh = False  # ... and the consistency mask the step launch computed no longer describes the state
         t = getattr(obj, self.slot)
         if self.slot in _MIRRORED:
             obj._escape(t)     # the caller holds a state tensor from now on (resident mirror: written out, watched)
@@ -74,6 +75,7 @@ class _Flushing(object):
         if self.slot in _MIRRORED:
             obj._touch()   # (a lazy mirror is written out to the tensors as they are before one of them is replaced)
         obj._last_fresh = False
+        obj._chk_fresh = False
         obj._state_dirty = True  # step() re-validates the layout and re-reads the pointers
         setattr(obj, self.slot, value)
         if self.slot in _MIRRORED:
@@ -95,6 +97,9 @@ class MultiSnake(object):
     _lazy_mirror = os.environ.get('WURM_RESIDENT_LAZY', '1') != '0'
     _watched = ()           # (tensor, version) of state tensors the caller holds: in-place edits make the mirror stale
     _write_outs = _touches = _steps = 0
+    _chk = None             # (2, N) int32: check_consistency's masks of the post-step / post-reset state, from the step launch
+    _chk_fresh = _chk_has_after = False
+    _check_calls = _check_step = 0
     _out_f = _out_b = _rewards_t = _boost_t = _mc_mode = _obs_after = None
     _want_after = False
     foods = _Flushing('foods')
@@ -294,6 +299,7 @@ class MultiSnake(object):
     def _touch(self):
         """something other than the step launch is about to read or write the state tensors"""
         self._write_out()
+        self._chk_fresh = False
         c = self._mc
         if c is not None:
             if c.resident and c.resident_valid:
@@ -310,6 +316,7 @@ class MultiSnake(object):
         """The caller holds the state tensor `t` from now on: it is brought up to date, written by every step (no lazy form
         any more) and watched for in-place edits through its version counter; without one (inference tensors) no mirror."""
         self._write_out()
+        self._chk_fresh = False
         if self._mc is not None:
             self._mc.resident_lazy = 0
         self._lazy_mirror = False
@@ -511,7 +518,15 @@ class MultiSnake(object):
                     self._mirror = torch.empty(nbytes, dtype=torch.uint8, device=dev)
                     c.resident, c.resident_valid = self._mirror.data_ptr(), 0
                     c.resident_lazy = int(self._lazy_mirror and not self._watched)
+                    # check_consistency()'s masks can come out of the step launch (the image it steps is its own): asked for
+                    # once the caller has called check_consistency(), dropped again if it stops doing so
+                    self._chk = torch.empty((2, N), dtype=torch.int32, device=dev)
             self._steps += 1
+            if self._chk is not None:
+                want = self._check_calls > 0 and self._steps - self._check_step <= 64
+                if want != bool(c.check_mask):
+                    c.check_mask = self._chk[0].data_ptr() if want else None
+                    c.check_mask_after = self._chk[1].data_ptr() if want else None
             if self._watched:
                 self._watch_ok()
             if self._state_dirty:
@@ -550,6 +565,8 @@ class MultiSnake(object):
 
         self._out_f, self._out_b = of, ob          # env.rewards / env.boost_this_step are views of these, made on demand
         self._obs_after = after
+        self._chk_fresh = bool(c.resident) and bool(c.check_mask)
+        self._chk_has_after = after is not None
         self._rewards_t = self._boost_t = None
 
         # reference :701-729 — per-agent dicts; the kernel wrote agent-major rows, so these are plain views
@@ -628,20 +645,44 @@ class MultiSnake(object):
     # ------------------------------------------------------------------ invariants
 
     def check_consistency(self):
-        """reference :733-769: raises RuntimeError if any env is inconsistent"""
-        foods, heads, bodies, dones, _, _, _ = self._state(write=False)
-        err = torch.empty(self.num_envs, dtype=torch.int32, device=self.device)
-        rc = _lib.call(self.device.index, _lib.lib().wurm_multi_check, _lib.ptr(foods), _lib.ptr(heads), _lib.ptr(bodies), _lib.ptr(dones),
-                                         _lib.ptr(err), _lib.i64(self.num_envs), self.num_snakes, self.size,
-                                         _lib.stream_ptr(self.device.index))
-        _lib.check(rc, 'MultiSnake.check_consistency')
+        """reference :733-769: raises RuntimeError if any env is inconsistent.  Right after a step (and the deferred reset
+        of its own `dones['__all__']`) on the resident mirror the masks come from that step's launch; anything else — the
+        state read from the fp32 tensors, looked at or edited since — runs the checker over the tensors."""
         from wurm_amd.utils import _raise_for, _or_reduce
+        self._check_calls += 1
+        self._check_step = self._steps
+        err = self._step_check_mask()
+        if err is not None:
+            if not bool(err.any()):
+                return
+            if bool((err == -1).any()):  # an env whose mask the launch could not vouch for
+                err = None
+        if err is None:
+            foods, heads, bodies, dones, _, _, _ = self._state(write=False)
+            err = torch.empty(self.num_envs, dtype=torch.int32, device=self.device)
+            rc = _lib.call(self.device.index, _lib.lib().wurm_multi_check, _lib.ptr(foods), _lib.ptr(heads), _lib.ptr(bodies),
+                           _lib.ptr(dones), _lib.ptr(err), _lib.i64(self.num_envs), self.num_snakes, self.size,
+                           _lib.stream_ptr(self.device.index))
+            _lib.check(rc, 'MultiSnake.check_consistency')
         mask = _or_reduce(err, 10)
         _raise_for(mask & 0x7f, one_food=False)
         if mask & 0x100:
             raise RuntimeError('An environment contains overlapping snakes')
         if mask & 0x200:
             raise RuntimeError('Dead snake contains non-zero elements.')
+
+    def _step_check_mask(self):
+        """(N) int32 masks of the state as it is now, computed inside the last step's launch (wurm_multi_call.check_mask /
+        check_mask_after), or None if they do not apply; -1 marks an env the launch could not vouch for"""
+        c = self._mc
+        if not self._chk_fresh or c is None or not c.resident or not c.resident_valid:
+            return None
+        if not self._pending:
+            return self._chk[0]
+        if self._chk_has_after:       # the postponed reset of the step's own mask: what obs_after observed
+            return self._chk[1]
+        # postponed, but the launch did not build that state: envs the reset rebuilds are not vouched for
+        return self._chk[0].masked_fill(self._pend != 0, -1)
 
     # ------------------------------------------------------------------ reset
 
