@@ -419,11 +419,20 @@ def fuzz_multi_resident(rng):
                     same(so[k], sh[k], f'{desc} state {k} t={t}')
             for k in ro:
                 same(ro[k], rh[k], f'{desc} {k} t={t}')
+            # check_consistency's mask out of the step launch (wurm_multi_call.check_mask): where it vouches, the checker's
+            got = mirror['masks'][0].cpu().numpy().astype(np.int64)
+            want_m = np.asarray(o.multi_check(so)).astype(np.int64)
+            known = got != -1
+            same(got[known], want_m[known], f'{desc} check_mask t={t}')
             if 'obs_after' in rh:
                 tmp = {k: v.copy() for k, v in so.items()}
                 o.call = call + 1
                 o.multi_reset(tmp, ro['all_done'], cfg, mode=mode)
                 same(o.last_reset_obs, rh['obs_after'], f'{desc} obs_after t={t}')
+                got = mirror['masks'][1].cpu().numpy().astype(np.int64)
+                want_m = np.asarray(o.multi_check(tmp)).astype(np.int64)
+                known = got != -1
+                same(got[known], want_m[known], f'{desc} check_mask_after t={t}')
             u = rng.rand()
             if u < 0.15:
                 prev = None
