@@ -92,3 +92,39 @@ def test_obs_mode_parsing():
     assert _lib.parse_obs_mode('default') == (_lib.OBS_DEFAULT, 0)
     with pytest.raises(ValueError):
         _lib.parse_obs_mode('bogus')
+
+
+def test_resident_mirror_sizes(monkeypatch):
+    """wurm_single_resident_bytes / wurm_multi_resident_bytes (host arithmetic only): which shapes are offered the mirror
+    of the per-call step, from which batch size, and how large it is"""
+    l = _lib.lib()
+    monkeypatch.delenv('WURM_RESIDENT_MIN_ENVS', raising=False)
+    part2, none, default = (_lib.OBS_PARTIAL, 2), (_lib.OBS_NONE, 0), (_lib.OBS_DEFAULT, 0)
+    assert l.wurm_single_resident_bytes(65536, 9, *part2) == 65536 * 32          # 9 x 9: 32 bytes per env
+    assert l.wurm_single_resident_bytes(4096, 9, *none) == 4096 * 32
+    assert l.wurm_single_resident_bytes(4095, 9, *part2) == 0                    # latency-bound anyway
+    assert l.wurm_single_resident_bytes(65536, 9, _lib.OBS_PARTIAL, 3) == 0      # other crops: not served
+    assert l.wurm_single_resident_bytes(65536, 10, *part2) == 0 and l.wurm_single_resident_bytes(65536, 11, *part2) == 0
+    # 12 x 12 and larger: the 16-bit clock grid (runs of 256 cells) + 48 bytes, every observation mode, from 2^20 cells on
+    assert l.wurm_single_resident_bytes(8192, 36, *default) == 8192 * (6 * 512 + 48)
+    assert l.wurm_single_resident_bytes(8192, 12, *default) == 8192 * (1 * 512 + 48)
+    assert l.wurm_single_resident_bytes(7000, 12, *default) == 0
+    assert l.wurm_single_resident_bytes(300, 64, _lib.OBS_PARTIAL, 6) == 300 * (16 * 512 + 48)
+    assert l.wurm_single_resident_bytes(1 << 20, 65, *default) == 0
+    # MultiSnake: K grids of 16-bit clocks, the food bytes, three ints per snake, each part padded to 16 bytes
+    K, S = 4, 25
+    per = (2 * K * S * S + 15) // 16 * 16 + (S * S + 15) // 16 * 16 + (12 * K + 15) // 16 * 16
+    assert l.wurm_multi_resident_bytes(4096, K, S) == 4096 * per
+    assert l.wurm_multi_resident_bytes(100, K, S) == 0
+    assert l.wurm_multi_resident_bytes(4096, 65, S) == 0 and l.wurm_multi_resident_bytes(4096, K, 4) == 0
+    monkeypatch.setenv('WURM_RESIDENT_MIN_ENVS', '0')                            # tests / tuning: a number of envs instead
+    assert l.wurm_single_resident_bytes(3, 9, *part2) == 96 and l.wurm_single_resident_bytes(3, 12, *default) == 3 * 560
+    assert l.wurm_multi_resident_bytes(2, K, S) == 2 * per
+    monkeypatch.setenv('WURM_RESIDENT_MIN_ENVS', '1000000000')
+    assert l.wurm_single_resident_bytes(65536, 9, *part2) == 0 and l.wurm_multi_resident_bytes(4096, K, S) == 0
+    # no-op flushes need no device
+    assert l.wurm_single_resident_flush(None, None) == _lib.ERR_INVALID_ARG
+    c = _lib.SingleCall()
+    assert l.wurm_single_resident_flush(ctypes.addressof(c), None) == _lib.OK
+    m = _lib.MultiCall()
+    assert l.wurm_multi_resident_flush(ctypes.addressof(m), None) == _lib.OK
