@@ -68,8 +68,8 @@ detail = {
     'fused_step_65536x9_partial2': traffic('void wurm::fused_step_kernel<2, true>', 4194304),
     'lane_step_65536x9_partial2': traffic('void wurm::lane_step_kernel<16, 9>', 262144),
     # the per-call step on the resident mirror (lane_resident.hpp, lazy form): without / with the reset observation
-    'resident_step_8192x9_partial2': traffic('void wurm::lane_resident_step_kernel<32, 1, 4, true>', 16384),
-    'resident_step_65536x9_partial2': traffic('void wurm::lane_resident_step_kernel<64, 1, 4, true>', 65536),
+    'resident_step_8192x9_partial2': traffic('void wurm::lane_resident_step_kernel<16, 1, 4, true>', 32768),
+    'resident_step_65536x9_partial2': traffic('void wurm::lane_resident_step_kernel<32, 1, 4, true>', 131072),
     'resident_step_65536x9_partial2_reset_obs': traffic('void wurm::lane_resident_step_kernel<32, 2, 4, true>', 131072),
     # dispatch order of multi_step_kernel at this grid: 20 launches of cfg4', 20 of cfg4 (both on the resident mirror, lazy),
     # 20 of cfg4 with the mirror switched off; the second ten of each

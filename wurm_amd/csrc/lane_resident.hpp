@@ -466,7 +466,9 @@ static hipError_t launch_lane_resident_form(const StepArgs &p, void *resident, b
     // envs per wave (0 = automatic; WURM_RESIDENT_EPW forces it, read per launch: tests and the tuning sweep)
     int epw = 0;
     if (const char *e = getenv("WURM_RESIDENT_EPW")) epw = atoi(e);
-    if (epw != 16 && epw != 32 && epw != 64) epw = p.N >= 32768 ? 64 / nw : (p.N >= 8192 ? 32 / nw : 16);
+    // measured (rocprofv3, us per launch at 16 / 32 / 64 envs per wave): 65 536 envs 8.5 / 7.3 / 7.6 without and 11.3 / 11.1 / -
+    // with the reset observation; 32 768 envs 6.3 / 5.9 / 6.3 and 7.6 / 8.4 / -
+    if (epw != 16 && epw != 32 && epw != 64) epw = nw == 1 ? (p.N >= 16384 ? 32 : 16) : (p.N >= 49152 ? 32 : 16);
     if (epw * nw > 64) epw = 32;
     auto go = [&](auto kernel, int e) {
         const long long waves = (p.N + e - 1) / e;
