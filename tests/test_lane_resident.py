@@ -425,6 +425,33 @@ def test_host_loop_grid_mirror_matches_the_path_without(mode):
             assert torch.equal(u, v), (i, j)
 
 
+def test_a_write_that_bypasses_the_version_counter_is_the_one_documented_deviation():
+    """DESIGN.md §5 deviation 11: an in-place write through `tensor.data` (its own version counter), a raw pointer or a DLPack
+    consumer between two steps is not seen by the mirror; the same write through the tensor itself is, and without the
+    mirror (WURM_RESIDENT_MIN_ENVS=1000000000) there is nothing to see"""
+    import torch
+    N, seed = 128, 3
+    a = torch.zeros(N, dtype=torch.long, device='cuda:0')
+
+    def run(min_envs, bypass):
+        with knobs(WURM_RESIDENT_MIN_ENVS=min_envs):
+            env = _make(N, 'partial_2', seed=seed)
+            env.step(a.clone())
+            e = env.envs
+            env.step(a.clone())
+            if bypass:
+                e.data[:, 0] = 0          # every food disappears behind the version counter's back
+            else:
+                e[:, 0] = 0
+            return env.step(a.clone())[0].clone(), env.envs[:, 0].sum().item()
+
+    ref_obs, ref_food = run(10 ** 9, True)            # no mirror: the edit is the state
+    seen_obs, seen_food = run(0, False)               # mirror, edit through the tensor: found by the version counter
+    assert torch.equal(seen_obs, ref_obs) and seen_food == ref_food
+    miss_obs, _ = run(0, True)                        # mirror, edit behind the counter: the step still shows the food
+    assert not torch.equal(miss_obs, ref_obs)
+
+
 @pytest.mark.parametrize('N', [4096, 40000])
 def test_at_the_natural_threshold(N):
     """as shipped (mirror from 4096 envs): the oracle follows single envs of the batch by their global id"""
