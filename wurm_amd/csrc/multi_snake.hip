@@ -915,62 +915,99 @@ __device__ __forceinline__ void multi_reset_grid(const Ctx &cx, const MultiArgs 
 // check_consistency (:733-769) of the env as it sits in LDS — the masks of multi_check_kernel, for an image that came from
 // the mirror or from a rebuild (16-bit clocks, one head cell per snake, food bytes 0 / 1: what the fp32 planes could
 // additionally hold — several heads, fractional values — cannot occur there).  ONE wave; sn = the snakes' scalars.
-__device__ __forceinline__ uint32_t lds_check(const Ctx &cx, const Snake &sn)
+// one snake's share: its verdict bits; occ / over collect the overlap test (bit 8 r + j of a lane's occ: cell
+// 512 r + 8 lane + j holds a body value of a snake seen so far; at most 8 runs: C <= 4096)
+__device__ __forceinline__ uint32_t lds_check_snake(const Ctx &cx, int s, int hc, bool dead, u64 &occ, int &over)
 {
-    const int C = cx.C, K = cx.K, lane = cx.lane;
+    const int C = cx.C, lane = cx.lane;
     // lane l owns cells 8 l .. 8 l + 7 of every run of 512: one 16-byte LDS read per run and snake.  The body grids start
     // on a 16-byte boundary (multi_layout) and snake s's at 2 s C bytes behind it: aligned for every s only if C is a
     // multiple of 8 — else the cells are read one by one
     const int runs = (C + 511) >> 9;
     const bool wide = (C & 7) == 0;
+    const int T = cx.tclk[s];
+    const unsigned short *b = cx.body + s * C;
     uint32_t m = 0;
-    u64 occ = 0; // bit 8 r + j: cell 512 r + 8 lane + j holds a body value of a snake seen so far (runs <= 8: C <= 4096)
-    int over = 0;
-    for (int s = 0; s < K; ++s) {
-        const int T = cx.tclk[s], hc = lane_value(sn.hc, s);
-        const bool dead = lane_value((int)sn.done, s) != 0;
-        const unsigned short *b = cx.body + s * C;
-        int bs = 0, bm = 0;
-        for (int r = 0; r < runs; ++r) {
-            const int c0 = 512 * r + 8 * lane;
-            u32 w[4] = {0, 0, 0, 0};
-            if (wide) {
-                if (c0 < C) {
-                    const uint4 q = *(const uint4 *)(b + c0);
-                    w[0] = q.x; w[1] = q.y; w[2] = q.z; w[3] = q.w;
-                }
-            } else {
-#pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    if (c0 + j < C) w[j >> 1] |= (u32)b[c0 + j] << (16 * (j & 1));
+    int bs = 0, bm = 0;
+    for (int r = 0; r < runs; ++r) {
+        const int c0 = 512 * r + 8 * lane;
+        u32 w[4] = {0, 0, 0, 0};
+        if (wide) {
+            if (c0 < C) {
+                const uint4 q = *(const uint4 *)(b + c0);
+                w[0] = q.x; w[1] = q.y; w[2] = q.z; w[3] = q.w;
             }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int v = max((int)((w[j >> 1] >> (16 * (j & 1))) & VMASK) - T, 0);
-                bs += v;
-                bm = max(bm, v);
-                const u64 bit = 1ull << (8 * r + j);
-                if (v > 0) {
-                    over |= (int)((occ & bit) != 0);
-                    occ |= bit;
-                }
-            }
-        }
-        const int t_bs = wave_sum_i32(bs), t_bm = wave_max_i32(bm);
-        if (dead) {
-            if (t_bs > 0 || hc >= 0) m |= WURM_MCHK_DEAD_NONZERO;
         } else {
-            const int t_hb = hc >= 0 ? BV(cx, s, hc) : 0, t_hf = hc >= 0 ? (int)cx.food[hc] : 0;
-            if (hc < 0) m |= WURM_CHK_ONE_HEAD;
-            if (!(t_bs > 0)) m |= WURM_CHK_HAS_SNAKE;
-            if (t_bm != t_hb) m |= WURM_CHK_HEAD_AT_END;
-            if (2 * t_bs != t_bm * (t_bm + 1)) m |= WURM_CHK_BODY_RANGE;
-            if (!(t_bs >= 6)) m |= WURM_CHK_MIN_LENGTH;
-            if (t_hf != 0) m |= WURM_CHK_HEAD_ON_FOOD;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (c0 + j < C) w[j >> 1] |= (u32)b[c0 + j] << (16 * (j & 1));
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int v = max((int)((w[j >> 1] >> (16 * (j & 1))) & VMASK) - T, 0);
+            bs += v;
+            bm = max(bm, v);
+            const u64 bit = 1ull << (8 * r + j);
+            if (v > 0) {
+                over |= (int)((occ & bit) != 0);
+                occ |= bit;
+            }
         }
     }
+    const int t_bs = wave_sum_i32(bs), t_bm = wave_max_i32(bm);
+    if (dead) {
+        if (t_bs > 0 || hc >= 0) m |= WURM_MCHK_DEAD_NONZERO;
+    } else {
+        const int t_hb = hc >= 0 ? BV(cx, s, hc) : 0, t_hf = hc >= 0 ? (int)cx.food[hc] : 0;
+        if (hc < 0) m |= WURM_CHK_ONE_HEAD;
+        if (!(t_bs > 0)) m |= WURM_CHK_HAS_SNAKE;
+        if (t_bm != t_hb) m |= WURM_CHK_HEAD_AT_END;
+        if (2 * t_bs != t_bm * (t_bm + 1)) m |= WURM_CHK_BODY_RANGE;
+        if (!(t_bs >= 6)) m |= WURM_CHK_MIN_LENGTH;
+        if (t_hf != 0) m |= WURM_CHK_HEAD_ON_FOOD;
+    }
+    return m;
+}
+
+__device__ __forceinline__ uint32_t lds_check(const Ctx &cx, const Snake &sn)
+{
+    uint32_t m = 0;
+    u64 occ = 0;
+    int over = 0;
+    for (int s = 0; s < cx.K; ++s)
+        m |= lds_check_snake(cx, s, lane_value(sn.hc, s), lane_value((int)sn.done, s) != 0, occ, over);
     if (ballot(over != 0)) m |= WURM_MCHK_OVERLAP;
     return m;
+}
+
+// The same by the `nw` waves of a workgroup (multi_step_wg_kernel): wave w takes snakes w, w + nw, ...; head cells from
+// cx.hcell, the done flags from cx.lmax (the caller parks them there); `scratch`: 8 * 64 * nw + 8 * nw bytes of LDS that
+// nobody else uses right now.  Every thread of the workgroup calls it; the same value comes back in all of them.
+__device__ __forceinline__ uint32_t wg_lds_check(const Ctx &cx, int wave, int nw, unsigned char *scratch)
+{
+    const int lane = cx.lane;
+    u64 *occs = (u64 *)scratch;                  // [nw][64]
+    u32 *flags = (u32 *)(scratch + 512 * nw);    // [nw][2]: verdict bits, overlap inside the wave's own snakes
+    uint32_t m = 0;
+    u64 occ = 0;
+    int over = 0;
+    for (int s = wave; s < cx.K; s += nw) m |= lds_check_snake(cx, s, cx.hcell[s], cx.lmax[s] != 0, occ, over);
+    occs[wave * 64 + lane] = occ;
+    if (lane == 0) { flags[2 * wave] = m; flags[2 * wave + 1] = 0; }
+    if (ballot(over != 0) && lane == 0) flags[2 * wave + 1] = 1;
+    __syncthreads();
+    uint32_t total = 0;
+    u64 seen = 0;
+    int cross = 0;
+    for (int w = 0; w < nw; ++w) {
+        total |= flags[2 * w] | (flags[2 * w + 1] ? WURM_MCHK_OVERLAP : 0u);
+        const u64 o = occs[w * 64 + lane];
+        cross |= (int)((seen & o) != 0);
+        seen |= o;
+    }
+    if (ballot(cross != 0)) total |= WURM_MCHK_OVERLAP;
+    __syncthreads();
+    return total;
 }
 
 constexpr uint32_t MCHK_NOT_COMPUTED = 0xffffffffu; // read from fp32 planes that hold what the image cannot: run multi_check_kernel
@@ -1257,10 +1294,20 @@ __global__ __launch_bounds__(256) void multi_step_wg_kernel(MultiArgs p)
     int hc0 = -1;
     if (wave == 0) step_middle(cx, p, env, rebuild, sn, r, hc0);
     const bool clean = from_mirror || rebuild || plain;
+    // check_consistency's mask by all four waves when the class-code buffer is there to lend them 2 KB (a snake per wave at
+    // a time), else by wave 0 alone
+    const int nwv = nth >> 6;
+    const bool spread = p.off_snap >= 0 && 2 * C >= 520 * nwv;
     uint32_t m_step = MCHK_NOT_COMPUTED;
-    if (wave == 0 && p.err != nullptr) {
-        if (clean) m_step = lds_check(cx, sn);
-        if (lane == 0) p.err[env] = m_step;
+    if (p.err != nullptr) {
+        if (clean && spread) {
+            if (wave == 0 && lane < K) cx.lmax[lane] = (int)sn.done; // (step_middle has read the lengths out of lmax)
+            __syncthreads();
+            m_step = wg_lds_check(cx, wave, nwv, (unsigned char *)cx.snap);
+        } else if (clean && wave == 0) {
+            m_step = lds_check(cx, sn);
+        }
+        if (tid == 0) p.err[env] = m_step;
     }
     __syncthreads();
     if (!lazy) {
@@ -1291,11 +1338,21 @@ __global__ __launch_bounds__(256) void multi_step_wg_kernel(MultiArgs p)
     if (p.obs_after == nullptr) return;
     if (wave == 0) {
         const bool touched = reset_for_obs_after(cx, p, env, sn, r);
-        if (p.err_after != nullptr) {
-            if (touched) m_step = clean ? lds_check(cx, sn) : MCHK_NOT_COMPUTED;
-            if (lane == 0) p.err_after[env] = m_step;
-        }
+        if (lane == 0) cx.hmap[0] = (unsigned char)touched; // (the head map is all-zero between observations: a flag)
+        if (lane < K) cx.lmax[lane] = (int)sn.done;
     }
+    __syncthreads();
+    if (p.err_after != nullptr) {
+        const bool touched = cx.hmap[0] != 0;
+        if (touched) {
+            if (clean && spread) m_step = wg_lds_check(cx, wave, nwv, (unsigned char *)cx.snap);
+            else if (clean && wave == 0) m_step = lds_check(cx, sn);
+            else if (!clean) m_step = MCHK_NOT_COMPUTED;
+        }
+        if (tid == 0) p.err_after[env] = m_step;
+    }
+    __syncthreads();
+    if (tid == 0) cx.hmap[0] = 0;
     __syncthreads();
     wg_observe_snap(cx, p, p.obs_after, env, tid, nth, wave);
 }
