@@ -128,11 +128,12 @@ __device__ __forceinline__ int BV(const Ctx &cx, int s, int c)
 // alone with its latency at 16 waves/CU: few large batches of loads, not many small ones).
 constexpr int LOAD_CHUNK = 16;
 
-// plain (nullable out, wave-uniform): the planes held nothing the LDS image cannot represent — food and head values 0 / 1,
+// plain (out if want_plain, wave-uniform; a reference, not a pointer: a conditional pointer to a local puts it in scratch):
+// the planes held nothing the LDS image cannot represent — food and head values 0 / 1,
 // at most one head per snake, body values integers in 0 .. 0x7fff — so lds_check sees all there is to check.
 __device__ __forceinline__ u64 load_env(const Ctx &cx, const float *__restrict__ foodp,
                                         const float *__restrict__ headp, const float *__restrict__ bodyp,
-                                        bool *plain = nullptr)
+                                        bool want_plain, bool &plain)
 {
     const int C = cx.C, lane = cx.lane, KC = cx.K * C;
     int odd = 0, nheads = 0;
@@ -189,9 +190,16 @@ __device__ __forceinline__ u64 load_env(const Ctx &cx, const float *__restrict__
         }
     }
     wave_lds_sync();
-    if (plain) // as many heads as snakes that have one <=> nobody has two
-        *plain = ballot(odd != 0) == 0 && wave_sum_i32(nheads) == popc64(ballot(lane < cx.K && cx.hcell[lane] >= 0));
+    if (want_plain) // as many heads as snakes that have one <=> nobody has two
+        plain = ballot(odd != 0) == 0 && wave_sum_i32(nheads) == popc64(ballot(lane < cx.K && cx.hcell[lane] >= 0));
     return fbits;
+}
+
+__device__ __forceinline__ u64 load_env(const Ctx &cx, const float *__restrict__ foodp, const float *__restrict__ headp,
+                                        const float *__restrict__ bodyp)
+{
+    bool unused = false;
+    return load_env(cx, foodp, headp, bodyp, false, unused);
 }
 
 // LDS -> HBM: body cells flagged DIRTY, the two head cells that changed, food cells that changed.
@@ -931,20 +939,27 @@ __device__ __forceinline__ uint32_t lds_check_snake(const Ctx &cx, int s, int hc
     int bs = 0, bm = 0;
     for (int r = 0; r < runs; ++r) {
         const int c0 = 512 * r + 8 * lane;
-        u32 w[4] = {0, 0, 0, 0};
+        u32 w0 = 0, w1 = 0, w2 = 0, w3 = 0; // (scalars, not an array: an indexed local array ends up in scratch)
         if (wide) {
             if (c0 < C) {
                 const uint4 q = *(const uint4 *)(b + c0);
-                w[0] = q.x; w[1] = q.y; w[2] = q.z; w[3] = q.w;
+                w0 = q.x; w1 = q.y; w2 = q.z; w3 = q.w;
             }
         } else {
 #pragma unroll
             for (int j = 0; j < 8; ++j)
-                if (c0 + j < C) w[j >> 1] |= (u32)b[c0 + j] << (16 * (j & 1));
+                if (c0 + j < C) {
+                    const u32 v16 = (u32)b[c0 + j] << (16 * (j & 1));
+                    if ((j >> 1) == 0) w0 |= v16;
+                    else if ((j >> 1) == 1) w1 |= v16;
+                    else if ((j >> 1) == 2) w2 |= v16;
+                    else w3 |= v16;
+                }
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int v = max((int)((w[j >> 1] >> (16 * (j & 1))) & VMASK) - T, 0);
+            const u32 word = (j >> 1) == 0 ? w0 : (j >> 1) == 1 ? w1 : (j >> 1) == 2 ? w2 : w3;
+            const int v = max((int)((word >> (16 * (j & 1))) & VMASK) - T, 0);
             bs += v;
             bm = max(bm, v);
             const u64 bit = 1ull << (8 * r + j);
@@ -1116,7 +1131,7 @@ __global__ __launch_bounds__(256) void multi_step_kernel(MultiArgs p)
     bool plain = false; // read from the fp32 planes, which held nothing the image cannot represent
     if (!rebuild) {
         fbits0 = from_mirror ? mirror_load(cx, mp, lane, 64, fence)
-                             : load_env(cx, foodp, headp, bodyp, p.err != nullptr ? &plain : nullptr);
+                             : load_env(cx, foodp, headp, bodyp, p.err != nullptr, plain);
     } else {
         if (snake) { cx.hcell[lane] = -1; cx.lmax[lane] = 0; cx.tclk[lane] = 0; } // the rest: multi_reset_grid(rebuild)
         wave_lds_sync();
@@ -1160,9 +1175,9 @@ __global__ __launch_bounds__(256) void multi_step_kernel(MultiArgs p)
 // stores.  Here the four waves of a workgroup share ONE env: all of them copy it in, turn it into class codes and write
 // it back (flat over the K * S * S cells; the K agents' observations go out one agent per wave), wave 0 alone runs the
 // transition in between.  Same LDS layout, same device functions for everything that is not a plain copy.
-// plain: as load_env's (nullable out, the same in every thread)
+// plain: as load_env's (the same in every thread)
 __device__ __forceinline__ u64 wg_load_env(const Ctx &cx, const float *__restrict__ foodp, const float *__restrict__ headp,
-                                           const float *__restrict__ bodyp, int tid, int nth, bool *plain = nullptr)
+                                           const float *__restrict__ bodyp, int tid, int nth, bool want_plain, bool &plain)
 {
     const int C = cx.C, KC = cx.K * C;
     int odd = 0, nheads = 0;
@@ -1207,7 +1222,7 @@ __device__ __forceinline__ u64 wg_load_env(const Ctx &cx, const float *__restric
         fbits |= (u64)f << k;
         odd |= (int)(fv != 0.0f && fv != 1.0f);
     }
-    if (plain) { // (the colour slots are free until step_middle loads them: a counter for the heads seen by all threads)
+    if (want_plain) { // (the colour slots are free until step_middle loads them: a counter for the heads seen by all threads)
         int *cnt = (int *)cx.colf;
         if (tid == 0) *cnt = 0;
         __syncthreads();
@@ -1215,10 +1230,17 @@ __device__ __forceinline__ u64 wg_load_env(const Ctx &cx, const float *__restric
         const int any_odd = __syncthreads_or(odd);
         int with_head = 0;
         for (int s2 = 0; s2 < cx.K; ++s2) with_head += (int)(cx.hcell[s2] >= 0);
-        *plain = !any_odd && *cnt == with_head;
+        plain = !any_odd && *cnt == with_head;
         __syncthreads();
     }
     return fbits;
+}
+
+__device__ __forceinline__ u64 wg_load_env(const Ctx &cx, const float *__restrict__ foodp, const float *__restrict__ headp,
+                                           const float *__restrict__ bodyp, int tid, int nth)
+{
+    bool unused = false;
+    return wg_load_env(cx, foodp, headp, bodyp, tid, nth, false, unused);
 }
 
 __device__ __forceinline__ void wg_store_env(const Ctx &cx, float *__restrict__ foodp, float *__restrict__ headp,
@@ -1285,7 +1307,7 @@ __global__ __launch_bounds__(256) void multi_step_wg_kernel(MultiArgs p)
     u64 fbits0 = 0;
     bool plain = false;
     if (!rebuild) fbits0 = from_mirror ? mirror_load(cx, mp, tid, nth, barrier)
-                                       : wg_load_env(cx, foodp, headp, bodyp, tid, nth, p.err != nullptr ? &plain : nullptr);
+                                       : wg_load_env(cx, foodp, headp, bodyp, tid, nth, p.err != nullptr, plain);
     else if (tid < K) { cx.hcell[tid] = -1; cx.lmax[tid] = 0; cx.tclk[tid] = 0; }
     __syncthreads();
     const int t0 = tid < K ? cx.tclk[tid] : 0;
