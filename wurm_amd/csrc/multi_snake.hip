@@ -1417,6 +1417,69 @@ __device__ __forceinline__ void build_occ(const Ctx &cx, int hc)
     wave_lds_sync();
 }
 
+// The respawn search of respawn_mode = 'any' (:805-831 -> _get_snake_addition :848-858) on row masks: the K-th cell, in
+// row-major order, that is at least 2 from the border with nothing (food, body, head) in its 3 x 3 neighbourhood, K =
+// mulhi(word, number of such cells); -1 if there is none.  Same cells in the same order as build_occ + spawn_cells +
+// rank_select — which read every (cell, snake) pair one by one: 420 LDS reads per lane at 10 snakes on 36 x 36, run in
+// nearly every step of such an env (some snake is almost always dead), half of the transition's time there.  Here lane l
+// reads cells 8 l .. 8 l + 7 of every run of 512 with one 16-byte read per snake, leaves one occupancy BIT per cell in the
+// scratch byte map, and lane r assembles row r's 64-bit mask from it; the rest is the dilation / popcount walk that the
+// rebuild of an env uses.  Needs S * S to be a multiple of 8 (16-byte aligned snake grids).
+__device__ __forceinline__ int respawn_cell_rows(const Ctx &cx, int hc, u32 word)
+{
+    const int S = cx.S, C = cx.C, K = cx.K, lane = cx.lane;
+    unsigned char *bm = cx.occ; // C bytes of scratch: C / 8 of bitmap, the rest zero padding for the row reads
+    const int myT = lane < K ? cx.tclk[lane] : 0;
+    for (int i = lane; i < (C >> 3) + 16 && i < C; i += 64) bm[i] = 0;
+    wave_lds_sync();
+    const int runs = (C + 511) >> 9;
+    for (int r = 0; r < runs; ++r) {
+        const int c0 = 512 * r + 8 * lane;
+        if (c0 >= C) continue;
+        const u64 f8 = *(const u64 *)(cx.food + c0);
+        u32 o8 = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o8 |= (u32)(((f8 >> (8 * j)) & 0xffull) != 0) << j;
+        for (int s = 0; s < K; ++s) {
+            const int T = lane_value(myT, s);
+            const uint4 q = *(const uint4 *)(cx.body + s * C + c0);
+            o8 |= (u32)((int)(q.x & VMASK) > T) | ((u32)((int)((q.x >> 16) & VMASK) > T) << 1) |
+                  ((u32)((int)(q.y & VMASK) > T) << 2) | ((u32)((int)((q.y >> 16) & VMASK) > T) << 3) |
+                  ((u32)((int)(q.z & VMASK) > T) << 4) | ((u32)((int)((q.z >> 16) & VMASK) > T) << 5) |
+                  ((u32)((int)(q.w & VMASK) > T) << 6) | ((u32)((int)((q.w >> 16) & VMASK) > T) << 7);
+        }
+        bm[c0 >> 3] = (unsigned char)o8;
+    }
+    wave_lds_sync();
+    if (lane < K && hc >= 0) atomicOr((u32 *)bm + (hc >> 5), 1u << (hc & 31)); // head cells (the map is 16-byte aligned)
+    wave_lds_sync();
+    u64 occ_row = 0;
+    if (lane < S) { // bits lane * S .. lane * S + S - 1 of the map
+        const int bit0 = lane * S, byte0 = bit0 >> 3, sh = bit0 & 7;
+        u64 lo = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) lo |= (u64)bm[byte0 + i] << (8 * i);
+        const u64 hi = bm[byte0 + 8];
+        const u64 v = sh ? (lo >> sh) | (hi << (64 - sh)) : lo;
+        occ_row = S == 64 ? v : v & ((1ull << S) - 1ull);
+    }
+    // available (:848-858): at least 2 from the border, nothing in the 3 x 3 neighbourhood
+    const u64 h = occ_row | (occ_row << 1) | (occ_row >> 1);
+    const u64 up = lane == 0 ? 0ull : (u64)__shfl_up((long long)h, 1);
+    const u64 dn = lane == 63 ? 0ull : (u64)__shfl_down((long long)h, 1);
+    const u64 cols = S >= 5 ? (((1ull << (S - 4)) - 1ull) << 2) : 0ull;
+    const u64 av = (lane >= 2 && lane <= S - 3) ? (~(h | up | dn) & cols) : 0ull;
+    const int cnt = popc64(av), n = wave_sum_i32(cnt);
+    if (n == 0) return -1;
+    int kth = (int)mulhi_range(word, (u32)n), r = 0;
+    for (; r < S - 1; ++r) {
+        const int c = lane_value(cnt, r);
+        if (kth < c) break;
+        kth -= c;
+    }
+    return r * S + nth_bit64((u64)lane_value64((long long)av, r), kth);
+}
+
 // writes a 3-segment snake `s` at `cell` heading `d` into LDS (body, occ); cell < 0: nothing
 __device__ __forceinline__ int place_snake(const Ctx &cx, int s, int cell, int d)
 {
@@ -1565,17 +1628,22 @@ __device__ __forceinline__ void multi_reset_grid(const Ctx &cx, const MultiArgs 
     }
     if (respawn) { // :805-831 the first dead snake of the env respawns if there is room
         const int f = first_bit(ballot(snake && sn.done));
-        build_occ(cx, sn.hc);
         int cell = -1, dnew = 0;
         if (p.has_rinj) {
+            build_occ(cx, sn.hc);
             cell = p.rinj.respawn[(offE + env) * 2];
             dnew = p.rinj.respawn[(offE + env) * 2 + 1];
         } else {
             Words w = rng_words(p.seed, call, env_id, RNG_SPAWN, (u32)K);
             dnew = (int)(w.w[1] >> 30);
-            u64 av = spawn_cells(cx);
-            int n = count_bits(cx, av);
-            if (n > 0) cell = selected_cell(rank_select(cx, av, (int)mulhi_range(w.w[0], (u32)n)));
+            if ((C & 7) == 0) {
+                cell = respawn_cell_rows(cx, sn.hc, w.w[0]);
+            } else {
+                build_occ(cx, sn.hc);
+                u64 av = spawn_cells(cx);
+                int n = count_bits(cx, av);
+                if (n > 0) cell = selected_cell(rank_select(cx, av, (int)mulhi_range(w.w[0], (u32)n)));
+            }
         }
         cell = uniform(cell);
         // bodies[first] = new_bodies (:826): the dead snake's grid is replaced (it reads all-zero in consistent
