@@ -20,6 +20,12 @@ time per call, not by the GPU, so:
     wurm_amd/_fastcall is built (wurm_amd/csrc/fastcall.c), else `PyStepper` below — the same logic, and the
     specification of the C type (tests/test_host_lazy_reset.py drives both through the same call patterns).
 
+  * large batches (SingleSnake 9 x 9 `partial_2` / no observation from 4096 envs, 12 x 12 and larger from 2^20 cells:
+    wurm_single_resident_bytes) hand the launch a compact MIRROR of the state (wurm_single_call.resident) which it steps
+    instead of re-reading the fp32 tensor every call; the tensor stays the state: reading `env.envs` writes it out (and from
+    then on every step writes it), any other entry point goes through `_touch()`, a tensor the caller holds is watched for
+    in-place edits through its version counter (DESIGN.md §4.10, §5 deviation 11).
+
 The host class provides: num_envs, size, device, seed, env_offset, observation_mode, lazy_reset, _CHANNELS,
 _STEP_SLOT (entry point name), _mode_info(mode) -> (mode code, n, obs shape), _lazy_supported(), _launch_reset(envs,
 done, obs, mode code, n, call), _configure_call(block), _make_out(i) -> what step returns for slot i.

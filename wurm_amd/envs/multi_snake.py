@@ -25,6 +25,11 @@ time; from then on the step launch also writes that observation (`obs_after`: th
 of the env after the step's own observation, with the counter the eager call would use) and `reset` hands it out and
 is deferred like the other form.  As for SingleSnake, a tensor alias taken before the deferred reset is the one thing
 that is not tracked.
+Large batches (from 2^20 cells: wurm_multi_resident_bytes) hand the step launch a compact MIRROR of foods / heads / bodies
+(wurm_multi_call.resident) which it steps instead of converting the fp32 tensors every call, and ask it for
+check_consistency()'s masks once the caller has used that method; the tensors stay the state — reading one of the three
+attributes writes them out (and from then on every step writes them), every other entry point goes through `_touch()`,
+tensors the caller holds are watched for in-place edits (DESIGN.md §4.10, §5 deviation 11).
 """
 import ctypes
 import os
