@@ -57,6 +57,19 @@ extern "C" {
 /* Library / build identification: "wurm_hip <version> gfx950". */
 const char *wurm_version(void);
 
+/* Tuning / test knobs (wurm_amd/csrc/options.hpp lists them: WURM_LANE_ROLLOUT_MIN_ENVS, WURM_RESIDENT_MIN_ENVS, ...).
+ * Each starts at its default, is overridden ONCE by the environment variable of the same name when the library is
+ * loaded, and changes afterwards only through these calls — no launch path reads the environment.  None of them
+ * changes results, only which kernel serves a call.  set / reset return WURM_ERR_INVALID_ARG for an unknown name,
+ * get returns INT64_MIN. */
+int wurm_set_option(const char *name, int64_t value);
+int64_t wurm_get_option(const char *name);
+int wurm_reset_option(const char *name);
+
+/* Number of kernels the library has launched in this process so far (a plain counter: bench.py divides its growth by
+ * the loop iterations to report launches per `step(a); reset(done)` iteration). */
+int64_t wurm_launch_count(void);
+
 /* Number of fp32 elements one env's observation occupies (0 = invalid mode for that env family). */
 int64_t wurm_single_obs_elems(int obs_mode, int obs_n, int size);
 int64_t wurm_grid_obs_elems(int obs_mode, int obs_n, int size);
@@ -151,6 +164,9 @@ int wurm_single_step_reset(const wurm_single_call *c, void *stream);
  * else writes `envs` (another entry point, the caller's own code).  A call that cannot use the mirror (inject_* /
  * post_reset) flushes a lazy mirror into envs first by itself. */
 int64_t wurm_single_resident_bytes(int64_t num_envs, int size, int obs_mode, int obs_n);
+/* the same without the batch-size threshold: the size of the mirror whenever the SHAPE is served (a caller that asked for
+ * the mirror explicitly, `resident_mirror=True` of the Python classes), 0 if it is not */
+int64_t wurm_single_resident_size(int64_t num_envs, int size, int obs_mode, int obs_n);
 
 /* resident_lazy: writes envs from the mirror (every env the mirror describes, whole; the others — states outside the
  * lane kernels' domain, which the step keeps in envs itself — are left as they are).  A no-op returning WURM_OK unless
@@ -364,6 +380,7 @@ int wurm_multi_step_packed(wurm_multi_call *c, float *out_f32, uint8_t *out_u8, 
  * (not with inject / pre_inject: such a call writes a lazy mirror out first and steps the fp32 state), the caller clears it
  * whenever anything else writes the state — after wurm_multi_resident_flush if the mirror is lazy. */
 int64_t wurm_multi_resident_bytes(int64_t num_envs, int num_snakes, int size);
+int64_t wurm_multi_resident_size(int64_t num_envs, int num_snakes, int size); /* without the batch-size threshold */
 int wurm_multi_resident_flush(const wurm_multi_call *c, void *stream);
 
 /* MultiSnake.reset (multi_snake.py:771-836): envs flagged in done_env (N bytes) are rebuilt (_create_envs

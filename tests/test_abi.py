@@ -94,11 +94,11 @@ def test_obs_mode_parsing():
         _lib.parse_obs_mode('bogus')
 
 
-def test_resident_mirror_sizes(monkeypatch):
+def test_resident_mirror_sizes():
     """wurm_single_resident_bytes / wurm_multi_resident_bytes (host arithmetic only): which shapes are offered the mirror
     of the per-call step, from which batch size, and how large it is"""
     l = _lib.lib()
-    monkeypatch.delenv('WURM_RESIDENT_MIN_ENVS', raising=False)
+    _lib.set_option('WURM_RESIDENT_MIN_ENVS', None)
     part2, none, default = (_lib.OBS_PARTIAL, 2), (_lib.OBS_NONE, 0), (_lib.OBS_DEFAULT, 0)
     assert l.wurm_single_resident_bytes(65536, 9, *part2) == 65536 * 32          # 9 x 9: 32 bytes per env
     assert l.wurm_single_resident_bytes(4096, 9, *none) == 4096 * 32
@@ -117,11 +117,12 @@ def test_resident_mirror_sizes(monkeypatch):
     assert l.wurm_multi_resident_bytes(4096, K, S) == 4096 * per
     assert l.wurm_multi_resident_bytes(100, K, S) == 0
     assert l.wurm_multi_resident_bytes(4096, 65, S) == 0 and l.wurm_multi_resident_bytes(4096, K, 4) == 0
-    monkeypatch.setenv('WURM_RESIDENT_MIN_ENVS', '0')                            # tests / tuning: a number of envs instead
+    _lib.set_option('WURM_RESIDENT_MIN_ENVS', 0)                                 # tests / tuning: a number of envs instead
     assert l.wurm_single_resident_bytes(3, 9, *part2) == 96 and l.wurm_single_resident_bytes(3, 12, *default) == 3 * 560
     assert l.wurm_multi_resident_bytes(2, K, S) == 2 * per
-    monkeypatch.setenv('WURM_RESIDENT_MIN_ENVS', '1000000000')
+    _lib.set_option('WURM_RESIDENT_MIN_ENVS', 1000000000)
     assert l.wurm_single_resident_bytes(65536, 9, *part2) == 0 and l.wurm_multi_resident_bytes(4096, K, S) == 0
+    _lib.set_option('WURM_RESIDENT_MIN_ENVS', None)
     # no-op flushes need no device
     assert l.wurm_single_resident_flush(None, None) == _lib.ERR_INVALID_ARG
     c = _lib.SingleCall()

@@ -31,6 +31,12 @@ class _Recorder(object):
     def wurm_single_resident_bytes(self, N, S, m, n):
         return self.mirror_bytes_per_env * int(getattr(N, 'value', N))
 
+    size_calls = 0
+
+    def wurm_single_resident_size(self, N, S, m, n):      # what `resident_mirror=True` asks: no batch-size threshold
+        self.size_calls += 1
+        return self.mirror_bytes_per_env * int(getattr(N, 'value', N))
+
     def wurm_single_resident_flush(self, c_addr, stream):
         c = _lib.SingleCall.from_address(c_addr)
         assert c.resident and c.resident_lazy and c.resident_valid  # (the library would do nothing otherwise)
@@ -434,3 +440,134 @@ def test_a_loop_that_invalidates_the_mirror_every_step_loses_it(env_and_log):
         if t % 20 == 19:
             e2.reset(torch.ones(8, dtype=torch.bool), return_observations=False)
     assert all(s['mirror'] for s in _steps(log)[env2_log_start + 1:])
+
+
+def test_changing_the_observation_mode_writes_a_lazy_mirror_out_first(env_and_log):
+    """in the lazy form `envs` lag behind; a mode change replaces (or drops) the mirror, so the old one has to be
+    written out to `envs` while the call block still names it — otherwise the batch rolls back to the last written state"""
+    env, log = env_and_log
+    rec = env._rec
+    for _ in range(3):
+        _, _, d, _ = _step(env)
+        env.reset(d, return_observations=False)
+    assert all(s['lazy'] and s['mirror'] for s in _steps(log)) and rec.flushes == []
+    env.observation_mode = 'partial_3'           # (the recorder serves every mode: a NEW mirror is made)
+    n = len(log)
+    _step(env)
+    assert rec.flushes == [n], 'the lazy mirror was not written out before the step of the new mode'
+    assert _steps(log)[-1]['mirror'] and not _steps(log)[-1]['mirror_valid']   # the new mirror starts stale
+    # ... and when the new mode has no mirror at all
+    for _ in range(2):
+        _, _, d, _ = _step(env)
+        env.reset(d, return_observations=False)
+    assert _steps(log)[-1]['lazy'] and _steps(log)[-1]['mirror_valid']
+    rec.mirror_bytes_per_env = 0
+    env.observation_mode = 'default'
+    n = len(log)
+    _step(env)
+    assert rec.flushes == [3, n] and not _steps(log)[-1]['mirror']
+
+
+def _make(monkeypatch_env, **kw):
+    from wurm_amd.envs import SingleSnake
+    return SingleSnake(num_envs=8, size=9, observation_mode='partial_2', device='cpu', seed=5, **kw)
+
+
+def test_resident_mirror_keyword_and_mirror_state(env_and_log):
+    env, log = env_and_log          # (the fixture's patches are in force for the envs made here)
+    rec = env._rec
+    assert env.mirror_state()['state'] == 'off' and env.mirror_state()['policy'] is None
+    _step(env)
+    st = env.mirror_state()
+    assert st['state'] == 'lazy' and st['current'] and st['why'] == 'on' and st['bytes'] == 8 * 32
+
+    off = _make(None, resident_mirror=False)
+    a = len(log)
+    _step(off); _step(off)
+    assert not any(s['mirror'] for s in _steps(log[a:])) and off.mirror_state() == {
+        'state': 'off', 'why': 'resident_mirror=False', 'policy': False, 'current': False, 'bytes': 0}
+
+    # True / 'lazy': asked for explicitly — sized without the batch threshold, and none of the adaptive rules applies
+    forced = _make(None, resident_mirror=True)
+    before = rec.size_calls
+    a = len(log)
+    for t in range(12):
+        _step(forced)
+        forced.reset(torch.ones(8, dtype=torch.bool), return_observations=False)   # eager resets after every step
+    assert rec.size_calls == before + 1
+    assert all(s['mirror'] and s['lazy'] for s in _steps(log[a:])), 'the adaptive switch-off applied under a keyword'
+    forced._observe('default'); _step(forced); forced._observe('default'); _step(forced)
+    assert _steps(log)[-1]['lazy'], "'second look ends the lazy form' applied under a keyword"
+    assert forced.mirror_state()['state'] == 'lazy' and forced.mirror_state()['policy'] == 'lazy'
+    e = forced.envs                  # correctness, not a heuristic: a tensor the caller holds ends the lazy form
+    _step(forced)
+    assert not _steps(log)[-1]['lazy'] and forced.mirror_state()['state'] == 'eager'
+    assert 'caller holds' in forced.mirror_state()['why']
+    del e
+
+    eager = _make(None, resident_mirror='eager')
+    a = len(log)
+    _step(eager); _step(eager)
+    assert all(s['mirror'] and not s['lazy'] for s in _steps(log[a:])) and eager.mirror_state()['state'] == 'eager'
+    with pytest.raises(ValueError):
+        _make(None, resident_mirror='sometimes')
+
+
+def test_the_adaptive_rules_say_why(env_and_log):
+    env, log = env_and_log
+    for t in range(12):
+        _step(env)
+        env.reset(torch.ones(8, dtype=torch.bool), return_observations=False)
+    st = env.mirror_state()
+    assert st['state'] == 'off' and st['why'].startswith('adaptive:')
+
+
+def test_reference_test_access_patterns_never_step_on_a_stale_mirror(env_and_log):
+    """The access patterns of the reference's own SingleSnake tests (tests/test_single_snake_env.py: rebinding `env.envs`
+    :54, in-place edits of what `env.envs` returned, `env.envs[...]` reads for env_consistency every step :24-31, reset(done)
+    / reset() in between) against the recorder with the mirror FORCED on: no step launch may be told the mirror is current
+    (resident_valid = 1) after anything wrote the state some other way, and no lazy launch may follow a write-less look."""
+    env, log = env_and_log
+    rec = env._rec
+    from wurm_amd.envs import SingleSnake
+    env = SingleSnake(num_envs=8, size=9, observation_mode='partial_2', device='cpu', seed=5, resident_mirror=True)
+    env._rec = rec
+    wrote = [False]          # something other than a step launch has written the state since the last step
+
+    def step():
+        n = len(log)
+        _step(env)
+        s = _steps(log[n:])[-1]
+        assert not (wrote[0] and s['mirror_valid']), 'a step launch was told the mirror is current after a write'
+        wrote[0] = False
+        return s
+
+    step(); step()
+    # :54 `env.envs = get_test_env(size, 'up').to(DEFAULT_DEVICE)`: rebinding
+    env.envs = torch.zeros(8, 3, 9, 9); wrote[0] = True
+    s = step()
+    assert not s['lazy']                                  # the caller holds that tensor
+    # in-place edit through an alias of the handed-in tensor and through what the attribute returns
+    env.envs[0, 0, 1, 1] = 1.0; wrote[0] = True
+    step()
+    e = env.envs
+    step()
+    e[1, 2, 3, 3] = 2.0; wrote[0] = True
+    step()
+    # :24-31 / experiments/main.py:212-227: step, consistency on a gathered copy, reset(done)
+    for _ in range(4):
+        n = len(log)
+        _, _, d, _ = _step(env)
+        assert not (wrote[0] and _steps(log[n:])[-1]['mirror_valid'])
+        wrote[0] = False
+        _ = env.envs[~d.squeeze(-1)]                      # a read: eager mirror, nothing to write out, stays current
+        env.reset(d)                                      # the step's own flags: postponed, applied by the next launch
+    # an eager reset (not the step's flags) and reset() with no argument write the state with another kernel
+    env.reset(torch.ones(8, dtype=torch.bool)); wrote[0] = True
+    step()
+    env.reset()                                           # = the last step's own flags (env.done): postponed as well
+    assert step()['pending']
+    # .data edits bypass the version counter: the documented hole (DESIGN.md §5 deviation 11) — the mirror stays "current"
+    env.envs.data[2, 0, 5, 5] = 1.0
+    s = step()
+    assert s['mirror_valid']

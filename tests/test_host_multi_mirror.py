@@ -41,6 +41,12 @@ class _Lib(object):
     def wurm_multi_resident_bytes(self, N, K, S):
         return self.mirror_bytes * int(getattr(N, 'value', N))
 
+    size_calls = 0
+
+    def wurm_multi_resident_size(self, N, K, S):      # `resident_mirror=True`: no batch-size threshold
+        self.size_calls += 1
+        return self.mirror_bytes * int(getattr(N, 'value', N))
+
     def wurm_multi_resident_flush(self, c_addr, stream):
         c = _lib.MultiCall.from_address(c_addr)
         assert c.resident and c.resident_lazy and c.resident_valid
@@ -202,3 +208,135 @@ def test_no_mirror_for_small_batches(env_and_log):
     a = {f'agent_{i}': torch.zeros(N, dtype=torch.long) for i in range(K)}
     e2.step(a)
     assert not _steps(log)[-1]['mirror'] and e2._mirror is None
+
+
+def test_an_in_place_edit_of_an_alias_after_the_step_is_seen_by_check_consistency(env_and_log):
+    """the masks of the step launch describe the state the launch left; an alias of a state tensor the caller
+    holds may have been edited since — the version counters are compared before the masks are trusted"""
+    env, log = env_and_log
+    _step(env)
+    env.check_consistency()
+    b = env.bodies                             # the caller holds it from now on (watched)
+    _step(env)
+    env._chk.zero_()
+    n = _names(log).count('check')
+    env.check_consistency()                    # nothing edited: served by the launch masks
+    assert _names(log).count('check') == n
+    _step(env)
+    env._chk.zero_()
+    b[0] = 7                                   # in-place edit AFTER the step
+    env.check_consistency()
+    assert _names(log).count('check') == n + 1, 'the launch masks were trusted over an edited tensor'
+    _step(env)
+    assert not _steps(log)[-1]['valid']        # and the mirror is rebuilt from the edited tensors
+
+
+def test_a_replaced_state_tensor_is_no_longer_watched(env_and_log):
+    """rebinding env.foods / heads / bodies every iteration must not keep every old tensor alive and watched"""
+    env, log = env_and_log
+    olds = []
+    for t in range(5):
+        _step(env)
+        new = torch.zeros(N, 1, S, S)
+        olds.append(new)
+        env.foods = new
+    assert len(env._watched) == 1 and env._watched[0][0] is olds[-1]
+    _step(env); _step(env)
+    assert _steps(log)[-1]['valid']
+    olds[0][0, 0, 1, 1] = 1.0                  # an edit of a tensor that is no longer part of the state: nothing to do
+    _step(env)
+    assert _steps(log)[-1]['valid']
+    olds[-1][0, 0, 1, 1] = 1.0                 # the current one: the mirror is stale
+    _step(env)
+    assert not _steps(log)[-1]['valid']
+
+
+def test_resident_mirror_keyword_and_mirror_state(env_and_log):
+    env, log = env_and_log
+    lib = env._lib
+    from wurm_amd.envs import MultiSnake
+    assert env.mirror_state()['state'] == 'off' and env.mirror_state()['why'] == 'no step yet'
+    _step(env)
+    assert env.mirror_state() == {'state': 'lazy', 'why': 'on', 'policy': None, 'current': True, 'bytes': 64 * N}
+
+    off = MultiSnake(N, K, S, device='cpu', seed=1, resident_mirror=False)
+    a = len(log)
+    _step(off); _step(off)
+    assert not any(s['mirror'] for s in _steps(log[a:])) and off.mirror_state()['why'] == 'resident_mirror=False'
+
+    forced = MultiSnake(N, K, S, device='cpu', seed=1, resident_mirror=True)
+    a = len(log)
+    for t in range(12):                        # eager resets after every step: the automatic policy would switch it off
+        _step(forced)
+        forced.reset(torch.ones(N, dtype=torch.bool), return_observations=False)
+    assert lib.size_calls == 1 and all(s['mirror'] and s['lazy'] for s in _steps(log[a:]))
+    forced._observe(); _step(forced); forced._observe(); _step(forced)
+    assert _steps(log)[-1]['lazy'] and forced.mirror_state()['state'] == 'lazy'
+    _ = forced.heads                           # correctness, not a heuristic
+    _step(forced)
+    assert not _steps(log)[-1]['lazy'] and 'caller holds' in forced.mirror_state()['why']
+
+    eager = MultiSnake(N, K, S, device='cpu', seed=1, resident_mirror='eager')
+    a = len(log)
+    _step(eager); _step(eager)
+    assert all(s['mirror'] and not s['lazy'] for s in _steps(log[a:]))
+
+    auto = MultiSnake(N, K, S, device='cpu', seed=1)
+    for t in range(12):
+        _step(auto)
+        auto.reset(torch.ones(N, dtype=torch.bool), return_observations=False)
+    assert auto.mirror_state()['state'] == 'off' and auto.mirror_state()['why'].startswith('adaptive:')
+
+
+def test_reference_test_access_patterns_never_step_on_a_stale_mirror(env_and_log):
+    """The access patterns of the reference's MultiSnake tests (tests/test_multi_snake_env.py:26-44 rebinding foods / heads /
+    bodies and in-place edits of what the attributes return, :130 check_consistency() every step, :180 / :288 / :401-403
+    dynamics attributes set after construction) with the mirror FORCED on: no step launch is told the mirror is current
+    after anything wrote the state some other way."""
+    env, log = env_and_log
+    from wurm_amd.envs import MultiSnake
+    env = MultiSnake(N, K, S, device='cpu', seed=1, resident_mirror=True, manual_setup=True)
+    wrote = [False]
+
+    def step():
+        n = len(log)
+        out = _step(env)
+        s = _steps(log[n:])[-1]
+        assert not (wrote[0] and s['valid']), 'a step launch was told the mirror is current after a write'
+        wrote[0] = False
+        return out
+
+    # :26-44: the board is written into the tensors the attributes return, orientations assigned
+    env.foods[:, 0, 1, 1] = 1
+    env.heads[0, 0, 5, 5] = 1
+    env.bodies[0, 0, 5, 5] = 4
+    env.orientations = torch.zeros(N * K, dtype=torch.long); wrote[0] = True
+    step()
+    # :130 check_consistency() after every step, actions in between
+    for _ in range(3):
+        step()
+        env._chk.zero_()
+        env.check_consistency()
+    # in-place edits between steps through the attribute and through an alias taken earlier
+    h = env.heads
+    step()
+    h[1, 0, 3, 3] = 1; wrote[0] = True
+    step()
+    env.bodies[2, 0, 4, 4] = 2; wrote[0] = True
+    step()
+    # rebinding (tests/test_multi_snake_env.py:29-36 assigns fresh tensors)
+    env.foods = torch.zeros(N, 1, S, S); wrote[0] = True
+    step()
+    # :180 / :288 / :401-403: dynamics attributes after construction do not touch the state
+    env.food_on_death_prob, env.boost, env.boost_cost_prob, env.respawn_mode = 1.0, False, 0.0, 'any'
+    step()
+    assert _steps(log)[-1]['valid']
+    # reset with flags of the caller's own, reset() and a rollout write the state with other kernels
+    env.reset(torch.ones(N, dtype=torch.bool), return_observations=False); wrote[0] = True
+    step()
+    env.reset(); wrote[0] = True
+    step()
+    _, _, d, _ = step()
+    env.reset(d['__all__'], return_observations=False)     # the step's own flags: postponed, nothing written
+    step()
+    assert _steps(log)[-1]['pending'] and _steps(log)[-1]['valid']

@@ -30,22 +30,7 @@ def hip():
     return HipBackend
 
 
-@contextlib.contextmanager
-def knobs(**kw):
-    old = {k: os.environ.get(k) for k in kw}
-    for k, v in kw.items():
-        if v is None:
-            os.environ.pop(k, None)
-        else:
-            os.environ[k] = str(v)
-    try:
-        yield
-    finally:
-        for k, v in old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
+from wurm_amd._lib import knobs  # noqa: E402  (library options + environment for child processes)
 
 
 def _same(a, b, what):

@@ -27,20 +27,9 @@ def hip():
 @contextlib.contextmanager
 def lane_path(epw=None, min_envs=0):
     """force (min_envs=0) or forbid (min_envs=huge) the lane kernel, optionally with a fixed envs-per-wave"""
-    old = {k: os.environ.get(k) for k in ('WURM_LANE_ROLLOUT_MIN_ENVS', 'WURM_LANE_ROLLOUT_EPW')}
-    os.environ['WURM_LANE_ROLLOUT_MIN_ENVS'] = str(min_envs)
-    if epw is not None:
-        os.environ['WURM_LANE_ROLLOUT_EPW'] = str(epw)
-    else:
-        os.environ.pop('WURM_LANE_ROLLOUT_EPW', None)
-    try:
+    from wurm_amd._lib import knobs
+    with knobs(WURM_LANE_ROLLOUT_MIN_ENVS=min_envs, WURM_LANE_ROLLOUT_EPW=epw):
         yield
-    finally:
-        for k, v in old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
 
 
 def _same(a, b, what):

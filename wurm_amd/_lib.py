@@ -3,6 +3,7 @@
 There is deliberately NO fallback: if the library is missing, or a call is made without a HIP device, the
 product raises.  The CPU oracle under oracle/ is test infrastructure and is never used from here.
 """
+import contextlib
 import ctypes
 import os
 import subprocess
@@ -19,11 +20,11 @@ ACT_I64, ACT_I32 = 0, 1
 
 # every symbol include/wurm_hip.h declares (tests/test_abi.py checks the header against this list and the .so)
 SYMBOLS = [
-    'wurm_version', 'wurm_single_obs_elems', 'wurm_grid_obs_elems',
+    'wurm_version', 'wurm_set_option', 'wurm_get_option', 'wurm_reset_option', 'wurm_launch_count', 'wurm_single_obs_elems', 'wurm_grid_obs_elems',
     'wurm_single_step', 'wurm_single_reset', 'wurm_single_observe', 'wurm_single_rollout', 'wurm_single_check',
-    'wurm_single_step_reset', 'wurm_single_resident_bytes', 'wurm_single_resident_flush', 'wurm_grid_step_reset', 'wurm_single_step_slot', 'wurm_grid_step_slot',
+    'wurm_single_step_reset', 'wurm_single_resident_bytes', 'wurm_single_resident_size', 'wurm_single_resident_flush', 'wurm_grid_step_reset', 'wurm_single_step_slot', 'wurm_grid_step_slot',
     'wurm_grid_step', 'wurm_grid_reset', 'wurm_grid_observe', 'wurm_grid_rollout',
-    'wurm_multi_obs_elems', 'wurm_multi_step', 'wurm_multi_step_reset', 'wurm_multi_step_packed', 'wurm_multi_resident_bytes', 'wurm_multi_resident_flush', 'wurm_multi_reset', 'wurm_multi_observe', 'wurm_multi_check',
+    'wurm_multi_obs_elems', 'wurm_multi_step', 'wurm_multi_step_reset', 'wurm_multi_step_packed', 'wurm_multi_resident_bytes', 'wurm_multi_resident_size', 'wurm_multi_resident_flush', 'wurm_multi_reset', 'wurm_multi_observe', 'wurm_multi_check',
     'wurm_multi_rollout',
     'wurm_multi_colours', 'wurm_orientations',
     'wurm_a2c_returns', 'wurm_a2c_returns_backward', 'wurm_single_stats', 'wurm_single_policy_rollout',
@@ -196,6 +197,44 @@ def multi_step_fn():
             fn = cfn
         _step_slot['wurm_multi_step_packed'] = fn
     return fn
+
+
+def set_option(name: str, value):
+    """Sets (value=None: back to its default) one of the library's knobs (include/wurm_hip.h: wurm_set_option); returns the
+    previous value.  The environment variable of the same name is read once, when the library is loaded."""
+    l = lib()
+    old = l.wurm_get_option(name.encode())
+    rc = l.wurm_reset_option(name.encode()) if value is None else l.wurm_set_option(name.encode(), int(value))
+    if rc != OK:
+        raise ValueError(f'unknown option {name}')
+    return old
+
+
+@contextlib.contextmanager
+def knobs(**kw):
+    """`with knobs(WURM_RESIDENT_MIN_ENVS=0): ...` — options set for the duration (None: the default), and the environment
+    variables of the same names with them, so that child processes started inside see the same values."""
+    old_opt = {k: set_option(k, v) for k, v in kw.items()}
+    old_env = {k: os.environ.get(k) for k in kw}
+    for k, v in kw.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = str(v)
+    try:
+        yield
+    finally:
+        for k, v in old_opt.items():
+            set_option(k, v)
+        for k, v in old_env.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def get_option(name: str) -> int:
+    return lib().wurm_get_option(name.encode())
 
 
 def check(rc: int, what: str):

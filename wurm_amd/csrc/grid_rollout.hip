@@ -737,15 +737,12 @@ hipError_t launch_grid_rollout(const StepArgs &p_in, hipStream_t stream)
     // configs[4], 16-step launches, median of 5 x 20 launches): 0.38-0.39 ms at 8-12 waves per CU, 0.39-0.46 ms with all
     // 32 resident — with every wave resident the launch runs in lockstep (all probing, then all storing) more often.
     // The effect is at the edge of the run-to-run noise; 12 is kept, WURM_GRID_WAVES_PER_CU overrides it.
-    static const int waves_per_cu = [] { // tuning knob, read once
-        const char *e = getenv("WURM_GRID_WAVES_PER_CU");
-        return e ? std::max(1, atoi(e)) : 12;
-    }();
+    const int waves_per_cu = (int)std::max(1ll, opt.grid_waves_per_cu); // tuning knob
     const size_t per_wave_target = (160u * 1024u / (unsigned)waves_per_cu) & ~255u;
     lds = std::min<size_t>(std::max(lds, per_wave_target * wpb), 64u * 1024u);
     (void)hipGetLastError();
-    if (grid_aligned(p)) hipLaunchKernelGGL(grid_rollout_kernel<true>, grid, block, lds, stream, p);
-    else hipLaunchKernelGGL(grid_rollout_kernel<false>, grid, block, lds, stream, p);
+    if (grid_aligned(p)) WURM_LAUNCH(grid_rollout_kernel<true>, grid, block, lds, stream, p);
+    else WURM_LAUNCH(grid_rollout_kernel<false>, grid, block, lds, stream, p);
     return hipGetLastError();
 }
 
@@ -757,8 +754,8 @@ hipError_t launch_grid_step(const StepArgs &p_in, hipStream_t stream)
     dim3 block(64 * wpb), grid((unsigned)((p.N + wpb - 1) / wpb));
     const size_t lds = (size_t)iters * 256 * sizeof(cell_t) * wpb; // one step per launch: as many waves per CU as fit
     (void)hipGetLastError();
-    if (grid_aligned(p)) hipLaunchKernelGGL(grid_step_kernel<true>, grid, block, lds, stream, p);
-    else hipLaunchKernelGGL(grid_step_kernel<false>, grid, block, lds, stream, p);
+    if (grid_aligned(p)) WURM_LAUNCH(grid_step_kernel<true>, grid, block, lds, stream, p);
+    else WURM_LAUNCH(grid_step_kernel<false>, grid, block, lds, stream, p);
     return hipGetLastError();
 }
 
@@ -770,8 +767,8 @@ hipError_t launch_grid_resident_flush(const StepArgs &p_in, hipStream_t stream)
     dim3 block(64 * wpb), grid((unsigned)((p.N + wpb - 1) / wpb));
     const size_t lds = (size_t)iters * 256 * sizeof(cell_t) * wpb;
     (void)hipGetLastError();
-    if (C % 4 == 0 && (uintptr_t)p.envs % 16 == 0) hipLaunchKernelGGL(grid_flush_kernel<true>, grid, block, lds, stream, p);
-    else hipLaunchKernelGGL(grid_flush_kernel<false>, grid, block, lds, stream, p);
+    if (C % 4 == 0 && (uintptr_t)p.envs % 16 == 0) WURM_LAUNCH(grid_flush_kernel<true>, grid, block, lds, stream, p);
+    else WURM_LAUNCH(grid_flush_kernel<false>, grid, block, lds, stream, p);
     return hipGetLastError();
 }
 

@@ -441,7 +441,7 @@ hipError_t launch_lane_resident_flush(const StepArgs &p, void *resident, hipStre
     const int wpb = waves >= 1024 ? 4 : 1;
     dim3 block(64 * wpb), grid((unsigned)((waves + wpb - 1) / wpb));
     (void)hipGetLastError();
-    hipLaunchKernelGGL(lane_resident_flush_kernel<EPW>, grid, block, (size_t)((EPW * LR_C3 + 16) * wpb), stream, a);
+    WURM_LAUNCH(lane_resident_flush_kernel<EPW>, grid, block, (size_t)((EPW * LR_C3 + 16) * wpb), stream, a);
     return hipGetLastError();
 }
 
@@ -457,15 +457,14 @@ static hipError_t launch_lane_resident_form(const StepArgs &p, void *resident, b
         const long long waves = (p.N + EPW - 1) / EPW;
         const int wpb = waves >= 1024 ? 4 : 1;
         dim3 block(64 * wpb), grid((unsigned)((waves + wpb - 1) / wpb));
-        hipLaunchKernelGGL(lane_resident_build_kernel<EPW>, grid, block, (size_t)(LaneRollLds<EPW>::BYTES * wpb), stream, a);
+        WURM_LAUNCH(lane_resident_build_kernel<EPW>, grid, block, (size_t)(LaneRollLds<EPW>::BYTES * wpb), stream, a);
         hipError_t err = hipGetLastError();
         if (err != hipSuccess) return err;
     }
     const bool crops = p.obs_mode == WURM_OBS_PARTIAL;
     const int nw = (crops && p.obs_after != nullptr) ? 2 : 1;
-    // envs per wave (0 = automatic; WURM_RESIDENT_EPW forces it, read per launch: tests and the tuning sweep)
-    int epw = 0;
-    if (const char *e = getenv("WURM_RESIDENT_EPW")) epw = atoi(e);
+    // envs per wave (automatic unless the option WURM_RESIDENT_EPW forces it: tests and the tuning sweep)
+    int epw = (int)opt.resident_epw;
     // measured (rocprofv3, us per launch at 16 / 32 / 64 envs per wave): 65 536 envs 8.5 / 7.3 / 7.6 without and 11.3 / 11.1 / -
     // with the reset observation; 32 768 envs 6.3 / 5.9 / 6.3 and 7.6 / 8.4 / -
     if (epw != 16 && epw != 32 && epw != 64) epw = nw == 1 ? (p.N >= 16384 ? 32 : 16) : (p.N >= 49152 ? 32 : 16);
@@ -474,7 +473,7 @@ static hipError_t launch_lane_resident_form(const StepArgs &p, void *resident, b
         const long long waves = (p.N + e - 1) / e;
         const int wpb = waves >= 1024 ? 4 : 1;
         dim3 block(64 * wpb), grid((unsigned)((waves + wpb - 1) / wpb));
-        hipLaunchKernelGGL(kernel, grid, block, (size_t)(LR_TAB + ResLds::BYTES * wpb), stream, a);
+        WURM_LAUNCH(kernel, grid, block, (size_t)(LR_TAB + ResLds::BYTES * wpb), stream, a);
     };
     if (!crops) {
         if (epw == 16) go(lane_resident_step_kernel<16, 1, WURM_OBS_NONE, LAZY>, 16);

@@ -570,11 +570,11 @@ bool lane_rollout_eligible(const StepArgs &p)
     return true;
 }
 
-// envs per wave: 0 = automatic.  Tests and the tuning sweep force it with WURM_LANE_ROLLOUT_EPW (read per launch).
+// envs per wave: automatic unless the option WURM_LANE_ROLLOUT_EPW forces it (tests and the tuning sweep).
 static int lane_rollout_epw(long long N)
 {
-    if (const char *e = getenv("WURM_LANE_ROLLOUT_EPW")) {
-        const int v = atoi(e);
+    {
+        const int v = (int)opt.lane_rollout_epw;
         if (v == 4 || v == 8 || v == 16 || v == 32 || v == 64) return v;
     }
     // measured (tools/tune_lane_rollout.py, profiles/r03_tune_lane_rollout.jsonl): 8 192 envs 8 per wave, 16 384 and 32 768: 16,
@@ -600,7 +600,7 @@ static hipError_t launch_lane_rollout_obs(const StepArgs &p, hipStream_t stream)
     dim3 block(64 * wpb), grid((unsigned)((waves + wpb - 1) / wpb));
     (void)hipGetLastError();
     auto go = [&](auto kernel, int lds_per_wave) {
-        hipLaunchKernelGGL(kernel, grid, block, (size_t)(LR_TAB + lds_per_wave * wpb), stream, p);
+        WURM_LAUNCH(kernel, grid, block, (size_t)(LR_TAB + lds_per_wave * wpb), stream, p);
     };
     if (inj) go(lane_rollout_kernel<16, OBSK, true>, LaneRollLds<16>::BYTES);
     else if (epw == 4) go(lane_rollout_kernel<4, OBSK, false>, LaneRollLds<4>::BYTES);

@@ -404,9 +404,9 @@ static hipError_t launch_lane_step(const StepArgs &p, hipStream_t stream)
         const long long waves = (p.N + epw - 1) / epw;
         dim3 block(64 * wpb), grid((unsigned)((waves + wpb - 1) / wpb));
         const size_t lds = (size_t)lds_per_wave * wpb;
-        if (p.S == 9) hipLaunchKernelGGL(k9, grid, block, lds, stream, a);
-        else if (p.S == 10) hipLaunchKernelGGL(k10, grid, block, lds, stream, a);
-        else hipLaunchKernelGGL(k11, grid, block, lds, stream, a);
+        if (p.S == 9) WURM_LAUNCH(k9, grid, block, lds, stream, a);
+        else if (p.S == 10) WURM_LAUNCH(k10, grid, block, lds, stream, a);
+        else WURM_LAUNCH(k11, grid, block, lds, stream, a);
     };
     if (epw == 4) go(lane_step_kernel<4, 9>, lane_step_kernel<4, 10>, lane_step_kernel<4, 11>, 4, LaneLds<4>::BYTES);
     else if (epw == 8) go(lane_step_kernel<8, 9>, lane_step_kernel<8, 10>, lane_step_kernel<8, 11>, 8, LaneLds<8>::BYTES);

@@ -2112,7 +2112,7 @@ static int multi_launch(MKind kind, MultiArgs &p, void *stream)
         dim3 block2(128), grid2((unsigned)p.N);
         (void)hipGetLastError();
         if (!allow_lds((const void *)multi_rollout_kernel<true>, (size_t)lds)) return WURM_ERR_HIP;
-        hipLaunchKernelGGL(multi_rollout_kernel<true>, grid2, block2, (size_t)lds, (hipStream_t)stream, p);
+        WURM_LAUNCH(multi_rollout_kernel<true>, grid2, block2, (size_t)lds, (hipStream_t)stream, p);
         return hipGetLastError() == hipSuccess ? WURM_OK : WURM_ERR_HIP;
     }
     if ((kind == MK_STEP || kind == MK_RESET || (kind == MK_OBSERVE && snap)) && lds * 4 > 65536 &&
@@ -2123,9 +2123,9 @@ static int multi_launch(MKind kind, MultiArgs &p, void *stream)
         const void *kf = kind == MK_STEP ? (const void *)multi_step_wg_kernel
                        : kind == MK_RESET ? (const void *)multi_reset_wg_kernel : (const void *)multi_observe_wg_kernel;
         if (!allow_lds(kf, (size_t)lds)) return WURM_ERR_HIP;
-        if (kind == MK_STEP) hipLaunchKernelGGL(multi_step_wg_kernel, g, b, (size_t)lds, (hipStream_t)stream, p);
-        else if (kind == MK_RESET) hipLaunchKernelGGL(multi_reset_wg_kernel, g, b, (size_t)lds, (hipStream_t)stream, p);
-        else hipLaunchKernelGGL(multi_observe_wg_kernel, g, b, (size_t)lds, (hipStream_t)stream, p);
+        if (kind == MK_STEP) WURM_LAUNCH(multi_step_wg_kernel, g, b, (size_t)lds, (hipStream_t)stream, p);
+        else if (kind == MK_RESET) WURM_LAUNCH(multi_reset_wg_kernel, g, b, (size_t)lds, (hipStream_t)stream, p);
+        else WURM_LAUNCH(multi_observe_wg_kernel, g, b, (size_t)lds, (hipStream_t)stream, p);
         return hipGetLastError() == hipSuccess ? WURM_OK : WURM_ERR_HIP;
     }
     while (wpb > 1 && lds * wpb > 65536) wpb >>= 1;
@@ -2139,11 +2139,11 @@ static int multi_launch(MKind kind, MultiArgs &p, void *stream)
                    : kind == MK_CHECK ? (const void *)multi_check_kernel : (const void *)multi_rollout_kernel<false>;
     if (!allow_lds(kf, shmem)) return WURM_ERR_HIP;
     switch (kind) {
-    case MK_STEP: hipLaunchKernelGGL(multi_step_kernel, grid, block, shmem, st, p); break;
-    case MK_RESET: hipLaunchKernelGGL(multi_reset_kernel, grid, block, shmem, st, p); break;
-    case MK_OBSERVE: hipLaunchKernelGGL(multi_observe_kernel, grid, block, shmem, st, p); break;
-    case MK_CHECK: hipLaunchKernelGGL(multi_check_kernel, grid, block, shmem, st, p); break;
-    case MK_ROLLOUT: hipLaunchKernelGGL(multi_rollout_kernel<false>, grid, block, shmem, st, p); break;
+    case MK_STEP: WURM_LAUNCH(multi_step_kernel, grid, block, shmem, st, p); break;
+    case MK_RESET: WURM_LAUNCH(multi_reset_kernel, grid, block, shmem, st, p); break;
+    case MK_OBSERVE: WURM_LAUNCH(multi_observe_kernel, grid, block, shmem, st, p); break;
+    case MK_CHECK: WURM_LAUNCH(multi_check_kernel, grid, block, shmem, st, p); break;
+    case MK_ROLLOUT: WURM_LAUNCH(multi_rollout_kernel<false>, grid, block, shmem, st, p); break;
     }
     return hipGetLastError() == hipSuccess ? WURM_OK : WURM_ERR_HIP;
 }
@@ -2239,12 +2239,17 @@ int wurm_multi_step_reset(const wurm_multi_call *c, void *stream)
     return multi_launch(MK_STEP, p, stream);
 }
 
-int64_t wurm_multi_resident_bytes(int64_t num_envs, int num_snakes, int size)
+int64_t wurm_multi_resident_size(int64_t num_envs, int num_snakes, int size)
 {
     if (num_envs <= 0 || num_snakes < 1 || num_snakes > 64 || size < 5 || size > 64) return 0;
-    const char *e = getenv("WURM_RESIDENT_MIN_ENVS");
-    const bool big = e ? num_envs >= atoll(e) : num_envs * (long long)num_snakes * size * size >= (1ll << 20);
-    return big ? num_envs * mirror_env_bytes(num_snakes, size * size) : 0;
+    return num_envs * mirror_env_bytes(num_snakes, size * size);
+}
+
+int64_t wurm_multi_resident_bytes(int64_t num_envs, int num_snakes, int size)
+{
+    const long long e = opt.resident_min_envs; // -1: by shape
+    const bool big = e >= 0 ? num_envs >= e : num_envs * (long long)num_snakes * size * size >= (1ll << 20);
+    return big ? wurm_multi_resident_size(num_envs, num_snakes, size) : 0;
 }
 
 int wurm_multi_resident_flush(const wurm_multi_call *c, void *stream)
@@ -2256,7 +2261,7 @@ int wurm_multi_resident_flush(const wurm_multi_call *c, void *stream)
     p.foods = c->foods; p.heads = c->heads; p.bodies = c->bodies; p.N = c->num_envs; p.K = c->num_snakes; p.S = c->size;
     p.resident = (unsigned char *)c->resident;
     (void)hipGetLastError();
-    hipLaunchKernelGGL(multi_flush_kernel, dim3((unsigned)p.N), dim3(256), 0, (hipStream_t)stream, p);
+    WURM_LAUNCH(multi_flush_kernel, dim3((unsigned)p.N), dim3(256), 0, (hipStream_t)stream, p);
     return hipGetLastError() == hipSuccess ? WURM_OK : WURM_ERR_HIP;
 }
 
@@ -2369,7 +2374,7 @@ int wurm_multi_colours(int16_t *colours, int64_t num_envs, int num_snakes, int f
     if (!colours) return WURM_ERR_INVALID_ARG;
     long long n = (long long)num_envs * num_snakes;
     (void)hipGetLastError();
-    hipLaunchKernelGGL(multi_colours_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+    WURM_LAUNCH(multi_colours_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        colours, (long long)num_envs, num_snakes, fixed, seed, call, (long long)env_offset);
     return hipGetLastError() == hipSuccess ? WURM_OK : WURM_ERR_HIP;
 }

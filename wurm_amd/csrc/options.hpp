@@ -1,0 +1,27 @@
+// options.hpp — tuning / test knobs of the library, read ONCE (at library load, from the environment) and changed
+// afterwards only through wurm_set_option (include/wurm_hip.h).  Launch paths read plain fields of `wurm::opt`: no
+// getenv on any path whose whole budget is a few microseconds.
+#pragma once
+
+namespace wurm {
+
+struct Options {
+    long long grid_step_min_cells;   // WURM_GRID_STEP_MIN_CELLS   per-call LDS clock-grid step from this many cells (2^20)
+    long long lane_step_min_envs;    // WURM_LANE_STEP_MIN_ENVS    per-call one-env-per-lane step from this many envs (12288)
+    long long lane_rollout_min_envs; // WURM_LANE_ROLLOUT_MIN_ENVS one-env-per-lane rollout from this many envs (6144)
+    long long lane_rollout_epw;      // WURM_LANE_ROLLOUT_EPW      envs per wave of that rollout (-1 = by batch size)
+    long long resident_min_envs;     // WURM_RESIDENT_MIN_ENVS     resident mirror from this many envs (-1 = by shape)
+    long long resident_epw;          // WURM_RESIDENT_EPW          envs per wave of the resident step (-1 = by batch size)
+    long long grid_waves_per_cu;     // WURM_GRID_WAVES_PER_CU     residency of the clock-grid rollout (12)
+    long long policy_generic;        // WURM_POLICY_GENERIC        1 = fused actor on the generic loop even on 9 x 9
+    long long multi_group_min_envs;  // WURM_MULTI_GROUP_MIN_ENVS  MultiSnake 'full' rollout: grouped writer from this many envs
+};
+
+extern Options opt;
+
+// number of kernels this library has launched in this process (wurm_launch_count, include/wurm_hip.h): bench.py reports
+// launches per loop iteration from it.  Plain increments: the Python classes launch from one thread.
+extern long long launch_count;
+#define WURM_LAUNCH(...) do { ++::wurm::launch_count; hipLaunchKernelGGL(__VA_ARGS__); } while (0)
+
+} // namespace wurm

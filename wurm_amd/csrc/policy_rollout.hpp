@@ -453,23 +453,23 @@ static int launch_policy_rollout(const PolicyArgs &p, int obs_n, void *stream)
     dim3 grid((unsigned)p.N), block(64);
     hipStream_t st = (hipStream_t)stream;
     (void)hipGetLastError();
-    const bool s9 = p.S == 9 && !getenv("WURM_POLICY_GENERIC"); // (debug switch: time / test the generic loop on 9x9 grids)
+    const bool s9 = p.S == 9 && !opt.policy_generic; // (debug switch: time / test the generic loop on 9x9 grids)
     switch (obs_n) {
     case 0:
-        if (s9) hipLaunchKernelGGL(policy_rollout_s9_kernel<0>, grid, block, lds, st, p);
-        else hipLaunchKernelGGL(policy_rollout_kernel<0>, grid, block, lds, st, p);
+        if (s9) WURM_LAUNCH(policy_rollout_s9_kernel<0>, grid, block, lds, st, p);
+        else WURM_LAUNCH(policy_rollout_kernel<0>, grid, block, lds, st, p);
         break;
     case 1:
-        if (s9) hipLaunchKernelGGL(policy_rollout_s9_kernel<1>, grid, block, lds, st, p);
-        else hipLaunchKernelGGL(policy_rollout_kernel<1>, grid, block, lds, st, p);
+        if (s9) WURM_LAUNCH(policy_rollout_s9_kernel<1>, grid, block, lds, st, p);
+        else WURM_LAUNCH(policy_rollout_kernel<1>, grid, block, lds, st, p);
         break;
     case 2:
-        if (s9) hipLaunchKernelGGL(policy_rollout_s9_kernel<2>, grid, block, lds, st, p);
-        else hipLaunchKernelGGL(policy_rollout_kernel<2>, grid, block, lds, st, p);
+        if (s9) WURM_LAUNCH(policy_rollout_s9_kernel<2>, grid, block, lds, st, p);
+        else WURM_LAUNCH(policy_rollout_kernel<2>, grid, block, lds, st, p);
         break;
     case 3:
-        if (s9) hipLaunchKernelGGL(policy_rollout_s9_kernel<3>, grid, block, lds, st, p);
-        else hipLaunchKernelGGL(policy_rollout_kernel<3>, grid, block, lds, st, p);
+        if (s9) WURM_LAUNCH(policy_rollout_s9_kernel<3>, grid, block, lds, st, p);
+        else WURM_LAUNCH(policy_rollout_kernel<3>, grid, block, lds, st, p);
         break;
     default: return WURM_ERR_UNSUPPORTED;
     }

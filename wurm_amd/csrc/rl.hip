@@ -109,7 +109,7 @@ int wurm_a2c_returns(const float *bootstrap, const float *rewards, const float *
     if (num_steps == 0 || num_envs == 0) return WURM_OK;
     if (!bootstrap || !rewards || !dones || !returns || (use_gae && !values)) return WURM_ERR_INVALID_ARG;
     (void)hipGetLastError();
-    hipLaunchKernelGGL(a2c_returns_kernel, dim3((unsigned)((num_envs + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+    WURM_LAUNCH(a2c_returns_kernel, dim3((unsigned)((num_envs + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        bootstrap, rewards, values, dones, gamma, use_gae, gamma_lambda, returns, (long long)num_steps,
                        (long long)num_envs);
     return hipGetLastError() == hipSuccess ? WURM_OK : WURM_ERR_HIP;
@@ -123,7 +123,7 @@ int wurm_a2c_returns_backward(const float *grad_returns, const uint8_t *dones, f
     if (num_envs == 0) return WURM_OK;
     if (!grad_returns || !dones) return WURM_ERR_INVALID_ARG;
     (void)hipGetLastError();
-    hipLaunchKernelGGL(a2c_returns_backward_kernel, dim3((unsigned)((num_envs + 255) / 256)), dim3(256), 0,
+    WURM_LAUNCH(a2c_returns_backward_kernel, dim3((unsigned)((num_envs + 255) / 256)), dim3(256), 0,
                        (hipStream_t)stream, grad_returns, dones, gamma, use_gae, gamma_lambda, grad_values,
                        grad_bootstrap, (long long)num_steps, (long long)num_envs);
     return hipGetLastError() == hipSuccess ? WURM_OK : WURM_ERR_HIP;
@@ -136,7 +136,7 @@ int wurm_single_stats(const float *envs, const float *reward, const uint8_t *don
     if (num_envs == 0) return WURM_OK;
     if (!envs || !reward || !done || !self_collision || !edge_collision || !accum) return WURM_ERR_INVALID_ARG;
     (void)hipGetLastError();
-    hipLaunchKernelGGL(single_stats_kernel, dim3((unsigned)((num_envs + 3) / 4)), dim3(256), 0, (hipStream_t)stream, envs,
+    WURM_LAUNCH(single_stats_kernel, dim3((unsigned)((num_envs + 3) / 4)), dim3(256), 0, (hipStream_t)stream, envs,
                        reward, done, self_collision, edge_collision, accum, (long long)num_envs, size);
     return hipGetLastError() == hipSuccess ? WURM_OK : WURM_ERR_HIP;
 }

@@ -1633,36 +1633,30 @@ static hipError_t launch_one(Kind kind, const StepArgs &p, dim3 grid, dim3 block
     if constexpr (SNAKE && CPL >= 4) {
         // large batches of large grids: the LDS clock-grid step (grid_rollout.hip: 16-byte loads, 34 VGPRs), then the
         // generic kernel for the envs it could not take.  Small batches stay on one launch: they are latency-bound.
-        static const long long min_cells = [] { // read once; tests force the path with WURM_GRID_STEP_MIN_CELLS=0
-            const char *e = getenv("WURM_GRID_STEP_MIN_CELLS");
-            return e ? atoll(e) : (1ll << 20);
-        }();
+        const long long min_cells = opt.grid_step_min_cells; // (tests force the path with WURM_GRID_STEP_MIN_CELLS = 0)
         if ((kind == K_STEP || kind == K_FUSED) && grid_step_eligible(p) &&
             (p.N * (long long)p.S * p.S >= min_cells || p.resident != nullptr)) { // (a mirror is kept by this kernel only)
             hipError_t err = launch_grid_step(p, st);
             if (err != hipSuccess) return err;
             StepArgs q = p;
             q.only_flagged = 1;
-            if (kind == K_STEP) hipLaunchKernelGGL((step_kernel<CPL, SNAKE>), grid, block, lds, st, q);
-            else hipLaunchKernelGGL((fused_step_kernel<CPL, SNAKE>), grid, block, lds, st, q);
+            if (kind == K_STEP) WURM_LAUNCH((step_kernel<CPL, SNAKE>), grid, block, lds, st, q);
+            else WURM_LAUNCH((fused_step_kernel<CPL, SNAKE>), grid, block, lds, st, q);
             return hipGetLastError();
         }
     }
     if constexpr (SNAKE && CPL == 2) {
         // large batches of small grids: one env per LANE (lane_step.hpp); envs outside its domain are stepped by the
         // one-env-per-wave code inside the same launch
-        static const long long min_envs = [] { // read once; tests force the path with WURM_LANE_STEP_MIN_ENVS=0
-            const char *e = getenv("WURM_LANE_STEP_MIN_ENVS");
-            return e ? atoll(e) : 12288ll;
-        }();
+        const long long min_envs = opt.lane_step_min_envs; // (tests force the path with WURM_LANE_STEP_MIN_ENVS = 0)
         if ((kind == K_STEP || kind == K_FUSED) && p.N >= min_envs && lane_step_eligible(p))
             return launch_lane_step(p, st);
     }
     switch (kind) {
-    case K_STEP: hipLaunchKernelGGL((step_kernel<CPL, SNAKE>), grid, block, lds, st, p); break;
-    case K_RESET: hipLaunchKernelGGL((reset_kernel<CPL, SNAKE>), grid, block, lds, st, p); break;
-    case K_OBSERVE: hipLaunchKernelGGL((observe_kernel<CPL, SNAKE>), grid, block, lds, st, p); break;
-    case K_FUSED: hipLaunchKernelGGL((fused_step_kernel<CPL, SNAKE>), grid, block, lds, st, p); break;
+    case K_STEP: WURM_LAUNCH((step_kernel<CPL, SNAKE>), grid, block, lds, st, p); break;
+    case K_RESET: WURM_LAUNCH((reset_kernel<CPL, SNAKE>), grid, block, lds, st, p); break;
+    case K_OBSERVE: WURM_LAUNCH((observe_kernel<CPL, SNAKE>), grid, block, lds, st, p); break;
+    case K_FUSED: WURM_LAUNCH((fused_step_kernel<CPL, SNAKE>), grid, block, lds, st, p); break;
     case K_ROLLOUT:
         if constexpr (SNAKE && CPL >= 4) {
             if (grid_rollout_eligible(p)) {
@@ -1671,49 +1665,48 @@ static hipError_t launch_one(Kind kind, const StepArgs &p, dim3 grid, dim3 block
                 if (err != hipSuccess) return err;
                 StepArgs q = p;
                 q.only_flagged = 1;
-                hipLaunchKernelGGL((rollout_kernel<CPL, SNAKE>), grid, block, lds, st, q);
+                WURM_LAUNCH((rollout_kernel<CPL, SNAKE>), grid, block, lds, st, q);
                 break;
             }
         }
         if constexpr (SNAKE && CPL == 2) {
             // large batches of 9 x 9: one env per LANE (lane_rollout.hpp); envs outside its domain are rolled out by the
             // one-env-per-wave code inside the same launch
-            // (threshold read per launch: a rollout launch is long, and the tests switch it with WURM_LANE_ROLLOUT_MIN_ENVS)
-            const char *lane_env = getenv("WURM_LANE_ROLLOUT_MIN_ENVS");
-            if (p.N >= (lane_env ? atoll(lane_env) : 6144ll) && lane_rollout_eligible(p)) return launch_lane_rollout(p, st);
+            // (the tests switch the threshold with wurm_set_option("WURM_LANE_ROLLOUT_MIN_ENVS", ..))
+            if (p.N >= opt.lane_rollout_min_envs && lane_rollout_eligible(p)) return launch_lane_rollout(p, st);
             const bool rng_mode = p.inject_food == nullptr && p.inject_reset == nullptr;
             if (p.inject_food != nullptr && p.inject_reset != nullptr && p.S == 9 &&
                 ((p.obs_mode == WURM_OBS_PARTIAL && p.obs_n <= 3) || p.obs_mode == WURM_OBS_NONE)) {
                 // recorded outcomes through the headline kernel itself
                 if (p.obs_mode == WURM_OBS_NONE)
-                    hipLaunchKernelGGL((rollout_s9_kernel<WURM_OBS_NONE, true>), grid, block, lds, st, p);
+                    WURM_LAUNCH((rollout_s9_kernel<WURM_OBS_NONE, true>), grid, block, lds, st, p);
                 else
-                    hipLaunchKernelGGL((rollout_s9_kernel<WURM_OBS_PARTIAL, true>), grid, block, lds, st, p);
+                    WURM_LAUNCH((rollout_s9_kernel<WURM_OBS_PARTIAL, true>), grid, block, lds, st, p);
                 break;
             }
             if (rng_mode && p.S >= 9 && ((p.obs_mode == WURM_OBS_PARTIAL && p.obs_n <= 3) || p.obs_mode == WURM_OBS_NONE)) {
                 if (p.S == 9 && p.obs_mode == WURM_OBS_NONE)
-                    hipLaunchKernelGGL((rollout_s9_kernel<WURM_OBS_NONE>), grid, block, lds, st, p);
+                    WURM_LAUNCH((rollout_s9_kernel<WURM_OBS_NONE>), grid, block, lds, st, p);
                 else if (p.S == 9)
-                    hipLaunchKernelGGL((rollout_s9_kernel<WURM_OBS_PARTIAL>), grid, block, lds, st, p);
+                    WURM_LAUNCH((rollout_s9_kernel<WURM_OBS_PARTIAL>), grid, block, lds, st, p);
                 else if (p.obs_mode == WURM_OBS_NONE)
-                    hipLaunchKernelGGL((rollout_lean_kernel<WURM_OBS_NONE, false>), grid, block, lds, st, p);
+                    WURM_LAUNCH((rollout_lean_kernel<WURM_OBS_NONE, false>), grid, block, lds, st, p);
                 else if (p.S <= 9)
-                    hipLaunchKernelGGL((rollout_lean_kernel<WURM_OBS_PARTIAL, true>), grid, block, lds, st, p);
+                    WURM_LAUNCH((rollout_lean_kernel<WURM_OBS_PARTIAL, true>), grid, block, lds, st, p);
                 else
-                    hipLaunchKernelGGL((rollout_lean_kernel<WURM_OBS_PARTIAL, false>), grid, block, lds, st, p);
+                    WURM_LAUNCH((rollout_lean_kernel<WURM_OBS_PARTIAL, false>), grid, block, lds, st, p);
                 break;
             }
             if (rng_mode && p.obs_mode == WURM_OBS_PARTIAL && p.obs_n <= 6) {
-                hipLaunchKernelGGL((rollout_kernel<CPL, SNAKE, WURM_OBS_PARTIAL, false>), grid, block, lds, st, p);
+                WURM_LAUNCH((rollout_kernel<CPL, SNAKE, WURM_OBS_PARTIAL, false>), grid, block, lds, st, p);
                 break;
             }
             if (rng_mode && p.obs_mode == WURM_OBS_NONE) {
-                hipLaunchKernelGGL((rollout_kernel<CPL, SNAKE, WURM_OBS_NONE, false>), grid, block, lds, st, p);
+                WURM_LAUNCH((rollout_kernel<CPL, SNAKE, WURM_OBS_NONE, false>), grid, block, lds, st, p);
                 break;
             }
         }
-        hipLaunchKernelGGL((rollout_kernel<CPL, SNAKE>), grid, block, lds, st, p);
+        WURM_LAUNCH((rollout_kernel<CPL, SNAKE>), grid, block, lds, st, p);
         break;
     }
     return hipGetLastError();
@@ -1918,19 +1911,25 @@ int wurm_single_resident_flush(const wurm_single_call *c, void *stream)
     return err == hipSuccess ? WURM_OK : WURM_ERR_HIP;
 }
 
+int64_t wurm_single_resident_size(int64_t num_envs, int size, int obs_mode, int obs_n)
+{
+    if (num_envs <= 0) return 0;
+    if (lane_resident_shape(size, obs_mode, obs_n)) return num_envs * 32; // 9 x 9: 32 bytes per env (lane_resident.hpp)
+    StepArgs p = {};
+    p.S = size;
+    if (grid_step_eligible(p) && obs_elems(true, obs_mode, obs_n, size) >= 0) // 12 x 12 and larger: grid + record per env
+        return grid_resident_bytes(num_envs, size);
+    return 0;
+}
+
 int64_t wurm_single_resident_bytes(int64_t num_envs, int size, int obs_mode, int obs_n)
 {
     if (num_envs <= 0) return 0;
-    const char *e = getenv("WURM_RESIDENT_MIN_ENVS");
-    if (lane_resident_shape(size, obs_mode, obs_n)) // 9 x 9: 32 bytes per env (lane_resident.hpp)
-        return num_envs >= (e ? atoll(e) : 4096ll) ? num_envs * 32 : 0;
-    StepArgs p = {};
-    p.S = size;
-    if (grid_step_eligible(p) && obs_elems(true, obs_mode, obs_n, size) >= 0) { // 12 x 12 and larger: grid + record per env
-        const bool big = e ? num_envs >= atoll(e) : num_envs * (long long)size * size >= (1ll << 20);
-        return big ? grid_resident_bytes(num_envs, size) : 0;
-    }
-    return 0;
+    const long long e = opt.resident_min_envs; // -1: by shape
+    const bool big = e >= 0 ? num_envs >= e
+                            : (lane_resident_shape(size, obs_mode, obs_n) ? num_envs >= 4096
+                                                                          : num_envs * (long long)size * size >= (1ll << 20));
+    return big ? wurm_single_resident_size(num_envs, size, obs_mode, obs_n) : 0;
 }
 
 int wurm_single_step_reset(const wurm_single_call *c, void *stream) { return fused_entry(true, c, stream); }
@@ -2012,14 +2011,14 @@ int wurm_single_check(const float *envs, uint32_t *err, int64_t num_envs, int si
     long long N = num_envs;
     (void)hipGetLastError();
     switch (cpl) {
-    case 2: hipLaunchKernelGGL(check_kernel<2>, grid, block, 0, st, envs, err, N, size); break;
-    case 4: hipLaunchKernelGGL(check_kernel<4>, grid, block, 0, st, envs, err, N, size); break;
-    case 8: hipLaunchKernelGGL(check_kernel<8>, grid, block, 0, st, envs, err, N, size); break;
-    case 16: hipLaunchKernelGGL(check_kernel<16>, grid, block, 0, st, envs, err, N, size); break;
-    case 24: hipLaunchKernelGGL(check_kernel<24>, grid, block, 0, st, envs, err, N, size); break;
-    case 32: hipLaunchKernelGGL(check_kernel<32>, grid, block, 0, st, envs, err, N, size); break;
-    case 48: hipLaunchKernelGGL(check_kernel<48>, grid, block, 0, st, envs, err, N, size); break;
-    default: hipLaunchKernelGGL(check_kernel<64>, grid, block, 0, st, envs, err, N, size); break;
+    case 2: WURM_LAUNCH(check_kernel<2>, grid, block, 0, st, envs, err, N, size); break;
+    case 4: WURM_LAUNCH(check_kernel<4>, grid, block, 0, st, envs, err, N, size); break;
+    case 8: WURM_LAUNCH(check_kernel<8>, grid, block, 0, st, envs, err, N, size); break;
+    case 16: WURM_LAUNCH(check_kernel<16>, grid, block, 0, st, envs, err, N, size); break;
+    case 24: WURM_LAUNCH(check_kernel<24>, grid, block, 0, st, envs, err, N, size); break;
+    case 32: WURM_LAUNCH(check_kernel<32>, grid, block, 0, st, envs, err, N, size); break;
+    case 48: WURM_LAUNCH(check_kernel<48>, grid, block, 0, st, envs, err, N, size); break;
+    default: WURM_LAUNCH(check_kernel<64>, grid, block, 0, st, envs, err, N, size); break;
     }
     return hipGetLastError() == hipSuccess ? WURM_OK : WURM_ERR_HIP;
 }
@@ -2039,14 +2038,14 @@ int wurm_orientations(const float *envs, int64_t *out, int64_t n, int size, void
     size_t lds = (size_t)lpw * wpb;
     (void)hipGetLastError();
     switch (cpl) {
-    case 2: hipLaunchKernelGGL(orientations_kernel<2>, grid, block, lds, st, envs, o, N, size, lpw); break;
-    case 4: hipLaunchKernelGGL(orientations_kernel<4>, grid, block, lds, st, envs, o, N, size, lpw); break;
-    case 8: hipLaunchKernelGGL(orientations_kernel<8>, grid, block, lds, st, envs, o, N, size, lpw); break;
-    case 16: hipLaunchKernelGGL(orientations_kernel<16>, grid, block, lds, st, envs, o, N, size, lpw); break;
-    case 24: hipLaunchKernelGGL(orientations_kernel<24>, grid, block, lds, st, envs, o, N, size, lpw); break;
-    case 32: hipLaunchKernelGGL(orientations_kernel<32>, grid, block, lds, st, envs, o, N, size, lpw); break;
-    case 48: hipLaunchKernelGGL(orientations_kernel<48>, grid, block, lds, st, envs, o, N, size, lpw); break;
-    default: hipLaunchKernelGGL(orientations_kernel<64>, grid, block, lds, st, envs, o, N, size, lpw); break;
+    case 2: WURM_LAUNCH(orientations_kernel<2>, grid, block, lds, st, envs, o, N, size, lpw); break;
+    case 4: WURM_LAUNCH(orientations_kernel<4>, grid, block, lds, st, envs, o, N, size, lpw); break;
+    case 8: WURM_LAUNCH(orientations_kernel<8>, grid, block, lds, st, envs, o, N, size, lpw); break;
+    case 16: WURM_LAUNCH(orientations_kernel<16>, grid, block, lds, st, envs, o, N, size, lpw); break;
+    case 24: WURM_LAUNCH(orientations_kernel<24>, grid, block, lds, st, envs, o, N, size, lpw); break;
+    case 32: WURM_LAUNCH(orientations_kernel<32>, grid, block, lds, st, envs, o, N, size, lpw); break;
+    case 48: WURM_LAUNCH(orientations_kernel<48>, grid, block, lds, st, envs, o, N, size, lpw); break;
+    default: WURM_LAUNCH(orientations_kernel<64>, grid, block, lds, st, envs, o, N, size, lpw); break;
     }
     return hipGetLastError() == hipSuccess ? WURM_OK : WURM_ERR_HIP;
 }

@@ -9,6 +9,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "options.hpp"
+
 namespace wurm {
 
 typedef unsigned long long u64;

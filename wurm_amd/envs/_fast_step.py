@@ -38,6 +38,19 @@ import torch
 from wurm_amd import _lib
 
 
+def parse_mirror_policy(value):
+    """`resident_mirror` keyword of the env classes -> None (automatic: by batch size, with the adaptive rules), False
+    (never), 'lazy' (whenever the shape is served, no adaptive rule; True means this) or 'eager' (the same, but every step
+    also writes the state tensors)."""
+    if value is None or value is False:
+        return value
+    if value is True or value == 'lazy':
+        return 'lazy'
+    if value == 'eager':
+        return 'eager'
+    raise ValueError("resident_mirror must be None, True, False, 'lazy' or 'eager'")
+
+
 class PyStepper(object):
     """Pure-Python twin of wurm_amd._fastcall.Stepper (same attributes, same methods, same results).
 
@@ -166,8 +179,13 @@ class FastStepMixin(object):
         # batches).  The library marks it current after each step launch; everything else that writes the state clears
         # the mark (_touch); a state tensor the caller got hold of is watched for in-place edits through its version counter
         self._mirror, self._mirror_key, self._mirror_off = None, None, False
-        self._lazy_mirror = os.environ.get('WURM_RESIDENT_LAZY', '1') != '0'
+        pol = parse_mirror_policy(getattr(self, '_resident_policy', None))
+        self._resident_policy = pol
+        if pol is False:
+            self._mirror_off = True
+        self._lazy_mirror = pol != 'eager' and os.environ.get('WURM_RESIDENT_LAZY', '1') != '0'
         self._write_outs = self._touches = self._mirror_step0 = 0
+        self._mirror_why = 'resident_mirror=False' if pol is False else 'no step yet'
 
     # state of the step machine that other methods of the classes read and write
     _call = property(lambda self: self._fs.call, lambda self, v: setattr(self._fs, 'call', v))
@@ -260,9 +278,12 @@ class FastStepMixin(object):
             # a loop in which (nearly) every step is followed by something that writes the state some other way — an eager
             # reset, a rollout — rebuilds the mirror every step for nothing: switch it off for this env object
             self._touches += 1
-            if self._touches >= 8 and 2 * self._touches >= self._fs.steps - self._mirror_step0:
+            if self._resident_policy is None and self._touches >= 8 and \
+                    2 * self._touches >= self._fs.steps - self._mirror_step0:
                 self._mirror_off, self._mirror, self._mirror_key = True, None, None
                 c.resident = None
+                self._mirror_why = ('adaptive: the state was written by something other than the step launch after %d of the '
+                                    'last %d steps' % (self._touches, self._fs.steps - self._mirror_step0))
         c.resident_valid = 0
 
     def _write_out(self):
@@ -275,8 +296,9 @@ class FastStepMixin(object):
             # a caller that keeps looking at the state (check_consistency() every step, experiments/main.py:214-215) pays
             # a whole-state write per look in the lazy form: from the second one on the steps write `envs` themselves
             self._write_outs += 1
-            if self._write_outs >= 2:
+            if self._write_outs >= 2 and self._resident_policy is None:
                 c.resident_lazy = 0
+                self._mirror_why = 'adaptive: the state was looked at twice, every step writes `envs` from now on'
 
     def _watch(self, t):
         """The caller holds the state tensor `t` from now on and may edit it in place at any time: every step compares its
@@ -284,12 +306,15 @@ class FastStepMixin(object):
         counters (made under torch.inference_mode()) cannot be watched: no mirror from then on."""
         fs = self._fs
         self._c.resident_lazy = 0  # the caller may READ it at any time as well: the step launches write `envs` from now on
+        if self._mirror is not None:
+            self._mirror_why = 'the caller holds the state tensor: every step writes `envs`, in-place edits are watched'
         try:
             fs.watch, fs.watch_version = t, t._version
         except (RuntimeError, AttributeError):
             fs.watch, fs.watch_version = None, -1
             self._mirror_off, self._mirror, self._mirror_key = True, None, None
             self._c.resident, self._c.resident_valid = None, 0
+            self._mirror_why = 'the state tensor has no version counter (inference mode): cannot be watched'
 
     def _mirror_sync(self):
         """the step machine saw another version of the watched state tensor: the mirror is stale"""
@@ -308,10 +333,18 @@ class FastStepMixin(object):
         key = (m, n)
         if key == self._mirror_key:
             return
+        # another observation mode: a LAZY mirror holds steps `envs` has not seen — written out while the old mirror is
+        # still the one the call block names, before it is replaced or dropped
+        self._touch()
         self._mirror_key = key
         nbytes = 0
         if self._CHANNELS == 3 and not self._mirror_off:
-            nbytes = int(_lib.lib().wurm_single_resident_bytes(_lib.i64(self.num_envs), self.size, m, n))
+            size_fn = _lib.lib().wurm_single_resident_bytes if self._resident_policy is None else \
+                _lib.lib().wurm_single_resident_size
+            nbytes = int(size_fn(_lib.i64(self.num_envs), self.size, m, n))
+            if not self._mirror_off:
+                self._mirror_why = ('shape / observation mode not served by the mirror kernels, or batch below the threshold'
+                                    if nbytes == 0 else 'on')
         self._mirror = torch.empty(nbytes, dtype=torch.uint8, device=self.device) if nbytes > 0 else None
         self._touches, self._mirror_step0 = 0, self._fs.steps
         self._c.resident = self._mirror.data_ptr() if self._mirror is not None else None
@@ -319,7 +352,20 @@ class FastStepMixin(object):
         # lazy (the step launches do not write `envs`, _touch() brings them up to date) as long as the caller has never
         # got hold of the state tensor
         self._c.resident_lazy = int(self._mirror is not None and self._fs.watch is None and self._lazy_mirror and
-                                    self._write_outs < 2)
+                                    (self._write_outs < 2 or self._resident_policy is not None))
+        if self._mirror is not None and self._fs.watch is not None:
+            self._mirror_why = 'the caller holds the state tensor: every step writes `envs`, in-place edits are watched'
+
+    def mirror_state(self) -> dict:
+        """What the resident mirror of the state is doing for this env object right now:
+        `state` 'off' (every step reads `envs`), 'eager' (steps read the mirror and write `envs`) or 'lazy' (steps do
+        not write `envs`; they are written out when something looks at them); `why`; `policy` (the `resident_mirror`
+        keyword: None = automatic); `current`: the mirror describes the state (False: the next step rebuilds it)."""
+        c = self._c
+        on = bool(c.resident) and self._mirror is not None
+        return {'state': 'off' if not on else ('lazy' if c.resident_lazy else 'eager'), 'why': self._mirror_why,
+                'policy': self._resident_policy, 'current': bool(on and c.resident_valid),
+                'bytes': int(self._mirror.numel()) if on else 0}
 
     def _checked(self, e: torch.Tensor) -> torch.Tensor:
         if e is self._envs_ok:

@@ -79,6 +79,9 @@ class _Flushing(object):
             obj._flush()  # the reference applied the reset before this assignment; the other tensors still need it
         if self.slot in _MIRRORED:
             obj._touch()   # (a lazy mirror is written out to the tensors as they are before one of them is replaced)
+            old = getattr(obj, self.slot, None)  # the tensor being replaced is no longer part of the state: not watched
+            if old is not None and obj._watched:
+                obj._watched = tuple((x, v) for x, v in obj._watched if x is not old)
         obj._last_fresh = False
         obj._chk_fresh = False
         obj._state_dirty = True  # step() re-validates the layout and re-reads the pointers
@@ -142,7 +145,17 @@ class MultiSnake(object):
                  agent_colours: str = 'random',
                  seed: int = None,
                  env_offset: int = 0,
-                 lazy_reset: bool = True):
+                 lazy_reset: bool = True,
+                 resident_mirror=None):
+        """Reference keywords (multi_snake.py:56-75) plus this build's: `seed`, `env_offset`, `lazy_reset` and
+        `resident_mirror` — None: large batches step on a compact mirror of foods / heads / bodies chosen
+        by batch size with adaptive rules; False: never; True / 'lazy' / 'eager': always, without the adaptive rules
+        (`env.mirror_state()` tells what is in effect and why)."""
+        from wurm_amd.envs._fast_step import parse_mirror_policy
+        self._resident_policy = pol = parse_mirror_policy(resident_mirror)
+        self._mirror_off = pol is False
+        self._lazy_mirror = pol != 'eager' and MultiSnake._lazy_mirror
+        self._mirror_why = 'resident_mirror=False' if pol is False else 'no step yet'
         self.num_envs = num_envs
         self.num_snakes = num_snakes
         self.lazy_reset = bool(lazy_reset)
@@ -297,9 +310,10 @@ class MultiSnake(object):
             # a caller that keeps looking at the state (experiments/speeds.py:30-38: check_consistency() every step) pays a
             # whole-state write per look in the lazy form: from the second one on the steps write the tensors themselves
             self._write_outs += 1
-            if self._write_outs >= 2:
+            if self._write_outs >= 2 and self._resident_policy is None:
                 c.resident_lazy = 0
                 self._lazy_mirror = False
+                self._mirror_why = 'adaptive: the state was looked at twice, every step writes the tensors from now on'
 
     def _touch(self):
         """something other than the step launch is about to read or write the state tensors"""
@@ -312,9 +326,11 @@ class MultiSnake(object):
                 # eager reset: experiments/speeds.py's check_consistency() flushes the postponed one every step) rebuilds
                 # the mirror every step for nothing: switch it off for this env object
                 self._touches += 1
-                if self._touches >= 8 and 2 * self._touches >= self._steps:
+                if self._resident_policy is None and self._touches >= 8 and 2 * self._touches >= self._steps:
                     self._mirror_off, self._mirror = True, None
                     c.resident = None
+                    self._mirror_why = ('adaptive: the state was written by something other than the step launch after %d '
+                                        'of %d steps' % (self._touches, self._steps))
             c.resident_valid = 0
 
     def _escape(self, t):
@@ -325,9 +341,12 @@ class MultiSnake(object):
         if self._mc is not None:
             self._mc.resident_lazy = 0
         self._lazy_mirror = False
+        if not self._mirror_off:
+            self._mirror_why = 'the caller holds a state tensor: every step writes them, in-place edits are watched'
         ver = _version_of(t) if isinstance(t, torch.Tensor) else -1
         if ver < 0:
             self._mirror_off, self._mirror = True, None
+            self._mirror_why = 'a state tensor has no version counter (inference mode): cannot be watched'
             if self._mc is not None:
                 self._mc.resident, self._mc.resident_valid = None, 0
             return
@@ -346,6 +365,17 @@ class MultiSnake(object):
                 self._mirror_off, self._mirror, self._watched = True, None, ()
                 self._mc.resident, self._mc.resident_valid = None, 0
         return ok
+
+    def mirror_state(self) -> dict:
+        """What the resident mirror of foods / heads / bodies is doing for this env object right now: `state` 'off' / 'eager'
+        (steps read the mirror and write the tensors) / 'lazy' (steps do not write them; they are written out when something
+        looks at them), `why`, `policy` (the `resident_mirror` keyword; None = automatic), `current` (the mirror describes
+        the state; False: the next step rebuilds it)."""
+        c = self._mc
+        on = c is not None and bool(c.resident) and self._mirror is not None
+        return {'state': 'off' if not on else ('lazy' if c.resident_lazy else 'eager'), 'why': self._mirror_why,
+                'policy': self._resident_policy, 'current': bool(on and c.resident_valid),
+                'bytes': int(self._mirror.numel()) if on else 0}
 
     def _log(self, msg: str):
         if self.verbose > 0:
@@ -518,7 +548,11 @@ class MultiSnake(object):
                                                                  'boost_', 'size_'))
                 # the resident mirror of foods / heads / bodies (large batches): the launch reads it instead of them;
                 # lazy (they are not written either) as long as the caller has never got hold of one of them
-                nbytes = 0 if self._mirror_off else int(_lib.lib().wurm_multi_resident_bytes(_lib.i64(N), K, S))
+                size_fn = _lib.lib().wurm_multi_resident_bytes if self._resident_policy is None else \
+                    _lib.lib().wurm_multi_resident_size
+                nbytes = 0 if self._mirror_off else int(size_fn(_lib.i64(N), K, S))
+                if not self._mirror_off:
+                    self._mirror_why = 'on' if nbytes > 0 else 'batch below the threshold (2^20 cells), or shape not served'
                 if nbytes > 0:
                     self._mirror = torch.empty(nbytes, dtype=torch.uint8, device=dev)
                     c.resident, c.resident_valid = self._mirror.data_ptr(), 0
@@ -680,6 +714,8 @@ class MultiSnake(object):
         """(N) int32 masks of the state as it is now, computed inside the last step's launch (wurm_multi_call.check_mask /
         check_mask_after), or None if they do not apply; -1 marks an env the launch could not vouch for"""
         c = self._mc
+        if self._watched and c is not None and not self._watch_ok():
+            return None                   # an alias the caller holds was edited in place since the launch (_touch() ran)
         if not self._chk_fresh or c is None or not c.resident or not c.resident_valid:
             return None
         if not self._pending:

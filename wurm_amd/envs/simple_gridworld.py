@@ -35,7 +35,11 @@ class SimpleGridworld(FastStepMixin):
                  verbose: int = 0,
                  seed: int = None,
                  env_offset: int = 0,
-                 lazy_reset: bool = True):
+                 lazy_reset: bool = True,
+                 resident_mirror=None):
+        # (`resident_mirror`: accepted like SingleSnake's; the two-channel gridworld state has no mirror kernels yet,
+        # so `env.mirror_state()` reports 'off' whatever is asked for)
+        self._resident_policy = resident_mirror
         self.num_envs = num_envs
         self.size = size
         self.on_death = on_death

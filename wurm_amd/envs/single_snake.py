@@ -56,7 +56,13 @@ class SingleSnake(FastStepMixin):
                  render_args: dict = None,
                  seed: int = None,
                  env_offset: int = 0,
-                 lazy_reset: bool = True):
+                 lazy_reset: bool = True,
+                 resident_mirror=None):
+        """Reference keywords (single_snake.py:55-65) plus this build's: `seed`, `env_offset` (module docstring),
+        `lazy_reset` (envs/_fast_step.py) and `resident_mirror` — None: large batches step on a compact mirror of the state
+         chosen by batch size with adaptive rules; False: never; True / 'lazy' / 'eager': whenever the
+        shape is served, without the adaptive rules (`env.mirror_state()` tells what is in effect and why)."""
+        self._resident_policy = resident_mirror
         self.num_envs = num_envs
         self.size = size
         self.max_timesteps = max_timesteps
