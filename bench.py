@@ -345,32 +345,35 @@ def worker(args) -> int:
                          'kernel': kernel, 'avg_launch_ms': avg_launch_s * 1e3,
                          'algorithmic_bytes_per_env_step': per, 'env_steps_per_launch': N * chunk,
                          'limiter': 'observation stores (HBM)' if lane else 'instruction issue of one wave per env',
-                         'note': '`achieved` prices the launch at the SURVEY §8(d) bytes of an UNFUSED step/reset pair; '
-                                 '`traffic` (rocprofv3 FETCH_SIZE + WRITE_SIZE per launch of this exact shape, '
-                                 'profiles/hbm_traffic.json) and `frac_real` are what the fused kernel really moves — '
-                                 'far less, because the env state never leaves the chip between steps. ' +
-                                 ('Batches of 6 144 envs and more run one env per lane and are bound by the observation '
-                                  'store stream (DESIGN.md §4.9).' if lane else
-                                  '512 envs are 512 lone waves on 1024 SIMDs: the kernel is bound by one wave\'s '
-                                  'instruction issue rate, not by HBM (DESIGN.md §4.4).')},
+                         'note': '`achieved` = SURVEY 8(d) bytes of an UNFUSED step/reset pair; `traffic` / `frac_real` = '
+                                 'rocprofv3 counter bytes of this launch shape (profiles/hbm_traffic.json)'},
             'cfg3_strong_scaling': {
                 'value': tot3 / el3, 'unit': 'env-steps/s', 'scaling': 'strong', 'global_num_envs': g3,
                 'num_envs_per_gpu': n3, 'batch_steps_per_launch': chunk3, 'steps': k3, 'warmup': w3,
                 'ms_per_step': el3 / k3 * 1e3, 'avg_launch_ms': avg3 * 1e3,
                 'obs_and_outputs_GBs_this_rank': (4 * OBS_ELEMS + 23) * n3 * chunk3 / avg3 / 1e9,
-                'what': 'BASELINE configs[2]: SingleSnake 65 536 x 9 x 9 partial_2 split over the ranks (shard_range, no '
-                        'data-path collective), same barrier + max-over-ranks protocol as the headline'},
+                'what': 'BASELINE configs[2] split over the ranks, same protocol as the headline'},
         }
         if args.dry_run:
             line['dry_run'] = True
-        if n_gpus == 1 and not args.no_extra and not args.dry_run:
-            line['extra'] = extra_measurements(device)
         if n_gpus == 1 and not args.no_cpu_baseline:
             try:
                 line['cpu_baseline'] = cpu_baseline(512,
                                                     budget_s=0.5 if args.dry_run else 5.0)
             except Exception as e:  # the baseline is a reported extra: never lose the bench line over it
                 line['cpu_baseline'] = {'error': repr(e)}
+        if n_gpus == 1 and not args.no_extra and not args.dry_run:
+            line['extra'] = extra_measurements(device)
+            for k, what in DESCRIPTIONS.items():   # what each extra measures: stderr (and profiles/bench_keys.md), not the line
+                print(f'# {k}: {what}', file=sys.stderr)
+            try:
+                os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
+                with open(os.path.join(ROOT, 'gpurun_out', 'bench_keys.md'), 'w') as f:
+                    f.write('# bench.py extras: what each key measures\n\n' +
+                            ''.join(f'* `{k}` — {what}\n' for k, what in DESCRIPTIONS.items()))
+            except OSError:
+                pass
+        line['key'] = key_numbers(line)   # LAST: the driver keeps the tail of the line
         print(json.dumps(line))
         sys.stdout.flush()
     if distributed:
@@ -390,203 +393,192 @@ def _timed(fn, reps):
     return (time.perf_counter() - t0) / reps
 
 
-def extra_measurements(device):
-    """Secondary numbers (not the headline): the per-call Python API on the same workload, the other BASELINE configs
-    through the fused rollout, the fused acting loop.  GB/s figures are REAL streams (the observation bytes the launch
-    writes), never the unfused byte model."""
+def _median(xs):
+    xs = sorted(xs)
+    return xs[len(xs) // 2]
+
+
+REPEATS = 3          # every extra is timed this many times; the record carries the median and the minimum
+DESCRIPTIONS = {}    # key -> what it measures (printed to stderr, kept in profiles/bench_keys.md; not in the JSON line)
+
+
+def _describe(key, what):
+    DESCRIPTIONS[key] = what
+
+
+def host_calibration(device):
+    """Host-side unit costs on this box (the small-batch per-call numbers are HOST-bound: VERDICT r03 saw cfg1 at 24 us per
+    iteration on the driver box against 7-10 us elsewhere — these figures say how fast the box's host side is)."""
     import torch
-    from wurm_amd.envs import SingleSnake, MultiSnake
+    from wurm_amd import _lib
+    l = _lib.lib()
     out = {}
-    # (a) step()/reset() call pairs from Python — the drop-in loop of experiments/main.py:212-227
-    N, T = 512, 4000
-    env = SingleSnake(num_envs=N, size=SIZE, observation_mode=OBS_MODE, device=device, seed=0)
-    actions = torch.randint(4, (T + 400, N), device=device, dtype=torch.int64)
-    # `per_call_api_512` is the reference's own call form (SingleSnake.reset always returns its observation,
-    # single_snake.py:322-342; experiments/main.py:212-227 discards it); the keyword form is this build's extension
-    for variant, kw in (('per_call_api_512', {}), ('per_call_api_512_no_reset_obs', {'return_observations': False})):
-        for t in range(400):
-            _, _, d, _ = env.step(actions[t])
-            env.reset(d, **kw)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for t in range(400, 400 + T):
-            _, _, d, _ = env.step(actions[t])
-            env.reset(d, **kw)
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        out[variant] = {'value': N * T / dt, 'unit': 'env-steps/s', 'us_per_batch_step': dt / T * 1e6,
-                        'what': 'Python loop of `obs, r, d, info = env.step(a); env.reset(d%s)`'
-                                % (', return_observations=False' if kw else '')}
-    del env, actions
+    n = 20000
+    t0 = time.perf_counter()
+    for _ in range(n):
+        l.wurm_launch_count()
+    out['ctypes_call_ns'] = (time.perf_counter() - t0) / n * 1e9
+    t0 = time.perf_counter()
+    for _ in range(200000):
+        pass
+    out['py_loop_iter_ns'] = (time.perf_counter() - t0) / 200000 * 1e9
+    x = torch.zeros(64, device=device)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(2000):
+        x.add_(1.0)
+    t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    out['torch_small_kernel_issue_us'] = (t1 - t0) / 2000 * 1e6
+    out['torch_small_kernel_drain_us'] = (time.perf_counter() - t0) / 2000 * 1e6
+    t0 = time.perf_counter()
+    for _ in range(2000):
+        torch.empty(64, device=device)
+    out['torch_empty_us'] = (time.perf_counter() - t0) / 2000 * 1e6
+    return {k: round(v, 2) for k, v in out.items()}
 
-    # (a') the same Python loop at BASELINE configs[2] whole (65 536 envs on one GPU: lane_step_kernel) and configs[3]
-    def per_call_case(key, env, step_args, reset_arg, T, what, reset_kw={'return_observations': False}, check=False):
-        def it(t):
-            out_ = env.step(step_args(t))
-            env.reset(reset_arg(out_[2]), **reset_kw)
-            if check:
-                env.check_consistency()
-        for t in range(10):
-            it(t)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for t in range(10, 10 + T):
-            it(t)
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        out[key] = {'value': env.num_envs * T / dt, 'unit': 'env-steps/s', 'us_per_batch_step': dt / T * 1e6, 'what': what}
-        t = traffic_detail.get({'per_call_api_cfg3_65536': 'resident_step_65536x9_partial2_reset_obs',
-                                'per_call_api_cfg3_65536_no_reset_obs': 'resident_step_65536x9_partial2',
-                                'per_call_api_cfg5_8192x36_default': 'grid_step_8192x36_default',
-                                'per_call_api_cfg4_4096x25_k4': 'multi_step_cfg4_4096x25_k4_full',
-                                'per_call_api_cfg4_4096x25_k4_no_mirror': 'multi_step_cfg4_4096x25_k4_full_no_mirror',
-                                'per_call_api_cfg5_8192x36_default_no_mirror': 'grid_step_8192x36_default_no_mirror'}.get(key, key))
-        if t:  # rocprofv3 FETCH_SIZE + WRITE_SIZE of one iteration's launches (profiles/hbm_traffic.json)
-            out[key]['traffic_bytes_per_batch_step'] = t['total_bytes']
-            out[key]['frac_real'] = t['total_bytes'] / (dt / T) / 1e9 / HBM_PEAK_GBS
 
+def extra_measurements(device):
+    """Secondary numbers (not the headline): the per-call Python API, the other BASELINE configs through the fused rollout,
+    the loops the reference ships.  Every entry: median and minimum of REPEATS timings.  GB/s figures are REAL streams
+    (rocprofv3 counter bytes of the same launch shape, profiles/hbm_traffic.json), never the unfused byte model.
+    The most important entries come LAST (the driver keeps the tail of the line)."""
+    import torch
+    from wurm_amd import _lib
+    from wurm_amd.envs import SingleSnake, MultiSnake, SimpleGridworld
+    from wurm_amd.utils import env_consistency
+    out = {}
+    l = _lib.lib()
     try:
         traffic_detail = json.load(open(os.path.join(ROOT, 'profiles', 'hbm_traffic.json'))).get('detail', {})
     except Exception:
         traffic_detail = {}
 
-    # BASELINE configs[2] whole on one GPU.  As for 512 envs, the plain key is the reference's own call form (reset(d) returns
-    # its observation); from 4096 envs of 9 x 9 the step runs on the resident mirror of the state
-    # (wurm_amd/csrc/lane_resident.hpp) — `_no_mirror` switches it off (lane_step_kernel, what rounds 2 measured)
-    N, T = 65536, 200
-    acts = torch.randint(4, (T + 10, N), device=device, dtype=torch.int64)
-    per_call_case('per_call_api_cfg3_65536', SingleSnake(N, SIZE, observation_mode=OBS_MODE, device=device, seed=0),
-                  lambda t: acts[t], lambda d: d, T,
-                  'BASELINE configs[2] whole on one GPU through `env.step(a); env.reset(d)` (resident mirror, lazy)', reset_kw={})
-    per_call_case('per_call_api_cfg3_65536_no_reset_obs', SingleSnake(N, SIZE, observation_mode=OBS_MODE, device=device, seed=0),
-                  lambda t: acts[t], lambda d: d, T,
-                  'the same through `env.step(a); env.reset(d, return_observations=False)`')
-    os.environ['WURM_RESIDENT_MIN_ENVS'] = str(10 ** 9)
-    try:
-        per_call_case('per_call_api_cfg3_65536_no_mirror', SingleSnake(N, SIZE, observation_mode=OBS_MODE, device=device, seed=0),
-                      lambda t: acts[t], lambda d: d, T,
-                      '`env.step(a); env.reset(d)` with the mirror switched off (WURM_RESIDENT_MIN_ENVS): lane_step_kernel '
-                      'reads the whole (N,3,9,9) state every call', reset_kw={})
-    finally:
-        os.environ.pop('WURM_RESIDENT_MIN_ENVS')
-    # algorithmic bytes of one resident step launch: two crops of 300 B per env, the mirror read and written (2 x 32 B),
-    # action in and out (16 B), reward + 4 flag bytes + the postponed reset's flag (9 B)
-    for key, per_env in (('per_call_api_cfg3_65536', 600 + 64 + 16 + 9), ('per_call_api_cfg3_65536_no_reset_obs', 300 + 64 + 16 + 9)):
-        e = out[key]
-        e['algorithmic_bytes_per_batch_step'] = per_env * N
-        e['frac_algorithmic'] = per_env * N / (e['us_per_batch_step'] * 1e-6) / 1e9 / HBM_PEAK_GBS
-    N, T = 8192, 200
-    acts = torch.randint(4, (T + 10, N), device=device, dtype=torch.int64)
-    per_call_case('per_call_api_cfg5_8192x36_default', SingleSnake(N, 36, observation_mode='default', device=device, seed=0),
-                  lambda t: acts[t], lambda d: d, T,
-                  'BASELINE configs[4] through `env.step(a); env.reset(d, return_observations=False)` (clock grids kept in the '
-                  'resident mirror, lazy: grid_rollout.hip)')
-    os.environ['WURM_RESIDENT_MIN_ENVS'] = str(10 ** 9)
-    try:
-        per_call_case('per_call_api_cfg5_8192x36_default_no_mirror',
-                      SingleSnake(N, 36, observation_mode='default', device=device, seed=0), lambda t: acts[t], lambda d: d, T,
-                      'the same with the mirror switched off: the step reads the (N,3,36,36) fp32 state every call')
-    finally:
-        os.environ.pop('WURM_RESIDENT_MIN_ENVS')
-    from wurm_amd.envs import SimpleGridworld
-    N, T = 64, 2000
-    acts = torch.randint(4, (T + 10, N), device=device, dtype=torch.int64)
-    per_call_case('per_call_api_cfg1_gridworld_64x9',
-                  SimpleGridworld(N, 9, start_location=(4, 4), observation_mode='default', device=device, seed=0),
-                  lambda t: acts[t], lambda d: d, T,
-                  'BASELINE configs[0] (SimpleGridworld 64 x 9 x 9, default observation) on the GPU, same loop')
-    N, K, T = 4096, 4, 100
-    acts = torch.randint(8, (T + 10, K, N), device=device, dtype=torch.int64)
-    keys = [f'agent_{i}' for i in range(K)]
-    per_call_case('per_call_api_cfg4_4096x25_k4', MultiSnake(N, K, 25, device=device, seed=0),
-                  lambda t: dict(zip(keys, acts[t].unbind(0))), lambda d: d['__all__'], T,
-                  "BASELINE configs[3] through `env.step(actions); env.reset(dones['__all__'], return_observations=False)` "
-                  '(grids kept in the resident mirror, lazy: multi_snake.hip)')
-    os.environ['WURM_RESIDENT_MIN_ENVS'] = str(10 ** 9)
-    try:
-        per_call_case('per_call_api_cfg4_4096x25_k4_no_mirror', MultiSnake(N, K, 25, device=device, seed=0),
-                      lambda t: dict(zip(keys, acts[t].unbind(0))), lambda d: d['__all__'], T,
-                      'the same with the mirror switched off: the step reads foods / heads / bodies (92 MB of fp32) every call')
-    finally:
-        os.environ.pop('WURM_RESIDENT_MIN_ENVS')
-    # (a'') the MultiSnake variants the reference itself runs: tests/test_multi_snake_env.py:100-104 (training dynamics,
-    # `partial_5` crops; SURVEY §8(d) "additionally") and experiments/speeds.py:10-44 (10 agents on 36 x 36, respawn 'any',
-    # `step; reset(done['__all__']); check_consistency()` — the reference's own benchmark loop, reset observation included)
-    def cfg4prime():
-        return MultiSnake(4096, 4, 25, device=device, seed=0, respawn_mode='any', food_mode='random_rate',
-                          boost_cost_prob=0.25, observation_mode='partial_5', food_on_death_prob=0.33, food_rate=2.5e-4)
+    def machine(env):
+        fs = getattr(env, '_fs', None)
+        if fs is not None:
+            m = 'C Stepper' if type(fs).__name__ == 'Stepper' else 'PyStepper'
+        else:
+            fn = getattr(env, '_mc_fn', None)
+            m = 'C shim' if fn is not None and 'partial' in type(fn).__name__ else 'ctypes'
+        ms = env.mirror_state()
+        return m + ('+torchinfo' if _lib.torch_helpers() else '') + ', mirror ' + ms['state']
 
-    def speeds_env():
-        return MultiSnake(4096, 10, 36, device=device, seed=0, boost=True, respawn_mode='any')
-    per_call_case('per_call_api_cfg4prime_4096x25_k4_partial5', cfg4prime(),
-                  lambda t: dict(zip(keys, acts[t].unbind(0))), lambda d: d['__all__'], T,
-                  "MultiSnake 4096x25x25 K=4 with the reference's training dynamics (tests/test_multi_snake_env.py:100-104: "
-                  "respawn 'any', random_rate food, partial_5), `env.step(a); env.reset(d['__all__'], return_observations=False)`")
-    N, K, T = 4096, 10, 30
-    acts = torch.randint(8, (T + 10, K, N), device=device, dtype=torch.int64)
-    keys10 = [f'agent_{i}' for i in range(K)]
-    per_call_case('per_call_api_speeds_4096x36_k10', speeds_env(),
-                  lambda t: dict(zip(keys10, acts[t].unbind(0))), lambda d: d['__all__'], T,
-                  "experiments/speeds.py shape (4096 x 36 x 36, 10 agents), `step; reset(d['__all__'], return_observations=False)`")
-    per_call_case('speeds_py_loop_4096x36_k10', speeds_env(),
-                  lambda t: dict(zip(keys10, acts[t].unbind(0))), lambda d: d['__all__'], T,
-                  "experiments/speeds.py:30-38 as written: `step(actions); reset(done['__all__']); check_consistency()` "
-                  '(the reset returns its 10 observations, the checker runs every step)', reset_kw={}, check=True)
-    del acts
+    def per_call(key, make_env, step_args, reset_arg, T, what, reset_kw=None, after_step=None, traffic_key=None):
+        """T iterations of `out = env.step(a); [after_step(env, out)]; env.reset(done, **reset_kw)`, REPEATS times"""
+        _describe(key, what)
+        reset_kw = {'return_observations': False} if reset_kw is None else reset_kw
+        env = make_env()
 
-    def rollout_case(key, make_env, shape_actions, A, chunk, reps, obs_bytes, what, traffic_key=None):
+        def it(t):
+            o = env.step(step_args(t))
+            if after_step is not None:
+                after_step(env, o)
+            env.reset(reset_arg(o[2]), **reset_kw)
+        for t in range(10):
+            it(t)
+        times, launches = [], 0
+        for r in range(REPEATS):
+            torch.cuda.synchronize()
+            c0 = l.wurm_launch_count()
+            t0 = time.perf_counter()
+            for t in range(10, 10 + T):
+                it(t)
+            torch.cuda.synchronize()
+            times.append((time.perf_counter() - t0) / T)
+            launches = (l.wurm_launch_count() - c0) / T
+        med = _median(times)
+        e = out[key] = {'value': env.num_envs * 1.0 / med, 'us': round(med * 1e6, 2), 'us_min': round(min(times) * 1e6, 2),
+                        'launches_per_iter': round(launches, 2), 'machine': machine(env)}
+        t = traffic_detail.get(traffic_key or key)
+        if t:  # rocprofv3 FETCH_SIZE + WRITE_SIZE of one iteration's launches (profiles/hbm_traffic.json)
+            e['traffic_bytes'] = round(t['total_bytes'])
+            e['frac_real'] = round(t['total_bytes'] / med / 1e9 / HBM_PEAK_GBS, 4)
+        return e
+
+    def rollout(key, make_env, shape_actions, A, chunk, reps, what, traffic_key=None):
+        _describe(key, what)
         env = make_env()
         acts = torch.randint(A, (reps + 1,) + shape_actions(chunk), device=device, dtype=torch.int64)
-        it = iter(range(reps + 1))
-        dt = _timed(lambda: env.rollout(acts[next(it)]), reps)
-        n_env = env.num_envs
-        eps = n_env * chunk / dt
-        out[key] = {'value': eps, 'unit': 'env-steps/s', 'ms_per_launch': dt * 1e3, 'batch_steps_per_launch': chunk,
-                    'obs_write_GBs': obs_bytes * eps / 1e9, 'obs_write_frac_of_hbm_peak': obs_bytes * eps / 1e9 / HBM_PEAK_GBS,
-                    'what': what}
+        times = []
+        for r in range(REPEATS):
+            it = iter(range(reps + 1))
+            times.append(_timed(lambda: env.rollout(acts[next(it)]), reps))
+        med = _median(times)
+        e = out[key] = {'value': env.num_envs * chunk / med, 'ms': round(med * 1e3, 4), 'ms_min': round(min(times) * 1e3, 4),
+                        'batch_steps_per_launch': chunk}
         t = traffic_detail.get(traffic_key) if traffic_key else None
-        if t:  # rocprofv3 FETCH_SIZE + WRITE_SIZE of exactly this launch shape (profiles/hbm_traffic.json)
-            out[key]['traffic_bytes_per_launch'] = t['total_bytes']
-            out[key]['frac_real'] = t['total_bytes'] / dt / 1e9 / HBM_PEAK_GBS
+        if t:  # counter bytes of exactly this launch shape
+            e['traffic_bytes'] = round(t['total_bytes'])
+            e['frac_real'] = round(t['total_bytes'] / med / 1e9 / HBM_PEAK_GBS, 4)
+            e['frac_real_best'] = round(t['total_bytes'] / min(times) / 1e9 / HBM_PEAK_GBS, 4)
+        return e
 
-    # (b) one GPU's share of configs[2] (8192 envs) and all of configs[2] on one GPU
-    rollout_case('rollout_8192', lambda: SingleSnake(8192, SIZE, observation_mode=OBS_MODE, device=device, seed=0),
-                 lambda c: (c, 8192), 4, 128, 16, 4 * OBS_ELEMS + 7 + 16,
-                 'BASELINE configs[2] per-GPU share (65536/8), fused rollout, 128 batch-steps per launch')
-    rollout_case('rollout_cfg3_65536', lambda: SingleSnake(65536, SIZE, observation_mode=OBS_MODE, device=device, seed=0),
-                 lambda c: (c, 65536), 4, 64, 8, 4 * OBS_ELEMS + 7 + 16,
-                 'BASELINE configs[2] whole (65536 envs) on ONE GPU, fused rollout, 64 batch-steps per launch')
-    # (c) BASELINE configs[4]: SingleSnake 8192 x 36 x 36, default RGB observation
-    rollout_case('rollout_cfg5_8192x36_default',
-                 lambda: SingleSnake(8192, 36, observation_mode='default', device=device, seed=0),
-                 lambda c: (c, 8192), 4, 16, 6, 12 * 36 * 36,
-                 'BASELINE configs[4]: SingleSnake 8192x36x36 default-RGB obs, fused rollout, 16 batch-steps per launch '
-                 '(the launch writes the 15 552 B observation per env-step; SURVEY byte model of an unfused pair: 41 511 B)',
-                 traffic_key='rollout_cfg5_8192x36_default_chunk16')
-    rollout_case('rollout_cfg5_8192x36_default_64steps',
-                 lambda: SingleSnake(8192, 36, observation_mode='default', device=device, seed=0),
-                 lambda c: (c, 8192), 4, 64, 4, 12 * 36 * 36,
-                 'BASELINE configs[4] as above with 64 batch-steps per launch (the state load / store and the launch are '
-                 'amortised over four times as many steps)')
-    # (d) BASELINE configs[3]: MultiSnake 4096 x 25 x 25, 4 agents, constructor defaults ('full' obs)
-    rollout_case('multi_rollout_cfg4_4096x25_k4_full_64steps', lambda: MultiSnake(4096, 4, 25, device=device, seed=0),
-                 lambda c: (c, 4, 4096), 8, 64, 4, 12 * 4 * 25 * 25,
-                 'BASELINE configs[3] with 64 batch-steps per launch')
-    rollout_case('multi_rollout_cfg4_4096x25_k4_full', lambda: MultiSnake(4096, 4, 25, device=device, seed=0),
-                 lambda c: (c, 4, 4096), 8, 16, 6, 12 * 4 * 25 * 25,
-                 'BASELINE configs[3]: MultiSnake 4096x25x25, 4 agents, defaults, step+observe+reset(__all__) per '
-                 'batch-step, fused rollout, 16 batch-steps per launch (30 000 B of observations per env-step; SURVEY byte '
-                 'model of an unfused pair: 75 160 B; reference torch-CPU: 3 280 env-steps/s)',
-                 traffic_key='multi_rollout_cfg4_4096x25_k4_full_chunk16')
-    rollout_case('multi_rollout_cfg4prime_4096x25_k4_partial5', cfg4prime, lambda c: (c, 4, 4096), 8, 16, 6, 12 * 4 * 11 * 11,
-                 "MultiSnake 4096x25x25 K=4, training dynamics (respawn 'any', random_rate food) and partial_5 crops "
-                 '(tests/test_multi_snake_env.py:100-104), fused rollout, 16 batch-steps per launch',
-                 traffic_key='multi_rollout_cfg4prime_4096x25_k4_partial5_chunk16')
-    rollout_case('multi_rollout_speeds_4096x36_k10', speeds_env, lambda c: (c, 10, 4096), 8, 4, 4, 12 * 10 * 36 * 36,
-                 "experiments/speeds.py shape: MultiSnake 4096x36x36, 10 agents, respawn 'any', 'full' observations "
-                 '(155 520 B per env-step), fused rollout, 4 batch-steps per launch',
-                 traffic_key='multi_rollout_speeds_4096x36_k10_chunk4')
-    # (e) the acting loop with the policy inside the env kernel (SURVEY 8f row 2): MLP 75->64->64->{4,1} + sampling
+    def guarded(fn):   # an extra is an extra: a failing case leaves {'error': ...} under its key, never loses the line
+        def run(key, *a, **kw):
+            try:
+                return fn(key, *a, **kw)
+            except Exception as e:
+                out[key] = {'error': repr(e)[:300]}
+                torch.cuda.synchronize()
+                return out[key]
+        return run
+    per_call, rollout = guarded(per_call), guarded(rollout)
+
+    out['host_calibration_before'] = host_calibration(device)
+    _describe('host_calibration_*', 'host unit costs of this box: a ctypes call, a Python loop iteration, issuing / draining a '
+              'tiny torch kernel, torch.empty — before and after the extras')
+
+    # ---- MultiSnake variants the reference itself runs (not BASELINE configs)
+    def cfg4prime(**kw):
+        return MultiSnake(4096, 4, 25, device=device, seed=0, respawn_mode='any', food_mode='random_rate',
+                          boost_cost_prob=0.25, observation_mode='partial_5', food_on_death_prob=0.33, food_rate=2.5e-4, **kw)
+
+    def speeds_env(**kw):
+        return MultiSnake(4096, 10, 36, device=device, seed=0, boost=True, respawn_mode='any', **kw)
+    N, K, T = 4096, 4, 60
+    T4 = T
+    acts4 = torch.randint(8, (T4 + 10, K, N), device=device, dtype=torch.int64)
+    keys4 = [f'agent_{i}' for i in range(K)]
+    a4 = lambda t: dict(zip(keys4, acts4[t].unbind(0)))   # noqa: E731
+    d_all = lambda d: d['__all__']                        # noqa: E731
+    per_call('per_call_cfg4prime_partial5', cfg4prime, a4, d_all, T,
+             "MultiSnake 4096x25x25 K=4, the reference's training dynamics (tests/test_multi_snake_env.py:100-104: respawn "
+             "'any', random_rate food, partial_5): `step(a); reset(d['__all__'], return_observations=False)`",
+             traffic_key='per_call_api_cfg4prime_4096x25_k4_partial5')
+    acts10 = torch.randint(8, (40, 10, N), device=device, dtype=torch.int64)
+    keys10 = [f'agent_{i}' for i in range(10)]
+    a10 = lambda t: dict(zip(keys10, acts10[t].unbind(0)))   # noqa: E731
+    per_call('per_call_speeds_4096x36_k10', speeds_env, a10, d_all, 30,
+             "experiments/speeds.py shape (4096 x 36 x 36, 10 agents): `step; reset(d['__all__'], return_observations=False)`",
+             traffic_key='per_call_api_speeds_4096x36_k10')
+    per_call('speeds_py_loop_4096x36_k10', speeds_env, a10, d_all, 30,
+             "experiments/speeds.py:30-38 as written: `step(actions); reset(done['__all__']); check_consistency()`",
+             reset_kw={}, after_step=None)
+    # (check_consistency() after the reset, as speeds.py has it)
+    _describe('speeds_py_loop_check_4096x36_k10', 'the same loop with env.check_consistency() after the reset (speeds.py:37)')
+    env = speeds_env()
+    for t in range(5):
+        o = env.step(a10(t)); env.reset(o[2]['__all__']); env.check_consistency()
+    times = []
+    for r in range(REPEATS):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for t in range(5, 30):
+            o = env.step(a10(t)); env.reset(o[2]['__all__']); env.check_consistency()
+        torch.cuda.synchronize()
+        times.append((time.perf_counter() - t0) / 25)
+    out['speeds_py_loop_check_4096x36_k10'] = {'value': 4096 / _median(times), 'us': round(_median(times) * 1e6, 1),
+                                               'us_min': round(min(times) * 1e6, 1), 'machine': machine(env)}
+    del env, acts10
+    rollout('multi_rollout_cfg4prime_partial5', cfg4prime, lambda c: (c, 4, 4096), 8, 16, 6,
+            "MultiSnake 4096x25x25 K=4, training dynamics + partial_5 crops, fused rollout, 16 batch-steps per launch",
+            traffic_key='multi_rollout_cfg4prime_4096x25_k4_partial5_chunk16')
+    rollout('multi_rollout_speeds_4096x36_k10', speeds_env, lambda c: (c, 10, 4096), 8, 4, 4,
+            "experiments/speeds.py shape, 'full' observations (155 520 B per env-step), fused rollout, 4 batch-steps per launch",
+            traffic_key='multi_rollout_speeds_4096x36_k10_chunk4')
+
+    # ---- the acting loop with the policy inside the env kernel (SURVEY 8f row 2) and the A2C loops the reference ships
     from wurm_amd.agents import FeedforwardAgent, pack_policy_params
     N, T, reps = 512, 256, 8
     torch.manual_seed(0)
@@ -596,12 +588,150 @@ def extra_measurements(device):
 
     def act():
         state[0] = env.policy_rollout(params, state[0], T, check=False)['state']
-    dt = _timed(act, reps)
-    out['policy_rollout_512'] = {
-        'value': N * T / dt, 'unit': 'env-steps/s',
-        'what': 'policy forward (random-init FeedforwardAgent) + Categorical sample + step + observe + reset per '
-                'env-step, fused in one kernel, launches of 256 batch-steps'}
+    times = [_timed(act, reps) for _ in range(REPEATS)]
+    out['policy_rollout_512'] = {'value': N * T / _median(times), 'ms': round(_median(times) * 1e3, 4)}
+    _describe('policy_rollout_512', 'policy forward (random-init FeedforwardAgent 75-64-64-{4,1}) + Categorical sample + step + '
+              'observe + reset per env-step fused in one kernel, launches of 256 batch-steps')
+    del env
+    try:
+        sys.path.insert(0, os.path.join(ROOT, 'examples'))
+        import a2c_loop
+        import a2c_fused_actor
+        a2c_loop.run(steps=100, log_interval=100, verbose=False, device=device)
+        h = [a2c_loop.run(steps=500, log_interval=500, verbose=False, device=device)[-1]['env_steps_per_s']
+             for _ in range(REPEATS)]
+        out['a2c_loop_512'] = {'value': _median(h), 'best': max(h), 'reference_readme': 4.2e4}
+        _describe('a2c_loop_512', "examples/a2c_loop.py = the reference's single-agent experiment (experiments/main.py:194-247; "
+                  "README.md:89-97: 512 envs, size 9, partial_2, feed-forward agent, update every 5 steps; the reference "
+                  "quotes 10M env-steps in about four minutes = 4.2e4 env-steps/s on a GTX 1080 Ti), env-steps/s incl. "
+                  "policy forward / backward / Adam in torch")
+        a2c_fused_actor.run(steps=200, log_interval=200, verbose=False, device=device)
+        h = [a2c_fused_actor.run(steps=2000, log_interval=2000, verbose=False, device=device)[-1]['env_steps_per_s']
+             for _ in range(REPEATS)]
+        out['a2c_fused_actor_512'] = {'value': _median(h), 'best': max(h)}
+        _describe('a2c_fused_actor_512', 'examples/a2c_fused_actor.py: the same experiment with the acting half (policy + sample '
+                  '+ step + reset) fused into the env kernel, learner in torch')
+    except Exception as e:  # an extra: never lose the line over it
+        out['a2c_loop_512'] = {'error': repr(e)[:200]}
+
+    # ---- cfg5 and cfg1 per call, cfg5 rollouts
+    N, T = 8192, 100
+    acts = torch.randint(4, (T + 10, N), device=device, dtype=torch.int64)
+    a1 = lambda t: acts[t]        # noqa: E731
+    same = lambda d: d            # noqa: E731
+    per_call('per_call_cfg5_8192x36_default_no_mirror',
+             lambda: SingleSnake(N, 36, observation_mode='default', device=device, seed=0, resident_mirror=False), a1, same, T,
+             'cfg5 per call with the mirror switched off: the step reads the (N,3,36,36) fp32 state every call',
+             traffic_key='grid_step_8192x36_default_no_mirror')
+    per_call('per_call_cfg5_8192x36_default', lambda: SingleSnake(N, 36, observation_mode='default', device=device, seed=0),
+             a1, same, T, 'BASELINE configs[4] through `env.step(a); env.reset(d, return_observations=False)` (clock grids '
+             'kept in the resident mirror, lazy: grid_rollout.hip)', traffic_key='grid_step_8192x36_default')
+    rollout('rollout_cfg5_8192x36_default_64steps', lambda: SingleSnake(8192, 36, observation_mode='default', device=device, seed=0),
+            lambda c: (c, 8192), 4, 64, 4, 'BASELINE configs[4] with 64 batch-steps per launch')
+    rollout('rollout_cfg5_8192x36_default', lambda: SingleSnake(8192, 36, observation_mode='default', device=device, seed=0),
+            lambda c: (c, 8192), 4, 16, 6, 'BASELINE configs[4]: SingleSnake 8192x36x36 default-RGB obs, fused rollout, 16 '
+            'batch-steps per launch (15 552 B of observation per env-step)', traffic_key='rollout_cfg5_8192x36_default_chunk16')
+
+    # ---- cfg3 (65 536 x 9 x 9) in the other observation modes (the reference's constructor default is one_channel)
+    for mode in ('one_channel', 'default'):
+        rollout(f'rollout_65536x9_{mode}', lambda: SingleSnake(65536, SIZE, observation_mode=mode, device=device, seed=0),
+                lambda c: (c, 65536), 4, 32, 6, f'SingleSnake 65 536 x 9 x 9 with observation_mode={mode!r}, fused rollout, 32 '
+                'batch-steps per launch', traffic_key=f'rollout_65536x9_{mode}_chunk32')
+
+    # ---- cfg4 (BASELINE configs[3]): MultiSnake 4096 x 25 x 25, 4 agents, constructor defaults ('full' observations)
+    per_call('per_call_cfg4_no_mirror', lambda: MultiSnake(4096, 4, 25, device=device, seed=0, resident_mirror=False), a4, d_all, T4,
+             'cfg4 per call with the mirror switched off: the step reads foods / heads / bodies (92 MB of fp32) every call',
+             traffic_key='multi_step_cfg4_4096x25_k4_full_no_mirror')
+    per_call('per_call_cfg4', lambda: MultiSnake(4096, 4, 25, device=device, seed=0), a4, d_all, T4,
+             "BASELINE configs[3] through `env.step(actions); env.reset(dones['__all__'], return_observations=False)`",
+             traffic_key='multi_step_cfg4_4096x25_k4_full')
+    rollout('multi_rollout_cfg4_full_64steps', lambda: MultiSnake(4096, 4, 25, device=device, seed=0),
+            lambda c: (c, 4, 4096), 8, 64, 4, 'BASELINE configs[3] with 64 batch-steps per launch')
+    rollout('multi_rollout_cfg4_full', lambda: MultiSnake(4096, 4, 25, device=device, seed=0),
+            lambda c: (c, 4, 4096), 8, 16, 6, 'BASELINE configs[3]: MultiSnake 4096x25x25, 4 agents, defaults, step + observe + '
+            'reset(__all__) per batch-step, fused rollout, 16 batch-steps per launch (30 000 B of observations per env-step)',
+            traffic_key='multi_rollout_cfg4_4096x25_k4_full_chunk16')
+    del acts4
+
+    # ---- cfg1 (BASELINE configs[0]) per call
+    N, T = 64, 2000
+    acts = torch.randint(4, (T + 10, N), device=device, dtype=torch.int64)
+    per_call('per_call_cfg1_gridworld_64x9',
+             lambda: SimpleGridworld(N, 9, start_location=(4, 4), observation_mode='default', device=device, seed=0),
+             a1, same, T, 'BASELINE configs[0] (SimpleGridworld 64 x 9 x 9, default observation) on the GPU, '
+             '`env.step(a); env.reset(d, return_observations=False)`')
+
+    # ---- the single-agent caller loop as the reference writes it (experiments/main.py:212-227)
+    def consistency(env, o):
+        env_consistency(env.envs[~o[2].squeeze(-1)])
+    for n_envs, T in ((512, 1000), (65536, 60)):
+        acts = torch.randint(4, (T + 10, n_envs), device=device, dtype=torch.int64)
+        per_call(f'main_py_loop_{n_envs}', lambda: SingleSnake(n_envs, SIZE, observation_mode=OBS_MODE, device=device, seed=0),
+                 a1, same, T, 'experiments/main.py:212-227 as written: `step(action); env_consistency(env.envs[~done.squeeze(-1)]); '
+                 'reset(done)` (the reset returns its observation; the checker gathers the live envs every step)',
+                 reset_kw={}, after_step=consistency)
+        per_call(f'main_py_loop_checked_on_device_{n_envs}',
+                 lambda: SingleSnake(n_envs, SIZE, observation_mode=OBS_MODE, device=device, seed=0),
+                 a1, same, T, 'the same loop with `env.check_consistency(~done)` in place of the gathered copy (the mask of the '
+                 'live envs is checked on the device, one `any()` per step)', reset_kw={},
+                 after_step=lambda env, o: env.check_consistency(~o[2].squeeze(-1)))
+
+    # ---- cfg3 whole on one GPU and one GPU's share, rollouts; then the per-call loops at cfg3 and cfg2
+    rollout('rollout_8192', lambda: SingleSnake(8192, SIZE, observation_mode=OBS_MODE, device=device, seed=0),
+            lambda c: (c, 8192), 4, 128, 16, 'BASELINE configs[2] per-GPU share (65536/8), fused rollout, 128 batch-steps per launch',
+            traffic_key='rollout_8192x9_chunk128')
+    rollout('rollout_cfg3_65536', lambda: SingleSnake(65536, SIZE, observation_mode=OBS_MODE, device=device, seed=0),
+            lambda c: (c, 65536), 4, 64, 8, 'BASELINE configs[2] whole (65536 envs) on ONE GPU, fused rollout, 64 batch-steps per launch',
+            traffic_key='rollout_65536x9_chunk64')
+    N, T = 65536, 200
+    acts = torch.randint(4, (T + 10, N), device=device, dtype=torch.int64)
+    per_call('per_call_cfg3_no_mirror', lambda: SingleSnake(N, SIZE, observation_mode=OBS_MODE, device=device, seed=0,
+                                                             resident_mirror=False), a1, same, T,
+             '`env.step(a); env.reset(d)` at 65 536 envs with the mirror switched off: lane_step_kernel reads the whole (N,3,9,9) '
+             'state every call', reset_kw={})
+    per_call('per_call_cfg3_no_reset_obs', lambda: SingleSnake(N, SIZE, observation_mode=OBS_MODE, device=device, seed=0),
+             a1, same, T, 'BASELINE configs[2] whole through `env.step(a); env.reset(d, return_observations=False)`',
+             traffic_key='resident_step_65536x9_partial2')
+    per_call('per_call_cfg3', lambda: SingleSnake(N, SIZE, observation_mode=OBS_MODE, device=device, seed=0), a1, same, T,
+             "BASELINE configs[2] whole on one GPU through the reference's own call form `env.step(a); env.reset(d)` (resident "
+             'mirror, lazy)', reset_kw={}, traffic_key='resident_step_65536x9_partial2_reset_obs')
+    N, T = 512, 4000
+    acts = torch.randint(4, (T + 10, N), device=device, dtype=torch.int64)
+    per_call('per_call_512_no_reset_obs', lambda: SingleSnake(N, SIZE, observation_mode=OBS_MODE, device=device, seed=0),
+             a1, same, T, 'cfg2 per call: `obs, r, d, info = env.step(a); env.reset(d, return_observations=False)`')
+    per_call('per_call_512', lambda: SingleSnake(N, SIZE, observation_mode=OBS_MODE, device=device, seed=0), a1, same, T,
+             "cfg2 per call in the reference's own call form: `obs, r, d, info = env.step(a); env.reset(d)`", reset_kw={})
+    out['host_calibration_after'] = host_calibration(device)
     return out
+
+
+def key_numbers(line):
+    """The numbers the round is judged on, short keys, printed LAST in the line (the driver keeps the tail of stdout)."""
+    ex = line.get('extra', {})
+
+    def g(k, f='value'):
+        v = ex.get(k, {}).get(f)
+        return None if v is None else (float('%.4g' % v) if isinstance(v, float) else v)
+    return {
+        'cfg2_rollout_eps': float('%.4g' % line['value']),
+        'cfg3_strong_scaling_eps': float('%.4g' % line['cfg3_strong_scaling']['value']),
+        'cfg3_rollout_eps': g('rollout_cfg3_65536'), 'cfg3_rollout_ms': g('rollout_cfg3_65536', 'ms'),
+        'cfg3_rollout_frac_real': g('rollout_cfg3_65536', 'frac_real'),
+        'cfg3_share_8192_eps': g('rollout_8192'),
+        'cfg3_one_channel_eps': g('rollout_65536x9_one_channel'), 'cfg3_default_eps': g('rollout_65536x9_default'),
+        'cfg4_rollout_ms': g('multi_rollout_cfg4_full', 'ms'), 'cfg4_rollout_frac_real': g('multi_rollout_cfg4_full', 'frac_real'),
+        'cfg4_rollout_eps': g('multi_rollout_cfg4_full'), 'cfg4_per_call_us': g('per_call_cfg4', 'us'),
+        'cfg5_rollout_ms': g('rollout_cfg5_8192x36_default', 'ms'),
+        'cfg5_rollout_frac_real': g('rollout_cfg5_8192x36_default', 'frac_real'), 'cfg5_per_call_us': g('per_call_cfg5_8192x36_default', 'us'),
+        'cfg1_per_call_us': g('per_call_cfg1_gridworld_64x9', 'us'), 'cfg1_machine': g('per_call_cfg1_gridworld_64x9', 'machine'),
+        'per_call_512_us': g('per_call_512', 'us'), 'per_call_512_eps': g('per_call_512'),
+        'per_call_512_launches': g('per_call_512', 'launches_per_iter'),
+        'per_call_cfg3_us': g('per_call_cfg3', 'us'), 'per_call_cfg3_eps': g('per_call_cfg3'),
+        'main_py_loop_512_us': g('main_py_loop_512', 'us'), 'main_py_loop_65536_us': g('main_py_loop_65536', 'us'),
+        'a2c_loop_512_eps': g('a2c_loop_512'), 'a2c_fused_actor_512_eps': g('a2c_fused_actor_512'),
+        'speeds_rollout_eps': g('multi_rollout_speeds_4096x36_k10'), 'speeds_py_loop_us': g('speeds_py_loop_4096x36_k10', 'us'),
+        'cfg4prime_rollout_eps': g('multi_rollout_cfg4prime_partial5'),
+    }
 
 
 def main() -> int:

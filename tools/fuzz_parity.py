@@ -16,6 +16,7 @@ import numpy as np  # noqa: E402
 from oracle import oracle as _o  # noqa: E402
 from tests.backends import OracleBackend  # noqa: E402
 from tests.hip_backend import HipBackend  # noqa: E402
+from wurm_amd import _lib  # noqa: E402
 
 
 def same(a, b, what):
@@ -138,10 +139,7 @@ def fuzz_resident(rng):
     desc = f'resident S={S} N={N} T={T} mode={mode} lazy={lazy} epw={epw} seed={seed} off={off}'
     if os.environ.get('WURM_FUZZ_VERBOSE'):
         print('start:', desc, flush=True)
-    if epw:
-        os.environ['WURM_RESIDENT_EPW'] = str(epw)
-    else:
-        os.environ.pop('WURM_RESIDENT_EPW', None)
+    _lib.set_option('WURM_RESIDENT_EPW', epw if epw else None)
     try:
         o, h = OracleBackend(seed, off), HipBackend(seed, off)
         eo = np.zeros((N, 3, S, S), np.float32)
@@ -185,7 +183,7 @@ def fuzz_resident(rng):
                 mirror['valid'] = 0
             call += 2
     finally:
-        os.environ.pop('WURM_RESIDENT_EPW', None)
+        _lib.set_option('WURM_RESIDENT_EPW', None)
     return desc
 
 
@@ -239,9 +237,8 @@ def fuzz_lane(rng):
     eo, eh = np.zeros((N, 3, S, S), np.float32), np.zeros((N, 3, S, S), np.float32)
     o.single_reset(eo, np.ones(N), 'none'); h.single_reset(eh, np.ones(N), 'none')
     o.call = h.call = int(rng.randint(1 << 50))
-    old = {k: os.environ.get(k) for k in ('WURM_LANE_ROLLOUT_MIN_ENVS', 'WURM_LANE_ROLLOUT_EPW',
-                                                                 'WURM_RESIDENT_MIN_ENVS')}
-    os.environ['WURM_LANE_ROLLOUT_MIN_ENVS'], os.environ['WURM_LANE_ROLLOUT_EPW'] = '0', str(epw)
+    old = {'WURM_LANE_ROLLOUT_MIN_ENVS': _lib.set_option('WURM_LANE_ROLLOUT_MIN_ENVS', 0),
+           'WURM_LANE_ROLLOUT_EPW': _lib.set_option('WURM_LANE_ROLLOUT_EPW', epw)}
     try:
         tc = 64 // epw
         for launch in range(int(rng.randint(1, 4))):
@@ -275,10 +272,7 @@ def fuzz_lane(rng):
                 eh[...] = eo
     finally:
         for k, v in old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
+            _lib.set_option(k, v)
     return desc
 
 
@@ -392,8 +386,7 @@ def fuzz_multi_resident(rng):
     desc = f'multi_resident S={S} K={K} N={N} T={T} mode={mode} lazy={lazy} seed={seed} off={off} cfg={cfg}'
     if os.environ.get('WURM_FUZZ_VERBOSE'):
         print('start:', desc, flush=True)
-    old = os.environ.get('WURM_RESIDENT_MIN_ENVS')
-    os.environ['WURM_RESIDENT_MIN_ENVS'] = '0'
+    old = _lib.set_option('WURM_RESIDENT_MIN_ENVS', 0)
     try:
         o, h = OracleBackend(seed, off), HipBackend(seed, off)
         so = _o.multi_empty_state(N, K, S)
@@ -446,10 +439,7 @@ def fuzz_multi_resident(rng):
                 sh['foods'][...] = so['foods']
                 mirror['valid'] = 0
     finally:
-        if old is None:
-            os.environ.pop('WURM_RESIDENT_MIN_ENVS', None)
-        else:
-            os.environ['WURM_RESIDENT_MIN_ENVS'] = old
+        _lib.set_option('WURM_RESIDENT_MIN_ENVS', old)
     return desc
 
 
@@ -499,7 +489,7 @@ if __name__ == '__main__':
                'total_cases': sum(n.values()), 'mismatches': fails, 'messages': messages,
                'forced_thresholds': {k: os.environ[k] for k in ('WURM_LANE_STEP_MIN_ENVS', 'WURM_GRID_STEP_MIN_CELLS',
                                                                  'WURM_LANE_ROLLOUT_MIN_ENVS', 'WURM_LANE_ROLLOUT_EPW',
-                                                                 'WURM_RESIDENT_MIN_ENVS')
+                                                                 'WURM_RESIDENT_MIN_ENVS', 'WURM_MULTI_GROUP_MIN_ENVS')
                                      if k in os.environ},
                'bar': 'bit-exact HIP (C ABI) vs oracle on every output of every step'}
         runs = []

@@ -4,6 +4,7 @@ reference form (`reset(d)` returns its observation) and without the reset observ
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+from wurm_amd import _lib
 from wurm_amd.envs import SingleSnake
 
 def run(N, form, iters=300):
@@ -25,10 +26,10 @@ for N in [int(x) for x in sys.argv[1:]] or [4096, 8192, 16384, 32768, 65536]:
     for form in ('ref', 'noobs'):
         row = []
         for mirror in (10 ** 9, 0):
-            os.environ['WURM_RESIDENT_MIN_ENVS'] = str(mirror)
+            _lib.set_option('WURM_RESIDENT_MIN_ENVS', mirror)
             for epw in ((None,) if mirror else (None, 16, 32, 64)):
-                if epw is None: os.environ.pop('WURM_RESIDENT_EPW', None)
-                else: os.environ['WURM_RESIDENT_EPW'] = str(epw)
+                if epw is None: _lib.set_option('WURM_RESIDENT_EPW', None)
+                else: _lib.set_option('WURM_RESIDENT_EPW', epw)
                 us, on = run(N, form)
                 row.append(f"{'mirror' if on else 'plain'}{'' if epw is None else '/' + str(epw)} {us:6.2f} us ({N / us / 1e3:5.2f}e9/s)")
         print(f'N={N:6d} {form:5s} ' + ' | '.join(row), flush=True)

@@ -89,21 +89,21 @@ def percall(N, S, mode, reset_obs=False):
 for N, S, mode in ((512, 9, 'partial_2'), (8192, 9, 'partial_2'), (65536, 9, 'partial_2'), (8192, 36, 'default')):
     percall(N, S, mode)
 percall(65536, 9, 'partial_2', reset_obs=True)
-os.environ['WURM_RESIDENT_MIN_ENVS'] = str(10 ** 9)
+_lib.set_option('WURM_RESIDENT_MIN_ENVS', 10 ** 9)
 percall(8192, 9, 'partial_2')
 percall(65536, 9, 'partial_2')
 percall(8192, 36, 'default')   # grid_step_kernel a second time: the first 30 launches kept their grids in the mirror
-os.environ.pop('WURM_RESIDENT_MIN_ENVS')
+_lib.set_option('WURM_RESIDENT_MIN_ENVS', None)
 # measured: the per-call MultiSnake loop at cfg4 (multi_step_kernel with the postponed reset in front)
 # — 20 launches on the resident mirror of foods / heads / bodies (lazy), then 20 with it switched off
 for mirror in (True, False):
     if not mirror:
-        os.environ['WURM_RESIDENT_MIN_ENVS'] = str(10 ** 9)
+        _lib.set_option('WURM_RESIDENT_MIN_ENVS', 10 ** 9)
     env = MultiSnake(4096, 4, 25, device=dev, seed=0)
     actions = torch.randint(8, (20, 4, 4096), device=dev, dtype=torch.int64)
     for t in range(20):
         _, _, d, _ = env.step({f'agent_{i}': actions[t, i] for i in range(4)})
         env.reset(d['__all__'], return_observations=False)
     torch.cuda.synchronize()
-os.environ.pop('WURM_RESIDENT_MIN_ENVS')
+_lib.set_option('WURM_RESIDENT_MIN_ENVS', None)
 print('traffic workload done')

@@ -7,7 +7,8 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import torch  # noqa: E402
+import torch
+from wurm_amd import _lib  # noqa: E402
 from wurm_amd.envs import SingleSnake  # noqa: E402
 
 with_obs = '--noobs' not in sys.argv
@@ -38,10 +39,10 @@ for N, T in SIZES:
         continue
     for epw in ['wave', 4, 8, 16, 32, 64]:
         if epw == 'wave':
-            os.environ['WURM_LANE_ROLLOUT_MIN_ENVS'] = str(1 << 40)
+            _lib.set_option('WURM_LANE_ROLLOUT_MIN_ENVS', 1 << 40)
         else:
-            os.environ['WURM_LANE_ROLLOUT_MIN_ENVS'] = '0'
-            os.environ['WURM_LANE_ROLLOUT_EPW'] = str(epw)
+            _lib.set_option('WURM_LANE_ROLLOUT_MIN_ENVS', 0)
+            _lib.set_option('WURM_LANE_ROLLOUT_EPW', epw)
             if N // epw < 64:
                 continue
         ms = time_rollout(N, T)

@@ -309,10 +309,18 @@ class SingleSnake(FastStepMixin):
 
     # ------------------------------------------------------------------ invariants
 
-    def check_consistency(self):
-        """wurm.utils.env_consistency on self.envs (reference wurm/utils.py:167-178)."""
-        from wurm_amd.utils import env_consistency
-        env_consistency(self._state(write=False))
+    def check_consistency(self, mask: torch.Tensor = None):
+        """wurm.utils.env_consistency on self.envs (reference wurm/utils.py:167-178).
+
+        mask (extension): a (num_envs,) bool tensor — only the envs it selects are checked, on the device and without
+        gathering them: `env.check_consistency(~done.squeeze(-1))` is what experiments/main.py:214-215 asks with
+        `env_consistency(env.envs[~done.squeeze(-1)])`, at the cost of one checker launch and one `any()`."""
+        from wurm_amd.utils import consistency_mask, _or_reduce, _raise_for
+        err = consistency_mask(self._state(write=False))
+        if mask is not None:
+            m = mask.view(self.num_envs)
+            err = err * (m if m.dtype == torch.bool else m != 0).to(err.dtype)
+        _raise_for(_or_reduce(err), one_food=True)
 
     # ------------------------------------------------------------------ rendering (host side)
 
