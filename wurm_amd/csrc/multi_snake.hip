@@ -70,6 +70,9 @@ struct MultiArgs {
     // describes them; lazy: the step does not write them
     unsigned char *resident;
     int resident_valid, resident_lazy;
+    // multi_rollout_group_kernel: offsets (bytes, from the start of the workgroup's LDS) of the env blocks, the two class
+    // code buffers and the two output buffers, and the size of one env's share of each
+    int grp_env0, grp_codes, grp_outs, grp_save, grp_code_bytes, grp_out_bytes;
 };
 
 struct Ctx {
@@ -90,10 +93,10 @@ struct Ctx {
 
 extern __shared__ __attribute__((aligned(16))) unsigned char wurm_multi_lds[];
 
-__device__ __forceinline__ Ctx make_ctx(const MultiArgs &p, int wave)
+__device__ __forceinline__ Ctx make_ctx(const MultiArgs &p, int wave, int base_off = 0)
 {
     Ctx cx;
-    unsigned char *base = wurm_multi_lds + (size_t)wave * p.lds_per_wave;
+    unsigned char *base = wurm_multi_lds + base_off + (size_t)wave * p.lds_per_wave;
     cx.S = p.S;
     cx.C = p.S * p.S;
     cx.K = p.K;
@@ -1946,6 +1949,348 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void m
     store_env(cx, foodp, headp, bodyp, fbits0, hc0, sn.hc, false);
 }
 
+
+// ---- 'full' observations of at most 5 snakes, large batches: G consecutive envs per WORKGROUP (round 4).
+// G stepper waves (one env each, as above) + W writer waves.  What changed against multi_rollout_kernel<true>, and why
+// (tools/microbench/store_runs.hip, profiles/r04_store_runs_microbench.txt):
+//   * the stream shape: writer wave w owns agent w (w + W, ...) and writes that agent's observations of the G envs of the
+//     group as ONE linear run of G * 3 S^2 floats per step (the layout is (T, K, N, 3 S^2): for a fixed agent consecutive
+//     envs are adjacent) — 60 KB at cfg4 with G = 8, 16-byte stores on 16-byte boundaries.  A pure store kernel of this
+//     shape runs at 5.5 TB/s (0.358 ms per 16 steps at cfg4) against 4.3 TB/s for one 7.5 KB run per wave; waves of one
+//     workgroup INTERLEAVING 1 KB pieces of the same run is the slow shape (3.3 - 3.9 TB/s);
+//   * the writer's arithmetic: the stepper leaves a 16-bit word per cell holding each agent's 3-bit CLASS of the cell
+//     (numbered in paint order: 0 background, 1 food, 2 own body, 3 own head, 4 other body, 5 other head, 6 border), the
+//     writer extracts its agent's field and reads the plane's value from a 3 x 8 float table in LDS: two VALU instructions
+//     and two LDS reads per float instead of ~14 VALU per 64-cell store group for the colour logic;
+//   * the steppers issue NO global memory instruction in the steady state: rewards / flags go to LDS and are written by a
+//     writer wave (the CU's vector memory pipeline is in order: a stepper's small stores queued behind the observation
+//     stream of the whole CU stall the stepper at issue).
+constexpr int GRP_MAX_SNAKES = 5;   // 3 bits per agent in a 16-bit word
+constexpr int GRP_TAB_BYTES = 128;  // float tab[3][8] at the start of the workgroup's LDS
+constexpr int GRP_CODE_SLACK = 1600; // bytes the writers may READ behind the last code array (grp_emit_segment)
+
+// (sum over a < K of 8^a): a 3-bit value replicated into the K agents' fields
+__device__ __forceinline__ u32 grp_rep(int K) { return (u32)(((1ull << (3 * K)) - 1ull) / 7ull); }
+
+// per-agent classes of every cell of the env in LDS -> codes[] (the wave that owns the env's state).  _observe_agent
+// :268-281 paints food, own body, own head, other bodies, other heads, then the border (:183-186): a later layer wins, so
+// the class of a cell for an agent is the LAST layer that covers it — with the classes numbered in paint order, the
+// maximum over the layers.  Bodies first (every cell), then the K head cells are raised.
+__device__ __forceinline__ void class_write(const Ctx &cx, int hc, unsigned short *codes)
+{
+    const int S = cx.S, C = cx.C, K = cx.K, lane = cx.lane;
+    const u32 REP = grp_rep(K);
+    // which snakes have their head on a cell: a bit mask per cell in hmap (all-zero outside this function; two heads may
+    // share a cell in hand-made states, so the bits are OR-ed in)
+    if (lane < K && hc >= 0) atomicOr((u32 *)(cx.hmap + (hc & ~3)), (1u << lane) << (8 * (hc & 3)));
+    wave_lds_sync();
+    for (int k = 0; k < cx.cpl; ++k) {
+        const int c = lane + 64 * k;
+        if (c < C) {
+            u32 bm = 0;
+            for (int s = 0; s < K; ++s) bm |= (u32)((int)(cx.body[s * C + c] & VMASK) > cx.tclk[s]) << s;
+            const u32 hm = cx.hmap[c], occ = bm | hm;
+            u32 code;
+            if (occ == 0) code = cx.food[c] != 0 ? REP : 0u;
+            else if ((occ & (occ - 1u)) == 0) // one snake: the others see 4 (body) / 5 (head), the snake itself 2 / 3
+                code = ((hm ? 5u : 4u) * REP) ^ (6u << (3 * (__ffs((int)occ) - 1)));
+            else { // several snakes on the cell (hand-made states, and heads that have just run into something)
+                code = 0;
+                for (int a = 0; a < K; ++a) {
+                    const u32 others = ~(1u << a);
+                    code |= ((hm & others) ? 5u : (bm & others) ? 4u : ((hm >> a) & 1u) ? 3u : 2u) << (3 * a);
+                }
+            }
+            codes[c] = (unsigned short)code;
+        }
+    }
+    wave_lds_sync();
+    // the border ring (:183-186) is painted last, over whatever sits there: its 4 S - 4 cells, whatever the state
+    for (int b = lane; b < 4 * S - 4; b += 64) {
+        const int j = b - 2 * S;                       // >= 0: the left / right columns, rows 1 .. S - 2
+        const int c = b < S ? b : b < 2 * S ? (S - 1) * S + (b - S) : ((j >> 1) + 1) * S + (j & 1) * (S - 1);
+        codes[c] = (unsigned short)(6u * REP);
+    }
+    if (lane < K && hc >= 0) cx.hmap[hc] = 0;
+    wave_lds_sync();
+}
+
+typedef float grp_vf4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) float grp_gfloat;     // a pointer KNOWN to be global memory: global_store, not flat_store
+typedef __attribute__((address_space(1))) grp_vf4 grp_gvf4;
+
+// one (agent, env, plane) segment of C floats from the env's class codes: dword stores up to the first 16-byte boundary and
+// behind the last one (one instruction for both), 16-byte stores in between.  The writer is bound by the LATENCY of its
+// two dependent LDS reads per float (measured: two writer waves per workgroup cannot keep up with eight steppers), so the
+// reads of three store groups (and of the edge store) are issued together: unconditional, on clamped cells; only the
+// stores are predicated.
+constexpr int GRP_UNROLL = 3; // 16-byte store groups per lane in flight: 3 x 64 x 4 = 768 floats >= one 25 x 25 plane
+
+// class of agent (sh = 3 a) in code q (0 / 1) of a 32-bit word holding two 16-bit codes, times 4: the byte offset into a
+// plane's row of the table (v_bfe_u32 + v_lshlrev_b32)
+__device__ __forceinline__ u32 grp_class4(u32 word, u32 sh, int q) { return __builtin_amdgcn_ubfe(word, sh + 16u * (u32)q, 3u) << 2; }
+
+__device__ __forceinline__ float grp_tab(const float *tabp, u32 off) { return *(const float *)((const unsigned char *)tabp + off); }
+
+// (reads run past the last store group of a plane and, for the last env of a buffer, past its code array: into the next
+// array / the output buffers of the same workgroup's LDS — never stored; the host layout keeps GRP_CODE_SLACK bytes behind
+// the code buffers)
+__device__ __forceinline__ void grp_emit_segment(grp_gfloat *seg, const unsigned short *cg, const float *tabp, u32 sh, int C, int lane)
+{
+    const int h = (int)((4u - (u32)(((size_t)seg >> 2) & 3u)) & 3u);   // floats in front of the first boundary
+    const int nb = (C - h) >> 2, r = (C - h) & 3, t0 = h + 4 * nb;
+    // the floats in front of the first and behind the last boundary: lanes 0 .. 3 and 4 .. 7
+    const int ecell = lane < 4 ? lane : t0 + lane - 4;
+    const bool eon = lane < 4 ? lane < h : lane - 4 < r;
+    const u32 ecode = cg[eon ? ecell : 0];
+    const unsigned char *cb = (const unsigned char *)(cg + h) + 8 * lane;   // this lane's first group: cells h + 4 lane ...
+    for (int base = 0; base < nb; base += 64 * GRP_UNROLL) {
+        u32 lo[GRP_UNROLL], hi[GRP_UNROLL];
+#pragma unroll
+        for (int u = 0; u < GRP_UNROLL; ++u) { // four 16-bit codes: two 4-byte reads (2-byte aligned: LDS takes unaligned reads)
+            const unsigned char *a = cb + 8 * (base + 64 * u);
+            __builtin_memcpy(&lo[u], a, 4);
+            __builtin_memcpy(&hi[u], a + 4, 4);
+        }
+        grp_vf4 v[GRP_UNROLL];
+#pragma unroll
+        for (int u = 0; u < GRP_UNROLL; ++u) {
+            v[u].x = grp_tab(tabp, grp_class4(lo[u], sh, 0));
+            v[u].y = grp_tab(tabp, grp_class4(lo[u], sh, 1));
+            v[u].z = grp_tab(tabp, grp_class4(hi[u], sh, 0));
+            v[u].w = grp_tab(tabp, grp_class4(hi[u], sh, 1));
+        }
+#pragma unroll
+        for (int u = 0; u < GRP_UNROLL; ++u) {
+            const int i = base + lane + 64 * u;
+            if (i < nb) *(grp_gvf4 *)(seg + h + 4 * i) = v[u];
+        }
+    }
+    const float ev = grp_tab(tabp, grp_class4(ecode, sh, 0));
+    if (eon) seg[ecell] = ev;
+}
+
+// Per-snake scalars of an env while its stepper wave works on another one (EPS > 1): 8 ints per snake in LDS
+__device__ __forceinline__ void grp_save(int *sv, int lane, int K, const Snake &sn, bool col_dirty, int hc0)
+{
+    if (lane < K) {
+        int *q = sv + 8 * lane;
+        q[0] = sn.hc; q[1] = sn.L; q[2] = (int)sn.done | ((int)sn.boosted << 1) | ((int)col_dirty << 2); q[3] = (int)sn.orient;
+        q[4] = (int)(unsigned short)sn.col[0] | ((int)(unsigned short)sn.col[1] << 16); q[5] = (int)sn.col[2]; q[6] = hc0;
+    }
+}
+
+__device__ __forceinline__ void grp_restore(const int *sv, int lane, int K, Snake &sn, bool &col_dirty, int &hc0)
+{
+    sn.hc = -1; sn.L = 0; sn.done = true; sn.orient = 0; sn.boosted = false; sn.col[0] = sn.col[1] = sn.col[2] = 0;
+    col_dirty = false; hc0 = -1;
+    if (lane < K) {
+        const int *q = sv + 8 * lane;
+        sn.hc = q[0]; sn.L = q[1]; sn.done = (q[2] & 1) != 0; sn.boosted = (q[2] & 2) != 0; col_dirty = (q[2] & 4) != 0;
+        sn.orient = q[3]; sn.col[0] = (short)(q[4] & 0xffff); sn.col[1] = (short)(q[4] >> 16); sn.col[2] = (short)q[5]; hc0 = q[6];
+    }
+}
+
+// G envs, G / EPS stepper waves (EPS envs each, one after the other within a step: the transition of one env is a chain of
+// dependent LDS operations that takes a wave ~5 us of the ~22 us the step's observations need on the store path, and a
+// stepper's register budget is what limits the waves per SIMD — so fewer, fuller stepper waves), W writer waves.
+template <int G, int W, int EPS, int OCC>
+__global__ __launch_bounds__(64 * (G / EPS + W)) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void multi_rollout_group_kernel(MultiArgs p)
+{
+    constexpr int NSW = G / EPS; // stepper waves
+    const int wave = uniform((int)(threadIdx.x >> 6)), lane = (int)(threadIdx.x & 63u);
+    const long long env0 = xcd_block(blockIdx.x, gridDim.x) * G;
+    if (env0 >= p.N) return;
+    const int nG = (int)min((long long)G, p.N - env0);
+    const int C = p.S * p.S, K = p.K;
+    const long long KN = (long long)K * p.N;
+    float *const tab = (float *)wurm_multi_lds;
+    unsigned char *const codes0 = wurm_multi_lds + p.grp_codes, *const outs0 = wurm_multi_lds + p.grp_outs;
+    if (threadIdx.x < 24) { // tab[plane][class]: the reference's colours / 255 (true divisions, as `.to(dtype) / 255` :281)
+        const int pl = (int)threadIdx.x >> 3, cls = (int)threadIdx.x & 7;
+        const float G1 = 192.0f / 255.0f, G2 = 96.0f / 255.0f;
+        float v = 0.0f;
+        if (cls == 0) v = 1.0f;                              // background (255, 255, 255)
+        else if (cls == 1) v = pl == 0 ? 1.0f : 0.0f;        // food (255, 0, 0)
+        else if (cls == 2) v = pl == 1 ? G2 : 0.0f;          // own body (0, 96, 0)
+        else if (cls == 3) v = pl == 1 ? G1 : 0.0f;          // own head (0, 192, 0)
+        else if (cls == 4) v = pl == 2 ? G2 : 0.0f;          // other body (0, 0, 96)
+        else if (cls == 5) v = pl == 2 ? G1 : 0.0f;          // other head (0, 0, 192)
+        tab[pl * 8 + cls] = v;                               // 6: border (0, 0, 0)
+    }
+    __syncthreads();
+
+    if (wave >= NSW) { // ---- a writer: the observations of step t from buffer t & 1, handed over by the barrier of step t
+        const int w = wave - NSW;
+        __builtin_amdgcn_s_setprio(2); // the store stream is what the launch is bound by: its waves issue first
+        for (long long t = 0; t < p.T; ++t) {
+            workgroup_handoff();
+            const unsigned char *cbuf = codes0 + (size_t)(t & 1) * G * p.grp_code_bytes;
+            // writer wave -> (agent, part of the group's envs): one agent after the other while there are at most as many
+            // waves as agents, else W / K waves per agent, each with its own contiguous part of the run
+            const int parts = W > K ? W / K : 1, part = W > K ? w / K : 0;
+            const int g0 = part * G / parts, g1 = min((part + 1) * G / parts, nG);
+            for (int a = W > K ? w % K : w; a < K && part < parts; a += W > K ? K : W) {
+                grp_gfloat *const run = (grp_gfloat *)uniform64((long long)(p.obs + ((t * K + a) * p.N + env0) * p.obs_elems));
+                const u32 sh = 3u * (u32)a;
+                for (int g = g0; g < g1; ++g) {
+                    const unsigned short *cg = (const unsigned short *)(cbuf + (size_t)g * p.grp_code_bytes);
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) grp_emit_segment(run + (size_t)(g * 3 + pl) * C, cg, tab + pl * 8, sh, C, lane);
+                }
+            }
+            if (w == 0) { // the steppers' per-step outputs: rows (j K + s) of G consecutive envs each
+                const unsigned char *obuf = outs0 + (size_t)(t & 1) * G * p.grp_out_bytes;
+                float *of = p.am_f32 + t * 3 * KN;
+                uint8_t *ob = p.am_u8 + t * 4 * KN;
+                for (int i = lane; i < 3 * K * G; i += 64) {
+                    const int g = i % G, js = i / G;
+                    if (g < nG) of[(long long)js * p.N + env0 + g] = ((const float *)(obuf + (size_t)g * p.grp_out_bytes))[js];
+                }
+                for (int i = lane; i < 4 * K * G; i += 64) {
+                    const int g = i % G, js = i / G;
+                    if (g < nG) ob[(long long)js * p.N + env0 + g] = (obuf + (size_t)g * p.grp_out_bytes)[12 * K + js];
+                }
+                if (lane < nG) p.all_done[t * p.N + env0 + lane] = (obuf + (size_t)lane * p.grp_out_bytes)[16 * K];
+            }
+        }
+        return;
+    }
+
+    // ---- a stepper: envs env0 + wave * EPS + e, e < EPS; the scalars of the envs it is not working on wait in LDS
+    const bool snake = lane < K;
+    int *const save0 = (int *)(wurm_multi_lds + p.grp_save);
+    for (int e = 0; e < EPS; ++e) {
+        const int g = wave * EPS + e;
+        const long long env = env0 + g;
+        if (env >= p.N) break;
+        const Ctx cx = make_ctx(p, g, p.grp_env0);
+        const long long agent = env * K + lane;
+        (void)load_env(cx, p.foods + env * C, p.heads + env * K * C, p.bodies + env * K * C);
+        Snake sn;
+        sn.hc = snake ? cx.hcell[lane] : -1;
+        sn.L = snake ? cx.lmax[lane] : 0;
+        sn.done = snake ? p.dones[agent] != 0 : true;
+        sn.orient = snake ? p.orientations[agent] : 0;
+        sn.boosted = false;
+        load_colour(p, agent, snake, sn);
+        grp_save(save0 + g * 8 * K, lane, K, sn, false, sn.hc);
+    }
+    wave_lds_sync();
+
+    for (long long t = 0; t < p.T; ++t) {
+        const u64 call = p.call + 2ull * (u64)t;
+        for (int e = 0; e < EPS; ++e) {
+            const int g = wave * EPS + e;
+            const long long env = env0 + g;
+            if (env >= p.N) break; // (a ragged last group: the barrier below is still the workgroup's)
+            const Ctx cx = make_ctx(p, g, p.grp_env0);
+            const u64 env_id = (u64)(p.env_offset + env);
+            const long long agent = env * K + lane;
+            Snake sn;
+            bool col_dirty;
+            int hc0;
+            grp_restore(save0 + g * 8 * K, lane, K, sn, col_dirty, hc0);
+            if ((t & 63) == 0) { // actions: 64 steps at a time into LDS (see multi_rollout_kernel)
+                const int nt = (int)min((long long)64, p.T - t);
+                wave_lds_sync();
+                for (int i = lane; i < nt * K; i += 64) {
+                    const int j = i / K, sidx = i - j * K;
+                    const long long av = p.actions[(t + j) * KN + (long long)sidx * p.N + env];
+                    cx.acts[i] = (unsigned char)(((int)(av % 4) + 4) | (av > 3 ? 8 : 0));
+                }
+                wave_lds_sync();
+            }
+            long long a = 0;
+            if (snake) {
+                const int b = cx.acts[(int)(t & 63) * K + lane];
+                const int d4 = (b & 7) - 4;
+                a = (b & 8) ? 4 + d4 : d4;
+            }
+            StepRes r;
+            multi_step_body(cx, p, env, env_id, call, a, sn, r, t * p.N * C, t * KN, t * p.N);
+            // buffer t & 1 is free: the writers finished with it before they arrived at the barrier of step t - 1
+            unsigned char *obuf = outs0 + ((size_t)(t & 1) * G + g) * p.grp_out_bytes;
+            if (snake) {
+                float *f = (float *)obuf;
+                f[lane] = r.reward;
+                f[K + lane] = r.foodcons;
+                f[2 * K + lane] = (float)sn.L;
+                unsigned char *b = obuf + 12 * K;
+                b[lane] = (unsigned char)sn.done;
+                b[K + lane] = (unsigned char)sn.boosted;
+                b[2 * K + lane] = (unsigned char)r.snakecol;
+                b[3 * K + lane] = (unsigned char)r.edgecol;
+            }
+            if (lane == 0) obuf[16 * K] = (unsigned char)r.all_done;
+            class_write(cx, sn.hc, (unsigned short *)(codes0 + ((size_t)(t & 1) * G + g) * p.grp_code_bytes));
+            if (lane == 0) ((int *)(save0 + g * 8 * K))[7] = (int)r.all_done;   // (slot 7 of snake 0: for the reset below)
+            grp_save(save0 + g * 8 * K, lane, K, sn, col_dirty, hc0);
+            wave_lds_sync();
+        }
+        // the writers start on step t NOW: the reset that follows the step (a rebuilt env costs as much as a whole
+        // transition) runs beside them, not in front of them
+        workgroup_handoff();
+        for (int e = 0; e < EPS; ++e) {
+            const int g = wave * EPS + e;
+            const long long env = env0 + g;
+            if (env >= p.N) break;
+            const Ctx cx = make_ctx(p, g, p.grp_env0);
+            const u64 env_id = (u64)(p.env_offset + env);
+            const long long agent = env * K + lane;
+            Snake sn;
+            bool col_dirty;
+            int hc0;
+            grp_restore(save0 + g * 8 * K, lane, K, sn, col_dirty, hc0);
+            const bool rebuild = uniform(((const int *)(save0 + g * 8 * K))[7]) != 0;
+            rebase_clocks(cx);
+
+            // reset(dones['__all__']) (:771-836)
+            if (snake && sn.done) sn.L = 0;
+            if (rebuild) sn.done = false;             // :798
+            if (snake) col_dirty |= reroll_colour(p, agent, sn.done, env_id, call + 1ull, t * KN, sn);
+            const bool respawn = p.cfg.respawn_any && ballot(snake && sn.done) != 0;
+            if (rebuild || respawn) {
+                bool orient_dirty = false;
+                multi_reset_grid(cx, p, env, env_id, call + 1ull, rebuild, respawn, sn, orient_dirty, t * KN, t * p.N);
+            }
+            grp_save(save0 + g * 8 * K, lane, K, sn, col_dirty, hc0);
+            wave_lds_sync();
+        }
+    }
+
+    for (int e = 0; e < EPS; ++e) {
+        const int g = wave * EPS + e;
+        const long long env = env0 + g;
+        if (env >= p.N) break;
+        const Ctx cx = make_ctx(p, g, p.grp_env0);
+        const long long agent = env * K + lane;
+        Snake sn;
+        bool col_dirty;
+        int hc0;
+        grp_restore(save0 + g * 8 * K, lane, K, sn, col_dirty, hc0);
+        if (snake) {
+            p.dones[agent] = (uint8_t)sn.done;
+            p.orientations[agent] = sn.orient;
+            if (p.boost_state) p.boost_state[agent] = (uint8_t)sn.boosted;
+            if (col_dirty) {
+                p.colours[agent * 3] = sn.col[0];
+                p.colours[agent * 3 + 1] = sn.col[1];
+                p.colours[agent * 3 + 2] = sn.col[2];
+            }
+            cx.hcell[lane] = sn.hc;
+        }
+        wave_lds_sync();
+        // the food plane is written whole (the original bits are not kept across the launch: ~cur marks every cell changed)
+        u64 cur = 0;
+        for (int k = 0; k < cx.cpl; ++k) {
+            const int c = lane + 64 * k;
+            if (c < C && cx.food[c]) cur |= 1ull << k;
+        }
+        store_env(cx, p.foods + env * C, p.heads + env * K * C, p.bodies + env * K * C, ~cur, hc0, sn.hc, false);
+    }
+}
+
 // check_consistency (:733-769) -> per-env bitmask.  Every plane is read once: the per-cell count of snakes (overlap test)
 // is kept in LDS, one byte per cell; a cell belongs to one lane, so plain read-modify-writes.
 // The env's planes are walked as ITEMS of (snake, 11 rows of 64 cells), double-buffered in registers: the 16 loads of item
@@ -2099,6 +2444,46 @@ static int multi_launch(MKind kind, MultiArgs &p, void *stream)
     // double-buffer it between a stepping and a writing wave (multi_rollout_kernel<true>)
     const bool snap = p.obs_mode == WURM_OBS_DEFAULT && p.K <= SNAP_MAX_SNAKES;
     const bool two = kind == MK_ROLLOUT && snap && p.T > 1;
+    if (two && p.K <= GRP_MAX_SNAKES && p.N >= opt.multi_group_min_envs) {
+        // large batches: G consecutive envs per workgroup, one linear observation run per agent (multi_rollout_group_kernel)
+        MultiArgs q = p;
+        const int lds_env = multi_layout(q, false, 0), C = p.S * p.S;
+        q.grp_code_bytes = (2 * C + 15) & ~15;
+        q.grp_out_bytes = (16 * p.K + 1 + 15) & ~15;
+        const int save_bytes = 32 * p.K; // grp_save: 8 ints per snake
+        // (the writers read up to GRP_CODE_SLACK bytes past a code array: what lies behind the last one must be this LDS)
+        auto slack = [&](int G) { return std::max(0, GRP_CODE_SLACK - G * (2 * q.grp_out_bytes + save_bytes)); };
+        auto total = [&](int G) { return GRP_TAB_BYTES + G * (lds_env + 2 * q.grp_code_bytes + 2 * q.grp_out_bytes + save_bytes) + slack(G); };
+        // shape: G envs, W writer waves, EPS envs per stepper wave, OCC waves per SIMD (option WURM_MULTI_GROUP_SHAPE =
+        // 1000 G + 100 W + 10 EPS + OCC picks one of the compiled shapes; 0 = automatic: the first that fits)
+        struct Shape { int G, W, eps, occ; const void *fn; };
+        static const Shape shapes[] = {
+            {8, 4, 2, 4, (const void *)multi_rollout_group_kernel<8, 4, 2, 4>}, {8, 4, 1, 6, (const void *)multi_rollout_group_kernel<8, 4, 1, 6>},
+            {4, 4, 1, 4, (const void *)multi_rollout_group_kernel<4, 4, 1, 4>}, {8, 4, 4, 5, (const void *)multi_rollout_group_kernel<8, 4, 4, 5>},
+            {8, 8, 2, 6, (const void *)multi_rollout_group_kernel<8, 8, 2, 6>}, {4, 4, 2, 6, (const void *)multi_rollout_group_kernel<4, 4, 2, 6>},
+        };
+        const Shape *sh = nullptr;
+        for (const Shape &c : shapes) {
+            const bool fits = total(c.G) <= LDS_MAX_BYTES;
+            if (opt.multi_group_shape ? (1000 * c.G + 100 * c.W + 10 * c.eps + c.occ == opt.multi_group_shape && fits)
+                                      : (fits && (c.G == 4 || 2 * total(8) <= LDS_MAX_BYTES))) { sh = &c; break; }
+        }
+        if (sh) {
+            const int G = sh->G, W = sh->W;
+            q.grp_env0 = GRP_TAB_BYTES;
+            q.grp_codes = q.grp_env0 + G * lds_env;
+            q.grp_outs = q.grp_codes + 2 * G * q.grp_code_bytes;
+            q.grp_save = q.grp_outs + 2 * G * q.grp_out_bytes;
+            const size_t bytes = (size_t)total(G);
+            const dim3 gg((unsigned)((p.N + G - 1) / G)), bb(64 * (G / sh->eps + W));
+            (void)hipGetLastError();
+            if (!allow_lds(sh->fn, bytes)) return WURM_ERR_HIP;
+            void *args[] = {&q};
+            ++launch_count;
+            if (hipLaunchKernel(sh->fn, gg, bb, args, bytes, (hipStream_t)stream) != hipSuccess) return WURM_ERR_HIP;
+            return hipGetLastError() == hipSuccess ? WURM_OK : WURM_ERR_HIP;
+        }
+    }
     int lds = multi_layout(p, p.obs_mode == WURM_OBS_PARTIAL, snap ? (two ? 2 : 1) : 0);
     if (kind == MK_CHECK) lds = p.lds_per_wave = (p.S * p.S + 15) & ~15; // the checker keeps one byte per cell
     // One env's grids must fit the LDS of a CU.  Up to 64 KB is the default limit of a launch; beyond it the kernel is
