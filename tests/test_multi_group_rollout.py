@@ -18,7 +18,7 @@ from wurm_amd._lib import knobs
 
 pytestmark = pytest.mark.gpu
 
-SHAPES = [8424, 8416, 4414, 8445, 8826, 4426]
+SHAPES = [8416, 4414, 8424]
 
 
 @pytest.fixture(scope='module')
@@ -92,7 +92,7 @@ def test_group_rollout_replays_the_reference(hip, name):
     fx = replay.load_multi(name)
     if fx['mode'] != 'full':
         pytest.skip('fixture does not use the full observation')
-    for shape in (8424, 4426):
+    for shape in (8416, 4414):
         with knobs(WURM_MULTI_GROUP_MIN_ENVS=0, WURM_MULTI_GROUP_SHAPE=shape):
             replay.replay_multi_rollout(hip(), fx)
 
@@ -126,3 +126,21 @@ def test_paint_order_on_hand_made_states(hip):
         _same(ro[k], rh[k], k)
     _same_state(so, sh, 'final state')
     del st0
+
+
+def test_per_call_parity_suites_with_the_grouped_writer():
+    """multi_step_kernel with `grp_emit` (the workgroup's waves write the 'full' observations together): the MultiSnake
+    per-call suites — oracle loops, fused step / reset, resident mirror, reference fixtures, KATs — in a child process
+    with WURM_MULTI_GROUP_MIN_ENVS=0, which turns it on for every batch size"""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get('WURM_MULTI_GROUP_MIN_ENVS') == '0':
+        pytest.skip('already inside the forced run')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WURM_MULTI_GROUP_MIN_ENVS='0')
+    r = subprocess.run([sys.executable, '-m', 'pytest', '-q', '-m', 'gpu', '-x', 'tests/test_hip_multi_vs_oracle.py',
+                        'tests/test_hip_multi_fused.py', 'tests/test_multi_resident.py', 'tests/test_kat_multi_snake.py',
+                        'tests/test_hip_golden.py', '-k', 'not larger_than_64kb'],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]

@@ -73,6 +73,8 @@ struct MultiArgs {
     // multi_rollout_group_kernel: offsets (bytes, from the start of the workgroup's LDS) of the env blocks, the two class
     // code buffers and the two output buffers, and the size of one env's share of each
     int grp_env0, grp_codes, grp_outs, grp_save, grp_code_bytes, grp_out_bytes;
+    int grp_variant; // multi_rollout_group_kernel, probe build only: bit 2 no observation stores, bit 3 no transition
+    int grp_emit; // multi_step_kernel: the workgroup's waves write the 'full' observations together (grp_env0: the table)
 };
 
 struct Ctx {
@@ -1113,14 +1115,43 @@ __device__ __forceinline__ bool reset_for_obs_after(const Ctx &cx, const MultiAr
     return rebuild_after || respawn_after;
 }
 
-__global__ __launch_bounds__(256) void multi_step_kernel(MultiArgs p)
+// (LDS written by some waves of a workgroup and read by others)
+__device__ __forceinline__ void workgroup_handoff()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// the pieces of the grouped 'full' observation writer (defined with multi_rollout_group_kernel below)
+__device__ __forceinline__ void class_write(const Ctx &cx, int hc, unsigned short *codes);
+__device__ __forceinline__ void grp_table_init(float *tab, int tid);
+__device__ __forceinline__ void grp_emit_group(const MultiArgs &p, float *obs, long long env0, int nG, int wave, int nwaves,
+                                               const unsigned char *codes0, int code_stride, const float *tab, int lane);
+
+// `p.grp_emit` (large batches, 'full' observations of at most 5 snakes, several envs per workgroup): the waves of the
+// workgroup first step their envs, then write the observations TOGETHER — wave w writes agent w's view of all the
+// workgroup's envs, one linear run (class codes + colour table: see multi_rollout_group_kernel).
+__global__ __launch_bounds__(512) void multi_step_kernel(MultiArgs p)
 {
     const int wave = (int)(threadIdx.x >> 6), wpb = (int)(blockDim.x >> 6);
-    const long long env = xcd_block(blockIdx.x, gridDim.x) * wpb + wave;
-    if (env >= p.N) return;
+    const long long env0 = xcd_block(blockIdx.x, gridDim.x) * wpb, env = env0 + wave;
+    const bool grouped = p.grp_emit != 0;
+    float *const tab = (float *)(wurm_multi_lds + p.grp_env0); // (grouped: the colour table behind the envs' blocks)
+    if (grouped) {
+        if (env0 >= p.N) return;
+        grp_table_init(tab, (int)threadIdx.x);
+    } else if (env >= p.N) return;
+    const bool active = env < p.N;
     const Ctx cx = make_ctx(p, wave);
     const int C = cx.C, K = cx.K, lane = cx.lane;
     const bool snake = lane < K;
+    const int nG = (int)min((long long)wpb, p.N - env0);
+    Snake sn;
+    StepRes r;
+    bool clean = false;
+    uint32_t m_step = MCHK_NOT_COMPUTED;
+    if (active) {
     float *foodp = p.foods + env * C, *headp = p.heads + env * K * C, *bodyp = p.bodies + env * K * C;
 
     // An env the postponed reset rebuilds is not read at all (as in multi_reset_kernel): the launch is one round of waves
@@ -1140,12 +1171,9 @@ __global__ __launch_bounds__(256) void multi_step_kernel(MultiArgs p)
         wave_lds_sync();
     }
     const int t0 = snake ? cx.tclk[lane] : 0; // the clocks as loaded (0 unless the state came from the mirror)
-    Snake sn;
-    StepRes r;
     int hc0;
     step_middle(cx, p, env, rebuild, sn, r, hc0);
-    const bool clean = from_mirror || rebuild || plain; // lds_check sees everything there is to check
-    uint32_t m_step = MCHK_NOT_COMPUTED;
+    clean = from_mirror || rebuild || plain; // lds_check sees everything there is to check
     if (p.err != nullptr) {
         if (clean) m_step = lds_check(cx, sn);
         if (lane == 0) p.err[env] = m_step;
@@ -1162,6 +1190,41 @@ __global__ __launch_bounds__(256) void multi_step_kernel(MultiArgs p)
         mirror_store(cx, mp, lane, 64, sn.hc, (snake && !sn.done) ? sn.L : 0, fence, // (a deleted snake's body reads all-zero)
                      from_mirror && !rebuild && !rebased, fbits0);
         wave_lds_sync();
+    }
+    }
+    if (grouped && p.grp_emit == 2) { // every wave for itself: its env's class codes -> its K agents' views (no barrier)
+        workgroup_handoff(); // (the table)
+        if (!active) return;
+        class_write(cx, sn.hc, cx.snap);
+        grp_emit_group(p, p.obs + env * p.obs_elems - env0 * p.obs_elems, env0, 1, 0, 1, (const unsigned char *)cx.snap, 0, tab, lane);
+        if (p.obs_after == nullptr) return;
+        const bool touched = reset_for_obs_after(cx, p, env, sn, r);
+        if (p.err_after != nullptr) {
+            if (touched) m_step = clean ? lds_check(cx, sn) : MCHK_NOT_COMPUTED;
+            if (lane == 0) p.err_after[env] = m_step;
+        }
+        class_write(cx, sn.hc, cx.snap);
+        grp_emit_group(p, p.obs_after + env * p.obs_elems - env0 * p.obs_elems, env0, 1, 0, 1, (const unsigned char *)cx.snap, 0, tab, lane);
+        return;
+    }
+    if (grouped) {
+        const unsigned char *codes0 = (const unsigned char *)make_ctx(p, 0).snap;
+        if (active) class_write(cx, sn.hc, cx.snap);
+        workgroup_handoff();
+        grp_emit_group(p, p.obs, env0, nG, wave, wpb, codes0, p.lds_per_wave, tab, lane);
+        if (p.obs_after == nullptr) return;
+        workgroup_handoff(); // every wave has read the codes of the stepped state
+        if (active) {
+            const bool touched = reset_for_obs_after(cx, p, env, sn, r);
+            if (p.err_after != nullptr) {
+                if (touched) m_step = clean ? lds_check(cx, sn) : MCHK_NOT_COMPUTED; // (else: the state the first mask describes)
+                if (lane == 0) p.err_after[env] = m_step;
+            }
+            class_write(cx, sn.hc, cx.snap);
+        }
+        workgroup_handoff();
+        grp_emit_group(p, p.obs_after, env0, nG, wave, wpb, codes0, p.lds_per_wave, tab, lane);
+        return;
     }
     if (p.obs_mode != WURM_OBS_NONE) observe(cx, p, p.obs, env, sn);
     if (p.obs_after == nullptr || p.obs_mode == WURM_OBS_NONE) return;
@@ -1834,12 +1897,6 @@ __global__ __launch_bounds__(256) void multi_observe_wg_kernel(MultiArgs p)
 // transition (latency-bound LDS work) and the observation (store-bound) of a launch otherwise ADD UP — every wave is in
 // the same phase — and interleaving them inside one wave does not help (measured); two waves with their own
 // instruction streams do overlap.
-__device__ __forceinline__ void workgroup_handoff()
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-}
 
 template <bool TWO>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void multi_rollout_kernel(MultiArgs p)
@@ -1967,7 +2024,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void m
 //     stream of the whole CU stall the stepper at issue).
 constexpr int GRP_MAX_SNAKES = 5;   // 3 bits per agent in a 16-bit word
 constexpr int GRP_TAB_BYTES = 128;  // float tab[3][8] at the start of the workgroup's LDS
-constexpr int GRP_CODE_SLACK = 1600; // bytes the writers may READ behind the last code array (grp_emit_segment)
+constexpr int GRP_CODE_SLACK = 640;  // bytes the writers may READ behind the last code array (grp_emit_cells: 5 x 64 codes)
 
 // (sum over a < K of 8^a): a 3-bit value replicated into the K agents' fields
 __device__ __forceinline__ u32 grp_rep(int K) { return (u32)(((1ull << (3 * K)) - 1ull) / 7ull); }
@@ -2015,59 +2072,99 @@ __device__ __forceinline__ void class_write(const Ctx &cx, int hc, unsigned shor
     wave_lds_sync();
 }
 
-typedef float grp_vf4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(1))) float grp_gfloat;     // a pointer KNOWN to be global memory: global_store, not flat_store
-typedef __attribute__((address_space(1))) grp_vf4 grp_gvf4;
+// Probe build (make -C wurm_amd/csrc probe -> libwurm_hip_probe.so; tools/multi_group_probe.py): WURM_MULTI_GROUP_VARIANT
+// bit 2 drops the writers' stores, bit 3 the steppers' transition — which half bounds the launch.  Results are wrong by
+// construction with either bit; the shipped library compiles the switches out.
+#ifdef WURM_GROUP_PROBE
+#define WURM_PROBE(probe, shipped) (probe)
+#else
+#define WURM_PROBE(probe, shipped) (shipped)
+#endif
 
 // one (agent, env, plane) segment of C floats from the env's class codes: dword stores up to the first 16-byte boundary and
 // behind the last one (one instruction for both), 16-byte stores in between.  The writer is bound by the LATENCY of its
 // two dependent LDS reads per float (measured: two writer waves per workgroup cannot keep up with eight steppers), so the
 // reads of three store groups (and of the edge store) are issued together: unconditional, on clamped cells; only the
 // stores are predicated.
-constexpr int GRP_UNROLL = 3; // 16-byte store groups per lane in flight: 3 x 64 x 4 = 768 floats >= one 25 x 25 plane
-
-// class of agent (sh = 3 a) in code q (0 / 1) of a 32-bit word holding two 16-bit codes, times 4: the byte offset into a
-// plane's row of the table (v_bfe_u32 + v_lshlrev_b32)
-__device__ __forceinline__ u32 grp_class4(u32 word, u32 sh, int q) { return __builtin_amdgcn_ubfe(word, sh + 16u * (u32)q, 3u) << 2; }
-
 __device__ __forceinline__ float grp_tab(const float *tabp, u32 off) { return *(const float *)((const unsigned char *)tabp + off); }
 
-// (reads run past the last store group of a plane and, for the last env of a buffer, past its code array: into the next
-// array / the output buffers of the same workgroup's LDS — never stored; the host layout keeps GRP_CODE_SLACK bytes behind
-// the code buffers)
-__device__ __forceinline__ void grp_emit_segment(grp_gfloat *seg, const unsigned short *cg, const float *tabp, u32 sh, int C, int lane)
+// The writer: one CELL per lane — its class is extracted ONCE and looked up in the three planes' rows of the table (three
+// LDS reads off one address register), three 4-byte stores per 64 cells (256 contiguous bytes each: the same stream rate as
+// 16-byte stores in tools/microbench/store_runs.hip, and nothing to align or peel).  Per 64 cells: 1 + 3 LDS reads, 2 VALU,
+// 3 stores.  (Round 4 first built the 16-byte-store form VERDICT r03 asked for — lane = 4 consecutive floats of a plane,
+// planes peeled to 16-byte boundaries: it extracts every class three times, once per plane, and pays ~60 instructions of
+// alignment / predication per plane; its writer waves alone took 17.6 us per step against 10.2 us for this form, the
+// launch 26.0 against 24.0 us per step on the same box: profiles/r04_multi_group_probe.txt.)
+template <int U>
+__device__ __forceinline__ void grp_emit_cells_chunk(grp_gfloat *blk, const unsigned short *cg, const float *tab, u32 sh, int C,
+                                                     int c0, bool stores)
 {
-    const int h = (int)((4u - (u32)(((size_t)seg >> 2) & 3u)) & 3u);   // floats in front of the first boundary
-    const int nb = (C - h) >> 2, r = (C - h) & 3, t0 = h + 4 * nb;
-    // the floats in front of the first and behind the last boundary: lanes 0 .. 3 and 4 .. 7
-    const int ecell = lane < 4 ? lane : t0 + lane - 4;
-    const bool eon = lane < 4 ? lane < h : lane - 4 < r;
-    const u32 ecode = cg[eon ? ecell : 0];
-    const unsigned char *cb = (const unsigned char *)(cg + h) + 8 * lane;   // this lane's first group: cells h + 4 lane ...
-    for (int base = 0; base < nb; base += 64 * GRP_UNROLL) {
-        u32 lo[GRP_UNROLL], hi[GRP_UNROLL];
+    u32 off[U];
 #pragma unroll
-        for (int u = 0; u < GRP_UNROLL; ++u) { // four 16-bit codes: two 4-byte reads (2-byte aligned: LDS takes unaligned reads)
-            const unsigned char *a = cb + 8 * (base + 64 * u);
-            __builtin_memcpy(&lo[u], a, 4);
-            __builtin_memcpy(&hi[u], a + 4, 4);
-        }
-        grp_vf4 v[GRP_UNROLL];
+    for (int u = 0; u < U; ++u) off[u] = __builtin_amdgcn_ubfe((u32)cg[c0 + 64 * u], sh, 3u) << 2; // (reads past C: see GRP_CODE_SLACK)
+    float r[U], g[U], b[U];
 #pragma unroll
-        for (int u = 0; u < GRP_UNROLL; ++u) {
-            v[u].x = grp_tab(tabp, grp_class4(lo[u], sh, 0));
-            v[u].y = grp_tab(tabp, grp_class4(lo[u], sh, 1));
-            v[u].z = grp_tab(tabp, grp_class4(hi[u], sh, 0));
-            v[u].w = grp_tab(tabp, grp_class4(hi[u], sh, 1));
-        }
+    for (int u = 0; u < U; ++u) {
+        r[u] = grp_tab(tab, off[u]);
+        g[u] = grp_tab(tab + 8, off[u]);
+        b[u] = grp_tab(tab + 16, off[u]);
+    }
 #pragma unroll
-        for (int u = 0; u < GRP_UNROLL; ++u) {
-            const int i = base + lane + 64 * u;
-            if (i < nb) *(grp_gvf4 *)(seg + h + 4 * i) = v[u];
+    for (int u = 0; u < U; ++u) {
+        const int c = c0 + 64 * u;
+        if (c < C && stores) {
+            blk[c] = r[u];
+            blk[C + c] = g[u];
+            blk[2 * C + c] = b[u];
         }
     }
-    const float ev = grp_tab(tabp, grp_class4(ecode, sh, 0));
-    if (eon) seg[ecell] = ev;
+}
+
+__device__ __forceinline__ void grp_emit_cells(grp_gfloat *blk, const unsigned short *cg, const float *tab, u32 sh, int C, int lane,
+                                               bool stores)
+{
+    const int cpl = (C + 63) >> 6;
+    int k = 0;
+    for (; k + 5 <= cpl; k += 5) grp_emit_cells_chunk<5>(blk, cg, tab, sh, C, lane + 64 * k, stores);
+    for (; k < cpl; ++k) grp_emit_cells_chunk<1>(blk, cg, tab, sh, C, lane + 64 * k, stores);
+}
+
+// tab[plane][class]: the reference's colours / 255 (true divisions, as `.to(dtype) / 255` :281); the caller synchronises
+__device__ __forceinline__ void grp_table_init(float *tab, int tid)
+{
+    if (tid < 24) {
+        const int pl = tid >> 3, cls = tid & 7;
+        const float G1 = 192.0f / 255.0f, G2 = 96.0f / 255.0f;
+        float v = 0.0f;
+        if (cls == 0) v = 1.0f;                              // background (255, 255, 255)
+        else if (cls == 1) v = pl == 0 ? 1.0f : 0.0f;        // food (255, 0, 0)
+        else if (cls == 2) v = pl == 1 ? G2 : 0.0f;          // own body (0, 96, 0)
+        else if (cls == 3) v = pl == 1 ? G1 : 0.0f;          // own head (0, 192, 0)
+        else if (cls == 4) v = pl == 2 ? G2 : 0.0f;          // other body (0, 0, 96)
+        else if (cls == 5) v = pl == 2 ? G1 : 0.0f;          // other head (0, 0, 192)
+        tab[pl * 8 + cls] = v;                               // 6: border (0, 0, 0)
+    }
+}
+
+// per-call kernels: the nwaves waves of a workgroup write the observations of its nG consecutive envs (first env0), wave w
+// the whole run of agent w (w + nwaves, ...); obs: this call's (K, N, 3 S^2) block
+__device__ __forceinline__ void grp_emit_group(const MultiArgs &p, float *obs, long long env0, int nG, int wave, int nwaves,
+                                               const unsigned char *codes0, int code_stride, const float *tab, int lane)
+{
+    const int C = p.S * p.S, K = p.K;
+    // wave -> (agent, part of the envs): one agent after the other while there are at most as many waves as agents, else
+    // nwaves / K waves per agent, each with its own contiguous part of the agent's run
+    const int parts = nwaves > K ? nwaves / K : 1, part = nwaves > K ? wave / K : 0;
+    const int g0 = part * nG / parts, g1 = (part + 1) * nG / parts;
+    for (int a = nwaves > K ? wave % K : wave; a < K && part < parts; a += nwaves > K ? K : nwaves) {
+        grp_gfloat *const run = (grp_gfloat *)uniform64((long long)(obs + ((long long)a * p.N + env0) * p.obs_elems));
+        const u32 sh = 3u * (u32)a;
+        for (int g = g0; g < g1; ++g) {
+            const unsigned short *cg = (const unsigned short *)(codes0 + (size_t)g * code_stride);
+            grp_emit_cells(run + g * 3 * C, cg, tab, sh, C, lane, true);
+        }
+    }
 }
 
 // Per-snake scalars of an env while its stepper wave works on another one (EPS > 1): 8 ints per snake in LDS
@@ -2106,23 +2203,12 @@ __global__ __launch_bounds__(64 * (G / EPS + W)) __attribute__((amdgpu_waves_per
     const long long KN = (long long)K * p.N;
     float *const tab = (float *)wurm_multi_lds;
     unsigned char *const codes0 = wurm_multi_lds + p.grp_codes, *const outs0 = wurm_multi_lds + p.grp_outs;
-    if (threadIdx.x < 24) { // tab[plane][class]: the reference's colours / 255 (true divisions, as `.to(dtype) / 255` :281)
-        const int pl = (int)threadIdx.x >> 3, cls = (int)threadIdx.x & 7;
-        const float G1 = 192.0f / 255.0f, G2 = 96.0f / 255.0f;
-        float v = 0.0f;
-        if (cls == 0) v = 1.0f;                              // background (255, 255, 255)
-        else if (cls == 1) v = pl == 0 ? 1.0f : 0.0f;        // food (255, 0, 0)
-        else if (cls == 2) v = pl == 1 ? G2 : 0.0f;          // own body (0, 96, 0)
-        else if (cls == 3) v = pl == 1 ? G1 : 0.0f;          // own head (0, 192, 0)
-        else if (cls == 4) v = pl == 2 ? G2 : 0.0f;          // other body (0, 0, 96)
-        else if (cls == 5) v = pl == 2 ? G1 : 0.0f;          // other head (0, 0, 192)
-        tab[pl * 8 + cls] = v;                               // 6: border (0, 0, 0)
-    }
+    grp_table_init(tab, (int)threadIdx.x);
     __syncthreads();
 
     if (wave >= NSW) { // ---- a writer: the observations of step t from buffer t & 1, handed over by the barrier of step t
         const int w = wave - NSW;
-        __builtin_amdgcn_s_setprio(2); // the store stream is what the launch is bound by: its waves issue first
+        const bool stores = WURM_PROBE(!(p.grp_variant & 4), true);
         for (long long t = 0; t < p.T; ++t) {
             workgroup_handoff();
             const unsigned char *cbuf = codes0 + (size_t)(t & 1) * G * p.grp_code_bytes;
@@ -2135,8 +2221,7 @@ __global__ __launch_bounds__(64 * (G / EPS + W)) __attribute__((amdgpu_waves_per
                 const u32 sh = 3u * (u32)a;
                 for (int g = g0; g < g1; ++g) {
                     const unsigned short *cg = (const unsigned short *)(cbuf + (size_t)g * p.grp_code_bytes);
-#pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) grp_emit_segment(run + (size_t)(g * 3 + pl) * C, cg, tab + pl * 8, sh, C, lane);
+                    grp_emit_cells(run + g * 3 * C, cg, tab, sh, C, lane, stores);
                 }
             }
             if (w == 0) { // the steppers' per-step outputs: rows (j K + s) of G consecutive envs each
@@ -2207,8 +2292,8 @@ __global__ __launch_bounds__(64 * (G / EPS + W)) __attribute__((amdgpu_waves_per
                 const int d4 = (b & 7) - 4;
                 a = (b & 8) ? 4 + d4 : d4;
             }
-            StepRes r;
-            multi_step_body(cx, p, env, env_id, call, a, sn, r, t * p.N * C, t * KN, t * p.N);
+            StepRes r = {};
+            if (WURM_PROBE(!(p.grp_variant & 8), true)) multi_step_body(cx, p, env, env_id, call, a, sn, r, t * p.N * C, t * KN, t * p.N);
             // buffer t & 1 is free: the writers finished with it before they arrived at the barrier of step t - 1
             unsigned char *obuf = outs0 + ((size_t)(t & 1) * G + g) * p.grp_out_bytes;
             if (snake) {
@@ -2458,9 +2543,10 @@ static int multi_launch(MKind kind, MultiArgs &p, void *stream)
         // 1000 G + 100 W + 10 EPS + OCC picks one of the compiled shapes; 0 = automatic: the first that fits)
         struct Shape { int G, W, eps, occ; const void *fn; };
         static const Shape shapes[] = {
-            {8, 4, 2, 4, (const void *)multi_rollout_group_kernel<8, 4, 2, 4>}, {8, 4, 1, 6, (const void *)multi_rollout_group_kernel<8, 4, 1, 6>},
-            {4, 4, 1, 4, (const void *)multi_rollout_group_kernel<4, 4, 1, 4>}, {8, 4, 4, 5, (const void *)multi_rollout_group_kernel<8, 4, 4, 5>},
-            {8, 8, 2, 6, (const void *)multi_rollout_group_kernel<8, 8, 2, 6>}, {4, 4, 2, 6, (const void *)multi_rollout_group_kernel<4, 4, 2, 6>},
+            // (automatic: the first that fits.  Measured at cfg4, 64-step launches, same box: 8416 1.61 ms, 8424 1.79, 4414 1.81;
+            // the two-wave kernel of round 3: 2.05 — profiles/r04_multi_group_sweep.txt)
+            {8, 4, 1, 6, (const void *)multi_rollout_group_kernel<8, 4, 1, 6>}, {4, 4, 1, 4, (const void *)multi_rollout_group_kernel<4, 4, 1, 4>},
+            {8, 4, 2, 4, (const void *)multi_rollout_group_kernel<8, 4, 2, 4>}, {8, 2, 1, 5, (const void *)multi_rollout_group_kernel<8, 2, 1, 5>},
         };
         const Shape *sh = nullptr;
         for (const Shape &c : shapes) {
@@ -2478,6 +2564,7 @@ static int multi_launch(MKind kind, MultiArgs &p, void *stream)
             const dim3 gg((unsigned)((p.N + G - 1) / G)), bb(64 * (G / sh->eps + W));
             (void)hipGetLastError();
             if (!allow_lds(sh->fn, bytes)) return WURM_ERR_HIP;
+            q.grp_variant = (int)opt.multi_group_variant;
             void *args[] = {&q};
             ++launch_count;
             if (hipLaunchKernel(sh->fn, gg, bb, args, bytes, (hipStream_t)stream) != hipSuccess) return WURM_ERR_HIP;
@@ -2492,7 +2579,8 @@ static int multi_launch(MKind kind, MultiArgs &p, void *stream)
     if (lds > LDS_MAX_BYTES) return WURM_ERR_UNSUPPORTED;
     // few envs: one wave per workgroup so that they spread over all 256 CUs; from 2048 envs on 4 waves per workgroup
     // (8 workgroups per CU either way; the observation stream of 4096 envs measured ~5 % faster this way)
-    int wpb = p.N < 2048 ? 1 : 4;
+    const bool want_group = kind == MK_STEP && snap && p.K <= GRP_MAX_SNAKES && p.N >= opt.multi_group_min_envs;
+    int wpb = (p.N < 2048 && !want_group) ? 1 : 4;
     if (two) { // one env per workgroup of two waves
         dim3 block2(128), grid2((unsigned)p.N);
         (void)hipGetLastError();
@@ -2514,8 +2602,17 @@ static int multi_launch(MKind kind, MultiArgs &p, void *stream)
         return hipGetLastError() == hipSuccess ? WURM_OK : WURM_ERR_HIP;
     }
     while (wpb > 1 && lds * wpb > 65536) wpb >>= 1;
+    size_t extra = 0;
+    if (want_group && wpb == 4 && opt.multi_group_step_wpb != 0) {
+        // large batches: the workgroup's waves write the 'full' observations together, one linear run per agent; eight envs
+        // per workgroup where two such workgroups fit a CU (option WURM_MULTI_GROUP_STEP_WPB: 0 = off, 4 / 8 = that many)
+        extra = GRP_TAB_BYTES + GRP_CODE_SLACK;
+        if (2 * (8 * (size_t)lds + extra) <= (size_t)LDS_MAX_BYTES && opt.multi_group_step_wpb != 4 && opt.multi_group_step_wpb != 1) wpb = 8;
+        p.grp_emit = opt.multi_group_step_wpb == 1 ? 2 : 1;
+        p.grp_env0 = lds * wpb; // the table, behind the envs' blocks
+    }
     dim3 block(64 * wpb), grid((unsigned)((p.N + wpb - 1) / wpb));
-    size_t shmem = (size_t)lds * wpb;
+    size_t shmem = (size_t)lds * wpb + extra;
     hipStream_t st = (hipStream_t)stream;
     (void)hipGetLastError();
     const void *kf = kind == MK_STEP ? (const void *)multi_step_kernel

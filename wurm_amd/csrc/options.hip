@@ -8,7 +8,7 @@
 
 namespace wurm {
 
-constexpr Options DEFAULTS = {1ll << 20, 12288, 6144, -1, -1, -1, 12, 0, 2048, 0};
+constexpr Options DEFAULTS = {1ll << 20, 12288, 6144, -1, -1, -1, 12, 0, 2048, 0, -1, 0};
 Options opt = DEFAULTS;
 long long launch_count = 0;
 
@@ -29,6 +29,8 @@ const Entry table[] = {
     {"WURM_GRID_WAVES_PER_CU", &Options::grid_waves_per_cu},
     {"WURM_POLICY_GENERIC", &Options::policy_generic},
     {"WURM_MULTI_GROUP_MIN_ENVS", &Options::multi_group_min_envs},
+    {"WURM_MULTI_GROUP_VARIANT", &Options::multi_group_variant},
+    {"WURM_MULTI_GROUP_STEP_WPB", &Options::multi_group_step_wpb},
     {"WURM_MULTI_GROUP_SHAPE", &Options::multi_group_shape},
 };
 
