@@ -128,7 +128,7 @@ class HipBackend(object):
         if resident is not None:
             resident['valid'] = int(inject_food is None and inject_reset is None and inject_pre_reset is None and
                                     not post_reset and grid is None and
-                                    ((S == 9 and (m == _lib.OBS_NONE or (m == _lib.OBS_PARTIAL and n == 2))) or 12 <= S <= 64))
+                                    int(self.lib.wurm_single_resident_size(_lib.i64(N), S, m, n)) > 0)
             if lazy:
                 resident['envs_dev'] = e
                 c.resident_valid = resident['valid']

@@ -103,7 +103,12 @@ def test_resident_mirror_sizes():
     assert l.wurm_single_resident_bytes(65536, 9, *part2) == 65536 * 32          # 9 x 9: 32 bytes per env
     assert l.wurm_single_resident_bytes(4096, 9, *none) == 4096 * 32
     assert l.wurm_single_resident_bytes(4095, 9, *part2) == 0                    # latency-bound anyway
-    assert l.wurm_single_resident_bytes(65536, 9, _lib.OBS_PARTIAL, 3) == 0      # other crops: not served
+    assert l.wurm_single_resident_bytes(65536, 9, _lib.OBS_PARTIAL, 1) == 65536 * 32   # crops up to 5 x 5,
+    assert l.wurm_single_resident_bytes(65536, 9, _lib.OBS_ONE_CHANNEL, 0) == 65536 * 32   # one_channel, default, positions
+    assert l.wurm_single_resident_bytes(65536, 9, _lib.OBS_DEFAULT, 0) == 65536 * 32
+    assert l.wurm_single_resident_bytes(65536, 9, _lib.OBS_POSITIONS, 0) == 65536 * 32
+    assert l.wurm_single_resident_bytes(65536, 9, _lib.OBS_RAW, 0) == 0             # 'raw' needs the body values: not served
+    assert l.wurm_single_resident_bytes(65536, 9, _lib.OBS_PARTIAL, 3) == 0         # 7 x 7 crops: the one-env-per-wave kernels
     assert l.wurm_single_resident_bytes(65536, 10, *part2) == 0 and l.wurm_single_resident_bytes(65536, 11, *part2) == 0
     # 12 x 12 and larger: the 16-bit clock grid (runs of 256 cells) + 48 bytes, every observation mode, from 2^20 cells on
     assert l.wurm_single_resident_bytes(8192, 36, *default) == 8192 * (6 * 512 + 48)

@@ -58,6 +58,12 @@ def _cmp(ro, rh, t):
     (131, 'partial_2', 70),   # an odd count: the crops of the ragged block go out float by float
     (64, 'none', 60),
     (3, 'partial_2', 50),
+    # round 4: every other observation but 'raw' (lr_obs_value) — 'one_channel' is the reference's constructor default
+    (137, 'one_channel', 60),
+    (70, 'default', 50),
+    (90, 'positions', 50),
+    (75, 'partial_0', 40),
+    (75, 'partial_1', 40),
 ])
 def test_abi_step_postponed_reset_and_obs_after(hip, epw, N, mode, T, lazy):
     S = 9

@@ -255,3 +255,69 @@ def test_bench_shape_8192x128(hip):
     envs = _fresh(o, N)
     o.call = h.call = 1
     _compare_rollout(o, h, envs, rng.randint(0, 4, size=(T, N)).astype(np.int64), 'partial_2')
+
+
+# ---- round 4: every other observation mode through the lane kernel (lr_write_generic)
+GENERIC_MODES = ['one_channel', 'default', 'positions', 'partial_0', 'partial_1',
+                 'partial_3']   # (7 x 7 crops are routed to the one-env-per-wave kernels: still one launch, same results)
+
+
+@pytest.mark.parametrize('epw', [4, 16, 64])
+@pytest.mark.parametrize('mode', GENERIC_MODES)
+def test_other_observation_modes_every_envs_per_wave(hip, epw, mode):
+    """'one_channel' is the reference's constructor default (single_snake.py:55-65); ragged batch, resets, food respawn"""
+    N, T = 2 * epw + 3, 90
+    rng = np.random.RandomState(epw + len(mode))
+    o, h = OracleBackend(seed=19, env_offset=7), hip(seed=19, env_offset=7)
+    envs = _fresh(o, N)
+    o.call = h.call = 1
+    with lane_path(epw):
+        from wurm_amd import _lib
+        n0 = _lib.lib().wurm_launch_count()
+        out = _compare_rollout(o, h, envs, rng.randint(0, 4, size=(T, N)).astype(np.int64), mode)
+        assert _lib.lib().wurm_launch_count() - n0 == 1     # one launch: the lane kernel, no second pass
+    assert out['done'].sum() > N and out['reward'].sum() > 0
+
+
+@pytest.mark.parametrize('mode', ['one_channel', 'default', 'partial_3'])
+def test_other_modes_start_states_outside_the_domain(hip, mode):
+    """envs the lane kernel hands to the one-env-per-wave code inside the launch (head on the ring, no head, two foods),
+    mixed with ordinary ones: the generic writer must leave their observations to that code"""
+    N, T = 150, 60
+    rng = np.random.RandomState(8)
+    o, h = OracleBackend(seed=21), hip(seed=21)
+    envs = _fresh(o, N)
+    for _ in range(9):
+        o.single_step(envs, rng.randint(0, 4, size=N).astype(np.int64), 'none')
+    envs[6, 0, 3, 3] = 1
+    hole = _fresh(OracleBackend(seed=24), 1)[0]
+    hole[2][hole[2] == 2] = 0
+    envs[71] = hole
+    if mode.startswith('partial'):
+        # the reference raises for an env without a head (:191); this build writes zeros — not part of this comparison
+        keep = envs[:, 1].sum(axis=(1, 2)) > 0
+        envs = envs[keep]
+        N = envs.shape[0]
+    o.call = h.call = 50
+    with lane_path(16):
+        _compare_rollout(o, h, envs, rng.randint(0, 4, size=(T, N)).astype(np.int64), mode, check=False)
+
+
+@pytest.mark.parametrize('mode', ['one_channel', 'default'])
+def test_other_modes_large_batch_default_routing(hip, mode):
+    N, T = 6144 + 37, 40
+    rng = np.random.RandomState(N)
+    o, h = OracleBackend(seed=31, env_offset=(1 << 33) + 5), hip(seed=31, env_offset=(1 << 33) + 5)
+    envs = _fresh(o, N)
+    o.call = h.call = (1 << 40) + 3
+    _compare_rollout(o, h, envs, rng.randint(0, 4, size=(T, N)).astype(np.int64), mode)
+
+
+def test_raw_stays_with_the_one_env_per_wave_kernel(hip):
+    N, T = 40, 50
+    rng = np.random.RandomState(1)
+    o, h = OracleBackend(seed=2), hip(seed=2)
+    envs = _fresh(o, N)
+    o.call = h.call = 1
+    with lane_path(8):
+        _compare_rollout(o, h, envs, rng.randint(0, 4, size=(T, N)).astype(np.int64), 'raw')

@@ -163,7 +163,11 @@ __global__ __launch_bounds__(256) void lane_resident_step_kernel(ResidentArgs a)
 {
     static_assert(EPW == 16 || EPW == 32 || EPW == 64, "envs per wave");
     static_assert(EPW * NW <= 64 && (NW == 1 || NW == 2), "pair lanes");
-    static_assert(OBSK == WURM_OBS_PARTIAL || (OBSK == WURM_OBS_NONE && NW == 1), "partial_2 or no observation");
+    static_assert(OBSK == WURM_OBS_PARTIAL || OBSK == LR_OBS_GENERIC || OBSK == LR_OBS_GRID1 || OBSK == LR_OBS_GRID3 ||
+                  (OBSK == WURM_OBS_NONE && NW == 1),
+                  "partial_2, one_channel / default through bit planes, any other mode at run time (lr_obs_value), or none");
+    constexpr bool GRID = OBSK == LR_OBS_GRID1 || OBSK == LR_OBS_GRID3;
+    constexpr int GE = OBSK == LR_OBS_GRID1 ? LR_C : LR_C3;     // floats per env of a grid mode
     constexpr int S = 9, C = LR_C, C3 = LR_C3;
     constexpr int LOG_EPW = EPW == 16 ? 4 : EPW == 32 ? 5 : 6;
     constexpr int NP = EPW * NW;                 // pair lanes
@@ -175,14 +179,21 @@ __global__ __launch_bounds__(256) void lane_resident_step_kernel(ResidentArgs a)
 
     float4 *tab = (float4 *)res_lds;
     u64 *wint = (u64 *)(res_lds + 4096);
+    // (generic observations: float -> channel / row / column, in place of tab; grid modes: behind their two tables)
+    unsigned short *lut = (unsigned short *)(res_lds + (GRID ? 8192 : 0));
+    float4 *tabB = (float4 *)(res_lds + 4096);
     if (OBSK == WURM_OBS_PARTIAL) {
         lr_build_tables(tab, wint);
+        __syncthreads();
+    } else if (OBSK == LR_OBS_GENERIC || GRID) {
+        lr_build_lut(lut, p.obs_mode, p.obs_n, (int)p.obs_elems);
+        if (GRID) lr_build_grid_tables<OBSK>(tab, tabB);
         __syncthreads();
     }
 
     const long long env0 = (xcd_block(blockIdx.x, gridDim.x) * wpb + wave) * EPW;
     if (env0 >= p.N) return;
-    unsigned char *lds = res_lds + LR_TAB + wave * ResLds::BYTES;
+    unsigned char *lds = res_lds + (GRID ? LR_TAB_GRID : LR_TAB) + wave * (ResLds::BYTES + (GRID ? LR_GRID_BITS : 0));
     const int nenv = (int)min((long long)EPW, p.N - env0);
     const bool mine = lane < nenv;                // env lanes: lane e owns env0 + e
     const long long env = env0 + lane;
@@ -393,6 +404,61 @@ __global__ __launch_bounds__(256) void lane_resident_step_kernel(ResidentArgs a)
         }
     }
 
+    if (OBSK == LR_OBS_GENERIC || GRID) {
+        // every other observation: records of the (which, env) pairs, then — 'one_channel' / 'default' — bit planes, nibbles
+        // and 16-byte stores (lane_rollout.hpp: lr_grid_planes), or float by float (lr_obs_value)
+        uint4 *io = (uint4 *)(lds + ResLds::IO);
+        u32 *gbits = (u32 *)(lds + ResLds::BYTES);
+        uint4 cr = make_uint4(rec.x, rec.y, (u32)ny | ((u32)nx << 4) | (act ? 0x100u : 0u), rw & 127u);
+        uint4 cr2 = cr;
+        if (NW == 2 && act && fin) {
+            const S9Reset r = s9_reset_draw(p.seed, p.call + 1ull, env_id);
+            const int hc = r.b & 127, sc = (r.b >> 7) & 127, t2 = (r.b >> 14) & 127;
+            const u64 oc2 = (1ull << hc) | (1ull << sc) | (1ull << t2);
+            cr2 = make_uint4((u32)oc2, (u32)(oc2 >> 32), (u32)(hc >> 3) | ((u32)(hc & 7) << 4) | 0x100u, (u32)(r.a >> 2) + 1u);
+        }
+        if (lane < EPW) { io[lane] = cr; if (NW == 2) io[EPW + lane] = cr2; }
+        if (GRID && nenv == EPW) {
+            constexpr int GPL = OBSK == LR_OBS_GRID1 ? 4 : 2;
+            constexpr int NWORDS = GPL * ((NP * GE + 31) / 32 + 4);
+            static_assert(NWORDS * 4 + 16 <= LR_GRID_BITS, "flat bit strings of a grid mode");
+            for (int i = lane; i < (NWORDS + 3) / 4; i += 64) ((uint4 *)gbits)[i] = make_uint4(0, 0, 0, 0);
+            wave_lds_sync();
+            if (lane < NP) {
+                const uint4 q = io[lane]; // pair lane (which, env) = (lane >> LOG_EPW, lane & (EPW - 1))
+                if (q.z & 0x100u)
+                    lr_grid_planes<OBSK>(gbits, lane, (u64)q.x | ((u64)q.y << 32), (int)(q.z & 15u), (int)((q.z >> 4) & 15u), (int)q.w - 1);
+            }
+            wave_lds_sync();
+            constexpr int GSG = EPW * GE / 4;   // 16-byte groups of one observation of the wave's envs
+            char *ob0 = (char *)(p.obs + env0 * GE), *ob1 = NW == 2 ? (char *)(p.obs_after + env0 * GE) : nullptr;
+#pragma unroll 4
+            for (int j = lane; j < NW * GSG; j += 64) {
+                const float4 v = lr_grid_group<OBSK>(gbits, tab, tabB, j);
+                const bool second = NW == 2 && j >= GSG;
+                *(float4 *)((second ? ob1 : ob0) + 16u * (unsigned)(second ? j - GSG : j)) = v;
+            }
+            wave_lds_sync();
+        } else {
+        wave_lds_sync();
+        const int E = (int)p.obs_elems, mode = p.obs_mode, n = p.obs_n, row = nenv * E;
+        const float rcpE = 1.0f / (float)E;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            float *orow = (w ? p.obs_after : p.obs) + env0 * E;
+#pragma unroll 2
+            for (int f = lane; f < row; f += 64) {
+                const int e = div_size(f, rcpE), r = f - e * E;
+                const uint4 q = io[w * EPW + e];
+                const u32 l = lut[r];
+                if (q.z & 0x100u) // (else an env outside the domain: fused_step_env below writes it)
+                    orow[f] = lr_obs_value((u64)q.x | ((u64)q.y << 32), (int)(q.z & 15u), (int)((q.z >> 4) & 15u), (int)q.w - 1, l, mode, n);
+            }
+        }
+        wave_lds_sync();
+        }
+    }
+
     WURM_TL(6); // crops issued; WURM_TL_STORE: drained
     if (OBSK == WURM_OBS_PARTIAL) WURM_TL_STORE(p.obs + env0 * LR_E, lane);
     // ---- envs outside the domain: the one-env-per-wave code reads and writes their state, outputs and crops itself
@@ -420,7 +486,8 @@ __global__ __launch_bounds__(256) void lane_resident_step_kernel(ResidentArgs a)
 // the shapes the resident step serves (the caller opts in per call by passing wurm_single_call.resident)
 bool lane_resident_shape(int S, int obs_mode, int obs_n)
 {
-    return S == 9 && (obs_mode == WURM_OBS_NONE || (obs_mode == WURM_OBS_PARTIAL && obs_n == 2));
+    // every observation but 'raw' (the body values) and crops of 7 x 7 and more (lane_rollout_eligible says why)
+    return S == 9 && obs_mode != WURM_OBS_RAW && !(obs_mode == WURM_OBS_PARTIAL && (obs_n < 0 || obs_n > 2));
 }
 
 bool lane_resident_eligible(const StepArgs &p)
@@ -461,21 +528,45 @@ static hipError_t launch_lane_resident_form(const StepArgs &p, void *resident, b
         hipError_t err = hipGetLastError();
         if (err != hipSuccess) return err;
     }
-    const bool crops = p.obs_mode == WURM_OBS_PARTIAL;
-    const int nw = (crops && p.obs_after != nullptr) ? 2 : 1;
+    const bool crops = p.obs_mode == WURM_OBS_PARTIAL && p.obs_n == 2;
+    const bool grid1 = p.obs_mode == WURM_OBS_ONE_CHANNEL, grid3 = p.obs_mode == WURM_OBS_DEFAULT;
+    const bool generic = p.obs_mode != WURM_OBS_NONE && !crops && !grid1 && !grid3;
+    const int nw = (p.obs_mode != WURM_OBS_NONE && p.obs_after != nullptr) ? 2 : 1;
     // envs per wave (automatic unless the option WURM_RESIDENT_EPW forces it: tests and the tuning sweep)
     int epw = (int)opt.resident_epw;
     // measured (rocprofv3, us per launch at 16 / 32 / 64 envs per wave): 65 536 envs 8.5 / 7.3 / 7.6 without and 11.3 / 11.1 / -
     // with the reset observation; 32 768 envs 6.3 / 5.9 / 6.3 and 7.6 / 8.4 / -
     if (epw != 16 && epw != 32 && epw != 64) epw = nw == 1 ? (p.N >= 16384 ? 32 : 16) : (p.N >= 49152 ? 32 : 16);
     if (epw * nw > 64) epw = 32;
+    const bool gridm = grid1 || grid3;
     auto go = [&](auto kernel, int e) {
         const long long waves = (p.N + e - 1) / e;
         const int wpb = waves >= 1024 ? 4 : 1;
         dim3 block(64 * wpb), grid((unsigned)((waves + wpb - 1) / wpb));
-        WURM_LAUNCH(kernel, grid, block, (size_t)(LR_TAB + ResLds::BYTES * wpb), stream, a);
+        WURM_LAUNCH(kernel, grid, block, (size_t)((gridm ? LR_TAB_GRID : LR_TAB) + (ResLds::BYTES + (gridm ? LR_GRID_BITS : 0)) * wpb), stream, a);
     };
-    if (!crops) {
+    if (grid1) {
+        if (nw == 2) {
+            if (epw == 16) go(lane_resident_step_kernel<16, 2, LR_OBS_GRID1, LAZY>, 16);
+            else go(lane_resident_step_kernel<32, 2, LR_OBS_GRID1, LAZY>, 32);
+        } else if (epw == 16) go(lane_resident_step_kernel<16, 1, LR_OBS_GRID1, LAZY>, 16);
+        else if (epw == 32) go(lane_resident_step_kernel<32, 1, LR_OBS_GRID1, LAZY>, 32);
+        else go(lane_resident_step_kernel<64, 1, LR_OBS_GRID1, LAZY>, 64);
+    } else if (grid3) {
+        if (nw == 2) {
+            if (epw == 16) go(lane_resident_step_kernel<16, 2, LR_OBS_GRID3, LAZY>, 16);
+            else go(lane_resident_step_kernel<32, 2, LR_OBS_GRID3, LAZY>, 32);
+        } else if (epw == 16) go(lane_resident_step_kernel<16, 1, LR_OBS_GRID3, LAZY>, 16);
+        else if (epw == 32) go(lane_resident_step_kernel<32, 1, LR_OBS_GRID3, LAZY>, 32);
+        else go(lane_resident_step_kernel<64, 1, LR_OBS_GRID3, LAZY>, 64);
+    } else if (generic) {
+        if (nw == 2) {
+            if (epw == 16) go(lane_resident_step_kernel<16, 2, LR_OBS_GENERIC, LAZY>, 16);
+            else go(lane_resident_step_kernel<32, 2, LR_OBS_GENERIC, LAZY>, 32);
+        } else if (epw == 16) go(lane_resident_step_kernel<16, 1, LR_OBS_GENERIC, LAZY>, 16);
+        else if (epw == 32) go(lane_resident_step_kernel<32, 1, LR_OBS_GENERIC, LAZY>, 32);
+        else go(lane_resident_step_kernel<64, 1, LR_OBS_GENERIC, LAZY>, 64);
+    } else if (!crops) {
         if (epw == 16) go(lane_resident_step_kernel<16, 1, WURM_OBS_NONE, LAZY>, 16);
         else if (epw == 32) go(lane_resident_step_kernel<32, 1, WURM_OBS_NONE, LAZY>, 32);
         else go(lane_resident_step_kernel<64, 1, WURM_OBS_NONE, LAZY>, 64);

@@ -159,6 +159,186 @@ __device__ __forceinline__ void lr_build_tables(float4 *tab, u64 *wint)
     }
 }
 
+// ---- every other observation of the 9 x 9 state (round 4): 'default' (243 floats), 'one_channel' (81, the reference's
+// constructor default: single_snake.py:55-65), 'positions' (4) and 'partial_n' with n != 2 (3 (2n+1)^2) — written FLOAT BY
+// FLOAT from the step records: lane = one float of a step's row of EPW consecutive observations (256 contiguous bytes per
+// store instruction), its (channel, row, column) read from a workgroup table, its value a function of the record's
+// occupancy mask / head / food codes (single_snake.py:104-195).  'raw' needs the body VALUES and stays with the
+// one-env-per-wave kernels.
+constexpr int LR_OBS_GENERIC = -1; // OBSK of lane_rollout_kernel: p.obs_mode / p.obs_n at run time
+
+// lut[r] = channel | a << 2 | b << 6 of float r of one env's observation: (a, b) = (row, column) of the grid for the grid
+// modes, of the window for a crop
+__device__ __forceinline__ void lr_build_lut(unsigned short *lut, int mode, int n, int E)
+{
+    for (int r = (int)threadIdx.x; r < E; r += (int)blockDim.x) {
+        int ch, a, b;
+        if (mode == WURM_OBS_PARTIAL) {
+            const int W = 2 * n + 1, W2 = W * W;
+            ch = r / W2;
+            const int w = r - ch * W2;
+            a = w / W; b = w - a * W;
+        } else if (mode == WURM_OBS_POSITIONS) {
+            ch = r; a = b = 0;
+        } else {
+            ch = r / LR_C;
+            const int cell = r - ch * LR_C;
+            a = cell / 9; b = cell - a * 9;
+        }
+        lut[r] = (unsigned short)(ch | (a << 2) | (b << 6));
+    }
+}
+
+// value of float (ch, a, b) of the observation of a state given as occupancy mask `oc` (cell codes 8 y + x), head (hy, hx)
+// — also when it is on the ring — and food code fc (-1: none)
+__device__ __forceinline__ float lr_obs_value(u64 oc, int hy, int hx, int fc, u32 l, int mode, int n)
+{
+    const int ch = (int)(l & 3u), a = (int)((l >> 2) & 15u), b = (int)((l >> 6) & 15u);
+    if (mode == WURM_OBS_POSITIONS) // argmax of the head / food channels (:153-163): (0, 0) when there is no food
+        return (float)(ch == 0 ? hy : ch == 1 ? hx : ch == 2 ? (fc >= 0 ? fc >> 3 : 0) : (fc >= 0 ? fc & 7 : 0));
+    const bool crop = mode == WURM_OBS_PARTIAL;
+    const int y = crop ? hy - n + a : a, x = crop ? hx - n + b : b;
+    const bool inside = (unsigned)y < 9u && (unsigned)x < 9u;          // F.pad zeros around the grid (:179)
+    const bool ring = y == 0 || y == 8 || x == 0 || x == 8;
+    const bool interior = inside && !ring;
+    const int code = 8 * y + x;
+    const bool occ = interior && ((oc >> (code & 63)) & 1ull) != 0;
+    const bool head = y == hy && x == hx, food = interior && fc == code;
+    if (mode == WURM_OBS_ONE_CHANNEL) // :142-151
+        return ring ? -1.0f : (occ ? 0.5f : 0.0f) + (head ? 0.5f : 0.0f) + (food ? 1.5f : 0.0f);
+    // 'default' / crops: background white, body (0,127,0), head (0,255,0), food (255,0,0), ring / padding black (:104-128)
+    if (!interior) return 0.0f;
+    if (food) return ch == 0 ? 1.0f : 0.0f;
+    if (head) return ch == 1 ? 1.0f : 0.0f;
+    if (occ) return ch == 1 ? 127.0f / 255.0f : 0.0f;
+    return 1.0f;
+}
+
+// the observations of a chunk's nt steps x nenv envs from their records io[step * EPW + env]
+template <int EPW>
+__device__ __forceinline__ void lr_write_generic(const StepArgs &p, const uint4 *io, const unsigned short *lut, float *obs_c,
+                                                 int nt, int nenv, int lane)
+{
+    const int E = (int)p.obs_elems, mode = p.obs_mode, n = p.obs_n;
+    const float rcpE = 1.0f / (float)E;
+    const int row = nenv * E;                               // < 2^16: div_size is exact
+    for (int s = 0; s < nt; ++s) {
+        float *orow = obs_c + (long long)s * p.N * E;
+        const uint4 *recs = io + s * EPW;
+#pragma unroll 2
+        for (int f = lane; f < row; f += 64) {
+            const int e = div_size(f, rcpE), r = f - e * E;
+            const uint4 rec = recs[e];
+            const u32 l = lut[r];
+            const int cp = (int)(rec.z & 63u), ai = (int)((rec.z >> 8) & 3u);   // head code before the move, the move
+            if (rec.w & 0x8000u) // (else an env outside the domain: the fallback writes it)
+                orow[f] = lr_obs_value((u64)rec.x | ((u64)rec.y << 32), (cp >> 3) + lr_dy(ai), (cp & 7) + lr_dx(ai),
+                                       (int)(rec.w & 127u) - 1, l, mode, n);
+        }
+    }
+}
+
+// ---- the two WHOLE-GRID observations through bit planes (round 4): 'one_channel' (81 floats: the reference's constructor
+// default) and 'default' (3 x 81 floats).  The float-by-float writer above costs ~80 VALU per 64 floats and was SLOWER
+// than the one-env-per-wave kernels at 65 536 envs (one_channel 3.9e9 against 4.4e9 env-steps/s, default 1.6e9 against
+// 3.1e9); here, as for the 'partial_2' crops: the (step, env) pair lane turns its record into 81-bit row-major planes
+// (bit 9 y + x), ORs them into the chunk's flat bit strings in LDS, and every lane then turns aligned nibbles of those
+// strings into four floats with a table read and stores 16 bytes.
+//   'default' (single_snake.py:104-128, :134-136): two planes of 243 bits per pair — "value is 1" = R | G << 81 | B << 162
+//       with R = free or food, G = free or head, B = free (all inside the ring), "value is 127/255" = body << 81 — and the
+//       nibble-pair table of the crops;
+//   'one_channel' (:142-151: 0.5 body + 0.5 head + 1.5 food, ring -1): four planes of 81 bits — body without the head
+//       (0.5), head (1.0 = 0.5 + 0.5), food (1.5), ring (-1) — and two tables whose results are ADDED: the planes exclude each
+//       other, so one of the two addends is always +0 and the sum is exact.
+constexpr int LR_OBS_GRID1 = -2, LR_OBS_GRID3 = -3;   // OBSK of the kernels: one_channel / default through bit planes
+constexpr int LR_GRID_BITS = 4096;                    // bytes per wave of their flat bit strings (behind LaneRollLds::BYTES)
+constexpr int LR_TAB_GRID = 8192 + 512;               // their workgroup tables: 2 x 256 float4, the float-by-float lut
+
+constexpr u64 LR_I9_LO = (0x7Full << 10) | (0x7Full << 19) | (0x7Full << 28) | (0x7Full << 37) | (0x7Full << 46) | (0x7Full << 55);
+constexpr u32 LR_I9_HI = 0x7Fu;                       // interior cells of the 9 x 9 grid, bit 9 y + x (bits 64 .. 80 in HI)
+
+// interior cells of an occupancy mask over codes 8 y + x -> bit 9 y + x
+__device__ __forceinline__ void lr_rows9(u64 oc, u64 &lo, u32 &hi)
+{
+    lo = 0;
+#pragma unroll
+    for (int y = 1; y <= 6; ++y) lo |= ((oc >> (8 * y + 1)) & 0x7Full) << (9 * y + 1);
+    hi = (u32)(oc >> 57) & 0x7Fu;
+}
+
+// ORs the 81 bits (lo, hi) into plane k of NPL interleaved flat bit strings at bit offset off (word w of plane k: bits[NPL w + k])
+template <int NPL>
+__device__ __forceinline__ void lr_or81(u32 *bits, int k, int off, u64 lo, u32 hi)
+{
+    const int w = off >> 5, sb = off & 31;
+    const u64 a = (u64)(u32)lo << sb, b = (u64)(u32)(lo >> 32) << sb, c = (u64)hi << sb;
+    u32 *P = bits + NPL * w + k;
+    atomicOr(&P[0], (u32)a);
+    atomicOr(&P[NPL], (u32)(a >> 32) | (u32)b);
+    atomicOr(&P[2 * NPL], (u32)(b >> 32) | (u32)c);
+    if ((u32)(c >> 32)) atomicOr(&P[3 * NPL], (u32)(c >> 32));
+}
+
+// the planes of pair p (bit offset E * p of every string) of a state: occupancy oc, head (hy, hx), food code fc (-1: none)
+template <int OBSK>
+__device__ __forceinline__ void lr_grid_planes(u32 *bits, int p, u64 oc, int hy, int hx, int fc)
+{
+    u64 olo; u32 ohi;
+    lr_rows9(oc, olo, ohi);
+    const bool hin = (unsigned)(hy - 1) < 7u && (unsigned)(hx - 1) < 7u;
+    const int hp = 9 * hy + hx, fp = fc >= 0 ? 9 * (fc >> 3) + (fc & 7) : -1;
+    const u64 hlo = hin && hp < 64 ? 1ull << hp : 0ull, flo = fp >= 0 && fp < 64 ? 1ull << fp : 0ull;
+    const u32 hhi = hin && hp >= 64 ? 1u << (hp - 64) : 0u, fhi = fp >= 64 ? 1u << (fp - 64) : 0u;
+    if (OBSK == LR_OBS_GRID1) {
+        const int off = LR_C * p;
+        lr_or81<4>(bits, 0, off, olo & ~hlo, ohi & ~hhi);           // body without the head: 0.5
+        lr_or81<4>(bits, 1, off, hlo, hhi);                         // head: 1.0
+        lr_or81<4>(bits, 2, off, flo, fhi);                         // food: 1.5
+        lr_or81<4>(bits, 3, off, ~LR_I9_LO, ~LR_I9_HI & 0x1FFFFu);  // ring: -1
+    } else {
+        const int off = LR_C3 * p;
+        const u64 free_lo = LR_I9_LO & ~olo & ~flo;
+        const u32 free_hi = LR_I9_HI & ~ohi & ~fhi;
+        lr_or81<2>(bits, 0, off, free_lo | flo, free_hi | fhi);               // R: free or food
+        lr_or81<2>(bits, 0, off + LR_C, free_lo | hlo, free_hi | hhi);        // G: free or head
+        lr_or81<2>(bits, 0, off + 2 * LR_C, free_lo, free_hi);                // B: free
+        lr_or81<2>(bits, 1, off + LR_C, olo & ~hlo, ohi & ~hhi);              // G = 127/255: body
+    }
+}
+
+// tables of the grid modes: tabA as lr_build_tables's for 'default'; for 'one_channel' tabA[low nibble: 0.5, high: 1.0],
+// tabB[low nibble: 1.5, high: -1.0]
+template <int OBSK>
+__device__ __forceinline__ void lr_build_grid_tables(float4 *tabA, float4 *tabB)
+{
+    for (int i = (int)threadIdx.x; i < 256; i += (int)blockDim.x) {
+        float a[4], b[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool lo = ((i >> j) & 1) != 0, hi = ((i >> (4 + j)) & 1) != 0;
+            if (OBSK == LR_OBS_GRID1) { a[j] = lo ? 0.5f : hi ? 1.0f : 0.0f; b[j] = lo ? 1.5f : hi ? -1.0f : 0.0f; }
+            else { a[j] = lo ? 1.0f : hi ? 127.0f / 255.0f : 0.0f; b[j] = 0.0f; }
+        }
+        tabA[i] = make_float4(a[0], a[1], a[2], a[3]);
+        if (OBSK == LR_OBS_GRID1) tabB[i] = make_float4(b[0], b[1], b[2], b[3]);
+    }
+}
+
+// 16-byte group j of a flat run of floats whose bits start at bit 0 of the strings -> four floats
+template <int OBSK>
+__device__ __forceinline__ float4 lr_grid_group(const u32 *bits, const float4 *tabA, const float4 *tabB, int j)
+{
+    const int w = j >> 3, sh = (j & 7) * 4;
+    if (OBSK == LR_OBS_GRID1) {
+        const uint4 q = ((const uint4 *)bits)[w];
+        const float4 a = tabA[((q.x >> sh) & 15u) | (((q.y >> sh) & 15u) << 4)];
+        const float4 b = tabB[((q.z >> sh) & 15u) | (((q.w >> sh) & 15u) << 4)];
+        return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+    }
+    const uint2 q = ((const uint2 *)bits)[w];
+    return tabA[((q.x >> sh) & 15u) | (((q.y >> sh) & 15u) << 4)];
+}
+
 // The state of a block of EPW consecutive envs (`block` = its first float), read cooperatively — lanes = (env, cell) pairs,
 // the few non-zero elements scattered into a per-env value -> cell table in LDS — then, per env lane: validation and the
 // state as occupancy mask + queue of moves.  act = the env is in the domain (header of this file).
@@ -265,7 +445,7 @@ __device__ __forceinline__ void lane_rollout_fallback(const StepArgs &p, long lo
     float *envp = p.envs + env * LR_C3;
     Env<2> e;
     load_state<2, true>(envp, g, e);
-    rollout_generic<2, true, OBSK, INJ>(p, env, envp, g, e, lds);
+    rollout_generic<2, true, (OBSK < 0 ? -1 : OBSK), INJ>(p, env, envp, g, e, lds); // (-1: the mode at run time)
 }
 
 template <int EPW, int OBSK, bool INJ>
@@ -273,7 +453,11 @@ __global__ __launch_bounds__(256) void lane_rollout_kernel(StepArgs p)
 {
     typedef LaneRollLds<EPW> Lds;
     static_assert(EPW == 4 || EPW == 8 || EPW == 16 || EPW == 32 || EPW == 64, "envs per wave");
-    static_assert(OBSK == WURM_OBS_PARTIAL || OBSK == WURM_OBS_NONE, "lane rollout: partial_2 or no observation");
+    static_assert(OBSK == WURM_OBS_PARTIAL || OBSK == WURM_OBS_NONE || OBSK == LR_OBS_GENERIC || OBSK == LR_OBS_GRID1 ||
+                  OBSK == LR_OBS_GRID3, "lane rollout: partial_2, one_channel, default, no observation, or any other mode at run time");
+    constexpr bool GRID = OBSK == LR_OBS_GRID1 || OBSK == LR_OBS_GRID3;
+    constexpr int GE = OBSK == LR_OBS_GRID1 ? LR_C : LR_C3;     // floats per env of a grid mode
+    constexpr int GPL = OBSK == LR_OBS_GRID1 ? 4 : 2;           // its interleaved bit planes
     constexpr int TC = 64 / EPW;                  // steps per chunk
     constexpr int LOG_EPW = EPW == 4 ? 2 : EPW == 8 ? 3 : EPW == 16 ? 4 : EPW == 32 ? 5 : 6;
     constexpr int GS = EPW * LR_E / 4;            // 16-byte groups per step of the wave's crops
@@ -285,12 +469,18 @@ __global__ __launch_bounds__(256) void lane_rollout_kernel(StepArgs p)
     // ---- workgroup tables
     float4 *tab = (float4 *)lr_lds;               // nibble pair -> four floats
     u64 *wint = (u64 *)(lr_lds + 4096);           // head (row, column) -> window cells that lie inside the border ring
-    lr_build_tables(tab, wint);
+    // (generic observations: float -> channel / row / column, in place of tab; grid modes: behind their two tables)
+    unsigned short *lut = (unsigned short *)(lr_lds + (GRID ? 8192 : 0));
+    float4 *tabB = (float4 *)(lr_lds + 4096);
+    if (OBSK == LR_OBS_GENERIC || GRID) lr_build_lut(lut, p.obs_mode, p.obs_n, (int)p.obs_elems);
+    if (GRID) lr_build_grid_tables<OBSK>(tab, tabB);
+    else if (OBSK != LR_OBS_GENERIC) lr_build_tables(tab, wint);
     __syncthreads();
 
     const long long env0 = (xcd_block(blockIdx.x, gridDim.x) * wpb + wave) * EPW;
     if (env0 >= p.N) return;
-    unsigned char *lds = lr_lds + LR_TAB + wave * Lds::BYTES;
+    unsigned char *lds = lr_lds + (GRID ? LR_TAB_GRID : LR_TAB) + wave * (Lds::BYTES + (GRID ? LR_GRID_BITS : 0));
+    u32 *gbits = (u32 *)(lds + Lds::BYTES);      // (grid modes: the flat bit strings of a chunk)
     const int nenv = (int)min((long long)EPW, p.N - env0);
     const bool mine = lane < nenv;                // env lanes: lane e owns env0 + e
     const int ps = lane >> LOG_EPW, pe = lane & (EPW - 1); // pair lanes: step ps of the chunk, env env0 + pe
@@ -332,7 +522,8 @@ __global__ __launch_bounds__(256) void lane_rollout_kernel(StepArgs p)
     u32 *bits = (u32 *)(lds + Lds::BITS);
     const u64 env_id = (u64)(p.env_offset + env0 + pe); // of the pair lane
     const bool pair_env = pe < nenv;
-    float *obs_c = p.obs + env0 * LR_E;               // crops of the chunk's first step, this wave's envs
+    const int E = OBSK == LR_OBS_GENERIC ? (int)p.obs_elems : GRID ? GE : LR_E;
+    float *obs_c = p.obs + env0 * E;                  // observations of the chunk's first step, this wave's envs
     const unsigned obs_step_bytes = (unsigned)(p.N * (LR_E * 4)); // (the launcher keeps TC * N * 300 below 2^32)
 
     for (long long T0 = 0; T0 < p.T; T0 += SUPER * TC) {
@@ -389,6 +580,7 @@ __global__ __launch_bounds__(256) void lane_rollout_kernel(StepArgs p)
             // sanitised action << 8, food code + 1 | ate << 8 | self collision << 9 | edge collision << 10 | valid << 15
             if constexpr (EPW == 64) {
                 rec = lr_transition<INJ>(occ, q0, q1, q2, c, tc, L, o, food, act, rec);              // pair lane == env lane: the record never leaves its registers
+                if (OBSK == LR_OBS_GENERIC || GRID) io[lane] = rec;                                    // (the float-by-float writer reads records by env)
             } else {
                 io[lane] = rec;
                 wave_lds_sync();
@@ -405,6 +597,11 @@ __global__ __launch_bounds__(256) void lane_rollout_kernel(StepArgs p)
 #pragma unroll
                 for (int i = lane; i < 2 * 152; i += 64) bits[i] = 0;
             }
+            if (GRID) {
+                constexpr int NWORDS = GPL * ((64 * GE + 31) / 32 + 4);
+                static_assert(NWORDS * 4 + 16 <= LR_GRID_BITS, "flat bit strings of a grid mode");
+                for (int i = lane; i < (NWORDS + 3) / 4; i += 64) ((uint4 *)gbits)[i] = make_uint4(0, 0, 0, 0);
+            }
             wave_lds_sync();
             if constexpr (EPW != 64) rec = io[lane];
 
@@ -418,6 +615,11 @@ __global__ __launch_bounds__(256) void lane_rollout_kernel(StepArgs p)
                     p.done[oi] = (uint8_t)((rw & 0x600u) != 0);
                     p.selfc[oi] = (uint8_t)((rw >> 9) & 1u);
                     p.edgec[oi] = (uint8_t)((rw >> 10) & 1u);
+                }
+                if (GRID && valid) { // planes of the stepped state (the head also when it is on the ring)
+                    const int cp = (int)(rz & 63u), ai = (int)((rz >> 8) & 3u);
+                    lr_grid_planes<OBSK>(gbits, lane, (u64)rec.x | ((u64)rec.y << 32), (cp >> 3) + lr_dy(ai), (cp & 7) + lr_dx(ai),
+                                         (int)(rw & 127u) - 1);
                 }
                 if (OBSK == WURM_OBS_PARTIAL && valid) {
                     // crop of the stepped state (single_snake.py:166-193): a window cell that is off the grid or on the
@@ -486,7 +688,29 @@ __global__ __launch_bounds__(256) void lane_rollout_kernel(StepArgs p)
                     }
                 }
             }
-            obs_c += (long long)TC * p.N * LR_E;
+            if (OBSK == LR_OBS_GENERIC) {
+                wave_lds_sync();
+                lr_write_generic<EPW>(p, io, lut, obs_c, nt, nenv, lane);
+                wave_lds_sync(); // (the next chunk's inputs go into io)
+            }
+            if (GRID) {
+                wave_lds_sync();
+                if (nenv == EPW && nt == TC) {
+                    constexpr int GSG = EPW * GE / 4, NGRP = TC * GSG;   // 16-byte groups per step / per chunk
+                    char *ob = (char *)obs_c;
+                    const size_t step_bytes = (size_t)p.N * (GE * 4);
+#pragma unroll 4
+                    for (int j = lane; j < NGRP; j += 64) {
+                        const float4 v = lr_grid_group<OBSK>(gbits, tab, tabB, j);
+                        const int s = EPW == 64 ? 0 : j / GSG;
+                        *(float4 *)(ob + (size_t)s * step_bytes + 16u * (unsigned)(j - s * GSG)) = v;
+                    }
+                } else { // the ragged last wave, the last chunk of a tape that is not a multiple of TC: float by float
+                    lr_write_generic<EPW>(p, io, lut, obs_c, nt, nenv, lane);
+                }
+                wave_lds_sync();
+            }
+            obs_c += (long long)TC * p.N * E;
         }
     }
     wave_lds_sync();
@@ -565,7 +789,10 @@ __global__ __launch_bounds__(256) void lane_rollout_kernel(StepArgs p)
 bool lane_rollout_eligible(const StepArgs &p)
 {
     if (p.S != 9 || p.only_flagged) return false;
-    if (p.obs_mode != WURM_OBS_NONE && !(p.obs_mode == WURM_OBS_PARTIAL && p.obs_n == 2)) return false;
+    // every observation but 'raw' (the body values) and crops of 7 x 7 and more: the float-by-float writer that serves
+    // partial_0 / partial_1 / positions loses to the one-env-per-wave kernels there (partial_3 at 65 536 envs: 2.5e9 against
+    // 5.9e9 env-steps/s), and the bit-plane form of the crops is written for the 5 x 5 window only
+    if (p.obs_mode == WURM_OBS_RAW || (p.obs_mode == WURM_OBS_PARTIAL && (p.obs_n < 0 || p.obs_n > 2))) return false;
     if ((p.inject_food == nullptr) != (p.inject_reset == nullptr)) return false;
     return true;
 }
@@ -586,7 +813,7 @@ static int lane_rollout_epw(long long N)
 static int lane_rollout_epw_checked(long long N)
 {
     int epw = lane_rollout_epw(N);
-    while (epw < 64 && (64 / epw) * N * (LR_E * 4) >= (1ll << 32)) epw *= 2;
+    while (epw < 64 && (64 / epw) * N * (LR_E * 4) >= (1ll << 32)) epw *= 2; // (partial_2 only: the generic writer uses 64-bit rows)
     return epw;
 }
 
@@ -600,7 +827,8 @@ static hipError_t launch_lane_rollout_obs(const StepArgs &p, hipStream_t stream)
     dim3 block(64 * wpb), grid((unsigned)((waves + wpb - 1) / wpb));
     (void)hipGetLastError();
     auto go = [&](auto kernel, int lds_per_wave) {
-        WURM_LAUNCH(kernel, grid, block, (size_t)(LR_TAB + lds_per_wave * wpb), stream, p);
+        constexpr bool GRID = OBSK == LR_OBS_GRID1 || OBSK == LR_OBS_GRID3;
+        WURM_LAUNCH(kernel, grid, block, (size_t)((GRID ? LR_TAB_GRID : LR_TAB) + (lds_per_wave + (GRID ? LR_GRID_BITS : 0)) * wpb), stream, p);
     };
     if (inj) go(lane_rollout_kernel<16, OBSK, true>, LaneRollLds<16>::BYTES);
     else if (epw == 4) go(lane_rollout_kernel<4, OBSK, false>, LaneRollLds<4>::BYTES);
@@ -613,8 +841,11 @@ static hipError_t launch_lane_rollout_obs(const StepArgs &p, hipStream_t stream)
 
 hipError_t launch_lane_rollout(const StepArgs &p, hipStream_t stream)
 {
-    return p.obs_mode == WURM_OBS_NONE ? launch_lane_rollout_obs<WURM_OBS_NONE>(p, stream)
-                                       : launch_lane_rollout_obs<WURM_OBS_PARTIAL>(p, stream);
+    if (p.obs_mode == WURM_OBS_NONE) return launch_lane_rollout_obs<WURM_OBS_NONE>(p, stream);
+    if (p.obs_mode == WURM_OBS_PARTIAL && p.obs_n == 2) return launch_lane_rollout_obs<WURM_OBS_PARTIAL>(p, stream);
+    if (p.obs_mode == WURM_OBS_ONE_CHANNEL) return launch_lane_rollout_obs<LR_OBS_GRID1>(p, stream);
+    if (p.obs_mode == WURM_OBS_DEFAULT) return launch_lane_rollout_obs<LR_OBS_GRID3>(p, stream);
+    return launch_lane_rollout_obs<LR_OBS_GENERIC>(p, stream);
 }
 
 } // namespace wurm
