@@ -64,3 +64,18 @@ def test_worker_under_an_external_torchrun():
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
     assert len(lines) == 1
     assert json.loads(lines[0])['n_gpus'] == 2
+
+
+def test_world_size_8_with_an_uneven_global_batch():
+    """the 8-GPU shape north_star names, on gloo: 65 537 envs do not divide by 8 — every rank gets a contiguous block,
+    the blocks tile the batch, the line's key numbers carry the strong-scaling value"""
+    d = _run('--gpus', '8', '--dry-run', '--steps', '2', '--warmup', '0', '--workload', 'cfg3', '--num-envs', '65537')
+    assert d['n_gpus'] == 8 and d['config']['world_size'] == 8 and d['scaling'] == 'strong'
+    assert d['config']['global_num_envs'] == 65537
+    assert d['config']['num_envs_per_gpu'] == 8193            # rank 0's block: the remainder goes to the first ranks
+    assert d['value'] > 0 and d['key']['cfg3_strong_scaling_eps'] > 0
+    from wurm_amd.sharding import shard_range
+    blocks = [shard_range(65537, r, 8) for r in range(8)]
+    assert blocks[0][0] == 0 and sum(n for _, n in blocks) == 65537
+    assert all(blocks[i][0] + blocks[i][1] == blocks[i + 1][0] for i in range(7))
+    assert max(n for _, n in blocks) - min(n for _, n in blocks) == 1
