@@ -143,6 +143,13 @@ typedef struct wurm_single_call {
     int resident_lazy;               /* != 0: the step does not write envs at all; envs is brought up to date by
                                         wurm_single_resident_flush (call it before anything else reads or writes
                                         envs, and before clearing resident_valid)                                 */
+    uint32_t *check_mask;            /* nullable out (N), SingleSnake: wurm_single_check's mask of the POST-STEP state of
+                                        every env, computed inside the step launch where the launch holds all there is to
+                                        check (the resident step: an env in its domain is a well-formed snake — what is
+                                        left to say is WURM_CHK_MIN_LENGTH / WURM_CHK_ONE_FOOD); WURM_CHK_NOT_COMPUTED for
+                                        an env that finished in this step or that the launch cannot vouch for, and for
+                                        every env when another kernel served the call.  experiments/main.py:214-215 checks
+                                        `env.envs[~done]` every step: with this the check is one any() over N words       */
 } wurm_single_call;
 
 /* One launch for one iteration of the caller loop of tests/test_single_snake_env.py:24-31 /
@@ -418,6 +425,7 @@ int wurm_multi_observe(const float *foods, const float *heads, const float *bodi
 
 /* MultiSnake.check_consistency (multi_snake.py:733-769) as a per-env bitmask: bits 0-6 = WURM_CHK_* of any living
  * snake, WURM_MCHK_OVERLAP, WURM_MCHK_DEAD_NONZERO. */
+#define WURM_CHK_NOT_COMPUTED 0xFFFFFFFFu /* wurm_single_call.check_mask / wurm_multi_call.check_mask: run the checker */
 #define WURM_MCHK_OVERLAP 0x100u
 #define WURM_MCHK_DEAD_NONZERO 0x200u
 int wurm_multi_check(const float *foods, const float *heads, const float *bodies, const uint8_t *dones, uint32_t *err,

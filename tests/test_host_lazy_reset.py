@@ -571,3 +571,58 @@ def test_reference_test_access_patterns_never_step_on_a_stale_mirror(env_and_log
     env.envs.data[2, 0, 5, 5] = 1.0
     s = step()
     assert s['mirror_valid']
+
+
+def test_check_consistency_uses_the_masks_of_the_step_launch(env_and_log, monkeypatch):
+    """SingleSnake.check_consistency(mask) — experiments/main.py:214-215 checks the live envs every step — is served by the
+    masks the resident step launch writes (wurm_single_call.check_mask) whenever they describe the current state; anything
+    else (first call, a look at / edit of the state in between, an env the launch could not vouch for) runs the checker"""
+    env, log = env_and_log
+    import wurm_amd.utils as U
+    from wurm_amd.envs import SingleSnake
+    env = SingleSnake(num_envs=8, size=9, observation_mode='partial_2', device='cpu', seed=5, resident_mirror=True)
+    ran = []
+    monkeypatch.setattr(U, 'consistency_mask', lambda e: (ran.append(1), torch.zeros(e.shape[0], dtype=torch.int32))[1])
+    _, _, d, _ = _step(env)
+    live = ~d.squeeze(-1)
+    env.check_consistency(live)
+    assert len(ran) == 1 and env._c.check_mask            # no masks yet: the checker ran, the request is armed
+    env.reset(d)
+    _, _, d, _ = _step(env)
+    env._chk.zero_()                                       # what the launch writes for consistent live envs
+    env.check_consistency(~d.squeeze(-1))
+    assert len(ran) == 1                                   # served by the launch's masks
+    env.reset(d)                                           # (the first reset after an undisturbed step asks for obs_after)
+    _, _, d, _ = _step(env)
+    env._chk.zero_()
+    env.check_consistency(~d.squeeze(-1))
+    assert len(ran) == 1
+    assert env.reset(d) is not None and env._fs.pending    # postponed: the masks still apply (rebuilt envs are consistent)
+    env._chk[3] = -1
+    env._pend[3] = 1
+    env.check_consistency()
+    assert len(ran) == 1
+    env._pend[3] = 0
+    _, _, d, _ = _step(env)
+    env._chk.zero_(); env._chk[2] = -1                     # an env the launch could not vouch for, and it is asked about
+    env.check_consistency(torch.ones(8, dtype=torch.bool))
+    assert len(ran) == 2
+    env.check_consistency(torch.tensor([1, 1, 0, 1, 1, 1, 1, 1], dtype=torch.bool))   # ... not asked about: fine
+    assert len(ran) == 2
+    env._chk[5] = U.CHK_ONE_FOOD
+    with pytest.raises(RuntimeError, match='exactly one food'):
+        env.check_consistency(torch.ones(8, dtype=torch.bool) & (torch.arange(8) != 2))
+    env._chk.zero_()
+    _ = env.envs                                           # the caller looked at the state (and may have edited it)
+    env.check_consistency()
+    assert len(ran) == 3
+    _step(env)
+    env._chk.zero_()
+    env.check_consistency()
+    assert len(ran) == 3                                   # a new step: its masks are good again
+    e = env.envs
+    _step(env)
+    env._chk.zero_()
+    e[0, 0, 1, 1] = 1.0                                    # in-place edit through an alias after the step
+    env.check_consistency()
+    assert len(ran) == 4

@@ -490,3 +490,46 @@ def test_per_call_parity_suite_on_the_mirror():
                         'tests/test_fuzz_gpu.py', 'tests/test_rl_gpu.py', 'tests/test_hip_golden.py'],
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def test_check_masks_of_the_step_launch_equal_the_checker(hip):
+    """wurm_single_call.check_mask (round 4): the masks the resident step launch writes == wurm_single_check / the oracle's
+    checker on the stepped state for every live env, 'not computed' (-1) for the envs that finished in the step; an env
+    without food shows WURM_CHK_ONE_FOOD; SingleSnake.check_consistency(~done) is served by them and raises as the
+    checker does"""
+    import torch
+    from wurm_amd.envs import SingleSnake
+    from oracle import oracle as _orc
+    N, T = 300, 40
+    env = SingleSnake(N, 9, observation_mode='partial_2', device='cuda:0', seed=3, resident_mirror=True)
+    g = torch.Generator().manual_seed(1)
+    st = env.envs
+    st[7, 0] = 0                      # env 7 loses its food (hand-edited: the mirror is rebuilt from the tensor)
+    served = 0
+    hungry = True                     # env 7 has no food until it finishes once and is rebuilt
+    for t in range(T):
+        a = torch.randint(4, (N,), generator=g).cuda()
+        if hungry:
+            a[7] = 3 if t % 2 == 0 else 1   # (keep it alive: back and forth — a reversal becomes a forward move)
+        _, _, d, _ = env.step(a)
+        live = ~d.squeeze(-1)
+        hungry = hungry and bool(live[7])
+        if t == 0:
+            env.check_consistency(live & (torch.arange(N, device='cuda') != 7))   # arms the request (runs the checker once)
+        else:
+            chk = env._chk.clone()
+            before = env._fs.steps
+            if hungry:
+                with pytest.raises(RuntimeError, match='exactly one food'):
+                    env.check_consistency(live)
+            env.check_consistency(live & (torch.arange(N, device='cuda') != 7))
+            assert env._chk_void_at < before, 'the masks were not used (the state was touched)'
+            served += 1
+            ref = _orc.single_check(env.envs.cpu().numpy())        # (reading env.envs voids the masks: after the checks)
+            lv = live.cpu().numpy()
+            got = chk.cpu().numpy()
+            assert (got[~lv] == -1).all(), 'finished envs must be "not computed"'
+            assert np.array_equal(got[lv].astype(np.uint32), ref[lv]), f't={t}'
+            assert not hungry or got[7] == _orc.CHK_ONE_FOOD
+        env.reset(d)
+    assert served >= T - 2

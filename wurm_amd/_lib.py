@@ -42,7 +42,7 @@ class SingleCall(ctypes.Structure):
                 ('actions_dtype', ctypes.c_int), ('obs_mode', ctypes.c_int), ('obs_n', ctypes.c_int),
                 ('size', ctypes.c_int), ('post_reset', ctypes.c_int), ('start_y', ctypes.c_int),
                 ('start_x', ctypes.c_int), ('resident', ctypes.c_void_p), ('resident_valid', ctypes.c_int),
-                ('resident_lazy', ctypes.c_int)]
+                ('resident_lazy', ctypes.c_int), ('check_mask', ctypes.c_void_p)]
 
 
 class SingleSlabs(ctypes.Structure):

@@ -40,6 +40,7 @@ constexpr int RES_BYTES = 32;
 struct ResidentArgs {
     StepArgs p;
     uint4 *res;
+    uint32_t *check_mask; // nullable (N): wurm_single_call.check_mask
 };
 
 template <int EPW>
@@ -267,6 +268,9 @@ __global__ __launch_bounds__(256) void lane_resident_step_kernel(ResidentArgs a)
         a.res[p.N + env] = make_uint4(q2, pk, act ? (RES_ACT | (fin ? RES_TERMINAL : 0u)) : (r1.z & ~RES_ACT),
                                       act ? ((u32)ny | ((u32)nx << 4)) : r1.w);
     }
+
+    if (mine && a.check_mask != nullptr) // wurm_single_check's mask of the stepped state: a live env of the domain is a well-formed snake
+        a.check_mask[env] = act && !fin ? ((L < 3 ? WURM_CHK_MIN_LENGTH : 0u) | (food < 0 ? WURM_CHK_ONE_FOOD : 0u)) : WURM_CHK_NOT_COMPUTED;
 
     WURM_TL(3); // outputs and mirror stored
     // ---- `envs`: the elements that change (single_snake.py:246-282), straight from the env lanes
@@ -503,6 +507,7 @@ hipError_t launch_lane_resident_flush(const StepArgs &p, void *resident, hipStre
     ResidentArgs a;
     a.p = p;
     a.res = (uint4 *)resident;
+    a.check_mask = nullptr;
     constexpr int EPW = 16;
     const long long waves = (p.N + EPW - 1) / EPW;
     const int wpb = waves >= 1024 ? 4 : 1;
@@ -513,11 +518,12 @@ hipError_t launch_lane_resident_flush(const StepArgs &p, void *resident, hipStre
 }
 
 template <bool LAZY>
-static hipError_t launch_lane_resident_form(const StepArgs &p, void *resident, bool valid, hipStream_t stream)
+static hipError_t launch_lane_resident_form(const StepArgs &p, void *resident, bool valid, uint32_t *check_mask, hipStream_t stream)
 {
     ResidentArgs a;
     a.p = p;
     a.res = (uint4 *)resident;
+    a.check_mask = check_mask;
     (void)hipGetLastError();
     if (!valid) {
         constexpr int EPW = 16;
@@ -581,10 +587,10 @@ static hipError_t launch_lane_resident_form(const StepArgs &p, void *resident, b
     return hipGetLastError();
 }
 
-hipError_t launch_lane_resident(const StepArgs &p, void *resident, bool valid, bool lazy, hipStream_t stream)
+hipError_t launch_lane_resident(const StepArgs &p, void *resident, bool valid, bool lazy, uint32_t *check_mask, hipStream_t stream)
 {
-    return lazy ? launch_lane_resident_form<true>(p, resident, valid, stream)
-                : launch_lane_resident_form<false>(p, resident, valid, stream);
+    return lazy ? launch_lane_resident_form<true>(p, resident, valid, check_mask, stream)
+                : launch_lane_resident_form<false>(p, resident, valid, check_mask, stream);
 }
 
 } // namespace wurm

@@ -1565,30 +1565,36 @@ __global__ __launch_bounds__(256) void check_kernel(const float *__restrict__ en
     if (env >= N) return;
     const Geo g = make_geo<CPL>(S);
     const float *envp = envs + env * 3 * g.C;
-    int bad_food = 0, hs = 0, bs = 0, bm = 0, hb = 0, hf = 0, fs = 0;
+    // in fp32 like the reference's sums (wurm/utils.py:113-178) — a state that holds non-integers (food 0.5, only ever by
+    // hand) gets the reference's verdict on every check, not only on the first one (tests/test_checker_failing_states.py).
+    // Sums of integer-valued floats are exact in any order; so are sums of a few halves and quarters.
+    int bad_food = 0;
+    float hs = 0.0f, bs = 0.0f, bm = -INFINITY, hb = 0.0f, hf = 0.0f, fs = 0.0f;
 #pragma unroll
     for (int k = 0; k < CPL; ++k) {
         int c = g.lane + 64 * k;
         if ((g.valid >> k) & 1) {
             float f = envp[c], h = envp[g.C + c], b = envp[2 * g.C + c];
-            int fi = __float2int_rn(f), hi = __float2int_rn(h), bi = __float2int_rn(b);
             bad_food |= !(f == 0.0f || f == 1.0f);
-            hs += hi; bs += bi; hb += hi * bi; hf += hi * fi; fs += fi;
-            bm = max(bm, bi);
+            hs += h; bs += b; hb += h * b; hf += h * f; fs += f;
+            bm = fmaxf(bm, b);
         }
     }
     bad_food = ballot(bad_food != 0) != 0;
-    hs = wave_sum_i32(hs); bs = wave_sum_i32(bs); hb = wave_sum_i32(hb); hf = wave_sum_i32(hf);
-    fs = wave_sum_i32(fs); bm = wave_max_i32(bm);
+#pragma unroll
+    for (int sh = 32; sh >= 1; sh >>= 1) {
+        hs += __shfl_xor(hs, sh); bs += __shfl_xor(bs, sh); hb += __shfl_xor(hb, sh); hf += __shfl_xor(hf, sh);
+        fs += __shfl_xor(fs, sh); bm = fmaxf(bm, __shfl_xor(bm, sh));
+    }
     uint32_t m = 0;
     if (bad_food) m |= WURM_CHK_FOOD_VALUE;
-    if (hs != 1) m |= WURM_CHK_ONE_HEAD;
-    if (!(bs > 0)) m |= WURM_CHK_HAS_SNAKE;
+    if (hs != 1.0f) m |= WURM_CHK_ONE_HEAD;
+    if (!(bs > 0.0f)) m |= WURM_CHK_HAS_SNAKE;
     if (bm != hb) m |= WURM_CHK_HEAD_AT_END;
-    if (2 * bs != bm * (bm + 1)) m |= WURM_CHK_BODY_RANGE; // (sqrt(8*bs+1)-1)/2 == bm  <=>  bs is the bm-th triangular number
-    if (!(bs >= 6)) m |= WURM_CHK_MIN_LENGTH;
-    if (hf != 0) m |= WURM_CHK_HEAD_ON_FOOD;
-    if (fs != 1) m |= WURM_CHK_ONE_FOOD;
+    if ((__fsqrt_rn(8.0f * bs + 1.0f) - 1.0f) / 2.0f != bm) m |= WURM_CHK_BODY_RANGE; // bs is the bm-th triangular number
+    if (!(bs >= 6.0f)) m |= WURM_CHK_MIN_LENGTH;
+    if (hf != 0.0f) m |= WURM_CHK_HEAD_ON_FOOD;
+    if (fs != 1.0f) m |= WURM_CHK_ONE_FOOD;
     if (g.lane == 0) err[env] = m;
 }
 
@@ -1860,6 +1866,11 @@ static int fused_entry(bool snake, const wurm_single_call *c, void *stream, int 
     p.envs = c->envs; p.actions = c->actions; p.act_dtype = c->actions_dtype; p.reward = c->reward; p.done = c->done;
     p.selfc = c->self_collision; p.edgec = c->edge_collision; p.obs = c->obs; p.obs_mode = c->obs_mode;
     p.obs_n = c->obs_n; p.obs_elems = obs_elems(snake, c->obs_mode, c->obs_n, c->size); p.N = N; p.S = c->size;
+    // check_mask: only the resident 9 x 9 step computes it (below); any other kernel leaves "not computed" for every env
+    auto no_mask = [&]() -> int {
+        if (c->check_mask == nullptr || N == 0) return WURM_OK;
+        return hipMemsetAsync(c->check_mask, 0xFF, (size_t)N * 4, (hipStream_t)stream) == hipSuccess ? WURM_OK : WURM_ERR_HIP;
+    };
     p.start_y = c->start_y; p.start_x = c->start_x; p.seed = c->seed; p.call = c->call; p.env_offset = c->env_offset;
     p.inject_food = c->inject_food; p.inject_reset = c->inject_reset; p.done_in = c->pre_done;
     p.obs_after = c->obs_after; p.done_copy = c->done_copy; p.inject_pre_reset = c->inject_pre_reset;
@@ -1868,12 +1879,13 @@ static int fused_entry(bool snake, const wurm_single_call *c, void *stream, int 
         p.lds_per_wave = ((p.S * p.S + 15) / 16) * 16;
         if (lane_resident_eligible(p)) {
             // the caller keeps a compact mirror of the state: the step reads that instead of envs (lane_resident.hpp)
-            if (launch_lane_resident(p, c->resident, c->resident_valid != 0, c->resident_lazy != 0, (hipStream_t)stream) !=
-                hipSuccess)
+            if (launch_lane_resident(p, c->resident, c->resident_valid != 0, c->resident_lazy != 0, c->check_mask,
+                                     (hipStream_t)stream) != hipSuccess)
                 return WURM_ERR_HIP;
             if (mirror_state) *mirror_state = 1;
             return WURM_OK;
         }
+        if (no_mask() != WURM_OK) return WURM_ERR_HIP;
         if (grid_resident_eligible(p)) {
             // 12 x 12 and larger: the LDS clock-grid step keeps its grids in the mirror (grid_rollout.hip)
             p.resident = c->resident;
@@ -1891,6 +1903,7 @@ static int fused_entry(bool snake, const wurm_single_call *c, void *stream, int 
             if (err != hipSuccess) return WURM_ERR_HIP;
         }
     }
+    if (!(snake && c->resident != nullptr && N > 0) && no_mask() != WURM_OK) return WURM_ERR_HIP;
     if (mirror_state) *mirror_state = 0;
     // nothing to rebuild and no second observation: the plain step kernel (lighter on registers for large grids)
     const Kind kind = resets ? K_FUSED : K_STEP;

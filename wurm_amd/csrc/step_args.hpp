@@ -67,7 +67,7 @@ hipError_t launch_lane_rollout(const StepArgs &p, hipStream_t stream);
 // per-call step of large 9 x 9 batches on a caller-owned compact mirror of the state (lane_resident.hpp, in lane_rollout.hip)
 bool lane_resident_shape(int S, int obs_mode, int obs_n);
 bool lane_resident_eligible(const StepArgs &p);
-hipError_t launch_lane_resident(const StepArgs &p, void *resident, bool valid, bool lazy, hipStream_t stream);
+hipError_t launch_lane_resident(const StepArgs &p, void *resident, bool valid, bool lazy, uint32_t *check_mask, hipStream_t stream);
 hipError_t launch_lane_resident_flush(const StepArgs &p, void *resident, hipStream_t stream);
 // the same for grids of 12 x 12 and larger (grid_rollout.hip: grid_step_kernel reads / maintains p.resident)
 bool grid_resident_eligible(const StepArgs &p);

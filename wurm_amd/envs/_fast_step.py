@@ -185,6 +185,9 @@ class FastStepMixin(object):
             self._mirror_off = True
         self._lazy_mirror = pol != 'eager' and os.environ.get('WURM_RESIDENT_LAZY', '1') != '0'
         self._write_outs = self._touches = self._mirror_step0 = 0
+        # check_consistency()'s masks from inside the step launch (wurm_single_call.check_mask): asked for once the caller
+        # has called check_consistency(), valid for the state the last step left until anything else touches the state
+        self._chk, self._chk_armed_at, self._chk_void_at, self._check_calls, self._check_step = None, 1 << 62, -1, 0, 0
         self._mirror_why = 'resident_mirror=False' if pol is False else 'no step yet'
 
     # state of the step machine that other methods of the classes read and write
@@ -233,6 +236,7 @@ class FastStepMixin(object):
         if fs.pending:
             self._flush()
         fs.obs_after = None
+        self._chk_void_at = fs.steps  # (the caller may edit what it gets)
         self._write_out()  # (lazy mirror: the step launches have not been writing `envs`; eager from now on, _watch)
         self._watch(self._envs)
         return self._envs
@@ -272,6 +276,7 @@ class FastStepMixin(object):
     def _touch(self):
         """Something other than the step launch is about to look at the state or to write it: a lazy mirror is written
         out to `envs` first (the step launches have not been writing them), and the next step rebuilds the mirror."""
+        self._chk_void_at = self._fs.steps  # the masks of the last step's launch no longer describe the state
         self._write_out()
         c = self._c
         if c.resident_valid and c.resident:
@@ -366,6 +371,28 @@ class FastStepMixin(object):
         return {'state': 'off' if not on else ('lazy' if c.resident_lazy else 'eager'), 'why': self._mirror_why,
                 'policy': self._resident_policy, 'current': bool(on and c.resident_valid),
                 'bytes': int(self._mirror.numel()) if on else 0}
+
+    def _step_check_mask(self):
+        """(N) int32 masks of wurm_single_check for the state as it is now, computed inside the last step's launch
+        (wurm_single_call.check_mask) — -1 where the launch could not vouch for an env or the env finished in that step —
+        or None if they do not describe the current state; arms the request for the following steps."""
+        fs, c = self._fs, self._c
+        self._check_calls += 1
+        self._check_step = fs.steps
+        if self._mirror is None or not c.resident:
+            return None
+        self._mirror_sync()  # (an in-place edit of a state tensor the caller holds voids the masks)
+        if self._chk is None:
+            self._chk = torch.full((self.num_envs,), -1, dtype=torch.int32, device=self.device)
+        if not c.check_mask:
+            c.check_mask = self._chk.data_ptr()
+            self._chk_armed_at = fs.steps          # steps from here on write the masks
+            return None
+        if not c.resident_valid or fs.steps <= self._chk_armed_at or fs.steps <= self._chk_void_at:
+            return None
+        if fs.pending:  # the postponed reset(done) rebuilds exactly the envs the masks left out: fresh envs are consistent
+            return self._chk.masked_fill(self._pend != 0, 0)
+        return self._chk
 
     def _checked(self, e: torch.Tensor) -> torch.Tensor:
         if e is self._envs_ok:

@@ -316,10 +316,22 @@ class SingleSnake(FastStepMixin):
         gathering them: `env.check_consistency(~done.squeeze(-1))` is what experiments/main.py:214-215 asks with
         `env_consistency(env.envs[~done.squeeze(-1)])`, at the cost of one checker launch and one `any()`."""
         from wurm_amd.utils import consistency_mask, _or_reduce, _raise_for
-        err = consistency_mask(self._state(write=False))
+        sel = None
         if mask is not None:
-            m = mask.view(self.num_envs)
-            err = err * (m if m.dtype == torch.bool else m != 0).to(err.dtype)
+            sel = mask.view(self.num_envs)
+            sel = sel if sel.dtype == torch.bool else sel != 0
+        err = self._step_check_mask()  # from inside the last step's launch, where it computed them (resident mirror)
+        if err is not None:
+            if sel is not None:
+                err = err * sel.to(err.dtype)
+            if not bool(err.any()):
+                return
+            if bool((err == -1).any()):  # an env the launch could not vouch for (or a finished one that was asked about)
+                err = None
+        if err is None:
+            err = consistency_mask(self._state(write=False))
+            if sel is not None:
+                err = err * sel.to(err.dtype)
         _raise_for(_or_reduce(err), one_food=True)
 
     # ------------------------------------------------------------------ rendering (host side)
