@@ -144,3 +144,25 @@ def test_per_call_parity_suites_with_the_grouped_writer():
                         'tests/test_hip_golden.py', '-k', 'not larger_than_64kb'],
                        cwd=root, env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+
+
+@pytest.mark.parametrize('shape', [5014, 4514, 3014])   # 1000 G + 100 W + 10 EPS + waves per SIMD: G 4 W 10, G 4 W 5, G 2 W 10
+@pytest.mark.parametrize('N,K,S,T,cfg', [
+    (9, 10, 36, 30, 'train'),       # experiments/speeds.py shape: 10 snakes on 36 x 36, respawn 'any'
+    (7, 6, 14, 70, 'dense'),
+    (5, 8, 25, 40, 'default'),
+    (3, 10, 12, 50, 'dense'),       # crowded
+])
+def test_wide_group_rollout_six_to_ten_snakes(hip, shape, N, K, S, T, cfg):
+    """6 .. 10 snakes: 32-bit class words, one code buffer, two barriers per step (multi_rollout_group_kernel<.., WIDE>)"""
+    cfg = CFGS[cfg]
+    rng = np.random.RandomState(13 * K + S + shape)
+    o, h = OracleBackend(seed=37, env_offset=2000), hip(seed=37, env_offset=2000)
+    so, sh = _fresh(o, h, N, K, S, cfg)
+    actions = rng.randint(0, 8, size=(T, K, N)).astype(np.int64)
+    ro = o.multi_rollout(so, actions, cfg, 'full')
+    with knobs(WURM_MULTI_GROUP_MIN_ENVS=0, WURM_MULTI_GROUP_SHAPE=shape):
+        rh = h.multi_rollout(sh, actions, cfg, 'full')
+    for k in ro:
+        _same(ro[k], rh[k], k)
+    _same_state(so, sh, 'final state')

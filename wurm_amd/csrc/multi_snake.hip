@@ -18,6 +18,8 @@
 //     the snake-level logic of all K snakes runs in parallel and exchanges values with shuffles / ballots;
 //   * cross-cell lookups (food under a head, bodies under a head) are single LDS reads at the head cell.
 // Integer/index work: no MFMA.  Bound: HBM ((1+2K)*S*S*4 B read + observation written per env-step).
+#include <type_traits>
+
 #include "wurm_device.hpp"
 #include "../../include/wurm_hip.h"
 
@@ -1124,7 +1126,8 @@ __device__ __forceinline__ void workgroup_handoff()
 }
 
 // the pieces of the grouped 'full' observation writer (defined with multi_rollout_group_kernel below)
-__device__ __forceinline__ void class_write(const Ctx &cx, int hc, unsigned short *codes);
+template <typename CT>
+__device__ __forceinline__ void class_write(const Ctx &cx, int hc, CT *codes);
 __device__ __forceinline__ void grp_table_init(float *tab, int tid);
 __device__ __forceinline__ void grp_emit_group(const MultiArgs &p, float *obs, long long env0, int nG, int wave, int nwaves,
                                                const unsigned char *codes0, int code_stride, const float *tab, int lane);
@@ -1195,7 +1198,7 @@ __global__ __launch_bounds__(512) void multi_step_kernel(MultiArgs p)
     if (grouped && p.grp_emit == 2) { // every wave for itself: its env's class codes -> its K agents' views (no barrier)
         workgroup_handoff(); // (the table)
         if (!active) return;
-        class_write(cx, sn.hc, cx.snap);
+        class_write<unsigned short>(cx, sn.hc, cx.snap);
         grp_emit_group(p, p.obs + env * p.obs_elems - env0 * p.obs_elems, env0, 1, 0, 1, (const unsigned char *)cx.snap, 0, tab, lane);
         if (p.obs_after == nullptr) return;
         const bool touched = reset_for_obs_after(cx, p, env, sn, r);
@@ -1203,13 +1206,13 @@ __global__ __launch_bounds__(512) void multi_step_kernel(MultiArgs p)
             if (touched) m_step = clean ? lds_check(cx, sn) : MCHK_NOT_COMPUTED;
             if (lane == 0) p.err_after[env] = m_step;
         }
-        class_write(cx, sn.hc, cx.snap);
+        class_write<unsigned short>(cx, sn.hc, cx.snap);
         grp_emit_group(p, p.obs_after + env * p.obs_elems - env0 * p.obs_elems, env0, 1, 0, 1, (const unsigned char *)cx.snap, 0, tab, lane);
         return;
     }
     if (grouped) {
         const unsigned char *codes0 = (const unsigned char *)make_ctx(p, 0).snap;
-        if (active) class_write(cx, sn.hc, cx.snap);
+        if (active) class_write<unsigned short>(cx, sn.hc, cx.snap);
         workgroup_handoff();
         grp_emit_group(p, p.obs, env0, nG, wave, wpb, codes0, p.lds_per_wave, tab, lane);
         if (p.obs_after == nullptr) return;
@@ -1220,7 +1223,7 @@ __global__ __launch_bounds__(512) void multi_step_kernel(MultiArgs p)
                 if (touched) m_step = clean ? lds_check(cx, sn) : MCHK_NOT_COMPUTED; // (else: the state the first mask describes)
                 if (lane == 0) p.err_after[env] = m_step;
             }
-            class_write(cx, sn.hc, cx.snap);
+            class_write<unsigned short>(cx, sn.hc, cx.snap);
         }
         workgroup_handoff();
         grp_emit_group(p, p.obs_after, env0, nG, wave, wpb, codes0, p.lds_per_wave, tab, lane);
@@ -2022,7 +2025,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void m
 //   * the steppers issue NO global memory instruction in the steady state: rewards / flags go to LDS and are written by a
 //     writer wave (the CU's vector memory pipeline is in order: a stepper's small stores queued behind the observation
 //     stream of the whole CU stall the stepper at issue).
-constexpr int GRP_MAX_SNAKES = 5;   // 3 bits per agent in a 16-bit word
+constexpr int GRP_MAX_SNAKES = 5;   // 3 bits per agent in a 16-bit word (double-buffered)
+constexpr int GRP_MAX_SNAKES32 = 10; // ... in a 32-bit word (single-buffered: 4 bytes per cell is what the LDS has room for once)
 constexpr int GRP_TAB_BYTES = 128;  // float tab[3][8] at the start of the workgroup's LDS
 constexpr int GRP_CODE_SLACK = 640;  // bytes the writers may READ behind the last code array (grp_emit_cells: 5 x 64 codes)
 
@@ -2033,20 +2037,29 @@ __device__ __forceinline__ u32 grp_rep(int K) { return (u32)(((1ull << (3 * K)) 
 // :268-281 paints food, own body, own head, other bodies, other heads, then the border (:183-186): a later layer wins, so
 // the class of a cell for an agent is the LAST layer that covers it — with the classes numbered in paint order, the
 // maximum over the layers.  Bodies first (every cell), then the K head cells are raised.
-__device__ __forceinline__ void class_write(const Ctx &cx, int hc, unsigned short *codes)
+template <typename CT>
+__device__ __forceinline__ void class_write(const Ctx &cx, int hc, CT *codes)
 {
     const int S = cx.S, C = cx.C, K = cx.K, lane = cx.lane;
     const u32 REP = grp_rep(K);
-    // which snakes have their head on a cell: a bit mask per cell in hmap (all-zero outside this function; two heads may
-    // share a cell in hand-made states, so the bits are OR-ed in)
-    if (lane < K && hc >= 0) atomicOr((u32 *)(cx.hmap + (hc & ~3)), (1u << lane) << (8 * (hc & 3)));
+    // which snake has its head on a cell: owner + 1 per cell in hmap (all-zero outside this function); two heads may share
+    // a cell in hand-made states — such a cell is marked 255 and its owners are looked up among the K head cells
+    if (lane < K && hc >= 0) cx.hmap[hc] = (unsigned char)(lane + 1);
+    wave_lds_sync();
+    if (lane < K && hc >= 0 && cx.hmap[hc] != (unsigned char)(lane + 1)) cx.hmap[hc] = 255;
     wave_lds_sync();
     for (int k = 0; k < cx.cpl; ++k) {
         const int c = lane + 64 * k;
         if (c < C) {
             u32 bm = 0;
             for (int s = 0; s < K; ++s) bm |= (u32)((int)(cx.body[s * C + c] & VMASK) > cx.tclk[s]) << s;
-            const u32 hm = cx.hmap[c], occ = bm | hm;
+            const u32 hv = cx.hmap[c];
+            u32 hm = hv ? 1u << (hv - 1u) : 0u;
+            if (hv == 255u) { // several heads on the cell
+                hm = 0;
+                for (int s = 0; s < K; ++s) hm |= (u32)(cx.hcell[s] == c) << s;
+            }
+            const u32 occ = bm | hm;
             u32 code;
             if (occ == 0) code = cx.food[c] != 0 ? REP : 0u;
             else if ((occ & (occ - 1u)) == 0) // one snake: the others see 4 (body) / 5 (head), the snake itself 2 / 3
@@ -2058,7 +2071,7 @@ __device__ __forceinline__ void class_write(const Ctx &cx, int hc, unsigned shor
                     code |= ((hm & others) ? 5u : (bm & others) ? 4u : ((hm >> a) & 1u) ? 3u : 2u) << (3 * a);
                 }
             }
-            codes[c] = (unsigned short)code;
+            codes[c] = (CT)code;
         }
     }
     wave_lds_sync();
@@ -2066,7 +2079,7 @@ __device__ __forceinline__ void class_write(const Ctx &cx, int hc, unsigned shor
     for (int b = lane; b < 4 * S - 4; b += 64) {
         const int j = b - 2 * S;                       // >= 0: the left / right columns, rows 1 .. S - 2
         const int c = b < S ? b : b < 2 * S ? (S - 1) * S + (b - S) : ((j >> 1) + 1) * S + (j & 1) * (S - 1);
-        codes[c] = (unsigned short)(6u * REP);
+        codes[c] = (CT)(6u * REP);
     }
     if (lane < K && hc >= 0) cx.hmap[hc] = 0;
     wave_lds_sync();
@@ -2096,8 +2109,8 @@ __device__ __forceinline__ float grp_tab(const float *tabp, u32 off) { return *(
 // planes peeled to 16-byte boundaries: it extracts every class three times, once per plane, and pays ~60 instructions of
 // alignment / predication per plane; its writer waves alone took 17.6 us per step against 10.2 us for this form, the
 // launch 26.0 against 24.0 us per step on the same box: profiles/r04_multi_group_probe.txt.)
-template <int U>
-__device__ __forceinline__ void grp_emit_cells_chunk(grp_gfloat *blk, const unsigned short *cg, const float *tab, u32 sh, int C,
+template <int U, typename CT>
+__device__ __forceinline__ void grp_emit_cells_chunk(grp_gfloat *blk, const CT *cg, const float *tab, u32 sh, int C,
                                                      int c0, bool stores)
 {
     u32 off[U];
@@ -2121,13 +2134,14 @@ __device__ __forceinline__ void grp_emit_cells_chunk(grp_gfloat *blk, const unsi
     }
 }
 
-__device__ __forceinline__ void grp_emit_cells(grp_gfloat *blk, const unsigned short *cg, const float *tab, u32 sh, int C, int lane,
+template <typename CT>
+__device__ __forceinline__ void grp_emit_cells(grp_gfloat *blk, const CT *cg, const float *tab, u32 sh, int C, int lane,
                                                bool stores)
 {
     const int cpl = (C + 63) >> 6;
     int k = 0;
-    for (; k + 5 <= cpl; k += 5) grp_emit_cells_chunk<5>(blk, cg, tab, sh, C, lane + 64 * k, stores);
-    for (; k < cpl; ++k) grp_emit_cells_chunk<1>(blk, cg, tab, sh, C, lane + 64 * k, stores);
+    for (; k + 5 <= cpl; k += 5) grp_emit_cells_chunk<5, CT>(blk, cg, tab, sh, C, lane + 64 * k, stores);
+    for (; k < cpl; ++k) grp_emit_cells_chunk<1, CT>(blk, cg, tab, sh, C, lane + 64 * k, stores);
 }
 
 // tab[plane][class]: the reference's colours / 255 (true divisions, as `.to(dtype) / 255` :281); the caller synchronises
@@ -2162,7 +2176,7 @@ __device__ __forceinline__ void grp_emit_group(const MultiArgs &p, float *obs, l
         const u32 sh = 3u * (u32)a;
         for (int g = g0; g < g1; ++g) {
             const unsigned short *cg = (const unsigned short *)(codes0 + (size_t)g * code_stride);
-            grp_emit_cells(run + g * 3 * C, cg, tab, sh, C, lane, true);
+            grp_emit_cells<unsigned short>(run + g * 3 * C, cg, tab, sh, C, lane, true);
         }
     }
 }
@@ -2191,9 +2205,13 @@ __device__ __forceinline__ void grp_restore(const int *sv, int lane, int K, Snak
 // G envs, G / EPS stepper waves (EPS envs each, one after the other within a step: the transition of one env is a chain of
 // dependent LDS operations that takes a wave ~5 us of the ~22 us the step's observations need on the store path, and a
 // stepper's register budget is what limits the waves per SIMD — so fewer, fuller stepper waves), W writer waves.
-template <int G, int W, int EPS, int OCC>
+// WIDE (6 .. 10 snakes): 32-bit class words and ONE code / output buffer — the steppers wait for the writers to be done with
+// step t - 1 before they write the codes of step t (a second barrier per step; the transition itself still runs beside the
+// writers: the speeds.py shape, 10 snakes on 36 x 36, has 41 KB of LDS per env with one 32-bit buffer and four envs per CU).
+template <int G, int W, int EPS, int OCC, bool WIDE = false>
 __global__ __launch_bounds__(64 * (G / EPS + W)) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void multi_rollout_group_kernel(MultiArgs p)
 {
+    typedef typename std::conditional<WIDE, u32, unsigned short>::type CT;
     constexpr int NSW = G / EPS; // stepper waves
     const int wave = uniform((int)(threadIdx.x >> 6)), lane = (int)(threadIdx.x & 63u);
     const long long env0 = xcd_block(blockIdx.x, gridDim.x) * G;
@@ -2210,8 +2228,10 @@ __global__ __launch_bounds__(64 * (G / EPS + W)) __attribute__((amdgpu_waves_per
         const int w = wave - NSW;
         const bool stores = WURM_PROBE(!(p.grp_variant & 4), true);
         for (long long t = 0; t < p.T; ++t) {
+            if (WIDE) workgroup_handoff();   // (the steppers may now overwrite the single buffer: the writers are done with t - 1)
             workgroup_handoff();
-            const unsigned char *cbuf = codes0 + (size_t)(t & 1) * G * p.grp_code_bytes;
+            const int buf = WIDE ? 0 : (int)(t & 1);
+            const unsigned char *cbuf = codes0 + (size_t)buf * G * p.grp_code_bytes;
             // writer wave -> (agent, part of the group's envs): one agent after the other while there are at most as many
             // waves as agents, else W / K waves per agent, each with its own contiguous part of the run
             const int parts = W > K ? W / K : 1, part = W > K ? w / K : 0;
@@ -2220,12 +2240,12 @@ __global__ __launch_bounds__(64 * (G / EPS + W)) __attribute__((amdgpu_waves_per
                 grp_gfloat *const run = (grp_gfloat *)uniform64((long long)(p.obs + ((t * K + a) * p.N + env0) * p.obs_elems));
                 const u32 sh = 3u * (u32)a;
                 for (int g = g0; g < g1; ++g) {
-                    const unsigned short *cg = (const unsigned short *)(cbuf + (size_t)g * p.grp_code_bytes);
-                    grp_emit_cells(run + g * 3 * C, cg, tab, sh, C, lane, stores);
+                    const CT *cg = (const CT *)(cbuf + (size_t)g * p.grp_code_bytes);
+                    grp_emit_cells<CT>(run + g * 3 * C, cg, tab, sh, C, lane, stores);
                 }
             }
             if (w == 0) { // the steppers' per-step outputs: rows (j K + s) of G consecutive envs each
-                const unsigned char *obuf = outs0 + (size_t)(t & 1) * G * p.grp_out_bytes;
+                const unsigned char *obuf = outs0 + (size_t)buf * G * p.grp_out_bytes;
                 float *of = p.am_f32 + t * 3 * KN;
                 uint8_t *ob = p.am_u8 + t * 4 * KN;
                 for (int i = lane; i < 3 * K * G; i += 64) {
@@ -2243,6 +2263,13 @@ __global__ __launch_bounds__(64 * (G / EPS + W)) __attribute__((amdgpu_waves_per
     }
 
     // ---- a stepper: envs env0 + wave * EPS + e, e < EPS; the scalars of the envs it is not working on wait in LDS
+    if (env0 + wave * EPS >= p.N) { // a ragged last group: nothing to step, but the barriers are the workgroup's
+        for (long long t = 0; t < p.T; ++t) {
+            if (WIDE) workgroup_handoff();
+            workgroup_handoff();
+        }
+        return;
+    }
     const bool snake = lane < K;
     int *const save0 = (int *)(wurm_multi_lds + p.grp_save);
     for (int e = 0; e < EPS; ++e) {
@@ -2295,7 +2322,10 @@ __global__ __launch_bounds__(64 * (G / EPS + W)) __attribute__((amdgpu_waves_per
             StepRes r = {};
             if (WURM_PROBE(!(p.grp_variant & 8), true)) multi_step_body(cx, p, env, env_id, call, a, sn, r, t * p.N * C, t * KN, t * p.N);
             // buffer t & 1 is free: the writers finished with it before they arrived at the barrier of step t - 1
-            unsigned char *obuf = outs0 + ((size_t)(t & 1) * G + g) * p.grp_out_bytes;
+            // (WIDE: the one buffer is free once the writers have passed the extra barrier of this step)
+            if (WIDE && e == 0) workgroup_handoff();
+            const int buf = WIDE ? 0 : (int)(t & 1);
+            unsigned char *obuf = outs0 + ((size_t)buf * G + g) * p.grp_out_bytes;
             if (snake) {
                 float *f = (float *)obuf;
                 f[lane] = r.reward;
@@ -2308,7 +2338,7 @@ __global__ __launch_bounds__(64 * (G / EPS + W)) __attribute__((amdgpu_waves_per
                 b[3 * K + lane] = (unsigned char)r.edgecol;
             }
             if (lane == 0) obuf[16 * K] = (unsigned char)r.all_done;
-            class_write(cx, sn.hc, (unsigned short *)(codes0 + ((size_t)(t & 1) * G + g) * p.grp_code_bytes));
+            class_write<CT>(cx, sn.hc, (CT *)(codes0 + ((size_t)buf * G + g) * p.grp_code_bytes));
             if (lane == 0) ((int *)(save0 + g * 8 * K))[7] = (int)r.all_done;   // (slot 7 of snake 0: for the reset below)
             grp_save(save0 + g * 8 * K, lane, K, sn, col_dirty, hc0);
             wave_lds_sync();
@@ -2529,19 +2559,28 @@ static int multi_launch(MKind kind, MultiArgs &p, void *stream)
     // double-buffer it between a stepping and a writing wave (multi_rollout_kernel<true>)
     const bool snap = p.obs_mode == WURM_OBS_DEFAULT && p.K <= SNAP_MAX_SNAKES;
     const bool two = kind == MK_ROLLOUT && snap && p.T > 1;
-    if (two && p.K <= GRP_MAX_SNAKES && p.N >= opt.multi_group_min_envs) {
+    if (two && p.K <= GRP_MAX_SNAKES32 && p.N >= opt.multi_group_min_envs) {
+        const bool wide = p.K > GRP_MAX_SNAKES; // 32-bit class words, one buffer
         // large batches: G consecutive envs per workgroup, one linear observation run per agent (multi_rollout_group_kernel)
         MultiArgs q = p;
         const int lds_env = multi_layout(q, false, 0), C = p.S * p.S;
-        q.grp_code_bytes = (2 * C + 15) & ~15;
+        q.grp_code_bytes = ((wide ? 4 : 2) * C + 15) & ~15;
+        const int nbuf = wide ? 1 : 2;
         q.grp_out_bytes = (16 * p.K + 1 + 15) & ~15;
         const int save_bytes = 32 * p.K; // grp_save: 8 ints per snake
         // (the writers read up to GRP_CODE_SLACK bytes past a code array: what lies behind the last one must be this LDS)
-        auto slack = [&](int G) { return std::max(0, GRP_CODE_SLACK - G * (2 * q.grp_out_bytes + save_bytes)); };
-        auto total = [&](int G) { return GRP_TAB_BYTES + G * (lds_env + 2 * q.grp_code_bytes + 2 * q.grp_out_bytes + save_bytes) + slack(G); };
+        auto slack = [&](int G) { return std::max(0, (wide ? 2 : 1) * GRP_CODE_SLACK - G * (nbuf * q.grp_out_bytes + save_bytes)); };
+        auto total = [&](int G) {
+            return GRP_TAB_BYTES + G * (lds_env + nbuf * q.grp_code_bytes + nbuf * q.grp_out_bytes + save_bytes) + slack(G);
+        };
         // shape: G envs, W writer waves, EPS envs per stepper wave, OCC waves per SIMD (option WURM_MULTI_GROUP_SHAPE =
         // 1000 G + 100 W + 10 EPS + OCC picks one of the compiled shapes; 0 = automatic: the first that fits)
         struct Shape { int G, W, eps, occ; const void *fn; };
+        static const Shape wide_shapes[] = { // 6 .. 10 snakes (the first that fits)
+            {4, 10, 1, 4, (const void *)multi_rollout_group_kernel<4, 10, 1, 4, true>},
+            {4, 5, 1, 4, (const void *)multi_rollout_group_kernel<4, 5, 1, 4, true>},
+            {2, 10, 1, 4, (const void *)multi_rollout_group_kernel<2, 10, 1, 4, true>},
+        };
         static const Shape shapes[] = {
             // (automatic: the first that fits.  Measured at cfg4, 64-step launches, same box: 8416 1.61 ms, 8424 1.79, 4414 1.81;
             // the two-wave kernel of round 3: 2.05 — profiles/r04_multi_group_sweep.txt)
@@ -2549,7 +2588,13 @@ static int multi_launch(MKind kind, MultiArgs &p, void *stream)
             {8, 4, 2, 4, (const void *)multi_rollout_group_kernel<8, 4, 2, 4>}, {8, 2, 1, 5, (const void *)multi_rollout_group_kernel<8, 2, 1, 5>},
         };
         const Shape *sh = nullptr;
+        for (const Shape &c : wide_shapes) {
+            if (!wide) break;
+            if (total(c.G) > LDS_MAX_BYTES) continue;
+            if (opt.multi_group_shape == 0 || 1000 * c.G + 100 * c.W + 10 * c.eps + c.occ == opt.multi_group_shape) { sh = &c; break; }
+        }
         for (const Shape &c : shapes) {
+            if (wide) break;
             const bool fits = total(c.G) <= LDS_MAX_BYTES;
             if (opt.multi_group_shape ? (1000 * c.G + 100 * c.W + 10 * c.eps + c.occ == opt.multi_group_shape && fits)
                                       : (fits && (c.G == 4 || 2 * total(8) <= LDS_MAX_BYTES))) { sh = &c; break; }
@@ -2558,8 +2603,8 @@ static int multi_launch(MKind kind, MultiArgs &p, void *stream)
             const int G = sh->G, W = sh->W;
             q.grp_env0 = GRP_TAB_BYTES;
             q.grp_codes = q.grp_env0 + G * lds_env;
-            q.grp_outs = q.grp_codes + 2 * G * q.grp_code_bytes;
-            q.grp_save = q.grp_outs + 2 * G * q.grp_out_bytes;
+            q.grp_outs = q.grp_codes + nbuf * G * q.grp_code_bytes;
+            q.grp_save = q.grp_outs + nbuf * G * q.grp_out_bytes;
             const size_t bytes = (size_t)total(G);
             const dim3 gg((unsigned)((p.N + G - 1) / G)), bb(64 * (G / sh->eps + W));
             (void)hipGetLastError();
