@@ -435,6 +435,25 @@ def host_calibration(device):
     for _ in range(2000):
         torch.empty(64, device=device)
     out['torch_empty_us'] = (time.perf_counter() - t0) / 2000 * 1e6
+    # what THIS box's HBM takes from a plain kernel: a 2 GB fill (the store ceiling of the observation streams: boxes of the
+    # pool differ by +-10 %) and a 1 GB copy
+    big = torch.empty(1 << 29, dtype=torch.float32, device=device)
+    big.fill_(1.0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        big.fill_(2.0)
+    torch.cuda.synchronize()
+    out['hbm_fill_2GB_TBps'] = 5 * big.numel() * 4 / (time.perf_counter() - t0) / 1e12
+    half = big.numel() // 2
+    big[half:].copy_(big[:half])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        big[half:].copy_(big[:half])
+    torch.cuda.synchronize()
+    out['hbm_copy_1GB_read_plus_write_TBps'] = 5 * 2 * half * 4 / (time.perf_counter() - t0) / 1e12
+    del big
     return {k: round(v, 2) for k, v in out.items()}
 
 
@@ -695,6 +714,11 @@ def extra_measurements(device):
     per_call('per_call_cfg3', lambda: SingleSnake(N, SIZE, observation_mode=OBS_MODE, device=device, seed=0), a1, same, T,
              "BASELINE configs[2] whole on one GPU through the reference's own call form `env.step(a); env.reset(d)` (resident "
              'mirror, lazy)', reset_kw={}, traffic_key='resident_step_65536x9_partial2_reset_obs')
+    for mode in ('default', 'one_channel'):
+        per_call(f'per_call_cfg3_{mode}', lambda: SingleSnake(N, SIZE, observation_mode=mode, device=device, seed=0), a1, same, T,
+                 f"65 536 x 9 x 9 with observation_mode={mode!r} ('one_channel' is the reference's constructor default) through "
+                 '`env.step(a); env.reset(d)` (resident mirror, bit-plane writer)', reset_kw={},
+                 traffic_key=f'resident_step_65536x9_{mode}_reset_obs')
     N, T = 512, 4000
     acts = torch.randint(4, (T + 10, N), device=device, dtype=torch.int64)
     per_call('per_call_512_no_reset_obs', lambda: SingleSnake(N, SIZE, observation_mode=OBS_MODE, device=device, seed=0),
@@ -718,7 +742,9 @@ def key_numbers(line):
         'cfg3_rollout_eps': g('rollout_cfg3_65536'), 'cfg3_rollout_ms': g('rollout_cfg3_65536', 'ms'),
         'cfg3_rollout_frac_real': g('rollout_cfg3_65536', 'frac_real'),
         'cfg3_share_8192_eps': g('rollout_8192'),
-        'cfg3_one_channel_eps': g('rollout_65536x9_one_channel'), 'cfg3_default_eps': g('rollout_65536x9_default'),
+        'cfg3_one_channel_eps': g('rollout_65536x9_one_channel'), 'cfg3_one_channel_frac_real': g('rollout_65536x9_one_channel', 'frac_real'),
+        'cfg3_default_eps': g('rollout_65536x9_default'), 'cfg3_default_frac_real': g('rollout_65536x9_default', 'frac_real'),
+        'per_call_cfg3_one_channel_us': g('per_call_cfg3_one_channel', 'us'),
         'cfg4_rollout_ms': g('multi_rollout_cfg4_full', 'ms'), 'cfg4_rollout_frac_real': g('multi_rollout_cfg4_full', 'frac_real'),
         'cfg4_rollout_eps': g('multi_rollout_cfg4_full'), 'cfg4_per_call_us': g('per_call_cfg4', 'us'),
         'cfg5_rollout_ms': g('rollout_cfg5_8192x36_default', 'ms'),
@@ -731,6 +757,7 @@ def key_numbers(line):
         'a2c_loop_512_eps': g('a2c_loop_512'), 'a2c_fused_actor_512_eps': g('a2c_fused_actor_512'),
         'speeds_rollout_eps': g('multi_rollout_speeds_4096x36_k10'), 'speeds_py_loop_us': g('speeds_py_loop_4096x36_k10', 'us'),
         'cfg4prime_rollout_eps': g('multi_rollout_cfg4prime_partial5'),
+        'box_hbm_fill_TBps': ex.get('host_calibration_after', {}).get('hbm_fill_2GB_TBps'),
     }
 
 

@@ -1,6 +1,6 @@
 #!/bin/bash
 # HBM traffic of the env kernels only (steps 3-4 of tools/collect_profiles.sh): bash tools/collect_traffic.sh <tag>
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/profiles_$TAG
 mkdir -p $OUT

@@ -38,6 +38,20 @@ for N, chunk in ((512, 1024), (8192, 128), (16384, 128), (32768, 64), (65536, 64
     for c in range(0, chunk * 5, chunk):
         env.rollout(actions[c:c + chunk])
     torch.cuda.synchronize()
+# measured (round 4): the other whole-grid observations of 9 x 9 through the lane kernels — one_channel (the reference's
+# constructor default) and default: rollout (32 batch-steps per launch) and the per-call loop in the reference's form
+for mode in ('one_channel', 'default'):
+    env = SingleSnake(num_envs=65536, size=9, observation_mode=mode, device=dev, seed=0)
+    actions = torch.randint(4, (32 * 5, 65536), device=dev, dtype=torch.int64)
+    for c in range(0, 32 * 5, 32):
+        env.rollout(actions[c:c + 32])
+    torch.cuda.synchronize()
+    env = SingleSnake(num_envs=65536, size=9, observation_mode=mode, device=dev, seed=0)
+    for t in range(30):
+        _, _, d, _ = env.step(actions[t])
+        env.reset(d)
+    torch.cuda.synchronize()
+    del env, actions
 # measured: the big-grid rollouts — cfg5 (grid_rollout_kernel) and cfg4 (multi_rollout_kernel), 16 batch-steps per launch
 env = SingleSnake(num_envs=8192, size=36, observation_mode='default', device=dev, seed=0)
 actions = torch.randint(4, (16 * 5, 8192), device=dev, dtype=torch.int64)
