@@ -18,7 +18,7 @@ from wurm_amd._lib import knobs
 
 pytestmark = pytest.mark.gpu
 
-SHAPES = [8416, 4414, 8424]
+SHAPES = [8215, 8416, 4414, 8424]
 
 
 @pytest.fixture(scope='module')

@@ -30,7 +30,7 @@ def run(chunk, reps=6, **kw):
 
 
 for name, opts in [('two-wave (r03)', dict(WURM_MULTI_GROUP_MIN_ENVS=1 << 40))] + \
-        [(f'group {s}', dict(WURM_MULTI_GROUP_MIN_ENVS=0, WURM_MULTI_GROUP_SHAPE=s)) for s in (8416, 8215, 4414)]:
+        [(f'group {s}', dict(WURM_MULTI_GROUP_MIN_ENVS=0, WURM_MULTI_GROUP_SHAPE=s)) for s in (8416, 8215)]:
     with _lib.knobs(**opts):
         for chunk in (16, 64):
             best, med = run(chunk)

@@ -2095,11 +2095,6 @@ typedef __attribute__((address_space(1))) float grp_gfloat;     // a pointer KNO
 #define WURM_PROBE(probe, shipped) (shipped)
 #endif
 
-// one (agent, env, plane) segment of C floats from the env's class codes: dword stores up to the first 16-byte boundary and
-// behind the last one (one instruction for both), 16-byte stores in between.  The writer is bound by the LATENCY of its
-// two dependent LDS reads per float (measured: two writer waves per workgroup cannot keep up with eight steppers), so the
-// reads of three store groups (and of the edge store) are issued together: unconditional, on clamped cells; only the
-// stores are predicated.
 __device__ __forceinline__ float grp_tab(const float *tabp, u32 off) { return *(const float *)((const unsigned char *)tabp + off); }
 
 // The writer: one CELL per lane — its class is extracted ONCE and looked up in the three planes' rows of the table (three
@@ -2181,6 +2176,28 @@ __device__ __forceinline__ void grp_emit_group(const MultiArgs &p, float *obs, l
     }
 }
 
+// Work sharing between the waves of a group: the K * nG (agent, env) observation blocks of a step are ITEMS handed out by
+// an LDS counter, in address order (agent-major: consecutive items are consecutive envs of one agent's run).  The writer
+// waves take items from the barrier of step t on; a stepper wave joins in once it has finished its own step t + 1 — what
+// the store path takes grows with the number of waves that have stores in flight (tools/microbench/store_window.hip: the
+// same bytes at 4.7 / 5.2 / 5.7 / 6.3 TB/s from 4 / 8 / 16 / 32 storing waves per CU), and the steppers are idle for half
+// of a step's period otherwise.
+template <typename CT>
+__device__ __forceinline__ void grp_take_items(const MultiArgs &p, int *ctr, const unsigned char *cbuf, long long t, long long env0,
+                                               int nG, const float *tab, int lane, bool stores)
+{
+    const int C = p.S * p.S, K = p.K, items = K * nG;
+    for (;;) {
+        int i = 0;
+        if (lane == 0) i = atomicAdd(ctr, 1);
+        i = uniform(i);
+        if (i >= items) break;
+        const int a = i / nG, g = i - a * nG;
+        grp_gfloat *const blk = (grp_gfloat *)uniform64((long long)(p.obs + ((t * K + a) * p.N + env0 + g) * p.obs_elems));
+        grp_emit_cells<CT>(blk, (const CT *)(cbuf + (size_t)g * p.grp_code_bytes), tab, 3u * (u32)a, C, lane, stores);
+    }
+}
+
 // Per-snake scalars of an env while its stepper wave works on another one (EPS > 1): 8 ints per snake in LDS
 __device__ __forceinline__ void grp_save(int *sv, int lane, int K, const Snake &sn, bool col_dirty, int hc0)
 {
@@ -2213,6 +2230,11 @@ __global__ __launch_bounds__(64 * (G / EPS + W)) __attribute__((amdgpu_waves_per
 {
     typedef typename std::conditional<WIDE, u32, unsigned short>::type CT;
     constexpr int NSW = G / EPS; // stepper waves
+    // SHARE: the (agent, env) blocks of a step are handed out by an LDS counter and the steppers take some too
+    // (grp_take_items) — measured to pay only where the writer waves alone cannot keep up (fewer writers than agents:
+    // 8 / 2 / 1 / 5 went from 1.93 to 1.64 ms per 64 steps at cfg4); with one writer per agent the steppers queueing on the
+    // store path lengthen the step (8 / 4 / 1 / 6: 1.61 -> 1.96 ms), so each writer keeps its own agent's run there
+    constexpr bool SHARE = W < 4 && !WIDE;
     const int wave = uniform((int)(threadIdx.x >> 6)), lane = (int)(threadIdx.x & 63u);
     const long long env0 = xcd_block(blockIdx.x, gridDim.x) * G;
     if (env0 >= p.N) return;
@@ -2221,29 +2243,23 @@ __global__ __launch_bounds__(64 * (G / EPS + W)) __attribute__((amdgpu_waves_per
     const long long KN = (long long)K * p.N;
     float *const tab = (float *)wurm_multi_lds;
     unsigned char *const codes0 = wurm_multi_lds + p.grp_codes, *const outs0 = wurm_multi_lds + p.grp_outs;
+    int *const ctr = (int *)(wurm_multi_lds + 96); // two item counters (one per buffer) behind the 24 floats of the table
     grp_table_init(tab, (int)threadIdx.x);
+    if (SHARE && threadIdx.x < 2) ctr[threadIdx.x] = 0;
     __syncthreads();
+#ifdef WURM_GROUP_PROBE
+    const bool stores = !(p.grp_variant & 4);
+#else
+    constexpr bool stores = true;
+#endif
 
     if (wave >= NSW) { // ---- a writer: the observations of step t from buffer t & 1, handed over by the barrier of step t
         const int w = wave - NSW;
-        const bool stores = WURM_PROBE(!(p.grp_variant & 4), true);
         for (long long t = 0; t < p.T; ++t) {
             if (WIDE) workgroup_handoff();   // (the steppers may now overwrite the single buffer: the writers are done with t - 1)
             workgroup_handoff();
             const int buf = WIDE ? 0 : (int)(t & 1);
             const unsigned char *cbuf = codes0 + (size_t)buf * G * p.grp_code_bytes;
-            // writer wave -> (agent, part of the group's envs): one agent after the other while there are at most as many
-            // waves as agents, else W / K waves per agent, each with its own contiguous part of the run
-            const int parts = W > K ? W / K : 1, part = W > K ? w / K : 0;
-            const int g0 = part * G / parts, g1 = min((part + 1) * G / parts, nG);
-            for (int a = W > K ? w % K : w; a < K && part < parts; a += W > K ? K : W) {
-                grp_gfloat *const run = (grp_gfloat *)uniform64((long long)(p.obs + ((t * K + a) * p.N + env0) * p.obs_elems));
-                const u32 sh = 3u * (u32)a;
-                for (int g = g0; g < g1; ++g) {
-                    const CT *cg = (const CT *)(cbuf + (size_t)g * p.grp_code_bytes);
-                    grp_emit_cells<CT>(run + g * 3 * C, cg, tab, sh, C, lane, stores);
-                }
-            }
             if (w == 0) { // the steppers' per-step outputs: rows (j K + s) of G consecutive envs each
                 const unsigned char *obuf = outs0 + (size_t)buf * G * p.grp_out_bytes;
                 float *of = p.am_f32 + t * 3 * KN;
@@ -2258,15 +2274,31 @@ __global__ __launch_bounds__(64 * (G / EPS + W)) __attribute__((amdgpu_waves_per
                 }
                 if (lane < nG) p.all_done[t * p.N + env0 + lane] = (obuf + (size_t)lane * p.grp_out_bytes)[16 * K];
             }
+            if (SHARE) {
+                grp_take_items<CT>(p, ctr + buf, cbuf, t, env0, nG, tab, lane, stores);
+            } else {
+                // writer wave -> (agent, part of the group's envs): one agent after the other while there are at most as many
+                // waves as agents, else W / K waves per agent, each with its own contiguous part of the run
+                const int parts = W > K ? W / K : 1, part = W > K ? w / K : 0;
+                const int g0 = part * G / parts, g1 = min((part + 1) * G / parts, nG);
+                for (int a = W > K ? w % K : w; a < K && part < parts; a += W > K ? K : W) {
+                    grp_gfloat *const run = (grp_gfloat *)uniform64((long long)(p.obs + ((t * K + a) * p.N + env0) * p.obs_elems));
+                    for (int g = g0; g < g1; ++g)
+                        grp_emit_cells<CT>(run + g * 3 * C, (const CT *)(cbuf + (size_t)g * p.grp_code_bytes), tab, 3u * (u32)a, C, lane,
+                                           stores);
+                }
+            }
         }
         return;
     }
 
     // ---- a stepper: envs env0 + wave * EPS + e, e < EPS; the scalars of the envs it is not working on wait in LDS
-    if (env0 + wave * EPS >= p.N) { // a ragged last group: nothing to step, but the barriers are the workgroup's
+    if (env0 + wave * EPS >= p.N) { // a ragged last group: nothing to step — the barriers are the workgroup's, and it writes
         for (long long t = 0; t < p.T; ++t) {
             if (WIDE) workgroup_handoff();
             workgroup_handoff();
+            const int buf = WIDE ? 0 : (int)(t & 1);
+            if (SHARE) grp_take_items<CT>(p, ctr + buf, codes0 + (size_t)buf * G * p.grp_code_bytes, t, env0, nG, tab, lane, stores);
         }
         return;
     }
@@ -2323,8 +2355,14 @@ __global__ __launch_bounds__(64 * (G / EPS + W)) __attribute__((amdgpu_waves_per
             if (WURM_PROBE(!(p.grp_variant & 8), true)) multi_step_body(cx, p, env, env_id, call, a, sn, r, t * p.N * C, t * KN, t * p.N);
             // buffer t & 1 is free: the writers finished with it before they arrived at the barrier of step t - 1
             // (WIDE: the one buffer is free once the writers have passed the extra barrier of this step)
-            if (WIDE && e == 0) workgroup_handoff();
+            if (WIDE && e == 0) {
+                // this wave's transition is done: the rest of step t - 1's observations, with the writers — then the one
+                // buffer is free for this step's codes
+                if (SHARE && t > 0) grp_take_items<CT>(p, ctr, codes0, t - 1, env0, nG, tab, lane, stores);
+                workgroup_handoff();
+            }
             const int buf = WIDE ? 0 : (int)(t & 1);
+            if (SHARE && e == 0 && wave == 0 && lane == 0) ctr[buf] = 0; // (everybody is done with the items this counter handed out last)
             unsigned char *obuf = outs0 + ((size_t)buf * G + g) * p.grp_out_bytes;
             if (snake) {
                 float *f = (float *)obuf;
@@ -2342,6 +2380,11 @@ __global__ __launch_bounds__(64 * (G / EPS + W)) __attribute__((amdgpu_waves_per
             if (lane == 0) ((int *)(save0 + g * 8 * K))[7] = (int)r.all_done;   // (slot 7 of snake 0: for the reset below)
             grp_save(save0 + g * 8 * K, lane, K, sn, col_dirty, hc0);
             wave_lds_sync();
+        }
+        // (two buffers: the codes of step t are in place — the rest of step t - 1's observations, with the writers)
+        if (SHARE && !WIDE && t > 0) {
+            const int pb = (int)((t - 1) & 1);
+            grp_take_items<CT>(p, ctr + pb, codes0 + (size_t)pb * G * p.grp_code_bytes, t - 1, env0, nG, tab, lane, stores);
         }
         // the writers start on step t NOW: the reset that follows the step (a rebuilt env costs as much as a whole
         // transition) runs beside them, not in front of them
@@ -2582,10 +2625,13 @@ static int multi_launch(MKind kind, MultiArgs &p, void *stream)
             {2, 10, 1, 4, (const void *)multi_rollout_group_kernel<2, 10, 1, 4, true>},
         };
         static const Shape shapes[] = {
-            // (automatic: the first that fits.  Measured at cfg4, 64-step launches, same box: 8416 1.61 ms, 8424 1.79, 4414 1.81;
-            // the two-wave kernel of round 3: 2.05 — profiles/r04_multi_group_sweep.txt)
-            {8, 4, 1, 6, (const void *)multi_rollout_group_kernel<8, 4, 1, 6>}, {4, 4, 1, 4, (const void *)multi_rollout_group_kernel<4, 4, 1, 4>},
-            {8, 4, 2, 4, (const void *)multi_rollout_group_kernel<8, 4, 2, 4>}, {8, 2, 1, 5, (const void *)multi_rollout_group_kernel<8, 2, 1, 5>},
+            // (automatic: the first that fits.  Measured at cfg4 on four boxes, ms per 16- / 64-step launch: 8 / 2 / 1 / 5 — two
+            // writers, the steppers sharing their work, 5 waves per SIMD at 96 VGPRs — 0.484-0.486 / 1.62-1.65 on every box;
+            // 8 / 4 / 1 / 6 — a writer per agent, 6 waves per SIMD at 80 VGPRs with 130 bytes of scratch — 0.44-0.51 / 1.57-1.81
+            // depending on the box and on how the allocator spills; 4 / 4 / 1 / 4: 0.51 / 1.66; 8 / 4 / 2 / 4: 1.79 per 64;
+            // the two-wave kernel of round 3: 0.55 / 1.73-2.15 — profiles/r04_multi_group_probe.txt)
+            {8, 2, 1, 5, (const void *)multi_rollout_group_kernel<8, 2, 1, 5>}, {8, 4, 1, 6, (const void *)multi_rollout_group_kernel<8, 4, 1, 6>},
+            {4, 4, 1, 4, (const void *)multi_rollout_group_kernel<4, 4, 1, 4>}, {8, 4, 2, 4, (const void *)multi_rollout_group_kernel<8, 4, 2, 4>},
         };
         const Shape *sh = nullptr;
         for (const Shape &c : wide_shapes) {
