@@ -62,7 +62,8 @@ detail = {
     'rollout_cfg5_8192x36_default_chunk16': traffic('void wurm::(anonymous namespace)::grid_rollout_kernel<true>', 524288),
     # round 4: G envs per workgroup (multi_rollout_group_kernel): cfg4 512 workgroups of 8 steppers + 4 writers, the speeds.py
     # shape 1024 workgroups of 4 + 10
-    'multi_rollout_cfg4_4096x25_k4_full_chunk16': traffic('void wurm::multi_rollout_group_kernel<8, 4, 1, 6, false>', 393216),
+    'multi_rollout_cfg4_4096x25_k4_full_chunk16': traffic('void wurm::multi_rollout_group_kernel<8, 2, 1, 5, false>', 327680) or
+                                                  traffic('void wurm::multi_rollout_group_kernel<8, 4, 1, 6, false>', 393216),
     'multi_rollout_speeds_4096x36_k10_chunk4': traffic('void wurm::multi_rollout_group_kernel<4, 10, 1, 4, true>', 917504),
     # round 4: one_channel / default of 65 536 x 9 x 9 through the lane kernels (bit planes): rollout, and per call (reference form)
     'rollout_65536x9_one_channel_chunk32': traffic('void wurm::lane_rollout_kernel<32, -2, false>', 131072),
