@@ -2118,13 +2118,14 @@ __device__ __forceinline__ void grp_emit_cells_chunk(grp_gfloat *blk, const CT *
         g[u] = grp_tab(tab + 8, off[u]);
         b[u] = grp_tab(tab + 16, off[u]);
     }
+    typedef __attribute__((address_space(1))) char gchar;
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-        const int c = c0 + 64 * u;
-        if (c < C && stores) {
-            blk[c] = r[u];
-            blk[C + c] = g[u];
-            blk[2 * C + c] = b[u];
+    for (int u = 0; u < U; ++u) { // (unsigned 32-bit BYTE offsets off the uniform block pointer: global_store with an SGPR base)
+        const u32 c = (u32)(c0 + 64 * u), o = 4u * c, pl = 4u * (u32)C;
+        if (c < (u32)C && stores) {
+            *(grp_gfloat *)((gchar *)blk + o) = r[u];
+            *(grp_gfloat *)((gchar *)blk + (o + pl)) = g[u];
+            *(grp_gfloat *)((gchar *)blk + (o + 2u * pl)) = b[u];
         }
     }
 }
