@@ -128,7 +128,7 @@ def fuzz_resident(rng):
     S = int(rng.choice([9, 9, 9, 12, 14, 20, 25, 36]))
     if S == 9:    # lane_resident.hpp: 32 bytes per env
         N = int(rng.choice([1, 3, 15, 16, 17, 31, 33, 63, 64, 65, 100, 129, 200, 257]))
-        mode = 'partial_2' if rng.rand() < 0.8 else 'none'
+        mode = ['partial_2', 'partial_2', 'none', 'one_channel', 'one_channel', 'default', 'positions', 'partial_0', 'partial_1'][rng.randint(9)]
     else:         # grid_rollout.hip: the clock grid + a record per env, every observation mode
         N = int(rng.randint(1, 24))
         mode = ['default', 'raw', 'one_channel', 'positions', f'partial_{rng.randint(1, 7)}', 'none'][rng.randint(6)]
@@ -227,7 +227,10 @@ def fuzz_lane(rng):
     hand-edited states between launches (they must fall back to the generic path inside the launch)."""
     epw = int(rng.choice([4, 8, 16, 32, 64]))
     N = int(rng.choice([1, 3, epw - 1, epw, epw + 1, 2 * epw + 5, 3 * epw, 200]))
-    mode = ['partial_2', 'partial_2', 'partial_2', 'none'][rng.randint(4)]
+    # (round 4: one_channel / default through bit planes, positions / partial_0 / partial_1 float by float; partial_3 is routed
+    # to the one-env-per-wave kernels inside the same entry point)
+    mode = ['partial_2', 'partial_2', 'none', 'one_channel', 'one_channel', 'default', 'default', 'positions', 'partial_0',
+            'partial_1', 'partial_3'][rng.randint(11)]
     seed, off = int(rng.randint(1 << 30)), int(rng.randint(1 << 40))
     desc = f'lane epw={epw} N={N} mode={mode} seed={seed} off={off}'
     if os.environ.get('WURM_FUZZ_VERBOSE'):
@@ -443,10 +446,63 @@ def fuzz_multi_resident(rng):
     return desc
 
 
+def fuzz_multi_group(rng):
+    """wurm_multi_rollout through multi_rollout_group_kernel (round 4: G envs per workgroup, per-agent class codes, work
+    sharing; 6 .. 10 snakes: 32-bit codes, one buffer) in every compiled shape, and wurm_multi_step_reset with the grouped
+    writer of the per-call kernel: 'full' observations, random K / S / N / T and dynamics, chained launches."""
+    K = int(rng.choice([1, 2, 3, 4, 4, 5, 6, 8, 10]))
+    S = int(rng.choice([8, 10, 12, 14, 18, 25, 27, 30, 36]))
+    while 2 * K * S * S + 8 * S * S > 60000:
+        S -= 4
+    N = int(rng.choice([1, 3, 7, 8, 9, 15, 16, 17, 33])) if S <= 18 else int(rng.randint(1, 12))
+    cfg = dict(boost=bool(rng.rand() < 0.8), food_on_death_prob=float(rng.choice([0.0, 0.2, 0.5, 0.9, 1.0])),
+               boost_cost_prob=float(rng.choice([0.0, 0.25, 0.5, 1.0])), food_mode=['only_one', 'random_rate'][rng.randint(2)],
+               food_rate=float(rng.choice([5e-4, 5e-3, 5e-2])), reward_on_death=float(rng.choice([-1, -2, 0])),
+               respawn_mode=['all', 'any'][rng.randint(2)], colour_mode=['random', 'fixed'][rng.randint(2)])
+    shape = int(rng.choice([0, 8215, 8416, 4414, 8424])) if K <= 5 else int(rng.choice([0, 5014, 4514, 3014]))
+    seed, off = int(rng.randint(1 << 30)), int(rng.randint(1 << 20))
+    desc = f'multi_group S={S} K={K} N={N} shape={shape} seed={seed} off={off} cfg={cfg}'
+    if os.environ.get('WURM_FUZZ_VERBOSE'):
+        print('start:', desc, flush=True)
+    o, h = OracleBackend(seed, off), HipBackend(seed, off)
+    so, sh = _o.multi_empty_state(N, K, S), _o.multi_empty_state(N, K, S)
+    so['colours'][...] = o.multi_colours(N, K, cfg['colour_mode'] == 'fixed', call=0)
+    sh['colours'][...] = so['colours']
+    o._next(); h._next()
+    fo, fh = o.multi_reset(so, np.ones(N), cfg), h.multi_reset(sh, np.ones(N), cfg)
+    assert fo == fh, f'{desc}: spawn failures {fo} vs {fh}'
+    old = {'WURM_MULTI_GROUP_MIN_ENVS': _lib.set_option('WURM_MULTI_GROUP_MIN_ENVS', 0),
+           'WURM_MULTI_GROUP_SHAPE': _lib.set_option('WURM_MULTI_GROUP_SHAPE', shape)}
+    try:
+        for launch in range(int(rng.randint(1, 4))):
+            T = int(rng.choice([1, 2, 5, 16, 30, 63, 64, 65, 100]) if S <= 18 else rng.choice([1, 2, 9, 20]))
+            a = rng.randint(0, 8, (T, K, N)).astype(np.int64)
+            ro, rh = o.multi_rollout(so, a, cfg, 'full'), h.multi_rollout(sh, a, cfg, 'full')
+            for k in ro:
+                same(ro[k], rh[k], f'{desc} launch {launch} T={T} {k}')
+            for k in so:
+                same(so[k], sh[k], f'{desc} launch {launch} state {k}')
+            if rng.rand() < 0.5:   # a few per-call iterations in between (the grouped writer of multi_step_kernel)
+                for t in range(int(rng.randint(1, 6))):
+                    at = rng.randint(0, 8, (K, N)).astype(np.int64)
+                    po, ph = o.multi_step(so, at, cfg, 'full'), h.multi_step(sh, at, cfg, 'full')
+                    for k in po:
+                        same(po[k], ph[k], f'{desc} per call {k} t={t}')
+                    o.multi_reset(so, po['all_done'], cfg, mode='full'); h.multi_reset(sh, ph['all_done'], cfg, mode='full')
+                    same(o.last_reset_obs, h.last_reset_obs, f'{desc} per call reset obs t={t}')
+                    for k in so:
+                        same(so[k], sh[k], f'{desc} per call state {k} t={t}')
+    finally:
+        for k, v in old.items():
+            _lib.set_option(k, v)
+    return desc
+
+
 FAMILIES = {'single': fuzz_single, 'fused': fuzz_fused, 'resident': fuzz_resident, 'lean': fuzz_lean, 'lane': fuzz_lane,
-            'policy': fuzz_policy, 'grid': fuzz_grid, 'multi': fuzz_multi, 'multi_resident': fuzz_multi_resident}
-WEIGHTS = {'single': 0.13, 'fused': 0.13, 'resident': 0.13, 'lean': 0.07, 'lane': 0.13, 'policy': 0.03, 'grid': 0.04,
-           'multi': 0.2, 'multi_resident': 0.14}
+            'policy': fuzz_policy, 'grid': fuzz_grid, 'multi': fuzz_multi, 'multi_resident': fuzz_multi_resident,
+            'multi_group': fuzz_multi_group}
+WEIGHTS = {'single': 0.1, 'fused': 0.1, 'resident': 0.14, 'lean': 0.05, 'lane': 0.16, 'policy': 0.03, 'grid': 0.04,
+           'multi': 0.12, 'multi_resident': 0.1, 'multi_group': 0.16}
 
 
 def library_sha256():
