@@ -70,6 +70,12 @@ int wurm_reset_option(const char *name);
  * the loop iterations to report launches per `step(a); reset(done)` iteration). */
 int64_t wurm_launch_count(void);
 
+/* Name of the row of the dispatch table (wurm_amd/csrc/single_snake.hip: route_of) that served the last SingleSnake /
+ * SimpleGridworld launch of this process: "generic", "grid_step", "lane_step", "lane_resident", "grid_rollout",
+ * "lane_rollout", "rollout_s9", "rollout_s9_injected", "rollout_lean", "rollout_generic_partial", "rollout_generic_none".
+ * Diagnostic only (bench.py and tests/test_dispatch_table.py name a launch by it); a static string. */
+const char *wurm_single_last_route(void);
+
 /* Number of fp32 elements one env's observation occupies (0 = invalid mode for that env family). */
 int64_t wurm_single_obs_elems(int obs_mode, int obs_n, int size);
 int64_t wurm_grid_obs_elems(int obs_mode, int obs_n, int size);

@@ -1632,87 +1632,121 @@ static int pick_cpl(int S)
     return -1;
 }
 
+// ---- which kernel serves a call.  ONE table (route_of), read top to bottom: the first row whose condition holds wins.
+//   kind             | condition                                                                    | route
+//   step / fused     | snake, S >= 12, grid_step_eligible, (N S^2 >= grid_step_min_cells or a mirror) | R_GRID_STEP   grid_rollout.hip (+ generic for the rest)
+//   step / fused     | snake, S <= 11, N >= lane_step_min_envs, lane_step_eligible                    | R_LANE_STEP   lane_step.hpp
+//   step/reset/observe/fused | otherwise                                                              | R_GENERIC     one env per wave
+//   rollout          | snake, S >= 12, grid_rollout_eligible                                          | R_GRID_ROLLOUT
+//   rollout          | snake, S <= 11, N >= lane_rollout_min_envs, lane_rollout_eligible              | R_LANE_ROLLOUT lane_rollout.hpp (9 x 9)
+//   rollout          | snake, S == 9, both inject arrays, partial_n (n <= 3) or none                  | R_S9_INJ      rollout_s9_kernel<., true>
+//   rollout          | snake, S == 9, RNG mode, partial_n (n <= 3) or none                            | R_S9          rollout_s9_kernel
+//   rollout          | snake, S = 10 / 11, RNG mode, partial_n (n <= 3) or none                       | R_LEAN        rollout_lean_kernel
+//   rollout          | snake, S <= 11, RNG mode, partial_n (n <= 6) / none                            | R_GENERIC_PARTIAL / R_GENERIC_NONE (mode as template argument)
+//   rollout          | otherwise                                                                      | R_GENERIC
+// (the resident 9 x 9 step, lane_resident.hpp, is chosen by fused_entry: it needs the caller's mirror)
+enum Route { R_GENERIC, R_GRID_STEP, R_LANE_STEP, R_GRID_ROLLOUT, R_LANE_ROLLOUT, R_S9_INJ, R_S9, R_LEAN, R_GENERIC_PARTIAL, R_GENERIC_NONE, R_LANE_RESIDENT };
+static Route last_route = R_GENERIC; // (wurm_single_last_route: what the tests and bench.py name a launch by)
+
+static const char *route_name(Route r)
+{
+    switch (r) {
+    case R_GRID_STEP: return "grid_step";
+    case R_LANE_STEP: return "lane_step";
+    case R_GRID_ROLLOUT: return "grid_rollout";
+    case R_LANE_ROLLOUT: return "lane_rollout";
+    case R_S9_INJ: return "rollout_s9_injected";
+    case R_S9: return "rollout_s9";
+    case R_LEAN: return "rollout_lean";
+    case R_GENERIC_PARTIAL: return "rollout_generic_partial";
+    case R_GENERIC_NONE: return "rollout_generic_none";
+    case R_LANE_RESIDENT: return "lane_resident";
+    default: return "generic";
+    }
+}
+
+static Route route_of(Kind kind, bool snake, int cpl, const StepArgs &p)
+{
+    const bool stepish = kind == K_STEP || kind == K_FUSED;
+    if (snake && cpl >= 4 && stepish && grid_step_eligible(p) &&
+        (p.N * (long long)p.S * p.S >= opt.grid_step_min_cells || p.resident != nullptr)) return R_GRID_STEP;
+    if (snake && cpl == 2 && stepish && p.N >= opt.lane_step_min_envs && lane_step_eligible(p)) return R_LANE_STEP;
+    if (kind != K_ROLLOUT || !snake) return R_GENERIC;
+    if (cpl >= 4) return grid_rollout_eligible(p) ? R_GRID_ROLLOUT : R_GENERIC;
+    if (p.N >= opt.lane_rollout_min_envs && lane_rollout_eligible(p)) return R_LANE_ROLLOUT;
+    const bool rng_mode = p.inject_food == nullptr && p.inject_reset == nullptr;
+    const bool injected = p.inject_food != nullptr && p.inject_reset != nullptr;
+    const bool small_crop_or_none = (p.obs_mode == WURM_OBS_PARTIAL && p.obs_n <= 3) || p.obs_mode == WURM_OBS_NONE;
+    if (injected && p.S == 9 && small_crop_or_none) return R_S9_INJ;
+    if (rng_mode && p.S == 9 && small_crop_or_none) return R_S9;
+    if (rng_mode && p.S > 9 && small_crop_or_none) return R_LEAN;
+    if (rng_mode && p.obs_mode == WURM_OBS_PARTIAL && p.obs_n <= 6) return R_GENERIC_PARTIAL;
+    if (rng_mode && p.obs_mode == WURM_OBS_NONE) return R_GENERIC_NONE;
+    return R_GENERIC;
+}
+
 template <int CPL, bool SNAKE>
 static hipError_t launch_one(Kind kind, const StepArgs &p, dim3 grid, dim3 block, size_t lds, hipStream_t st)
 {
     (void)hipGetLastError(); // drop any stale error left by earlier runtime calls of this thread
-    if constexpr (SNAKE && CPL >= 4) {
-        // large batches of large grids: the LDS clock-grid step (grid_rollout.hip: 16-byte loads, 34 VGPRs), then the
-        // generic kernel for the envs it could not take.  Small batches stay on one launch: they are latency-bound.
-        const long long min_cells = opt.grid_step_min_cells; // (tests force the path with WURM_GRID_STEP_MIN_CELLS = 0)
-        if ((kind == K_STEP || kind == K_FUSED) && grid_step_eligible(p) &&
-            (p.N * (long long)p.S * p.S >= min_cells || p.resident != nullptr)) { // (a mirror is kept by this kernel only)
+    const Route route = route_of(kind, SNAKE, CPL, p);
+    last_route = route;
+    StepArgs q = p;
+    q.only_flagged = 1; // (the generic kernel behind a grid kernel: only the envs that one could not take)
+    switch (route) {
+    case R_GRID_STEP:
+        if constexpr (SNAKE && CPL >= 4) {
             hipError_t err = launch_grid_step(p, st);
             if (err != hipSuccess) return err;
-            StepArgs q = p;
-            q.only_flagged = 1;
             if (kind == K_STEP) WURM_LAUNCH((step_kernel<CPL, SNAKE>), grid, block, lds, st, q);
             else WURM_LAUNCH((fused_step_kernel<CPL, SNAKE>), grid, block, lds, st, q);
-            return hipGetLastError();
         }
-    }
-    if constexpr (SNAKE && CPL == 2) {
-        // large batches of small grids: one env per LANE (lane_step.hpp); envs outside its domain are stepped by the
-        // one-env-per-wave code inside the same launch
-        const long long min_envs = opt.lane_step_min_envs; // (tests force the path with WURM_LANE_STEP_MIN_ENVS = 0)
-        if ((kind == K_STEP || kind == K_FUSED) && p.N >= min_envs && lane_step_eligible(p))
-            return launch_lane_step(p, st);
-    }
-    switch (kind) {
-    case K_STEP: WURM_LAUNCH((step_kernel<CPL, SNAKE>), grid, block, lds, st, p); break;
-    case K_RESET: WURM_LAUNCH((reset_kernel<CPL, SNAKE>), grid, block, lds, st, p); break;
-    case K_OBSERVE: WURM_LAUNCH((observe_kernel<CPL, SNAKE>), grid, block, lds, st, p); break;
-    case K_FUSED: WURM_LAUNCH((fused_step_kernel<CPL, SNAKE>), grid, block, lds, st, p); break;
-    case K_ROLLOUT:
+        break;
+    case R_LANE_STEP:
+        if constexpr (SNAKE && CPL == 2) return launch_lane_step(p, st);
+        break;
+    case R_GRID_ROLLOUT:
         if constexpr (SNAKE && CPL >= 4) {
-            if (grid_rollout_eligible(p)) {
-                // LDS-resident clock grid (grid_rollout.hip); then the generic kernel for the envs it could not take
-                hipError_t err = launch_grid_rollout(p, st);
-                if (err != hipSuccess) return err;
-                StepArgs q = p;
-                q.only_flagged = 1;
-                WURM_LAUNCH((rollout_kernel<CPL, SNAKE>), grid, block, lds, st, q);
-                break;
-            }
+            hipError_t err = launch_grid_rollout(p, st);
+            if (err != hipSuccess) return err;
+            WURM_LAUNCH((rollout_kernel<CPL, SNAKE>), grid, block, lds, st, q);
         }
+        break;
+    case R_LANE_ROLLOUT:
+        if constexpr (SNAKE && CPL == 2) return launch_lane_rollout(p, st);
+        break;
+    case R_S9_INJ:
         if constexpr (SNAKE && CPL == 2) {
-            // large batches of 9 x 9: one env per LANE (lane_rollout.hpp); envs outside its domain are rolled out by the
-            // one-env-per-wave code inside the same launch
-            // (the tests switch the threshold with wurm_set_option("WURM_LANE_ROLLOUT_MIN_ENVS", ..))
-            if (p.N >= opt.lane_rollout_min_envs && lane_rollout_eligible(p)) return launch_lane_rollout(p, st);
-            const bool rng_mode = p.inject_food == nullptr && p.inject_reset == nullptr;
-            if (p.inject_food != nullptr && p.inject_reset != nullptr && p.S == 9 &&
-                ((p.obs_mode == WURM_OBS_PARTIAL && p.obs_n <= 3) || p.obs_mode == WURM_OBS_NONE)) {
-                // recorded outcomes through the headline kernel itself
-                if (p.obs_mode == WURM_OBS_NONE)
-                    WURM_LAUNCH((rollout_s9_kernel<WURM_OBS_NONE, true>), grid, block, lds, st, p);
-                else
-                    WURM_LAUNCH((rollout_s9_kernel<WURM_OBS_PARTIAL, true>), grid, block, lds, st, p);
-                break;
-            }
-            if (rng_mode && p.S >= 9 && ((p.obs_mode == WURM_OBS_PARTIAL && p.obs_n <= 3) || p.obs_mode == WURM_OBS_NONE)) {
-                if (p.S == 9 && p.obs_mode == WURM_OBS_NONE)
-                    WURM_LAUNCH((rollout_s9_kernel<WURM_OBS_NONE>), grid, block, lds, st, p);
-                else if (p.S == 9)
-                    WURM_LAUNCH((rollout_s9_kernel<WURM_OBS_PARTIAL>), grid, block, lds, st, p);
-                else if (p.obs_mode == WURM_OBS_NONE)
-                    WURM_LAUNCH((rollout_lean_kernel<WURM_OBS_NONE, false>), grid, block, lds, st, p);
-                else if (p.S <= 9)
-                    WURM_LAUNCH((rollout_lean_kernel<WURM_OBS_PARTIAL, true>), grid, block, lds, st, p);
-                else
-                    WURM_LAUNCH((rollout_lean_kernel<WURM_OBS_PARTIAL, false>), grid, block, lds, st, p);
-                break;
-            }
-            if (rng_mode && p.obs_mode == WURM_OBS_PARTIAL && p.obs_n <= 6) {
-                WURM_LAUNCH((rollout_kernel<CPL, SNAKE, WURM_OBS_PARTIAL, false>), grid, block, lds, st, p);
-                break;
-            }
-            if (rng_mode && p.obs_mode == WURM_OBS_NONE) {
-                WURM_LAUNCH((rollout_kernel<CPL, SNAKE, WURM_OBS_NONE, false>), grid, block, lds, st, p);
-                break;
-            }
+            if (p.obs_mode == WURM_OBS_NONE) WURM_LAUNCH((rollout_s9_kernel<WURM_OBS_NONE, true>), grid, block, lds, st, p);
+            else WURM_LAUNCH((rollout_s9_kernel<WURM_OBS_PARTIAL, true>), grid, block, lds, st, p);
         }
-        WURM_LAUNCH((rollout_kernel<CPL, SNAKE>), grid, block, lds, st, p);
+        break;
+    case R_S9:
+        if constexpr (SNAKE && CPL == 2) {
+            if (p.obs_mode == WURM_OBS_NONE) WURM_LAUNCH((rollout_s9_kernel<WURM_OBS_NONE>), grid, block, lds, st, p);
+            else WURM_LAUNCH((rollout_s9_kernel<WURM_OBS_PARTIAL>), grid, block, lds, st, p);
+        }
+        break;
+    case R_LEAN:
+        if constexpr (SNAKE && CPL == 2) {
+            if (p.obs_mode == WURM_OBS_NONE) WURM_LAUNCH((rollout_lean_kernel<WURM_OBS_NONE, false>), grid, block, lds, st, p);
+            else WURM_LAUNCH((rollout_lean_kernel<WURM_OBS_PARTIAL, false>), grid, block, lds, st, p);
+        }
+        break;
+    case R_GENERIC_PARTIAL:
+        if constexpr (SNAKE && CPL == 2) WURM_LAUNCH((rollout_kernel<CPL, SNAKE, WURM_OBS_PARTIAL, false>), grid, block, lds, st, p);
+        break;
+    case R_GENERIC_NONE:
+        if constexpr (SNAKE && CPL == 2) WURM_LAUNCH((rollout_kernel<CPL, SNAKE, WURM_OBS_NONE, false>), grid, block, lds, st, p);
+        break;
+    case R_GENERIC:
+        switch (kind) {
+        case K_STEP: WURM_LAUNCH((step_kernel<CPL, SNAKE>), grid, block, lds, st, p); break;
+        case K_RESET: WURM_LAUNCH((reset_kernel<CPL, SNAKE>), grid, block, lds, st, p); break;
+        case K_OBSERVE: WURM_LAUNCH((observe_kernel<CPL, SNAKE>), grid, block, lds, st, p); break;
+        case K_FUSED: WURM_LAUNCH((fused_step_kernel<CPL, SNAKE>), grid, block, lds, st, p); break;
+        case K_ROLLOUT: WURM_LAUNCH((rollout_kernel<CPL, SNAKE>), grid, block, lds, st, p); break;
+        }
         break;
     }
     return hipGetLastError();
@@ -1778,6 +1812,7 @@ using namespace wurm;
 extern "C" {
 
 const char *wurm_version(void) { return "wurm_hip 0.1 gfx950"; }
+const char *wurm_single_last_route(void) { return route_name(last_route); }
 
 int64_t wurm_single_obs_elems(int obs_mode, int obs_n, int size) { return obs_elems(true, obs_mode, obs_n, size); }
 int64_t wurm_grid_obs_elems(int obs_mode, int obs_n, int size) { return obs_elems(false, obs_mode, obs_n, size); }
@@ -1882,6 +1917,7 @@ static int fused_entry(bool snake, const wurm_single_call *c, void *stream, int 
             if (launch_lane_resident(p, c->resident, c->resident_valid != 0, c->resident_lazy != 0, c->check_mask,
                                      (hipStream_t)stream) != hipSuccess)
                 return WURM_ERR_HIP;
+            last_route = R_LANE_RESIDENT;
             if (mirror_state) *mirror_state = 1;
             return WURM_OK;
         }
