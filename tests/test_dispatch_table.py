@@ -116,7 +116,7 @@ def test_reset_and_observe_are_generic(hip):
 def test_gridworld_is_generic(hip):
     h = hip(seed=1)
     envs = np.zeros((16, 2, 9, 9), np.float32)
-    h.grid_reset(envs, np.ones(16, np.uint8), None, 'default')
+    h.grid_reset(envs, np.ones(16, np.uint8), (4, 4), 'default')
     h.grid_step(envs, np.zeros(16, np.int64), 'default')
     assert _route() == 'generic'
 
