@@ -128,17 +128,18 @@ def test_paint_order_on_hand_made_states(hip):
     del st0
 
 
-def test_per_call_parity_suites_with_the_grouped_writer():
-    """multi_step_kernel with `grp_emit` (the workgroup's waves write the 'full' observations together): the MultiSnake
-    per-call suites — oracle loops, fused step / reset, resident mirror, reference fixtures, KATs — in a child process
-    with WURM_MULTI_GROUP_MIN_ENVS=0, which turns it on for every batch size"""
+@pytest.mark.parametrize('wpb', ['-1', '8'])   # automatic (every wave its own env's views) / eight envs per workgroup, shared runs
+def test_per_call_parity_suites_with_the_grouped_writer(wpb):
+    """multi_step_kernel with `grp_emit` ('full' observations through class codes and the colour table, per wave or by the
+    workgroup's waves together): the MultiSnake per-call suites — oracle loops, fused step / reset, resident mirror,
+    reference fixtures, KATs — in a child process with WURM_MULTI_GROUP_MIN_ENVS=0, which turns it on for every batch size"""
     import os
     import subprocess
     import sys
     if os.environ.get('WURM_MULTI_GROUP_MIN_ENVS') == '0':
         pytest.skip('already inside the forced run')
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, WURM_MULTI_GROUP_MIN_ENVS='0')
+    env = dict(os.environ, WURM_MULTI_GROUP_MIN_ENVS='0', WURM_MULTI_GROUP_STEP_WPB=wpb)
     r = subprocess.run([sys.executable, '-m', 'pytest', '-q', '-m', 'gpu', '-x', 'tests/test_hip_multi_vs_oracle.py',
                         'tests/test_hip_multi_fused.py', 'tests/test_multi_resident.py', 'tests/test_kat_multi_snake.py',
                         'tests/test_hip_golden.py', '-k', 'not larger_than_64kb'],

@@ -15,7 +15,8 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 ap = argparse.ArgumentParser()
-ap.add_argument('--kernel', default='resident', choices=['resident', 'lane_step'])
+ap.add_argument('--kernel', default='resident', choices=['resident', 'lane_step', 'grid'])
+ap.add_argument('--size', type=int, default=36, help='--kernel grid: the grid size (cfg5: 8192 envs of 36 x 36, default observation)')
 ap.add_argument('--envs', type=int, default=65536)
 ap.add_argument('--epw', type=int, default=0)
 ap.add_argument('--form', default='ref', choices=['ref', 'noobs'])
@@ -24,7 +25,11 @@ args = ap.parse_args()
 if 'timeline' not in os.environ.get('WURM_HIP_LIBRARY', ''):
     sys.exit('set WURM_HIP_LIBRARY to the instrumented library (see the docstring)')
 N = args.envs
-if args.kernel == 'resident':
+if args.kernel == 'grid':
+    os.environ['WURM_GRID_STEP_MIN_CELLS'] = '0'
+    names = ['entry', 'grid in LDS', 'action', 'stepped', 'outputs', 'obs issued', 'state stored', 'drained']
+    epw = 1
+elif args.kernel == 'resident':
     os.environ['WURM_RESIDENT_MIN_ENVS'] = '0'
     nw = 2 if args.form == 'ref' else 1
     epw = args.epw or (64 // nw if N >= 32768 else (32 // nw if N >= 8192 else 16))
@@ -40,7 +45,9 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 from wurm_amd.envs import SingleSnake  # noqa: E402
 
-env = SingleSnake(num_envs=N, size=9, observation_mode='partial_2', device='cuda', seed=0)
+S_, mode_ = (args.size, 'default') if args.kernel == 'grid' else (9, 'partial_2')
+E_ = 3 * S_ * S_ if args.kernel == 'grid' else 75
+env = SingleSnake(num_envs=N, size=S_, observation_mode=mode_, device='cuda', seed=0)
 g = torch.Generator(device='cuda').manual_seed(1)
 nw_ = N // epw
 segs, life = [], []
@@ -51,7 +58,7 @@ for it in range(args.iters):
     torch.cuda.synchronize()
     if it < 4:
         continue
-    st = obs.detach().reshape(-1)[:nw_ * epw * 75].reshape(nw_, epw * 75)[:, :16].contiguous().view(torch.int64)
+    st = obs.detach().reshape(-1)[:nw_ * epw * E_].reshape(nw_, epw * E_)[:, :16].contiguous().view(torch.int64)
     st = st.cpu().numpy().astype(np.int64)
     ok = (st[:, 7] > st[:, 0]) & (st[:, 7] - st[:, 0] < 10 ** 7)
     st = st[ok]

@@ -453,13 +453,43 @@ __device__ __forceinline__ void mirror_store_rec(const Grid &g, int *rec, const 
     if (lane < MR_INTS) rec[lane] = v;
 }
 // returns the flags; s and head_body from the record
-__device__ __forceinline__ int mirror_load_rec(const Grid &g, const int *rec, Snk &s, int &head_body)
+// (v: the lane's word of the record, lanes 0 .. MR_INTS - 1)
+__device__ __forceinline__ int mirror_parse_rec(int v, Snk &s, int &head_body)
 {
-    const int v = g.lane < MR_INTS ? rec[g.lane] : 0;
     s.hc = lane_value(v, 0); s.hy = lane_value(v, 1); s.hx = lane_value(v, 2); s.L = lane_value(v, 3);
     s.o = lane_value(v, 4); s.food = lane_value(v, 5); s.G = lane_value(v, 6); s.T = lane_value(v, 7);
     head_body = lane_value(v, 8);
     return lane_value(v, 9);
+}
+
+__device__ __forceinline__ int mirror_load_rec(const Grid &g, const int *rec, Snk &s, int &head_body)
+{
+    return mirror_parse_rec(g.lane < MR_INTS ? rec[g.lane] : 0, s, head_body);
+}
+
+// mirror_load_grid in two halves: the loads of the first eight rows of 256 cells are REQUESTED (grid_step_kernel asks for
+// everything it will need in one go — its record, its action, its grid — instead of one memory round trip after the other),
+// later they are written to LDS (and the rows beyond the eighth, S > 45, fetched the plain way)
+__device__ __forceinline__ void mirror_grid_request(const Grid &g, const cell_t *src, uint2 (&v)[8])
+{
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = *(const uint2 *)(src + min(j, g.iters - 1) * 256 + 4 * g.lane);
+}
+
+__device__ __forceinline__ void mirror_grid_commit(const Grid &g, const cell_t *src, const uint2 (&v)[8])
+{
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        if (j < g.iters) *(uint2 *)(g.ex + j * 256 + 4 * g.lane) = v[j];
+    for (int it0 = 8; it0 < g.iters; it0 += 8) {
+        uint2 w[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) w[j] = *(const uint2 *)(src + min(it0 + j, g.iters - 1) * 256 + 4 * g.lane);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (it0 + j < g.iters) *(uint2 *)(g.ex + (it0 + j) * 256 + 4 * g.lane) = w[j];
+    }
+    wave_lds_sync();
 }
 
 template <bool VEC>
@@ -576,26 +606,39 @@ __global__ __launch_bounds__(256) void grid_step_kernel(StepArgs p)
     float *envp = p.envs + env * 3 * C;
     const u64 env_id = (u64)(p.env_offset + env);
     Snk s;
-    const bool pre = p.done_in != nullptr && uniform((int)p.done_in[env]) != 0;
+    WURM_TL_DECL;
+    WURM_TL(0); // entry
     const bool mirrored = p.resident != nullptr;
     const bool lazy = mirrored && p.resident_lazy != 0;
     cell_t *mgrid = mirrored ? mirror_grid(p, g, env) : nullptr;
     int *mrec = mirrored ? mirror_rec(p, g, env) : nullptr;
+    // everything the step reads before it can start, requested in one go: "was this env finished by the last call", its
+    // record in the mirror, its action, its grid (speculatively: a finished env does not use it).  One after the other they
+    // were four dependent memory round trips at the head of a 32 us launch.
+    const bool from_mirror = mirrored && p.resident_valid != 0;
+    const int pre_byte = p.done_in != nullptr ? (int)p.done_in[env] : 0;
+    const int rec_word = (from_mirror && lane < MR_INTS) ? mrec[lane] : 0;
+    const long long a_word = load_action(p.actions, p.act_dtype, env);
+    const bool inj_f = p.inject_food != nullptr;
+    const int inj_word = inj_f ? p.inject_food[env] : -1;
+    uint2 gv[8];
+    if (from_mirror) mirror_grid_request(g, mgrid, gv);
+    const bool pre = uniform(pre_byte) != 0;
     bool whole = true; // the mirror's grid has to be stored whole (else: the cells this step changed)
     if (pre) {
         grid_clear(g, s);
         grid_reset(g, s, p.seed, p.pre_call, env_id, p.inject_pre_reset ? p.inject_pre_reset + env * 4 : nullptr);
     } else {
         int flags = 0, hb = 0;
-        if (mirrored && p.resident_valid) flags = mirror_load_rec(g, mrec, s, hb);
+        if (from_mirror) flags = mirror_parse_rec(rec_word, s, hb);
         if ((flags & (MR_ACT | MR_TERMINAL)) == MR_ACT) {
-            mirror_load_grid(g, mgrid);
+            mirror_grid_commit(g, mgrid, gv);
             whole = false;
         } else if (flags & MR_ACT) {
             // finished by the last step and not rebuilt: outside the domain.  The generic kernel steps it on envs (second
             // launch) — which the lazy form has not been writing: its last state goes out first
             if (lazy) {
-                mirror_load_grid(g, mgrid);
+                mirror_grid_commit(g, mgrid, gv);
                 grid_observe<VEC>(g, view_of(s, hb), envp, WURM_OBS_RAW, 0);
             }
             if (lane == 0) { mrec[9] = 0; p.done[env] = GRID_SKIPPED; }
@@ -608,12 +651,14 @@ __global__ __launch_bounds__(256) void grid_step_kernel(StepArgs p)
             return;
         }
     }
-    const long long a_in = uniform64(load_action(p.actions, p.act_dtype, env));
-    const bool inj_f = p.inject_food != nullptr;
-    const int inj_cell = inj_f ? uniform(p.inject_food[env]) : -1;
+    WURM_TL(1); // the env's grid is in LDS (or rebuilt)
+    const long long a_in = uniform64(a_word);
+    const int inj_cell = inj_f ? uniform(inj_word) : -1;
     const int food0 = s.food, T0 = s.T;
     StepEv ev;
+    WURM_TL(2); // action loaded
     grid_step(g, s, (a_in >= 0 && a_in < 4) ? (int)a_in : -1, (int)(a_in % 4), inj_f, inj_cell, p.seed, p.call, env_id, ev);
+    WURM_TL(3); // stepped
     const bool done = ev.selfc | ev.edgec;
     const int head_body = s.L + (ev.selfc ? ev.v - s.T : 0);
     if (lane == 0) {
@@ -624,8 +669,10 @@ __global__ __launch_bounds__(256) void grid_step_kernel(StepArgs p)
         p.edgec[env] = (uint8_t)ev.edgec;
         if (p.done_copy) p.done_copy[env] = (uint8_t)done;
     }
+    WURM_TL(4); // outputs stored
     if (p.obs_mode != WURM_OBS_NONE)
         grid_observe<VEC>(g, view_of(s, head_body), p.obs + env * p.obs_elems, p.obs_mode, p.obs_n);
+    WURM_TL(5); // observation issued
 
     // ---- the post-step state back to HBM
     const bool rebuild_after = done && p.post_reset;
@@ -676,6 +723,10 @@ __global__ __launch_bounds__(256) void grid_step_kernel(StepArgs p)
         mirror_store_rec(g, mrec, s, head_body, MR_ACT | (done ? MR_TERMINAL : 0));
         wave_lds_sync();
     }
+    WURM_TL(6); // state / mirror stored; WURM_TL_STORE: drained
+#ifdef WURM_TIMELINE
+    if (!p.post_reset && p.obs_after == nullptr && p.obs_mode != WURM_OBS_NONE) WURM_TL_STORE(p.obs + env * p.obs_elems, lane);
+#endif
     if (!p.post_reset && p.obs_after == nullptr) return;
     if (done) grid_reset(g, s, p.seed, p.call + 1ull, env_id, p.inject_reset ? p.inject_reset + env * 4 : nullptr);
     if (rebuild_after) grid_observe<VEC>(g, view_of(s, s.L), envp, WURM_OBS_RAW, 0);

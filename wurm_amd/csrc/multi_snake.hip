@@ -261,38 +261,62 @@ __host__ __device__ __forceinline__ long long mirror_env_bytes(int K, int C)
 // thread's food bits in load_env's layout (bit k = food at cell tid + nth * k).  hcell / lmax / tclk as load_env leaves
 // them (lmax = the snake's length).
 template <typename Sync>
-__device__ __forceinline__ u64 mirror_load(const Ctx &cx, const unsigned char *__restrict__ m, int tid, int nth, Sync sync)
+__device__ __forceinline__ u64 mirror_load(const Ctx &cx, const unsigned char *__restrict__ m, int tid, int nth, Sync sync,
+                                           bool want_bits = true)
 {
     const int C = cx.C, K = cx.K, nb = mirror_body_bytes(K, C) >> 4, nf = mirror_food_bytes(C) >> 4;
     const uint4 *mb = (const uint4 *)m, *mf = (const uint4 *)(m + mirror_body_bytes(K, C));
     const int *ms = (const int *)(m + mirror_body_bytes(K, C) + mirror_food_bytes(C));
     // (the grids start on 16-byte boundaries in LDS and are followed by padding up to the next one: multi_layout)
     uint4 *lb = (uint4 *)cx.body, *lf = (uint4 *)cx.food;
-    for (int i0 = 0; i0 < nb; i0 += 8 * nth) {
+    if (nb <= 8 * nth && nf <= nth) {
+        // the whole image in ONE round of loads (cfg4: 313 + 40 sixteen-byte pieces and 12 ints for one wave): bodies, food and
+        // the per-snake words are requested before anything is waited for — three dependent round trips took 13 400 cycles of
+        // a stepper's 67 000 per call (tools/multi_timeline.py) — and the head map is cleared while they are under way
         uint4 v[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = mb[min(i0 + tid + j * nth, nb - 1)];
+        for (int j = 0; j < 8; ++j) v[j] = mb[min(tid + j * nth, nb - 1)];
+        const uint4 f = mf[min(tid, nf - 1)];
+        int w0 = 0, w1 = 0, w2 = 0;
+        if (tid < K) { w0 = ms[tid]; w1 = ms[K + tid]; w2 = ms[2 * K + tid]; }
+        for (int c = tid; c < C; c += nth) cx.hmap[c] = 0;
 #pragma unroll
         for (int j = 0; j < 8; ++j)
-            if (i0 + tid + j * nth < nb) lb[i0 + tid + j * nth] = v[j];
+            if (tid + j * nth < nb) lb[tid + j * nth] = v[j];
+        if (tid < nf) lf[tid] = f;
+        if (tid < K) { cx.tclk[tid] = w0; cx.hcell[tid] = w1; cx.lmax[tid] = w2; }
+        WURM_TLS(cx, 13);
+    } else {
+        for (int i0 = 0; i0 < nb; i0 += 8 * nth) {
+            uint4 v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = mb[min(i0 + tid + j * nth, nb - 1)];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (i0 + tid + j * nth < nb) lb[i0 + tid + j * nth] = v[j];
+        }
+        for (int i = tid; i < nf; i += nth) lf[i] = mf[i];
+        if (tid < K) {
+            cx.tclk[tid] = ms[tid];
+            cx.hcell[tid] = ms[K + tid];
+            cx.lmax[tid] = ms[2 * K + tid];
+        }
+        for (int c = tid; c < C; c += nth) cx.hmap[c] = 0;
     }
-    for (int i = tid; i < nf; i += nth) lf[i] = mf[i];
-    if (tid < K) {
-        cx.tclk[tid] = ms[tid];
-        cx.hcell[tid] = ms[K + tid];
-        cx.lmax[tid] = ms[2 * K + tid];
-    }
-    for (int c = tid; c < C; c += nth) cx.hmap[c] = 0;
     sync();
     u64 fbits = 0;
-    for (int k = 0, c = tid; c < C; ++k, c += nth) fbits |= (u64)(cx.food[c] != 0) << k;
+    if (want_bits) { // (only store_env — the write-back to the fp32 planes — compares with them)
+#pragma unroll 5
+        for (int k = 0, c = tid; c < C; ++k, c += nth) fbits |= (u64)(cx.food[c] != 0) << k;
+    }
+    WURM_TLS(cx, 14);
     return fbits;
 }
 
 // LDS -> mirror (the DIRTY bits stay behind: they mean "written since the load from fp32").  hc / L: the snake's head
 // cell and length as of now (threads 0..K-1).
-// sparse: the grids came from this mirror in this launch — only the body cells written since (DIRTY) and the food cells
-// that differ from fbits0 (mirror_load's return value) are stored.
+// sparse: the grids came from this mirror in this launch — only the body cells written since (DIRTY) are stored, and the
+// food grid whole (C bytes).
 template <typename Sync>
 __device__ __forceinline__ void mirror_store(const Ctx &cx, unsigned char *__restrict__ m, int tid, int nth, int hc, int L,
                                              Sync sync, bool sparse = false, u64 fbits0 = 0)
@@ -303,23 +327,29 @@ __device__ __forceinline__ void mirror_store(const Ctx &cx, unsigned char *__res
     const uint4 *lb = (const uint4 *)cx.body, *lf = (const uint4 *)cx.food;
     sync();
     const u32 keep = (u32)VMASK * 0x00010001u, dirty = (u32)DIRTY * 0x00010001u;
+    (void)fbits0;
     if (sparse) {
+        // (LDS reads in batches, the few stores afterwards: read-test-store cell by cell was a chain of dependent LDS round
+        // trips — 5 400 cycles of a stepper's 67 000 per call at cfg4)
         unsigned short *mb16 = (unsigned short *)m;
-        unsigned char *mf8 = m + mirror_body_bytes(K, C);
-        for (int i = tid; i < nb; i += nth) {
-            const uint4 v = lb[i];
-            if (((v.x | v.y | v.z | v.w) & dirty) == 0) continue;
-            const u32 w[4] = {v.x, v.y, v.z, v.w};
+        for (int i0 = 0; i0 < nb; i0 += 4 * nth) {
+            uint4 v[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                if (w[q] & (u32)DIRTY) mb16[8 * i + 2 * q] = (unsigned short)(w[q] & VMASK);
-                if (w[q] & ((u32)DIRTY << 16)) mb16[8 * i + 2 * q + 1] = (unsigned short)((w[q] >> 16) & VMASK);
+            for (int j = 0; j < 4; ++j) v[j] = lb[min(i0 + tid + j * nth, nb - 1)];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int i = i0 + tid + j * nth;
+                if (i >= nb || ((v[j].x | v[j].y | v[j].z | v[j].w) & dirty) == 0) continue;
+                const u32 w[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (w[q] & (u32)DIRTY) mb16[8 * i + 2 * q] = (unsigned short)(w[q] & VMASK);
+                    if (w[q] & ((u32)DIRTY << 16)) mb16[8 * i + 2 * q + 1] = (unsigned short)((w[q] >> 16) & VMASK);
+                }
             }
         }
-        for (int k = 0, c = tid; c < C; ++k, c += nth) {
-            const int f = cx.food[c] != 0;
-            if (f != (int)((fbits0 >> k) & 1)) mf8[c] = (unsigned char)f;
-        }
+        // (the food grid whole: C bytes per env — cheaper than finding the few cells that changed)
+        for (int i = tid; i < nf; i += nth) mf[i] = lf[i];
     } else {
         for (int i = tid; i < nb; i += nth) {
             uint4 v = lb[i];
@@ -530,6 +560,24 @@ __device__ __forceinline__ int count_bits(const Ctx &cx, u64 bits)
     return n;
 }
 
+// number of food cells of the env: four cells per lane and LDS read (the byte grid starts on a 16-byte boundary), one DPP
+// sum — the per-cell form (a read, a ballot and a popcount per row of 64 cells) was 3 000 cycles of every step at cfg4.
+// Wave-uniform call sites only (wave_sum_i32).
+__device__ __forceinline__ int food_count(const Ctx &cx)
+{
+    const int C = cx.C, nd = (C + 3) >> 2;
+    const u32 *f = (const u32 *)cx.food;
+    const u32 last = (C & 3) ? (1u << (8 * (C & 3))) - 1u : 0xffffffffu; // (the bytes behind the grid are padding)
+    int n = 0;
+#pragma unroll 4
+    for (int i = cx.lane; i < nd; i += 64) {
+        u32 w = f[i];
+        if (i == nd - 1) w &= last;
+        n += __popc((((w & 0x7f7f7f7fu) + 0x7f7f7f7fu) | w) & 0x80808080u); // non-zero bytes
+    }
+    return wave_sum_i32(n);
+}
+
 // ------------------------------------------------------------------------------------------------ observations
 
 // 'full' observation (_observe_agent :268-281 + _make_generic_rgb :175-192) of every agent from LDS.
@@ -632,14 +680,15 @@ __device__ __forceinline__ void snap_write(const Ctx &cx, int hc, unsigned short
 }
 
 // the K agents' observations of one env from its class codes, agent by agent (any wave of the workgroup may run this)
+// (k0 .. k1: the rows of 64 cells to write — a workgroup hands out parts of an agent's view: wg_observe_snap)
 __device__ __forceinline__ void snap_emit_agent(const Ctx &cx, const MultiArgs &p, float *obs_env,
-                                                const unsigned short *snap, int a)
+                                                const unsigned short *snap, int a, int k0 = 0, int k1 = 1 << 30)
 {
     const int C = cx.C, lane = cx.lane;
     const float G1 = 192.0f / 255.0f, G2 = 96.0f / 255.0f;
     {
         float *const base = obs_env + a * (p.N * p.obs_elems);
-        for (int k = 0; k < cx.cpl; ++k) {
+        for (int k = k0; k < min(k1, cx.cpl); ++k) {
             const int c = lane + 64 * k;
             if (c < C) {
                 const u32 v = (u32)snap[c];
@@ -853,20 +902,18 @@ __device__ __forceinline__ void multi_step_body(const Ctx &cx, const MultiArgs &
         delete_done(cx, done, has_body, hc);    // :595-596
     }
 
+    WURM_TLS(cx, 3);
     run_phase(cx, snake, dir, hc, L, done, reward, foodcons, snakecol, edgecol); // :613-660
+    WURM_TLS(cx, 4);
     if (p.cfg.food_on_death)                    // :662-673
         food_from_death(cx, done, has_body, p.has_inj ? p.inj.death_b + offC + env * C : nullptr,
                         p.cfg.death_threshold, p.seed, call, env_id, RNG_DEATH_FOOD_B);
     delete_done(cx, done, has_body, hc);        // :676-677
+    WURM_TLS(cx, 5);
 
     // _add_food (:368-410)
     {
-        u64 fb = 0;
-        for (int k = 0; k < cx.cpl; ++k) {
-            int c = lane + 64 * k;
-            if (c < C && cx.food[c]) fb |= 1ull << k;
-        }
-        const int nfood = count_bits(cx, fb);
+        const int nfood = food_count(cx);
         if (p.cfg.food_mode == 0) {
             if (nfood == 0) {                   // :371-379
                 if (p.has_inj) {
@@ -904,6 +951,7 @@ __device__ __forceinline__ void multi_step_body(const Ctx &cx, const MultiArgs &
         wave_lds_sync();
     }
 
+    WURM_TLS(cx, 6);
     if (snake && done && !done0) reward += p.cfg.reward_on_death; // :683-685
 
     sn.hc = hc;
@@ -1037,8 +1085,29 @@ constexpr uint32_t MCHK_NOT_COMPUTED = 0xffffffffu; // read from fp32 planes tha
 // The part of the per-call step between the load and the store of the env (LDS state ready, hcell / lmax / tclk set):
 // [the reset(done) the caller postponed, exactly multi_reset_kernel without observation, with its own counter,] the
 // transition, and the per-agent outputs.  Runs on ONE wave.  hc0: the head cells HBM holds (sparse write-back).
+// what step_middle reads from global memory before anything else: a kernel requests it at its entry, together with the
+// env's image, so that the transition does not start with a memory round trip of its own (2 400 of a stepper's 67 000 cycles
+// per call at cfg4: tools/multi_timeline.py)
+struct StepIn {
+    bool done;
+    long long orient, a;
+    short col[3];
+};
+
+__device__ __forceinline__ void step_inputs(const MultiArgs &p, long long env, int lane, StepIn &in)
+{
+    const bool snake = lane < p.K;
+    const long long agent = env * p.K + lane;
+    in.done = snake ? p.dones[agent] != 0 : true;
+    in.orient = snake ? p.orientations[agent] : 0;
+    in.a = snake ? p.actions[(long long)lane * p.N + env] : 0;
+    Snake c;
+    load_colour(p, agent, snake && (p.done_env != nullptr || p.obs_mode == WURM_OBS_PARTIAL), c);
+    in.col[0] = c.col[0]; in.col[1] = c.col[1]; in.col[2] = c.col[2];
+}
+
 __device__ __forceinline__ void step_middle(const Ctx &cx, const MultiArgs &p, long long env, bool rebuild, Snake &sn,
-                                            StepRes &r, int &hc0)
+                                            StepRes &r, int &hc0, const StepIn *in = nullptr)
 {
     const int K = cx.K, lane = cx.lane;
     const bool snake = lane < K;
@@ -1046,13 +1115,14 @@ __device__ __forceinline__ void step_middle(const Ctx &cx, const MultiArgs &p, l
     const long long agent = env * K + lane;
     sn.hc = snake ? cx.hcell[lane] : -1;
     sn.L = snake ? cx.lmax[lane] : 0;
-    sn.done = snake ? p.dones[agent] != 0 : true;
-    sn.orient = snake ? p.orientations[agent] : 0;
+    sn.done = in ? in->done : snake ? p.dones[agent] != 0 : true;
+    sn.orient = in ? in->orient : snake ? p.orientations[agent] : 0;
     sn.boosted = false;
     hc0 = sn.hc;
     if (p.done_env != nullptr) {
         if (rebuild) sn.done = false; // :798
-        load_colour(p, agent, snake, sn);
+        if (in) { sn.col[0] = in->col[0]; sn.col[1] = in->col[1]; sn.col[2] = in->col[2]; }
+        else load_colour(p, agent, snake, sn);
         if (snake && reroll_colour(p, agent, sn.done, env_id, p.pre_call, 0, sn)) {
             p.colours[agent * 3] = sn.col[0];
             p.colours[agent * 3 + 1] = sn.col[1];
@@ -1064,10 +1134,13 @@ __device__ __forceinline__ void step_middle(const Ctx &cx, const MultiArgs &p, l
             multi_reset_grid(cx, p, env, env_id, p.pre_call, rebuild, respawn, sn, orient_dirty, 0, 0);
         }
     } else {
-        load_colour(p, agent, snake && p.obs_mode == WURM_OBS_PARTIAL, sn);
+        if (in) { sn.col[0] = in->col[0]; sn.col[1] = in->col[1]; sn.col[2] = in->col[2]; }
+        else load_colour(p, agent, snake && p.obs_mode == WURM_OBS_PARTIAL, sn);
     }
-    const long long a = snake ? p.actions[(long long)lane * p.N + env] : 0;
+    const long long a = in ? in->a : snake ? p.actions[(long long)lane * p.N + env] : 0;
+    WURM_TLS(cx, 2);
     multi_step_body(cx, p, env, env_id, p.call, a, sn, r, 0, 0, 0);
+    WURM_TLS(cx, 7);
 
     // outputs (:701-729)
     if (snake) {
@@ -1126,8 +1199,9 @@ __device__ __forceinline__ void workgroup_handoff()
 }
 
 // the pieces of the grouped 'full' observation writer (defined with multi_rollout_group_kernel below)
+__device__ __forceinline__ u64 border_bits(const Ctx &cx);
 template <typename CT>
-__device__ __forceinline__ void class_write(const Ctx &cx, int hc, CT *codes);
+__device__ __forceinline__ void class_write(const Ctx &cx, int hc, CT *codes, u64 border);
 __device__ __forceinline__ void grp_table_init(float *tab, int tid);
 __device__ __forceinline__ void grp_emit_group(const MultiArgs &p, float *obs, long long env0, int nG, int wave, int nwaves,
                                                const unsigned char *codes0, int code_stride, const float *tab, int lane);
@@ -1150,6 +1224,8 @@ __global__ __launch_bounds__(512) void multi_step_kernel(MultiArgs p)
     const int C = cx.C, K = cx.K, lane = cx.lane;
     const bool snake = lane < K;
     const int nG = (int)min((long long)wpb, p.N - env0);
+    WURM_TLS(cx, 0);
+    const u64 ring = grouped ? border_bits(cx) : 0ull;
     Snake sn;
     StepRes r;
     bool clean = false;
@@ -1157,25 +1233,33 @@ __global__ __launch_bounds__(512) void multi_step_kernel(MultiArgs p)
     if (active) {
     float *foodp = p.foods + env * C, *headp = p.heads + env * K * C, *bodyp = p.bodies + env * K * C;
 
-    // An env the postponed reset rebuilds is not read at all (as in multi_reset_kernel): the launch is one round of waves
-    // and ends with its slowest env, and a rebuilt env — rebuild + whole-env store — is the slowest already.
-    const bool rebuild = p.done_env != nullptr && uniform((int)p.done_env[env]) != 0;
+    // An env the postponed reset rebuilds is not read from the fp32 planes (as in multi_reset_kernel): the launch is one
+    // round of waves and ends with its slowest env, and a rebuilt env — rebuild + whole-env store — is the slowest already.
+    // The compact image is requested whether or not the env is rebuilt: "is it rebuilt" is itself a load, and waiting for
+    // it first made two memory round trips of one.
+    StepIn in;
+    step_inputs(p, env, lane, in); // (requested here, used after the env's image has arrived)
+    const int rebuild_byte = p.done_env != nullptr ? (int)p.done_env[env] : 0;
     const bool mirrored = p.resident != nullptr, lazy = mirrored && p.resident_lazy != 0;
     const bool from_mirror = mirrored && p.resident_valid != 0;
     unsigned char *mp = mirrored ? p.resident + env * mirror_env_bytes(K, C) : nullptr;
     auto fence = [] { wave_lds_sync(); };
     u64 fbits0 = 0;
     bool plain = false; // read from the fp32 planes, which held nothing the image cannot represent
+    if (from_mirror) fbits0 = mirror_load(cx, mp, lane, 64, fence, !lazy);
+    const bool rebuild = uniform(rebuild_byte) != 0;
     if (!rebuild) {
-        fbits0 = from_mirror ? mirror_load(cx, mp, lane, 64, fence)
-                             : load_env(cx, foodp, headp, bodyp, p.err != nullptr, plain);
+        if (!from_mirror) fbits0 = load_env(cx, foodp, headp, bodyp, p.err != nullptr, plain);
     } else {
+        fbits0 = 0;
         if (snake) { cx.hcell[lane] = -1; cx.lmax[lane] = 0; cx.tclk[lane] = 0; } // the rest: multi_reset_grid(rebuild)
         wave_lds_sync();
     }
     const int t0 = snake ? cx.tclk[lane] : 0; // the clocks as loaded (0 unless the state came from the mirror)
     int hc0;
-    step_middle(cx, p, env, rebuild, sn, r, hc0);
+    WURM_TLS(cx, 1);
+    step_middle(cx, p, env, rebuild, sn, r, hc0, &in);
+    WURM_TLS(cx, 8);
     clean = from_mirror || rebuild || plain; // lds_check sees everything there is to check
     if (p.err != nullptr) {
         if (clean) m_step = lds_check(cx, sn);
@@ -1198,7 +1282,7 @@ __global__ __launch_bounds__(512) void multi_step_kernel(MultiArgs p)
     if (grouped && p.grp_emit == 2) { // every wave for itself: its env's class codes -> its K agents' views (no barrier)
         workgroup_handoff(); // (the table)
         if (!active) return;
-        class_write<unsigned short>(cx, sn.hc, cx.snap);
+        class_write<unsigned short>(cx, sn.hc, cx.snap, ring);
         grp_emit_group(p, p.obs + env * p.obs_elems - env0 * p.obs_elems, env0, 1, 0, 1, (const unsigned char *)cx.snap, 0, tab, lane);
         if (p.obs_after == nullptr) return;
         const bool touched = reset_for_obs_after(cx, p, env, sn, r);
@@ -1206,15 +1290,25 @@ __global__ __launch_bounds__(512) void multi_step_kernel(MultiArgs p)
             if (touched) m_step = clean ? lds_check(cx, sn) : MCHK_NOT_COMPUTED;
             if (lane == 0) p.err_after[env] = m_step;
         }
-        class_write<unsigned short>(cx, sn.hc, cx.snap);
+        class_write<unsigned short>(cx, sn.hc, cx.snap, ring);
         grp_emit_group(p, p.obs_after + env * p.obs_elems - env0 * p.obs_elems, env0, 1, 0, 1, (const unsigned char *)cx.snap, 0, tab, lane);
         return;
     }
     if (grouped) {
         const unsigned char *codes0 = (const unsigned char *)make_ctx(p, 0).snap;
-        if (active) class_write<unsigned short>(cx, sn.hc, cx.snap);
+        WURM_TLS(cx, 9);
+        if (active) class_write<unsigned short>(cx, sn.hc, cx.snap, ring);
+        WURM_TLS(cx, 10);
         workgroup_handoff();
+        WURM_TLS(cx, 11);
         grp_emit_group(p, p.obs, env0, nG, wave, wpb, codes0, p.lds_per_wave, tab, lane);
+        WURM_TLS(cx, 12);
+#ifdef WURM_TIMELINE
+        if (p.obs_after == nullptr) {
+            workgroup_handoff(); // (the stamps go over what another wave has written)
+            if (active) WURM_TLS_STORE(cx, p.obs + env * p.obs_elems);
+        }
+#endif
         if (p.obs_after == nullptr) return;
         workgroup_handoff(); // every wave has read the codes of the stepped state
         if (active) {
@@ -1223,7 +1317,7 @@ __global__ __launch_bounds__(512) void multi_step_kernel(MultiArgs p)
                 if (touched) m_step = clean ? lds_check(cx, sn) : MCHK_NOT_COMPUTED; // (else: the state the first mask describes)
                 if (lane == 0) p.err_after[env] = m_step;
             }
-            class_write<unsigned short>(cx, sn.hc, cx.snap);
+            class_write<unsigned short>(cx, sn.hc, cx.snap, ring);
         }
         workgroup_handoff();
         grp_emit_group(p, p.obs_after, env0, nG, wave, wpb, codes0, p.lds_per_wave, tab, lane);
@@ -1356,7 +1450,14 @@ __device__ __forceinline__ void wg_observe_snap(const Ctx &cx, const MultiArgs &
     __syncthreads();
     if (tid < K && hc >= 0) cx.hmap[hc] = 0;
     float *obs_env = (float *)uniform64((long long)(obs + env * p.obs_elems));
-    for (int a = wave; a < K; a += nth >> 6) snap_emit_agent(cx, p, obs_env, cx.snap, a);
+    // (agent, half of its rows) items, dealt round robin: 10 agents over 4 waves were 3 + 3 + 2 + 2 whole views — the
+    // workgroup waited for the waves with three
+    const int nw = nth >> 6, half = (cx.cpl + 1) >> 1;
+    if (p.grp_variant & 1) { // (A/B switch, WURM_MULTI_GROUP_VARIANT bit 0: whole views, round robin)
+        for (int a = wave; a < K; a += nw) snap_emit_agent(cx, p, obs_env, cx.snap, a);
+    } else {
+        for (int i = wave; i < 2 * K; i += nw) snap_emit_agent(cx, p, obs_env, cx.snap, i >> 1, (i & 1) * half, (i & 1) ? cx.cpl : half);
+    }
     __syncthreads();
 }
 
@@ -1367,23 +1468,36 @@ __global__ __launch_bounds__(256) void multi_step_wg_kernel(MultiArgs p)
     if (env >= p.N) return; // the whole workgroup: the barriers below see every wave or none
     const Ctx cx = make_ctx(p, 0);
     const int C = cx.C, K = cx.K, lane = cx.lane;
+    if (wave == 0) WURM_TLS(cx, 0);
     float *foodp = p.foods + env * C, *headp = p.heads + env * K * C, *bodyp = p.bodies + env * K * C;
-    const bool rebuild = p.done_env != nullptr && p.done_env[env] != 0;
+    // (the rebuild flag, wave 0's step inputs and the compact image are requested together: see multi_step_kernel)
+    const int rebuild_byte = p.done_env != nullptr ? (int)p.done_env[env] : 0;
+    StepIn in = {};
+    if (wave == 0) step_inputs(p, env, lane, in);
     const bool mirrored = p.resident != nullptr, lazy = mirrored && p.resident_lazy != 0;
     const bool from_mirror = mirrored && p.resident_valid != 0;
     unsigned char *mp = mirrored ? p.resident + env * mirror_env_bytes(K, C) : nullptr;
     auto barrier = [] { __syncthreads(); };
     u64 fbits0 = 0;
     bool plain = false;
-    if (!rebuild) fbits0 = from_mirror ? mirror_load(cx, mp, tid, nth, barrier)
-                                       : wg_load_env(cx, foodp, headp, bodyp, tid, nth, p.err != nullptr, plain);
-    else if (tid < K) { cx.hcell[tid] = -1; cx.lmax[tid] = 0; cx.tclk[tid] = 0; }
+    if (from_mirror) fbits0 = mirror_load(cx, mp, tid, nth, barrier, !lazy);
+    const bool rebuild = rebuild_byte != 0;
+    if (!rebuild) {
+        if (!from_mirror) fbits0 = wg_load_env(cx, foodp, headp, bodyp, tid, nth, p.err != nullptr, plain);
+    } else {
+        fbits0 = 0;
+        if (tid < K) { cx.hcell[tid] = -1; cx.lmax[tid] = 0; cx.tclk[tid] = 0; }
+    }
     __syncthreads();
     const int t0 = tid < K ? cx.tclk[tid] : 0;
     Snake sn;
     StepRes r;
     int hc0 = -1;
-    if (wave == 0) step_middle(cx, p, env, rebuild, sn, r, hc0);
+    if (wave == 0) {
+        WURM_TLS(cx, 1);
+        step_middle(cx, p, env, rebuild, sn, r, hc0, &in);
+        WURM_TLS(cx, 8);
+    }
     const bool clean = from_mirror || rebuild || plain;
     // check_consistency's mask by all four waves when the class-code buffer is there to lend them 2 KB (a snake per wave at
     // a time), else by wave 0 alone
@@ -1425,7 +1539,14 @@ __global__ __launch_bounds__(256) void multi_step_wg_kernel(MultiArgs p)
         __syncthreads();
     }
     if (p.obs_mode == WURM_OBS_NONE) return;
+    if (wave == 0) WURM_TLS(cx, 9);
     wg_observe_snap(cx, p, p.obs, env, tid, nth, wave);
+#ifdef WURM_TIMELINE
+    if (p.obs_after == nullptr && wave == 0) {
+        WURM_TLS(cx, 12);
+        WURM_TLS_STORE(cx, p.obs + env * p.obs_elems);
+    }
+#endif
     if (p.obs_after == nullptr) return;
     if (wave == 0) {
         const bool touched = reset_for_obs_after(cx, p, env, sn, r);
@@ -2037,51 +2158,73 @@ __device__ __forceinline__ u32 grp_rep(int K) { return (u32)(((1ull << (3 * K)) 
 // :268-281 paints food, own body, own head, other bodies, other heads, then the border (:183-186): a later layer wins, so
 // the class of a cell for an agent is the LAST layer that covers it — with the classes numbered in paint order, the
 // maximum over the layers.  Bodies first (every cell), then the K head cells are raised.
-template <typename CT>
-__device__ __forceinline__ void class_write(const Ctx &cx, int hc, CT *codes)
+// bit k of the lane's mask <=> cell lane + 64 k lies on the border ring (:183-186): a property of the grid, worked out once
+// per kernel (class_write paints the ring last, over whatever sits there)
+__device__ __forceinline__ u64 border_bits(const Ctx &cx)
 {
-    const int S = cx.S, C = cx.C, K = cx.K, lane = cx.lane;
-    const u32 REP = grp_rep(K);
-    // which snake has its head on a cell: owner + 1 per cell in hmap (all-zero outside this function); two heads may share
-    // a cell in hand-made states — such a cell is marked 255 and its owners are looked up among the K head cells
-    if (lane < K && hc >= 0) cx.hmap[hc] = (unsigned char)(lane + 1);
-    wave_lds_sync();
-    if (lane < K && hc >= 0 && cx.hmap[hc] != (unsigned char)(lane + 1)) cx.hmap[hc] = 255;
-    wave_lds_sync();
+    const int S = cx.S, C = cx.C;
+    u64 m = 0;
     for (int k = 0; k < cx.cpl; ++k) {
-        const int c = lane + 64 * k;
-        if (c < C) {
-            u32 bm = 0;
-            for (int s = 0; s < K; ++s) bm |= (u32)((int)(cx.body[s * C + c] & VMASK) > cx.tclk[s]) << s;
-            const u32 hv = cx.hmap[c];
-            u32 hm = hv ? 1u << (hv - 1u) : 0u;
-            if (hv == 255u) { // several heads on the cell
-                hm = 0;
-                for (int s = 0; s < K; ++s) hm |= (u32)(cx.hcell[s] == c) << s;
+        const int c = cx.lane + 64 * k, y = div_size(c, cx.rcpS), x = c - y * S;
+        if (c < C && (y == 0 || x == 0 || y == S - 1 || x == S - 1)) m |= 1ull << k;
+    }
+    return m;
+}
+
+template <typename CT>
+__device__ __forceinline__ void class_write(const Ctx &cx, int hc, CT *codes, u64 border)
+{
+    const int C = cx.C, K = cx.K, lane = cx.lane;
+    const u32 REP = grp_rep(K), REP4 = 4u * REP, REP5 = 5u * REP, REP6 = 6u * REP;
+    // Five 64-cell rows at a time: for each snake its clock and head cell come out of lanes 0 .. K-1 (readlane), its five
+    // body cells are read TOGETHER (one LDS round trip per snake and block, not per cell), "head on this cell" is a compare
+    // with the K head cells — no head map, no pass over the border afterwards, one fence at the end — and the code of a cell
+    // is a few selects; only a cell with several snakes on it branches.  (The first form read cell by cell, kept a
+    // head-owner map in LDS and painted the border in a second pass: 11 000 cycles of a stepper's 67 000 per call at cfg4,
+    // tools/multi_timeline.py.)
+    constexpr int U = 5;
+    const int myT = lane < K ? cx.tclk[lane] : 0, myH = lane < K ? hc : -1;
+    for (int k0 = 0; k0 < cx.cpl; k0 += U) {
+        int cc[U];
+        u32 bm[U], hm[U], fd[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            cc[u] = min(lane + 64 * (k0 + u), C - 1); // (rows past the grid: the last cell again, not stored)
+            bm[u] = hm[u] = 0;
+            fd[u] = cx.food[cc[u]];
+        }
+        for (int s = 0; s < K; ++s) {
+            const int T = lane_value(myT, s), H = lane_value(myH, s);
+            const unsigned short *b = cx.body + s * C;
+            u32 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) v[u] = b[cc[u]];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                bm[u] |= (u32)((int)(v[u] & VMASK) > T) << s;
+                hm[u] |= (u32)(cc[u] == H) << s;
             }
-            const u32 occ = bm | hm;
-            u32 code;
-            if (occ == 0) code = cx.food[c] != 0 ? REP : 0u;
-            else if ((occ & (occ - 1u)) == 0) // one snake: the others see 4 (body) / 5 (head), the snake itself 2 / 3
-                code = ((hm ? 5u : 4u) * REP) ^ (6u << (3 * (__ffs((int)occ) - 1)));
-            else { // several snakes on the cell (hand-made states, and heads that have just run into something)
+        }
+        const u32 bb = (u32)(border >> k0);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int c = lane + 64 * (k0 + u);
+            const u32 occ = bm[u] | hm[u];
+            const int first = max(__ffs((int)occ) - 1, 0);
+            // one snake: the others see 4 (body) / 5 (head), the snake itself 2 / 3
+            u32 code = occ == 0 ? (fd[u] != 0 ? REP : 0u) : ((hm[u] ? REP5 : REP4) ^ (6u << (3 * first)));
+            const bool ring = ((bb >> u) & 1u) != 0;
+            if ((occ & (occ - 1u)) != 0 && !ring) { // several snakes on the cell (hand-made states, heads that have just run into something)
                 code = 0;
                 for (int a = 0; a < K; ++a) {
                     const u32 others = ~(1u << a);
-                    code |= ((hm & others) ? 5u : (bm & others) ? 4u : ((hm >> a) & 1u) ? 3u : 2u) << (3 * a);
+                    code |= ((hm[u] & others) ? 5u : (bm[u] & others) ? 4u : ((hm[u] >> a) & 1u) ? 3u : 2u) << (3 * a);
                 }
             }
-            codes[c] = (CT)code;
+            if (ring) code = REP6;
+            if (c < C) codes[c] = (CT)code;
         }
     }
-    wave_lds_sync();
-    // the border ring (:183-186) is painted last, over whatever sits there: its 4 S - 4 cells, whatever the state
-    for (int b = lane; b < 4 * S - 4; b += 64) {
-        const int j = b - 2 * S;                       // >= 0: the left / right columns, rows 1 .. S - 2
-        const int c = b < S ? b : b < 2 * S ? (S - 1) * S + (b - S) : ((j >> 1) + 1) * S + (j & 1) * (S - 1);
-        codes[c] = (CT)(6u * REP);
-    }
-    if (lane < K && hc >= 0) cx.hmap[hc] = 0;
     wave_lds_sync();
 }
 
@@ -2304,6 +2447,7 @@ __global__ __launch_bounds__(64 * (G / EPS + W)) __attribute__((amdgpu_waves_per
         return;
     }
     const bool snake = lane < K;
+    const u64 ring = border_bits(make_ctx(p, 0, p.grp_env0));
     int *const save0 = (int *)(wurm_multi_lds + p.grp_save);
     for (int e = 0; e < EPS; ++e) {
         const int g = wave * EPS + e;
@@ -2377,7 +2521,7 @@ __global__ __launch_bounds__(64 * (G / EPS + W)) __attribute__((amdgpu_waves_per
                 b[3 * K + lane] = (unsigned char)r.edgecol;
             }
             if (lane == 0) obuf[16 * K] = (unsigned char)r.all_done;
-            class_write<CT>(cx, sn.hc, (CT *)(codes0 + ((size_t)buf * G + g) * p.grp_code_bytes));
+            class_write<CT>(cx, sn.hc, (CT *)(codes0 + ((size_t)buf * G + g) * p.grp_code_bytes), ring);
             if (lane == 0) ((int *)(save0 + g * 8 * K))[7] = (int)r.all_done;   // (slot 7 of snake 0: for the reset below)
             grp_save(save0 + g * 8 * K, lane, K, sn, col_dirty, hc0);
             wave_lds_sync();
@@ -2685,6 +2829,7 @@ static int multi_launch(MKind kind, MultiArgs &p, void *stream)
         // an env too large for four per workgroup: one env per workgroup of four waves (multi_step_wg_kernel)
         (void)hipGetLastError();
         const dim3 g((unsigned)p.N), b(256);
+        p.grp_variant = (int)opt.multi_group_variant;
         const void *kf = kind == MK_STEP ? (const void *)multi_step_wg_kernel
                        : kind == MK_RESET ? (const void *)multi_reset_wg_kernel : (const void *)multi_observe_wg_kernel;
         if (!allow_lds(kf, (size_t)lds)) return WURM_ERR_HIP;
@@ -2696,11 +2841,16 @@ static int multi_launch(MKind kind, MultiArgs &p, void *stream)
     while (wpb > 1 && lds * wpb > 65536) wpb >>= 1;
     size_t extra = 0;
     if (want_group && wpb == 4 && opt.multi_group_step_wpb != 0) {
-        // large batches: the workgroup's waves write the 'full' observations together, one linear run per agent; eight envs
-        // per workgroup where two such workgroups fit a CU (option WURM_MULTI_GROUP_STEP_WPB: 0 = off, 4 / 8 = that many)
+        // large batches: 'full' observations through per-agent class codes and the colour table (class_write, grp_emit_cells).
+        // Option WURM_MULTI_GROUP_STEP_WPB: 0 = off; 1 (and -1, automatic) = every wave writes its own env's K views, no
+        // barrier; 4 / 8 = the workgroup's waves write one linear run per agent together, that many envs per workgroup.
+        // One call's observations (123 MB at cfg4) are absorbed by the 256 MB Infinity Cache — the per-call launch is a chain
+        // of latencies (tools/multi_timeline.py), not a stream, so the barrier of the shared form costs more than its
+        // longer runs gain: 36.8 against 37.8 us per iteration at cfg4 (profiles/r04_multi_percall_timeline.txt).
+        const long long mode = opt.multi_group_step_wpb < 0 ? 1 : opt.multi_group_step_wpb;
         extra = GRP_TAB_BYTES + GRP_CODE_SLACK;
-        if (2 * (8 * (size_t)lds + extra) <= (size_t)LDS_MAX_BYTES && opt.multi_group_step_wpb != 4 && opt.multi_group_step_wpb != 1) wpb = 8;
-        p.grp_emit = opt.multi_group_step_wpb == 1 ? 2 : 1;
+        if (2 * (8 * (size_t)lds + extra) <= (size_t)LDS_MAX_BYTES && mode != 4 && mode != 1) wpb = 8;
+        p.grp_emit = mode == 1 ? 2 : 1;
         p.grp_env0 = lds * wpb; // the table, behind the envs' blocks
     }
     dim3 block(64 * wpb), grid((unsigned)((p.N + wpb - 1) / wpb));

@@ -1739,6 +1739,7 @@ static hipError_t launch_one(Kind kind, const StepArgs &p, dim3 grid, dim3 block
     case R_GENERIC_NONE:
         if constexpr (SNAKE && CPL == 2) WURM_LAUNCH((rollout_kernel<CPL, SNAKE, WURM_OBS_NONE, false>), grid, block, lds, st, p);
         break;
+    case R_LANE_RESIDENT: // (chosen by fused_entry, which launches it itself)
     case R_GENERIC:
         switch (kind) {
         case K_STEP: WURM_LAUNCH((step_kernel<CPL, SNAKE>), grid, block, lds, st, p); break;

@@ -213,10 +213,27 @@ __device__ __forceinline__ int tap_x(int i) { return i == 1 ? 1 : (i == 3 ? -1 :
             tl_o[4] = tl_4; tl_o[5] = tl_5; tl_o[6] = tl_6; tl_o[7] = tl_7;                                              \
         }                                                                                                                \
     } while (0)
+// MultiSnake per-call kernels (tools/multi_timeline.py): up to 16 stamps in LDS slots — the `acts` block of the wave's env,
+// which only rollouts use — so that device functions (step_middle, multi_step_body, class_write) can stamp too; the wave
+// copies them over the first 128 bytes of agent 0's observation of its env once its stores have drained.
+#define WURM_TLS(cx, k)                                                                                                  \
+    do {                                                                                                                 \
+        const unsigned long long tls_t = __builtin_amdgcn_s_memtime();                                                   \
+        if ((cx).lane == 0) ((unsigned long long *)(cx).acts)[k] = tls_t;                                                \
+    } while (0)
+#define WURM_TLS_STORE(cx, ptr)                                                                                          \
+    do {                                                                                                                 \
+        __builtin_amdgcn_s_waitcnt(0);                                                                                   \
+        WURM_TLS(cx, 15);                                                                                                \
+        __builtin_amdgcn_s_waitcnt(0);                                                                                   \
+        if ((cx).lane < 16) ((unsigned long long *)(ptr))[(cx).lane] = ((unsigned long long *)(cx).acts)[(cx).lane];     \
+    } while (0)
 #else
 #define WURM_TL_DECL
 #define WURM_TL(k)
 #define WURM_TL_STORE(ptr, lane)
+#define WURM_TLS(cx, k)
+#define WURM_TLS_STORE(cx, ptr)
 #endif
 
 } // namespace wurm

@@ -609,27 +609,29 @@ class MultiSnake(object):
         self._rewards_t = self._boost_t = None
 
         # reference :701-729 — per-agent dicts; the kernel wrote agent-major rows, so these are plain views
-        rf, rb = of.unbind(0), ob.unbind(0)
+        # (only the agent-major rows are unbound — a view object per row is most of what this method costs on the host:
+        # rf = rewards, food, size; rb = dones, boost, snake_collision, edge_collision, all_done)
+        K2, K3, K4 = 2 * K, 3 * K, 4 * K
+        rf, rb = of[K3:].unbind(0), ob[K3:].unbind(0)
         k_agent, k_snake, k_edge, k_food, k_boost, k_size = self._keys
-        K3, K4, K5, K6, K7 = 3 * K, 4 * K, 5 * K, 6 * K, 7 * K
-        all_done = rb[K7]
-        dones_out = dict(zip(k_agent, rb[K3:K4]))
+        all_done = rb[K4]
+        dones_out = dict(zip(k_agent, rb[:K]))
         if self._lifetimes_touched:
             all_done = all_done | (self._env_lifetimes > self.max_env_lifetime)  # :703-705
         dones_out['__all__'] = all_done
-        rewards = dict(zip(k_agent, rf[K3:K4]))
+        rewards = dict(zip(k_agent, rf[:K]))
 
-        info = dict(zip(k_snake, rb[K5:K6]))
-        info.update(zip(k_edge, rb[K6:K7]))
+        info = dict(zip(k_snake, rb[K2:K3]))
+        info.update(zip(k_edge, rb[K3:K4]))
         if self._half:  # reference :477 / :724: food and size carry the env's dtype
             rh = of[K4:].to(torch.half).unbind(0)
             info.update(zip(k_food, rh[:K]))
             info.update(zip(k_size, rh[K:]))
             obs = obs.to(torch.half)
         else:
-            info.update(zip(k_food, rf[K4:K5]))
-            info.update(zip(k_size, rf[K5:K6]))
-        info.update(zip(k_boost, rb[K4:K5]))
+            info.update(zip(k_food, rf[K:K2]))
+            info.update(zip(k_size, rf[K2:]))
+        info.update(zip(k_boost, rb[K:K2]))
         self.info = info
 
         self._last_all_done, self._last_version = all_done, _version_of(all_done)
