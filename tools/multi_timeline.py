@@ -17,6 +17,7 @@ ap.add_argument('--envs', type=int, default=4096)
 ap.add_argument('--snakes', type=int, default=4)
 ap.add_argument('--size', type=int, default=25)
 ap.add_argument('--iters', type=int, default=24)
+ap.add_argument('--rollout', type=int, default=0, help='fused rollout of this many steps with the training dynamics and partial_5 (cfg4-prime): per-segment TOTALS over the launch')
 ap.add_argument('--speeds', action='store_true', help="experiments/speeds.py's env: boost, respawn_mode='any' (one env per workgroup at 10 x 36 x 36)")
 args = ap.parse_args()
 if 'timeline' not in os.environ.get('WURM_HIP_LIBRARY', ''):
@@ -30,6 +31,27 @@ names = ['entry', 'loaded', 'inputs', 'prologue', 'phase', 'death/delete', 'add_
          'class codes', 'barrier', 'obs issued', 'image in LDS', 'food bits', 'drained']
 order = [0, 13, 14, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 15]  # the stamps in the order a wave passes them
 kw = dict(boost=True, respawn_mode='any') if args.speeds else {}
+if args.rollout:
+    T = args.rollout
+    env = MultiSnake(N, K, S, device=torch.device('cuda:0'), seed=0, observation_mode='partial_5', food_mode='random_rate',
+                     respawn_mode='any', boost_cost_prob=0.25, food_on_death_prob=0.33, food_rate=2.5e-4)
+    acts = torch.randint(8, (6, T, K, N), device='cuda')
+    tot = []
+    for it in range(6):
+        out = env.rollout(acts[it])
+        torch.cuda.synchronize()
+        if it >= 2:
+            tot.append(out['observations'][0, 0].reshape(N, -1)[:, :32].contiguous().view(torch.int64).cpu().numpy())
+    tot = np.concatenate(tot).astype(np.float64) / T
+    seg = {0: 'reset (prev step)', 2: 'actions', 3: 'boost phase', 4: 'phase', 5: 'death food / delete', 6: 'add_food', 7: 'body tail',
+           8: 'outputs', 9: 'observation'}
+    life = tot[:, :15].sum(1)
+    print(f'multi_rollout_kernel, {N} x {S} x {S} x {K}, training dynamics, partial_5, {T} steps: cycles per step (mean over waves; p90)')
+    for k, name in seg.items():
+        c = tot[:, k]
+        print(f'  {name:>20s}  mean {c.mean():8.0f}  p90 {np.percentile(c, 90):8.0f}   {100 * c.mean() / life.mean():5.1f} %')
+    print(f'  per step: mean {life.mean():.0f}  p90 {np.percentile(life, 90):.0f}')
+    sys.exit(0)
 env = MultiSnake(N, K, S, device=torch.device('cuda:0'), seed=0, **kw)
 if args.speeds:  # multi_step_wg_kernel stamps fewer points
     order = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 12, 15]

@@ -68,6 +68,7 @@ struct MultiArgs {
     long long T;          // rollout: number of fused step+reset iterations
     uint8_t *boost_state; // rollout: boost_this_step (N*K) written back at the end
     int lds_per_wave, off_body, off_food, off_occ, off_hmap, off_img, off_col, off_snap, off_acts;
+    int off_tl; // timeline build only: 32 stamp slots per env (WURM_TLS)
     // per-call step: the caller's compact mirror of foods / heads / bodies (wurm_multi_call.resident), nullable; valid: it
     // describes them; lazy: the step does not write them
     unsigned char *resident;
@@ -93,6 +94,7 @@ struct Ctx {
     unsigned char *acts;   // [64][K] rollout: the actions of the current 64-step chunk (see multi_rollout_kernel)
     short *img;            // [C][4] env image (partial_n): r, g, b, 0
     float *colf;           // [K][4]: r, g, b, 1 + 0.5*boost
+    unsigned long long *tl; // timeline build: stamp slots (WURM_TLS)
 };
 
 extern __shared__ __attribute__((aligned(16))) unsigned char wurm_multi_lds[];
@@ -118,6 +120,7 @@ __device__ __forceinline__ Ctx make_ctx(const MultiArgs &p, int wave, int base_o
     cx.acts = base + p.off_acts;
     cx.img = (short *)(base + p.off_img);
     cx.colf = (float *)(base + p.off_col);
+    cx.tl = (unsigned long long *)(base + p.off_tl);
     return cx;
 }
 
@@ -506,26 +509,40 @@ __device__ __forceinline__ bool rebase_clocks(const Ctx &cx)
     return true;
 }
 
-// bit k set <=> cell lane + 64k is interior and has no food, head or body on it (:439-445, :393-399)
+// bit k set <=> cell lane + 64k is interior and has no food, head or body on it (:439-445, :393-399).
+// Five rows of 64 cells at a time: each snake's clock and head cell come out of lanes 0 .. K-1 (readlane) and its five body
+// cells are read together — one LDS round trip per snake and block.  (Cell by cell — K dependent reads each — this scan was
+// most of the 21 000 cycles `_add_food` took of a 51 000-cycle step with random_rate food: tools/multi_timeline.py --rollout.)
 __device__ __forceinline__ u64 free_cells(const Ctx &cx, int hc, int margin)
 {
-    const int S = cx.S, C = cx.C, lane = cx.lane;
-    u64 headbits = 0;
-    for (int s = 0; s < cx.K; ++s) {
-        int h = lane_value(hc, s);
-        if (h >= 0 && (h & 63) == lane) headbits |= 1ull << (h >> 6);
-    }
+    const int S = cx.S, C = cx.C, K = cx.K, lane = cx.lane;
+    const int myT = lane < K ? cx.tclk[lane] : 0, myH = lane < K ? hc : -1;
+    constexpr int U = 5;
     u64 fr = 0;
-    for (int k = 0; k < cx.cpl; ++k) {
-        int c = lane + 64 * k;
-        if (c >= C) continue;
-        int y = div_size(c, cx.rcpS), x = c - y * S;
-        if (y < margin || x < margin || y > S - 1 - margin || x > S - 1 - margin) continue;
-        if (cx.food[c] || ((headbits >> k) & 1)) continue;
-        bool occ = false;
-#pragma unroll 4
-        for (int s = 0; s < cx.K; ++s) occ |= BV(cx, s, c) > 0;
-        if (!occ) fr |= 1ull << k;
+    for (int k0 = 0; k0 < cx.cpl; k0 += U) {
+        int cc[U];
+        u32 taken[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            cc[u] = min(lane + 64 * (k0 + u), C - 1); // (rows past the grid: the last cell again, dropped below)
+            taken[u] = cx.food[cc[u]];
+        }
+        for (int s = 0; s < K; ++s) {
+            const int T = lane_value(myT, s), H = lane_value(myH, s);
+            const unsigned short *b = cx.body + s * C;
+            u32 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) v[u] = b[cc[u]];
+#pragma unroll
+            for (int u = 0; u < U; ++u) taken[u] |= (u32)((int)(v[u] & VMASK) > T) | (u32)(cc[u] == H);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int c = lane + 64 * (k0 + u);
+            const int y = div_size(cc[u], cx.rcpS), x = cc[u] - y * S;
+            const bool inside = c < C && y >= margin && x >= margin && y <= S - 1 - margin && x <= S - 1 - margin;
+            if (inside && taken[u] == 0) fr |= 1ull << (k0 + u);
+        }
     }
     return fr;
 }
@@ -740,11 +757,29 @@ struct StepRes {
     bool snakecol, edgecol, all_done;
 };
 
+// v / 255.0f, correctly rounded, for the integers a pixel can hold: one multiplication by the rounded reciprocal and one
+// Newton step in fused arithmetic give the IEEE quotient for every integer in [0, 70 000) (checked exhaustively against the
+// division in exact rational arithmetic: tests/test_div255.py); anything else takes the division itself (~11 instructions, three
+// per pixel: a tenth of the VALU work of a step with partial_n observations).
+__device__ __forceinline__ float div255(int v)
+{
+    const float x = (float)v;
+    if ((unsigned)v < 70000u) {
+        const float rc = 1.0f / 255.0f;
+        const float q = x * rc;
+        return __fmaf_rn(__fmaf_rn(-q, 255.0f, x), rc, q);
+    }
+    return x / 255.0f;
+}
+
 // 'partial_n' observation (:289-332): the crop of the env image (_get_env_images :194-227) around each living head.
 // Round 2 rendered the whole image into LDS (8 bytes per cell) and cropped it; the K windows hold K (2n+1)^2 cells —
-// 484 against the image's 625 at K = 4, 25 x 25, partial_5 — so the pixels are now computed for the (agent, window cell)
-// PAIRS directly, 64 per pass with no idle lanes: no image buffer (5 KB of LDS per env less: 4096 envs of cfg4' are
-// resident in one round instead of 1.33), no image write + read, the same pixel function of the cell as before.
+// 484 against the image's 625 at K = 4, 25 x 25, partial_5 — so the pixels are computed for the window cells directly: no
+// image buffer (5 KB of LDS per env less: 4096 envs of cfg4' are resident in one round instead of 1.33), no image write +
+// read.  Agent by agent (round 4): the observer's head cell, its row and column and "it is dead" are wave-uniform, a lane
+// only splits its window index into row and column — the (agent, window cell) pair form of round 3 gathered the observer's
+// words from LDS and divided three times per pixel pass; 18 000 of a step's 43 000 cycles at cfg4' (tools/multi_timeline.py
+// --rollout), VALU-bound.
 __device__ __forceinline__ void observe_partial(const Ctx &cx, const MultiArgs &p, float *__restrict__ obs,
                                                 long long env, const Snake &sn)
 {
@@ -753,8 +788,8 @@ __device__ __forceinline__ void observe_partial(const Ctx &cx, const MultiArgs &
         cx.colf[lane * 4 + 0] = (float)sn.col[0];
         cx.colf[lane * 4 + 1] = (float)sn.col[1];
         cx.colf[lane * 4 + 2] = (float)sn.col[2];
-        // :198 the brightening of a boosting snake; the SIGN carries "this observer is dead" (zeros, :320-323)
-        cx.colf[lane * 4 + 3] = (1.0f + 0.5f * (sn.boosted ? 1.0f : 0.0f)) * (sn.done ? -1.0f : 1.0f);
+        // :198 the brightening of a boosting snake
+        cx.colf[lane * 4 + 3] = 1.0f + 0.5f * (sn.boosted ? 1.0f : 0.0f);
         cx.hcell[lane] = sn.hc;
     }
     wave_lds_sync();
@@ -771,55 +806,61 @@ __device__ __forceinline__ void observe_partial(const Ctx &cx, const MultiArgs &
         }
     };
     four(0);
-    const int W = 2 * n + 1, W2 = W * W, pairs = K * W2;
-    const float rcpW = 1.0f / (float)W, rcpW2 = 1.0f / (float)W2;
+    const int W = 2 * n + 1, W2 = W * W;
+    const float rcpW = 1.0f / (float)W;
     const long long agent_stride = p.N * p.obs_elems;
     float *const o_env = obs + env * p.obs_elems;
-    for (int idx = lane; idx < pairs; idx += 64) {
-        const int a = div_size(idx, rcpW2), w = idx - a * W2;
-        const int wy = div_size(w, rcpW), wx = w - wy * W;
-        const int h = cx.colf[a * 4 + 3] < 0.0f ? -1 : cx.hcell[a];
-        const int hy = h >= 0 ? div_size(h, cx.rcpS) : 0, hx = h - hy * S;
-        const int y = hy - n + wy, x = hx - n + wx;
-        float r = 0.0f, g = 0.0f, b = 0.0f; // dead snakes (:320-323) and the zero padding (:302)
-        if (h >= 0 && y >= 0 && y < S && x >= 0 && x < S) {
-            const int c = y * S + x;
-            float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;
-            for (int s0 = 0; s0 < K; s0 += 4) {
-                if (K > 4) four(s0); // more than four snakes: the registers are re-filled per pass
-                unsigned short bv[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) bv[j] = cx.body[min(s0 + j, K - 1) * C + c];
-                u32 mb = 0, mh = 0;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    mb |= (u32)((int)(bv[j] & VMASK) > tk[j]) << j;
-                    mh |= (u32)(hk[j] == c) << j;
-                }
-                for (u32 m = mb | mh; m; m &= m - 1) {
-                    const int j = __ffs((int)m) - 1, s = s0 + j;
-                    // :197 `body.float() * 1/3 + head.float() * 1/3`: 1.0f / 3.0f is the correctly rounded quotient the
-                    // two IEEE divisions gave; a snake that is not on the cell adds inten = 0, i.e. nothing
-                    const float third = 1.0f / 3.0f;
-                    float inten = (((mb >> j) & 1u) ? third : 0.0f) + (((mh >> j) & 1u) ? third : 0.0f);
-                    inten *= fabsf(cx.colf[s * 4 + 3]);
-                    a0 += inten * cx.colf[s * 4 + 0];
-                    a1 += inten * cx.colf[s * 4 + 1];
-                    a2 += inten * cx.colf[s * 4 + 2];
-                }
-            }
-            int ri = (int)a0, gi = (int)a1, bi = (int)a2;     // :206 .short() truncates
-            if (cx.food[c]) ri += 255;                          // :208-209
-            if (ri == 0 && gi == 0 && bi == 0) ri = gi = bi = 255; // :214-219
-            if (y == 0 || x == 0 || y == S - 1 || x == S - 1) ri = gi = bi = 0; // :225
-            r = (float)ri / 255.0f;
-            g = (float)gi / 255.0f;
-            b = (float)bi / 255.0f;
+    const u64 dead = ballot(lane < K && sn.done); // a dead observer sees zeros (:320-323)
+    for (int a = 0; a < K; ++a) {
+        float *const o = (float *)uniform64((long long)(o_env + (long long)a * agent_stride));
+        const int h = ((dead >> a) & 1ull) ? -1 : lane_value(sn.hc, a);
+        if (h < 0) {
+            for (int w = lane; w < W2; w += 64) { o[w] = 0.0f; o[W2 + w] = 0.0f; o[2 * W2 + w] = 0.0f; }
+            continue;
         }
-        float *o = o_env + (long long)a * agent_stride;
-        o[w] = r;
-        o[W2 + w] = g;
-        o[2 * W2 + w] = b;
+        const int hy = div_size(h, cx.rcpS), hx = h - hy * S; // (uniform)
+        for (int w = lane; w < W2; w += 64) {
+            const int wy = div_size(w, rcpW), wx = w - wy * W;
+            const int y = hy - n + wy, x = hx - n + wx;
+            float r = 0.0f, g = 0.0f, b = 0.0f; // the zero padding (:302)
+            if (y >= 0 && y < S && x >= 0 && x < S) {
+                const int c = y * S + x;
+                float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;
+                for (int s0 = 0; s0 < K; s0 += 4) {
+                    if (K > 4) four(s0); // more than four snakes: the registers are re-filled per pass
+                    unsigned short bv[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) bv[j] = cx.body[min(s0 + j, K - 1) * C + c];
+                    u32 mb = 0, mh = 0;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        mb |= (u32)((int)(bv[j] & VMASK) > tk[j]) << j;
+                        mh |= (u32)(hk[j] == c) << j;
+                    }
+                    for (u32 m = mb | mh; m; m &= m - 1) {
+                        const int j = __ffs((int)m) - 1, s = s0 + j;
+                        // :197 `body.float() * 1/3 + head.float() * 1/3`: 1.0f / 3.0f is the correctly rounded quotient the
+                        // two IEEE divisions gave; a snake that is not on the cell adds inten = 0, i.e. nothing
+                        const float third = 1.0f / 3.0f;
+                        float inten = (((mb >> j) & 1u) ? third : 0.0f) + (((mh >> j) & 1u) ? third : 0.0f);
+                        inten *= cx.colf[s * 4 + 3];
+                        a0 += inten * cx.colf[s * 4 + 0];
+                        a1 += inten * cx.colf[s * 4 + 1];
+                        a2 += inten * cx.colf[s * 4 + 2];
+                    }
+                }
+                int ri = (int)a0, gi = (int)a1, bi = (int)a2;     // :206 .short() truncates
+                if (cx.food[c]) ri += 255;                          // :208-209
+                if (ri == 0 && gi == 0 && bi == 0) ri = gi = bi = 255; // :214-219
+                if (y == 0 || x == 0 || y == S - 1 || x == S - 1) ri = gi = bi = 0; // :225
+                r = div255(ri);
+                g = div255(gi);
+                b = div255(bi);
+            }
+            o[w] = r;
+            o[W2 + w] = g;
+            o[2 * W2 + w] = b;
+        }
     }
     wave_lds_sync();
 }
@@ -1224,6 +1265,7 @@ __global__ __launch_bounds__(512) void multi_step_kernel(MultiArgs p)
     const int C = cx.C, K = cx.K, lane = cx.lane;
     const bool snake = lane < K;
     const int nG = (int)min((long long)wpb, p.N - env0);
+    WURM_TLS_INIT(cx);
     WURM_TLS(cx, 0);
     const u64 ring = grouped ? border_bits(cx) : 0ull;
     Snake sn;
@@ -1468,7 +1510,7 @@ __global__ __launch_bounds__(256) void multi_step_wg_kernel(MultiArgs p)
     if (env >= p.N) return; // the whole workgroup: the barriers below see every wave or none
     const Ctx cx = make_ctx(p, 0);
     const int C = cx.C, K = cx.K, lane = cx.lane;
-    if (wave == 0) WURM_TLS(cx, 0);
+    if (wave == 0) { WURM_TLS_INIT(cx); WURM_TLS(cx, 0); }
     float *foodp = p.foods + env * C, *headp = p.heads + env * K * C, *bodyp = p.bodies + env * K * C;
     // (the rebuild flag, wave 0's step inputs and the compact image are requested together: see multi_step_kernel)
     const int rebuild_byte = p.done_env != nullptr ? (int)p.done_env[env] : 0;
@@ -2054,9 +2096,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void m
     load_colour(p, agent, snake, sn);
     bool col_dirty = false;
     const int hc0 = sn.hc; // what HBM holds: for the sparse write-back at the end
+    WURM_TLS_INIT(cx);
 
     for (long long t = 0; t < p.T; ++t) {
         const u64 call = p.call + 2ull * (u64)t;
+        WURM_TLS(cx, 0); // (timeline: the segment that ends here is the previous step's reset)
         // Actions come from LDS, 64 steps at a time.  A global LOAD inside the step loop would queue behind the
         // observation stores of the whole CU — the vector memory pipeline is in order — and every step would wait for
         // the store backlog to drain: that, not the arithmetic, is why transition and observation time used to add up.
@@ -2078,7 +2122,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void m
             a = (b & 8) ? 4 + d4 : d4; // same a % 4 and a > 3 as the caller's value (a > 3 implies a % 4 >= 0)
         }
         StepRes r;
+        WURM_TLS(cx, 2); // actions decoded
         multi_step_body(cx, p, env, env_id, call, a, sn, r, t * p.N * C, t * KN, t * p.N);
+        WURM_TLS(cx, 7);
         if (snake) {
             const long long am = (long long)lane * p.N + env;
             float *of = p.am_f32 + t * 3 * KN;
@@ -2097,7 +2143,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void m
             snap_write(cx, sn.hc, cx.snap + (t & 1) * C);
             workgroup_handoff();
         } else if (p.obs_mode != WURM_OBS_NONE) {
+            WURM_TLS(cx, 8); // outputs stored
             observe(cx, p, p.obs + t * KN * p.obs_elems, env, sn);
+            WURM_TLS(cx, 9); // observation issued
         }
         rebase_clocks(cx);
 
@@ -2128,6 +2176,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void m
     // only what may differ from HBM: body cells that have held a value since the load (DIRTY survives deletions, rebuilds
     // and re-bases), the head cell of each snake, food cells that changed
     store_env(cx, foodp, headp, bodyp, fbits0, hc0, sn.hc, false);
+#ifdef WURM_TIMELINE
+    if (!TWO && p.obs_mode != WURM_OBS_NONE) WURM_TLA_STORE(cx, p.obs + env * p.obs_elems); // (step 0, agent 0: garbage by construction)
+#endif
 }
 
 
@@ -2725,6 +2776,11 @@ static int multi_layout(MultiArgs &p, bool need_img, int need_snap)
     p.off_snap = -1;
     if (need_snap) { p.off_snap = off; off += need_snap * ((2 * C + 15) & ~15); }
     p.off_acts = off; off += 64 * K;
+    off = (off + 15) & ~15;
+    p.off_tl = p.off_acts;
+#ifdef WURM_TIMELINE
+    p.off_tl = off; off += 256;
+#endif
     p.lds_per_wave = (off + 15) & ~15;
     return p.lds_per_wave;
 }

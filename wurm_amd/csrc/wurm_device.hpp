@@ -213,27 +213,45 @@ __device__ __forceinline__ int tap_x(int i) { return i == 1 ? 1 : (i == 3 ? -1 :
             tl_o[4] = tl_4; tl_o[5] = tl_5; tl_o[6] = tl_6; tl_o[7] = tl_7;                                              \
         }                                                                                                                \
     } while (0)
-// MultiSnake per-call kernels (tools/multi_timeline.py): up to 16 stamps in LDS slots — the `acts` block of the wave's env,
-// which only rollouts use — so that device functions (step_middle, multi_step_body, class_write) can stamp too; the wave
-// copies them over the first 128 bytes of agent 0's observation of its env once its stores have drained.
+// MultiSnake kernels (tools/multi_timeline.py): 32 eight-byte slots of LDS per env (Ctx::tl; multi_layout reserves them in the
+// timeline build only) so that device functions (step_middle, multi_step_body, class_write) can stamp too.  WURM_TLS(cx, k)
+// writes the stamp into slot k (per-call kernels: a wave passes each point once) AND adds the time since the wave's previous
+// stamp to slot 16 + k (rollouts: per-segment totals over the launch; slot 15's accumulator place, 31, holds the previous
+// stamp).  WURM_TLS_STORE copies slots 0 .. 15, WURM_TLA_STORE the totals 16 .. 31, over the first 128 bytes of `ptr` once
+// the wave's stores have drained.
 #define WURM_TLS(cx, k)                                                                                                  \
     do {                                                                                                                 \
         const unsigned long long tls_t = __builtin_amdgcn_s_memtime();                                                   \
-        if ((cx).lane == 0) ((unsigned long long *)(cx).acts)[k] = tls_t;                                                \
+        if ((cx).lane == 0) {                                                                                            \
+            (cx).tl[k] = tls_t;                                                                                          \
+            (cx).tl[16 + (k)] += tls_t - (cx).tl[31];                                                                    \
+            (cx).tl[31] = tls_t;                                                                                         \
+        }                                                                                                                \
+    } while (0)
+#define WURM_TLS_INIT(cx)                                                                                                \
+    do {                                                                                                                 \
+        if ((cx).lane < 32) (cx).tl[(cx).lane] = (cx).lane == 31 ? __builtin_amdgcn_s_memtime() : 0ull;                  \
     } while (0)
 #define WURM_TLS_STORE(cx, ptr)                                                                                          \
     do {                                                                                                                 \
         __builtin_amdgcn_s_waitcnt(0);                                                                                   \
         WURM_TLS(cx, 15);                                                                                                \
         __builtin_amdgcn_s_waitcnt(0);                                                                                   \
-        if ((cx).lane < 16) ((unsigned long long *)(ptr))[(cx).lane] = ((unsigned long long *)(cx).acts)[(cx).lane];     \
+        if ((cx).lane < 16) ((unsigned long long *)(ptr))[(cx).lane] = (cx).tl[(cx).lane];                               \
+    } while (0)
+#define WURM_TLA_STORE(cx, ptr)                                                                                          \
+    do {                                                                                                                 \
+        __builtin_amdgcn_s_waitcnt(0);                                                                                   \
+        if ((cx).lane < 15) ((unsigned long long *)(ptr))[(cx).lane] = (cx).tl[16 + (cx).lane];                          \
     } while (0)
 #else
 #define WURM_TL_DECL
 #define WURM_TL(k)
 #define WURM_TL_STORE(ptr, lane)
 #define WURM_TLS(cx, k)
+#define WURM_TLS_INIT(cx)
 #define WURM_TLS_STORE(cx, ptr)
+#define WURM_TLA_STORE(cx, ptr)
 #endif
 
 } // namespace wurm
