@@ -40,8 +40,13 @@ bash $R/tools/pmc_percall.sh 65536 noobs > /dev/null
 cp $R/gpurun_out/pmc_percall/summary.json $OUT/${TAG}_percall_65536x9_resident_noobs_instmix_pmc.json
 # 5b. in-kernel timelines (needs `make -C wurm_amd/csrc timeline`) and the per-call loop with / without the mirror
 if [ -f $R/wurm_amd/libwurm_hip_timeline.so ]; then
-  for K in "--kernel lane_step" "--kernel resident --form ref" "--kernel resident --form noobs" "--kernel resident --form noobs --epw 16"; do
-    WURM_HIP_LIBRARY=$R/wurm_amd/libwurm_hip_timeline.so python3 $R/tools/kernel_timeline.py $K 2>/dev/null | grep -v amdgpu.ids >> $OUT/${TAG}_kernel_timeline.txt
+  rm -f $OUT/${TAG}_kernel_timeline.txt
+  for K in "--kernel lane_step" "--kernel resident --form ref" "--kernel resident --form noobs" "--kernel resident --form noobs --epw 16" "--kernel grid --envs 8192 --form noobs"; do
+    WURM_HIP_LIBRARY=$R/wurm_amd/libwurm_hip_timeline.so python3 $R/tools/kernel_timeline.py $K 2>&1 | grep -v amdgpu.ids >> $OUT/${TAG}_kernel_timeline.txt
+  done
+  # MultiSnake: the per-call step at cfg4 and at the speeds.py shape, the training-dynamics rollout (totals per step)
+  for K in "" "--speeds --snakes 10 --size 36" "--rollout 16"; do
+    WURM_HIP_LIBRARY=$R/wurm_amd/libwurm_hip_timeline.so python3 $R/tools/multi_timeline.py $K 2>&1 | grep -v amdgpu.ids >> $OUT/${TAG}_kernel_timeline.txt
   done
 fi
 python3 $R/tools/percall_sweep.py 2>/dev/null | grep -v amdgpu.ids > $OUT/${TAG}_percall_sweep.txt
