@@ -42,6 +42,14 @@ CFGS = {
 }
 
 
+def test_workgroup_kernel_whole_views_per_wave(hip):
+    """multi_step_wg_kernel deals the K agents' views to its four waves as (agent, half) items; bit 0 of
+    WURM_MULTI_GROUP_VARIANT selects whole views per wave (the A/B switch of tools/multi_speeds_percall.py): same bytes"""
+    from wurm_amd._lib import knobs
+    with knobs(WURM_MULTI_GROUP_VARIANT=1):
+        test_multi_step_reset_loop(hip, 4, 10, 36, 25, 'full', 'train')
+
+
 @pytest.mark.parametrize('N,K,S,T,mode,cfg', [
     (24, 2, 12, 120, 'full', 'default'),
     (10, 4, 25, 80, 'full', 'default'),        # BASELINE cfg4 shape

@@ -1324,8 +1324,15 @@ __global__ __launch_bounds__(512) void multi_step_kernel(MultiArgs p)
     if (grouped && p.grp_emit == 2) { // every wave for itself: its env's class codes -> its K agents' views (no barrier)
         workgroup_handoff(); // (the table)
         if (!active) return;
+        WURM_TLS(cx, 9);
         class_write<unsigned short>(cx, sn.hc, cx.snap, ring);
+        WURM_TLS(cx, 10);
+        WURM_TLS(cx, 11); // (no barrier in this form)
         grp_emit_group(p, p.obs + env * p.obs_elems - env0 * p.obs_elems, env0, 1, 0, 1, (const unsigned char *)cx.snap, 0, tab, lane);
+        WURM_TLS(cx, 12);
+#ifdef WURM_TIMELINE
+        if (p.obs_after == nullptr) WURM_TLS_STORE(cx, p.obs + env * p.obs_elems);
+#endif
         if (p.obs_after == nullptr) return;
         const bool touched = reset_for_obs_after(cx, p, env, sn, r);
         if (p.err_after != nullptr) {
