@@ -76,7 +76,8 @@ struct MultiArgs {
     // multi_rollout_group_kernel: offsets (bytes, from the start of the workgroup's LDS) of the env blocks, the two class
     // code buffers and the two output buffers, and the size of one env's share of each
     int grp_env0, grp_codes, grp_outs, grp_save, grp_code_bytes, grp_out_bytes;
-    int grp_variant; // multi_rollout_group_kernel, probe build only: bit 2 no observation stores, bit 3 no transition
+    int grp_variant; // WURM_MULTI_GROUP_VARIANT.  bit 0 (every build): multi_step_wg_kernel writes whole agent views per wave (A/B switch,
+                     // same bytes); multi_rollout_group_kernel, probe build only: bit 2 no observation stores, bit 3 no transition
     int grp_emit; // multi_step_kernel: the workgroup's waves write the 'full' observations together (grp_env0: the table)
 };
 

@@ -15,7 +15,7 @@ struct Options {
     long long grid_waves_per_cu;     // WURM_GRID_WAVES_PER_CU     residency of the clock-grid rollout (12)
     long long policy_generic;        // WURM_POLICY_GENERIC        1 = fused actor on the generic loop even on 9 x 9
     long long multi_group_min_envs;  // WURM_MULTI_GROUP_MIN_ENVS  MultiSnake 'full' rollout: grouped writer from this many envs
-    long long multi_group_variant;   // WURM_MULTI_GROUP_VARIANT   tuning / probe bits of that kernel (multi_snake.hip: grp_variant)
+    long long multi_group_variant;   // WURM_MULTI_GROUP_VARIANT   tuning / probe bits (multi_snake.hip: grp_variant; none changes a result in the shipped build)
     long long multi_group_step_wpb;  // WURM_MULTI_GROUP_STEP_WPB  per-call step: envs per workgroup of the grouped writer (-1 auto, 0 off)
     long long multi_group_shape;     // WURM_MULTI_GROUP_SHAPE     100 G + 10 W + waves per SIMD of that kernel (0 = automatic)
 };
