@@ -1257,11 +1257,16 @@ __global__ __launch_bounds__(512) void multi_step_kernel(MultiArgs p)
     const long long env0 = xcd_block(blockIdx.x, gridDim.x) * wpb, env = env0 + wave;
     const bool grouped = p.grp_emit != 0;
     float *const tab = (float *)(wurm_multi_lds + p.grp_env0); // (grouped: the colour table behind the envs' blocks)
+    const bool solo = p.grp_emit == 2; // every wave writes its own env's views
     if (grouped) {
         if (env0 >= p.N) return;
         grp_table_init(tab, (int)threadIdx.x);
+        // (solo: the table is handed over HERE, where the workgroup's waves still run together — a barrier behind the step
+        // would wait for the slowest of its envs)
+        if (solo) workgroup_handoff();
     } else if (env >= p.N) return;
     const bool active = env < p.N;
+    if (solo && !active) return;
     const Ctx cx = make_ctx(p, wave);
     const int C = cx.C, K = cx.K, lane = cx.lane;
     const bool snake = lane < K;
@@ -1273,8 +1278,39 @@ __global__ __launch_bounds__(512) void multi_step_kernel(MultiArgs p)
     StepRes r;
     bool clean = false;
     uint32_t m_step = MCHK_NOT_COMPUTED;
+    float *foodp = nullptr, *headp = nullptr, *bodyp = nullptr;
+    const bool mirrored = p.resident != nullptr, lazy = mirrored && p.resident_lazy != 0;
+    const bool from_mirror = mirrored && p.resident_valid != 0;
+    unsigned char *mp = nullptr;
+    auto fence = [] { wave_lds_sync(); };
+    u64 fbits0 = 0;
+    bool rebuild = false;
+    int t0 = 0, hc0 = -1;
+    // the stepped state back to memory: the check mask, the fp32 planes (unless the mirror is lazy), the mirror.  In front of
+    // the observation everywhere but in the solo form, where it follows it: nothing the observation needs depends on it, and
+    // in a launch that is a chain of latencies (section 4.11 item 7 of DESIGN.md) it was 5 900 cycles in front of the first
+    // observation store.
+    auto store_state = [&]() {
+        if (p.err != nullptr) {
+            if (clean) m_step = lds_check(cx, sn);
+            if (lane == 0) p.err[env] = m_step;
+        }
+        if (!lazy) {
+            if (from_mirror) { // (step_middle has read the lengths out of lmax)
+                if (snake) cx.lmax[lane] = t0;
+                wave_lds_sync();
+            }
+            store_env(cx, foodp, headp, bodyp, fbits0, hc0, sn.hc, rebuild, from_mirror); // a rebuilt env is stored whole
+        }
+        if (mirrored) {
+            const bool rebased = rebase_clocks(cx); // the clocks stay with the mirror from call to call
+            mirror_store(cx, mp, lane, 64, sn.hc, (snake && !sn.done) ? sn.L : 0, fence, // (a deleted snake's body reads all-zero)
+                         from_mirror && !rebuild && !rebased, fbits0);
+            wave_lds_sync();
+        }
+    };
     if (active) {
-    float *foodp = p.foods + env * C, *headp = p.heads + env * K * C, *bodyp = p.bodies + env * K * C;
+    foodp = p.foods + env * C; headp = p.heads + env * K * C; bodyp = p.bodies + env * K * C;
 
     // An env the postponed reset rebuilds is not read from the fp32 planes (as in multi_reset_kernel): the launch is one
     // round of waves and ends with its slowest env, and a rebuilt env — rebuild + whole-env store — is the slowest already.
@@ -1283,14 +1319,10 @@ __global__ __launch_bounds__(512) void multi_step_kernel(MultiArgs p)
     StepIn in;
     step_inputs(p, env, lane, in); // (requested here, used after the env's image has arrived)
     const int rebuild_byte = p.done_env != nullptr ? (int)p.done_env[env] : 0;
-    const bool mirrored = p.resident != nullptr, lazy = mirrored && p.resident_lazy != 0;
-    const bool from_mirror = mirrored && p.resident_valid != 0;
-    unsigned char *mp = mirrored ? p.resident + env * mirror_env_bytes(K, C) : nullptr;
-    auto fence = [] { wave_lds_sync(); };
-    u64 fbits0 = 0;
+    mp = mirrored ? p.resident + env * mirror_env_bytes(K, C) : nullptr;
     bool plain = false; // read from the fp32 planes, which held nothing the image cannot represent
     if (from_mirror) fbits0 = mirror_load(cx, mp, lane, 64, fence, !lazy);
-    const bool rebuild = uniform(rebuild_byte) != 0;
+    rebuild = uniform(rebuild_byte) != 0;
     if (!rebuild) {
         if (!from_mirror) fbits0 = load_env(cx, foodp, headp, bodyp, p.err != nullptr, plain);
     } else {
@@ -1298,39 +1330,21 @@ __global__ __launch_bounds__(512) void multi_step_kernel(MultiArgs p)
         if (snake) { cx.hcell[lane] = -1; cx.lmax[lane] = 0; cx.tclk[lane] = 0; } // the rest: multi_reset_grid(rebuild)
         wave_lds_sync();
     }
-    const int t0 = snake ? cx.tclk[lane] : 0; // the clocks as loaded (0 unless the state came from the mirror)
-    int hc0;
+    t0 = snake ? cx.tclk[lane] : 0; // the clocks as loaded (0 unless the state came from the mirror)
     WURM_TLS(cx, 1);
     step_middle(cx, p, env, rebuild, sn, r, hc0, &in);
     WURM_TLS(cx, 8);
     clean = from_mirror || rebuild || plain; // lds_check sees everything there is to check
-    if (p.err != nullptr) {
-        if (clean) m_step = lds_check(cx, sn);
-        if (lane == 0) p.err[env] = m_step;
+    if (!solo) store_state();
     }
-    if (!lazy) {
-        if (from_mirror) { // (step_middle has read the lengths out of lmax)
-            if (snake) cx.lmax[lane] = t0;
-            wave_lds_sync();
-        }
-        store_env(cx, foodp, headp, bodyp, fbits0, hc0, sn.hc, rebuild, from_mirror); // a rebuilt env is stored whole
-    }
-    if (mirrored) {
-        const bool rebased = rebase_clocks(cx); // the clocks stay with the mirror from call to call
-        mirror_store(cx, mp, lane, 64, sn.hc, (snake && !sn.done) ? sn.L : 0, fence, // (a deleted snake's body reads all-zero)
-                     from_mirror && !rebuild && !rebased, fbits0);
-        wave_lds_sync();
-    }
-    }
-    if (grouped && p.grp_emit == 2) { // every wave for itself: its env's class codes -> its K agents' views (no barrier)
-        workgroup_handoff(); // (the table)
-        if (!active) return;
+    if (solo) { // every wave for itself: its env's class codes -> its K agents' views (no barrier)
         WURM_TLS(cx, 9);
         class_write<unsigned short>(cx, sn.hc, cx.snap, ring);
         WURM_TLS(cx, 10);
         WURM_TLS(cx, 11); // (no barrier in this form)
         grp_emit_group(p, p.obs + env * p.obs_elems - env0 * p.obs_elems, env0, 1, 0, 1, (const unsigned char *)cx.snap, 0, tab, lane);
         WURM_TLS(cx, 12);
+        store_state();
 #ifdef WURM_TIMELINE
         if (p.obs_after == nullptr) WURM_TLS_STORE(cx, p.obs + env * p.obs_elems);
 #endif
@@ -1340,7 +1354,7 @@ __global__ __launch_bounds__(512) void multi_step_kernel(MultiArgs p)
             if (touched) m_step = clean ? lds_check(cx, sn) : MCHK_NOT_COMPUTED;
             if (lane == 0) p.err_after[env] = m_step;
         }
-        class_write<unsigned short>(cx, sn.hc, cx.snap, ring);
+        if (touched) class_write<unsigned short>(cx, sn.hc, cx.snap, ring); // (else: the codes of the stepped state are still there)
         grp_emit_group(p, p.obs_after + env * p.obs_elems - env0 * p.obs_elems, env0, 1, 0, 1, (const unsigned char *)cx.snap, 0, tab, lane);
         return;
     }
