@@ -424,6 +424,22 @@ int wurm_multi_rollout(float *foods, float *heads, float *bodies, uint8_t *dones
                        uint64_t call0, int64_t env_offset, const wurm_multi_inject *inject,
                        const wurm_multi_reset_inject *reset_inject, void *stream);
 
+/* wurm_multi_rollout (RNG mode) for a caller that keeps the compact mirror of wurm_multi_call (`resident`,
+ * wurm_multi_resident_bytes() bytes; same meaning of *resident_valid / resident_lazy as there): where the launch is served by
+ * the kernel that can keep it ('full' observations of at most 10 snakes, more than one step, a large batch) the state is
+ * read from the mirror when *resident_valid != 0 — 2 K + 1 bytes per cell instead of (1 + 2 K) fp32 planes — and the mirror
+ * describes the final state afterwards (*resident_valid = 1); foods / heads / bodies are then written only if
+ * resident_lazy == 0.  Any other shape runs wurm_multi_rollout on the fp32 planes: a lazy valid mirror is written out to
+ * them first (wurm_multi_resident_flush) and *resident_valid = 0 afterwards.  resident == NULL: wurm_multi_rollout.
+ * Replaces nothing in the reference (MultiSnake has no fused loop); it is to `env.rollout` what wurm_multi_step_packed's
+ * mirror is to `env.step` (multi_snake.py:462-731, 771-836 over T iterations). */
+int wurm_multi_rollout_resident(float *foods, float *heads, float *bodies, uint8_t *dones, int64_t *orientations,
+                                int16_t *colours, uint8_t *boost_this_step, const int64_t *actions, float *out_f32,
+                                uint8_t *out_u8, uint8_t *all_done, float *obs, int obs_mode, int obs_n, int64_t num_envs,
+                                int num_snakes, int size, int64_t num_steps, const wurm_multi_config *cfg, uint64_t seed,
+                                uint64_t call0, int64_t env_offset, void *resident, int *resident_valid, int resident_lazy,
+                                void *stream);
+
 /* MultiSnake._observe (multi_snake.py:283-334) */
 int wurm_multi_observe(const float *foods, const float *heads, const float *bodies, const uint8_t *dones,
                        const uint8_t *boost_this_step, const int16_t *colours, float *obs, int obs_mode, int obs_n,

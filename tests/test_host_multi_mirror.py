@@ -38,6 +38,20 @@ class _Lib(object):
         self.calls.append(('rollout', {}))
         return 0
 
+    rollout_keeps_mirror = False   # True: the batch is one the library's mirror-keeping rollout kernel serves
+
+    def wurm_multi_rollout_resident(self, *a):
+        resident, valid_addr, lazy = a[22], a[23], a[24]
+        valid = ctypes.c_int.from_address(valid_addr)
+        self.calls.append(('rollout_resident', dict(mirror=bool(resident), valid=bool(valid.value), lazy=bool(lazy))))
+        if self.rollout_keeps_mirror:
+            valid.value = 1
+        else:                        # the library's fallback: a lazy mirror is written out first, and it is stale afterwards
+            if lazy and valid.value:
+                self.calls.append(('flush', {}))
+            valid.value = 0
+        return 0
+
     def wurm_multi_resident_bytes(self, N, K, S):
         return self.mirror_bytes * int(getattr(N, 'value', N))
 
@@ -145,6 +159,37 @@ def test_other_entry_points(env_and_log):
     env.rollout(torch.zeros((2, K, N), dtype=torch.long))
     _step(env)
     assert not _steps(log)[-1]['valid']
+
+
+def test_rollout_on_the_mirror(env_and_log):
+    """env.rollout hands the mirror to wurm_multi_rollout_resident: nothing is written out in front of it, the mirror stays
+    current where the library's mirror-keeping kernel serves the batch, and is stale (a lazy one written out by the library
+    itself) where it does not"""
+    env, log = env_and_log
+    env._lib.rollout_keeps_mirror = True
+    env.rollout(torch.zeros((2, K, N), dtype=torch.long))                 # a fresh env: the rollout makes the mirror
+    assert _names(log) == ['rollout_resident'] and log[-1][1] == dict(mirror=True, valid=False, lazy=True)
+    _step(env)
+    assert _steps(log)[-1]['valid'] and _steps(log)[-1]['lazy']            # ... and the step reads it
+    env.rollout(torch.zeros((3, K, N), dtype=torch.long))
+    assert log[-1] == ('rollout_resident', dict(mirror=True, valid=True, lazy=True)) and 'flush' not in _names(log)
+    _, _, d, _ = _step(env)
+    env.reset(d['__all__'], return_observations=False)                    # postponed into the next launch ...
+    env.rollout(torch.zeros((2, K, N), dtype=torch.long))                 # ... which is not a step: applied first
+    assert _names(log)[-2:] == ['reset', 'rollout_resident']
+    b = env.bodies                                                        # the caller holds a tensor: eager from now on
+    _step(env)
+    env.rollout(torch.zeros((2, K, N), dtype=torch.long))
+    assert log[-1][1]['lazy'] is False
+    b[0, 0, 1, 1] = 3                                                     # an in-place edit is noticed by the rollout too
+    env.rollout(torch.zeros((2, K, N), dtype=torch.long))
+    assert log[-1][1]['valid'] is False
+    env._lib.rollout_keeps_mirror = False                                 # a batch the kernel does not serve
+    _step(env)
+    env.rollout(torch.zeros((2, K, N), dtype=torch.long))
+    _step(env)
+    assert not _steps(log)[-1]['valid']
+    assert env.mirror_state()['state'] in ('eager', 'lazy')
 
 
 def test_check_consistency_uses_the_masks_of_the_step_launch(env_and_log):

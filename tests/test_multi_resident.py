@@ -176,6 +176,80 @@ def test_class_loop_on_the_lazy_mirror_against_the_oracle(cfg_name, mode, shape)
         check_state('final')
 
 
+# ------------------------------------------------------------------ rollouts on the mirror (wurm_multi_rollout_resident)
+
+@pytest.mark.parametrize('cfg_name,mode,shape', [('default', 'full', (19, 4, 14, 9)), ('train', 'full', (10, 10, 36, 5)),
+                                                 ('dense', 'full', (21, 3, 12, 11)), ('train', 'full', (13, 4, 25, 7)),
+                                                 ('train', 'partial_5', (12, 4, 25, 8)), ('dense', 'partial_2', (9, 6, 14, 6)),
+                                                 ('default', 'full', (8, 12, 20, 5))])   # (12 snakes: no class codes)
+@pytest.mark.parametrize('group', [True, False])
+def test_class_rollouts_and_steps_interleaved_on_the_mirror(cfg_name, mode, shape, group):
+    """env.rollout on the resident mirror (wurm_multi_rollout_resident): fused rollouts and per-call steps take turns on the
+    same env object — the mirror made by a rollout is read by the next step and the other way round, lazily (the fp32
+    tensors are looked at only now and then), then with a tensor held by the caller (eager) and edited in place — every
+    output of every step and the state at the looks against the oracle.  The grouped writer ('full', at most 10 snakes, large
+    batches) and the one-wave-per-env rollout (crops, more snakes) keep the mirror; group=False with 'full' observations is
+    the two-wave form, which does not — the library writes a lazy mirror out itself and works on the tensors."""
+    import torch
+    cfg = CFGS[cfg_name]
+    (N, K, S, T), seed = shape, 41
+    with knobs(WURM_RESIDENT_MIN_ENVS=0, WURM_MULTI_GROUP_MIN_ENVS=0 if group else 1 << 40):
+        env = _class_env(N, K, S, seed, mode, cfg)
+        o = OracleBackend(seed=seed, env_offset=7)
+        st = _o.multi_empty_state(N, K, S)
+        st['colours'][...] = o.multi_colours(N, K, cfg['colour_mode'] == 'fixed', call=0)
+        o.call = 1
+        assert o.multi_reset(st, np.ones(N), cfg) == 0
+        g = torch.Generator().manual_seed(9)
+
+        def check_state(what):
+            _same(env.foods.cpu().numpy(), st['foods'], what + ' foods')
+            _same(env.heads.cpu().numpy(), st['heads'], what + ' heads')
+            _same(env.bodies.cpu().numpy(), st['bodies'], what + ' bodies')
+            _same(env.dones.cpu().numpy().astype(np.uint8), st['dones'], what + ' dones')
+            _same(env.orientations.cpu().numpy(), st['orientations'], what + ' orientations')
+
+        def rollout(what):
+            a = torch.randint(8, (T, K, N), generator=g)
+            out = env.rollout(a.cuda())
+            ref = o.multi_rollout(st, a.numpy(), cfg, mode)
+            _same(out['observations'].cpu().numpy().reshape(ref['obs'].shape), ref['obs'], what + ' obs')
+            _same(out['all_done'].cpu().numpy().astype(np.uint8), ref['all_done'], what + ' all_done')
+            _same(out['rewards'].cpu().numpy().transpose(0, 2, 1).reshape(T, -1), ref['rewards'].reshape(T, -1), what + ' rewards')
+            _same(out['size'].cpu().numpy().transpose(0, 2, 1).reshape(T, -1), ref['size'].reshape(T, -1), what + ' size')
+
+        def steps(n, what):
+            for t in range(n):
+                a = torch.randint(8, (K, N), generator=g)
+                ac = a.cuda()
+                obs, rew, dones, info = env.step({f'agent_{i}': ac[i] for i in range(K)})
+                r = o.multi_step(st, a.numpy(), cfg, mode)
+                for i in range(K):
+                    _same(obs[f'agent_{i}'].cpu().numpy(), r['obs'][i], f'{what} obs {i} t={t}')
+                _same(dones['__all__'].cpu().numpy().astype(np.uint8), r['all_done'], f'{what} all_done t={t}')
+                env.reset(dones['__all__'], return_observations=False)
+                o.multi_reset(st, r['all_done'], cfg)
+
+        rollout('first rollout (makes the mirror)')
+        kept = group or mode != 'full' or K > 10      # (else: the two-wave form, which works on the tensors)
+        assert env._mirror is not None and env._mc.resident_lazy == 1 and env._mc.resident_valid == (1 if kept else 0)
+        steps(4, 'steps after a rollout')
+        rollout('second rollout')                # (a postponed reset is pending: applied first)
+        rollout('third rollout')
+        steps(3, 'steps again')
+        check_state('first look')                # written out; the lazy form may end here
+        rollout('rollout after a look')
+        alias = env.foods                        # the caller holds a tensor: eager from now on
+        assert env._mc.resident_lazy == 0
+        rollout('eager rollout')
+        check_state('after the eager rollout')
+        alias[1, 0, 3, 3] = 1.0                  # an in-place edit through the alias, found by the version counter
+        st['foods'][1, 0, 3, 3] = 1.0
+        rollout('rollout after an edit')
+        steps(3, 'steps at the end')
+        check_state('final')
+
+
 # ------------------------------------------------------------------ check_consistency inside the step launch
 
 @pytest.mark.parametrize('cfg_name,mode,shape', [('default', 'full', (24, 4, 14, 120)), ('train', 'partial_3', (20, 3, 12, 120)),

@@ -25,7 +25,7 @@ SYMBOLS = [
     'wurm_single_step_reset', 'wurm_single_resident_bytes', 'wurm_single_resident_size', 'wurm_single_resident_flush', 'wurm_grid_step_reset', 'wurm_single_step_slot', 'wurm_grid_step_slot',
     'wurm_grid_step', 'wurm_grid_reset', 'wurm_grid_observe', 'wurm_grid_rollout',
     'wurm_multi_obs_elems', 'wurm_multi_step', 'wurm_multi_step_reset', 'wurm_multi_step_packed', 'wurm_multi_resident_bytes', 'wurm_multi_resident_size', 'wurm_multi_resident_flush', 'wurm_multi_reset', 'wurm_multi_observe', 'wurm_multi_check',
-    'wurm_multi_rollout',
+    'wurm_multi_rollout', 'wurm_multi_rollout_resident',
     'wurm_multi_colours', 'wurm_orientations',
     'wurm_a2c_returns', 'wurm_a2c_returns_backward', 'wurm_single_stats', 'wurm_single_policy_rollout',
 ]

@@ -78,6 +78,7 @@ struct MultiArgs {
     int grp_env0, grp_codes, grp_outs, grp_save, grp_code_bytes, grp_out_bytes;
     int grp_variant; // WURM_MULTI_GROUP_VARIANT.  bit 0 (every build): multi_step_wg_kernel writes whole agent views per wave (A/B switch,
                      // same bytes); multi_rollout_group_kernel, probe build only: bit 2 no observation stores, bit 3 no transition
+    int resident_used; // out (host side): the rollout launch kept the mirror (multi_rollout_group_kernel)
     int grp_emit; // multi_step_kernel: the workgroup's waves write the 'full' observations together (grp_env0: the table)
 };
 
@@ -2108,7 +2109,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void m
     const long long agent = env * K + lane, KN = (long long)K * p.N;
     float *foodp = p.foods + env * C, *headp = p.heads + env * K * C, *bodyp = p.bodies + env * K * C;
 
-    const u64 fbits0 = load_env(cx, foodp, headp, bodyp);
+    // (the caller's compact mirror when it describes the state — wurm_multi_rollout_resident — else the fp32 planes; the writer
+    // wave of the TWO form never gets here with a mirror: that form works on the planes)
+    const bool mirrored = !TWO && p.resident != nullptr, from_mirror = mirrored && p.resident_valid != 0;
+    unsigned char *const mp = mirrored ? p.resident + env * mirror_env_bytes(K, C) : nullptr;
+    const u64 fbits0 = from_mirror ? mirror_load(cx, mp, lane, 64, [] { wave_lds_sync(); }, false) : load_env(cx, foodp, headp, bodyp);
     Snake sn;
     sn.hc = snake ? cx.hcell[lane] : -1;
     sn.L = snake ? cx.lmax[lane] : 0;
@@ -2196,8 +2201,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void m
     }
     wave_lds_sync();
     // only what may differ from HBM: body cells that have held a value since the load (DIRTY survives deletions, rebuilds
-    // and re-bases), the head cell of each snake, food cells that changed
-    store_env(cx, foodp, headp, bodyp, fbits0, hc0, sn.hc, false);
+    // and re-bases), the head cell of each snake, food cells that changed — everything when the state came from the mirror,
+    // nothing while the mirror is lazy
+    if (!(mirrored && p.resident_lazy)) store_env(cx, foodp, headp, bodyp, fbits0, hc0, sn.hc, from_mirror);
+    if (mirrored) {
+        (void)rebase_clocks(cx);
+        mirror_store(cx, mp, lane, 64, sn.hc, (snake && !sn.done) ? sn.L : 0, [] { wave_lds_sync(); });
+        wave_lds_sync();
+    }
 #ifdef WURM_TIMELINE
     if (!TWO && p.obs_mode != WURM_OBS_NONE) WURM_TLA_STORE(cx, p.obs + env * p.obs_elems); // (step 0, agent 0: garbage by construction)
 #endif
@@ -2528,7 +2539,13 @@ __global__ __launch_bounds__(64 * (G / EPS + W)) __attribute__((amdgpu_waves_per
         if (env >= p.N) break;
         const Ctx cx = make_ctx(p, g, p.grp_env0);
         const long long agent = env * K + lane;
-        (void)load_env(cx, p.foods + env * C, p.heads + env * K * C, p.bodies + env * K * C);
+        // the caller's compact mirror (wurm_multi_rollout_resident), when it describes the state: 2 K + 1 bytes per cell
+        // instead of (1 + 2 K) fp32 planes — 23 MB against 92 at cfg4, 110 against 446 at the speeds.py shape, which is a
+        // tenth of a 4-step launch there
+        if (p.resident != nullptr && p.resident_valid)
+            (void)mirror_load(cx, p.resident + env * mirror_env_bytes(K, C), lane, 64, [] { wave_lds_sync(); }, false);
+        else
+            (void)load_env(cx, p.foods + env * C, p.heads + env * K * C, p.bodies + env * K * C);
         Snake sn;
         sn.hc = snake ? cx.hcell[lane] : -1;
         sn.L = snake ? cx.lmax[lane] : 0;
@@ -2663,7 +2680,17 @@ __global__ __launch_bounds__(64 * (G / EPS + W)) __attribute__((amdgpu_waves_per
             const int c = lane + 64 * k;
             if (c < C && cx.food[c]) cur |= 1ull << k;
         }
-        store_env(cx, p.foods + env * C, p.heads + env * K * C, p.bodies + env * K * C, ~cur, hc0, sn.hc, false);
+        // the fp32 planes: not at all while the mirror is lazy; whole when the state came from the mirror (the DIRTY marks
+        // only cover what was written since a load from the planes); else what changed
+        const bool from_mirror = p.resident != nullptr && p.resident_valid;
+        if (!(p.resident != nullptr && p.resident_lazy))
+            store_env(cx, p.foods + env * C, p.heads + env * K * C, p.bodies + env * K * C, ~cur, hc0, sn.hc, from_mirror);
+        if (p.resident != nullptr) {
+            (void)rebase_clocks(cx);
+            mirror_store(cx, p.resident + env * mirror_env_bytes(K, C), lane, 64, sn.hc, (snake && !sn.done) ? sn.L : 0,
+                         [] { wave_lds_sync(); });
+            wave_lds_sync();
+        }
     }
 }
 
@@ -2818,17 +2845,18 @@ static bool allow_lds(const void *kernel, size_t bytes)
     return hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess;
 }
 
-static int multi_launch(MKind kind, MultiArgs &p, void *stream)
+struct GroupShape { int G, W, eps, occ; const void *fn; };
+
+// The shape of multi_rollout_group_kernel that serves this rollout ('full' observations of at most 10 snakes, several steps,
+// a large batch), or nullptr; q: p with the kernel's LDS layout filled in, bytes: its dynamic LDS.
+static const GroupShape *multi_group_shape(const MultiArgs &p, MultiArgs &q, size_t &bytes)
 {
-    if (p.N == 0) return WURM_OK;
-    // 'full' observations of at most 10 snakes go through a per-cell class code in LDS (observe_full_snap); rollouts
-    // double-buffer it between a stepping and a writing wave (multi_rollout_kernel<true>)
     const bool snap = p.obs_mode == WURM_OBS_DEFAULT && p.K <= SNAP_MAX_SNAKES;
-    const bool two = kind == MK_ROLLOUT && snap && p.T > 1;
-    if (two && p.K <= GRP_MAX_SNAKES32 && p.N >= opt.multi_group_min_envs) {
+    if (!(snap && p.T > 1 && p.K <= GRP_MAX_SNAKES32 && p.N >= opt.multi_group_min_envs)) return nullptr;
+    {
         const bool wide = p.K > GRP_MAX_SNAKES; // 32-bit class words, one buffer
         // large batches: G consecutive envs per workgroup, one linear observation run per agent (multi_rollout_group_kernel)
-        MultiArgs q = p;
+        q = p;
         const int lds_env = multi_layout(q, false, 0), C = p.S * p.S;
         q.grp_code_bytes = ((wide ? 4 : 2) * C + 15) & ~15;
         const int nbuf = wide ? 1 : 2;
@@ -2841,7 +2869,7 @@ static int multi_launch(MKind kind, MultiArgs &p, void *stream)
         };
         // shape: G envs, W writer waves, EPS envs per stepper wave, OCC waves per SIMD (option WURM_MULTI_GROUP_SHAPE =
         // 1000 G + 100 W + 10 EPS + OCC picks one of the compiled shapes; 0 = automatic: the first that fits)
-        struct Shape { int G, W, eps, occ; const void *fn; };
+        typedef GroupShape Shape;
         static const Shape wide_shapes[] = { // 6 .. 10 snakes (the first that fits)
             {4, 10, 1, 4, (const void *)multi_rollout_group_kernel<4, 10, 1, 4, true>},
             {4, 5, 1, 4, (const void *)multi_rollout_group_kernel<4, 5, 1, 4, true>},
@@ -2868,20 +2896,37 @@ static int multi_launch(MKind kind, MultiArgs &p, void *stream)
             if (opt.multi_group_shape ? (1000 * c.G + 100 * c.W + 10 * c.eps + c.occ == opt.multi_group_shape && fits)
                                       : (fits && (c.G == 4 || 2 * total(8) <= LDS_MAX_BYTES))) { sh = &c; break; }
         }
-        if (sh) {
-            const int G = sh->G, W = sh->W;
-            q.grp_env0 = GRP_TAB_BYTES;
-            q.grp_codes = q.grp_env0 + G * lds_env;
-            q.grp_outs = q.grp_codes + nbuf * G * q.grp_code_bytes;
-            q.grp_save = q.grp_outs + nbuf * G * q.grp_out_bytes;
-            const size_t bytes = (size_t)total(G);
-            const dim3 gg((unsigned)((p.N + G - 1) / G)), bb(64 * (G / sh->eps + W));
+        if (!sh) return nullptr;
+        const int G = sh->G;
+        q.grp_env0 = GRP_TAB_BYTES;
+        q.grp_codes = q.grp_env0 + G * lds_env;
+        q.grp_outs = q.grp_codes + nbuf * G * q.grp_code_bytes;
+        q.grp_save = q.grp_outs + nbuf * G * q.grp_out_bytes;
+        bytes = (size_t)total(G);
+        return sh;
+    }
+}
+
+static int multi_launch(MKind kind, MultiArgs &p, void *stream)
+{
+    if (p.N == 0) return WURM_OK;
+    // 'full' observations of at most 10 snakes go through a per-cell class code in LDS (observe_full_snap); rollouts
+    // double-buffer it between a stepping and a writing wave (multi_rollout_kernel<true>)
+    const bool snap = p.obs_mode == WURM_OBS_DEFAULT && p.K <= SNAP_MAX_SNAKES;
+    const bool two = kind == MK_ROLLOUT && snap && p.T > 1;
+    if (kind == MK_ROLLOUT) {
+        // large batches: G consecutive envs per workgroup, one linear observation run per agent (multi_rollout_group_kernel)
+        MultiArgs q;
+        size_t bytes = 0;
+        if (const GroupShape *sh = multi_group_shape(p, q, bytes)) {
+            const dim3 gg((unsigned)((p.N + sh->G - 1) / sh->G)), bb(64 * (sh->G / sh->eps + sh->W));
             (void)hipGetLastError();
             if (!allow_lds(sh->fn, bytes)) return WURM_ERR_HIP;
             q.grp_variant = (int)opt.multi_group_variant;
             void *args[] = {&q};
             ++launch_count;
             if (hipLaunchKernel(sh->fn, gg, bb, args, bytes, (hipStream_t)stream) != hipSuccess) return WURM_ERR_HIP;
+            p.resident_used = 1; // (the kernel keeps the caller's mirror, if one was given)
             return hipGetLastError() == hipSuccess ? WURM_OK : WURM_ERR_HIP;
         }
     }
@@ -3135,6 +3180,57 @@ int wurm_multi_rollout(float *foods, float *heads, float *bodies, uint8_t *dones
     if (inject) { p.inj = *inject; p.has_inj = 1; }
     if (reset_inject) { p.rinj = *reset_inject; p.has_rinj = 1; }
     if ((inject == nullptr) != (reset_inject == nullptr)) return WURM_ERR_INVALID_ARG; // replay needs both tapes
+    return multi_launch(MK_ROLLOUT, p, stream);
+}
+
+int wurm_multi_rollout_resident(float *foods, float *heads, float *bodies, uint8_t *dones, int64_t *orientations,
+                                int16_t *colours, uint8_t *boost_this_step, const int64_t *actions, float *out_f32,
+                                uint8_t *out_u8, uint8_t *all_done, float *obs, int obs_mode, int obs_n, int64_t num_envs,
+                                int num_snakes, int size, int64_t num_steps, const wurm_multi_config *cfg, uint64_t seed,
+                                uint64_t call0, int64_t env_offset, void *resident, int *resident_valid, int resident_lazy,
+                                void *stream)
+{
+    if (resident == nullptr)
+        return wurm_multi_rollout(foods, heads, bodies, dones, orientations, colours, boost_this_step, actions, out_f32, out_u8,
+                                  all_done, obs, obs_mode, obs_n, num_envs, num_snakes, size, num_steps, cfg, seed, call0,
+                                  env_offset, nullptr, nullptr, stream);
+    if (resident_valid == nullptr) return WURM_ERR_INVALID_ARG;
+    int rc = multi_check_args(num_envs, num_snakes, size, obs_mode, obs_n, obs);
+    if (rc) return rc;
+    if (!cfg || num_steps < 0) return WURM_ERR_INVALID_ARG;
+    if (size < 5) return WURM_ERR_UNSUPPORTED;
+    if (num_envs > 0 && (!foods || !heads || !bodies || !dones || !orientations || !colours)) return WURM_ERR_INVALID_ARG;
+    if (num_envs > 0 && num_steps > 0 && (!actions || !out_f32 || !out_u8 || !all_done)) return WURM_ERR_INVALID_ARG;
+    if (num_steps == 0 || num_envs == 0) return WURM_OK;
+    MultiArgs p = {};
+    p.foods = foods; p.heads = heads; p.bodies = bodies; p.dones = dones; p.orientations = (long long *)orientations;
+    p.colours = colours; p.boost_state = boost_this_step; p.actions = (const long long *)actions; p.am_f32 = out_f32;
+    p.am_u8 = out_u8; p.all_done = all_done; p.obs = obs; p.obs_mode = obs_mode; p.obs_n = obs_n;
+    p.obs_elems = multi_obs_elems(obs_mode, obs_n, size); p.N = num_envs; p.K = num_snakes; p.S = size; p.T = num_steps;
+    p.cfg = *cfg; p.seed = seed; p.call = call0; p.env_offset = env_offset;
+    MultiArgs q;
+    size_t bytes = 0;
+    // the kernels that keep a mirror: the grouped writer, and the one-wave-per-env rollout (everything but 'full'
+    // observations of at most 10 snakes over several steps in a small batch, which goes to the two-wave form)
+    const bool two = obs_mode == WURM_OBS_DEFAULT && num_snakes <= SNAP_MAX_SNAKES && num_steps > 1;
+    if (multi_group_shape(p, q, bytes) != nullptr || !two) {
+        p.resident = (unsigned char *)resident;
+        p.resident_valid = *resident_valid != 0;
+        p.resident_lazy = resident_lazy != 0;
+        rc = multi_launch(MK_ROLLOUT, p, stream);
+        if (rc == WURM_OK) *resident_valid = 1;
+        return rc;
+    }
+    // any other rollout kernel works on the fp32 planes: a lazy mirror is written out to them first, and it is stale afterwards
+    if (resident_lazy && *resident_valid) {
+        MultiArgs f = {};
+        f.foods = foods; f.heads = heads; f.bodies = bodies; f.N = num_envs; f.K = num_snakes; f.S = size;
+        f.resident = (unsigned char *)resident;
+        (void)hipGetLastError();
+        WURM_LAUNCH(multi_flush_kernel, dim3((unsigned)f.N), dim3(256), 0, (hipStream_t)stream, f);
+        if (hipGetLastError() != hipSuccess) return WURM_ERR_HIP;
+    }
+    *resident_valid = 0;
     return multi_launch(MK_ROLLOUT, p, stream);
 }
 

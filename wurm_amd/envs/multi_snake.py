@@ -500,6 +500,41 @@ class MultiSnake(object):
 
     # ------------------------------------------------------------------ step
 
+    def _ensure_call(self):
+        """the argument block of the per-call launches (wurm_multi_call), made on first use — and with it the resident
+        mirror of foods / heads / bodies, where the library offers one for this batch (or the caller asked for one)"""
+        c = self._mc
+        if c is not None:
+            return c
+        N, K, S, dev = self.num_envs, self.num_snakes, self.size, self.device
+        c = self._mc = _lib.MultiCall()
+        c.num_envs, c.env_offset, c.seed = N, self.env_offset, _lib.u64(self.seed)
+        c.num_snakes, c.size = K, S
+        self._pend = torch.zeros(N, dtype=torch.uint8, device=dev)
+        c.all_done_copy = self._pend.data_ptr()
+        self._mc_addr = ctypes.addressof(c)
+        self._mc_cfg = None
+        self._mc_fn = _lib.multi_step_fn()
+        self._get_device, self._get_stream = _lib.accessors()
+        ks = [str(i) for i in range(K)]
+        self._keys = tuple([p + k for k in ks] for p in ('agent_', 'snake_collision_', 'edge_collision_', 'food_',
+                                                         'boost_', 'size_'))
+        # the resident mirror of foods / heads / bodies (large batches): the launch reads it instead of them;
+        # lazy (they are not written either) as long as the caller has never got hold of one of them
+        size_fn = _lib.lib().wurm_multi_resident_bytes if self._resident_policy is None else \
+            _lib.lib().wurm_multi_resident_size
+        nbytes = 0 if self._mirror_off else int(size_fn(_lib.i64(N), K, S))
+        if not self._mirror_off:
+            self._mirror_why = 'on' if nbytes > 0 else 'batch below the threshold (2^20 cells), or shape not served'
+        if nbytes > 0:
+            self._mirror = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            c.resident, c.resident_valid = self._mirror.data_ptr(), 0
+            c.resident_lazy = int(self._lazy_mirror and not self._watched)
+            # check_consistency()'s masks can come out of the step launch (the image it steps is its own): asked for
+            # once the caller has called check_consistency(), dropped again if it stops doing so
+            self._chk = torch.empty((2, N), dtype=torch.int32, device=dev)
+        return c
+
     def step(self, actions: Dict[str, torch.Tensor]) -> Tuple[Dict[str, torch.Tensor], dict, dict, dict]:
         """reference :462-731"""
         if len(actions) != self.num_snakes:
@@ -532,34 +567,7 @@ class MultiSnake(object):
         self._pending = False  # consumed by this launch (the raw attributes below do not flush)
         call = self._call
         try:  # if anything below raises, the postponed reset and the counter are still owed
-            c = self._mc
-            if c is None:
-                c = self._mc = _lib.MultiCall()
-                c.num_envs, c.env_offset, c.seed = N, self.env_offset, _lib.u64(self.seed)
-                c.num_snakes, c.size = K, S
-                self._pend = torch.zeros(N, dtype=torch.uint8, device=dev)
-                c.all_done_copy = self._pend.data_ptr()
-                self._mc_addr = ctypes.addressof(c)
-                self._mc_cfg = None
-                self._mc_fn = _lib.multi_step_fn()
-                self._get_device, self._get_stream = _lib.accessors()
-                ks = [str(i) for i in range(K)]
-                self._keys = tuple([p + k for k in ks] for p in ('agent_', 'snake_collision_', 'edge_collision_', 'food_',
-                                                                 'boost_', 'size_'))
-                # the resident mirror of foods / heads / bodies (large batches): the launch reads it instead of them;
-                # lazy (they are not written either) as long as the caller has never got hold of one of them
-                size_fn = _lib.lib().wurm_multi_resident_bytes if self._resident_policy is None else \
-                    _lib.lib().wurm_multi_resident_size
-                nbytes = 0 if self._mirror_off else int(size_fn(_lib.i64(N), K, S))
-                if not self._mirror_off:
-                    self._mirror_why = 'on' if nbytes > 0 else 'batch below the threshold (2^20 cells), or shape not served'
-                if nbytes > 0:
-                    self._mirror = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-                    c.resident, c.resident_valid = self._mirror.data_ptr(), 0
-                    c.resident_lazy = int(self._lazy_mirror and not self._watched)
-                    # check_consistency()'s masks can come out of the step launch (the image it steps is its own): asked for
-                    # once the caller has called check_consistency(), dropped again if it stops doing so
-                    self._chk = torch.empty((2, N), dtype=torch.int32, device=dev)
+            c = self._ensure_call()
             self._steps += 1
             if self._chk is not None:
                 want = self._check_calls > 0 and self._steps - self._check_step <= 64
@@ -657,18 +665,42 @@ class MultiSnake(object):
         if not actions.is_contiguous() or actions.device != dev:
             raise RuntimeError('rollout actions must be a contiguous device tensor')
         T = actions.shape[0]
-        foods, heads, bodies, dones, orientations, colours, boost = self._state()
+        # The resident mirror (large batches): the launch reads the compact image instead of the fp32 tensors when it
+        # describes them, and keeps it current — in the lazy form without writing the tensors (wurm_multi_rollout_resident;
+        # the library itself falls back to the tensors, writing a lazy mirror out first, for the shapes its mirror-keeping
+        # kernel does not serve).  Same protocol as step(): a postponed reset is applied first, watched tensors are checked
+        # for in-place edits, nothing is "touched".
+        if self._pending:
+            self._flush()
+        c = self._ensure_call() if T > 0 else self._mc
+        if c is not None and c.resident and self._watched:
+            self._watch_ok()
+        mirrored = c is not None and bool(c.resident)
+        if mirrored:
+            foods, heads, bodies, dones, orientations, colours, boost = self._step_state()
+            self._chk_fresh = False  # (the masks of the last step launch describe an older state)
+        else:
+            foods, heads, bodies, dones, orientations, colours, boost = self._state()
         m, n, obs1 = self._obs_args(self.observation_mode if return_observations else None)
         obs = torch.empty((T,) + tuple(obs1.shape), dtype=torch.float32, device=dev) if obs1 is not None else None
         out_f = torch.empty((T, 3, K, N), dtype=torch.float32, device=dev)
         out_b = torch.empty((T, 4, K, N), dtype=torch.bool, device=dev)
         all_done = torch.empty((T, N), dtype=torch.bool, device=dev)
         cfg = self._cfg()
-        rc = _lib.call(self.device.index, _lib.lib().wurm_multi_rollout, 
-            _lib.ptr(foods), _lib.ptr(heads), _lib.ptr(bodies), _lib.ptr(dones), _lib.ptr(orientations),
-            _lib.ptr(colours), _lib.ptr(boost), _lib.ptr(actions), _lib.ptr(out_f), _lib.ptr(out_b), _lib.ptr(all_done),
-            _lib.ptr(obs), m, n, _lib.i64(N), K, S, _lib.i64(T), ctypes.byref(cfg), _lib.u64(self.seed),
-            _lib.u64(self._next_call(2 * T)), _lib.i64(self.env_offset), None, None, _lib.stream_ptr(self.device.index))
+        if mirrored:
+            rc = _lib.call(self.device.index, _lib.lib().wurm_multi_rollout_resident,
+                _lib.ptr(foods), _lib.ptr(heads), _lib.ptr(bodies), _lib.ptr(dones), _lib.ptr(orientations),
+                _lib.ptr(colours), _lib.ptr(boost), _lib.ptr(actions), _lib.ptr(out_f), _lib.ptr(out_b), _lib.ptr(all_done),
+                _lib.ptr(obs), m, n, _lib.i64(N), K, S, _lib.i64(T), ctypes.byref(cfg), _lib.u64(self.seed),
+                _lib.u64(self._next_call(2 * T)), _lib.i64(self.env_offset), c.resident,
+                self._mc_addr + _lib.MultiCall.resident_valid.offset, int(c.resident_lazy),
+                _lib.stream_ptr(self.device.index))
+        else:
+            rc = _lib.call(self.device.index, _lib.lib().wurm_multi_rollout,
+                _lib.ptr(foods), _lib.ptr(heads), _lib.ptr(bodies), _lib.ptr(dones), _lib.ptr(orientations),
+                _lib.ptr(colours), _lib.ptr(boost), _lib.ptr(actions), _lib.ptr(out_f), _lib.ptr(out_b), _lib.ptr(all_done),
+                _lib.ptr(obs), m, n, _lib.i64(N), K, S, _lib.i64(T), ctypes.byref(cfg), _lib.u64(self.seed),
+                _lib.u64(self._next_call(2 * T)), _lib.i64(self.env_offset), None, None, _lib.stream_ptr(self.device.index))
         _lib.check(rc, 'MultiSnake.rollout')
         if T > 0:
             self.rewards = out_f[-1, 0].t().reshape(-1)
