@@ -498,11 +498,84 @@ def fuzz_multi_group(rng):
     return desc
 
 
+def fuzz_multi_mirror_class(rng):
+    """MultiSnake through the host class with the resident mirror on: fused rollouts (wurm_multi_rollout_resident — the
+    grouped writer, the one-wave rollout, or the two-wave form that does not keep the mirror) and per-call steps take turns
+    on one env object, the state tensors are looked at, held and edited in place in between; every output and the state at
+    the looks against the oracle."""
+    import torch
+    from wurm_amd.envs import MultiSnake
+    S = int(rng.choice([8, 10, 12, 14, 18, 25, 30, 36]))
+    K = int(rng.choice([1, 2, 3, 4, 4, 5, 8, 10, 12]))
+    while 2 * K * S * S + 8 * S * S > 60000:
+        K = max(1, K // 2)
+    N = int(rng.randint(1, 24 if S <= 18 else 8))
+    mode = ['full', 'full', f'partial_{rng.randint(1, 6)}'][rng.randint(3)]
+    cfg = dict(boost=bool(rng.rand() < 0.8), food_on_death_prob=float(rng.choice([0.0, 0.2, 0.5, 0.9, 1.0])),
+               boost_cost_prob=float(rng.choice([0.0, 0.25, 0.5, 1.0])), food_mode=['only_one', 'random_rate'][rng.randint(2)],
+               food_rate=float(rng.choice([5e-4, 5e-3, 5e-2])), reward_on_death=float(rng.choice([-1, -2, 0])),
+               respawn_mode=['all', 'any'][rng.randint(2)], colour_mode=['random', 'fixed'][rng.randint(2)])
+    group = bool(rng.rand() < 0.7)
+    seed, off = int(rng.randint(1 << 30)), int(rng.randint(1 << 20))
+    desc = f'multi_mirror_class S={S} K={K} N={N} mode={mode} group={group} seed={seed} off={off} cfg={cfg}'
+    if os.environ.get('WURM_FUZZ_VERBOSE'):
+        print('start:', desc, flush=True)
+    with _lib.knobs(WURM_RESIDENT_MIN_ENVS=0, WURM_MULTI_GROUP_MIN_ENVS=0 if group else 1 << 40):
+        env = MultiSnake(N, K, S, device='cuda:0', seed=seed, env_offset=off, observation_mode=mode, boost=cfg['boost'],
+                         food_on_death_prob=cfg['food_on_death_prob'], boost_cost_prob=cfg['boost_cost_prob'],
+                         food_mode=cfg['food_mode'], food_rate=cfg['food_rate'], respawn_mode=cfg['respawn_mode'],
+                         reward_on_death=cfg['reward_on_death'], agent_colours=cfg['colour_mode'])
+        o = OracleBackend(seed, off)
+        st = _o.multi_empty_state(N, K, S)
+        st['colours'][...] = o.multi_colours(N, K, cfg['colour_mode'] == 'fixed', call=0)
+        o.call = 1
+        o.multi_reset(st, np.ones(N), cfg)
+        alias = None
+        for op in range(int(rng.randint(4, 12))):
+            u = rng.rand()
+            if u < 0.45:
+                T = int(rng.randint(1, 12))
+                a = rng.randint(0, 8, size=(T, K, N)).astype(np.int64)
+                out = env.rollout(torch.from_numpy(a).cuda())
+                ref = o.multi_rollout(st, a, cfg, mode)
+                same(out['observations'].cpu().numpy().reshape(ref['obs'].shape), ref['obs'], f'{desc} op {op} rollout obs')
+                same(out['all_done'].cpu().numpy().astype(np.uint8), ref['all_done'], f'{desc} op {op} rollout all_done')
+                same(out['rewards'].cpu().numpy().transpose(0, 2, 1).reshape(T, -1), ref['rewards'].reshape(T, -1),
+                     f'{desc} op {op} rollout rewards')
+            elif u < 0.8:
+                for t in range(int(rng.randint(1, 6))):
+                    a = rng.randint(0, 8, size=(K, N)).astype(np.int64)
+                    ac = torch.from_numpy(a).cuda()
+                    obs, rew, dones, info = env.step({f'agent_{i}': ac[i] for i in range(K)})
+                    r = o.multi_step(st, a, cfg, mode)
+                    for i in range(K):
+                        same(obs[f'agent_{i}'].cpu().numpy(), r['obs'][i], f'{desc} op {op} step {t} obs {i}')
+                    same(dones['__all__'].cpu().numpy().astype(np.uint8), r['all_done'], f'{desc} op {op} step {t} all_done')
+                    env.reset(dones['__all__'], return_observations=False)
+                    o.multi_reset(st, r['all_done'], cfg)
+            elif u < 0.9:
+                same(env.foods.cpu().numpy(), st['foods'], f'{desc} op {op} look foods')
+                same(env.bodies.cpu().numpy(), st['bodies'], f'{desc} op {op} look bodies')
+                same(env.heads.cpu().numpy(), st['heads'], f'{desc} op {op} look heads')
+                alias = env.foods
+            elif alias is not None:     # an in-place edit through a tensor the caller holds
+                e, y, x = int(rng.randint(N)), int(rng.randint(1, S - 1)), int(rng.randint(1, S - 1))
+                occupied = st['bodies'].reshape(N, K, S, S)[e, :, y, x].sum() + st['heads'].reshape(N, K, S, S)[e, :, y, x].sum()
+                if occupied == 0:
+                    alias[e, 0, y, x] = 1.0
+                    st['foods'][e, 0, y, x] = 1.0
+        same(env.foods.cpu().numpy(), st['foods'], f'{desc} final foods')
+        same(env.heads.cpu().numpy(), st['heads'], f'{desc} final heads')
+        same(env.bodies.cpu().numpy(), st['bodies'], f'{desc} final bodies')
+        same(env.dones.cpu().numpy().astype(np.uint8), st['dones'], f'{desc} final dones')
+        same(env.orientations.cpu().numpy(), st['orientations'], f'{desc} final orientations')
+
+
 FAMILIES = {'single': fuzz_single, 'fused': fuzz_fused, 'resident': fuzz_resident, 'lean': fuzz_lean, 'lane': fuzz_lane,
             'policy': fuzz_policy, 'grid': fuzz_grid, 'multi': fuzz_multi, 'multi_resident': fuzz_multi_resident,
-            'multi_group': fuzz_multi_group}
-WEIGHTS = {'single': 0.1, 'fused': 0.1, 'resident': 0.14, 'lean': 0.05, 'lane': 0.16, 'policy': 0.03, 'grid': 0.04,
-           'multi': 0.12, 'multi_resident': 0.1, 'multi_group': 0.16}
+            'multi_group': fuzz_multi_group, 'multi_mirror_class': fuzz_multi_mirror_class}
+WEIGHTS = {'single': 0.09, 'fused': 0.09, 'resident': 0.13, 'lean': 0.05, 'lane': 0.15, 'policy': 0.03, 'grid': 0.04,
+           'multi': 0.11, 'multi_resident': 0.09, 'multi_group': 0.14, 'multi_mirror_class': 0.08}
 
 
 def library_sha256():
@@ -515,15 +588,17 @@ if __name__ == '__main__':
     ap = argparse.ArgumentParser()
     ap.add_argument('--seconds', type=float, default=60)
     ap.add_argument('--seed', type=int, default=0)
+    ap.add_argument('--only', default=None, help='comma-separated families (default: all, by weight)')
     ap.add_argument('--summary', default=None,
                     help='append a JSON record of this run (library sha256, seed, cases per family, forced thresholds, '
                          'mismatches) to this file, e.g. profiles/r03_fuzz_summary.json')
     args = ap.parse_args()
     rng = np.random.RandomState(args.seed)
-    kinds = list(FAMILIES)
+    kinds = [k for k in FAMILIES if args.only is None or k in args.only.split(',')]
     t0, n, fails, messages = time.time(), {k: 0 for k in kinds}, 0, []
     while time.time() - t0 < args.seconds:
-        kind = kinds[rng.choice(len(kinds), p=[WEIGHTS[k] for k in kinds])]
+        w = np.array([WEIGHTS[k] for k in kinds])
+        kind = kinds[rng.choice(len(kinds), p=w / w.sum())]
         try:
             FAMILIES[kind](rng)
             n[kind] += 1
