@@ -342,6 +342,22 @@ def test_a_state_tensor_the_caller_holds_is_watched_for_in_place_edits(env_and_l
     assert not _steps(log)[-1]['mirror_valid']
 
 
+def test_an_edit_followed_by_a_look_is_not_forgotten(env_and_log):
+    """edit through an alias, then READ env.envs again (which takes the tensor's version anew), then step: the step must not
+    be told the mirror is current (found by tools/fuzz_parity.py's class-level family in round 4)"""
+    env, log = env_and_log
+    _step(env)
+    e = env.envs
+    _step(env); _step(env)
+    assert _steps(log)[-1]['mirror_valid']
+    e[0, 0, 3, 3] = 1.0
+    assert env.envs is e             # a look between the edit and the next step
+    _step(env)
+    assert not _steps(log)[-1]['mirror_valid']
+    _step(env)
+    assert _steps(log)[-1]['mirror_valid']
+
+
 def test_a_state_tensor_without_version_counter_switches_the_mirror_off(env_and_log):
     env, log = env_and_log
     _step(env)

@@ -169,6 +169,7 @@ def test_rollout_on_the_mirror(env_and_log):
     env._lib.rollout_keeps_mirror = True
     env.rollout(torch.zeros((2, K, N), dtype=torch.long))                 # a fresh env: the rollout makes the mirror
     assert _names(log) == ['rollout_resident'] and log[-1][1] == dict(mirror=True, valid=False, lazy=True)
+    assert env._mc.foods and env._mc.heads and env._mc.bodies             # (what a write-out of this mirror will need)
     _step(env)
     assert _steps(log)[-1]['valid'] and _steps(log)[-1]['lazy']            # ... and the step reads it
     env.rollout(torch.zeros((3, K, N), dtype=torch.long))
@@ -274,6 +275,27 @@ def test_an_in_place_edit_of_an_alias_after_the_step_is_seen_by_check_consistenc
     assert _names(log).count('check') == n + 1, 'the launch masks were trusted over an edited tensor'
     _step(env)
     assert not _steps(log)[-1]['valid']        # and the mirror is rebuilt from the edited tensors
+
+
+def test_an_edit_followed_by_a_look_is_not_forgotten(env_and_log):
+    """edit through an alias, then read an attribute again (which takes the tensor's version anew), then step / rollout: the
+    launch must not be told the mirror is current (found by tools/fuzz_parity.py's class-level family in round 4)"""
+    env, log = env_and_log
+    _step(env)
+    b = env.bodies
+    _step(env); _step(env)
+    assert _steps(log)[-1]['valid']
+    b[0, 0, 3, 3] = 2.0
+    assert env.bodies is b           # a look between the edit and the next launch
+    _step(env)
+    assert not _steps(log)[-1]['valid']
+    _step(env)
+    assert _steps(log)[-1]['valid']
+    b[1, 0, 4, 4] = 1.0
+    assert env.foods is not None     # (a look at ANOTHER attribute)
+    env._lib.rollout_keeps_mirror = True
+    env.rollout(torch.zeros((2, K, N), dtype=torch.long))
+    assert log[-1][0] == 'rollout_resident' and log[-1][1]['valid'] is False
 
 
 def test_a_replaced_state_tensor_is_no_longer_watched(env_and_log):

@@ -505,9 +505,12 @@ def fuzz_multi_mirror_class(rng):
     the looks against the oracle."""
     import torch
     from wurm_amd.envs import MultiSnake
+    case = int(os.environ.get('WURM_FUZZ_REPLAY_CASE', 0)) or int(rng.randint(1, 1 << 30))
+    rng = np.random.RandomState(case)   # (everything below is drawn from the case's own stream: `--replay multi_mirror_class:<case>`)
+    verbose = bool(os.environ.get('WURM_FUZZ_VERBOSE'))
     S = int(rng.choice([8, 10, 12, 14, 18, 25, 30, 36]))
     K = int(rng.choice([1, 2, 3, 4, 4, 5, 8, 10, 12]))
-    while 2 * K * S * S + 8 * S * S > 60000:
+    while 2 * K * S * S + 8 * S * S > 60000 or 16 * K > (S - 4) * (S - 4):   # (and room to place every snake: the constructor raises)
         K = max(1, K // 2)
     N = int(rng.randint(1, 24 if S <= 18 else 8))
     mode = ['full', 'full', f'partial_{rng.randint(1, 6)}'][rng.randint(3)]
@@ -517,7 +520,7 @@ def fuzz_multi_mirror_class(rng):
                respawn_mode=['all', 'any'][rng.randint(2)], colour_mode=['random', 'fixed'][rng.randint(2)])
     group = bool(rng.rand() < 0.7)
     seed, off = int(rng.randint(1 << 30)), int(rng.randint(1 << 20))
-    desc = f'multi_mirror_class S={S} K={K} N={N} mode={mode} group={group} seed={seed} off={off} cfg={cfg}'
+    desc = f'multi_mirror_class case={case} S={S} K={K} N={N} mode={mode} group={group} seed={seed} off={off} cfg={cfg}'
     if os.environ.get('WURM_FUZZ_VERBOSE'):
         print('start:', desc, flush=True)
     with _lib.knobs(WURM_RESIDENT_MIN_ENVS=0, WURM_MULTI_GROUP_MIN_ENVS=0 if group else 1 << 40):
@@ -533,6 +536,8 @@ def fuzz_multi_mirror_class(rng):
         alias = None
         for op in range(int(rng.randint(4, 12))):
             u = rng.rand()
+            if verbose:
+                print(f'  op {op}: u={u:.3f} mirror={env.mirror_state()} pending={env._pending}', flush=True)
             if u < 0.45:
                 T = int(rng.randint(1, 12))
                 a = rng.randint(0, 8, size=(T, K, N)).astype(np.int64)
@@ -559,6 +564,9 @@ def fuzz_multi_mirror_class(rng):
                 same(env.heads.cpu().numpy(), st['heads'], f'{desc} op {op} look heads')
                 alias = env.foods
             elif alias is not None:     # an in-place edit through a tensor the caller holds
+                # (the attribute is re-read first, as the reference's callers do: that applies a postponed reset — an edit
+                # through an alias taken BEFORE `step; reset` lands in front of that reset, DESIGN.md deviation 9)
+                assert env.foods is alias
                 e, y, x = int(rng.randint(N)), int(rng.randint(1, S - 1)), int(rng.randint(1, S - 1))
                 occupied = st['bodies'].reshape(N, K, S, S)[e, :, y, x].sum() + st['heads'].reshape(N, K, S, S)[e, :, y, x].sum()
                 if occupied == 0:
@@ -589,11 +597,19 @@ if __name__ == '__main__':
     ap.add_argument('--seconds', type=float, default=60)
     ap.add_argument('--seed', type=int, default=0)
     ap.add_argument('--only', default=None, help='comma-separated families (default: all, by weight)')
+    ap.add_argument('--replay', default=None, help='family:case — one case of a family that draws from its own stream (multi_mirror_class)')
     ap.add_argument('--summary', default=None,
                     help='append a JSON record of this run (library sha256, seed, cases per family, forced thresholds, '
                          'mismatches) to this file, e.g. profiles/r03_fuzz_summary.json')
     args = ap.parse_args()
     rng = np.random.RandomState(args.seed)
+    if args.replay:
+        fam, case = args.replay.split(':')
+        os.environ['WURM_FUZZ_REPLAY_CASE'] = case
+        os.environ['WURM_FUZZ_VERBOSE'] = '1'
+        FAMILIES[fam](rng)
+        print('replay: no mismatch')
+        sys.exit(0)
     kinds = [k for k in FAMILIES if args.only is None or k in args.only.split(',')]
     t0, n, fails, messages = time.time(), {k: 0 for k in kinds}, 0, []
     while time.time() - t0 < args.seconds:

@@ -238,6 +238,8 @@ class FastStepMixin(object):
         fs.obs_after = None
         self._chk_void_at = fs.steps  # (the caller may edit what it gets)
         self._write_out()  # (lazy mirror: the step launches have not been writing `envs`; eager from now on, _watch)
+        self._mirror_sync()  # (an edit through an alias since the last look must not be forgotten when _watch takes the
+                             # tensor's version again: edit, look, step would step on a stale mirror)
         self._watch(self._envs)
         return self._envs
 

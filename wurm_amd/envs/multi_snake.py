@@ -336,6 +336,9 @@ class MultiSnake(object):
     def _escape(self, t):
         """The caller holds the state tensor `t` from now on: it is brought up to date, written by every step (no lazy form
         any more) and watched for in-place edits through its version counter; without one (inference tensors) no mirror."""
+        if self._watched:
+            self._watch_ok()   # (an edit through a tensor the caller already holds must not be forgotten when its version is
+                               # taken again below: edit, look, step would step on a stale mirror)
         self._write_out()
         self._chk_fresh = False
         if self._mc is not None:
@@ -678,6 +681,11 @@ class MultiSnake(object):
         mirrored = c is not None and bool(c.resident)
         if mirrored:
             foods, heads, bodies, dones, orientations, colours, boost = self._step_state()
+            # (the argument block names the tensors for wurm_multi_resident_flush — a look at the state right after this
+            # rollout writes the mirror out through it, whether or not a step() has ever filled it in)
+            c.foods, c.heads, c.bodies = foods.data_ptr(), heads.data_ptr(), bodies.data_ptr()
+            c.dones, c.orientations, c.colours = dones.data_ptr(), orientations.data_ptr(), colours.data_ptr()
+            self._state_dirty = False
             self._chk_fresh = False  # (the masks of the last step launch describe an older state)
         else:
             foods, heads, bodies, dones, orientations, colours, boost = self._state()
