@@ -579,11 +579,111 @@ def fuzz_multi_mirror_class(rng):
         same(env.orientations.cpu().numpy(), st['orientations'], f'{desc} final orientations')
 
 
+def fuzz_single_mirror_class(rng):
+    """SingleSnake through the host class, the same random sequence of operations on two env objects — the resident mirror
+    forced on (WURM_RESIDENT_MIN_ENVS=0: the 32-byte records of 9 x 9, the clock-grid image from 12 x 12 on) and off (the
+    per-call kernels, themselves checked against the oracle by the other families): steps with every flavour of reset,
+    fused rollouts, looks at `envs`, in-place edits through a held alias (with and without a look in between),
+    check_consistency(), a changed observation mode; every output and the state must be identical."""
+    import torch
+    from wurm_amd.envs import SingleSnake
+    case = int(os.environ.get('WURM_FUZZ_REPLAY_CASE', 0)) or int(rng.randint(1, 1 << 30))
+    rng = np.random.RandomState(case)
+    verbose = bool(os.environ.get('WURM_FUZZ_VERBOSE'))
+    S = int(rng.choice([9, 9, 9, 12, 16, 25, 36]))
+    N = int(rng.randint(1, 400 if S == 9 else 48))
+    modes = ['partial_2', 'one_channel', 'default', 'positions', 'partial_1'] if S == 9 else \
+        ['default', 'partial_2', 'partial_5', 'one_channel', 'raw', 'positions']
+    mode = modes[rng.randint(len(modes))]
+    lazy_reset = bool(rng.rand() < 0.8)
+    seed = int(rng.randint(1 << 30))
+    nops = int(rng.randint(5, 25))
+    desc = f'single_mirror_class case={case} S={S} N={N} mode={mode} lazy_reset={lazy_reset} seed={seed}'
+    if verbose:
+        print('start:', desc, flush=True)
+    plan = []
+    for _ in range(nops):
+        u = rng.rand()
+        if u < 0.5:
+            plan.append(('steps', [(rng.randint(-1, 5, N), int(rng.randint(4))) for _ in range(int(rng.randint(1, 6)))]))
+        elif u < 0.65:
+            T = int(rng.randint(1, 20))
+            plan.append(('rollout', rng.randint(-1, 5, (T, N)), bool(rng.rand() < 0.8)))
+        elif u < 0.75:
+            plan.append(('look',))
+        elif u < 0.8:
+            plan.append(('hold',))
+        elif u < 0.92:
+            plan.append(('edit', int(rng.randint(N)), int(rng.randint(1 << 30)), bool(rng.rand() < 0.5)))
+        elif u < 0.97:
+            plan.append(('check',))
+        else:
+            plan.append(('mode', modes[rng.randint(len(modes))]))
+
+    def run(mirror):
+        out = []
+        with _lib.knobs(WURM_RESIDENT_MIN_ENVS=0 if mirror else 10 ** 9):
+            env = SingleSnake(N, S, observation_mode=mode, device='cuda:0', seed=seed, lazy_reset=lazy_reset)
+            alias = None
+            for i, op in enumerate(plan):
+                if verbose and mirror:
+                    print(f'  op {i}: {op[0]} mirror={env.mirror_state()}', flush=True)
+                if op[0] == 'steps':
+                    for a_np, how in op[1]:
+                        a = torch.from_numpy(a_np).cuda()
+                        obs, r, d, info = env.step(a)
+                        # (how == 3: no reset at all — finished envs are stepped again, and the mirror stays current with
+                        # nothing postponed: the state in which a look must not forget an edit)
+                        back = env.reset(d) if how == 0 else env.reset(d.clone()) if how == 1 else \
+                            env.reset(d, return_observations=False) if how == 2 else None
+                        out.append([x.clone() for x in (obs, r, d, info['self_collision'], info['edge_collision'], a)] +
+                                   ([back.clone()] if back is not None else []))
+                elif op[0] == 'rollout':
+                    a = torch.from_numpy(op[1]).cuda()
+                    res = env.rollout(a, return_observations=op[2])
+                    out.append([a.clone()] + [v.clone() for v in res.values() if v is not None])
+                elif op[0] == 'look':
+                    out.append([env.envs.clone()])
+                elif op[0] == 'hold':
+                    alias = env.envs
+                elif op[0] == 'edit' and alias is not None:
+                    e, r2 = op[1], np.random.RandomState(op[2])
+                    if not op[3]:
+                        assert env.envs is alias     # (re-read first: applies a postponed reset, DESIGN.md deviation 9)
+                    else:
+                        env.reset(torch.zeros(N, dtype=torch.bool, device='cuda:0'), return_observations=False)  # (flushes a postponed reset; no look)
+                    st = alias[e].cpu().numpy()
+                    free = np.argwhere((st[2, 1:-1, 1:-1] == 0) & (st[1, 1:-1, 1:-1] == 0)) + 1
+                    if len(free):
+                        y, x = free[r2.randint(len(free))]
+                        alias[e, 0] = 0                  # the food of env e moves: version counter bumps
+                        alias[e, 0, int(y), int(x)] = 1
+                    out.append([alias.clone()])
+                elif op[0] == 'check':
+                    try:        # (an env stepped on after it finished is inconsistent: both objects must say so)
+                        env.check_consistency()
+                        out.append([torch.zeros(1)])
+                    except RuntimeError:
+                        out.append([torch.ones(1)])
+                elif op[0] == 'mode':
+                    env.observation_mode = op[1]
+            out.append([env.envs.clone()])
+        return out
+
+    a, b = run(True), run(False)
+    assert len(a) == len(b), desc
+    for i, (xa, xb) in enumerate(zip(a, b)):
+        assert len(xa) == len(xb), f'{desc} record {i}'
+        for j, (x, y) in enumerate(zip(xa, xb)):
+            assert x.shape == y.shape and torch.equal(x, y), f'{desc} record {i} output {j}: {int((x != y).sum())} mismatches'
+
+
 FAMILIES = {'single': fuzz_single, 'fused': fuzz_fused, 'resident': fuzz_resident, 'lean': fuzz_lean, 'lane': fuzz_lane,
             'policy': fuzz_policy, 'grid': fuzz_grid, 'multi': fuzz_multi, 'multi_resident': fuzz_multi_resident,
-            'multi_group': fuzz_multi_group, 'multi_mirror_class': fuzz_multi_mirror_class}
+            'multi_group': fuzz_multi_group, 'multi_mirror_class': fuzz_multi_mirror_class,
+            'single_mirror_class': fuzz_single_mirror_class}
 WEIGHTS = {'single': 0.09, 'fused': 0.09, 'resident': 0.13, 'lean': 0.05, 'lane': 0.15, 'policy': 0.03, 'grid': 0.04,
-           'multi': 0.11, 'multi_resident': 0.09, 'multi_group': 0.14, 'multi_mirror_class': 0.08}
+           'multi': 0.11, 'multi_resident': 0.09, 'multi_group': 0.14, 'multi_mirror_class': 0.08, 'single_mirror_class': 0.08}
 
 
 def library_sha256():
@@ -597,7 +697,7 @@ if __name__ == '__main__':
     ap.add_argument('--seconds', type=float, default=60)
     ap.add_argument('--seed', type=int, default=0)
     ap.add_argument('--only', default=None, help='comma-separated families (default: all, by weight)')
-    ap.add_argument('--replay', default=None, help='family:case — one case of a family that draws from its own stream (multi_mirror_class)')
+    ap.add_argument('--replay', default=None, help='family:case — one case of a family that draws from its own stream (multi_mirror_class, single_mirror_class)')
     ap.add_argument('--summary', default=None,
                     help='append a JSON record of this run (library sha256, seed, cases per family, forced thresholds, '
                          'mismatches) to this file, e.g. profiles/r03_fuzz_summary.json')
