@@ -555,9 +555,27 @@ def fuzz_multi_mirror_class(rng):
                     r = o.multi_step(st, a, cfg, mode)
                     for i in range(K):
                         same(obs[f'agent_{i}'].cpu().numpy(), r['obs'][i], f'{desc} op {op} step {t} obs {i}')
+                        same(rew[f'agent_{i}'].cpu().numpy(), r['rewards'].reshape(N, K)[:, i], f'{desc} op {op} step {t} reward {i}')
                     same(dones['__all__'].cpu().numpy().astype(np.uint8), r['all_done'], f'{desc} op {op} step {t} all_done')
-                    env.reset(dones['__all__'], return_observations=False)
-                    o.multi_reset(st, r['all_done'], cfg)
+                    how = int(rng.randint(4))   # the reset: postponed, with its observations, eager (not the step's own tensor), none
+                    if how == 0:
+                        env.reset(dones['__all__'], return_observations=False)
+                        o.multi_reset(st, r['all_done'], cfg)
+                    elif how == 1:
+                        back = env.reset(dones['__all__'])
+                        o.multi_reset(st, r['all_done'], cfg, mode=mode)
+                        for i in range(K):
+                            same(back[f'agent_{i}'].cpu().numpy(), o.last_reset_obs[i], f'{desc} op {op} step {t} reset obs {i}')
+                    elif how == 2:
+                        env.reset(dones['__all__'].clone(), return_observations=False)
+                        o.multi_reset(st, r['all_done'], cfg)
+                    if rng.rand() < 0.15:       # experiments/speeds.py:37
+                        ok = bool((o.multi_check(st) == 0).all())
+                        try:
+                            env.check_consistency()
+                            assert ok, f'{desc} op {op} step {t}: check_consistency passed, the oracle finds a fault'
+                        except RuntimeError:
+                            assert not ok, f'{desc} op {op} step {t}: check_consistency raised, the oracle finds none'
             elif u < 0.9:
                 same(env.foods.cpu().numpy(), st['foods'], f'{desc} op {op} look foods')
                 same(env.bodies.cpu().numpy(), st['bodies'], f'{desc} op {op} look bodies')
