@@ -2565,7 +2565,6 @@ __global__ __launch_bounds__(64 * (G / EPS + W)) __attribute__((amdgpu_waves_per
             if (env >= p.N) break; // (a ragged last group: the barrier below is still the workgroup's)
             const Ctx cx = make_ctx(p, g, p.grp_env0);
             const u64 env_id = (u64)(p.env_offset + env);
-            const long long agent = env * K + lane;
             Snake sn;
             bool col_dirty;
             int hc0;
