@@ -103,6 +103,17 @@ def test_step_rows(hip, S, N, mode, lane_min, grid_min, row):
     assert np.array_equal(eo, eh)
 
 
+def test_grid_rows_in_an_env_dependent_order(hip):
+    """WURM_GRID_ROTATE = 1 (off by default): the clock-grid kernels start every env's observation rows at an env-dependent
+    row — the same bytes in another order (tools/placement_probe.py)"""
+    from wurm_amd._lib import knobs
+    with knobs(WURM_GRID_ROTATE=1):
+        test_rollout_rows(hip, 20, 12, 'default', 0, 'grid_rollout')
+        test_rollout_rows(hip, 36, 9, 'raw', 0, 'grid_rollout')
+        test_rollout_rows(hip, 17, 11, 'one_channel', 0, 'grid_rollout')
+        test_step_rows(hip, 36, 8, 'default', 0, 0, 'grid_step')
+
+
 def test_reset_and_observe_are_generic(hip):
     o, h = OracleBackend(seed=9), hip(seed=9)
     envs = _fresh(o, 33, 9)

@@ -70,6 +70,7 @@ struct Grid {
     cell_t *ex; // this wave's clock grid, iters * 256 cells
     int S, C, iters, lane;
     float rcpS;
+    int rot;    // grid_observe starts its rows of 256 cells at row `rot` (and wraps): see make_grid
 };
 
 __device__ __forceinline__ bool ring_cell(const Grid &g, int c)
@@ -150,7 +151,8 @@ __device__ __forceinline__ void grid_observe(const Grid &g, const StepView &s, f
     if (mode == WURM_OBS_DEFAULT) {
         // _get_rgb (:104-128): body (0,127,0), head (0,255,0), food (255,0,0) on white, ring black, / 255
         const float c127 = 127.0f / 255.0f;
-        for (int it = 0; it < g.iters; ++it) {
+        for (int i = 0; i < g.iters; ++i) {
+            const int it = i + g.rot < g.iters ? i + g.rot : i + g.rot - g.iters;
             const int c0 = it * 256 + 4 * lane;
             const int4v e = read4(g.ex, c0);
             float4v r, gr, b;
@@ -165,7 +167,8 @@ __device__ __forceinline__ void grid_observe(const Grid &g, const StepView &s, f
             store3<VEC>(o, C, c0, r, gr, b);
         }
     } else if (mode == WURM_OBS_RAW) { // clone of the state: food, head, body
-        for (int it = 0; it < g.iters; ++it) {
+        for (int i = 0; i < g.iters; ++i) {
+            const int it = i + g.rot < g.iters ? i + g.rot : i + g.rot - g.iters;
             const int c0 = it * 256 + 4 * lane;
             const int4v e = read4(g.ex, c0);
             float4v f, h, b;
@@ -180,7 +183,8 @@ __device__ __forceinline__ void grid_observe(const Grid &g, const StepView &s, f
             store3<VEC>(o, C, c0, f, h, b);
         }
     } else if (mode == WURM_OBS_ONE_CHANNEL) { // :142-151: 0.5 body + 0.5 head + 1.5 food, ring -1
-        for (int it = 0; it < g.iters; ++it) {
+        for (int i = 0; i < g.iters; ++i) {
+            const int it = i + g.rot < g.iters ? i + g.rot : i + g.rot - g.iters;
             const int c0 = it * 256 + 4 * lane;
             const int4v e = read4(g.ex, c0);
             float4v v;
@@ -225,7 +229,14 @@ struct Snk {
     int G, T;       // clocks: G = T + L
 };
 
-__device__ __forceinline__ Grid make_grid(const StepArgs &p, int wave)
+// env: the env this wave works on (-1: none yet).  Its observation is written row by row of 256 cells, every wave of the chip
+// in the SAME order: all concurrent stores lie on one lattice of addresses (env stride 12 S^2 bytes, same offset), and how that
+// lattice falls on the HBM channels depends on the physical pages the 2 GB output happens to lie on — the same cfg5 launch
+// takes 0.37 to 0.48 ms by allocation within one process, while a linear fill of the same blocks runs at 7.0-7.2 TB/s in each
+// (tools/placement_probe.py, profiles/r04_placement_probe.txt).  Option WURM_GRID_ROTATE = 1 starts every env's rows at an
+// env-dependent row (the same bytes): that removes the dependence — and is as slow as the worst allocation everywhere
+// (0.47-0.50 ms): it is the compact lattice that is fast.  Off by default; kept for the record.
+__device__ __forceinline__ Grid make_grid(const StepArgs &p, int wave, long long env = -1)
 {
     Grid g;
     g.S = p.S;
@@ -234,6 +245,7 @@ __device__ __forceinline__ Grid make_grid(const StepArgs &p, int wave)
     g.lane = (int)(threadIdx.x & 63u);
     g.rcpS = 1.0f / (float)p.S;
     g.ex = (cell_t *)grid_lds_raw + wave * (g.iters * 256);
+    g.rot = (p.grid_rotate && env >= 0) ? (int)((unsigned long long)env % (unsigned)g.iters) : 0;
     return g;
 }
 
@@ -498,7 +510,7 @@ __global__ __launch_bounds__(256) void grid_rollout_kernel(StepArgs p)
     const int wave = uniform((int)(threadIdx.x >> 6)), wpb = (int)(blockDim.x >> 6);
     const long long env = xcd_block(blockIdx.x, gridDim.x) * wpb + wave;
     if (env >= p.N) return;
-    const Grid g = make_grid(p, wave);
+    const Grid g = make_grid(p, wave, env);
     const int lane = g.lane;
     float *envp = p.envs + env * 3 * g.C;
     const u64 env_id = (u64)(p.env_offset + env);
@@ -601,7 +613,7 @@ __global__ __launch_bounds__(256) void grid_step_kernel(StepArgs p)
     const int wave = uniform((int)(threadIdx.x >> 6)), wpb = (int)(blockDim.x >> 6);
     const long long env = xcd_block(blockIdx.x, gridDim.x) * wpb + wave;
     if (env >= p.N) return;
-    const Grid g = make_grid(p, wave);
+    const Grid g = make_grid(p, wave, env);
     const int lane = g.lane, C = g.C;
     float *envp = p.envs + env * 3 * C;
     const u64 env_id = (u64)(p.env_offset + env);
@@ -741,7 +753,7 @@ __global__ __launch_bounds__(256) void grid_flush_kernel(StepArgs p)
     const int wave = uniform((int)(threadIdx.x >> 6)), wpb = (int)(blockDim.x >> 6);
     const long long env = xcd_block(blockIdx.x, gridDim.x) * wpb + wave;
     if (env >= p.N) return;
-    const Grid g = make_grid(p, wave);
+    const Grid g = make_grid(p, wave, env);
     Snk s;
     int hb = 0;
     const int flags = mirror_load_rec(g, mirror_rec(p, g, env), s, hb);
@@ -780,6 +792,7 @@ static bool grid_aligned(const StepArgs &p)
 hipError_t launch_grid_rollout(const StepArgs &p_in, hipStream_t stream)
 {
     StepArgs p = p_in;
+    p.grid_rotate = opt.grid_rotate != 0;
     const int C = p.S * p.S, iters = (C + 255) >> 8;
     const int wpb = p.N <= 4096 ? 1 : 4;
     dim3 block(64 * wpb), grid((unsigned)((p.N + wpb - 1) / wpb));
@@ -800,6 +813,7 @@ hipError_t launch_grid_rollout(const StepArgs &p_in, hipStream_t stream)
 hipError_t launch_grid_step(const StepArgs &p_in, hipStream_t stream)
 {
     StepArgs p = p_in;
+    p.grid_rotate = opt.grid_rotate != 0;
     const int C = p.S * p.S, iters = (C + 255) >> 8;
     const int wpb = p.N <= 4096 ? 1 : 4;
     dim3 block(64 * wpb), grid((unsigned)((p.N + wpb - 1) / wpb));

@@ -8,7 +8,7 @@
 
 namespace wurm {
 
-constexpr Options DEFAULTS = {1ll << 20, 12288, 6144, -1, -1, -1, 12, 0, 2048, 0, -1, 0};
+constexpr Options DEFAULTS = {1ll << 20, 12288, 6144, -1, -1, -1, 12, 0, 2048, 0, -1, 0, 0};
 Options opt = DEFAULTS;
 long long launch_count = 0;
 
@@ -32,6 +32,7 @@ const Entry table[] = {
     {"WURM_MULTI_GROUP_VARIANT", &Options::multi_group_variant},
     {"WURM_MULTI_GROUP_STEP_WPB", &Options::multi_group_step_wpb},
     {"WURM_MULTI_GROUP_SHAPE", &Options::multi_group_shape},
+    {"WURM_GRID_ROTATE", &Options::grid_rotate},
 };
 
 const Entry *find(const char *name)

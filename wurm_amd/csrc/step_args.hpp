@@ -33,6 +33,7 @@ struct StepArgs {
     u64 pre_call;
     int post_reset;
     int only_flagged; // rollout_kernel: process only the envs the grid kernel marked GRID_SKIPPED in done[0][env]
+    int grid_rotate;  // grid_rollout.hip: every env's observation rows start at an env-dependent row (make_grid)
     // grid_step_kernel: the caller's compact mirror of the state (wurm_single_call.resident, S >= 12: the clock grids
     // and the per-env scalars as the kernel holds them), nullable; valid: it describes envs; lazy: envs are not written
     void *resident;
