@@ -13,8 +13,14 @@ from wurm_amd.envs import SingleSnake  # noqa: E402
 dev = torch.device('cuda:0')
 if '--prealloc' in sys.argv:           # what bench.py's host calibration does first: a 2 GB block, freed into the cache
     x = torch.empty(2 << 30, dtype=torch.uint8, device=dev); x.fill_(1); torch.cuda.synchronize(); del x
-env = SingleSnake(8192, 36, observation_mode='default', device=dev, seed=0)
-acts = torch.randint(4, (16, 8192), device=dev)
+CFG4 = '--cfg4' in sys.argv   # MultiSnake 4 096 x 25 x 25 x 4 'full', 16 steps: 1.97 GB of observations
+if CFG4:
+    from wurm_amd.envs import MultiSnake
+    env = MultiSnake(4096, 4, 25, device=dev, seed=0)
+    acts = torch.randint(8, (16, 4, 4096), device=dev)
+else:
+    env = SingleSnake(8192, 36, observation_mode='default', device=dev, seed=0)
+    acts = torch.randint(4, (16, 8192), device=dev)
 env.rollout(acts.clone()); torch.cuda.synchronize()
 
 
@@ -32,7 +38,7 @@ def one(rotate=1):
     return e0.elapsed_time(e1), out
 
 
-numel = 16 * 8192 * 3 * 36 * 36
+numel = 16 * 4 * 4096 * 3 * 25 * 25 if CFG4 else 16 * 8192 * 3 * 36 * 36
 held = []
 for j in range(8):
     # both forms into the SAME block (results are dropped: the caching allocator hands the block back), three launches each
@@ -49,4 +55,4 @@ for j in range(8):
         fills.append(e0.elapsed_time(e1))
     held.append(x)
     print(f'block {j} at 0x{p:x}: rollout, every env\'s rows in the same order {same:.3f} ms, rows started at an env-dependent row {rot:.3f} ms;   '
-          f'linear fill of the same 2.04 GB {min(fills):.3f} ms = {numel * 4 / min(fills) / 1e9:.2f} TB/s', flush=True)
+          f'linear fill of the same block {min(fills):.3f} ms = {numel * 4 / min(fills) / 1e9:.2f} TB/s', flush=True)
