@@ -1,0 +1,316 @@
+"""Bounded-exhaustive enumeration of caller event sequences against the simulating stand-in (tests/protocol_sim.py).
+
+Every sequence of length <= L over the alphabet below is played on TWO env objects built over two independent simulators:
+the object under test (deferred reset, resident mirror in one of its forms, Python or C step machine) and a TWIN with
+`lazy_reset=False, resident_mirror=False` (every reset eager, every step on the tensors).  After each event the values the
+caller sees (returned tensors bit for bit, exceptions, the in-place sanitised actions) must be equal; after the last one the
+state tensors and the RNG counter as well.  The simulator's hash algebra makes any difference in the order, counter, mask,
+mode, start location or configuration of a logical operation — and any use of a stale mirror — a difference in values.
+
+Used by tests/test_protocol_enumeration.py (short sequences, every configuration) and tools/protocol_enumerate.py (length 6).
+"""
+import itertools
+
+import torch
+
+from tests import protocol_sim as ps
+
+N_ENVS, SIZE = 3, 9
+SKIP = object()
+
+
+def pack(x):
+    """a value the caller sees -> something comparable bit for bit"""
+    if isinstance(x, torch.Tensor):
+        return (str(x.dtype), tuple(x.shape), x.detach().contiguous().cpu().numpy().tobytes())
+    if isinstance(x, dict):
+        return tuple((k, pack(v)) for k, v in x.items())      # (key order is part of what the caller sees)
+    if isinstance(x, (tuple, list)):
+        return tuple(pack(v) for v in x)
+    return x
+
+
+class SingleDriver(object):
+    """caller events on a SingleSnake / SimpleGridworld object"""
+
+    MODES = ('partial_2', 'default')
+    EVENTS = ('step', 'reset_d', 'reset_d_noobs', 'reset_view', 'reset_other', 'reset_none', 'look', 'edit_alias',
+              'edit_done', 'assign', 'observe', 'check', 'rollout', 'mode', 'lazy', 'read_done')
+
+    def __init__(self, env, twin: bool):
+        self.env, self.twin = env, twin
+        self.k = 0
+        self.d = None
+        self.alias = None
+
+    def _actions(self, *shape):
+        self.k += 1
+        n = 1
+        for s in shape:
+            n *= s
+        return ((torch.arange(n, dtype=torch.long) * 3 + self.k) % 4).reshape(shape)
+
+    def step(self):
+        a = self._actions(N_ENVS)
+        out = self.env.step(a)
+        self.d = out[2]
+        return pack(out), pack(a)
+
+    def reset_d(self):
+        return SKIP if self.d is None else pack(self.env.reset(self.d))
+
+    def reset_d_noobs(self):
+        return SKIP if self.d is None else pack(self.env.reset(self.d, return_observations=False))
+
+    def reset_view(self):
+        return pack(self.env.reset(self.env.done))
+
+    def reset_other(self):
+        return SKIP if self.d is None else pack(self.env.reset(self.d.clone()))
+
+    def reset_none(self):
+        return pack(self.env.reset())
+
+    def look(self):
+        self.alias = self.env.envs
+        return pack(self.alias)
+
+    def edit_alias(self):
+        if self.alias is None:
+            return SKIP
+        self.k += 1
+        self.alias[1, 0, 1, 1 + self.k % 3] = float(100 + self.k % 50)
+        return None
+
+    def edit_done(self):
+        if self.d is None:
+            return SKIP
+        self.d[0] = True
+        return None
+
+    def assign(self):
+        x = self.env.envs.clone()
+        self.k += 1
+        x[0, 0, 1, 1] = float(150 + self.k % 50)
+        self.env.envs = x
+        self.alias = None
+        return None
+
+    def observe(self):
+        return pack(self.env._observe('default'))
+
+    def check(self):
+        try:
+            self.env.check_consistency()
+        except RuntimeError as e:
+            return 'RuntimeError: %s' % e
+        return None
+
+    def rollout(self):
+        a = self._actions(2, N_ENVS)
+        out = self.env.rollout(a)
+        self.d = None          # (the rollout's flags are not a step's `done`)
+        return pack(out), pack(a)
+
+    def mode(self):
+        m = self.MODES
+        self.env.observation_mode = m[1 - m.index(self.env.observation_mode)]
+        return None
+
+    def lazy(self):
+        if not self.twin:
+            self.env.lazy_reset = not self.env.lazy_reset
+        return None
+
+    def read_done(self):
+        return pack(self.env.done)
+
+    def final(self):
+        return pack(self.env.envs), int(self.env._call)
+
+
+class GridDriver(SingleDriver):
+    MODES = ('default', 'raw')
+    EVENTS = tuple(e for e in SingleDriver.EVENTS if e != 'check') + ('start',)
+
+    def start(self):
+        self.env.start_location = (3, 3) if tuple(self.env.start_location) == (4, 4) else (4, 4)
+        return None
+
+
+def install_single(monkeypatch, kind, machine):
+    """points wurm_amd._lib at ONE simulator (it keeps no state of its own: everything lives in the tensors, the mirror and
+    the call blocks, so the object under test and its twin share it).  machine: 'python' / 'c' / 'c+torchinfo'."""
+    sim = ps.SimSingle(channels=3 if kind == 'single' else 2)
+    tinfo = None
+    if machine == 'c+torchinfo':
+        from tests.test_host_lazy_reset import _torchinfo_addresses
+        sim._keep = _torchinfo_addresses()
+        tinfo = sim._keep[1]
+    ps.install(monkeypatch, sim, torch, c_stepper=machine != 'python', torchinfo=tinfo)
+    return sim
+
+
+def make_single(kind, mirror, twin=False):
+    """driver of a fresh SingleSnake ('single') / SimpleGridworld ('grid');  mirror: False / 'lazy' / 'eager' / None
+    (automatic: the simulator offers it).  The twin: every reset eager, every step on the tensors."""
+    kw = dict(device='cpu', seed=5, lazy_reset=not twin, resident_mirror=False if twin else mirror)
+    if kind == 'single':
+        from wurm_amd.envs import SingleSnake
+        return SingleDriver(SingleSnake(num_envs=N_ENVS, size=SIZE, observation_mode='partial_2', **kw), twin)
+    from wurm_amd.envs import SimpleGridworld
+    return GridDriver(SimpleGridworld(num_envs=N_ENVS, size=SIZE, observation_mode='default', start_location=(4, 4), **kw), twin)
+
+
+M_N, M_K, M_S = 3, 2, 6
+
+
+class MultiDriver(object):
+    """caller events on a MultiSnake object"""
+
+    MODES = ('full', 'partial_2')
+    EVENTS = ('step', 'reset_d', 'reset_d_noobs', 'reset_other', 'reset_none', 'look', 'look_dones', 'edit_alias', 'edit_done',
+              'assign', 'observe', 'check', 'rollout', 'mode', 'lazy', 'respawn', 'food_mode', 'read_rewards')
+
+    def __init__(self, env, twin: bool):
+        self.env, self.twin = env, twin
+        self.k = 0
+        self.d = None
+        self.alias = None
+
+    def _actions(self, *shape):
+        self.k += 1
+        n = 1
+        for s in shape:
+            n *= s
+        return ((torch.arange(n, dtype=torch.long) * 3 + self.k) % 8).reshape(shape)
+
+    def step(self):
+        a = self._actions(M_K, M_N)
+        out = self.env.step({'agent_%d' % i: a[i] for i in range(M_K)})
+        self.d = out[2]['__all__']
+        return pack(out)
+
+    def reset_d(self):
+        return SKIP if self.d is None else pack(self.env.reset(self.d))
+
+    def reset_d_noobs(self):
+        return SKIP if self.d is None else pack(self.env.reset(self.d, return_observations=False))
+
+    def reset_other(self):
+        return SKIP if self.d is None else pack(self.env.reset(self.d.clone()))
+
+    def reset_none(self):
+        return pack(self.env.reset())
+
+    def look(self):
+        self.alias = self.env.bodies
+        return pack((self.env.foods, self.env.heads, self.alias, self.env.orientations, self.env.agent_colours))
+
+    def look_dones(self):
+        return pack(self.env.dones)
+
+    def edit_alias(self):
+        if self.alias is None:
+            return SKIP
+        self.k += 1
+        self.alias[1, 0, 0, 1 + self.k % 3] = float(100 + self.k % 50)
+        return None
+
+    def edit_done(self):
+        if self.d is None:
+            return SKIP
+        self.d[0] = True
+        return None
+
+    def assign(self):
+        x = self.env.foods.clone()
+        self.k += 1
+        x[0, 0, 1, 1] = float(150 + self.k % 50)
+        self.env.foods = x
+        return None
+
+    def observe(self):
+        return pack(self.env._observe())
+
+    def check(self):
+        try:
+            self.env.check_consistency()
+        except RuntimeError as e:
+            return 'RuntimeError: %s' % e
+        return None
+
+    def rollout(self):
+        a = self._actions(2, M_K, M_N)
+        out = self.env.rollout(a)
+        self.d = None
+        return pack(out)
+
+    def mode(self):
+        m = self.MODES
+        self.env.observation_mode = m[1 - m.index(self.env.observation_mode)]
+        return None
+
+    def lazy(self):
+        if not self.twin:
+            self.env.lazy_reset = not self.env.lazy_reset
+        return None
+
+    def respawn(self):
+        self.env.respawn_mode = 'any' if self.env.respawn_mode == 'all' else 'all'
+        return None
+
+    def food_mode(self):
+        self.env.food_mode = 'random_rate' if self.env.food_mode == 'only_one' else 'only_one'
+        return None
+
+    def read_rewards(self):
+        return pack((self.env.rewards, self.env.boost_this_step))
+
+    def final(self):
+        e = self.env
+        return pack((e.foods, e.heads, e.bodies, e.dones, e.orientations, e.agent_colours)), int(e._call)
+
+
+def install_multi(monkeypatch, rollout_keeps_mirror=True):
+    sim = ps.SimMulti()
+    sim.rollout_keeps_mirror = rollout_keeps_mirror
+    ps.install(monkeypatch, sim, torch)
+    return sim
+
+
+def make_multi(mirror, twin=False):
+    from wurm_amd.envs import MultiSnake
+    env = MultiSnake(M_N, M_K, M_S, device='cpu', seed=1, lazy_reset=not twin, resident_mirror=False if twin else mirror)
+    return MultiDriver(env, twin)
+
+
+def run_sequence(make_test, make_twin, seq):
+    """None if the test object and the twin agree on every value along `seq`; else a description of the first difference.
+    A sequence with an inapplicable event returns SKIP (its applicable prefix is another, shorter, sequence)."""
+    t, r = make_test(), make_twin()
+    for i, ev in enumerate(seq):
+        try:
+            a = getattr(t, ev)()
+        except Exception as e:  # noqa: BLE001 — an exception the twin does not raise is a finding, not a crash
+            a = 'raised %s: %s' % (type(e).__name__, e)
+        try:
+            b = getattr(r, ev)()
+        except Exception as e:  # noqa: BLE001
+            b = 'raised %s: %s' % (type(e).__name__, e)
+        if a is SKIP or b is SKIP:
+            return SKIP
+        if a != b:
+            return 'event %d (%s) of %s: the caller sees other values than with lazy_reset=False, resident_mirror=False' % (i, ev, list(seq))
+    if t.final() != r.final():
+        return 'after %s: state tensors / RNG counter differ from the twin' % (list(seq),)
+    return None
+
+
+def enumerate_sequences(events, length, first=None):
+    """all sequences of exactly `length` events (first event fixed if given)"""
+    if first is not None:
+        for rest in itertools.product(events, repeat=length - 1):
+            yield (first,) + rest
+    else:
+        yield from itertools.product(events, repeat=length)

@@ -351,7 +351,7 @@ def test_an_edit_followed_by_a_look_is_not_forgotten(env_and_log):
     _step(env); _step(env)
     assert _steps(log)[-1]['mirror_valid']
     e[0, 0, 3, 3] = 1.0
-    assert env.envs is e             # a look between the edit and the next step
+    assert env.envs.data_ptr() == e.data_ptr()   # a look between the edit and the next step
     _step(env)
     assert not _steps(log)[-1]['mirror_valid']
     _step(env)
@@ -570,6 +570,7 @@ def test_reference_test_access_patterns_never_step_on_a_stale_mirror(env_and_log
     step()
     e[1, 2, 3, 3] = 2.0; wrote[0] = True
     step()
+    del e   # (while the caller holds an alias of the state no reset is postponed: _alias_free)
     # :24-31 / experiments/main.py:212-227: step, consistency on a gathered copy, reset(done)
     for _ in range(4):
         n = len(log)

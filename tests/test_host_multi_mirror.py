@@ -286,7 +286,7 @@ def test_an_edit_followed_by_a_look_is_not_forgotten(env_and_log):
     _step(env); _step(env)
     assert _steps(log)[-1]['valid']
     b[0, 0, 3, 3] = 2.0
-    assert env.bodies is b           # a look between the edit and the next launch
+    assert env.bodies.data_ptr() == b.data_ptr()   # a look between the edit and the next launch
     _step(env)
     assert not _steps(log)[-1]['valid']
     _step(env)
@@ -307,7 +307,7 @@ def test_a_replaced_state_tensor_is_no_longer_watched(env_and_log):
         new = torch.zeros(N, 1, S, S)
         olds.append(new)
         env.foods = new
-    assert len(env._watched) == 1 and env._watched[0][0] is olds[-1]
+    assert len(env._watched) == 1 and env._watched[0][0].data_ptr() == olds[-1].data_ptr()
     _step(env); _step(env)
     assert _steps(log)[-1]['valid']
     olds[0][0, 0, 1, 1] = 1.0                  # an edit of a tensor that is no longer part of the state: nothing to do
@@ -403,6 +403,7 @@ def test_reference_test_access_patterns_never_step_on_a_stale_mirror(env_and_log
     step()
     env.reset(); wrote[0] = True
     step()
+    del h   # (while the caller holds an alias of a state tensor no reset is postponed: _alias_free)
     _, _, d, _ = step()
     env.reset(d['__all__'], return_observations=False)     # the step's own flags: postponed, nothing written
     step()

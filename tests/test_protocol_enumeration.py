@@ -1,0 +1,117 @@
+"""The host protocols (deferred reset, resident mirror, attribute changes) by BOUNDED-EXHAUSTIVE ENUMERATION on the CPU:
+every caller event sequence up to a length, object under test against a twin with `lazy_reset=False,
+resident_mirror=False`, on the simulating stand-in of the library (tests/protocol_sim.py, tests/protocol_enum.py).
+
+Here: every sequence of length <= 3 for each class x mirror policy (Python step machine; the C machines on the automatic
+policy), plus the longer sequences that found something once.  tools/protocol_enumerate.py runs the long lengths over all
+cores; its record is profiles/r05_protocol_enumeration.json.
+"""
+import itertools
+
+import pytest
+
+from tests import protocol_enum as pe
+from tests.test_host_lazy_reset import _have_c_stepper, _torchinfo_addresses
+
+
+def _machine_or_skip(machine):
+    if machine != 'python' and not _have_c_stepper():
+        pytest.skip('wurm_amd/_fastcall is not built')
+    if machine == 'c+torchinfo' and _torchinfo_addresses() is None:
+        pytest.skip('wurm_amd/libwurm_torchinfo.so is not built')
+
+
+def _run_all(make, events, max_len, extra=()):
+    bad, n = [], 0
+    seqs = itertools.chain(*(itertools.product(events, repeat=L) for L in range(1, max_len + 1)), extra)
+    for seq in seqs:
+        r = pe.run_sequence(make, lambda: make(True), seq)
+        n += 1
+        if r is not None and r is not pe.SKIP:
+            bad.append(r)
+    assert not bad, '%d of %d sequences differ from the twin; first: %s' % (len(bad), n, bad[:5])
+
+
+# sequences (length 4-6) that exposed a hole at some point — VERDICT r04's two repros first
+SINGLE_REGRESSIONS = [
+    ('step', 'reset_d', 'step', 'mode', 'reset_d'),              # pre-computed reset observation of the OLD mode
+    ('step', 'reset_d', 'step', 'mode', 'reset_view'),
+    ('step', 'reset_d', 'step', 'reset_d', 'mode', 'step'),
+    ('look', 'step', 'reset_d_noobs', 'edit_alias'),              # alias across a postponed reset (was deviation 9)
+    ('step', 'look', 'reset_d_noobs', 'edit_alias', 'step'),
+    ('step', 'reset_d', 'step', 'look', 'edit_alias', 'reset_d'),
+    ('step', 'reset_d_noobs', 'lazy', 'step', 'reset_d', 'step'),
+    ('step', 'check', 'step', 'reset_d_noobs', 'check', 'step'),
+    ('step', 'reset_d', 'rollout', 'step', 'reset_d', 'look'),
+    ('step', 'edit_done', 'reset_d', 'step', 'reset_d', 'step'),
+    ('assign', 'step', 'reset_d', 'step', 'reset_d', 'observe'),
+]
+GRID_REGRESSIONS = [
+    ('step', 'reset_d_noobs', 'start'),                          # start_location assigned after the reset was postponed
+    ('step', 'reset_d_noobs', 'start', 'look'),
+    ('step', 'reset_d', 'step', 'start', 'reset_d', 'step'),
+    ('step', 'reset_d', 'step', 'mode', 'reset_d'),
+]
+MULTI_REGRESSIONS = [
+    ('step', 'reset_d', 'step', 'mode', 'reset_d'),              # 'full' -> 'partial_n' between step and reset
+    ('step', 'reset_d_noobs', 'respawn'),                        # dynamics attribute assigned after the reset was postponed
+    ('step', 'reset_d_noobs', 'food_mode', 'step'),
+    ('step', 'reset_d', 'step', 'respawn', 'reset_d', 'step'),
+    ('look', 'step', 'reset_d_noobs', 'edit_alias'),
+    ('step', 'look', 'reset_d_noobs', 'edit_alias', 'step'),
+    ('step', 'check', 'step', 'reset_d_noobs', 'check', 'step'),
+    ('step', 'reset_d', 'rollout', 'step', 'reset_d', 'look'),
+]
+
+
+@pytest.mark.parametrize('mirror,machine', [(False, 'python'), ('lazy', 'python'), ('eager', 'python'), (None, 'python'),
+                                            (None, 'c'), (None, 'c+torchinfo'), ('lazy', 'c+torchinfo')])
+def test_single_snake_every_sequence_up_to_3(monkeypatch, mirror, machine):
+    _machine_or_skip(machine)
+    pe.install_single(monkeypatch, 'single', machine)
+    _run_all(lambda twin=False: pe.make_single('single', mirror, twin), pe.SingleDriver.EVENTS, 3, SINGLE_REGRESSIONS)
+
+
+@pytest.mark.parametrize('machine', ['python', 'c', 'c+torchinfo'])
+def test_gridworld_every_sequence_up_to_3(monkeypatch, machine):
+    _machine_or_skip(machine)
+    pe.install_single(monkeypatch, 'grid', machine)
+    _run_all(lambda twin=False: pe.make_single('grid', False, twin), pe.GridDriver.EVENTS, 3, GRID_REGRESSIONS)
+
+
+@pytest.mark.parametrize('mirror,keep', [(False, True), ('lazy', True), ('eager', True), (None, True), ('lazy', False),
+                                         (None, False)])
+def test_multi_snake_every_sequence_up_to_3(monkeypatch, mirror, keep):
+    pe.install_multi(monkeypatch, rollout_keeps_mirror=keep)
+    _run_all(lambda twin=False: pe.make_multi(mirror, twin), pe.MultiDriver.EVENTS, 3, MULTI_REGRESSIONS)
+
+
+def test_the_harness_sees_a_wrong_counter_and_a_stale_mirror(monkeypatch):
+    """the simulator must make protocol mistakes VISIBLE: a deferred reset applied with another counter, and a step on a
+    mirror that was not invalidated after a foreign write, both change what the caller sees"""
+    import torch
+    from tests import protocol_sim as ps
+    sim = pe.install_single(monkeypatch, 'single', 'python')
+
+    def broken_counter(twin=False):
+        d = pe.make_single('single', False, twin)
+        if not twin:
+            fs = d.env._fs
+            orig = fs.fn
+            fs.fn = lambda blk, sl, i, a, dt, call, pend, pre, want, st: orig(blk, sl, i, a, dt, call, pend, pre + (1 if pend else 0), want, st)
+        return d
+    long = ('step', 'reset_d_noobs') * 3 + ('step', 'look')
+    assert pe.run_sequence(lambda: pe.make_single('single', False), lambda: pe.make_single('single', False, True), long) is None
+    r = pe.run_sequence(broken_counter, lambda: broken_counter(True), long)
+    assert r is not None and r is not pe.SKIP
+
+    def stale_mirror(twin=False):
+        d = pe.make_single('single', 'lazy', twin)
+        if not twin:
+            d.env._touch = lambda: None             # foreign writes no longer invalidate the mirror
+        return d
+    seq = ('step', 'reset_other', 'step', 'reset_other', 'step', 'look')
+    assert pe.run_sequence(lambda: pe.make_single('single', 'lazy'), lambda: pe.make_single('single', 'lazy', True), seq) is None
+    r = pe.run_sequence(stale_mirror, lambda: stale_mirror(True), seq)
+    assert r is not None and r is not pe.SKIP
+    assert isinstance(sim, ps.SimSingle) and torch is not None

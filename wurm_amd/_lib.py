@@ -85,13 +85,14 @@ class MultiCall(ctypes.Structure):
 
 
 def multi_config(num_snakes, boost, food_on_death_prob, boost_cost_prob, food_mode, food_rate, reward_on_death,
-                 respawn_mode, colour_mode):
+                 respawn_mode, colour_mode, max_food=None):
     import numpy as np
     if food_mode not in ('only_one', 'random_rate'):
         raise ValueError('food_mechanics not recognised')
     return MultiConfig(int(bool(boost)), int(food_on_death_prob > 0), float(np.float32(1 - food_on_death_prob)),
                        float(np.float32(boost_cost_prob)), 0 if food_mode == 'only_one' else 1,
-                       float(np.float32(food_rate)), 8 * num_snakes, float(np.float32(reward_on_death)),
+                       float(np.float32(food_rate)), 8 * num_snakes if max_food is None else int(max_food),
+                       float(np.float32(reward_on_death)),
                        int(respawn_mode == 'any'), int(colour_mode == 'random'))
 
 

@@ -38,6 +38,9 @@ import torch
 from wurm_amd import _lib
 
 
+_storage_use_count = torch._C._storage_Use_Count
+
+
 def parse_mirror_policy(value):
     """`resident_mirror` keyword of the env classes -> None (automatic: by batch size, with the adaptive rules), False
     (never), 'lazy' (whenever the shape is served, no adaptive rule; True means this) or 'eager' (the same, but every step
@@ -189,6 +192,7 @@ class FastStepMixin(object):
         # has called check_consistency(), valid for the state the last step left until anything else touches the state
         self._chk, self._chk_armed_at, self._chk_void_at, self._check_calls, self._check_step = None, 1 << 62, -1, 0, 0
         self._mirror_why = 'resident_mirror=False' if pol is False else 'no step yet'
+        self._stor = None
 
     # state of the step machine that other methods of the classes read and write
     _call = property(lambda self: self._fs.call, lambda self, v: setattr(self._fs, 'call', v))
@@ -206,6 +210,9 @@ class FastStepMixin(object):
         fs = getattr(self, '_fs', None)
         if fs is not None:
             fs.ok = False  # the next step builds output slabs of the new shape
+            # the observation the last step's launch pre-computed for `reset(done)` is one of the OLD mode: the reference
+            # observes at reset time in the mode of that moment (single_snake.py:342) — that reset runs eagerly
+            fs.obs_after = None
 
     @property
     def lazy_reset(self) -> bool:
@@ -241,7 +248,9 @@ class FastStepMixin(object):
         self._mirror_sync()  # (an edit through an alias since the last look must not be forgotten when _watch takes the
                              # tensor's version again: edit, look, step would step on a stale mirror)
         self._watch(self._envs)
-        return self._envs
+        # a tensor object of the caller's own on the same storage (and version counter): `_alias_free` can then tell from
+        # the storage's use count whether the caller still holds the state — or any view of it
+        return self._envs.detach()
 
     @envs.setter
     def envs(self, value: torch.Tensor):
@@ -252,8 +261,19 @@ class FastStepMixin(object):
         fs.ok = False
         self._touch()  # (a lazy mirror is written out to the tensor that is being replaced, which is still ours here)
         self._envs_ok = None
-        self._envs = value
-        self._watch(value)
+        self._envs = value.detach() if isinstance(value, torch.Tensor) else value  # (our own tensor object: see the getter)
+        self._watch(self._envs)
+
+    def _alias_free(self) -> bool:
+        """Nobody but this object holds a tensor on the state's storage (the caller's `e = env.envs`, a slice of it, the
+        tensor it assigned): only then may a reset be postponed — with an alias alive the caller could read or edit the
+        un-reset state through it, which the reference would show reset (single_snake.py:322-342)."""
+        e = self._envs
+        st = self._stor
+        if st is None or st[0] is not e:
+            s = e.untyped_storage()
+            st = self._stor = (e, s, s._cdata)
+        return _storage_use_count(st[2]) <= 2  # this object's tensor + the storage handle kept in `_stor`
 
     def _flush(self):
         """Applies the postponed reset(done) now, with the ordinary reset kernel and the counter it was given."""
@@ -491,6 +511,8 @@ class FastStepMixin(object):
             if fs.slot >= fs.R or self._slab_mode != self.observation_mode or \
                     (fs.want_obs_after and fs.obs_afters is None):
                 self._new_slab()
+            else:
+                self._configure_call(self._c)  # (attributes the call block carries may have been assigned: start_location)
             e = self._envs
             if e is not self._envs_ok:
                 self._checked(e)
@@ -517,6 +539,8 @@ class FastStepMixin(object):
 
     def _try_lazy_reset(self, done: torch.Tensor, return_observations: bool):
         """(True, obs) if reset(done) could be postponed into the next step's launch, else (False, None)."""
+        if not self._alias_free():
+            return False, None
         obs = self._fs.reset_lazy(done, return_observations)
         if obs is NotImplemented:
             return False, None

@@ -64,6 +64,25 @@ class SimpleGridworld(FastStepMixin):
         self.food_colour = torch.tensor((255, 0, 0), dtype=torch.short, device=self.device)
         self.edge_colour = torch.tensor((0, 0, 0), dtype=torch.short, device=self.device)
 
+    @property
+    def start_location(self):
+        return self._start_location
+
+    @start_location.setter
+    def start_location(self, value):
+        """reference :254-262 reads it at reset time: a reset(done) that was postponed is applied with the start location
+        of the moment it was called (the old one), and the observation the last step's launch pre-computed for
+        `reset(done)` assumed the old one as well"""
+        fs = getattr(self, '_fs', None)
+        if fs is not None:
+            if fs.pending:
+                self._flush()
+            fs.obs_after = None
+            fs.ok = False       # the next step goes through _slow_step, which hands the call block the new location
+        self._start_location = value
+        if fs is not None:
+            fs.lazy_ok = self._lazy_reset and self._lazy_supported()
+
     def _lazy_supported(self) -> bool:
         return self.size > 4 and self.start_location is not None
 
