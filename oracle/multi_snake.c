@@ -292,14 +292,41 @@ static void multi_step_env(float *food, float *heads, float *bodies, uint8_t *do
         }
     } else {
         if (fsum < (float)cfg->max_food) {                                           /* :382 */
+            /* :393-408 every free interior cell spawns food independently with probability food_rate.  Injected: the
+             * reference's own rand() outcomes per cell.  RNG mode (this build's own specification): the NUMBER of cells is
+             * Binomial(n free cells, food_rate), drawn by inversion from one uniform, and the cells are a uniformly random
+             * subset of that size (the j-th pick: the mulhi(word, n - j)-th remaining free cell in row-major order) — the
+             * same distribution as n independent draws; cell by cell when P(no food) is too small for the recurrence. */
+            int nfree = 0;
+            uint8_t *fr = (uint8_t *)malloc((size_t)C);
             for (int y = 0; y < S; ++y)
                 for (int x = 0; x < S; ++x) {
-                    int c = y * S + x;
-                    if (!cell_free(food, heads, bodies, K, S, y, x)) continue;       /* :393-399,405 */
+                    fr[y * S + x] = (uint8_t)cell_free(food, heads, bodies, K, S, y, x);
+                    nfree += fr[y * S + x];
+                }
+            const float pw = inj ? 0.0f : oracle_pow_n(1.0f - cfg->food_rate, nfree);
+            if (inj || !(cfg->food_rate > 0.0f) || pw < ORACLE_BINOMIAL_MIN_P0) {
+                for (int c = 0; c < C; ++c) {
+                    if (!fr[c]) continue;
                     int hit = inj ? inj->rate[env_local * C + c] != 0
                                   : oracle_cell_u01(seed, call, env_id, RNG_RATE_FOOD, (uint32_t)c) < cfg->food_rate; /* :401-403 */
                     if (hit) food[c] += 1.0f;                                        /* :408 */
                 }
+            } else {
+                uint32_t w[4];
+                oracle_rng_words(seed, call, env_id, RNG_RATE_FOOD, 0, w);
+                const int k = oracle_binomial_inverse(nfree, cfg->food_rate, pw, oracle_u01(w[0]));
+                for (int j = 0; j < k; ++j) {
+                    const int wi = j + 1;
+                    if ((wi & 3) == 0) oracle_rng_words(seed, call, env_id, RNG_RATE_FOOD, (uint32_t)(wi >> 2), w);
+                    int rank = (int)(((uint64_t)w[wi & 3] * (uint64_t)(nfree - j)) >> 32);
+                    for (int c = 0; c < C; ++c) {
+                        if (!fr[c]) continue;
+                        if (rank-- == 0) { food[c] += 1.0f; fr[c] = 0; break; }
+                    }
+                }
+            }
+            free(fr);
         }
     }
 

@@ -85,6 +85,36 @@ static inline uint32_t oracle_mulhi(uint32_t w, uint32_t n) { return (uint32_t)(
 /* uniform float32 in [0,1) with 24 random bits (same lattice as torch.rand's float32) */
 static inline float oracle_u01(uint32_t w) { return (float)(w >> 8) * (1.0f / 16777216.0f); }
 
+/* q^n in fp32 by binary exponentiation: this operation order is part of this build's RNG specification
+ * (wurm_amd/csrc/wurm_device.hpp: pow_n) */
+static inline float oracle_pow_n(float q, int n)
+{
+    float pw = 1.0f, base = q;
+    for (int e = n; e; e >>= 1) {
+        if (e & 1) pw = pw * base;
+        base = base * base;
+    }
+    return pw;
+}
+
+/* Number of successes among n independent Bernoulli(p) trials from ONE uniform u by inversion of the Binomial(n, p)
+ * distribution function (wurm_device.hpp: binomial_inverse); pw = oracle_pow_n(1 - p, n) >= ORACLE_BINOMIAL_MIN_P0. */
+#define ORACLE_BINOMIAL_MIN_P0 1e-6f
+static inline int oracle_binomial_inverse(int n, float p, float pw, float u)
+{
+    const float r = p / (1.0f - p);
+    float pmf = pw, cdf = pw;
+    int k = 0;
+    while (u >= cdf && k < n) {
+        pmf = pmf * ((float)(n - k) * r) / (float)(k + 1);
+        const float nc = cdf + pmf;
+        ++k;
+        if (nc == cdf) break;
+        cdf = nc;
+    }
+    return k;
+}
+
 /* per-cell uniform for cell index `cell` of an env.  Cells c, c+64, c+128, c+192 share one Philox block
  * (sub = (c >> 8) * 64 + (c & 63), word = (c >> 6) & 3): on the GPU one lane owns all four. */
 static inline float oracle_cell_u01(uint64_t seed, uint64_t call, uint64_t env_id, uint32_t purpose, uint32_t cell)

@@ -289,10 +289,10 @@ def test_gridworld_class_loop_equals_oracle_loop(lazy):
     replay._eq(env.envs.cpu().numpy(), ref, 'final state', T)
 
 
-def test_alias_taken_before_the_deferred_reset_is_the_one_documented_deviation():
-    """DESIGN.md §5 deviation 9: a tensor alias of `env.envs` taken BEFORE `step(a); reset(d)` shows the un-reset state
-    until the next step or the next look at the attribute (which is what the reference's callers do:
-    experiments/main.py:215,273 re-read `env.envs`); with lazy_reset=False the alias is exact at once."""
+def test_alias_taken_before_the_reset_shows_the_reset_state():
+    """Round 5 (was DESIGN.md §5 deviation 9): while the caller holds a tensor alias of `env.envs` the reset is not
+    postponed (`_alias_free`: the storage's use count), so the alias shows the reset state at once, with either setting of
+    lazy_reset, as the reference's would."""
     import torch
     from oracle import oracle
     from wurm_amd.envs import SingleSnake

@@ -187,9 +187,9 @@ def test_class_loop_with_reset_observations(cfg_name, mode, shape):
     _same(env.orientations.cpu().numpy(), st['orientations'], 'final orientations')
 
 
-def test_alias_taken_before_the_deferred_reset_is_the_one_documented_deviation():
-    """DESIGN.md §5 deviation 9 for MultiSnake: aliases of `foods / heads / bodies` taken before `step; reset(all_done,
-    return_observations=False)` show the un-reset state until the next step or the next look at an attribute."""
+def test_alias_taken_before_the_reset_shows_the_reset_state():
+    """Round 5 (was DESIGN.md §5 deviation 9): while the caller holds aliases of `foods / heads / bodies` the reset is not
+    postponed (`_alias_free`: the storages' use counts), so the aliases show the reset state at once, as the reference's."""
     import torch
     from wurm_amd.envs import MultiSnake
     cfg = CFGS['default']
@@ -211,11 +211,10 @@ def test_alias_taken_before_the_deferred_reset_is_the_one_documented_deviation()
         assert env.reset(dones['__all__'], return_observations=False) is None
         o.multi_reset(st, r['all_done'], cfg)
         if r['all_done'].any():
-            _same(bodies_alias.cpu().numpy(), pre['bodies'], 'alias before the flush: un-reset bodies')
-            _same(foods_alias.cpu().numpy(), pre['foods'], 'alias before the flush: un-reset foods')
+            assert pre is not None
+            _same(bodies_alias.cpu().numpy(), st['bodies'], 'alias right after reset(all_done)')
+            _same(foods_alias.cpu().numpy(), st['foods'], 'alias right after reset(all_done)')
             _same(env.bodies.cpu().numpy(), st['bodies'], 'the attribute')
-            _same(bodies_alias.cpu().numpy(), st['bodies'], 'alias after the flush')
-            _same(foods_alias.cpu().numpy(), st['foods'], 'alias after the flush')
             return
     raise AssertionError('no env finished in 200 steps')
 

@@ -37,6 +37,9 @@ CFGS = {
                   food_rate=2.5e-4, reward_on_death=-1, respawn_mode='any', colour_mode='random'),
     'dense': dict(boost=True, food_on_death_prob=0.9, boost_cost_prob=0.8, food_mode='random_rate', food_rate=2e-2,
                   reward_on_death=-2, respawn_mode='any', colour_mode='fixed'),
+    # rates at which P(no food) = (1 - p)^n drops below 1e-6: rate food is drawn cell by cell, not as a Binomial count
+    'flood': dict(boost=True, food_on_death_prob=0.5, boost_cost_prob=0.5, food_mode='random_rate', food_rate=0.3,
+                  reward_on_death=-1, respawn_mode='any', colour_mode='random'),
     'noboost': dict(boost=False, food_on_death_prob=0.0, boost_cost_prob=0.5, food_mode='only_one', food_rate=5e-4,
                     reward_on_death=-1, respawn_mode='any', colour_mode='random'),
 }
@@ -63,6 +66,8 @@ def test_workgroup_kernel_whole_views_per_wave(hip):
     (5, 1, 9, 60, 'full', 'dense'),
     (7, 1, 5, 60, 'full', 'default'),          # the smallest grid the reference can populate (seed rows 2..S-3)
     (7, 1, 6, 60, 'partial_1', 'train'),
+    (8, 3, 12, 60, 'partial_2', 'flood'),      # rate food cell by cell (the Binomial recurrence's domain ends at P0 = 1e-6)
+    (8, 2, 9, 40, 'full', 'flood'),
 ])
 def test_multi_step_reset_loop(hip, N, K, S, T, mode, cfg):
     cfg = CFGS[cfg]
@@ -125,6 +130,7 @@ def test_observe_entry_point(hip):
     (10, 6, 14, 80, 'partial_2', 'dense'),
     (9, 2, 12, 150, 'full', 'noboost'),
     (4, 10, 36, 30, 'full', 'train'),
+    (8, 3, 12, 60, 'partial_2', 'flood'),
 ])
 def test_multi_rollout_equals_loop(hip, N, K, S, T, mode, cfg):
     """wurm_multi_rollout == T x (step; reset(__all__)) of the oracle, bit for bit, with the build's RNG."""

@@ -104,6 +104,62 @@ def test_multi_bernoulli_rates():
     assert st['foods'][:, 0, 0].sum() == 0 and st['foods'][:, 0, :, 0].sum() == 0  # never on the ring
 
 
+def test_rate_food_count_and_cells_match_independent_bernoulli_draws():
+    """Round 5: rate food is drawn as COUNT ~ Binomial(n free cells, p) from one uniform + a uniformly random subset of that
+    size (oracle/multi_snake.c, wurm_amd/csrc/multi_snake.hip).  The reference draws every free cell independently
+    (multi_snake.py:401-408): the count must follow Binomial(n, p), every free cell must be hit at rate p, and cells must
+    be hit independently of one another (pairs at rate p^2)."""
+    N, K, S = 40000, 2, 9
+    p = 0.06
+    st = _multi_board(N, K, S)
+    st['dones'][:] = 1                          # no snakes: every interior cell is free
+    st['foods'][:, 0, 3, 3] = 1                 # ... but one, which already holds food
+    cfg = o.multi_cfg(K, boost=False, food_on_death_prob=0.0, food_mode='random_rate', food_rate=p)
+    o.multi_step(st, np.zeros((K, N), np.int64), cfg, 'full', seed=21, call=5)
+    new = st['foods'][:, 0].copy()
+    new[:, 3, 3] -= 1
+    assert new.min() == 0 and new.max() == 1
+    assert new[:, 0].sum() == 0 and new[:, -1].sum() == 0 and new[:, :, 0].sum() == 0 and new[:, :, -1].sum() == 0
+    n = (S - 2) ** 2 - 1
+    counts = new.reshape(N, -1).sum(axis=1).astype(int)
+    # the count: chi-square against Binomial(n, p), tail pooled
+    kmax = 9
+    obs = np.bincount(np.minimum(counts, kmax), minlength=kmax + 1)
+    exp = stats.binom.pmf(np.arange(kmax + 1), n, p)
+    exp[kmax] = 1 - exp[:kmax].sum()
+    assert stats.chisquare(obs, exp * N).pvalue > ALPHA
+    # every free cell at rate p: uniform over the cells, and the total at rate p
+    per_cell = new[:, 1:-1, 1:-1].reshape(N, -1).sum(axis=0)
+    free = np.ones((S - 2) ** 2, bool)
+    free[2 * (S - 2) + 2] = False               # (3, 3) in interior coordinates
+    assert per_cell[~free].sum() == 0
+    assert stats.chisquare(per_cell[free]).pvalue > ALPHA
+    assert stats.binomtest(int(per_cell.sum()), N * n, p).pvalue > ALPHA
+    # independence: two fixed cells are hit together at rate p^2
+    both = (new[:, 1, 1] * new[:, 5, 6]).sum()
+    assert stats.binomtest(int(both), N, p * p).pvalue > ALPHA
+
+
+def test_rate_food_at_rates_far_above_the_references_draws_cell_by_cell():
+    """P(no food) = (1 - p)^n below 1e-6: the recurrence would start from too few bits — cell by cell (the round-2 form)"""
+    N, K, S = 3000, 2, 12
+    st = _multi_board(N, K, S)
+    st['dones'][:] = 1
+    cfg = o.multi_cfg(K, boost=False, food_on_death_prob=0.0, food_mode='random_rate', food_rate=0.5)
+    o.multi_step(st, np.zeros((K, N), np.int64), cfg, 'full', seed=12, call=1)
+    trials = N * (S - 2) ** 2
+    assert stats.binomtest(int(st['foods'].sum()), trials, 0.5).pvalue > ALPHA
+    per_cell = st['foods'][:, 0, 1:-1, 1:-1].reshape(N, -1).sum(axis=0)
+    assert stats.chisquare(per_cell).pvalue > ALPHA
+    # p = 1: every free cell; p = 0: none
+    for rate, want in ((1.0, (S - 2) ** 2), (0.0, 0)):
+        st = _multi_board(8, K, S)
+        st['dones'][:] = 1
+        o.multi_step(st, np.zeros((K, 8), np.int64), o.multi_cfg(K, boost=False, food_on_death_prob=0.0,
+                                                                 food_mode='random_rate', food_rate=rate), 'full', seed=1, call=1)
+        assert (st['foods'].reshape(8, -1).sum(axis=1) == want).all()
+
+
 def test_multi_spawn_cells_are_uniform_over_available_cells():
     N, K, S = 30000, 1, 10
     st = _multi_board(N, K, S)

@@ -43,8 +43,9 @@ if args.rollout:
         if it >= 2:
             tot.append(out['observations'][0, 0].reshape(N, -1)[:, :32].contiguous().view(torch.int64).cpu().numpy())
     tot = np.concatenate(tot).astype(np.float64) / T
-    seg = {0: 'reset (prev step)', 2: 'actions', 3: 'boost phase', 4: 'phase', 5: 'death food / delete', 6: 'add_food', 7: 'body tail',
-           8: 'outputs', 9: 'observation'}
+    seg = {0: 'reset (prev step)', 2: 'actions', 3: 'boost phase', 4: 'phase', 5: 'death food / delete', 10: 'food count',
+           11: 'free cells', 12: 'count + binomial', 6: 'food placed', 7: 'body tail', 8: 'outputs', 13: 'pixel codes + table',
+           9: 'crops written'}
     life = tot[:, :15].sum(1)
     print(f'multi_rollout_kernel, {N} x {S} x {S} x {K}, training dynamics, partial_5, {T} steps: cycles per step (mean over waves; p90)')
     for k, name in seg.items():

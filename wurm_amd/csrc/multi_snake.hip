@@ -97,11 +97,14 @@ struct Ctx {
     short *img;            // [C][4] env image (partial_n): r, g, b, 0
     float *colf;           // [K][4]: r, g, b, 1 + 0.5*boost
     unsigned long long *tl; // timeline build: stamp slots (WURM_TLS)
+    u64 ring;              // bit k <=> cell lane + 64 k lies on the border ring (border_bits), where make_ctx was asked for it
+    bool has_ring;
 };
 
 extern __shared__ __attribute__((aligned(16))) unsigned char wurm_multi_lds[];
 
-__device__ __forceinline__ Ctx make_ctx(const MultiArgs &p, int wave, int base_off = 0)
+__device__ __forceinline__ u64 border_bits(const Ctx &cx); // (with the grouped 'full' writer below)
+__device__ __forceinline__ Ctx make_ctx(const MultiArgs &p, int wave, int base_off = 0, bool want_ring = false)
 {
     Ctx cx;
     unsigned char *base = wurm_multi_lds + base_off + (size_t)wave * p.lds_per_wave;
@@ -123,6 +126,8 @@ __device__ __forceinline__ Ctx make_ctx(const MultiArgs &p, int wave, int base_o
     cx.img = (short *)(base + p.off_img);
     cx.colf = (float *)(base + p.off_col);
     cx.tl = (unsigned long long *)(base + p.off_tl);
+    cx.has_ring = want_ring;
+    cx.ring = want_ring ? border_bits(cx) : 0ull;
     return cx;
 }
 
@@ -752,6 +757,7 @@ struct Snake {
     long long orient; // stored orientation (multi_snake.py:108,494)
     bool boosted;     // boost_this_step of the last step (brightens the snake in partial_n observations)
     short col[3];     // agent colour
+    bool cmap_ok = false; // wave-uniform: cx.hmap holds cell_codes of the state as it is (multi_step_body leaves it; a reset voids it)
 };
 
 struct StepRes {
@@ -775,17 +781,164 @@ __device__ __forceinline__ float div255(int v)
 }
 
 // 'partial_n' observation (:289-332): the crop of the env image (_get_env_images :194-227) around each living head.
-// Round 2 rendered the whole image into LDS (8 bytes per cell) and cropped it; the K windows hold K (2n+1)^2 cells —
-// 484 against the image's 625 at K = 4, 25 x 25, partial_5 — so the pixels are computed for the window cells directly: no
-// image buffer (5 KB of LDS per env less: 4096 envs of cfg4' are resident in one round instead of 1.33), no image write +
-// read.  Agent by agent (round 4): the observer's head cell, its row and column and "it is dead" are wave-uniform, a lane
-// only splits its window index into row and column — the (agent, window cell) pair form of round 3 gathered the observer's
-// words from LDS and divided three times per pixel pass; 18 000 of a step's 43 000 cycles at cfg4' (tools/multi_timeline.py
-// --rollout), VALU-bound.
+// The image is the same for every observer, and a cell of it can only show a handful of different pixels: background,
+// border, food, and per snake its body and its head (brightened while it boosts, :198).  So (round 5):
+//   * one pass over the grid gives every cell a one-byte CODE (cell_codes):
+//     0 background, 1 border ring, 2 food, 3 + 2s body of snake s, 4 + 2s head of snake s, 255 anything else (several
+//     snakes on the cell, food under a snake, a head without its body: hand-made states, heads that have just collided);
+//   * lanes 0 .. 2K+2 compute the 2K + 3 pixels once per step with the reference's own arithmetic (pixel_table: the
+//     float products, `.short()`, black -> white, `/ 255`) into an LDS table of 16-byte entries;
+//   * a window cell is then a byte read, one 16-byte table read and three stores (crop_emit); a cell with code 255 is
+//     rendered on the spot (pixel_slow: the sum over the snakes found there, ascending, as :201-205 sums).
+// History: round 2 rendered the whole image into LDS (8 bytes per cell) and cropped it; rounds 3-4 computed every (agent,
+// window cell) pixel directly — 16 000 of a step's 40 400 cycles at cfg4' (profiles/r04_kernel_timeline.txt), VALU-bound.
+constexpr int PC_BG = 0, PC_RING = 1, PC_FOOD = 2, PC_SNAKE0 = 3, PC_COMPLEX = 255;
+
+// One pass over the grid.  Bodies only in the scan — five 64-cell rows at a time so that the five reads of a snake are in
+// flight together, and per (cell, snake) just a mask, a compare, a select and a carry-add (the compiler must keep this loop
+// free of branches: check the ISA after touching it) — the K head cells are raised afterwards by the K lanes that own them:
+// a head sits on its own body in every state the dynamics produce; anywhere else the cell is marked complex.
+// The same map answers _add_food's "free interior cell" (code 0: free_from_codes), so a step with random_rate food and
+// crops scans the grids once, not twice (multi_step_body builds it, observe_partial reuses it: Snake::cmap_ok).
+__device__ __forceinline__ void cell_codes(const Ctx &cx, int hc, unsigned char *codes, u64 ring)
+{
+    const int C = cx.C, K = cx.K, lane = cx.lane;
+    constexpr int U = 5;
+    const int myT = lane < K ? cx.tclk[lane] : 0;
+    for (int k0 = 0; k0 < cx.cpl; k0 += U) {
+        int cc[U];
+        u32 fd[U], code[U], cnt[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            cc[u] = min(lane + 64 * (k0 + u), C - 1); // (rows past the grid: the last cell again, not stored)
+            fd[u] = cx.food[cc[u]];
+            code[u] = PC_BG;
+            cnt[u] = 0;
+        }
+        for (int s = 0; s < K; ++s) {
+            const int T = lane_value(myT, s);
+            const u32 mine = (u32)(PC_SNAKE0 + 2 * s);
+            const unsigned short *b = cx.body + s * C;
+            u32 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) v[u] = b[cc[u]];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const bool live = (int)(v[u] & VMASK) > T;
+                code[u] = live ? mine : code[u];
+                cnt[u] += (u32)live;
+            }
+        }
+        const u32 rb = (u32)(ring >> k0);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            u32 c1 = cnt[u] > 1u ? (u32)PC_COMPLEX : code[u];             // two bodies on the cell
+            c1 = fd[u] != 0 ? (c1 == PC_BG ? (u32)PC_FOOD : (u32)PC_COMPLEX) : c1; // food; food under a body
+            c1 = ((rb >> u) & 1u) ? (u32)PC_RING : c1;                    // :225 the border wins over everything
+            if (lane + 64 * (k0 + u) < C) codes[cc[u]] = (unsigned char)c1;
+        }
+    }
+    wave_lds_sync();
+    // heads: the cell must hold its own snake's body (code 3 + 2s) and becomes 4 + 2s; anything else under a head — no
+    // body, food, another snake's body, the ring is fine (it wins anyway) — is complex.  Two heads on one cell: at most one of
+    // them finds its own code there; the other lanes all write the same value.
+    int want = -1;
+    if (lane < K && hc >= 0) {
+        const int code = codes[hc];
+        want = code == PC_RING ? -1 : code == PC_SNAKE0 + 2 * lane ? PC_SNAKE0 + 2 * lane + 1 : PC_COMPLEX;
+    }
+    wave_lds_sync();
+    if (want == PC_COMPLEX) codes[hc] = (unsigned char)PC_COMPLEX;
+    wave_lds_sync();
+    if (want >= 0 && want != PC_COMPLEX && codes[hc] != PC_COMPLEX) codes[hc] = (unsigned char)want;
+    wave_lds_sync();
+}
+
+// bit k <=> cell lane + 64 k is a free interior cell (:439-445, :393-399): code 0 of cell_codes
+__device__ __forceinline__ u64 free_from_codes(const Ctx &cx, const unsigned char *codes)
+{
+    u64 fr = 0;
+    for (int k = 0; k < cx.cpl; ++k) {
+        const int c = cx.lane + 64 * k;
+        if (c < cx.C && codes[c] == PC_BG) fr |= 1ull << k;
+    }
+    return fr;
+}
+
+// food on a cell (wave-uniform or per-lane `cell`; the caller fences), and its code with it where the map is current
+__device__ __forceinline__ void put_food(const Ctx &cx, int cell, bool cmap_ok)
+{
+    cx.food[cell] = 1;
+    if (cmap_ok) {
+        const int code = cx.hmap[cell];
+        cx.hmap[cell] = (unsigned char)(code == PC_BG || code == PC_FOOD ? PC_FOOD : code == PC_RING ? PC_RING : PC_COMPLEX);
+    }
+}
+
+// the reference's pixel of a cell from the float sums of :201-205: .short() truncation, food, black -> white (:206-219)
+__device__ __forceinline__ void pixel_finish(float a0, float a1, float a2, bool food, float &r, float &g, float &b)
+{
+    int ri = (int)a0, gi = (int)a1, bi = (int)a2;         // :206 .short() truncates
+    if (food) ri += 255;                                  // :208-209
+    if (ri == 0 && gi == 0 && bi == 0) ri = gi = bi = 255; // :214-219
+    r = div255(ri);
+    g = div255(gi);
+    b = div255(bi);
+}
+
+// the 2K + 3 pixels a cell with a simple code can show -> tab[code] = (r, g, b, -); colf[s] = (colour, 1 + 0.5 boost) is
+// in LDS already.  Lane j computes entry j (K <= 64: two rounds at most).
+__device__ __forceinline__ void pixel_table(const Ctx &cx, float *tab)
+{
+    const int K = cx.K;
+    for (int j = cx.lane; j < 2 * K + PC_SNAKE0; j += 64) {
+        float r = 0.0f, g = 0.0f, b = 0.0f;                // PC_RING (:225)
+        if (j != PC_RING) {
+            float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;
+            if (j >= PC_SNAKE0) {
+                const int s = (j - PC_SNAKE0) >> 1;
+                // :197 `body.float() * 1/3 + head.float() * 1/3`: 1.0f / 3.0f is the correctly rounded quotient the two
+                // IEEE divisions gave; then the boost factor, then the colour (:198-205), summed from 0 as torch's sum does
+                const float third = 1.0f / 3.0f;
+                float inten = third + (((j - PC_SNAKE0) & 1) ? third : 0.0f);
+                inten *= cx.colf[s * 4 + 3];
+                a0 += inten * cx.colf[s * 4 + 0];
+                a1 += inten * cx.colf[s * 4 + 1];
+                a2 += inten * cx.colf[s * 4 + 2];
+            }
+            pixel_finish(a0, a1, a2, j == PC_FOOD, r, g, b);
+        }
+        tab[4 * j + 0] = r;
+        tab[4 * j + 1] = g;
+        tab[4 * j + 2] = b;
+    }
+}
+
+// a cell whose code is PC_COMPLEX, rendered from the grids (interior cells only: the ring has its own code)
+__device__ __forceinline__ void pixel_slow(const Ctx &cx, int c, float &r, float &g, float &b)
+{
+    const int C = cx.C, K = cx.K;
+    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;
+    for (int s = 0; s < K; ++s) {
+        const bool isb = (int)(cx.body[s * C + c] & VMASK) > cx.tclk[s], ish = cx.hcell[s] == c;
+        if (isb || ish) { // a snake that is not on the cell adds inten = 0, i.e. nothing
+            const float third = 1.0f / 3.0f;
+            float inten = (isb ? third : 0.0f) + (ish ? third : 0.0f);
+            inten *= cx.colf[s * 4 + 3];
+            a0 += inten * cx.colf[s * 4 + 0];
+            a1 += inten * cx.colf[s * 4 + 1];
+            a2 += inten * cx.colf[s * 4 + 2];
+        }
+    }
+    pixel_finish(a0, a1, a2, cx.food[c] != 0, r, g, b);
+}
+
 __device__ __forceinline__ void observe_partial(const Ctx &cx, const MultiArgs &p, float *__restrict__ obs,
                                                 long long env, const Snake &sn)
 {
-    const int S = cx.S, C = cx.C, K = cx.K, lane = cx.lane, n = p.obs_n;
+    const int S = cx.S, K = cx.K, lane = cx.lane, n = p.obs_n;
+    unsigned char *const codes = cx.hmap;      // (the head map of observe_full: free in a launch that writes crops)
+    float *const tab = (float *)cx.img;        // 16 bytes per code (multi_layout: need_img)
     if (lane < K) {
         cx.colf[lane * 4 + 0] = (float)sn.col[0];
         cx.colf[lane * 4 + 1] = (float)sn.col[1];
@@ -795,69 +948,34 @@ __device__ __forceinline__ void observe_partial(const Ctx &cx, const MultiArgs &
         cx.hcell[lane] = sn.hc;
     }
     wave_lds_sync();
-    // Which snakes are on a cell: four snakes per pass with their clocks and head cells in registers, so that the body
-    // reads of one cell are independent LDS loads issued together; only the snakes found there enter the colour sum
-    // (in ascending index, the reference's summation order :201-205).
-    int tk[4], hk[4];
-    auto four = [&](int s0) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const bool in = s0 + j < K;
-            tk[j] = in ? cx.tclk[s0 + j] : 0x7fffffff;
-            hk[j] = in ? cx.hcell[s0 + j] : -2;
-        }
-    };
-    four(0);
+    pixel_table(cx, tab);
+    if (!sn.cmap_ok) cell_codes(cx, sn.hc, codes, cx.has_ring ? cx.ring : border_bits(cx));
+    wave_lds_sync(); // (the table)
+    WURM_TLS(cx, 13);
     const int W = 2 * n + 1, W2 = W * W;
     const float rcpW = 1.0f / (float)W;
     const long long agent_stride = p.N * p.obs_elems;
     float *const o_env = obs + env * p.obs_elems;
     const u64 dead = ballot(lane < K && sn.done); // a dead observer sees zeros (:320-323)
-    for (int a = 0; a < K; ++a) {
-        float *const o = (float *)uniform64((long long)(o_env + (long long)a * agent_stride));
-        const int h = ((dead >> a) & 1ull) ? -1 : lane_value(sn.hc, a);
-        if (h < 0) {
-            for (int w = lane; w < W2; w += 64) { o[w] = 0.0f; o[W2 + w] = 0.0f; o[2 * W2 + w] = 0.0f; }
-            continue;
-        }
-        const int hy = div_size(h, cx.rcpS), hx = h - hy * S; // (uniform)
-        for (int w = lane; w < W2; w += 64) {
-            const int wy = div_size(w, rcpW), wx = w - wy * W;
-            const int y = hy - n + wy, x = hx - n + wx;
-            float r = 0.0f, g = 0.0f, b = 0.0f; // the zero padding (:302)
-            if (y >= 0 && y < S && x >= 0 && x < S) {
-                const int c = y * S + x;
-                float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;
-                for (int s0 = 0; s0 < K; s0 += 4) {
-                    if (K > 4) four(s0); // more than four snakes: the registers are re-filled per pass
-                    unsigned short bv[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) bv[j] = cx.body[min(s0 + j, K - 1) * C + c];
-                    u32 mb = 0, mh = 0;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        mb |= (u32)((int)(bv[j] & VMASK) > tk[j]) << j;
-                        mh |= (u32)(hk[j] == c) << j;
-                    }
-                    for (u32 m = mb | mh; m; m &= m - 1) {
-                        const int j = __ffs((int)m) - 1, s = s0 + j;
-                        // :197 `body.float() * 1/3 + head.float() * 1/3`: 1.0f / 3.0f is the correctly rounded quotient the
-                        // two IEEE divisions gave; a snake that is not on the cell adds inten = 0, i.e. nothing
-                        const float third = 1.0f / 3.0f;
-                        float inten = (((mb >> j) & 1u) ? third : 0.0f) + (((mh >> j) & 1u) ? third : 0.0f);
-                        inten *= cx.colf[s * 4 + 3];
-                        a0 += inten * cx.colf[s * 4 + 0];
-                        a1 += inten * cx.colf[s * 4 + 1];
-                        a2 += inten * cx.colf[s * 4 + 2];
+    for (int w = lane; w < W2; w += 64) {
+        // the lane's window cell relative to the observer's head: the same for every agent
+        const int wy = div_size(w, rcpW), wx = w - wy * W, dy = wy - n, dx = wx - n;
+        for (int a = 0; a < K; ++a) {
+            float *const o = (float *)uniform64((long long)(o_env + (long long)a * agent_stride));
+            const int h = ((dead >> a) & 1ull) ? -1 : lane_value(sn.hc, a);
+            float r = 0.0f, g = 0.0f, b = 0.0f; // a dead observer; the zero padding (:302)
+            if (h >= 0) {
+                const int hy = div_size(h, cx.rcpS), hx = h - hy * S; // (uniform)
+                const int y = hy + dy, x = hx + dx;
+                if (y >= 0 && y < S && x >= 0 && x < S) {
+                    const int c = y * S + x;
+                    const int code = codes[c];
+                    if (code == PC_COMPLEX) pixel_slow(cx, c, r, g, b);
+                    else {
+                        const float4 t = *(const float4 *)(tab + 4 * code);
+                        r = t.x; g = t.y; b = t.z;
                     }
                 }
-                int ri = (int)a0, gi = (int)a1, bi = (int)a2;     // :206 .short() truncates
-                if (cx.food[c]) ri += 255;                          // :208-209
-                if (ri == 0 && gi == 0 && bi == 0) ri = gi = bi = 255; // :214-219
-                if (y == 0 || x == 0 || y == S - 1 || x == S - 1) ri = gi = bi = 0; // :225
-                r = div255(ri);
-                g = div255(gi);
-                b = div255(bi);
             }
             o[w] = r;
             o[W2 + w] = g;
@@ -955,39 +1073,73 @@ __device__ __forceinline__ void multi_step_body(const Ctx &cx, const MultiArgs &
     WURM_TLS(cx, 5);
 
     // _add_food (:368-410)
+    bool cmap_ok = false;
     {
         const int nfood = food_count(cx);
+        WURM_TLS(cx, 10);
+        // The map of cell codes (cell_codes: one scan of the K grids) serves both "which interior cells are free" here and the
+        // crops of observe_partial; it lives where observe_full keeps its head map, so only launches without 'full'
+        // observations build it.
+        const bool want_free = p.cfg.food_mode == 0 ? (nfood == 0 && !p.has_inj) : nfood < p.cfg.max_food;
+        if (p.obs_mode != WURM_OBS_DEFAULT && cx.has_ring && (want_free || p.obs_mode == WURM_OBS_PARTIAL)) {
+            cell_codes(cx, hc, cx.hmap, cx.ring);
+            cmap_ok = true;
+        }
         if (p.cfg.food_mode == 0) {
             if (nfood == 0) {                   // :371-379
                 if (p.has_inj) {
                     int cell = p.inj.food_cell[offE + env];
-                    if (cell >= 0 && cell < C && lane == 0) cx.food[cell] = 1;
+                    if (cell >= 0 && cell < C && lane == 0) put_food(cx, cell, cmap_ok);
                 } else {
-                    u64 fr = free_cells(cx, hc, 1);
+                    u64 fr = cmap_ok ? free_from_codes(cx, cx.hmap) : free_cells(cx, hc, 1);
                     int nf = count_bits(cx, fr);
                     if (nf > 0) {
                         int Kr = (int)mulhi_range(rng_words(p.seed, call, env_id, RNG_FOOD, 0).w[0], (u32)nf);
                         int k = rank_select(cx, fr, Kr);
-                        if (k >= 0) cx.food[lane + 64 * k] = 1;
+                        if (k >= 0) put_food(cx, lane + 64 * k, cmap_ok);
                     }
                 }
             }
         } else if (nfood < p.cfg.max_food) {    // :382-408
-            u64 fr = free_cells(cx, hc, 1);
+            u64 fr = cmap_ok ? free_from_codes(cx, cx.hmap) : free_cells(cx, hc, 1);
+            WURM_TLS(cx, 11);
             if (p.has_inj) {
                 for (int k = 0; k < cx.cpl; ++k)
-                    if (((fr >> k) & 1) && p.inj.rate[offC + env * C + lane + 64 * k] != 0) cx.food[lane + 64 * k] = 1;
+                    if (((fr >> k) & 1) && p.inj.rate[offC + env * C + lane + 64 * k] != 0) put_food(cx, lane + 64 * k, cmap_ok);
             } else {
-                // cell_u01: the cells lane + 64k, k = 4j .. 4j+3, share Philox block j of this lane (word k & 3) — one
-                // evaluation for the four of them (this draw ran once per CELL and was 12 of the 26 us of a step at
-                // 4096 x 25 x 25 with the reference's multi-agent defaults)
-                for (int j = 0; 4 * j < cx.cpl; ++j) {
-                    const u32 four = (u32)(fr >> (4 * j)) & 15u;
-                    if (!four) continue;
-                    const Words w = rng_words(p.seed, call, env_id, RNG_RATE_FOOD, ((u32)j << 6) | (u32)lane);
+                // Every free cell spawns food independently with probability food_rate (:401-408).  RNG mode draws the NUMBER
+                // of cells — Binomial(n free, food_rate) by inversion from ONE uniform — and then that many distinct cells,
+                // the j-th as the mulhi(word, n - j)-th remaining free cell in row-major order: the same distribution as n
+                // independent draws (this build's own RNG specification, oracle/multi_snake.c step_env), for one Philox block
+                // per env-step instead of one per four cells and lane (625 draws to place 0.13 foods on average at cfg4').
+                const int nf = count_bits(cx, fr);
+                const float pw = pow_n(1.0f - p.cfg.food_rate, nf);
+                if (!(p.cfg.food_rate > 0.0f) || pw < BINOMIAL_MIN_P0) {
+                    // P(no food) too small for the recurrence (rates far above the reference's): cell by cell — the cells
+                    // lane + 64k, k = 4j .. 4j+3, share Philox block j of this lane (word k & 3)
+                    for (int j = 0; 4 * j < cx.cpl; ++j) {
+                        const u32 four = (u32)(fr >> (4 * j)) & 15u;
+                        if (!four) continue;
+                        const Words w = rng_words(p.seed, call, env_id, RNG_RATE_FOOD, ((u32)j << 6) | (u32)lane);
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        if (((four >> q) & 1u) && u01(w.w[q]) < p.cfg.food_rate) cx.food[lane + 64 * (4 * j + q)] = 1;
+                        for (int q = 0; q < 4; ++q)
+                            if (((four >> q) & 1u) && u01(w.w[q]) < p.cfg.food_rate) put_food(cx, lane + 64 * (4 * j + q), cmap_ok);
+                    }
+                } else {
+                    Words w = rng_words(p.seed, call, env_id, RNG_RATE_FOOD, 0);
+                    const int kf = uniform(binomial_inverse(nf, p.cfg.food_rate, pw, u01(w.w[0])));
+                    WURM_TLS(cx, 12);
+                    for (int j = 0; j < kf; ++j) {
+                        const int wi = j + 1;
+                        if ((wi & 3) == 0) w = rng_words(p.seed, call, env_id, RNG_RATE_FOOD, (u32)(wi >> 2));
+                        const u32 wj = (wi & 3) == 0 ? w.w[0] : (wi & 3) == 1 ? w.w[1] : (wi & 3) == 2 ? w.w[2] : w.w[3];
+                        const int Kr = (int)mulhi_range(wj, (u32)(nf - j));
+                        const int k = rank_select(cx, fr, Kr);
+                        if (k >= 0) {
+                            put_food(cx, lane + 64 * k, cmap_ok);
+                            fr &= ~(1ull << k);
+                        }
+                    }
                 }
             }
         }
@@ -1002,6 +1154,7 @@ __device__ __forceinline__ void multi_step_body(const Ctx &cx, const MultiArgs &
     sn.done = done;
     sn.orient = orient;
     sn.boosted = boosted;
+    sn.cmap_ok = cmap_ok;
     res.reward = reward;
     res.foodcons = foodcons;
     res.snakecol = snakecol;
@@ -1268,7 +1421,7 @@ __global__ __launch_bounds__(512) void multi_step_kernel(MultiArgs p)
     } else if (env >= p.N) return;
     const bool active = env < p.N;
     if (solo && !active) return;
-    const Ctx cx = make_ctx(p, wave);
+    const Ctx cx = make_ctx(p, wave, 0, p.obs_mode != WURM_OBS_DEFAULT); // (the ring bits: multi_step_body's map of cell codes)
     const int C = cx.C, K = cx.K, lane = cx.lane;
     const bool snake = lane < K;
     const int nG = (int)min((long long)wpb, p.N - env0);
@@ -1790,6 +1943,7 @@ __device__ __forceinline__ void multi_reset_grid(const Ctx &cx, const MultiArgs 
 {
     const int C = cx.C, K = cx.K, lane = cx.lane;
     const bool snake = lane < K;
+    sn.cmap_ok = false; // (the map of cell codes describes the state before this reset)
     if (rebuild) { // _create_envs (:996-1019)
         { // value 0; a cell that ever held one stays marked.  Four cells per access: the grids start on a 16-byte
           // boundary and are followed by padding up to the next one, so the last access may run into the padding.
@@ -2093,7 +2247,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void m
     const int wave = uniform((int)(threadIdx.x >> 6)), wpb = TWO ? 1 : (int)(blockDim.x >> 6);
     const long long env = xcd_block(blockIdx.x, gridDim.x) * wpb + (TWO ? 0 : wave);
     if (env >= p.N) return;
-    const Ctx cx = make_ctx(p, TWO ? 0 : wave);
+    const Ctx cx = make_ctx(p, TWO ? 0 : wave, 0, !TWO && p.obs_mode != WURM_OBS_DEFAULT);
     const int C = cx.C, K = cx.K, lane = cx.lane;
     if (TWO && wave == 1) { // the writer: observation of step t from buffer t & 1, handed over by the barrier of step t
         const long long KNw = (long long)K * p.N;
@@ -2819,7 +2973,7 @@ static int multi_layout(MultiArgs &p, bool need_img, int need_snap)
     off = (off + 15) & ~15;
     p.off_hmap = off; off += C;
     off = (off + 15) & ~15;
-    p.off_img = off; (void)need_img;        // (round 2 kept the env image of partial_n here: 8 bytes per cell)
+    p.off_img = off; if (need_img) off += 16 * (2 * K + 3); // partial_n: the pixel table (pixel_table), 16 bytes per cell code
     off = (off + 15) & ~15;
     p.off_snap = -1;
     if (need_snap) { p.off_snap = off; off += need_snap * ((2 * C + 15) & ~15); }

@@ -57,6 +57,38 @@ __device__ __forceinline__ Words rng_words(u64 seed, u64 call, u64 env_id, u32 p
 __device__ __forceinline__ u32 mulhi_range(u32 w, u32 n) { return __umulhi(w, n); } // uniform in [0,n)
 __device__ __forceinline__ float u01(u32 w) { return (float)(w >> 8) * (1.0f / 16777216.0f); }
 
+// q^n in fp32 by binary exponentiation — this exact operation order is the specification (oracle/oracle_common.h:
+// oracle_pow_n does the same); 0 <= q <= 1
+__device__ __forceinline__ float pow_n(float q, int n)
+{
+    float pw = 1.0f, base = q;
+    for (int e = n; e; e >>= 1) {
+        if (e & 1) pw = pw * base;
+        base = base * base;
+    }
+    return pw;
+}
+
+// Number of successes among n independent Bernoulli(p) trials from ONE uniform u, by inversion of the Binomial(n, p)
+// distribution function (oracle/oracle_common.h: oracle_binomial_inverse, the same fp32 operations in the same order).
+// pw = pow_n(1 - p, n) = P(0 successes), which the caller has compared against BINOMIAL_MIN_P0 (below it the recurrence
+// starts from a number with too few bits, or from an underflowed 0: the caller draws cell by cell instead).
+constexpr float BINOMIAL_MIN_P0 = 1e-6f;
+__device__ __forceinline__ int binomial_inverse(int n, float p, float pw, float u)
+{
+    const float r = p / (1.0f - p);
+    float pmf = pw, cdf = pw;
+    int k = 0;
+    while (u >= cdf && k < n) {
+        pmf = pmf * ((float)(n - k) * r) / (float)(k + 1);
+        const float nc = cdf + pmf;
+        ++k;
+        if (nc == cdf) break; // the tail beyond is below the rounding of the sum
+        cdf = nc;
+    }
+    return k;
+}
+
 // per-cell uniform: cells c, c+64, c+128, c+192 share one Philox block (sub = (c >> 8) * 64 + (c & 63),
 // word = (c >> 6) & 3), so the lane that owns them (c & 63) computes one block for four of its cells.
 __device__ __forceinline__ float cell_u01(u64 seed, u64 call, u64 env_id, u32 purpose, u32 cell)
