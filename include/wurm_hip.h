@@ -385,6 +385,24 @@ int wurm_multi_step_reset(const wurm_multi_call *c, void *stream);
 int wurm_multi_step_packed(wurm_multi_call *c, float *out_f32, uint8_t *out_u8, float *obs, float *obs_after,
                            const int64_t *actions, uint64_t call, int apply_pending, uint64_t pre_call, void *stream);
 
+/* Caller-allocated output slabs holding the fresh output tensors of the next `steps` step() calls of MultiSnake (as
+ * wurm_single_slabs: the host class carves the tensors of its per-agent dicts, multi_snake.py:701-729, out of them ONCE per
+ * slab; a slab is never written twice).  Per step the layouts of wurm_multi_step_packed:
+ * out_f32 (steps, 6 K N) floats; out_u8 (steps, 7 K N + N) bytes; obs, obs_after (steps, K, N, elems) floats. */
+typedef struct wurm_multi_slabs {
+    float *out_f32;
+    uint8_t *out_u8;
+    float *obs;
+    float *obs_after; /* nullable */
+    int64_t steps;
+    int64_t obs_elems; /* floats per (agent, env) of an observation: wurm_multi_obs_elems(c->obs_mode, c->obs_n, c->size) */
+} wurm_multi_slabs;
+
+/* wurm_multi_step_packed on slot `slot` of the slabs (obs_after only if want_obs_after): one C call per
+ * `env.step(actions)` with nothing to allocate or to compute on the host (wurm_amd/csrc/fastcall.c: Stepper.step_multi). */
+int wurm_multi_step_slot(wurm_multi_call *c, const wurm_multi_slabs *slabs, int64_t slot, const int64_t *actions,
+                         uint64_t call, int apply_pending, uint64_t pre_call, int want_obs_after, void *stream);
+
 /* The mirror of wurm_multi_call.resident: per env the 16-bit clock grids of the K bodies, the food grid as bytes and three
  * ints per snake — (2 K + 1) S^2 bytes and change instead of (1 + 2 K) S^2 fp32 read every call
  * (wurm_amd/csrc/multi_snake.hip).  Returns its size in bytes, 0 if it is not offered for this batch (fewer than 2^20

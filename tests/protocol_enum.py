@@ -272,10 +272,15 @@ class MultiDriver(object):
         return pack((e.foods, e.heads, e.bodies, e.dones, e.orientations, e.agent_colours)), int(e._call)
 
 
-def install_multi(monkeypatch, rollout_keeps_mirror=True):
+def install_multi(monkeypatch, rollout_keeps_mirror=True, machine='python'):
     sim = ps.SimMulti()
     sim.rollout_keeps_mirror = rollout_keeps_mirror
-    ps.install(monkeypatch, sim, torch)
+    tinfo = None
+    if machine == 'c+torchinfo':
+        from tests.test_host_lazy_reset import _torchinfo_addresses
+        sim._keep = _torchinfo_addresses()
+        tinfo = sim._keep[1]
+    ps.install(monkeypatch, sim, torch, c_stepper=machine != 'python', torchinfo=tinfo)
     return sim
 
 

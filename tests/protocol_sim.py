@@ -309,6 +309,20 @@ class SimSingle(object):
 
 _STEP_SLOT_T = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
                                 ctypes.c_int, ctypes.c_uint64, ctypes.c_int, ctypes.c_uint64, ctypes.c_int, ctypes.c_void_p)
+_MULTI_SLOT_T = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
+                                 ctypes.c_uint64, ctypes.c_int, ctypes.c_uint64, ctypes.c_int, ctypes.c_void_p)
+
+
+class CMultiSlot(object):
+    """a stand-in's wurm_multi_step_slot behind a real C function pointer (wurm_amd._fastcall.Stepper, multi side)"""
+
+    def __init__(self, sim):
+        self._cb = _MULTI_SLOT_T(lambda c, sl, slot, a, call, pend, pre, want, st: sim.step_slot(c, sl, slot, a, call, pend, pre,
+                                                                                         want, st))
+        self.c_address = ctypes.cast(self._cb, ctypes.c_void_p).value
+
+    def __call__(self, *args):
+        return self._cb(*args)
 
 
 class CSlot(object):
@@ -409,11 +423,19 @@ class SimMulti(object):
         return bytes(c) if isinstance(c, ctypes.Structure) else bytes(_lib.MultiConfig.from_address(_addr(c)))
 
     @staticmethod
+    def _reset_cfg(cfgb):
+        """what wurm_multi_reset reads of the configuration: respawn_any and colour_random (multi_snake.hip: reroll_colour,
+        multi_reset_grid; reference :800-831) — a change of the step dynamics between step and reset does not matter to it"""
+        c = _lib.MultiConfig.from_buffer_copy(cfgb)
+        return b'%d,%d' % (c.respawn_any, c.colour_random)
+
+    @staticmethod
     def _reset_toks(mt, rt, d, call, off, cfgb):
         """after wurm_multi_reset(done_env = d): EVERY env passes through it (colours of snakes that are still dead are
         re-rolled, respawn 'any' acts on envs that are not flagged), so every token changes; flagged envs become fresh, the
         others keep the checker's verdict (a respawned snake is a well-formed one)"""
         out = []
+        cfgb = SimMulti._reset_cfg(cfgb)
         for e, (m, r) in enumerate(zip(mt, rt)):
             hv = H('mreset', m, r, call, off + e, int(d[e]), cfgb)
             out.append(((hv << 2) | (1 if d[e] else (m & 2))) & MASK64)
@@ -480,6 +502,20 @@ class SimMulti(object):
         raw = hashlib.shake_128(b'o' + b''.join(_tb(t) for t in toks)).digest(13 * K * N)
         return (np.frombuffer(raw[:6 * K * N], np.uint8).astype(np.float32).reshape(6 * K, N),
                 (np.frombuffer(raw[6 * K * N:], np.uint8) & 1).reshape(7 * K, N))
+
+    def step_slot(self, c_addr, sl_addr, slot, actions, call, pending, pre_call, want_after, stream):
+        """wurm_multi_step_slot: wurm_multi_step_packed on slot `slot` of the slabs"""
+        c = _lib.MultiCall.from_address(_addr(c_addr))
+        sl = _lib.MultiSlabs.from_address(_addr(sl_addr))
+        slot = _int(slot)
+        assert 0 <= slot < sl.steps
+        KN = c.num_snakes * c.num_envs
+        per_obs = 4 * KN * sl.obs_elems
+        if want_after:
+            assert sl.obs_after, 'want_obs_after without a slab for it'
+        return self.step_packed(c_addr, sl.out_f32 + 4 * slot * 6 * KN, sl.out_u8 + slot * (7 * KN + c.num_envs),
+                                sl.obs + slot * per_obs, sl.obs_after + slot * per_obs if want_after else None, actions, call,
+                                pending, pre_call, stream)
 
     def step_packed(self, c_addr, of, ob, obs, obs_after, actions, call, pending, pre_call, stream):
         c = _lib.MultiCall.from_address(_addr(c_addr))
@@ -606,4 +642,7 @@ def install(monkeypatch, sim, torch, c_stepper=False, torchinfo=None):
             return err
         monkeypatch.setattr(U, 'consistency_mask', consistency_mask)
     else:
-        monkeypatch.setattr(_lib, 'multi_step_fn', lambda: sim.step_packed)
+        slot = CMultiSlot(sim) if c_stepper else sim.step_slot
+        sim._slot_keep = slot
+        monkeypatch.setattr(_lib, 'step_slot_fn', lambda name='wurm_multi_step_slot': slot)
+        monkeypatch.setattr(_lib, 'torch_helpers', lambda: torchinfo)

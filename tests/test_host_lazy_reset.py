@@ -93,7 +93,8 @@ def _torchinfo_addresses():
     l = ctypes.PyDLL(path)
     keep = (l, ctypes.CFUNCTYPE(ctypes.c_void_p, ctypes.c_int)(lambda idx: 0), ctypes.CFUNCTYPE(ctypes.c_int)(lambda: -1))
     return keep, (ctypes.cast(l.wurm_torch_tensor_info, ctypes.c_void_p).value,
-                  ctypes.cast(keep[1], ctypes.c_void_p).value, ctypes.cast(keep[2], ctypes.c_void_p).value)
+                  ctypes.cast(keep[1], ctypes.c_void_p).value, ctypes.cast(keep[2], ctypes.c_void_p).value,
+                  ctypes.cast(l.wurm_torch_alias_free, ctypes.c_void_p).value)   # (the real one: it works on CPU tensors)
 
 
 @pytest.fixture(params=['python', 'c', 'c+torchinfo'])

@@ -67,10 +67,10 @@ class _Lib(object):
         self.calls.append(('flush', {}))
         return 0
 
-    def step_packed(self, c_addr, of, ob, obs, obs_after, actions, call, pending, pre_call, stream):
+    def step_slot(self, c_addr, sl_addr, slot, actions, call, pending, pre_call, want_after, stream):
         c = _lib.MultiCall.from_address(c_addr)
         self.calls.append(('step', dict(mirror=bool(c.resident), valid=bool(c.resident_valid), lazy=bool(c.resident_lazy),
-                                        masks=bool(c.check_mask), pending=bool(pending), after=bool(obs_after))))
+                                        masks=bool(c.check_mask), pending=bool(pending), after=bool(want_after))))
         if c.resident:
             c.resident_valid = 1
         return 0
@@ -87,7 +87,8 @@ def env_and_log(monkeypatch):
     monkeypatch.setattr(_lib, 'stream_ptr', lambda i=None: 0)
     monkeypatch.setattr(_lib, 'call', lambda idx, fn, *a: fn(*a))
     monkeypatch.setattr(_lib, 'accessors', lambda: ((lambda: None), (lambda i: 0)))
-    monkeypatch.setattr(_lib, 'multi_step_fn', lambda: lib.step_packed)
+    monkeypatch.setattr(_lib, 'step_slot_fn', lambda name='wurm_multi_step_slot': lib.step_slot)
+    monkeypatch.setattr(_lib, 'torch_helpers', lambda: None)
     monkeypatch.setattr(_lib, 'ptr', lambda t: None if t is None else ctypes.c_void_p(t.data_ptr()))
     from wurm_amd.envs import MultiSnake
     env = MultiSnake(N, K, S, device='cpu', seed=1)

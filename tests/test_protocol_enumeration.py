@@ -79,10 +79,12 @@ def test_gridworld_every_sequence_up_to_3(monkeypatch, machine):
     _run_all(lambda twin=False: pe.make_single('grid', False, twin), pe.GridDriver.EVENTS, 3, GRID_REGRESSIONS)
 
 
-@pytest.mark.parametrize('mirror,keep', [(False, True), ('lazy', True), ('eager', True), (None, True), ('lazy', False),
-                                         (None, False)])
-def test_multi_snake_every_sequence_up_to_3(monkeypatch, mirror, keep):
-    pe.install_multi(monkeypatch, rollout_keeps_mirror=keep)
+@pytest.mark.parametrize('mirror,keep,machine', [(False, True, 'python'), ('lazy', True, 'python'), ('eager', True, 'python'),
+                                                 (None, True, 'python'), ('lazy', False, 'python'), (None, False, 'python'),
+                                                 (None, True, 'c'), (None, True, 'c+torchinfo'), ('lazy', False, 'c+torchinfo')])
+def test_multi_snake_every_sequence_up_to_3(monkeypatch, mirror, keep, machine):
+    _machine_or_skip(machine)
+    pe.install_multi(monkeypatch, rollout_keeps_mirror=keep, machine=machine)
     _run_all(lambda twin=False: pe.make_multi(mirror, twin), pe.MultiDriver.EVENTS, 3, MULTI_REGRESSIONS)
 
 

@@ -25,10 +25,11 @@ def _configs():
             out.append(('single', mirror, machine))
     for machine in ('python', 'c', 'c+torchinfo'):
         out.append(('grid', False, machine))
-    for mirror in (False, 'lazy', 'eager', None):
-        out.append(('multi', mirror, 'keep'))
-    out.append(('multi', 'lazy', 'nokeep'))
-    out.append(('multi', None, 'nokeep'))
+    for machine in ('python', 'c', 'c+torchinfo'):
+        for mirror in (False, 'lazy', 'eager', None):
+            out.append(('multi', mirror, 'keep/' + machine))
+        out.append(('multi', 'lazy', 'nokeep/' + machine))
+        out.append(('multi', None, 'nokeep/' + machine))
     return out
 
 
@@ -39,7 +40,8 @@ def _work(job):
     mpatch = pytest.MonkeyPatch()
     try:
         if kind == 'multi':
-            pe.install_multi(mpatch, rollout_keeps_mirror=machine == 'keep')
+            keep, mach = machine.split('/')
+            pe.install_multi(mpatch, rollout_keeps_mirror=keep == 'keep', machine=mach)
             events = pe.MultiDriver.EVENTS
             make = lambda twin=False: pe.make_multi(mirror, twin)  # noqa: E731
         else:
@@ -74,7 +76,7 @@ def main():
     for cfg in _configs():
         if args.only and cfg[0] != args.only:
             continue
-        if args.machines and cfg[0] != 'multi' and cfg[2] not in args.machines.split(','):
+        if args.machines and cfg[2].split('/')[-1] not in args.machines.split(','):
             continue
         events = pe.MultiDriver.EVENTS if cfg[0] == 'multi' else (pe.SingleDriver.EVENTS if cfg[0] == 'single' else pe.GridDriver.EVENTS)
         for L in range(1, args.length + 1):

@@ -24,7 +24,7 @@ SYMBOLS = [
     'wurm_single_step', 'wurm_single_reset', 'wurm_single_observe', 'wurm_single_rollout', 'wurm_single_check',
     'wurm_single_step_reset', 'wurm_single_resident_bytes', 'wurm_single_resident_size', 'wurm_single_resident_flush', 'wurm_grid_step_reset', 'wurm_single_step_slot', 'wurm_grid_step_slot',
     'wurm_grid_step', 'wurm_grid_reset', 'wurm_grid_observe', 'wurm_grid_rollout',
-    'wurm_multi_obs_elems', 'wurm_multi_step', 'wurm_multi_step_reset', 'wurm_multi_step_packed', 'wurm_multi_resident_bytes', 'wurm_multi_resident_size', 'wurm_multi_resident_flush', 'wurm_multi_reset', 'wurm_multi_observe', 'wurm_multi_check',
+    'wurm_multi_obs_elems', 'wurm_multi_step', 'wurm_multi_step_reset', 'wurm_multi_step_packed', 'wurm_multi_step_slot', 'wurm_multi_resident_bytes', 'wurm_multi_resident_size', 'wurm_multi_resident_flush', 'wurm_multi_reset', 'wurm_multi_observe', 'wurm_multi_check',
     'wurm_multi_rollout', 'wurm_multi_rollout_resident',
     'wurm_multi_colours', 'wurm_orientations',
     'wurm_a2c_returns', 'wurm_a2c_returns_backward', 'wurm_single_stats', 'wurm_single_policy_rollout',
@@ -82,6 +82,12 @@ class MultiCall(ctypes.Structure):
         ('obs_mode', ctypes.c_int), ('obs_n', ctypes.c_int), ('cfg', MultiConfig), ('resident', ctypes.c_void_p),
         ('resident_valid', ctypes.c_int), ('resident_lazy', ctypes.c_int), ('check_mask', ctypes.c_void_p),
         ('check_mask_after', ctypes.c_void_p)]
+
+
+class MultiSlabs(ctypes.Structure):
+    """wurm_multi_slabs of include/wurm_hip.h"""
+    _fields_ = [('out_f32', ctypes.c_void_p), ('out_u8', ctypes.c_void_p), ('obs', ctypes.c_void_p),
+                ('obs_after', ctypes.c_void_p), ('steps', ctypes.c_int64), ('obs_elems', ctypes.c_int64)]
 
 
 def multi_config(num_snakes, boost, food_on_death_prob, boost_cost_prob, food_mode, food_rate, reward_on_death,
@@ -163,14 +169,16 @@ class _SlotFn(object):
     """wurm_single_step_slot / wurm_grid_step_slot as a Python callable (through the CPython shim wurm_amd/_fastcall when
     it is built, else ctypes) that also carries the C address of the entry point for wurm_amd._fastcall.Stepper."""
 
-    def __init__(self, cfn):
+    def __init__(self, cfn, shim=True):
         self.c_address = ctypes.cast(cfn, ctypes.c_void_p).value
-        try:
-            import functools
-            from wurm_amd import _fastcall
-            self._call = functools.partial(_fastcall.step_slot, self.c_address)
-        except ImportError:
-            self._call = cfn
+        self._call = cfn
+        if shim:  # (wurm_multi_step_slot has another signature: the ctypes function itself)
+            try:
+                import functools
+                from wurm_amd import _fastcall
+                self._call = functools.partial(_fastcall.step_slot, self.c_address)
+            except ImportError:
+                pass
 
     def __call__(self, *args):
         return self._call(*args)
@@ -181,7 +189,7 @@ def step_slot_fn(name: str = 'wurm_single_step_slot'):
     whichever way it ends up being called."""
     fn = _step_slot.get(name)
     if fn is None:
-        fn = _step_slot[name] = _SlotFn(getattr(lib(), name))
+        fn = _step_slot[name] = _SlotFn(getattr(lib(), name), shim=name != 'wurm_multi_step_slot')
     return fn
 
 
@@ -301,9 +309,9 @@ def _torch_accessors():
 _torchinfo = None
 
 
-def torch_helpers():
-    """(tensor_info, raw_stream, current_device) addresses of wurm_amd/libwurm_torchinfo.so (csrc/torchinfo.cpp: facts about
-    a tensor and torch's current device / stream straight from ATen), or None if that optional helper is not built."""
+def _load_torchinfo():
+    """(library, addresses of its three per-step helpers) of wurm_amd/libwurm_torchinfo.so, or False if that optional
+    helper is not built / switched off (WURM_TORCHINFO=0)"""
     global _torchinfo
     if _torchinfo is None:
         _torchinfo = False
@@ -313,10 +321,44 @@ def torch_helpers():
                 import torch  # noqa: F401  (its libraries first: the helper links against them)
                 l = ctypes.PyDLL(path)
                 _torchinfo = (l, tuple(ctypes.cast(getattr(l, n), ctypes.c_void_p).value for n in
-                                       ('wurm_torch_tensor_info', 'wurm_torch_raw_stream', 'wurm_torch_current_device')))
+                                       ('wurm_torch_tensor_info', 'wurm_torch_raw_stream', 'wurm_torch_current_device',
+                                        'wurm_torch_alias_free')))
             except (OSError, AttributeError):
                 _torchinfo = False
-    return _torchinfo[1] if _torchinfo else None
+    return _torchinfo
+
+
+def torch_helpers():
+    """(tensor_info, raw_stream, current_device, alias_free) addresses of wurm_amd/libwurm_torchinfo.so (csrc/torchinfo.cpp: facts about
+    a tensor and torch's current device / stream straight from ATen), or None if that optional helper is not built."""
+    t = _load_torchinfo()
+    return t[1] if t else None
+
+
+_row_views = None
+
+
+def row_views(t, lead: int, lo: int = 0, hi: int = -1):
+    """The leading `lead` dimensions of the contiguous tensor `t` unbound at once: a list of prod(t.shape[:lead]) views of
+    shape t.shape[lead:] that share t's storage and version counter — through wurm_amd/libwurm_torchinfo.so
+    (csrc/torchinfo.cpp: wurm_torch_row_views, ~0.3 us per view) where it is built, else `unbind` (~0.65 us per view).
+    lead == 2 with lo / hi: only the rows lo <= j < hi of the second dimension (for each index of the first)."""
+    global _row_views
+    if _row_views is None:
+        _row_views = False
+        info = _load_torchinfo()
+        if info:
+            try:
+                fn = info[0].wurm_torch_row_views
+                fn.restype, fn.argtypes = ctypes.py_object, [ctypes.py_object] + [ctypes.c_longlong] * 3
+                _row_views = fn
+            except AttributeError:
+                pass
+    if _row_views:
+        return _row_views(t, lead, lo, hi)
+    if lead == 2 and hi >= 0:
+        return [v for part in t.unbind(0) for v in part[lo:hi].unbind(0)]
+    return list(t.reshape((-1,) + tuple(t.shape[lead:])).unbind(0))
 
 
 def accessors():

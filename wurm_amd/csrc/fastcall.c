@@ -90,17 +90,26 @@ typedef struct wurm_tensor_info { void *ptr; long long size0; int dtype, dim, co
 typedef int (*tensor_info_fn)(PyObject *, wurm_tensor_info *);
 typedef void *(*raw_stream_fn)(int);
 typedef int (*current_device_fn)(void);
+typedef int (*alias_free_fn)(PyObject *);
+
+typedef int (*multi_slot_fn)(void *call_block, const void *slabs, int64_t slot, const int64_t *actions, uint64_t call,
+                             int apply_pending, uint64_t pre_call, int want_obs_after, void *stream);
 
 typedef struct {
     PyObject_HEAD
-    step_slot_fn fn;
+    step_slot_fn fn;           /* wurm_single_step_slot / wurm_grid_step_slot; with `multi`: a multi_slot_fn (wurm_multi_step_slot) */
     tensor_info_fn tinfo;      /* all three or none */
     raw_stream_fn raw_stream;
     current_device_fn cur_dev;
+    alias_free_fn alias_fn;    /* optional fourth helper: "nobody else holds a tensor on these storages" */
+    PyObject *state;           /* tuple of the state tensors a reset may only be postponed for while nobody else holds them, or None */
+    PyObject *alias_free;      /* Python callable saying the same (used where alias_fn is missing), or None */
     void *blk, *slabs;
     long long slot, R, num_envs, dev_index, slab_version;
     unsigned long long call, pend_call, steps;
-    char ok, pending, last_fresh, want_obs_after, lazy_ok;
+    char ok, pending, last_fresh, want_obs_after, lazy_ok, multi;
+    long long num_agents;                         /* MultiSnake: K */
+    PyObject *last_out;                           /* what the last step returned */
     PyObject *outs, *done2s, *obs_afters;         /* per slot of the current slab: output tuple, (N,1) done, reset obs */
     PyObject *last_done2, *done_view, *obs_after; /* of the last step */
     PyObject *watch;                              /* a tensor the caller may edit in place (the state), or None ... */
@@ -122,8 +131,9 @@ static void set_obj(PyObject **slot, PyObject *v)
 static int stepper_init(Stepper *self, PyObject *args, PyObject *kwds)
 {
     (void)kwds;
-    PyObject *fn, *blk, *slabs, *gd, *gs, *d64, *d32, *d16, *ti = NULL, *rs = NULL, *cd = NULL;
-    if (!PyArg_ParseTuple(args, "OOOOOOOO|OOO", &fn, &blk, &slabs, &gd, &gs, &d64, &d32, &d16, &ti, &rs, &cd)) return -1;
+    PyObject *fn, *blk, *slabs, *gd, *gs, *d64, *d32, *d16, *ti = NULL, *rs = NULL, *cd = NULL, *af = NULL;
+    if (!PyArg_ParseTuple(args, "OOOOOOOO|OOOO", &fn, &blk, &slabs, &gd, &gs, &d64, &d32, &d16, &ti, &rs, &cd, &af)) return -1;
+    self->alias_fn = (af && af != Py_None) ? (alias_free_fn)PyLong_AsVoidPtr(af) : NULL;
     self->fn = (step_slot_fn)PyLong_AsVoidPtr(fn);
     self->tinfo = NULL; self->raw_stream = NULL; self->cur_dev = NULL;
     if (ti && rs && cd && ti != Py_None && rs != Py_None && cd != Py_None) { /* addresses of torchinfo.cpp's helpers */
@@ -144,6 +154,11 @@ static int stepper_init(Stepper *self, PyObject *args, PyObject *kwds)
     set_obj(&self->outs, Py_None); set_obj(&self->done2s, Py_None); set_obj(&self->obs_afters, Py_None);
     set_obj(&self->last_done2, Py_None); set_obj(&self->done_view, Py_None); set_obj(&self->obs_after, Py_None);
     set_obj(&self->watch, Py_None);
+    set_obj(&self->last_out, Py_None);
+    set_obj(&self->state, Py_None);
+    set_obj(&self->alias_free, Py_None);
+    self->multi = 0;
+    self->num_agents = 0;
     self->watch_version = -1;
     self->slot = self->R = 0;
     self->slab_version = -1;
@@ -156,6 +171,7 @@ static int stepper_traverse(Stepper *self, visitproc visit, void *arg)
 {
     Py_VISIT(self->outs); Py_VISIT(self->done2s); Py_VISIT(self->obs_afters);
     Py_VISIT(self->last_done2); Py_VISIT(self->done_view); Py_VISIT(self->obs_after); Py_VISIT(self->watch);
+    Py_VISIT(self->last_out); Py_VISIT(self->state); Py_VISIT(self->alias_free);
     Py_VISIT(self->get_device); Py_VISIT(self->get_stream);
     Py_VISIT(self->dt_i64); Py_VISIT(self->dt_i32); Py_VISIT(self->dt_i16);
     return 0;
@@ -165,6 +181,7 @@ static int stepper_clear(Stepper *self)
 {
     Py_CLEAR(self->outs); Py_CLEAR(self->done2s); Py_CLEAR(self->obs_afters);
     Py_CLEAR(self->last_done2); Py_CLEAR(self->done_view); Py_CLEAR(self->obs_after); Py_CLEAR(self->watch);
+    Py_CLEAR(self->last_out); Py_CLEAR(self->state); Py_CLEAR(self->alias_free);
     Py_CLEAR(self->get_device); Py_CLEAR(self->get_stream);
     Py_CLEAR(self->dt_i64); Py_CLEAR(self->dt_i32); Py_CLEAR(self->dt_i16);
     return 0;
@@ -196,6 +213,10 @@ static PyObject *stepper_finish(Stepper *self, long long i, int rc);
 static PyObject *stepper_step(Stepper *self, PyObject *actions)
 {
     wurm_tensor_info ti;
+    if (self->multi) {
+        PyErr_SetString(PyExc_RuntimeError, "Stepper.step: this machine drives wurm_multi_step_slot (step_multi)");
+        return NULL;
+    }
     if (self->tinfo && self->tinfo(actions, &ti) == 0 && ti.dim >= 1) {
         /* the same checks, in the same order, on the facts torchinfo.cpp read from the at::Tensor (ScalarType: Short = 2,
          * Int = 3, Long = 4); anything that is not a tensor of at least one dimension takes the generic path below */
@@ -317,8 +338,84 @@ static PyObject *stepper_finish(Stepper *self, long long i, int rc)
     self->last_fresh = 1;
     set_obj(&self->obs_after, self->want_obs_after ? PyList_GET_ITEM(self->obs_afters, i) : Py_None);
     PyObject *out = PyList_GET_ITEM(self->outs, i);
+    set_obj(&self->last_out, out);
     Py_INCREF(out);
     return out;
+}
+
+/* ---- MultiSnake: the same machine over wurm_multi_step_slot (PyStepper.step_multi / launch_multi are the specification) */
+
+static PyObject *stepper_launch_multi_ptr(Stepper *self, const int64_t *a_ptr, void *stream)
+{
+    const long long i = self->slot;
+    const int rc = ((multi_slot_fn)self->fn)(self->blk, self->slabs, (int64_t)i, a_ptr, (uint64_t)self->call, self->pending,
+                                             (uint64_t)self->pend_call, self->want_obs_after, stream);
+    return stepper_finish(self, i, rc);
+}
+
+/* launch_multi(a_ptr): the launch of slot `slot` on a prepared (K, N) int64 action block, and the bookkeeping after it */
+static PyObject *stepper_launch_multi(Stepper *self, PyObject *arg)
+{
+    const int64_t *a_ptr = (const int64_t *)PyLong_AsVoidPtr(arg);
+    if (PyErr_Occurred()) return NULL;
+    if (!self->multi || self->slot >= self->R || self->outs == Py_None) {
+        PyErr_SetString(PyExc_RuntimeError, "launch_multi: no slot prepared");
+        return NULL;
+    }
+    void *stream;
+    if (self->raw_stream) stream = self->raw_stream((int)self->dev_index);
+    else {
+        PyObject *idx = PyLong_FromLongLong(self->dev_index);
+        if (!idx) return NULL;
+        PyObject *st = PyObject_CallOneArg(self->get_stream, idx);
+        Py_DECREF(idx);
+        if (!st) return NULL;
+        stream = PyLong_AsVoidPtr(st);
+        Py_DECREF(st);
+        if (PyErr_Occurred()) return NULL;
+    }
+    return stepper_launch_multi_ptr(self, a_ptr, stream);
+}
+
+/* step_multi(actions: dict) -> the prebuilt (observations, rewards, dones, info) of this step; None: the caller prepares
+ * something first (new slab, state to re-validate, actions that are not the rows of one (K, N) int64 device tensor, not a
+ * plain dict, another device current, no tensor-facts helper) and calls launch_multi; a non-zero int: the entry point's
+ * error code.  Argument errors as the reference raises them (multi_snake.py:463-472), in its order. */
+static PyObject *stepper_step_multi(Stepper *self, PyObject *actions)
+{
+    if (!self->multi || !self->tinfo || !PyDict_CheckExact(actions)) Py_RETURN_NONE;
+    if ((long long)PyDict_GET_SIZE(actions) != self->num_agents) {
+        PyErr_SetString(PyExc_RuntimeError, "Must have a Tensor of actions for each snake");
+        return NULL;
+    }
+    Py_ssize_t pos = 0;
+    PyObject *key, *val;
+    const char *a0 = NULL;
+    long long n = 0;
+    int rows_ok = 1;
+    const long long row = 8 * self->num_envs;
+    while (PyDict_Next(actions, &pos, &key, &val)) {
+        wurm_tensor_info ti;
+        if (self->tinfo(val, &ti) != 0 || ti.dim < 1) Py_RETURN_NONE; /* not a tensor: the generic path raises what Python would */
+        if (ti.dtype != 2 && ti.dtype != 3 && ti.dtype != 4) {
+            PyErr_SetString(PyExc_TypeError, "actions Tensor must be an integer type i.e. "
+                                             "{torch.ShortTensor, torch.IntTensor, torch.LongTensor}");
+            return NULL;
+        }
+        if (ti.size0 != self->num_envs) {
+            PyErr_SetString(PyExc_RuntimeError, "Must have the same number of actions as environments.");
+            return NULL;
+        }
+        if (rows_ok) {
+            if (ti.dtype != 4 || ti.dim != 1 || !ti.contiguous || (long long)ti.device != self->dev_index) rows_ok = 0;
+            else if (n == 0) a0 = (const char *)ti.ptr;
+            else if ((const char *)ti.ptr != a0 + n * row) rows_ok = 0;
+        }
+        ++n;
+    }
+    if (!self->ok || self->slot >= self->R || (self->want_obs_after && self->obs_afters == Py_None) || !rows_ok) Py_RETURN_NONE;
+    if ((long long)self->cur_dev() != self->dev_index) Py_RETURN_NONE; /* kernels launch on the current device */
+    return stepper_launch_multi_ptr(self, (const int64_t *)a0, self->raw_stream((int)self->dev_index));
 }
 
 /* reset_lazy(done, return_observations) -> what reset(done) returns if the reset could be postponed into the next
@@ -334,6 +431,25 @@ static PyObject *stepper_reset_lazy(Stepper *self, PyObject *const *args, Py_ssi
     if (want < 0) return NULL;
     if (self->last_fresh && self->lazy_ok &&
         (done == self->last_done2 || (self->done_view != Py_None && done == self->done_view))) {
+        /* only while nobody else holds a tensor on the state's storage: through an alias the caller could read or edit the
+         * un-reset state, which the reference would show reset */
+        int free_ = 1;
+        if (self->alias_fn && self->state != Py_None) free_ = self->alias_fn(self->state);
+        else if (self->alias_free != Py_None) free_ = -1;
+        if (free_ < 0) {
+            if (self->alias_free == Py_None) free_ = 0;
+            else {
+                PyObject *r = PyObject_CallNoArgs(self->alias_free);
+                if (!r) return NULL;
+                free_ = PyObject_IsTrue(r);
+                Py_DECREF(r);
+                if (free_ < 0) return NULL;
+            }
+        }
+        if (!free_) {
+            Py_INCREF(Py_NotImplemented);
+            return Py_NotImplemented;
+        }
         long long ver = -1;
         PyObject *vo = PyObject_GetAttr(done, s_version);
         if (vo) {
@@ -379,6 +495,11 @@ static PyMemberDef stepper_members[] = {
     {"last_fresh", T_BOOL, offsetof(Stepper, last_fresh), 0, NULL},
     {"want_obs_after", T_BOOL, offsetof(Stepper, want_obs_after), 0, NULL},
     {"lazy_ok", T_BOOL, offsetof(Stepper, lazy_ok), 0, NULL},
+    {"multi", T_BOOL, offsetof(Stepper, multi), 0, NULL},
+    {"num_agents", T_LONGLONG, offsetof(Stepper, num_agents), 0, NULL},
+    {"last_out", T_OBJECT, offsetof(Stepper, last_out), 0, NULL},
+    {"state", T_OBJECT, offsetof(Stepper, state), 0, NULL},
+    {"alias_free", T_OBJECT, offsetof(Stepper, alias_free), 0, NULL},
     {"outs", T_OBJECT, offsetof(Stepper, outs), 0, NULL},
     {"done2s", T_OBJECT, offsetof(Stepper, done2s), 0, NULL},
     {"obs_afters", T_OBJECT, offsetof(Stepper, obs_afters), 0, NULL},
@@ -392,6 +513,8 @@ static PyMemberDef stepper_members[] = {
 static PyMethodDef stepper_methods[] = {
     {"step", (PyCFunction)stepper_step, METH_O, "see fastcall.c"},
     {"reset_lazy", (PyCFunction)(void (*)(void))stepper_reset_lazy, METH_FASTCALL, "see fastcall.c"},
+    {"step_multi", (PyCFunction)stepper_step_multi, METH_O, "see fastcall.c"},
+    {"launch_multi", (PyCFunction)stepper_launch_multi, METH_O, "see fastcall.c"},
     {NULL, NULL, 0, NULL}};
 
 static PyTypeObject StepperType = {

@@ -3288,6 +3288,19 @@ int wurm_multi_step_packed(wurm_multi_call *c, float *out_f32, uint8_t *out_u8, 
     return rc;
 }
 
+int wurm_multi_step_slot(wurm_multi_call *c, const wurm_multi_slabs *slabs, int64_t slot, const int64_t *actions,
+                         uint64_t call, int apply_pending, uint64_t pre_call, int want_obs_after, void *stream)
+{
+    if (!c || !slabs || slot < 0 || slot >= slabs->steps) return WURM_ERR_INVALID_ARG;
+    if (want_obs_after && !slabs->obs_after) return WURM_ERR_INVALID_ARG;
+    const long long KN = (long long)c->num_snakes * c->num_envs, per_obs = KN * slabs->obs_elems;
+    return wurm_multi_step_packed(c, slabs->out_f32 ? slabs->out_f32 + slot * 6 * KN : nullptr,
+                                  slabs->out_u8 ? slabs->out_u8 + slot * (7 * KN + c->num_envs) : nullptr,
+                                  slabs->obs ? slabs->obs + slot * per_obs : nullptr,
+                                  want_obs_after ? slabs->obs_after + slot * per_obs : nullptr, actions, call, apply_pending,
+                                  pre_call, stream);
+}
+
 int wurm_multi_reset(float *foods, float *heads, float *bodies, uint8_t *dones, int64_t *orientations,
                      int16_t *colours, const uint8_t *done_env, int32_t *status, const uint8_t *boost_this_step,
                      float *obs, int obs_mode, int obs_n, int64_t num_envs, int num_snakes, int size,

@@ -119,11 +119,75 @@ class PyStepper(object):
         self.obs_after = self.obs_afters[i] if self.want_obs_after else None
         return self.outs[i]
 
+    # ---- MultiSnake: the same machine over wurm_multi_step_slot (`mfn`), actions a dict of K tensors
+    mfn = None
+    num_agents = 0
+    last_out = None
+    state = None        # (the C machine: the tuple of state tensors for its own storage-use-count check)
+    alias_free = None   # callable: nobody else holds a tensor on the state's storage
+
+    def step_multi(self, actions):
+        """MultiSnake.step(actions: dict): the prebuilt (observations, rewards, dones, info) of this step; None: the caller
+        has to prepare something first (as `step`; also: the K action tensors are not the rows of one (K, N) int64 tensor
+        on the device — the caller stacks them) and calls launch_multi; a non-zero int: the entry point's error code.
+        Argument errors as the reference raises them (multi_snake.py:463-472)."""
+        if actions.__class__ is not dict:
+            return None  # (an OrderedDict may iterate in another order than its dict storage: the caller's generic path)
+        if len(actions) != self.num_agents:
+            raise RuntimeError('Must have a Tensor of actions for each snake')
+        a_ptr, row, n = 0, 8 * self.num_envs, 0
+        rows_ok = True
+        for act in actions.values():
+            dt = act.dtype
+            if dt is not self.dt_i64 and dt is not self.dt_i32 and dt is not self.dt_i16:
+                raise TypeError('actions Tensor must be an integer type i.e. '
+                                '{torch.ShortTensor, torch.IntTensor, torch.LongTensor}')
+            if act.size(0) != self.num_envs:
+                raise RuntimeError('Must have the same number of actions as environments.')
+            if rows_ok:
+                if dt is not self.dt_i64 or act.dim() != 1 or not act.is_contiguous() or act.get_device() != self.dev_index:
+                    rows_ok = False
+                else:
+                    ptr = act.data_ptr()
+                    if n == 0:
+                        a_ptr = ptr
+                    elif ptr != a_ptr + n * row:
+                        rows_ok = False
+            n += 1
+        i = self.slot
+        if not self.ok or i >= self.R or (self.want_obs_after and self.obs_afters is None) or not rows_ok:
+            return None
+        if self.get_device() != self.dev_index:
+            return None
+        return self.launch_multi(a_ptr)
+
+    def launch_multi(self, a_ptr):
+        """the launch of slot `slot` on a prepared (K, N) int64 action block, and the bookkeeping after it"""
+        i = self.slot
+        rc = self.mfn(self.blk, self.slabs, i, a_ptr, self.call, self.pending, self.pend_call, self.want_obs_after,
+                      self.get_stream(self.dev_index))
+        if rc:
+            return int(rc)
+        self.call += 1
+        self.steps += 1
+        self.pending = False
+        self.slot = i + 1
+        self.last_done2 = self.done2s[i]
+        self.done_view = None
+        self.last_fresh = True
+        self.obs_after = self.obs_afters[i] if self.want_obs_after else None
+        self.last_out = self.outs[i]
+        return self.last_out
+
     def reset_lazy(self, done, return_observations):
         """What reset(done) returns if the reset could be postponed into the next step's launch (None, or the observation
         the last step's launch already wrote), else NotImplemented."""
         if self.last_fresh and self.lazy_ok and (done is self.last_done2 or
                                                  (self.done_view is not None and done is self.done_view)):
+            # only while nobody else holds a tensor on the state's storage: through an alias the caller could read or edit the
+            # un-reset state, which the reference would show reset (single_snake.py:322-342, multi_snake.py:771-836)
+            if self.alias_free is not None and not self.alias_free():
+                return NotImplemented
             try:
                 ver = done._version
             except RuntimeError:  # inference tensors do not track versions: cannot prove `done` is unmodified
@@ -147,19 +211,27 @@ class PyStepper(object):
 
 def _make_stepper(name, blk_addr, slabs_addr):
     """C Stepper over the entry point's address when wurm_amd/_fastcall is built and the entry point is a real C function;
-    else PyStepper over whatever callable _lib.step_slot_fn hands out (ctypes function / test stand-in)."""
+    else PyStepper over whatever callable _lib.step_slot_fn hands out (ctypes function / test stand-in).  MultiSnake's
+    entry point (wurm_multi_step_slot) has another signature: the machine's `mfn` / step_multi / launch_multi side."""
     get_device, get_stream = _lib.accessors()
     fn = _lib.step_slot_fn(name)
+    multi = name == 'wurm_multi_step_slot'
     addr = getattr(fn, 'c_address', None)
     if addr is not None:
         try:
             from wurm_amd import _fastcall
             helpers = _lib.torch_helpers() or (None, None, None)
-            return _fastcall.Stepper(addr, blk_addr, slabs_addr, get_device, get_stream, torch.int64, torch.int32,
-                                     torch.int16, *helpers)
+            fs = _fastcall.Stepper(addr, blk_addr, slabs_addr, get_device, get_stream, torch.int64, torch.int32,
+                                   torch.int16, *helpers)
+            if multi:
+                fs.multi = True  # (AttributeError with an older build of the extension: the Python machine)
+            return fs
         except (ImportError, AttributeError):
             pass
-    return PyStepper(fn, blk_addr, slabs_addr, get_device, get_stream, torch.int64, torch.int32, torch.int16)
+    fs = PyStepper(None if multi else fn, blk_addr, slabs_addr, get_device, get_stream, torch.int64, torch.int32, torch.int16)
+    if multi:
+        fs.mfn = fn
+    return fs
 
 
 class FastStepMixin(object):
@@ -169,12 +241,14 @@ class FastStepMixin(object):
         c.num_envs, c.env_offset, c.seed, c.size = N, self.env_offset, _lib.u64(self.seed), self.size
         self._sl = _lib.SingleSlabs()
         self._fs = _make_stepper(self._STEP_SLOT, ctypes.addressof(c), ctypes.addressof(self._sl))
+        self._fs.alias_free = self._alias_free
         self._fs.num_envs = N
         self._fs.dev_index = -1 if self.device.index is None else self.device.index
         self._get_device = _lib.accessors()[0]
         self._pend = None              # (N) bytes: the kernels' own copy of the last step's `done`
         self._slab_mode = None
         self._envs = torch.zeros((N, self._CHANNELS, self.size, self.size), device=self.device)
+        self._fs.state = (self._envs,)
         self._envs_ok = None           # the state tensor that has been validated (None: validate before the next launch)
         # env.done: what the caller (or the constructor / rollout) assigned, valid until the next step overwrites it
         self._done, self._done_stamp = torch.zeros(N, dtype=torch.bool, device=self.device), 0
@@ -262,6 +336,7 @@ class FastStepMixin(object):
         self._touch()  # (a lazy mirror is written out to the tensor that is being replaced, which is still ours here)
         self._envs_ok = None
         self._envs = value.detach() if isinstance(value, torch.Tensor) else value  # (our own tensor object: see the getter)
+        self._fs.state = (self._envs,)
         self._watch(self._envs)
 
     def _alias_free(self) -> bool:
@@ -426,6 +501,7 @@ class FastStepMixin(object):
             # callers rebind env.envs (reference tests/test_single_snake_env.py:54): normalise once
             e = e.to(device=self.device, dtype=torch.float32).contiguous()
             self._envs = e
+            self._fs.state = (e,)
         self._envs_ok = e
         self._c.envs = e.data_ptr()
         self._c.resident_valid = 0  # another tensor (its setter already dealt with a lazy mirror of the old one)
@@ -539,8 +615,6 @@ class FastStepMixin(object):
 
     def _try_lazy_reset(self, done: torch.Tensor, return_observations: bool):
         """(True, obs) if reset(done) could be postponed into the next step's launch, else (False, None)."""
-        if not self._alias_free():
-            return False, None
         obs = self._fs.reset_lazy(done, return_observations)
         if obs is NotImplemented:
             return False, None

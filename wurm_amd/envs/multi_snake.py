@@ -91,18 +91,72 @@ class _Flushing(object):
         if isinstance(value, torch.Tensor):
             value = value.detach()   # (our own tensor object: see __get__)
         setattr(obj, self.slot, value)
+        obj._sync_state()
         if self.slot in _MIRRORED:
             obj._escape(value)
 
 
-class _Dynamic(object):
-    """Dynamics attribute of MultiSnake that callers assign after construction (reference tests/test_multi_snake_env.py:
-    180,288,401-403,618; experiments/multiagent.py:340,345).  The reference reads it at the moment of each call, so before it
-    changes a postponed reset(done) is applied with the OLD value (that reset was called then), and the observation the last
-    step's launch pre-computed for `reset(done)` — with the old value — is dropped."""
+class _LazyInfo(dict):
+    """`info` of one step (reference :707-729: snake_collision_i, edge_collision_i, food_i, size_i, boost_i).  A dict whose 5 K
+    tensors are carved from the step's output block the first time anything looks at it: a view object per row is most of
+    what a step costs on the host, and callers that read `info` every step are rare (the reference's loops log from it every
+    few hundred steps).  Every reading method fills it first, so it behaves as the plain dict it then is."""
+    __slots__ = ('_src',)
 
-    def __init__(self, name, flush=True):
-        self.slot, self.flush = '_dyn_' + name, flush
+    def __init__(self, src):
+        dict.__init__(self)
+        self._src = src
+
+    def _fill(self):
+        src = self._src
+        if src is not None:
+            self._src = None
+            f, b, keys, K = src  # the step's packed floats (6K, N) / flags (7K + 1, N): agent-major rows from 3K on
+            rf, rb = f[3 * K:].unbind(0), b[3 * K:7 * K].unbind(0)
+            k_snake, k_edge, k_food, k_boost, k_size = keys
+            dict.update(self, zip(k_snake, rb[2 * K:3 * K]))
+            dict.update(self, zip(k_edge, rb[3 * K:]))
+            dict.update(self, zip(k_food, rf[K:2 * K]))
+            dict.update(self, zip(k_size, rf[2 * K:]))
+            dict.update(self, zip(k_boost, rb[K:2 * K]))
+
+    def __missing__(self, key):
+        if self._src is None:
+            raise KeyError(key)
+        self._fill()
+        return dict.__getitem__(self, key)
+
+    def __reduce__(self):
+        self._fill()
+        return (dict, (dict(self),))
+
+
+def _filling(name):
+    method = getattr(dict, name)
+
+    def wrapper(self, *a, **kw):
+        self._fill()
+        return method(self, *a, **kw)
+    wrapper.__name__ = name
+    return wrapper
+
+
+for _name in ('__contains__', '__iter__', '__len__', '__eq__', '__ne__', '__repr__', '__setitem__', '__delitem__', '__or__',
+              '__ror__', '__ior__', '__reversed__', 'get', 'keys', 'values', 'items', 'copy', 'pop', 'popitem', 'setdefault',
+              'update', 'clear'):
+    setattr(_LazyInfo, _name, _filling(_name))
+
+
+class _Dynamic(object):
+    """Attribute of MultiSnake that callers assign after construction (reference tests/test_multi_snake_env.py:180,288,
+    401-403,618; experiments/multiagent.py:340,345 anneal `food_rate` / `food_on_death_prob` every step).  The reference reads
+    it at the moment of each call.  `reset` — the kernels' and the reference's (:771-836) — reads only `respawn_mode`,
+    `colour_mode` and `initial_snake_length`: before one of THOSE changes a postponed reset(done) is applied with the old
+    value (that reset was called then) and the observation the last step's launch pre-computed for `reset(done)` is dropped
+    (`reset=True`); `observation_mode` only drops that observation; the step dynamics only mark the configuration block."""
+
+    def __init__(self, name, reset=False, observes=False):
+        self.slot, self.reset, self.drops = '_dyn_' + name, reset, reset or observes
 
     def __get__(self, obj, cls):
         if obj is None:
@@ -113,10 +167,12 @@ class _Dynamic(object):
             raise AttributeError(self.slot[5:]) from None
 
     def __set__(self, obj, value):
-        if self.flush and obj._pending:
+        if self.reset and obj._pending:
             obj._flush()
-        obj._obs_after = None
+        if self.drops:
+            obj._obs_after = None
         obj._cfg_dirty = True
+        obj._fs.ok = False   # the next step goes through _slow_step (configuration block, observation shape)
         obj.__dict__[self.slot] = value
 
 
@@ -127,19 +183,49 @@ _SLOTS = _MIRRORED + ('_dones', '_orientations', '_agent_colours')
 class MultiSnake(object):
     """Batched multi-agent snake environment (reference multi_snake.py:18-48)."""
 
-    _pending = False
-    _last_fresh = False
-    _state_dirty = True
+    # The deferred-reset protocol lives in the step machine `_fs` (wurm_amd/envs/_fast_step.py: PyStepper, the specification;
+    # wurm_amd/csrc/fastcall.c: Stepper, its C twin) — the same one SingleSnake and SimpleGridworld use.
+    _pending = property(lambda self: self._fs.pending, lambda self, v: setattr(self._fs, 'pending', v))
+    _pend_call = property(lambda self: self._fs.pend_call, lambda self, v: setattr(self._fs, 'pend_call', v))
+    _call = property(lambda self: self._fs.call, lambda self, v: setattr(self._fs, 'call', v))
+    _last_fresh = property(lambda self: self._fs.last_fresh, lambda self, v: setattr(self._fs, 'last_fresh', v))
+    _obs_after = property(lambda self: self._fs.obs_after, lambda self, v: setattr(self._fs, 'obs_after', v))
+    _want_after = property(lambda self: self._fs.want_obs_after, lambda self, v: setattr(self._fs, 'want_obs_after', v))
+    _steps = property(lambda self: self._fs.steps)
     _mirror = None          # the compact mirror of foods / heads / bodies the step launch reads instead of them
     _mirror_off = False
     _lazy_mirror = os.environ.get('WURM_RESIDENT_LAZY', '1') != '0'
     _watched = ()           # (tensor, version) of state tensors the caller holds: in-place edits make the mirror stale
-    _write_outs = _touches = _steps = 0
+    _write_outs = _touches = 0
     _chk = None             # (2, N) int32: check_consistency's masks of the post-step / post-reset state, from the step launch
-    _chk_fresh = _chk_has_after = False
+    _chk_has_after = False
+    _chk_armed_at, _chk_void_at = 1 << 62, -1
     _check_calls = _check_step = 0
-    _out_f = _out_b = _rewards_t = _boost_t = _mc_mode = _obs_after = None
-    _want_after = False
+    _rewards_t = _boost_t = _mc_mode = _info = None
+    _rewards_at = _boost_at = 0
+    _slab = None            # (out_f32, out_u8) of the current output slab
+    _mc_ready = False
+
+    @property
+    def _state_dirty(self):
+        return not self._fs.ok
+
+    @_state_dirty.setter
+    def _state_dirty(self, v):
+        if v:
+            self._fs.ok = False  # the next step goes through _slow_step, which re-validates the layout and re-reads the pointers
+
+    @property
+    def _chk_fresh(self):
+        """the masks the last step's launch wrote describe the state as it is (nothing has looked at or written it since)"""
+        c, st = self._mc, self._fs.steps
+        return bool(c.resident) and bool(c.check_mask) and st > self._chk_armed_at and st > self._chk_void_at
+
+    @_chk_fresh.setter
+    def _chk_fresh(self, v):
+        if not v:
+            self._chk_void_at = self._fs.steps
+
     foods = _Flushing('foods')
     heads = _Flushing('heads')
     bodies = _Flushing('bodies')
@@ -147,8 +233,8 @@ class MultiSnake(object):
     orientations = _Flushing('orientations')
     agent_colours = _Flushing('agent_colours')
     # (observation_mode: nothing to apply — a postponed reset does not observe — but what was pre-computed is of the old mode)
-    observation_mode = _Dynamic('observation_mode', flush=False)
-    respawn_mode = _Dynamic('respawn_mode')
+    observation_mode = _Dynamic('observation_mode', observes=True)
+    respawn_mode = _Dynamic('respawn_mode', reset=True)
     food_on_death_prob = _Dynamic('food_on_death_prob')
     boost = _Dynamic('boost')
     boost_cost_prob = _Dynamic('boost_cost_prob')
@@ -156,10 +242,8 @@ class MultiSnake(object):
     food_rate = _Dynamic('food_rate')
     max_food = _Dynamic('max_food')
     reward_on_death = _Dynamic('reward_on_death')
-    colour_mode = _Dynamic('colour_mode')
-    initial_snake_length = _Dynamic('initial_snake_length')
-    _cfg_dirty = True
-
+    colour_mode = _Dynamic('colour_mode', reset=True)
+    initial_snake_length = _Dynamic('initial_snake_length', reset=True)
     spec = Spec(float('inf'))
     metadata = {
         'render.modes': ['rgb_array'],
@@ -194,7 +278,17 @@ class MultiSnake(object):
         `resident_mirror` — None: large batches step on a compact mirror of foods / heads / bodies chosen
         by batch size with adaptive rules; False: never; True / 'lazy' / 'eager': always, without the adaptive rules
         (`env.mirror_state()` tells what is in effect and why)."""
-        from wurm_amd.envs._fast_step import parse_mirror_policy
+        from wurm_amd.envs._fast_step import parse_mirror_policy, _make_stepper
+        self.device = _lib.require_device(device)
+        self._cfg_dirty = True
+        # the argument block of the per-call launches, the output slabs and the step machine over them (the block is filled
+        # in on first use: _ensure_call)
+        self._mc, self._sl = _lib.MultiCall(), _lib.MultiSlabs()
+        self._mc_addr = ctypes.addressof(self._mc)
+        self._fs = fs = _make_stepper('wurm_multi_step_slot', self._mc_addr, ctypes.addressof(self._sl))
+        fs.num_envs, fs.num_agents = num_envs, num_snakes
+        fs.alias_free = self._alias_free
+        fs.dev_index = -1 if self.device.index is None else self.device.index
         self._resident_policy = pol = parse_mirror_policy(resident_mirror)
         self._mirror_off = pol is False
         self._lazy_mirror = pol != 'eager' and MultiSnake._lazy_mirror
@@ -203,17 +297,12 @@ class MultiSnake(object):
         self.num_snakes = num_snakes
         self.lazy_reset = bool(lazy_reset)
         self._pend = None            # (N) bytes: the kernels' own copy of the last step's dones['__all__']
-        self._pend_call = 0
-        self._last_all_done = None   # the tensor the last step returned as dones['__all__']
-        self._last_version = -1
         self._cfg_cache = (None, None)
-        self._mc = None              # persistent wurm_multi_call block
         self._lifetimes_touched = False
         self._stor = [None] * len(_SLOTS)
         self.size = size
         self.initial_snake_length = initial_snake_length
         self.on_death = on_death
-        self.device = _lib.require_device(device)
         self.verbose = verbose
         if dtype not in (torch.float, torch.half):
             raise NotImplementedError('wurm_amd.MultiSnake: dtype must be torch.float or torch.half')
@@ -225,7 +314,6 @@ class MultiSnake(object):
             self.observation_size = 2 * int(observation_mode.split('_')[1]) + 1
         self.seed = _draw_seed() if seed is None else int(seed)
         self.env_offset = int(env_offset)
-        self._call = 0
 
         if render_args is None:
             self.render_args = {'num_rows': 1, 'num_cols': 1, 'size': 256}
@@ -296,46 +384,87 @@ class MultiSnake(object):
 
     # ------------------------------------------------------------------ helpers
 
+    @property
+    def lazy_reset(self) -> bool:
+        return self._lazy_reset
+
+    @lazy_reset.setter
+    def lazy_reset(self, value: bool):
+        self._lazy_reset = bool(value)
+        self._fs.lazy_ok = self._lazy_ok()
+
+    def _lazy_ok(self) -> bool:
+        # (env_lifetimes: `env_lifetimes[done] = 0`, :797, is a no-op only while nobody has asked for that tensor)
+        return self._lazy_reset and getattr(self, 'size', 0) >= 5 and not self._lifetimes_touched
+
     def _next_call(self, n: int = 1) -> int:
-        c = self._call
-        self._call += n
-        self._last_fresh = False
+        fs = self._fs
+        c = fs.call
+        fs.call = c + n
+        fs.last_fresh = False  # the counter the last step's `obs_after` assumed for its reset is gone
         return c
+
+    @property
+    def info(self) -> dict:
+        """reference :131 / :729: the info dict of the last step"""
+        if self._info is not None:
+            return self._info
+        out = self._fs.last_out
+        return out[3] if out is not None else {}
+
+    @info.setter
+    def info(self, value):
+        self._info = value
 
     @property
     def env_lifetimes(self) -> torch.Tensor:
         """reference :106.  The reference never increments it (its use at :705 is dead code): as long as no
         caller has asked for the tensor it is all zeros and `dones['__all__'] |= env_lifetimes > max_env_lifetime`
         (:705) / `env_lifetimes[done] = 0` (:797) are skipped; once somebody has, both run as in the reference."""
-        self._lifetimes_touched = True
+        self._touch_lifetimes()
         return self._env_lifetimes
 
     @env_lifetimes.setter
     def env_lifetimes(self, value):
-        self._lifetimes_touched = True
+        self._touch_lifetimes()
         self._env_lifetimes = value
+
+    def _touch_lifetimes(self):
+        if not self._lifetimes_touched:
+            if self._pending:
+                self._flush()   # (a reset postponed as a no-op on lifetimes: applied before somebody can see them)
+            self._lifetimes_touched = True
+            self._fs.lazy_ok = False
+            self._fs.last_fresh = False
 
     @property
     def rewards(self) -> torch.Tensor:
         """reference :105/:478: (num_envs*num_snakes,) float, env-major — a view of the last step's output block"""
-        if self._rewards_t is None:
-            self._rewards_t = self._out_f.view(-1)[:self.num_envs * self.num_snakes]
+        st = self._fs.steps
+        if self._rewards_at != st:  # (the env-major block at the start of the last step's packed floats)
+            self._rewards_t, self._rewards_at = self._slab[0][self._fs.slot - 1].view(-1)[:self.num_envs * self.num_snakes], st
         return self._rewards_t
 
     @rewards.setter
     def rewards(self, value):
-        self._rewards_t = value
+        self._rewards_t, self._rewards_at = value, self._fs.steps
 
     @property
     def boost_this_step(self) -> torch.Tensor:
         """reference :104: (num_envs*num_snakes,) env-major — a view of the last step's output block"""
-        if self._boost_t is None:
-            self._boost_t = self._out_b.view(-1)[:self.num_envs * self.num_snakes]
+        st = self._fs.steps
+        if self._boost_at != st:
+            self._boost_t, self._boost_at = self._slab[1][self._fs.slot - 1].view(-1)[:self.num_envs * self.num_snakes], st
         return self._boost_t
 
     @boost_this_step.setter
     def boost_this_step(self, value):
-        self._boost_t = value
+        self._boost_t, self._boost_at = value, self._fs.steps
+
+    def _sync_state(self):
+        """the state tensors as the step machine knows them (its own storage-use-count check, wurm_torch_alias_free)"""
+        d = self.__dict__
+        self._fs.state = tuple(d[n] for n in _SLOTS) if all(n in d for n in _SLOTS) else None
 
     def _alias_free(self) -> bool:
         """Nobody but this object holds a tensor on the storage of a state tensor (what the caller read from `env.foods`
@@ -353,8 +482,9 @@ class MultiSnake(object):
 
     def _flush(self):
         """Applies the postponed reset(done) now, with the ordinary reset kernel and the counter it was given."""
-        self._pending = False
-        self._launch_reset(self._pend, None, _lib.OBS_NONE, 0, self._pend_call, None)
+        fs = self._fs
+        fs.pending = False
+        self._launch_reset(self._pend, None, _lib.OBS_NONE, 0, fs.pend_call, None)
 
     # ---- the resident mirror (include/wurm_hip.h: wurm_multi_call.resident; protocol as in envs/_fast_step.py)
 
@@ -464,6 +594,7 @@ class MultiSnake(object):
             t = t.to(device=self.device, dtype=dtype).contiguous()
             if raw:  # (not through the descriptor: nobody else holds the normalised copy)
                 setattr(self, '_' + name, t)
+                self._sync_state()
                 self._state_dirty = True
                 if '_' + name in _MIRRORED and self._mc is not None:
                     self._mc.resident_valid = 0
@@ -563,21 +694,19 @@ class MultiSnake(object):
     # ------------------------------------------------------------------ step
 
     def _ensure_call(self):
-        """the argument block of the per-call launches (wurm_multi_call), made on first use — and with it the resident
+        """the argument block of the per-call launches (wurm_multi_call), filled in on first use — and with it the resident
         mirror of foods / heads / bodies, where the library offers one for this batch (or the caller asked for one)"""
         c = self._mc
-        if c is not None:
+        if self._mc_ready:
             return c
+        self._mc_ready = True
         N, K, S, dev = self.num_envs, self.num_snakes, self.size, self.device
-        c = self._mc = _lib.MultiCall()
         c.num_envs, c.env_offset, c.seed = N, self.env_offset, _lib.u64(self.seed)
         c.num_snakes, c.size = K, S
         self._pend = torch.zeros(N, dtype=torch.uint8, device=dev)
         c.all_done_copy = self._pend.data_ptr()
-        self._mc_addr = ctypes.addressof(c)
         self._mc_cfg = None
-        self._mc_fn = _lib.multi_step_fn()
-        self._get_device, self._get_stream = _lib.accessors()
+        self._get_device = _lib.accessors()[0]
         ks = [str(i) for i in range(K)]
         self._keys = tuple([p + k for k in ks] for p in ('agent_', 'snake_collision_', 'edge_collision_', 'food_',
                                                          'boost_', 'size_'))
@@ -597,8 +726,85 @@ class MultiSnake(object):
             self._chk = torch.empty((2, N), dtype=torch.int32, device=dev)
         return c
 
+    def _arm_masks(self):
+        """check_consistency()'s masks from inside the step launch: asked for while the caller keeps calling that method"""
+        c = self._mc
+        if self._chk is None:
+            return
+        want = self._check_calls > 0 and self._fs.steps - self._check_step <= 64
+        if want != bool(c.check_mask):
+            c.check_mask = self._chk[0].data_ptr() if want else None
+            c.check_mask_after = self._chk[1].data_ptr() if want else None
+            self._chk_armed_at = self._fs.steps if want else 1 << 62  # (steps from here on write them)
+
+    def _new_slab(self):
+        """Fresh output tensors for the next R steps in four allocations, and the R x (8 K + 1) per-agent views and 4 dicts
+        `step` returns (reference :701-729) made ONCE per slab — a view object per row was most of what a step cost on the
+        host.  A slab is never written twice; it is released when the last tensor carved from it is."""
+        N, K, dev, fs = self.num_envs, self.num_snakes, self.device, self._fs
+        if self._slab is not None and fs.steps > 0:
+            _, _ = self.rewards, self.boost_this_step  # (views of the slab that is being replaced: made while it is at hand)
+        c = self._mc
+        mode = self.observation_mode
+        c.obs_mode, c.obs_n, o = self._obs_args(mode)
+        inner = tuple(o.shape[2:])
+        self._mc_mode = mode
+        elems = int(torch.Size(inner).numel())
+        want_after = bool(fs.want_obs_after)
+        per_step = K * N * (4 * elems * (2 if want_after else 1) + 24 + 7) + N
+        R = max(1, min(64, (1 << 30) // max(per_step, 1)))  # (cfg4 'full': 123 MB of observations per step -> 8 steps)
+        of = torch.empty((R, 6 * K, N), dtype=torch.float32, device=dev)
+        ob = torch.empty((R, 7 * K + 1, N), dtype=torch.bool, device=dev)
+        obs = torch.empty((R, K, N) + inner, dtype=torch.float32, device=dev)
+        after = torch.empty((R, K, N) + inner, dtype=torch.float32, device=dev) if want_after else None
+        sl = self._sl
+        sl.out_f32, sl.out_u8, sl.obs, sl.steps, sl.obs_elems = of.data_ptr(), ob.data_ptr(), obs.data_ptr(), R, elems
+        sl.obs_after = after.data_ptr() if after is not None else None
+        self._slab = (of.unbind(0), ob.unbind(0))
+        try:
+            fs.slab_version = ob._version
+        except RuntimeError:   # allocated under torch.inference_mode(): no version counters, so no deferral (eager resets)
+            fs.slab_version = -1
+        # what callers read every step — observations, rewards, dones — is carved now (row_views: ~0.3 us per tensor); the
+        # 5 K tensors of `info` when somebody looks (_LazyInfo)
+        K3, K4 = 3 * K, 4 * K
+        ofs, obs_ = self._slab
+        rf = _lib.row_views(of, 2, K3, K4)                      # rewards (agent-major rows 3K .. 4K)
+        ob2 = ob.view(R, 7 * K + 1, N)
+        rd = _lib.row_views(ob2, 2, K3, K4)                     # dones
+        ra = _lib.row_views(ob2, 2, 7 * K, 7 * K + 1)           # all_done
+        ov = _lib.row_views(obs, 2)
+        av = _lib.row_views(after, 2) if after is not None else None
+        k_agent, k_snake, k_edge, k_food, k_boost, k_size = self._keys
+        info_keys = (k_snake, k_edge, k_food, k_boost, k_size)
+        outs, done2s, afters = [], [], []
+        for i in range(R):
+            f, b = rf[i * K:(i + 1) * K], rd[i * K:(i + 1) * K] + [ra[i]]
+            dones_out = dict(zip(k_agent, b[:K]))
+            dones_out['__all__'] = b[K]
+            info = _LazyInfo((ofs[i], obs_[i], info_keys, K))
+            outs.append((OrderedDict(zip(k_agent, ov[i * K:(i + 1) * K])), dict(zip(k_agent, f)), dones_out, info))
+            done2s.append(b[K])
+            if av is not None:
+                afters.append(OrderedDict(zip(k_agent, av[i * K:(i + 1) * K])))
+        fs.outs, fs.done2s, fs.obs_afters = outs, done2s, (afters if av is not None else None)
+        fs.R, fs.slot = R, 0
+        fs.lazy_ok = self._lazy_ok()
+        self._arm_masks()
+
     def step(self, actions: Dict[str, torch.Tensor]) -> Tuple[Dict[str, torch.Tensor], dict, dict, dict]:
-        """reference :462-731"""
+        """reference :462-731.  One launch (wurm_multi_step_slot) from the step machine; the four dicts it returns were
+        built when the output slab was."""
+        if not (self._watched or self._lifetimes_touched or self._half):
+            out = self._fs.step_multi(actions)
+            if out.__class__ is tuple:
+                return out
+        return self._slow_step(actions)
+
+    def _slow_step(self, actions):
+        """What the step machine cannot do by itself: the first call, a new output slab, state tensors or configuration that
+        changed, tensors the caller holds (watched for in-place edits), actions that have to be stacked, `dtype=torch.half`,
+        `env_lifetimes` in use — then the launch through the machine, and the error codes of the entry point."""
         if len(actions) != self.num_snakes:
             raise RuntimeError('Must have a Tensor of actions for each snake')
 
@@ -610,7 +816,7 @@ class MultiSnake(object):
             if act.shape[0] != self.num_envs:
                 raise RuntimeError('Must have the same number of actions as environments.')
 
-        N, K, S, dev = self.num_envs, self.num_snakes, self.size, self.device
+        N, K, dev, fs = self.num_envs, self.num_snakes, self.device, self._fs
         # reference :492: stack in dict order -> (K, N); the kernel reads agent i's action of env e at [i*N + e].
         # Rows of one (K, N) int64 tensor (e.g. `tape[t, i]`) are used where they lie.
         vals = list(actions.values())
@@ -625,88 +831,51 @@ class MultiSnake(object):
         if not a_ptr:
             vals = torch.stack([v.reshape(N) for v in vals]).to(device=dev, dtype=torch.long).contiguous()
             a_ptr = vals.data_ptr()
-        pending = self._pending
-        self._pending = False  # consumed by this launch (the raw attributes below do not flush)
-        call = self._call
-        try:  # if anything below raises, the postponed reset and the counter are still owed
-            c = self._ensure_call()
-            self._steps += 1
-            if self._chk is not None:
-                want = self._check_calls > 0 and self._steps - self._check_step <= 64
-                if want != bool(c.check_mask):
-                    c.check_mask = self._chk[0].data_ptr() if want else None
-                    c.check_mask_after = self._chk[1].data_ptr() if want else None
-            if self._watched:
-                self._watch_ok()
-            if self._state_dirty:
+        # (if anything below raises, the postponed reset and the counter are still owed: the machine consumes them only
+        # once the launch has been accepted)
+        c = self._ensure_call()
+        if self._watched:
+            self._watch_ok()
+        if not fs.ok:  # (first call, a state tensor rebound, the configuration or the observation mode assigned)
+            pend, fs.pending = fs.pending, False  # (the raw tensors: the postponed reset belongs in front of THIS launch)
+            try:
                 foods, heads, bodies, dones, orientations, colours, _ = self._step_state()
-                c.foods, c.heads, c.bodies = foods.data_ptr(), heads.data_ptr(), bodies.data_ptr()
-                c.dones, c.orientations, c.colours = dones.data_ptr(), orientations.data_ptr(), colours.data_ptr()
-                self._state_dirty = False
-            mode = self.observation_mode
-            if mode != self._mc_mode:
-                c.obs_mode, c.obs_n, o = self._obs_args(mode)
-                self._obs_shape, self._mc_mode = tuple(o.shape), mode
-            obs = torch.empty(self._obs_shape, dtype=torch.float32, device=dev)
-            # a caller that reads what reset(dones['__all__']) returns gets it from this launch from now on (reset below)
-            after = torch.empty(self._obs_shape, dtype=torch.float32, device=dev) if self._want_after else None
-            a_after = after.data_ptr() if after is not None else 0
-            cfg = self._cfg()
-            if cfg is not self._mc_cfg:
-                c.cfg = self._mc_cfg = cfg
-
-            # packed outputs (include/wurm_hip.h wurm_multi_step_packed): env-major blocks first, then agent-major rows
-            of = torch.empty((6 * K, N), dtype=torch.float32, device=dev)
-            ob = torch.empty((7 * K + 1, N), dtype=torch.bool, device=dev)
-            self._call = call + 1
-            idx = dev.index
-            if self._get_device() != idx:  # a process driving several GPUs has another device current
-                rc = _lib.call(idx, self._mc_fn, self._mc_addr, of.data_ptr(), ob.data_ptr(), obs.data_ptr(), a_after, a_ptr,
-                               call, pending, self._pend_call, _lib.stream_ptr(idx))
-            else:
-                rc = self._mc_fn(self._mc_addr, of.data_ptr(), ob.data_ptr(), obs.data_ptr(), a_after, a_ptr, call, pending,
-                                 self._pend_call, self._get_stream(idx))
-            if rc:
-                _lib.check(rc, 'MultiSnake.step')
-        except BaseException:
-            self._pending, self._call = pending, call
-            raise
-
-        self._out_f, self._out_b = of, ob          # env.rewards / env.boost_this_step are views of these, made on demand
-        self._obs_after = after
-        self._chk_fresh = bool(c.resident) and bool(c.check_mask)
-        self._chk_has_after = after is not None
-        self._rewards_t = self._boost_t = None
-
-        # reference :701-729 — per-agent dicts; the kernel wrote agent-major rows, so these are plain views
-        # (only the agent-major rows are unbound — a view object per row is most of what this method costs on the host:
-        # rf = rewards, food, size; rb = dones, boost, snake_collision, edge_collision, all_done)
-        K2, K3, K4 = 2 * K, 3 * K, 4 * K
-        rf, rb = of[K3:].unbind(0), ob[K3:].unbind(0)
-        k_agent, k_snake, k_edge, k_food, k_boost, k_size = self._keys
-        all_done = rb[K4]
-        dones_out = dict(zip(k_agent, rb[:K]))
-        if self._lifetimes_touched:
-            all_done = all_done | (self._env_lifetimes > self.max_env_lifetime)  # :703-705
-        dones_out['__all__'] = all_done
-        rewards = dict(zip(k_agent, rf[:K]))
-
-        info = dict(zip(k_snake, rb[K2:K3]))
-        info.update(zip(k_edge, rb[K3:K4]))
-        if self._half:  # reference :477 / :724: food and size carry the env's dtype
-            rh = of[K4:].to(torch.half).unbind(0)
-            info.update(zip(k_food, rh[:K]))
-            info.update(zip(k_size, rh[K:]))
-            obs = obs.to(torch.half)
+            finally:
+                fs.pending = pend
+            c.foods, c.heads, c.bodies = foods.data_ptr(), heads.data_ptr(), bodies.data_ptr()
+            c.dones, c.orientations, c.colours = dones.data_ptr(), orientations.data_ptr(), colours.data_ptr()
+        if fs.slot >= fs.R or self.observation_mode != self._mc_mode or (fs.want_obs_after and fs.obs_afters is None):
+            self._new_slab()
         else:
-            info.update(zip(k_food, rf[K:K2]))
-            info.update(zip(k_size, rf[K2:]))
-        info.update(zip(k_boost, rb[K:K2]))
-        self.info = info
-
-        self._last_all_done, self._last_version = all_done, _version_of(all_done)
-        self._last_fresh = not self._lifetimes_touched
-        return OrderedDict(zip(k_agent, obs.unbind(0))), rewards, dones_out, info
+            self._arm_masks()
+        cfg = self._cfg()
+        if cfg is not self._mc_cfg:
+            c.cfg = self._mc_cfg = cfg
+        fs.ok = True
+        idx = fs.dev_index
+        if self._get_device() != idx:  # a process driving several GPUs has another device current
+            with torch.cuda.device(idx):
+                out = fs.launch_multi(a_ptr)
+        else:
+            out = fs.launch_multi(a_ptr)
+        if out.__class__ is not tuple:
+            _lib.check(int(out), 'MultiSnake.step')
+            raise RuntimeError(f'MultiSnake.step: unexpected return {out!r}')
+        self._info = None
+        if self._lifetimes_touched or self._half:
+            obs, rewards, dones_out, info = out
+            dones_out = dict(dones_out)
+            if self._lifetimes_touched:
+                dones_out['__all__'] = dones_out['__all__'] | (self._env_lifetimes > self.max_env_lifetime)  # :703-705
+                fs.last_fresh = False  # (not the kernel's own flags any more)
+            if self._half:  # reference :477 / :724: observations, food and size carry the env's dtype
+                info = dict(info.items())
+                for k in self._keys[3] + self._keys[5]:
+                    info[k] = info[k].to(torch.half)
+                obs = OrderedDict((k, v.to(torch.half)) for k, v in obs.items())
+            self._info = info
+            out = (obs, rewards, dones_out, info)
+        return out
 
     # ------------------------------------------------------------------ fused multi-step loop (extension)
 
@@ -815,6 +984,7 @@ class MultiSnake(object):
         """(N) int32 masks of the state as it is now, computed inside the last step's launch (wurm_multi_call.check_mask /
         check_mask_after), or None if they do not apply; -1 marks an env the launch could not vouch for"""
         c = self._mc
+        self._arm_masks()   # (from the next step on, if they are not being written yet)
         if self._watched and c is not None and not self._watch_ok():
             return None                   # an alias the caller holds was edited in place since the launch (_touch() ran)
         if not self._chk_fresh or c is None or not c.resident or not c.resident_valid:
@@ -860,21 +1030,19 @@ class MultiSnake(object):
         """
         if self.initial_snake_length != 3:
             raise NotImplementedError('Only initial snake length = 3 has been implemented.')
-        if done is not None and done is self._last_all_done and self._last_fresh and self.lazy_reset and \
-                self.size >= 5 and self._last_version >= 0 and _version_of(done) == self._last_version and \
-                self._alias_free():
-            # env_lifetimes is all zeros here (nobody has asked for it): `env_lifetimes[done] = 0` (:797) is a no-op
-            if not return_observations:
-                self._want_after = False
-                self._pending, self._pend_call = True, self._next_call()
-                return None
-            # (the step launch already wrote what this reset returns — in the mode of THAT launch: the reference observes at
-            # reset time, :836, so a mode changed since then makes this reset an eager one)
-            if self._obs_after is not None and self._mc_mode == self.observation_mode:
-                obs, self._obs_after = self._obs_after, None
-                self._pending, self._pend_call = True, self._next_call()
-                return self._obs_dict(obs)
-            self._want_after = True          # from the next step on it does; this one runs at once
+        if done is not None:
+            fs = self._fs
+            had_after = fs.obs_after is not None
+            # (the machine checks that `done` is the very tensor the last step returned, unmodified, that nothing has consumed a
+            # counter since, and that nobody else holds a state tensor: _alias_free / wurm_torch_alias_free)
+            if fs.last_fresh:
+                obs = fs.reset_lazy(done, return_observations)
+                if obs is not NotImplemented:
+                    # env_lifetimes is all zeros here (nobody has asked for it): `env_lifetimes[done] = 0` (:797) is a no-op
+                    self._chk_has_after = had_after  # the launch also left the masks of the state this reset produces
+                    if obs is not None and self._half:
+                        obs = OrderedDict((k, v.to(torch.half)) for k, v in obs.items())
+                    return obs
         if done is None:
             done = self._norm('dones', (self.num_envs * self.num_snakes,), torch.bool) \
                 .view(self.num_envs, self.num_snakes).all(dim=1)
