@@ -559,7 +559,10 @@ def extra_measurements(device):
     T4 = T
     acts4 = torch.randint(8, (T4 + 10, K, N), device=device, dtype=torch.int64)
     keys4 = [f'agent_{i}' for i in range(K)]
-    a4 = lambda t: dict(zip(keys4, acts4[t].unbind(0)))   # noqa: E731
+    # (the action dicts are what the policy hands over: built before the timed loops — indexing the tape and unbinding it
+    # inside them cost ~5 us per iteration of benchmark, not of env)
+    dicts4 = [dict(zip(keys4, acts4[t].unbind(0))) for t in range(T4 + 10)]
+    a4 = lambda t: dicts4[t]   # noqa: E731
     d_all = lambda d: d['__all__']                        # noqa: E731
     per_call('per_call_cfg4prime_partial5', cfg4prime, a4, d_all, T,
              "MultiSnake 4096x25x25 K=4, the reference's training dynamics (tests/test_multi_snake_env.py:100-104: respawn "
@@ -567,7 +570,8 @@ def extra_measurements(device):
              traffic_key='per_call_api_cfg4prime_4096x25_k4_partial5')
     acts10 = torch.randint(8, (40, 10, N), device=device, dtype=torch.int64)
     keys10 = [f'agent_{i}' for i in range(10)]
-    a10 = lambda t: dict(zip(keys10, acts10[t].unbind(0)))   # noqa: E731
+    dicts10 = [dict(zip(keys10, acts10[t].unbind(0))) for t in range(40)]
+    a10 = lambda t: dicts10[t]   # noqa: E731
     per_call('per_call_speeds_4096x36_k10', speeds_env, a10, d_all, 30,
              "experiments/speeds.py shape (4096 x 36 x 36, 10 agents): `step; reset(d['__all__'], return_observations=False)`",
              traffic_key='per_call_api_speeds_4096x36_k10')
@@ -670,7 +674,21 @@ def extra_measurements(device):
             lambda c: (c, 4, 4096), 8, 16, 6, 'BASELINE configs[3]: MultiSnake 4096x25x25, 4 agents, defaults, step + observe + '
             'reset(__all__) per batch-step, fused rollout, 16 batch-steps per launch (30 000 B of observations per env-step)',
             traffic_key='multi_rollout_cfg4_4096x25_k4_full_chunk16')
-    del acts4
+    del acts4, dicts4
+    # small MultiSnake batches: host-bound (one C call per step: wurm_amd/csrc/fastcall.c Stepper.step_multi)
+    for key, (n_, k_, s_), kw_, what in (
+            ('per_call_multi_512x12_k2', (512, 2, 12), {}, "MultiSnake 512 x 12 x 12, 2 snakes, constructor defaults (the board size of "
+             "the reference's own tests, tests/test_multi_snake_env.py:21-47)"),
+            ('per_call_multi_512x25_k4_train_partial5', (512, 4, 25),
+             dict(respawn_mode='any', food_mode='random_rate', boost_cost_prob=0.25, observation_mode='partial_5',
+                  food_on_death_prob=0.33, food_rate=2.5e-4), "MultiSnake 512 x 25 x 25, 4 snakes, the reference's training dynamics")):
+        Ts = 300
+        tape = torch.randint(8, (Ts + 10, k_, n_), device=device, dtype=torch.int64)
+        ks = [f'agent_{i}' for i in range(k_)]
+        ds = [dict(zip(ks, tape[t].unbind(0))) for t in range(Ts + 10)]
+        per_call(key, lambda: MultiSnake(n_, k_, s_, device=device, seed=0, **kw_), lambda t: ds[t], d_all, Ts,
+                 what + ": `step(a); reset(d['__all__'], return_observations=False)`, one launch per iteration")
+        del tape, ds
 
     # ---- cfg1 (BASELINE configs[0]) per call
     N, T = 64, 2000
@@ -756,7 +774,10 @@ def key_numbers(line):
         'main_py_loop_512_us': g('main_py_loop_512', 'us'), 'main_py_loop_65536_us': g('main_py_loop_65536', 'us'),
         'a2c_loop_512_eps': g('a2c_loop_512'), 'a2c_fused_actor_512_eps': g('a2c_fused_actor_512'),
         'speeds_rollout_eps': g('multi_rollout_speeds_4096x36_k10'), 'speeds_py_loop_us': g('speeds_py_loop_4096x36_k10', 'us'),
-        'cfg4prime_rollout_eps': g('multi_rollout_cfg4prime_partial5'),
+        'cfg4prime_rollout_eps': g('multi_rollout_cfg4prime_partial5'), 'cfg4prime_rollout_ms': g('multi_rollout_cfg4prime_partial5', 'ms'),
+        'cfg4prime_per_call_us': g('per_call_cfg4prime_partial5', 'us'),
+        'multi_512x12_k2_per_call_us': g('per_call_multi_512x12_k2', 'us'),
+        'multi_512x25_k4_train_per_call_us': g('per_call_multi_512x25_k4_train_partial5', 'us'),
         'box_hbm_fill_TBps': ex.get('host_calibration_after', {}).get('hbm_fill_2GB_TBps'),
     }
 

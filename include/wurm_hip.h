@@ -61,7 +61,9 @@ const char *wurm_version(void);
  * Each starts at its default, is overridden ONCE by the environment variable of the same name when the library is
  * loaded, and changes afterwards only through these calls — no launch path reads the environment.  None of them
  * changes results, only which kernel serves a call.  set / reset return WURM_ERR_INVALID_ARG for an unknown name,
- * get returns INT64_MIN. */
+ * get returns INT64_MIN.  The knobs are PROCESS-WIDE (every env object and thread sees them); an environment variable that
+ * is not a whole decimal number leaves the default in place.  wurm_launch_count is an atomic diagnostic counter,
+ * wurm_single_last_route names the calling thread's last launch; neither is state a later call depends on. */
 int wurm_set_option(const char *name, int64_t value);
 int64_t wurm_get_option(const char *name);
 int wurm_reset_option(const char *name);

@@ -392,7 +392,9 @@ def test_host_loop_grid_mirror_matches_the_path_without(mode):
             for t in range(T):
                 a = acts[t].clone()
                 obs, r, d, info = env.step(a)
-                assert (env._mirror is not None) == (min_envs == 0)
+                if alias is None:   # (while the caller holds the state no reset is postponed — round 5, _alias_free — and a
+                    # loop whose every step is followed by an eager reset gives the mirror up: the adaptive rule)
+                    assert (env._mirror is not None) == (min_envs == 0)
                 # (one reset form per phase: alternating them makes every other reset eager, and a loop that invalidates
                 # the mirror every other step loses it — tests/test_host_lazy_reset.py)
                 back = env.reset(d) if t >= 35 else env.reset(d, return_observations=False)

@@ -557,7 +557,12 @@ def fuzz_multi_mirror_class(rng):
                         same(obs[f'agent_{i}'].cpu().numpy(), r['obs'][i], f'{desc} op {op} step {t} obs {i}')
                         same(rew[f'agent_{i}'].cpu().numpy(), r['rewards'].reshape(N, K)[:, i], f'{desc} op {op} step {t} reward {i}')
                     same(dones['__all__'].cpu().numpy().astype(np.uint8), r['all_done'], f'{desc} op {op} step {t} all_done')
-                    how = int(rng.randint(4))   # the reset: postponed, with its observations, eager (not the step's own tensor), none
+                    how = int(rng.randint(5))   # the reset: postponed, with its observations, eager (not the step's own tensor), none,
+                    # with its observations after the observation mode was changed (VERDICT r04's repro)
+                    if how == 4:
+                        mode = 'full' if mode != 'full' else f'partial_{rng.randint(1, 6)}'
+                        env.observation_mode = mode
+                        how = 1
                     if how == 0:
                         env.reset(dones['__all__'], return_observations=False)
                         o.multi_reset(st, r['all_done'], cfg)
@@ -581,10 +586,24 @@ def fuzz_multi_mirror_class(rng):
                 same(env.bodies.cpu().numpy(), st['bodies'], f'{desc} op {op} look bodies')
                 same(env.heads.cpu().numpy(), st['heads'], f'{desc} op {op} look heads')
                 alias = env.foods
-            elif alias is not None:     # an in-place edit through a tensor the caller holds
-                # (the attribute is re-read first, as the reference's callers do: that applies a postponed reset — an edit
-                # through an alias taken BEFORE `step; reset` lands in front of that reset, DESIGN.md deviation 9)
-                assert env.foods is alias
+            elif u < 0.94:              # round 5: an attribute assigned between calls (reference tests/test_multi_snake_env.py:
+                # 180,288,401-403,618; experiments/multiagent.py:340,345) — with a reset possibly postponed in front of it
+                which = int(rng.randint(4))
+                if which == 0:
+                    cfg['respawn_mode'] = 'any' if cfg['respawn_mode'] == 'all' else 'all'
+                    env.respawn_mode = cfg['respawn_mode']
+                elif which == 1:
+                    cfg['food_rate'] = float(rng.choice([5e-4, 5e-3, 5e-2, 0.4]))
+                    env.food_rate = cfg['food_rate']
+                elif which == 2:
+                    cfg['food_on_death_prob'] = float(rng.choice([0.0, 0.33, 1.0]))
+                    env.food_on_death_prob = cfg['food_on_death_prob']
+                else:
+                    mode = ['full', f'partial_{rng.randint(1, 6)}'][rng.randint(2)]
+                    env.observation_mode = mode
+            elif alias is not None:     # an in-place edit through a tensor the caller holds (no look first: while the caller
+                # holds a state tensor no reset is postponed — round 5, _alias_free — so the edit lands where the reference's would)
+                assert env.foods.data_ptr() == alias.data_ptr()
                 e, y, x = int(rng.randint(N)), int(rng.randint(1, S - 1)), int(rng.randint(1, S - 1))
                 occupied = st['bodies'].reshape(N, K, S, S)[e, :, y, x].sum() + st['heads'].reshape(N, K, S, S)[e, :, y, x].sum()
                 if occupied == 0:
@@ -623,7 +642,8 @@ def fuzz_single_mirror_class(rng):
     for _ in range(nops):
         u = rng.rand()
         if u < 0.5:
-            plan.append(('steps', [(rng.randint(-1, 5, N), int(rng.randint(4))) for _ in range(int(rng.randint(1, 6)))]))
+            plan.append(('steps', [(rng.randint(-1, 5, N), int(rng.randint(6)), modes[rng.randint(len(modes))])
+                                   for _ in range(int(rng.randint(1, 6)))]))
         elif u < 0.65:
             T = int(rng.randint(1, 20))
             plan.append(('rollout', rng.randint(-1, 5, (T, N)), bool(rng.rand() < 0.8)))
@@ -647,9 +667,15 @@ def fuzz_single_mirror_class(rng):
                 if verbose and mirror:
                     print(f'  op {i}: {op[0]} mirror={env.mirror_state()}', flush=True)
                 if op[0] == 'steps':
-                    for a_np, how in op[1]:
+                    for a_np, how, other in op[1]:
                         a = torch.from_numpy(a_np).cuda()
                         obs, r, d, info = env.step(a)
+                        if how == 4:    # round 5 (VERDICT r04's repro): the observation mode changes between step and reset(d)
+                            env.observation_mode = other
+                            how = 0
+                        elif how == 5:  # ... or lazy_reset does
+                            env.lazy_reset = not env.lazy_reset
+                            how = 0
                         # (how == 3: no reset at all — finished envs are stepped again, and the mirror stays current with
                         # nothing postponed: the state in which a look must not forget an edit)
                         back = env.reset(d) if how == 0 else env.reset(d.clone()) if how == 1 else \
@@ -667,7 +693,7 @@ def fuzz_single_mirror_class(rng):
                 elif op[0] == 'edit' and alias is not None:
                     e, r2 = op[1], np.random.RandomState(op[2])
                     if not op[3]:
-                        assert env.envs is alias     # (re-read first: applies a postponed reset, DESIGN.md deviation 9)
+                        assert env.envs.data_ptr() == alias.data_ptr()   # (a look first)
                     else:
                         env.reset(torch.zeros(N, dtype=torch.bool, device='cuda:0'), return_observations=False)  # (flushes a postponed reset; no look)
                     st = alias[e].cpu().numpy()

@@ -3077,7 +3077,7 @@ static int multi_launch(MKind kind, MultiArgs &p, void *stream)
             if (!allow_lds(sh->fn, bytes)) return WURM_ERR_HIP;
             q.grp_variant = (int)opt.multi_group_variant;
             void *args[] = {&q};
-            ++launch_count;
+            launch_count.fetch_add(1, std::memory_order_relaxed);
             if (hipLaunchKernel(sh->fn, gg, bb, args, bytes, (hipStream_t)stream) != hipSuccess) return WURM_ERR_HIP;
             p.resident_used = 1; // (the kernel keeps the caller's mirror, if one was given)
             return hipGetLastError() == hipSuccess ? WURM_OK : WURM_ERR_HIP;

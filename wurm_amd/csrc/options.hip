@@ -1,5 +1,7 @@
 // options.hip — the library's knobs (options.hpp): defaults, one read of the environment when the library is loaded,
 // wurm_set_option / wurm_get_option afterwards.  Host code only.
+#include <atomic>
+#include <cerrno>
 #include <cstdlib>
 #include <cstring>
 
@@ -9,8 +11,10 @@
 namespace wurm {
 
 constexpr Options DEFAULTS = {1ll << 20, 12288, 6144, -1, -1, -1, 12, 0, 2048, 0, -1, 0, 0};
+// PROCESS-WIDE: every env object and every thread of the process sees the same knobs (documented in include/wurm_hip.h);
+// the launch counter is a diagnostic that concurrent launchers may bump at the same time, hence atomic.
 Options opt = DEFAULTS;
-long long launch_count = 0;
+std::atomic<long long> launch_count{0};
 
 namespace {
 
@@ -43,10 +47,27 @@ const Entry *find(const char *name)
     return nullptr;
 }
 
+// an environment variable that is not a whole decimal number (empty, garbage, out of range) leaves the default in place —
+// atoll() would have turned it into 0, which for the *_MIN_ENVS thresholds means "always"
+bool parse_whole(const char *v, long long &out)
+{
+    if (!v || !*v) return false;
+    errno = 0;
+    char *end = nullptr;
+    const long long x = strtoll(v, &end, 10);
+    if (errno != 0 || end == v) return false;
+    while (*end == ' ' || *end == '\t' || *end == '\n') ++end;
+    if (*end != '\0') return false;
+    out = x;
+    return true;
+}
+
 __attribute__((constructor)) void read_environment()
 {
-    for (const Entry &e : table)
-        if (const char *v = getenv(e.name)) opt.*(e.field) = atoll(v);
+    for (const Entry &e : table) {
+        long long x;
+        if (parse_whole(getenv(e.name), x)) opt.*(e.field) = x;
+    }
 }
 
 } // namespace
@@ -68,7 +89,7 @@ int64_t wurm_get_option(const char *name)
     return e ? (int64_t)(wurm::opt.*(e->field)) : INT64_MIN;
 }
 
-int64_t wurm_launch_count(void) { return (int64_t)wurm::launch_count; }
+int64_t wurm_launch_count(void) { return (int64_t)wurm::launch_count.load(std::memory_order_relaxed); }
 
 int wurm_reset_option(const char *name)
 {

@@ -2,6 +2,7 @@
 // afterwards only through wurm_set_option (include/wurm_hip.h).  Launch paths read plain fields of `wurm::opt`: no
 // getenv on any path whose whole budget is a few microseconds.
 #pragma once
+#include <atomic>
 
 namespace wurm {
 
@@ -24,8 +25,8 @@ struct Options {
 extern Options opt;
 
 // number of kernels this library has launched in this process (wurm_launch_count, include/wurm_hip.h): bench.py reports
-// launches per loop iteration from it.  Plain increments: the Python classes launch from one thread.
-extern long long launch_count;
-#define WURM_LAUNCH(...) do { ++::wurm::launch_count; hipLaunchKernelGGL(__VA_ARGS__); } while (0)
+// launches per loop iteration from it.  Atomic: concurrent launchers may bump it at the same time.
+extern std::atomic<long long> launch_count;
+#define WURM_LAUNCH(...) do { ::wurm::launch_count.fetch_add(1, std::memory_order_relaxed); hipLaunchKernelGGL(__VA_ARGS__); } while (0)
 
 } // namespace wurm

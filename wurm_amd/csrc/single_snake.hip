@@ -1567,7 +1567,10 @@ __global__ __launch_bounds__(256) void check_kernel(const float *__restrict__ en
     const float *envp = envs + env * 3 * g.C;
     // in fp32 like the reference's sums (wurm/utils.py:113-178) — a state that holds non-integers (food 0.5, only ever by
     // hand) gets the reference's verdict on every check, not only on the first one (tests/test_checker_failing_states.py).
-    // Sums of integer-valued floats are exact in any order; so are sums of a few halves and quarters.
+    // Sums of integer-valued floats are exact in any order WHILE THEY STAY BELOW 2^24 (so are sums of a few halves and
+    // quarters): a body sum reaches 2^24 only for a snake of more than 5 792 cells (S = 64 has 4 096), so for every snake a
+    // grid of the supported sizes can hold the lane-then-butterfly order here and torch's .sum() agree bit for bit; with
+    // hand-made non-dyadic values the two orders may round differently, and so may the verdict.
     int bad_food = 0;
     float hs = 0.0f, bs = 0.0f, bm = -INFINITY, hb = 0.0f, hf = 0.0f, fs = 0.0f;
 #pragma unroll
@@ -1646,7 +1649,7 @@ static int pick_cpl(int S)
 //   rollout          | otherwise                                                                      | R_GENERIC
 // (the resident 9 x 9 step, lane_resident.hpp, is chosen by fused_entry: it needs the caller's mirror)
 enum Route { R_GENERIC, R_GRID_STEP, R_LANE_STEP, R_GRID_ROLLOUT, R_LANE_ROLLOUT, R_S9_INJ, R_S9, R_LEAN, R_GENERIC_PARTIAL, R_GENERIC_NONE, R_LANE_RESIDENT };
-static Route last_route = R_GENERIC; // (wurm_single_last_route: what the tests and bench.py name a launch by)
+static thread_local Route last_route = R_GENERIC; // (wurm_single_last_route: the route of the CALLING THREAD's last launch — a diagnostic the tests and bench.py name a launch by; no state that a later call depends on)
 
 static const char *route_name(Route r)
 {

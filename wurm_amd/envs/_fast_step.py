@@ -268,6 +268,33 @@ class FastStepMixin(object):
         self._mirror_why = 'resident_mirror=False' if pol is False else 'no step yet'
         self._stor = None
 
+    # ------------------------------------------------------------------ copy / pickle
+    # The reference's envs are plain attribute bags: copy.deepcopy(env) and pickle work on them (single_snake.py:55-102).
+    # Here the object also owns ctypes blocks, a step machine and device buffers that are derived state: they are left out
+    # and rebuilt on the other side (`_fast_init`), after the postponed reset and a lazy mirror have been applied to the
+    # tensor that IS the state.
+    _DERIVED = ('_c', '_sl', '_fs', '_get_device', '_pend', '_slab_mode', '_envs_ok', '_done', '_done_stamp', '_mirror',
+                '_mirror_key', '_mirror_off', '_lazy_mirror', '_write_outs', '_touches', '_mirror_step0', '_chk',
+                '_chk_armed_at', '_chk_void_at', '_check_calls', '_check_step', '_mirror_why', '_stor', '_v_obs', '_v_reward',
+                '_v_done2', '_v_selfc', '_v_edgec')
+
+    def __getstate__(self):
+        envs = self._state()   # (applies a postponed reset, writes a lazy mirror out)
+        st = {k: v for k, v in self.__dict__.items() if k not in self._DERIVED}
+        st['_envs'] = envs
+        st['_copy_call'], st['_copy_done'] = int(self._fs.call), self.done
+        return st
+
+    def __setstate__(self, st):
+        st = dict(st)
+        call, done, envs = st.pop('_copy_call'), st.pop('_copy_done'), st.pop('_envs')
+        self.__dict__.update(st)
+        self._fast_init()
+        self.envs = envs
+        self._fs.watch, self._fs.watch_version = None, -1   # (nobody holds the restored tensor but this object)
+        self._fs.call = call
+        self.done = done
+
     # state of the step machine that other methods of the classes read and write
     _call = property(lambda self: self._fs.call, lambda self, v: setattr(self._fs, 'call', v))
     _pending = property(lambda self: self._fs.pending, lambda self, v: setattr(self._fs, 'pending', v))
@@ -476,8 +503,8 @@ class FastStepMixin(object):
         fs, c = self._fs, self._c
         self._check_calls += 1
         self._check_step = fs.steps
-        if self._mirror is None or not c.resident:
-            return None
+        if self._mirror is None or not c.resident or self.size != 9:
+            return None      # (only the 9 x 9 lane-resident step computes masks: a grid mirror would pay a fill per step for -1s)
         self._mirror_sync()  # (an in-place edit of a state tensor the caller holds voids the masks)
         if self._chk is None:
             self._chk = torch.full((self.num_envs,), -1, dtype=torch.int32, device=self.device)
@@ -555,6 +582,9 @@ class FastStepMixin(object):
             self._pend = torch.zeros(N, dtype=torch.uint8, device=dev)
             self._c.done_copy = self._pend.data_ptr()
         self._configure_call(self._c)
+        if self._c.check_mask and fs.steps - self._check_step > 64:
+            # check_consistency() has not been called for a while: the step launches stop writing its masks
+            self._c.check_mask, self._chk_armed_at = None, 1 << 62
         self._c.obs_mode, self._c.obs_n = m, n
         self._setup_mirror(m, n)
         sl = self._sl

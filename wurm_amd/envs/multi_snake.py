@@ -278,17 +278,9 @@ class MultiSnake(object):
         `resident_mirror` — None: large batches step on a compact mirror of foods / heads / bodies chosen
         by batch size with adaptive rules; False: never; True / 'lazy' / 'eager': always, without the adaptive rules
         (`env.mirror_state()` tells what is in effect and why)."""
-        from wurm_amd.envs._fast_step import parse_mirror_policy, _make_stepper
+        from wurm_amd.envs._fast_step import parse_mirror_policy
         self.device = _lib.require_device(device)
-        self._cfg_dirty = True
-        # the argument block of the per-call launches, the output slabs and the step machine over them (the block is filled
-        # in on first use: _ensure_call)
-        self._mc, self._sl = _lib.MultiCall(), _lib.MultiSlabs()
-        self._mc_addr = ctypes.addressof(self._mc)
-        self._fs = fs = _make_stepper('wurm_multi_step_slot', self._mc_addr, ctypes.addressof(self._sl))
-        fs.num_envs, fs.num_agents = num_envs, num_snakes
-        fs.alias_free = self._alias_free
-        fs.dev_index = -1 if self.device.index is None else self.device.index
+        self._make_machine(num_envs, num_snakes)
         self._resident_policy = pol = parse_mirror_policy(resident_mirror)
         self._mirror_off = pol is False
         self._lazy_mirror = pol != 'eager' and MultiSnake._lazy_mirror
@@ -381,6 +373,48 @@ class MultiSnake(object):
                                           want_status=True)
             if failures:
                 raise RuntimeError('There is no available locations to create snake!')
+
+    def _make_machine(self, num_envs: int, num_snakes: int):
+        """the argument block of the per-call launches, the output slabs and the step machine over them (the block is filled
+        in on first use: _ensure_call) — derived state: made by the constructor and again by __setstate__"""
+        from wurm_amd.envs._fast_step import _make_stepper
+        self._cfg_dirty = True
+        self._mc, self._sl = _lib.MultiCall(), _lib.MultiSlabs()
+        self._mc_addr = ctypes.addressof(self._mc)
+        self._fs = fs = _make_stepper('wurm_multi_step_slot', self._mc_addr, ctypes.addressof(self._sl))
+        fs.num_envs, fs.num_agents = num_envs, num_snakes
+        fs.alias_free = self._alias_free
+        fs.dev_index = -1 if self.device.index is None else self.device.index
+
+    # ------------------------------------------------------------------ copy / pickle
+    # The reference's env is a plain attribute bag: copy.deepcopy(env) and pickle work on it (multi_snake.py:56-160).  The
+    # ctypes blocks, the step machine, the mirror and the output slabs are derived state: left out here and rebuilt on the
+    # other side, after the postponed reset and a lazy mirror have been applied to the tensors that ARE the state.
+    _DERIVED = ('_mc', '_sl', '_mc_addr', '_fs', '_pend', '_cfg_cache', '_mc_cfg', '_mc_ready', '_mc_mode', '_mirror',
+                '_mirror_off', '_lazy_mirror', '_mirror_why', '_watched', '_write_outs', '_touches', '_chk', '_chk_has_after',
+                '_chk_armed_at', '_chk_void_at', '_check_calls', '_check_step', '_slab', '_stor', '_keys', '_get_device',
+                '_rewards_t', '_boost_t', '_rewards_at', '_boost_at', '_info', '_cfg_dirty')
+
+    def __getstate__(self):
+        self._state()   # (applies a postponed reset, writes a lazy mirror out)
+        st = {k: v for k, v in self.__dict__.items() if k not in self._DERIVED}
+        st['_copy_call'] = int(self._fs.call)
+        st['_copy_rewards'], st['_copy_boost'] = self.rewards, self.boost_this_step
+        return st
+
+    def __setstate__(self, st):
+        st = dict(st)
+        call, rewards, boost = st.pop('_copy_call'), st.pop('_copy_rewards'), st.pop('_copy_boost')
+        self.__dict__.update(st)
+        self._make_machine(self.num_envs, self.num_snakes)
+        self._pend, self._cfg_cache, self._stor = None, (None, None), [None] * len(_SLOTS)
+        self._mirror_off = self._resident_policy is False
+        self._lazy_mirror = self._resident_policy != 'eager' and MultiSnake._lazy_mirror
+        self._mirror_why = 'resident_mirror=False' if self._resident_policy is False else 'no step yet'
+        self._fs.call = call
+        self._fs.lazy_ok = self._lazy_ok()
+        self.rewards, self.boost_this_step = rewards, boost
+        self._sync_state()
 
     # ------------------------------------------------------------------ helpers
 
@@ -752,7 +786,10 @@ class MultiSnake(object):
         elems = int(torch.Size(inner).numel())
         want_after = bool(fs.want_obs_after)
         per_step = K * N * (4 * elems * (2 if want_after else 1) + 24 + 7) + N
-        R = max(1, min(64, (1 << 30) // max(per_step, 1)))  # (cfg4 'full': 123 MB of observations per step -> 8 steps)
+        # 64 MB per slab at most: a caller that drops what a step returned before the next one gets the SAME block back from
+        # torch's allocator, and one call's outputs (123 MB at cfg4 'full': one step per slab) then stay in the 256 MB
+        # Infinity Cache; a slab of several such steps would stream to HBM (measured: 39 against 35 us per iteration at cfg4)
+        R = max(1, min(64, (64 << 20) // max(per_step, 1)))
         of = torch.empty((R, 6 * K, N), dtype=torch.float32, device=dev)
         ob = torch.empty((R, 7 * K + 1, N), dtype=torch.bool, device=dev)
         obs = torch.empty((R, K, N) + inner, dtype=torch.float32, device=dev)
