@@ -17,11 +17,15 @@ ap.add_argument('--size', type=int, default=25)
 ap.add_argument('--chunk', type=int, default=16)
 ap.add_argument('--mode', default='partial_5')
 ap.add_argument('--percall', type=int, default=200)
+ap.add_argument('--defaults', action='store_true', help="constructor defaults and 'full' observations (BASELINE configs[3]) instead of the training dynamics")
 args = ap.parse_args()
 N, K, S, T = args.envs, args.snakes, args.size, args.chunk
 dev = torch.device('cuda:0')
 kw = dict(observation_mode=args.mode, food_mode='random_rate', respawn_mode='any', boost_cost_prob=0.25,
           food_on_death_prob=0.33, food_rate=2.5e-4)
+if args.defaults:
+    kw = dict(observation_mode='full')
+    args.mode = 'full (defaults)'
 env = MultiSnake(N, K, S, device=dev, seed=0, **kw)
 acts = torch.randint(8, (8, T, K, N), device=dev)
 for i in range(3):

@@ -800,11 +800,21 @@ constexpr int PC_BG = 0, PC_RING = 1, PC_FOOD = 2, PC_SNAKE0 = 3, PC_COMPLEX = 2
 // a head sits on its own body in every state the dynamics produce; anywhere else the cell is marked complex.
 // The same map answers _add_food's "free interior cell" (code 0: free_from_codes), so a step with random_rate food and
 // crops scans the grids once, not twice (multi_step_body builds it, observe_partial reuses it: Snake::cmap_ok).
-__device__ __forceinline__ void cell_codes(const Ctx &cx, int hc, unsigned char *codes, u64 ring)
+__device__ __forceinline__ u64 free_from_codes(const Ctx &cx, const unsigned char *codes);
+struct CellCounts {
+    u64 free;   // bit k <=> cell lane + 64 k is a free interior cell (code 0), as free_cells(cx, hc, 1) / free_from_codes
+    int nfree;  // their number over the wave (count_bits)
+    int nfood;  // cells that hold food, whatever else is on them (food_count)
+};
+
+__device__ __forceinline__ CellCounts cell_codes(const Ctx &cx, int hc, unsigned char *codes, u64 ring)
 {
     const int C = cx.C, K = cx.K, lane = cx.lane;
     constexpr int U = 5;
     const int myT = lane < K ? cx.tclk[lane] : 0;
+    CellCounts cc_out;
+    cc_out.free = 0;
+    cc_out.nfree = cc_out.nfood = 0;
     for (int k0 = 0; k0 < cx.cpl; k0 += U) {
         int cc[U];
         u32 fd[U], code[U], cnt[U];
@@ -835,7 +845,13 @@ __device__ __forceinline__ void cell_codes(const Ctx &cx, int hc, unsigned char 
             u32 c1 = cnt[u] > 1u ? (u32)PC_COMPLEX : code[u];             // two bodies on the cell
             c1 = fd[u] != 0 ? (c1 == PC_BG ? (u32)PC_FOOD : (u32)PC_COMPLEX) : c1; // food; food under a body
             c1 = ((rb >> u) & 1u) ? (u32)PC_RING : c1;                    // :225 the border wins over everything
-            if (lane + 64 * (k0 + u) < C) codes[cc[u]] = (unsigned char)c1;
+            const bool valid = lane + 64 * (k0 + u) < C;
+            if (valid) codes[cc[u]] = (unsigned char)c1;
+            // the counts _add_food needs come out of the same pass (the compares' own wave masks, counted on the scalar unit)
+            const bool fr = valid && c1 == PC_BG;
+            cc_out.free |= (u64)fr << (k0 + u);
+            cc_out.nfree += popc64(ballot(fr));
+            cc_out.nfood += popc64(ballot(valid && fd[u] != 0));
         }
     }
     wave_lds_sync();
@@ -852,6 +868,11 @@ __device__ __forceinline__ void cell_codes(const Ctx &cx, int hc, unsigned char 
     wave_lds_sync();
     if (want >= 0 && want != PC_COMPLEX && codes[hc] != PC_COMPLEX) codes[hc] = (unsigned char)want;
     wave_lds_sync();
+    if (ballot(want == PC_COMPLEX) != 0) { // (a head on a cell without its own body may have stood on a "free" cell: hand-made states)
+        cc_out.free = free_from_codes(cx, codes);
+        cc_out.nfree = count_bits(cx, cc_out.free);
+    }
+    return cc_out;
 }
 
 // bit k <=> cell lane + 64 k is a free interior cell (:439-445, :393-399): code 0 of cell_codes
@@ -1075,24 +1096,35 @@ __device__ __forceinline__ void multi_step_body(const Ctx &cx, const MultiArgs &
     // _add_food (:368-410)
     bool cmap_ok = false;
     {
-        const int nfood = food_count(cx);
-        WURM_TLS(cx, 10);
         // The map of cell codes (cell_codes: one scan of the K grids) serves both "which interior cells are free" here and the
-        // crops of observe_partial; it lives where observe_full keeps its head map, so only launches without 'full'
-        // observations build it.
-        const bool want_free = p.cfg.food_mode == 0 ? (nfood == 0 && !p.has_inj) : nfood < p.cfg.max_food;
-        if (p.obs_mode != WURM_OBS_DEFAULT && cx.has_ring && (want_free || p.obs_mode == WURM_OBS_PARTIAL)) {
-            cell_codes(cx, hc, cx.hmap, cx.ring);
+        // crops of observe_partial, and counts the food and the free cells on the way; it lives where observe_full keeps its
+        // head map, so only launches without 'full' observations build it — a launch that writes crops every step, one
+        // without observations when food has to be placed.
+        CellCounts cc;
+        cc.free = 0;
+        cc.nfree = -1;
+        int nfood;
+        if (p.obs_mode == WURM_OBS_PARTIAL && cx.has_ring) {
+            cc = cell_codes(cx, hc, cx.hmap, cx.ring);
             cmap_ok = true;
+            nfood = cc.nfood;
+        } else {
+            nfood = food_count(cx);
+            const bool want_free = p.cfg.food_mode == 0 ? (nfood == 0 && !p.has_inj) : nfood < p.cfg.max_food;
+            if (p.obs_mode == WURM_OBS_NONE && cx.has_ring && want_free) {
+                cc = cell_codes(cx, hc, cx.hmap, cx.ring);
+                cmap_ok = true;
+            }
         }
+        WURM_TLS(cx, 10);
         if (p.cfg.food_mode == 0) {
             if (nfood == 0) {                   // :371-379
                 if (p.has_inj) {
                     int cell = p.inj.food_cell[offE + env];
                     if (cell >= 0 && cell < C && lane == 0) put_food(cx, cell, cmap_ok);
                 } else {
-                    u64 fr = cmap_ok ? free_from_codes(cx, cx.hmap) : free_cells(cx, hc, 1);
-                    int nf = count_bits(cx, fr);
+                    u64 fr = cmap_ok ? cc.free : free_cells(cx, hc, 1);
+                    int nf = cmap_ok ? cc.nfree : count_bits(cx, fr);
                     if (nf > 0) {
                         int Kr = (int)mulhi_range(rng_words(p.seed, call, env_id, RNG_FOOD, 0).w[0], (u32)nf);
                         int k = rank_select(cx, fr, Kr);
@@ -1101,7 +1133,7 @@ __device__ __forceinline__ void multi_step_body(const Ctx &cx, const MultiArgs &
                 }
             }
         } else if (nfood < p.cfg.max_food) {    // :382-408
-            u64 fr = cmap_ok ? free_from_codes(cx, cx.hmap) : free_cells(cx, hc, 1);
+            u64 fr = cmap_ok ? cc.free : free_cells(cx, hc, 1);
             WURM_TLS(cx, 11);
             if (p.has_inj) {
                 for (int k = 0; k < cx.cpl; ++k)
@@ -1112,7 +1144,7 @@ __device__ __forceinline__ void multi_step_body(const Ctx &cx, const MultiArgs &
                 // the j-th as the mulhi(word, n - j)-th remaining free cell in row-major order: the same distribution as n
                 // independent draws (this build's own RNG specification, oracle/multi_snake.c step_env), for one Philox block
                 // per env-step instead of one per four cells and lane (625 draws to place 0.13 foods on average at cfg4').
-                const int nf = count_bits(cx, fr);
+                const int nf = cmap_ok ? cc.nfree : count_bits(cx, fr);
                 const float pw = pow_n(1.0f - p.cfg.food_rate, nf);
                 if (!(p.cfg.food_rate > 0.0f) || pw < BINOMIAL_MIN_P0) {
                     // P(no food) too small for the recurrence (rates far above the reference's): cell by cell — the cells
@@ -1405,8 +1437,13 @@ __device__ __forceinline__ void grp_emit_group(const MultiArgs &p, float *obs, l
 // `p.grp_emit` (large batches, 'full' observations of at most 5 snakes, several envs per workgroup): the waves of the
 // workgroup first step their envs, then write the observations TOGETHER — wave w writes agent w's view of all the
 // workgroup's envs, one linear run (class codes + colour table: see multi_rollout_group_kernel).
-__global__ __launch_bounds__(512) void multi_step_kernel(MultiArgs p)
+// INJ / OBS: as multi_rollout_kernel — a launch that draws its own random outcomes, with the observation mode a constant.
+template <bool INJ = true, int OBS = -1>
+__global__ __launch_bounds__(512) void multi_step_kernel(MultiArgs p_in)
 {
+    MultiArgs p = p_in;
+    if (!INJ) p.has_inj = p.has_rinj = 0;
+    if (OBS >= 0) p.obs_mode = OBS;
     const int wave = (int)(threadIdx.x >> 6), wpb = (int)(blockDim.x >> 6);
     const long long env0 = xcd_block(blockIdx.x, gridDim.x) * wpb, env = env0 + wave;
     const bool grouped = p.grp_emit != 0;
@@ -2241,9 +2278,16 @@ __global__ __launch_bounds__(256) void multi_observe_wg_kernel(MultiArgs p)
 // the same phase — and interleaving them inside one wave does not help (measured); two waves with their own
 // instruction streams do overlap.
 
-template <bool TWO>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void multi_rollout_kernel(MultiArgs p)
+// INJ = false: the launch draws its random outcomes itself (every launch but the replays of recorded fixtures) — the
+// injected-outcome branches of the step and of the reset, their nine pointers and three running offsets fold away, which
+// matters in a kernel whose uniform state does not fit the scalar registers (profiles/r05_kernel_resources.txt).
+// OBS >= 0: the observation mode is a compile-time constant too (the other modes' writers and their loop invariants go).
+template <bool TWO, bool INJ, int OBS = -1>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void multi_rollout_kernel(MultiArgs p_in)
 {
+    MultiArgs p = p_in;
+    if (!INJ) p.has_inj = p.has_rinj = 0;
+    if (OBS >= 0) p.obs_mode = OBS;
     const int wave = uniform((int)(threadIdx.x >> 6)), wpb = TWO ? 1 : (int)(blockDim.x >> 6);
     const long long env = xcd_block(blockIdx.x, gridDim.x) * wpb + (TWO ? 0 : wave);
     if (env >= p.N) return;
@@ -2607,9 +2651,13 @@ __device__ __forceinline__ void grp_restore(const int *sv, int lane, int K, Snak
 // WIDE (6 .. 10 snakes): 32-bit class words and ONE code / output buffer — the steppers wait for the writers to be done with
 // step t - 1 before they write the codes of step t (a second barrier per step; the transition itself still runs beside the
 // writers: the speeds.py shape, 10 snakes on 36 x 36, has 41 KB of LDS per env with one 32-bit buffer and four envs per CU).
-template <int G, int W, int EPS, int OCC, bool WIDE = false>
-__global__ __launch_bounds__(64 * (G / EPS + W)) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void multi_rollout_group_kernel(MultiArgs p)
+// INJ = false: as multi_rollout_kernel — the launch draws its own random outcomes, the injected-outcome branches fold away.
+template <int G, int W, int EPS, int OCC, bool WIDE = false, bool INJ = true>
+__global__ __launch_bounds__(64 * (G / EPS + W)) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void multi_rollout_group_kernel(MultiArgs p_in)
 {
+    MultiArgs p = p_in;
+    if (!INJ) p.has_inj = p.has_rinj = 0;
+    p.obs_mode = WURM_OBS_DEFAULT; // (what multi_group_shape requires: a constant here)
     typedef typename std::conditional<WIDE, u32, unsigned short>::type CT;
     constexpr int NSW = G / EPS; // stepper waves
     // SHARE: the (agent, env) blocks of a step are handed out by an LDS counter and the steppers take some too
@@ -2998,7 +3046,7 @@ static bool allow_lds(const void *kernel, size_t bytes)
     return hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess;
 }
 
-struct GroupShape { int G, W, eps, occ; const void *fn; };
+struct GroupShape { int G, W, eps, occ; const void *fn; const void *fn_rng; }; // fn_rng: the INJ = false instantiation where one is compiled
 
 // The shape of multi_rollout_group_kernel that serves this rollout ('full' observations of at most 10 snakes, several steps,
 // a large batch), or nullptr; q: p with the kernel's LDS layout filled in, bytes: its dynamic LDS.
@@ -3024,9 +3072,9 @@ static const GroupShape *multi_group_shape(const MultiArgs &p, MultiArgs &q, siz
         // 1000 G + 100 W + 10 EPS + OCC picks one of the compiled shapes; 0 = automatic: the first that fits)
         typedef GroupShape Shape;
         static const Shape wide_shapes[] = { // 6 .. 10 snakes (the first that fits)
-            {4, 10, 1, 4, (const void *)multi_rollout_group_kernel<4, 10, 1, 4, true>},
-            {4, 5, 1, 4, (const void *)multi_rollout_group_kernel<4, 5, 1, 4, true>},
-            {2, 10, 1, 4, (const void *)multi_rollout_group_kernel<2, 10, 1, 4, true>},
+            {4, 10, 1, 4, (const void *)multi_rollout_group_kernel<4, 10, 1, 4, true>, (const void *)multi_rollout_group_kernel<4, 10, 1, 4, true, false>},
+            {4, 5, 1, 4, (const void *)multi_rollout_group_kernel<4, 5, 1, 4, true>, nullptr},
+            {2, 10, 1, 4, (const void *)multi_rollout_group_kernel<2, 10, 1, 4, true>, nullptr},
         };
         static const Shape shapes[] = {
             // (automatic: the first that fits.  Measured at cfg4 on four boxes, ms per 16- / 64-step launch: 8 / 2 / 1 / 5 — two
@@ -3034,8 +3082,10 @@ static const GroupShape *multi_group_shape(const MultiArgs &p, MultiArgs &q, siz
             // 8 / 4 / 1 / 6 — a writer per agent, 6 waves per SIMD at 80 VGPRs with 130 bytes of scratch — 0.44-0.51 / 1.57-1.81
             // depending on the box and on how the allocator spills; 4 / 4 / 1 / 4: 0.51 / 1.66; 8 / 4 / 2 / 4: 1.79 per 64;
             // the two-wave kernel of round 3: 0.55 / 1.73-2.15 — profiles/r04_multi_group_probe.txt)
-            {8, 2, 1, 5, (const void *)multi_rollout_group_kernel<8, 2, 1, 5>}, {8, 4, 1, 6, (const void *)multi_rollout_group_kernel<8, 4, 1, 6>},
-            {4, 4, 1, 4, (const void *)multi_rollout_group_kernel<4, 4, 1, 4>}, {8, 4, 2, 4, (const void *)multi_rollout_group_kernel<8, 4, 2, 4>},
+            {8, 2, 1, 5, (const void *)multi_rollout_group_kernel<8, 2, 1, 5>, (const void *)multi_rollout_group_kernel<8, 2, 1, 5, false, false>},
+            {8, 4, 1, 6, (const void *)multi_rollout_group_kernel<8, 4, 1, 6>, (const void *)multi_rollout_group_kernel<8, 4, 1, 6, false, false>},
+            {4, 4, 1, 4, (const void *)multi_rollout_group_kernel<4, 4, 1, 4>, (const void *)multi_rollout_group_kernel<4, 4, 1, 4, false, false>},
+            {8, 4, 2, 4, (const void *)multi_rollout_group_kernel<8, 4, 2, 4>, nullptr},
         };
         const Shape *sh = nullptr;
         for (const Shape &c : wide_shapes) {
@@ -3074,11 +3124,12 @@ static int multi_launch(MKind kind, MultiArgs &p, void *stream)
         if (const GroupShape *sh = multi_group_shape(p, q, bytes)) {
             const dim3 gg((unsigned)((p.N + sh->G - 1) / sh->G)), bb(64 * (sh->G / sh->eps + sh->W));
             (void)hipGetLastError();
-            if (!allow_lds(sh->fn, bytes)) return WURM_ERR_HIP;
+            const void *kfn = (!p.has_inj && !p.has_rinj && sh->fn_rng) ? sh->fn_rng : sh->fn;
+            if (!allow_lds(kfn, bytes)) return WURM_ERR_HIP;
             q.grp_variant = (int)opt.multi_group_variant;
             void *args[] = {&q};
             launch_count.fetch_add(1, std::memory_order_relaxed);
-            if (hipLaunchKernel(sh->fn, gg, bb, args, bytes, (hipStream_t)stream) != hipSuccess) return WURM_ERR_HIP;
+            if (hipLaunchKernel(kfn, gg, bb, args, bytes, (hipStream_t)stream) != hipSuccess) return WURM_ERR_HIP;
             p.resident_used = 1; // (the kernel keeps the caller's mirror, if one was given)
             return hipGetLastError() == hipSuccess ? WURM_OK : WURM_ERR_HIP;
         }
@@ -3096,8 +3147,11 @@ static int multi_launch(MKind kind, MultiArgs &p, void *stream)
     if (two) { // one env per workgroup of two waves
         dim3 block2(128), grid2((unsigned)p.N);
         (void)hipGetLastError();
-        if (!allow_lds((const void *)multi_rollout_kernel<true>, (size_t)lds)) return WURM_ERR_HIP;
-        WURM_LAUNCH(multi_rollout_kernel<true>, grid2, block2, (size_t)lds, (hipStream_t)stream, p);
+        const bool inj2 = p.has_inj || p.has_rinj;
+        if (!allow_lds(inj2 ? (const void *)multi_rollout_kernel<true, true> : (const void *)multi_rollout_kernel<true, false>, (size_t)lds))
+            return WURM_ERR_HIP;
+        if (inj2) WURM_LAUNCH((multi_rollout_kernel<true, true>), grid2, block2, (size_t)lds, (hipStream_t)stream, p);
+        else WURM_LAUNCH((multi_rollout_kernel<true, false>), grid2, block2, (size_t)lds, (hipStream_t)stream, p);
         return hipGetLastError() == hipSuccess ? WURM_OK : WURM_ERR_HIP;
     }
     if ((kind == MK_STEP || kind == MK_RESET || (kind == MK_OBSERVE && snap)) && lds * 4 > 65536 &&
@@ -3133,17 +3187,36 @@ static int multi_launch(MKind kind, MultiArgs &p, void *stream)
     size_t shmem = (size_t)lds * wpb + extra;
     hipStream_t st = (hipStream_t)stream;
     (void)hipGetLastError();
-    const void *kf = kind == MK_STEP ? (const void *)multi_step_kernel
+    const bool rng = !p.has_inj && !p.has_rinj;
+    const void *kstep = !rng ? (const void *)multi_step_kernel<true, -1>
+                      : p.obs_mode == WURM_OBS_DEFAULT ? (const void *)multi_step_kernel<false, WURM_OBS_DEFAULT>
+                      : p.obs_mode == WURM_OBS_PARTIAL ? (const void *)multi_step_kernel<false, WURM_OBS_PARTIAL>
+                      : (const void *)multi_step_kernel<false, WURM_OBS_NONE>;
+    const void *kf = kind == MK_STEP ? kstep
                    : kind == MK_RESET ? (const void *)multi_reset_kernel
                    : kind == MK_OBSERVE ? (const void *)multi_observe_kernel
-                   : kind == MK_CHECK ? (const void *)multi_check_kernel : (const void *)multi_rollout_kernel<false>;
+                   : kind == MK_CHECK ? (const void *)multi_check_kernel
+                   : (p.has_inj || p.has_rinj) ? (const void *)multi_rollout_kernel<false, true>
+                   : p.obs_mode == WURM_OBS_PARTIAL ? (const void *)multi_rollout_kernel<false, false, WURM_OBS_PARTIAL>
+                   : p.obs_mode == WURM_OBS_NONE ? (const void *)multi_rollout_kernel<false, false, WURM_OBS_NONE>
+                   : (const void *)multi_rollout_kernel<false, false>;
     if (!allow_lds(kf, shmem)) return WURM_ERR_HIP;
     switch (kind) {
-    case MK_STEP: WURM_LAUNCH(multi_step_kernel, grid, block, shmem, st, p); break;
+    case MK_STEP: {
+        void *kargs[] = {&p};
+        launch_count.fetch_add(1, std::memory_order_relaxed);
+        if (hipLaunchKernel(kstep, grid, block, kargs, shmem, st) != hipSuccess) return WURM_ERR_HIP;
+        break;
+    }
     case MK_RESET: WURM_LAUNCH(multi_reset_kernel, grid, block, shmem, st, p); break;
     case MK_OBSERVE: WURM_LAUNCH(multi_observe_kernel, grid, block, shmem, st, p); break;
     case MK_CHECK: WURM_LAUNCH(multi_check_kernel, grid, block, shmem, st, p); break;
-    case MK_ROLLOUT: WURM_LAUNCH(multi_rollout_kernel<false>, grid, block, shmem, st, p); break;
+    case MK_ROLLOUT:
+        if (p.has_inj || p.has_rinj) WURM_LAUNCH((multi_rollout_kernel<false, true>), grid, block, shmem, st, p);
+        else if (p.obs_mode == WURM_OBS_PARTIAL) WURM_LAUNCH((multi_rollout_kernel<false, false, WURM_OBS_PARTIAL>), grid, block, shmem, st, p);
+        else if (p.obs_mode == WURM_OBS_NONE) WURM_LAUNCH((multi_rollout_kernel<false, false, WURM_OBS_NONE>), grid, block, shmem, st, p);
+        else WURM_LAUNCH((multi_rollout_kernel<false, false>), grid, block, shmem, st, p);
+        break;
     }
     return hipGetLastError() == hipSuccess ? WURM_OK : WURM_ERR_HIP;
 }

@@ -41,6 +41,10 @@ __device__ __forceinline__ Words rng_words(u64 seed, u64 call, u64 env_id, u32 p
     const u32 M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
     u32 c0 = (u32)env_id, c1 = (u32)call, c2 = (u32)(call >> 32), c3 = (purpose & 0xffu) | (sub << 8);
     u32 k0 = (u32)seed, k1 = (u32)(seed >> 32);
+    // (the key is wave-uniform and loop-invariant in every rollout kernel: left alone, the compiler hoists the ten round keys
+    // out of the step loop — twenty more live SGPRs in kernels that already spill a hundred — for the sake of eighteen
+    // scalar adds per evaluation; the empty asm makes the key opaque at each evaluation)
+    asm volatile("" : "+s"(k0), "+s"(k1));
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
         const u64 p0 = (u64)M0 * c0, p1 = (u64)M1 * c2; // one 32x32->64 multiply each (v_mad_u64_u32 per lane)
