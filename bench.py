@@ -211,13 +211,17 @@ def worker(args) -> int:
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     distributed = 'WORLD_SIZE' in os.environ and 'RANK' in os.environ  # started by torchrun (even with one rank)
     dist = None
+    t_init = 0.0
     if distributed:
         import torch.distributed as dist
+        t_i0 = time.perf_counter()
         if args.dry_run:
             dist.init_process_group('gloo')
         else:
             torch.cuda.set_device(local_rank)
             dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+            dist.barrier()   # (RCCL builds its communicator on first use: counted as init, not as bench time)
+        t_init = time.perf_counter() - t_i0
     n_gpus = world
     if args.gpus != n_gpus and rank == 0:
         print(f'# note: --gpus {args.gpus} but WORLD_SIZE={world}; running {n_gpus} rank(s)', file=sys.stderr)
@@ -301,6 +305,16 @@ def worker(args) -> int:
     else:
         el3, tot3, avg3, _ = timed_region(n3, off3, chunk3, k3, w3)
 
+    # every rank's own record: the first run on a multi-GPU node should explain itself
+    mine = {'rank': rank, 'local_rank': local_rank, 'device': None if args.dry_run else torch.cuda.get_device_name(local_rank),
+            'env_offset': int(offset), 'num_envs': int(N), 'cfg3_shard': [int(off3), int(off3 + n3)],
+            'comm_init_s': round(t_init, 3), 'avg_launch_ms': round(avg_launch_s * 1e3, 4),
+            'cfg3_avg_launch_ms': round(avg3 * 1e3, 4), 'host': os.uname().nodename, 'pid': os.getpid()}
+    ranks = [mine]
+    if distributed:
+        ranks = [None] * world
+        dist.all_gather_object(ranks, mine)
+
     rc = 0
     if rank == 0:
         per = algorithmic_bytes_per_env_step(SIZE, OBS_ELEMS)
@@ -354,6 +368,7 @@ def worker(args) -> int:
                 'obs_and_outputs_GBs_this_rank': (4 * OBS_ELEMS + 23) * n3 * chunk3 / avg3 / 1e9,
                 'what': 'BASELINE configs[2] split over the ranks, same protocol as the headline'},
         }
+        line['ranks'] = ranks
         if args.dry_run:
             line['dry_run'] = True
         if n_gpus == 1 and not args.no_cpu_baseline:
@@ -423,6 +438,9 @@ def host_calibration(device):
         pass
     out['py_loop_iter_ns'] = (time.perf_counter() - t0) / 200000 * 1e9
     x = torch.zeros(64, device=device)
+    for _ in range(300):   # (warm: the first calibration of a process measured 37 us against 3.4 us afterwards — VERDICT r04)
+        x.add_(1.0)
+        torch.empty(64, device=device)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(2000):

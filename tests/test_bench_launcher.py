@@ -79,3 +79,8 @@ def test_world_size_8_with_an_uneven_global_batch():
     assert blocks[0][0] == 0 and sum(n for _, n in blocks) == 65537
     assert all(blocks[i][0] + blocks[i][1] == blocks[i + 1][0] for i in range(7))
     assert max(n for _, n in blocks) - min(n for _, n in blocks) == 1
+    # every rank's own record rides in the line (device, shard, communicator init, launch time): VERDICT r04 #9
+    ranks = d['ranks']
+    assert [r['rank'] for r in ranks] == list(range(8))
+    assert [(r['env_offset'], r['num_envs']) for r in ranks] == blocks
+    assert all(r['comm_init_s'] >= 0 and r['avg_launch_ms'] > 0 for r in ranks)

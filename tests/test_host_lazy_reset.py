@@ -585,7 +585,7 @@ def test_reference_test_access_patterns_never_step_on_a_stale_mirror(env_and_log
     step()
     env.reset()                                           # = the last step's own flags (env.done): postponed as well
     assert step()['pending']
-    # .data edits bypass the version counter: the documented hole (DESIGN.md §5 deviation 11) — the mirror stays "current"
+    # .data edits bypass the version counter: the documented hole (DESIGN.md §7 deviation 9) — the mirror stays "current"
     env.envs.data[2, 0, 5, 5] = 1.0
     s = step()
     assert s['mirror_valid']

@@ -419,7 +419,7 @@ def test_host_loop_grid_mirror_matches_the_path_without(mode):
 
 
 def test_a_write_that_bypasses_the_version_counter_is_the_one_documented_deviation():
-    """DESIGN.md §5 deviation 11: an in-place write through `tensor.data` (its own version counter), a raw pointer or a DLPack
+    """DESIGN.md §7 deviation 9: an in-place write through `tensor.data` (its own version counter), a raw pointer or a DLPack
     consumer between two steps is not seen by the mirror; the same write through the tensor itself is, and without the
     mirror (WURM_RESIDENT_MIN_ENVS=1000000000) there is nothing to see"""
     import torch

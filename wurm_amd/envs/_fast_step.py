@@ -13,9 +13,10 @@ time per call, not by the GPU, so:
     kernel, so `env.envs` always is what the reference would show.  If the caller reads the observation `reset(done)`
     returns (the reference's `reset` always returns it, single_snake.py:322-342), the step launch writes that one too
     (the observation of every env once the finished ones are rebuilt).
-    The one thing that is not tracked is a tensor alias taken BEFORE the deferred reset
-    (`e = env.envs; env.step(a); env.reset(d); e[...]` shows the un-reset state until the next step or the next look at
-    `env.envs`): read the attribute again, or pass `lazy_reset=False` (DESIGN.md §5 deviation 9, tests/test_hip_fused_step.py);
+    A reset is only postponed while nobody else holds a tensor on the state's storage (`_alias_free`: the storage's use
+    count; the `envs` attribute hands out a tensor object of the caller's own on the same storage and version counter), so an
+    alias the caller keeps — `e = env.envs; env.step(a); env.reset(d); e[...]` — shows the reset state, as the reference's
+    would (round 5; rounds 2-4 documented this as a deviation);
   * the bodies of `step` and of the deferred `reset` are a small state machine, `Stepper`: in C where the extension
     wurm_amd/_fastcall is built (wurm_amd/csrc/fastcall.c), else `PyStepper` below — the same logic, and the
     specification of the C type (tests/test_host_lazy_reset.py drives both through the same call patterns).
@@ -24,7 +25,7 @@ time per call, not by the GPU, so:
     wurm_single_resident_bytes) hand the launch a compact MIRROR of the state (wurm_single_call.resident) which it steps
     instead of re-reading the fp32 tensor every call; the tensor stays the state: reading `env.envs` writes it out (and from
     then on every step writes it), any other entry point goes through `_touch()`, a tensor the caller holds is watched for
-    in-place edits through its version counter (DESIGN.md §4.10, §5 deviation 11).
+    in-place edits through its version counter (DESIGN.md §5, §7 deviation 9).
 
 The host class provides: num_envs, size, device, seed, env_offset, observation_mode, lazy_reset, _CHANNELS,
 _STEP_SLOT (entry point name), _mode_info(mode) -> (mode code, n, obs shape), _lazy_supported(), _launch_reset(envs,

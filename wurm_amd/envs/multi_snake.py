@@ -23,13 +23,13 @@ the RNG counter the eager call would have used — bit-identical results; the st
 looks at the state.  A reset whose observation is asked for (the reference's default) is executed at once the first
 time; from then on the step launch also writes that observation (`obs_after`: the reset is applied to the on-chip copy
 of the env after the step's own observation, with the counter the eager call would use) and `reset` hands it out and
-is deferred like the other form.  As for SingleSnake, a tensor alias taken before the deferred reset is the one thing
-that is not tracked.
+is deferred like the other form.  A reset is only postponed while nobody else holds a tensor on a state tensor's storage
+(`_alias_free`), so an alias the caller keeps shows what the reference's would.
 Large batches (from 2^20 cells: wurm_multi_resident_bytes) hand the step launch a compact MIRROR of foods / heads / bodies
 (wurm_multi_call.resident) which it steps instead of converting the fp32 tensors every call, and ask it for
 check_consistency()'s masks once the caller has used that method; the tensors stay the state — reading one of the three
 attributes writes them out (and from then on every step writes them), every other entry point goes through `_touch()`,
-tensors the caller holds are watched for in-place edits (DESIGN.md §4.10, §5 deviation 11).
+tensors the caller holds are watched for in-place edits (DESIGN.md §5, §7 deviation 9).
 """
 import ctypes
 import os
