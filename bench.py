@@ -560,7 +560,35 @@ def extra_measurements(device):
                 torch.cuda.synchronize()
                 return out[key]
         return run
-    per_call, rollout = guarded(per_call), guarded(rollout)
+    def alloc_spread(key, make_env, shape_actions, A, chunk, n_blocks, what):
+        """The HBM-bound rollouts take 0.37-0.48 ms for the SAME launch depending on the allocation their output lies in
+        (profiles/r04_placement_probe.txt): p10 / p50 / p90 of one launch over `n_blocks` fresh output allocations of this
+        process (earlier outputs are kept alive so that every launch gets a block of its own; each block is written once
+        untimed first)."""
+        _describe(key, what)
+        env = make_env()
+        acts = torch.randint(A, (2,) + shape_actions(chunk), device=device, dtype=torch.int64)
+        held, times = [], []
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for b in range(n_blocks):
+            o = env.rollout(acts[0])
+            del o                       # (the allocator hands the block that was just freed to the next launch)
+            torch.cuda.synchronize()
+            e0.record()
+            o = env.rollout(acts[1])
+            e1.record()
+            torch.cuda.synchronize()
+            times.append(e0.elapsed_time(e1))
+            held.append(o)
+        times.sort()
+        q = lambda f: times[min(len(times) - 1, int(f * len(times)))]   # noqa: E731
+        out[key] = {'value': env.num_envs * chunk / (q(0.5) * 1e-3), 'ms_p10': round(q(0.1), 4), 'ms_p50': round(q(0.5), 4),
+                    'ms_p90': round(q(0.9), 4), 'ms_min': round(times[0], 4), 'ms_max': round(times[-1], 4),
+                    'allocations': n_blocks, 'batch_steps_per_launch': chunk}
+        del held
+        return out[key]
+
+    per_call, rollout, alloc_spread = guarded(per_call), guarded(rollout), guarded(alloc_spread)
 
     out['host_calibration_before'] = host_calibration(device)
     _describe('host_calibration_*', 'host unit costs of this box: a ctypes call, a Python loop iteration, issuing / draining a '
@@ -673,6 +701,9 @@ def extra_measurements(device):
             lambda c: (c, 8192), 4, 16, 6, 'BASELINE configs[4]: SingleSnake 8192x36x36 default-RGB obs, fused rollout, 16 '
             'batch-steps per launch (15 552 B of observation per env-step)', traffic_key='rollout_cfg5_8192x36_default_chunk16')
 
+    alloc_spread('rollout_cfg5_alloc_spread', lambda: SingleSnake(8192, 36, observation_mode='default', device=device, seed=0),
+                 lambda c: (c, 8192), 4, 16, 10, 'BASELINE configs[4], the 16-step launch over 10 fresh output allocations (2 GB each)')
+
     # ---- cfg3 (65 536 x 9 x 9) in the other observation modes (the reference's constructor default is one_channel)
     for mode in ('one_channel', 'default'):
         rollout(f'rollout_65536x9_{mode}', lambda: SingleSnake(65536, SIZE, observation_mode=mode, device=device, seed=0),
@@ -738,6 +769,8 @@ def extra_measurements(device):
     rollout('rollout_cfg3_65536', lambda: SingleSnake(65536, SIZE, observation_mode=OBS_MODE, device=device, seed=0),
             lambda c: (c, 65536), 4, 64, 8, 'BASELINE configs[2] whole (65536 envs) on ONE GPU, fused rollout, 64 batch-steps per launch',
             traffic_key='rollout_65536x9_chunk64')
+    alloc_spread('rollout_cfg3_alloc_spread', lambda: SingleSnake(65536, SIZE, observation_mode=OBS_MODE, device=device, seed=0),
+                 lambda c: (c, 65536), 4, 64, 10, 'BASELINE configs[2] whole on one GPU, the 64-step launch over 10 fresh output allocations')
     N, T = 65536, 200
     acts = torch.randint(4, (T + 10, N), device=device, dtype=torch.int64)
     per_call('per_call_cfg3_no_mirror', lambda: SingleSnake(N, SIZE, observation_mode=OBS_MODE, device=device, seed=0,
@@ -795,6 +828,8 @@ def key_numbers(line):
         'cfg4prime_rollout_eps': g('multi_rollout_cfg4prime_partial5'), 'cfg4prime_rollout_ms': g('multi_rollout_cfg4prime_partial5', 'ms'),
         'cfg4prime_per_call_us': g('per_call_cfg4prime_partial5', 'us'),
         'multi_512x12_k2_per_call_us': g('per_call_multi_512x12_k2', 'us'),
+        'cfg5_rollout_ms_p10_p50_p90': [g('rollout_cfg5_alloc_spread', f) for f in ('ms_p10', 'ms_p50', 'ms_p90')],
+        'cfg3_rollout_ms_p10_p50_p90': [g('rollout_cfg3_alloc_spread', f) for f in ('ms_p10', 'ms_p50', 'ms_p90')],
         'multi_512x25_k4_train_per_call_us': g('per_call_multi_512x25_k4_train_partial5', 'us'),
         'box_hbm_fill_TBps': ex.get('host_calibration_after', {}).get('hbm_fill_2GB_TBps'),
     }

@@ -1972,6 +1972,50 @@ __device__ __forceinline__ bool reroll_colour(const MultiArgs &p, long long agen
     return true;
 }
 
+// The respawn search from the map of cell codes the step left (cell_codes + put_food: Snake::cmap_ok) — any state, any
+// size: a cell is occupied iff its code is neither 0 nor the ring's (what sits ON the ring never matters: a spawn cell is
+// at least 2 from the border, so its 3 x 3 neighbourhood stops at row / column 1).  Ten ballots give the occupancy of the
+// 64-cell chunks, lane r cuts grid row r out of at most two of them, and the rest is the dilation / popcount walk of the
+// rebuild: ~100 instructions for what build_occ + spawn_cells + rank_select read cell by cell — K clock compares and nine
+// byte reads per cell, 5 100 of a step's 30 000 cycles with respawn_mode = 'any' (profiles/r05_kernel_timeline.txt: 2 850 now).
+__device__ __forceinline__ int respawn_cell_codes(const Ctx &cx, const unsigned char *codes, u32 word)
+{
+    const int S = cx.S, C = cx.C, lane = cx.lane;
+    u64 *chunks = (u64 *)cx.occ;   // scratch: cpl <= 64 masks of 64 cells (C bytes, 16-byte aligned; 8 cpl <= C for S >= 5)
+    u64 mine = 0;
+    for (int k = 0; k < cx.cpl; ++k) {
+        const int c = lane + 64 * k;
+        const int code = c < C ? (int)codes[c] : PC_BG;
+        const u64 m = ballot(code != PC_BG && code != PC_RING);
+        if (lane == k) mine = m;
+    }
+    if (lane < cx.cpl) chunks[lane] = mine;
+    wave_lds_sync();
+    u64 occ_row = 0;
+    if (lane < S) { // grid row `lane`: bits lane * S .. lane * S + S - 1 of the linear occupancy
+        const int b = lane * S, q = b >> 6, off = b & 63;
+        const u64 lo = chunks[q], hi = (q + 1 < cx.cpl) ? chunks[q + 1] : 0ull;
+        occ_row = (lo >> off) | (off ? hi << (64 - off) : 0ull);
+        if (S < 64) occ_row &= (1ull << S) - 1ull;
+    }
+    wave_lds_sync();
+    // available (:848-858): at least 2 from the border, nothing in the 3 x 3 neighbourhood
+    const u64 h = occ_row | (occ_row << 1) | (occ_row >> 1);
+    const u64 up = lane == 0 ? 0ull : (u64)__shfl_up((long long)h, 1);
+    const u64 dn = lane == 63 ? 0ull : (u64)__shfl_down((long long)h, 1);
+    const u64 cols = S >= 5 ? (((1ull << (S - 4)) - 1ull) << 2) : 0ull;
+    const u64 av = (lane >= 2 && lane <= S - 3) ? (~(h | up | dn) & cols) : 0ull;
+    const int cnt = popc64(av), n = wave_sum_i32(cnt);
+    if (n == 0) return -1;
+    int kth = (int)mulhi_range(word, (u32)n), r = 0;
+    for (; r < S - 1; ++r) { // the K-th available cell in row-major order
+        const int c = lane_value(cnt, r);
+        if (kth < c) break;
+        kth -= c;
+    }
+    return r * S + nth_bit64((u64)lane_value64((long long)av, r), kth);
+}
+
 // the grid part of MultiSnake.reset on the env held in LDS: _create_envs (:996-1019) when `rebuild`, then the
 // respawn of the first dead snake (:805-831) when `respawn`.  sn.done must already be false for rebuilt envs (:798).
 __device__ __forceinline__ void multi_reset_grid(const Ctx &cx, const MultiArgs &p, long long env, u64 env_id, u64 call,
@@ -1980,7 +2024,8 @@ __device__ __forceinline__ void multi_reset_grid(const Ctx &cx, const MultiArgs 
 {
     const int C = cx.C, K = cx.K, lane = cx.lane;
     const bool snake = lane < K;
-    sn.cmap_ok = false; // (the map of cell codes describes the state before this reset)
+    const bool had_map = sn.cmap_ok && !rebuild; // the step's map of cell codes still describes the grids the respawn looks at
+    sn.cmap_ok = false; // (... but not the state this reset leaves)
     if (rebuild) { // _create_envs (:996-1019)
         { // value 0; a cell that ever held one stays marked.  Four cells per access: the grids start on a 16-byte
           // boundary and are followed by padding up to the next one, so the last access may run into the padding.
@@ -2082,7 +2127,9 @@ __device__ __forceinline__ void multi_reset_grid(const Ctx &cx, const MultiArgs 
         } else {
             Words w = rng_words(p.seed, call, env_id, RNG_SPAWN, (u32)K);
             dnew = (int)(w.w[1] >> 30);
-            if ((C & 7) == 0) {
+            if (had_map) {
+                cell = respawn_cell_codes(cx, cx.hmap, w.w[0]);
+            } else if ((C & 7) == 0) {
                 cell = respawn_cell_rows(cx, sn.hc, w.w[0]);
             } else {
                 build_occ(cx, sn.hc);
