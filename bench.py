@@ -705,7 +705,7 @@ def extra_measurements(device):
                  lambda c: (c, 8192), 4, 16, 10, 'BASELINE configs[4], the 16-step launch over 10 fresh output allocations (2 GB each)')
 
     # ---- cfg3 (65 536 x 9 x 9) in the other observation modes (the reference's constructor default is one_channel)
-    for mode in ('one_channel', 'default'):
+    for mode in ('one_channel', 'default', 'raw', 'partial_3'):
         rollout(f'rollout_65536x9_{mode}', lambda: SingleSnake(65536, SIZE, observation_mode=mode, device=device, seed=0),
                 lambda c: (c, 65536), 4, 32, 6, f'SingleSnake 65 536 x 9 x 9 with observation_mode={mode!r}, fused rollout, 32 '
                 'batch-steps per launch', traffic_key=f'rollout_65536x9_{mode}_chunk32')
@@ -771,6 +771,12 @@ def extra_measurements(device):
             traffic_key='rollout_65536x9_chunk64')
     alloc_spread('rollout_cfg3_alloc_spread', lambda: SingleSnake(65536, SIZE, observation_mode=OBS_MODE, device=device, seed=0),
                  lambda c: (c, 65536), 4, 64, 10, 'BASELINE configs[2] whole on one GPU, the 64-step launch over 10 fresh output allocations')
+    for mode, steps in (('default', 16), ('raw', 16), ('positions', 64)):
+        rollout(f'rollout_65536x9_gridworld_{mode}',
+                lambda: SimpleGridworld(65536, 9, start_location=(4, 4), observation_mode=mode, device=device, seed=0),
+                lambda c: (c, 65536), 4, steps, 8, f'SimpleGridworld 65 536 x 9 x 9, observation_mode={mode!r}, fused rollout of '
+                f'{steps} batch-steps per launch (one env per lane, gridworld_lane.hip)',
+                traffic_key=f'rollout_65536x9_gridworld_{mode}_chunk16')
     N, T = 65536, 200
     acts = torch.randint(4, (T + 10, N), device=device, dtype=torch.int64)
     per_call('per_call_cfg3_no_mirror', lambda: SingleSnake(N, SIZE, observation_mode=OBS_MODE, device=device, seed=0,
@@ -818,6 +824,9 @@ def key_numbers(line):
         'cfg4_rollout_eps': g('multi_rollout_cfg4_full'), 'cfg4_per_call_us': g('per_call_cfg4', 'us'),
         'cfg5_rollout_ms': g('rollout_cfg5_8192x36_default', 'ms'),
         'cfg5_rollout_frac_real': g('rollout_cfg5_8192x36_default', 'frac_real'), 'cfg5_per_call_us': g('per_call_cfg5_8192x36_default', 'us'),
+        'gridworld_65536_default_eps': g('rollout_65536x9_gridworld_default'), 'gridworld_65536_default_ms': g('rollout_65536x9_gridworld_default', 'ms'),
+        'gridworld_65536_default_frac_real': g('rollout_65536x9_gridworld_default', 'frac_real'),
+        'cfg3_raw_eps': g('rollout_65536x9_raw'), 'cfg3_partial3_eps': g('rollout_65536x9_partial_3'),
         'cfg1_per_call_us': g('per_call_cfg1_gridworld_64x9', 'us'), 'cfg1_machine': g('per_call_cfg1_gridworld_64x9', 'machine'),
         'per_call_512_us': g('per_call_512', 'us'), 'per_call_512_eps': g('per_call_512'),
         'per_call_512_launches': g('per_call_512', 'launches_per_iter'),

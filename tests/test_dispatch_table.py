@@ -124,12 +124,23 @@ def test_reset_and_observe_are_generic(hip):
     assert _route() == 'generic'
 
 
-def test_gridworld_is_generic(hip):
+def test_gridworld_calls_are_generic_and_large_rollouts_take_the_lane_row(hip):
+    from wurm_amd._lib import knobs
     h = hip(seed=1)
     envs = np.zeros((16, 2, 9, 9), np.float32)
     h.grid_reset(envs, np.ones(16, np.uint8), (4, 4), 'default')
     h.grid_step(envs, np.zeros(16, np.int64), 'default')
     assert _route() == 'generic'
+    for mode, min_envs, row in [('default', 0, 'gridworld_lane'), ('raw', 0, 'gridworld_lane'),
+                                ('positions', 0, 'gridworld_lane'), ('none', 0, 'gridworld_lane'),
+                                ('default', 17, 'generic'), ('default', 16, 'gridworld_lane')]:
+        with knobs(WURM_LANE_ROLLOUT_MIN_ENVS=min_envs):
+            h.grid_rollout(envs, np.zeros((3, 16), np.int64), (4, 4), mode)
+            assert _route() == row, (mode, min_envs)
+    with knobs(WURM_LANE_ROLLOUT_MIN_ENVS=0):  # recorded outcomes: the one-env-per-wave kernel consumes them
+        h.grid_rollout(envs, np.zeros((3, 16), np.int64), (4, 4), 'default', inject_food=np.zeros((3, 16), np.int32),
+                       inject_reset=np.zeros((3, 16), np.int32))
+        assert _route() == 'generic'
 
 
 def test_defaults_of_the_thresholds():

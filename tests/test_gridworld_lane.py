@@ -1,0 +1,173 @@
+"""SimpleGridworld rollouts of large batches: one env per lane (wurm_amd/csrc/gridworld_lane.hip) against the oracle, which
+follows /root/reference wurm/envs/simple_gridworld.py:135-202 (step), :111-133 (_observe), :225-268 (reset).  The route
+is forced with WURM_LANE_ROLLOUT_MIN_ENVS = 0 (it takes over from 6144 envs by default) and checked with
+wurm_single_last_route().  Bit-exact: bytes, indices and floats that are 0.0 or 1.0."""
+import numpy as np
+import pytest
+
+from tests.backends import OracleBackend
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def hip():
+    from tests.hip_backend import HipBackend
+    return HipBackend
+
+
+def _route():
+    from wurm_amd import _lib
+    return _lib.lib().wurm_single_last_route().decode()
+
+
+def _same(a, b, what):
+    if a is None:
+        assert b is None, what
+        return
+    a, b = np.asarray(a), np.asarray(b)
+    assert a.shape == b.shape and a.dtype == b.dtype, what
+    if a.dtype == np.float32:
+        a, b = a.view(np.uint32), b.view(np.uint32)
+    if not np.array_equal(a, b):
+        bad = np.argwhere(a != b)
+        raise AssertionError(f'{what}: {len(bad)} elements differ, first at {bad[0].tolist()}: oracle {a[tuple(bad[0])]} '
+                             f'hip {b[tuple(bad[0])]}; envs {sorted(set(bad[:, 1].tolist()))[:10] if bad.shape[1] > 1 else ""}')
+
+
+def _fresh(o, N, S, start):
+    envs = np.zeros((N, 2, S, S), np.float32)
+    o.grid_reset(envs, np.ones(N, np.uint8), start, 'none')
+    return envs
+
+
+def _both(hip, envs, actions, start, mode, seed=8, call=40, offset=0, min_envs=0, row='gridworld_lane'):
+    from wurm_amd._lib import knobs
+    o, h = OracleBackend(seed=seed), hip(seed=seed)
+    o.call = h.call = call
+    o.env_offset = h.env_offset = offset
+    eo, eh, ao, ah = envs.copy(), envs.copy(), actions.copy(), actions.copy()
+    with knobs(WURM_LANE_ROLLOUT_MIN_ENVS=min_envs):
+        rh = h.grid_rollout(eh, ah, start, mode)
+        assert _route() == row
+    ro = o.grid_rollout(eo, ao, start, mode)
+    for k in ro:
+        _same(ro[k], rh[k], k)
+    _same(eo, eh, 'final state')
+    _same(ao, ah, 'actions')
+    return ro
+
+
+@pytest.mark.parametrize('mode', ['default', 'raw', 'positions', 'none'])
+@pytest.mark.parametrize('N,S,T', [(64, 9, 40), (131, 9, 33), (70, 5, 25), (257, 7, 20), (33, 12, 30), (3, 30, 50),
+                                   (65, 5, 9)])
+def test_lane_rollout_matches_the_oracle(hip, N, S, T, mode):
+    """ragged and odd batches (an odd N puts every second step's observation block off the 16-byte boundary), sizes from
+    the smallest the reference resets (5, simple_gridworld.py:249-250) to 30"""
+    rng = np.random.RandomState(N * 31 + S)
+    start = (S // 2, S // 2)
+    o = OracleBackend(seed=8)
+    envs = _fresh(o, N, S, start)
+    actions = rng.randint(0, 4, size=(T, N)).astype(np.int64)
+    ro = _both(hip, envs, actions, start, mode)
+    assert ro['done'].sum() > 0 or S > 12
+
+
+@pytest.mark.parametrize('dtype', [np.int32, np.int64])
+def test_action_dtypes_and_negative_actions(hip, dtype):
+    """actions outside 0..3 wrap like the reference's `actions % 4` on the tensor would — the C-ABI takes them as they
+    come (oracle/single_snake.c load_action)"""
+    rng = np.random.RandomState(5)
+    N, S, T = 100, 9, 24
+    envs = _fresh(OracleBackend(seed=8), N, S, (4, 4))
+    actions = rng.randint(0, 4, size=(T, N)).astype(dtype)
+    _both(hip, envs, actions, (4, 4), 'default')
+
+
+def test_start_location_off_centre_and_on_the_border(hip):
+    rng = np.random.RandomState(6)
+    N, S, T = 96, 9, 30
+    for start in [(1, 7), (6, 2)]:
+        envs = _fresh(OracleBackend(seed=8), N, S, start)
+        actions = rng.randint(0, 4, size=(T, N)).astype(np.int64)
+        _both(hip, envs, actions, start, 'default', seed=11, call=6)
+
+
+def test_env_offset_and_call_counter_enter_the_draws(hip):
+    rng = np.random.RandomState(7)
+    N, S, T = 80, 9, 30
+    envs = _fresh(OracleBackend(seed=8), N, S, (4, 4))
+    actions = rng.randint(0, 4, size=(T, N)).astype(np.int64)
+    a = _both(hip, envs, actions, (4, 4), 'raw', seed=3, call=2 ** 33 + 5, offset=10 ** 7)
+    b = _both(hip, envs, actions, (4, 4), 'raw', seed=3, call=2 ** 33 + 7, offset=10 ** 7)
+    assert not np.array_equal(a['obs'], b['obs'])
+
+
+@pytest.mark.parametrize('mode', ['default', 'raw', 'positions'])
+def test_hand_made_envs_fall_back_to_the_generic_kernel(hip, mode):
+    """envs outside the lane kernel's domain (two foods, no agent, other values, food under the agent) are rolled out by
+    the one-env-per-wave kernel in a second launch; their neighbours in the same wave are not disturbed.  (Two agents in
+    one env or a food of another value than 1 are outside the library's domain altogether: DESIGN.md, deviation 7.)"""
+    rng = np.random.RandomState(9)
+    N, S, T = 150, 9, 20
+    envs = _fresh(OracleBackend(seed=8), N, S, (4, 4))
+    envs[10, 0, 6, 6] = 1         # a second food (unless it was there)
+    envs[64, 1] = 0               # no agent
+    envs[65, 0] = 0               # no food: inside the domain
+    envs[130, 1] *= 0.5           # an agent of value 0.5
+    envs[140, 0] = envs[140, 1]   # the food under the agent
+    envs[149, 0, 0, 3] = 1        # a food on the border ring as well
+    envs[20, 0] = 0
+    envs[20, 0, 3, 4] = 1         # the only food right above the agent, and (in the domain)
+    envs[21, 0] = 0
+    envs[21, 0, 0, 4] = 1         # the only food on the border ring (in the domain: invisible in 'default', eaten while dying)
+    envs[21, 1] = 0
+    envs[21, 1, 1, 4] = 1
+    envs[30, 1] = 0
+    envs[30, 1, 0, 0] = 1         # the agent in a corner (in the domain)
+    actions = rng.randint(0, 4, size=(T, N)).astype(np.int64)
+    _both(hip, envs, actions, (4, 4), mode)
+    for a in range(4):
+        actions[0, 20:22] = a
+        _both(hip, envs, actions, (4, 4), mode)
+
+
+def test_rollout_equals_the_loop(hip):
+    """T fused iterations == T x (step; reset(done)) through the per-call entry points (which stay one env per wave)"""
+    rng = np.random.RandomState(12)
+    N, S, T, start = 90, 9, 25, (4, 4)
+    from wurm_amd._lib import knobs
+    h1, h2 = hip(seed=4), hip(seed=4)
+    envs = _fresh(OracleBackend(seed=4), N, S, start)
+    actions = rng.randint(0, 4, size=(T, N)).astype(np.int64)
+    e1, e2 = envs.copy(), envs.copy()
+    h1.call = h2.call = 10
+    with knobs(WURM_LANE_ROLLOUT_MIN_ENVS=0):
+        r = h1.grid_rollout(e1, actions.copy(), start, 'default')
+        assert _route() == 'gridworld_lane'
+    for t in range(T):
+        obs, rew, done, ec = h2.grid_step(e2, actions[t].copy(), 'default')
+        _same(r['obs'][t], obs, f'obs {t}')
+        _same(r['reward'][t], rew, f'reward {t}')
+        _same(r['done'][t], done, f'done {t}')
+        h2.grid_reset(e2, done, start, 'none')
+    _same(e1, e2, 'final state')
+
+
+def test_below_the_threshold_and_recorded_outcomes_stay_generic(hip):
+    rng = np.random.RandomState(13)
+    N, S, T = 70, 9, 10
+    envs = _fresh(OracleBackend(seed=8), N, S, (4, 4))
+    actions = rng.randint(0, 4, size=(T, N)).astype(np.int64)
+    _both(hip, envs, actions, (4, 4), 'default', min_envs=1 << 40, row='generic')
+
+
+def test_a_large_batch_at_the_default_threshold(hip):
+    """65536 x 9 x 9, the driver's `rollout_65536x9_gridworld_default` shape, with the knobs at their defaults"""
+    rng = np.random.RandomState(14)
+    N, S, T = 65536, 9, 8
+    envs = _fresh(OracleBackend(seed=8), N, S, (4, 4))
+    actions = rng.randint(0, 4, size=(T, N)).astype(np.int64)
+    from wurm_amd import _lib
+    assert _lib.lib().wurm_get_option(b'WURM_LANE_ROLLOUT_MIN_ENVS') <= N
+    _both(hip, envs, actions, (4, 4), 'default', min_envs=_lib.lib().wurm_get_option(b'WURM_LANE_ROLLOUT_MIN_ENVS'))

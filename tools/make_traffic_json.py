@@ -62,15 +62,18 @@ detail = {
     'rollout_cfg5_8192x36_default_chunk16': traffic('void wurm::(anonymous namespace)::grid_rollout_kernel<true>', 524288),
     # round 4: G envs per workgroup (multi_rollout_group_kernel): cfg4 512 workgroups of 8 steppers + 4 writers, the speeds.py
     # shape 1024 workgroups of 4 + 10
-    'multi_rollout_cfg4_4096x25_k4_full_chunk16': traffic('void wurm::multi_rollout_group_kernel<8, 2, 1, 5, false>', 327680) or
-                                                  traffic('void wurm::multi_rollout_group_kernel<8, 4, 1, 6, false>', 393216),
-    'multi_rollout_speeds_4096x36_k10_chunk4': traffic('void wurm::multi_rollout_group_kernel<4, 10, 1, 4, true>', 917504),
+    'multi_rollout_cfg4_4096x25_k4_full_chunk16': traffic('void wurm::multi_rollout_group_kernel<8, 2, 1, 5, false, false>', 327680) or
+                                                  traffic('void wurm::multi_rollout_group_kernel<8, 4, 1, 6, false, false>', 393216),
+    'multi_rollout_speeds_4096x36_k10_chunk4': traffic('void wurm::multi_rollout_group_kernel<4, 10, 1, 4, true, false>', 917504),
     # round 4: one_channel / default of 65 536 x 9 x 9 through the lane kernels (bit planes): rollout, and per call (reference form)
     'rollout_65536x9_one_channel_chunk32': traffic('void wurm::lane_rollout_kernel<32, -2, false>', 131072),
     'rollout_65536x9_default_chunk32': traffic('void wurm::lane_rollout_kernel<32, -3, false>', 131072),
     'resident_step_65536x9_one_channel_reset_obs': traffic('void wurm::lane_resident_step_kernel<32, 2, -2, true>', 131072),
     'resident_step_65536x9_default_reset_obs': traffic('void wurm::lane_resident_step_kernel<32, 2, -3, true>', 131072),
-    'multi_rollout_cfg4prime_4096x25_k4_partial5_chunk16': traffic('void wurm::multi_rollout_kernel<false>', 262144),
+    # round 5: SimpleGridworld one env per lane (16 envs per wave at this batch size): zero fill + two floats per env
+    'rollout_65536x9_gridworld_default_chunk16': traffic('void wurm::(anonymous namespace)::gridworld_lane_rollout_kernel<0, 16>', 262144),
+    'rollout_65536x9_gridworld_raw_chunk16': traffic('void wurm::(anonymous namespace)::gridworld_lane_rollout_kernel<1, 16>', 262144),
+    'multi_rollout_cfg4prime_4096x25_k4_partial5_chunk16': traffic('void wurm::multi_rollout_kernel<false, false, 4>', 262144),
     'fused_step_512x9_partial2': traffic('void wurm::fused_step_kernel<2, true>', 32768),
     'fused_step_8192x9_partial2': traffic('void wurm::fused_step_kernel<2, true>', 524288),
     'fused_step_65536x9_partial2': traffic('void wurm::fused_step_kernel<2, true>', 4194304),
@@ -79,12 +82,13 @@ detail = {
     'resident_step_8192x9_partial2': traffic('void wurm::lane_resident_step_kernel<16, 1, 4, true>', 32768),
     'resident_step_65536x9_partial2': traffic('void wurm::lane_resident_step_kernel<32, 1, 4, true>', 131072),
     'resident_step_65536x9_partial2_reset_obs': traffic('void wurm::lane_resident_step_kernel<32, 2, 4, true>', 131072),
-    # dispatch order of multi_step_kernel at this grid: 20 launches of cfg4', 20 of cfg4 (both on the resident mirror, lazy),
-    # 20 of cfg4 with the mirror switched off; the second ten of each
-    'multi_step_cfg4_4096x25_k4_full': traffic('wurm::multi_step_kernel', 262144, (3, 6)),
-    'multi_step_cfg4_4096x25_k4_full_no_mirror': traffic('wurm::multi_step_kernel', 262144, (5, 6)),
-    'per_call_api_cfg4prime_4096x25_k4_partial5': traffic('wurm::multi_step_kernel', 262144, (1, 6)),
-    'per_call_api_speeds_4096x36_k10': traffic('wurm::multi_step_wg_kernel', 1048576),
+    # multi_step_kernel<INJ, OBS> (round 5: one instantiation per observation family).  Dispatch order of <false, 0> ('full')
+    # at this grid: 20 launches of cfg4 on the resident mirror (lazy), 20 with the mirror switched off; the second ten of
+    # each.  <false, 4> (partial_n): the 20 launches of cfg4', the second ten
+    'multi_step_cfg4_4096x25_k4_full': traffic('void wurm::multi_step_kernel<false, 0>', 262144, (1, 4)),
+    'multi_step_cfg4_4096x25_k4_full_no_mirror': traffic('void wurm::multi_step_kernel<false, 0>', 262144, (3, 4)),
+    'per_call_api_cfg4prime_4096x25_k4_partial5': traffic('void wurm::multi_step_kernel<false, 4>', 262144, (1, 2)),
+    'per_call_api_speeds_4096x36_k10': traffic('void wurm::multi_step_wg_kernel<false>', 1048576) or traffic('wurm::multi_step_wg_kernel', 1048576),
     # dispatch order: 30 launches on the resident mirror (lazy: the fp32 state is neither read nor written), then 30 without
     'grid_step_8192x36_default': traffic('void wurm::(anonymous namespace)::grid_step_kernel<true>', 524288, (0, 2)),
     'grid_step_8192x36_default_no_mirror': traffic('void wurm::(anonymous namespace)::grid_step_kernel<true>', 524288, (1, 2)),

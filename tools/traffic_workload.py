@@ -120,4 +120,13 @@ for mirror in (True, False):
         env.reset(d['__all__'], return_observations=False)
     torch.cuda.synchronize()
 _lib.set_option('WURM_RESIDENT_MIN_ENVS', None)
+# measured (round 5): SimpleGridworld 65 536 x 9 x 9 through the one-env-per-lane rollout (gridworld_lane.hip), 16 steps per launch
+from wurm_amd.envs import SimpleGridworld  # noqa: E402
+for mode in ('default', 'raw'):
+    env = SimpleGridworld(65536, 9, start_location=(4, 4), observation_mode=mode, device=dev, seed=0)
+    actions = torch.randint(4, (16 * 5, 65536), device=dev, dtype=torch.int64)
+    for c in range(0, 16 * 5, 16):
+        env.rollout(actions[c:c + 16])
+    torch.cuda.synchronize()
+    del env, actions
 print('traffic workload done')

