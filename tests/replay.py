@@ -70,6 +70,26 @@ def replay_single_rollout(backend, fx):
     _eq(envs, fx['state_reset'][-1].astype(np.float32), 'final state', T - 1)
 
 
+def replay_single_rollout_vs_oracle(backend, oracle, fx, mode):
+    """The tape's recorded random outcomes injected through the fused entry point in ANOTHER observation mode than the one
+    the reference was recorded in: everything but the observation is still checked against the reference's record, the
+    observation against the oracle driven by the same injection."""
+    N, S, T = (int(v) for v in fx['meta'][:3])
+    assert int(fx['meta'][4]) == 1
+    envs, envs_o = fx['state0'].astype(np.float32), fx['state0'].astype(np.float32)
+    actions, actions_o = fx['actions_in'].copy(), fx['actions_in'].copy()
+    out = backend.single_rollout(envs, actions, mode, inject_food=fx['inject_food'], inject_reset=fx['inject_reset'])
+    want = oracle.single_rollout(envs_o, actions_o, mode, inject_food=fx['inject_food'], inject_reset=fx['inject_reset'])
+    _eq(actions, fx['actions_out'], 'sanitised actions', 'all')
+    _eq(out['reward'], fx['reward'], 'reward', 'all')
+    _eq(out['done'], fx['done'], 'done', 'all')
+    _eq(out['self_collision'], fx['self_collision'], 'self_collision', 'all')
+    _eq(out['edge_collision'], fx['edge_collision'], 'edge_collision', 'all')
+    _eq(envs, fx['state_reset'][-1].astype(np.float32), 'final state', T - 1)
+    _eq(out['obs'], want['obs'], f'step observations ({mode}) against the oracle', 'all')
+    _eq(envs, envs_o, 'final state against the oracle', T - 1)
+
+
 def replay_grid(backend, fx):
     mode = str(fx['mode'])
     N, S, T = (int(v) for v in fx['meta'][:3])

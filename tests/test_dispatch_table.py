@@ -36,8 +36,11 @@ ROLLOUT_ROWS = [
     (9, 70, 'positions', 0, 'lane_rollout'),
     (9, 70, 'partial_2', 1 << 40, 'rollout_s9'),
     (9, 70, 'none', 1 << 40, 'rollout_s9'),
-    (9, 70, 'partial_3', 0, 'rollout_s9'),              # 7 x 7 crops are outside the lane kernel's domain
-    (9, 70, 'raw', 0, 'generic'),
+    (9, 70, 'partial_3', 0, 'lane_rollout'),            # (round 5: 7 x 7 crops through bit planes)
+    (9, 70, 'raw', 0, 'lane_rollout'),                  # (round 5: the state itself through a byte slab)
+    (9, 70, 'partial_3', 1 << 40, 'rollout_s9'),
+    (9, 70, 'raw', 1 << 40, 'generic'),
+    (9, 70, 'partial_4', 0, 'rollout_generic_partial'), # 9 x 9 crops are outside the lane kernel's domain
     (9, 70, 'one_channel', 1 << 40, 'generic'),
     (9, 70, 'partial_4', 1 << 40, 'rollout_generic_partial'),
     (10, 70, 'partial_2', 0, 'rollout_lean'),

@@ -259,10 +259,11 @@ def test_bench_shape_8192x128(hip):
 
 # ---- round 4: every other observation mode through the lane kernel (lr_write_generic)
 GENERIC_MODES = ['one_channel', 'default', 'positions', 'partial_0', 'partial_1',
-                 'partial_3']   # (7 x 7 crops are routed to the one-env-per-wave kernels: still one launch, same results)
+                 'partial_3', 'raw',   # (round 5: 7 x 7 crops through bit planes, 'raw' through a byte slab)
+                 'partial_4']          # (9 x 9 crops are routed to the one-env-per-wave kernels: still one launch, same results)
 
 
-@pytest.mark.parametrize('epw', [4, 16, 64])
+@pytest.mark.parametrize('epw', [4, 8, 16, 32, 64])
 @pytest.mark.parametrize('mode', GENERIC_MODES)
 def test_other_observation_modes_every_envs_per_wave(hip, epw, mode):
     """'one_channel' is the reference's constructor default (single_snake.py:55-65); ragged batch, resets, food respawn"""
@@ -279,7 +280,7 @@ def test_other_observation_modes_every_envs_per_wave(hip, epw, mode):
     assert out['done'].sum() > N and out['reward'].sum() > 0
 
 
-@pytest.mark.parametrize('mode', ['one_channel', 'default', 'partial_3'])
+@pytest.mark.parametrize('mode', ['one_channel', 'default', 'partial_3', 'raw'])
 def test_other_modes_start_states_outside_the_domain(hip, mode):
     """envs the lane kernel hands to the one-env-per-wave code inside the launch (head on the ring, no head, two foods),
     mixed with ordinary ones: the generic writer must leave their observations to that code"""
@@ -303,7 +304,7 @@ def test_other_modes_start_states_outside_the_domain(hip, mode):
         _compare_rollout(o, h, envs, rng.randint(0, 4, size=(T, N)).astype(np.int64), mode, check=False)
 
 
-@pytest.mark.parametrize('mode', ['one_channel', 'default'])
+@pytest.mark.parametrize('mode', ['one_channel', 'default', 'partial_3', 'raw'])
 def test_other_modes_large_batch_default_routing(hip, mode):
     N, T = 6144 + 37, 40
     rng = np.random.RandomState(N)
@@ -313,11 +314,80 @@ def test_other_modes_large_batch_default_routing(hip, mode):
     _compare_rollout(o, h, envs, rng.randint(0, 4, size=(T, N)).astype(np.int64), mode)
 
 
-def test_raw_stays_with_the_one_env_per_wave_kernel(hip):
-    N, T = 40, 50
-    rng = np.random.RandomState(1)
-    o, h = OracleBackend(seed=2), hip(seed=2)
+@pytest.mark.parametrize('epw', [4, 32, 64])
+@pytest.mark.parametrize('mode', ['raw', 'partial_3'])
+def test_long_snakes_in_the_round_5_modes(hip, epw, mode):
+    """the serpentine sweep of test_long_snakes_and_food_respawn: long bodies ('raw' shows every body VALUE: the walk down
+    the move queue), self collisions ('raw' shows the SUM of the new head and the segment it ran into,
+    single_snake.py:258-262), heads on the ring (7 x 7 windows that reach three cells past the grid)"""
+    N, T = 70, 600
+    o, h = OracleBackend(seed=11), hip(seed=11)
     envs = _fresh(o, N)
+    tape = []
+    for t in range(T):
+        phase = t % 12
+        tape.append(3 if phase < 5 else 0 if phase == 5 else 1 if phase < 11 else 0)
+    actions = np.repeat(np.asarray(tape, np.int64)[:, None], N, axis=1)
+    rng = np.random.RandomState(2)
+    noise = rng.rand(T, N) < 0.12
+    actions[noise] = rng.randint(0, 4, size=int(noise.sum()))
     o.call = h.call = 1
+    with lane_path(epw):
+        out = _compare_rollout(o, h, envs, actions, mode)
+        assert _route() == 'lane_rollout'
+    assert out['reward'].sum() > 3 * N and out['self_collision'].sum() > 0 and out['edge_collision'].sum() > 0
+    if mode == 'raw':
+        assert out['obs'][:, :, 2].max() >= 8        # bodies of 8 and more segments were observed
+
+
+@pytest.mark.parametrize('mode', ['raw', 'partial_3'])
+def test_snake_longer_than_32_segments_in_the_round_5_modes(hip, mode):
+    N, T, S = 8, 60, 9
+    o, h = OracleBackend(seed=4), hip(seed=4)
+    envs = _fresh(o, N)
+    path = []
+    for r in range(1, 8):
+        cols = range(1, 8) if r % 2 == 1 else range(7, 0, -1)
+        path += [(r, c) for c in cols]
+    for i, L in enumerate([40, 33, 17, 48]):
+        e = np.zeros((3, S, S), np.float32)
+        for v, (y, x) in enumerate(path[:L], start=1):
+            e[2, y, x] = v
+        hy, hx = path[L - 1]
+        e[1, hy, hx] = 1
+        fy, fx = path[L]
+        e[0, fy, fx] = 1
+        envs[i] = e
+    rng = np.random.RandomState(9)
+    o.call = h.call = 3
     with lane_path(8):
-        _compare_rollout(o, h, envs, rng.randint(0, 4, size=(T, N)).astype(np.int64), 'raw')
+        _compare_rollout(o, h, envs, rng.randint(0, 4, size=(T, N)).astype(np.int64), mode)
+        assert _route() == 'lane_rollout'
+
+
+@pytest.mark.parametrize('epw,T', [(64, 1), (64, 17), (8, 7), (8, 9), (16, 130), (32, 3)])
+@pytest.mark.parametrize('mode', ['raw', 'partial_3'])
+def test_round_5_modes_tape_lengths_around_the_chunk(hip, mode, epw, T):
+    N = 2 * epw + 5
+    rng = np.random.RandomState(T + epw)
+    o, h = OracleBackend(seed=6), hip(seed=6)
+    envs = _fresh(o, N)
+    o.call = h.call = 9
+    with lane_path(epw):
+        _compare_rollout(o, h, envs, rng.randint(-3, 9, size=(T, N)).astype(np.int64), mode)
+
+
+def test_reference_tape_injected_through_the_round_5_modes(hip):
+    """the recorded reference tapes whose observation mode is 'raw' or 'partial_3' (tests/golden), injected through
+    lane_rollout_kernel<16, ., INJ>; where the fixtures hold neither mode, the 'partial_2' tape's random outcomes drive the
+    same launch in those modes and the oracle (injected alike) is the checker"""
+    tape = replay.load('single_s9_partial2')
+    with lane_path():
+        for mode in ('raw', 'partial_3'):
+            replay.replay_single_rollout_vs_oracle(hip(), OracleBackend(), tape, mode)
+            assert _route() == 'lane_rollout'
+
+
+def _route():
+    from wurm_amd import _lib
+    return _lib.lib().wurm_single_last_route().decode()

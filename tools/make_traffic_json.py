@@ -70,6 +70,8 @@ detail = {
     'rollout_65536x9_default_chunk32': traffic('void wurm::lane_rollout_kernel<32, -3, false>', 131072),
     'resident_step_65536x9_one_channel_reset_obs': traffic('void wurm::lane_resident_step_kernel<32, 2, -2, true>', 131072),
     'resident_step_65536x9_default_reset_obs': traffic('void wurm::lane_resident_step_kernel<32, 2, -3, true>', 131072),
+    'rollout_65536x9_raw_chunk32': traffic('void wurm::lane_rollout_kernel<32, -5, false>', 131072),
+    'rollout_65536x9_partial_3_chunk32': traffic('void wurm::lane_rollout_kernel<32, -4, false>', 131072),
     # round 5: SimpleGridworld one env per lane (16 envs per wave at this batch size): zero fill + two floats per env
     'rollout_65536x9_gridworld_default_chunk16': traffic('void wurm::(anonymous namespace)::gridworld_lane_rollout_kernel<0, 16>', 262144),
     'rollout_65536x9_gridworld_raw_chunk16': traffic('void wurm::(anonymous namespace)::gridworld_lane_rollout_kernel<1, 16>', 262144),

@@ -120,6 +120,14 @@ for mirror in (True, False):
         env.reset(d['__all__'], return_observations=False)
     torch.cuda.synchronize()
 _lib.set_option('WURM_RESIDENT_MIN_ENVS', None)
+# measured (round 5): 'raw' and 'partial_3' of 65 536 x 9 x 9 through the lane kernel (byte slab / 7 x 7 bit planes), 32 steps per launch
+for mode in ('raw', 'partial_3'):
+    env = SingleSnake(num_envs=65536, size=9, observation_mode=mode, device=dev, seed=0)
+    actions = torch.randint(4, (32 * 5, 65536), device=dev, dtype=torch.int64)
+    for c in range(0, 32 * 5, 32):
+        env.rollout(actions[c:c + 32])
+    torch.cuda.synchronize()
+    del env, actions
 # measured (round 5): SimpleGridworld 65 536 x 9 x 9 through the one-env-per-lane rollout (gridworld_lane.hip), 16 steps per launch
 from wurm_amd.envs import SimpleGridworld  # noqa: E402
 for mode in ('default', 'raw'):

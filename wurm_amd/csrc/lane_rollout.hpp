@@ -85,9 +85,11 @@ constexpr u64 LR_INTERIOR = ~LR_RING;          // codes 8 r + c, r, c in 1..7
 // out: x, y = occupancy of the stepped state, z = head code before the move | sanitised action << 8,
 //      w = food code + 1 | ate << 8 | self collision << 9 | edge collision << 10 | valid << 15
 // RESET = false: the step alone (the per-call kernel of lane_resident.hpp rebuilds finished envs in the NEXT launch)
-template <bool INJ, bool RESET = true>
+// RAWB: the stepped (pre-reset) state also as one byte per float of the 'raw' observation (food, head, body VALUES: 243
+// bytes at `raw`, zeroed by the caller)
+template <bool INJ, bool RESET = true, bool RAWB = false>
 __device__ __forceinline__ uint4 lr_transition(u64 &occ, u32 &q0, u32 &q1, u32 &q2, int &c, int &tc, int &L, int &o, int &food,
-                                               const bool act, const uint4 &cur)
+                                               const bool act, const uint4 &cur, unsigned char *raw = nullptr)
 {
     u32 rz = 0, rw = 0;
     u64 occ_rec = 0;
@@ -122,6 +124,22 @@ __device__ __forceinline__ uint4 lr_transition(u64 &occ, u32 &q0, u32 &q1, u32 &
         occ_rec = occ;
         rz = (u32)c_prev | (((u32)a_out & 0xffu) << 8);
         rw = (u32)(food + 1) | ((u32)eat << 8) | (selfc << 9) | (edge << 10) | 0x8000u;
+        if constexpr (RAWB) {
+            // single_snake.py:139-140 'raw' = the state itself.  Body: the neck has L - 1, ... the tail 1 (walking the queue
+            // of moves from the neck); the head cell ADDS L (:258-262) — after a self collision it shows the sum with the
+            // segment it ran into, on the ring after an edge collision
+            const int hy = (c_prev >> 3) + lr_dy(ai), hx = (c_prev & 7) + lr_dx(ai);
+            if (food >= 0) raw[9 * (food >> 3) + (food & 7)] = 1;
+            raw[LR_C + 9 * hy + hx] = 1;
+            int code = c_prev;
+            u32 w0 = (q0 >> 2) | (q1 << 30), w1 = (q1 >> 2) | (q2 << 30), w2 = q2 >> 2;
+            for (int v = L - 1; v >= 1; --v) {
+                raw[2 * LR_C + 9 * (code >> 3) + (code & 7)] = (unsigned char)v;
+                code -= lr_dcode((int)(w0 & 3u));
+                w0 = (w0 >> 2) | (w1 << 30); w1 = (w1 >> 2) | (w2 << 30); w2 >>= 2;
+            }
+            raw[2 * LR_C + 9 * hy + hx] += (unsigned char)L;
+        }
         if (RESET && (selfc | edge)) {                                  // :322-387
             const u32 r = cur.y;
             const int hc = (int)(r & 127u), sc = (int)((r >> 7) & 127u), d = (int)((r >> 21) & 3u);
@@ -251,6 +269,10 @@ __device__ __forceinline__ void lr_write_generic(const StepArgs &p, const uint4 
 //       (0.5), head (1.0 = 0.5 + 0.5), food (1.5), ring (-1) — and two tables whose results are ADDED: the planes exclude each
 //       other, so one of the two addends is always +0 and the sum is exact.
 constexpr int LR_OBS_GRID1 = -2, LR_OBS_GRID3 = -3;   // OBSK of the kernels: one_channel / default through bit planes
+constexpr int LR_OBS_CROP3 = -4;                      // 'partial_3' (round 5): 7 x 7 crops through the same bit planes, 147 floats per env
+constexpr int LR_OBS_RAW = -5;                        // 'raw' (round 5): the state itself, through one byte per float
+constexpr int LR_E3 = 147;                            // floats of a 7 x 7 crop
+constexpr int LR_RAW_SLAB = 64 * LR_C3 + 16;          // bytes of a chunk's 'raw' observations, one byte per float (64 pairs)
 constexpr int LR_GRID_BITS = 4096;                    // bytes per wave of their flat bit strings (behind LaneRollLds::BYTES)
 constexpr int LR_TAB_GRID = 8192 + 512;               // their workgroup tables: 2 x 256 float4, the float-by-float lut
 
@@ -338,6 +360,74 @@ __device__ __forceinline__ float4 lr_grid_group(const u32 *bits, const float4 *t
     const uint2 q = ((const uint2 *)bits)[w];
     return tabA[((q.x >> sh) & 15u) | (((q.y >> sh) & 15u) << 4)];
 }
+
+// ---- 'partial_3' (round 5): the 7 x 7 window of the occupancy mask around the head is still ONE 64-bit shift (window bit
+// 8 i + j <-> code sh + 8 i + j, i, j < 7: 55 bits); the planes of the 'default' colours restricted to the window cells
+// inside the ring, rows of 7 bits compacted to 49 contiguous bits per channel, 147 bits per pair in the crop's (c, y, x) order
+__device__ __forceinline__ void lr_build_wint7(u64 *wint)
+{
+    for (int i = (int)threadIdx.x; i < LR_C; i += (int)blockDim.x) {
+        const int hy = i / 9, hx = i - hy * 9;
+        u64 m = 0;
+#pragma unroll
+        for (int wy = 0; wy < 7; ++wy)
+#pragma unroll
+            for (int wx = 0; wx < 7; ++wx)
+                if ((unsigned)(hy - 3 + wy - 1) < 7u && (unsigned)(hx - 3 + wx - 1) < 7u) m |= 1ull << (8 * wy + wx);
+        wint[i] = m;
+    }
+}
+
+__device__ __forceinline__ u64 lr_compact7(u64 x)
+{
+    return (x & 0x7Full) | ((x >> 1) & (0x7Full << 7)) | ((x >> 2) & (0x7Full << 14)) | ((x >> 3) & (0x7Full << 21)) |
+           ((x >> 4) & (0x7Full << 28)) | ((x >> 5) & (0x7Full << 35)) | ((x >> 6) & (0x7Full << 42));
+}
+
+// ORs 49 bits into plane k of NPL interleaved flat bit strings at bit offset off
+template <int NPL>
+__device__ __forceinline__ void lr_or49(u32 *bits, int k, int off, u64 v)
+{
+    const int w = off >> 5, sb = off & 31;
+    const u64 a = (u64)(u32)v << sb, b = (u64)(u32)(v >> 32) << sb;
+    u32 *P = bits + NPL * w + k;
+    atomicOr(&P[0], (u32)a);
+    atomicOr(&P[NPL], (u32)(a >> 32) | (u32)b);
+    if ((u32)(b >> 32)) atomicOr(&P[2 * NPL], (u32)(b >> 32));
+}
+
+// planes of pair p: occupancy oc of the stepped state, head (hy, hx) — also on the ring —, food code fc (-1: none)
+__device__ __forceinline__ void lr_crop3_planes(u32 *bits, const u64 *wint7, int p, u64 oc, int hy, int hx, int fc)
+{
+    const int sh = 8 * hy + hx - 27;
+    const u64 V = sh >= 0 ? oc >> sh : oc << (-sh);
+    const u64 W = wint7[hy * 9 + hx];
+    const int fpos_w = fc - sh;
+    const u64 F = fc >= 0 && (unsigned)fpos_w < 56u ? (1ull << fpos_w) & W : 0ull;
+    const u64 R = W & ~V;                         // free or food: red
+    const u64 B = R & ~F;                         // free: blue (and green)
+    const u64 CENTRE = 1ull << 27;
+    const u64 G1 = B | (W & CENTRE);              // green 1: free, or the head inside the ring
+    const u64 GH = V & W & ~CENTRE;               // green 127/255: body
+    const int off = LR_E3 * p;
+    lr_or49<2>(bits, 0, off, lr_compact7(R));
+    lr_or49<2>(bits, 0, off + 49, lr_compact7(G1));
+    lr_or49<2>(bits, 0, off + 98, lr_compact7(B));
+    lr_or49<2>(bits, 1, off + 49, lr_compact7(GH));
+}
+
+// per-wave LDS of lane_rollout_kernel<EPW, OBSK, ·>: the grid / crop modes keep their flat bit strings behind
+// LaneRollLds::BYTES, 'raw' its byte slab from LaneRollLds::SCR on (that scratch is free between the state read and the
+// write-back)
+template <int EPW, int OBSK>
+constexpr int lr_wave_bytes()
+{
+    typedef LaneRollLds<EPW> Lds;
+    if (OBSK == LR_OBS_RAW) return Lds::BYTES > Lds::SCR + LR_RAW_SLAB ? Lds::BYTES : ((Lds::SCR + LR_RAW_SLAB + 15) & ~15);
+    if (OBSK == LR_OBS_GRID1 || OBSK == LR_OBS_GRID3 || OBSK == LR_OBS_CROP3) return Lds::BYTES + LR_GRID_BITS;
+    return Lds::BYTES;
+}
+constexpr bool lr_grid_tables(int OBSK) { return OBSK == LR_OBS_GRID1 || OBSK == LR_OBS_GRID3 || OBSK == LR_OBS_CROP3 || OBSK == LR_OBS_RAW; }
 
 // The state of a block of EPW consecutive envs (`block` = its first float), read cooperatively — lanes = (env, cell) pairs,
 // the few non-zero elements scattered into a per-env value -> cell table in LDS — then, per env lane: validation and the
@@ -454,9 +544,12 @@ __global__ __launch_bounds__(256) void lane_rollout_kernel(StepArgs p)
     typedef LaneRollLds<EPW> Lds;
     static_assert(EPW == 4 || EPW == 8 || EPW == 16 || EPW == 32 || EPW == 64, "envs per wave");
     static_assert(OBSK == WURM_OBS_PARTIAL || OBSK == WURM_OBS_NONE || OBSK == LR_OBS_GENERIC || OBSK == LR_OBS_GRID1 ||
-                  OBSK == LR_OBS_GRID3, "lane rollout: partial_2, one_channel, default, no observation, or any other mode at run time");
-    constexpr bool GRID = OBSK == LR_OBS_GRID1 || OBSK == LR_OBS_GRID3;
-    constexpr int GE = OBSK == LR_OBS_GRID1 ? LR_C : LR_C3;     // floats per env of a grid mode
+                  OBSK == LR_OBS_GRID3 || OBSK == LR_OBS_CROP3 || OBSK == LR_OBS_RAW,
+                  "lane rollout: partial_2, partial_3, one_channel, default, raw, no observation, or any other mode at run time");
+    constexpr bool GRID = OBSK == LR_OBS_GRID1 || OBSK == LR_OBS_GRID3 || OBSK == LR_OBS_CROP3; // flat bit strings -> table
+    constexpr bool RAW = OBSK == LR_OBS_RAW;                                                    // byte slab -> floats
+    constexpr bool GTAB = lr_grid_tables(OBSK);                 // LDS layout of the grid modes
+    constexpr int GE = OBSK == LR_OBS_GRID1 ? LR_C : OBSK == LR_OBS_CROP3 ? LR_E3 : LR_C3; // floats per env of such a mode
     constexpr int GPL = OBSK == LR_OBS_GRID1 ? 4 : 2;           // its interleaved bit planes
     constexpr int TC = 64 / EPW;                  // steps per chunk
     constexpr int LOG_EPW = EPW == 4 ? 2 : EPW == 8 ? 3 : EPW == 16 ? 4 : EPW == 32 ? 5 : 6;
@@ -470,17 +563,19 @@ __global__ __launch_bounds__(256) void lane_rollout_kernel(StepArgs p)
     float4 *tab = (float4 *)lr_lds;               // nibble pair -> four floats
     u64 *wint = (u64 *)(lr_lds + 4096);           // head (row, column) -> window cells that lie inside the border ring
     // (generic observations: float -> channel / row / column, in place of tab; grid modes: behind their two tables)
-    unsigned short *lut = (unsigned short *)(lr_lds + (GRID ? 8192 : 0));
+    unsigned short *lut = (unsigned short *)(lr_lds + (GTAB ? 8192 : 0));
     float4 *tabB = (float4 *)(lr_lds + 4096);
     if (OBSK == LR_OBS_GENERIC || GRID) lr_build_lut(lut, p.obs_mode, p.obs_n, (int)p.obs_elems);
     if (GRID) lr_build_grid_tables<OBSK>(tab, tabB);
-    else if (OBSK != LR_OBS_GENERIC) lr_build_tables(tab, wint);
+    else if (OBSK != LR_OBS_GENERIC && !RAW) lr_build_tables(tab, wint);
+    if (OBSK == LR_OBS_CROP3) lr_build_wint7(wint); // (in the place of 'one_channel's second table)
     __syncthreads();
 
     const long long env0 = (xcd_block(blockIdx.x, gridDim.x) * wpb + wave) * EPW;
     if (env0 >= p.N) return;
-    unsigned char *lds = lr_lds + (GRID ? LR_TAB_GRID : LR_TAB) + wave * (Lds::BYTES + (GRID ? LR_GRID_BITS : 0));
+    unsigned char *lds = lr_lds + (GTAB ? LR_TAB_GRID : LR_TAB) + wave * lr_wave_bytes<EPW, OBSK>();
     u32 *gbits = (u32 *)(lds + Lds::BYTES);      // (grid modes: the flat bit strings of a chunk)
+    unsigned char *gb = lds + Lds::SCR;          // ('raw': the chunk's observations, one byte per float)
     const int nenv = (int)min((long long)EPW, p.N - env0);
     const bool mine = lane < nenv;                // env lanes: lane e owns env0 + e
     const int ps = lane >> LOG_EPW, pe = lane & (EPW - 1); // pair lanes: step ps of the chunk, env env0 + pe
@@ -522,7 +617,7 @@ __global__ __launch_bounds__(256) void lane_rollout_kernel(StepArgs p)
     u32 *bits = (u32 *)(lds + Lds::BITS);
     const u64 env_id = (u64)(p.env_offset + env0 + pe); // of the pair lane
     const bool pair_env = pe < nenv;
-    const int E = OBSK == LR_OBS_GENERIC ? (int)p.obs_elems : GRID ? GE : LR_E;
+    const int E = OBSK == LR_OBS_GENERIC ? (int)p.obs_elems : (GRID || RAW) ? GE : LR_E;
     float *obs_c = p.obs + env0 * E;                  // observations of the chunk's first step, this wave's envs
     const unsigned obs_step_bytes = (unsigned)(p.N * (LR_E * 4)); // (the launcher keeps TC * N * 300 below 2^32)
 
@@ -578,9 +673,13 @@ __global__ __launch_bounds__(256) void lane_rollout_kernel(StepArgs p)
             // (2) env lanes: TC transitions (single_snake.py:197-304, then the reset of :322-387 for a finished env).
             // in: x = action bits, y = would-be reset, z = food word;  out: occupancy, head code before the move |
             // sanitised action << 8, food code + 1 | ate << 8 | self collision << 9 | edge collision << 10 | valid << 15
+            if (RAW) { // the chunk's byte slab: zero, then the env lanes leave every stepped state in it
+                for (int i = lane; i < LR_RAW_SLAB / 16; i += 64) ((uint4 *)gb)[i] = make_uint4(0, 0, 0, 0);
+                wave_lds_sync();
+            }
             if constexpr (EPW == 64) {
-                rec = lr_transition<INJ>(occ, q0, q1, q2, c, tc, L, o, food, act, rec);              // pair lane == env lane: the record never leaves its registers
-                if (OBSK == LR_OBS_GENERIC || GRID) io[lane] = rec;                                    // (the float-by-float writer reads records by env)
+                rec = lr_transition<INJ, true, RAW>(occ, q0, q1, q2, c, tc, L, o, food, act, rec, gb + lane * LR_C3); // pair lane == env lane: the record never leaves its registers
+                if (OBSK == LR_OBS_GENERIC || GRID || RAW) io[lane] = rec;                             // (the float-by-float writer reads records by env)
             } else {
                 io[lane] = rec;
                 wave_lds_sync();
@@ -589,7 +688,8 @@ __global__ __launch_bounds__(256) void lane_rollout_kernel(StepArgs p)
                     for (int s2 = 0; s2 < nt; ++s2) {
                         const uint4 cur = in;
                         if (s2 + 1 < nt) in = io[(s2 + 1) * EPW + lane];
-                        io[s2 * EPW + lane] = lr_transition<INJ>(occ, q0, q1, q2, c, tc, L, o, food, act, cur);
+                        io[s2 * EPW + lane] = lr_transition<INJ, true, RAW>(occ, q0, q1, q2, c, tc, L, o, food, act, cur,
+                                                                            gb + (s2 * EPW + lane) * LR_C3);
                     }
                 }
             }
@@ -618,8 +718,12 @@ __global__ __launch_bounds__(256) void lane_rollout_kernel(StepArgs p)
                 }
                 if (GRID && valid) { // planes of the stepped state (the head also when it is on the ring)
                     const int cp = (int)(rz & 63u), ai = (int)((rz >> 8) & 3u);
-                    lr_grid_planes<OBSK>(gbits, lane, (u64)rec.x | ((u64)rec.y << 32), (cp >> 3) + lr_dy(ai), (cp & 7) + lr_dx(ai),
-                                         (int)(rw & 127u) - 1);
+                    if constexpr (OBSK == LR_OBS_CROP3)
+                        lr_crop3_planes(gbits, wint, lane, (u64)rec.x | ((u64)rec.y << 32), (cp >> 3) + lr_dy(ai), (cp & 7) + lr_dx(ai),
+                                        (int)(rw & 127u) - 1);
+                    else
+                        lr_grid_planes<OBSK>(gbits, lane, (u64)rec.x | ((u64)rec.y << 32), (cp >> 3) + lr_dy(ai), (cp & 7) + lr_dx(ai),
+                                             (int)(rw & 127u) - 1);
                 }
                 if (OBSK == WURM_OBS_PARTIAL && valid) {
                     // crop of the stepped state (single_snake.py:166-193): a window cell that is off the grid or on the
@@ -710,6 +814,29 @@ __global__ __launch_bounds__(256) void lane_rollout_kernel(StepArgs p)
                 }
                 wave_lds_sync();
             }
+            if (RAW) {
+                wave_lds_sync();
+                if (nenv == EPW && nt == TC) {
+                    constexpr int GSG = EPW * LR_C3 / 4, NGRP = TC * GSG;   // 16-byte groups per step / per chunk
+                    char *ob = (char *)obs_c;
+                    const size_t step_bytes = (size_t)p.N * (LR_C3 * 4);
+                    const u32 *g4 = (const u32 *)gb;
+#pragma unroll 4
+                    for (int j = lane; j < NGRP; j += 64) {
+                        const u32 b = g4[j];
+                        const int s = EPW == 64 ? 0 : j / GSG;
+                        *(float4 *)(ob + (size_t)s * step_bytes + 16u * (unsigned)(j - s * GSG)) =
+                            make_float4((float)(b & 0xffu), (float)((b >> 8) & 0xffu), (float)((b >> 16) & 0xffu), (float)(b >> 24));
+                    }
+                } else { // the ragged last wave, the last chunk of a tape that is not a multiple of TC: float by float
+                    for (int f = lane; f < 64 * LR_C3; f += 64) {
+                        const int pr = f / LR_C3, k2 = f - pr * LR_C3, s = pr >> LOG_EPW, e = pr & (EPW - 1);
+                        if (s < nt && e < nenv && (io[pr].w & 0x8000u))
+                            obs_c[(long long)s * p.N * LR_C3 + e * LR_C3 + k2] = (float)gb[f];
+                    }
+                }
+                wave_lds_sync();
+            }
             obs_c += (long long)TC * p.N * E;
         }
     }
@@ -789,10 +916,10 @@ __global__ __launch_bounds__(256) void lane_rollout_kernel(StepArgs p)
 bool lane_rollout_eligible(const StepArgs &p)
 {
     if (p.S != 9 || p.only_flagged) return false;
-    // every observation but 'raw' (the body values) and crops of 7 x 7 and more: the float-by-float writer that serves
-    // partial_0 / partial_1 / positions loses to the one-env-per-wave kernels there (partial_3 at 65 536 envs: 2.5e9 against
-    // 5.9e9 env-steps/s), and the bit-plane form of the crops is written for the 5 x 5 window only
-    if (p.obs_mode == WURM_OBS_RAW || (p.obs_mode == WURM_OBS_PARTIAL && (p.obs_n < 0 || p.obs_n > 2))) return false;
+    // every observation but crops of 9 x 9 and more: the float-by-float writer that serves partial_0 / partial_1 / positions
+    // loses to the one-env-per-wave kernels there (partial_3 that way at 65 536 envs: 2.5e9 against 5.9e9 env-steps/s); the
+    // bit-plane form of the crops is written for the 5 x 5 and (round 5) the 7 x 7 window, 'raw' goes through bytes (round 5)
+    if (p.obs_mode == WURM_OBS_PARTIAL && (p.obs_n < 0 || p.obs_n > 3)) return false;
     if ((p.inject_food == nullptr) != (p.inject_reset == nullptr)) return false;
     return true;
 }
@@ -827,15 +954,17 @@ static hipError_t launch_lane_rollout_obs(const StepArgs &p, hipStream_t stream)
     dim3 block(64 * wpb), grid((unsigned)((waves + wpb - 1) / wpb));
     (void)hipGetLastError();
     auto go = [&](auto kernel, int lds_per_wave) {
-        constexpr bool GRID = OBSK == LR_OBS_GRID1 || OBSK == LR_OBS_GRID3;
-        WURM_LAUNCH(kernel, grid, block, (size_t)((GRID ? LR_TAB_GRID : LR_TAB) + (lds_per_wave + (GRID ? LR_GRID_BITS : 0)) * wpb), stream, p);
+        const size_t lds_bytes = (size_t)((lr_grid_tables(OBSK) ? LR_TAB_GRID : LR_TAB) + lds_per_wave * wpb);
+        // ('raw' with four waves per workgroup: 80 KB — beyond the 64 KB a launch gets without the kernel's opt-in)
+        if (lds_bytes > 65536) (void)hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        WURM_LAUNCH(kernel, grid, block, lds_bytes, stream, p);
     };
-    if (inj) go(lane_rollout_kernel<16, OBSK, true>, LaneRollLds<16>::BYTES);
-    else if (epw == 4) go(lane_rollout_kernel<4, OBSK, false>, LaneRollLds<4>::BYTES);
-    else if (epw == 8) go(lane_rollout_kernel<8, OBSK, false>, LaneRollLds<8>::BYTES);
-    else if (epw == 16) go(lane_rollout_kernel<16, OBSK, false>, LaneRollLds<16>::BYTES);
-    else if (epw == 32) go(lane_rollout_kernel<32, OBSK, false>, LaneRollLds<32>::BYTES);
-    else go(lane_rollout_kernel<64, OBSK, false>, LaneRollLds<64>::BYTES);
+    if (inj) go(lane_rollout_kernel<16, OBSK, true>, lr_wave_bytes<16, OBSK>());
+    else if (epw == 4) go(lane_rollout_kernel<4, OBSK, false>, lr_wave_bytes<4, OBSK>());
+    else if (epw == 8) go(lane_rollout_kernel<8, OBSK, false>, lr_wave_bytes<8, OBSK>());
+    else if (epw == 16) go(lane_rollout_kernel<16, OBSK, false>, lr_wave_bytes<16, OBSK>());
+    else if (epw == 32) go(lane_rollout_kernel<32, OBSK, false>, lr_wave_bytes<32, OBSK>());
+    else go(lane_rollout_kernel<64, OBSK, false>, lr_wave_bytes<64, OBSK>());
     return hipGetLastError();
 }
 
@@ -845,6 +974,8 @@ hipError_t launch_lane_rollout(const StepArgs &p, hipStream_t stream)
     if (p.obs_mode == WURM_OBS_PARTIAL && p.obs_n == 2) return launch_lane_rollout_obs<WURM_OBS_PARTIAL>(p, stream);
     if (p.obs_mode == WURM_OBS_ONE_CHANNEL) return launch_lane_rollout_obs<LR_OBS_GRID1>(p, stream);
     if (p.obs_mode == WURM_OBS_DEFAULT) return launch_lane_rollout_obs<LR_OBS_GRID3>(p, stream);
+    if (p.obs_mode == WURM_OBS_PARTIAL && p.obs_n == 3) return launch_lane_rollout_obs<LR_OBS_CROP3>(p, stream);
+    if (p.obs_mode == WURM_OBS_RAW) return launch_lane_rollout_obs<LR_OBS_RAW>(p, stream);
     return launch_lane_rollout_obs<LR_OBS_GENERIC>(p, stream);
 }
 
