@@ -789,7 +789,7 @@ def extra_measurements(device):
     per_call('per_call_cfg3', lambda: SingleSnake(N, SIZE, observation_mode=OBS_MODE, device=device, seed=0), a1, same, T,
              "BASELINE configs[2] whole on one GPU through the reference's own call form `env.step(a); env.reset(d)` (resident "
              'mirror, lazy)', reset_kw={}, traffic_key='resident_step_65536x9_partial2_reset_obs')
-    for mode in ('default', 'one_channel'):
+    for mode in ('default', 'one_channel', 'raw', 'partial_3'):
         per_call(f'per_call_cfg3_{mode}', lambda: SingleSnake(N, SIZE, observation_mode=mode, device=device, seed=0), a1, same, T,
                  f"65 536 x 9 x 9 with observation_mode={mode!r} ('one_channel' is the reference's constructor default) through "
                  '`env.step(a); env.reset(d)` (resident mirror, bit-plane writer)', reset_kw={},
@@ -827,6 +827,7 @@ def key_numbers(line):
         'gridworld_65536_default_eps': g('rollout_65536x9_gridworld_default'), 'gridworld_65536_default_ms': g('rollout_65536x9_gridworld_default', 'ms'),
         'gridworld_65536_default_frac_real': g('rollout_65536x9_gridworld_default', 'frac_real'),
         'cfg3_raw_eps': g('rollout_65536x9_raw'), 'cfg3_partial3_eps': g('rollout_65536x9_partial_3'),
+        'per_call_cfg3_raw_us': g('per_call_cfg3_raw', 'us'), 'per_call_cfg3_partial3_us': g('per_call_cfg3_partial_3', 'us'),
         'cfg1_per_call_us': g('per_call_cfg1_gridworld_64x9', 'us'), 'cfg1_machine': g('per_call_cfg1_gridworld_64x9', 'machine'),
         'per_call_512_us': g('per_call_512', 'us'), 'per_call_512_eps': g('per_call_512'),
         'per_call_512_launches': g('per_call_512', 'launches_per_iter'),

@@ -58,12 +58,17 @@ def _cmp(ro, rh, t):
     (131, 'partial_2', 70),   # an odd count: the crops of the ragged block go out float by float
     (64, 'none', 60),
     (3, 'partial_2', 50),
-    # round 4: every other observation but 'raw' (lr_obs_value) — 'one_channel' is the reference's constructor default
+    # round 4: every other observation (lr_obs_value) — 'one_channel' is the reference's constructor default
     (137, 'one_channel', 60),
     (70, 'default', 50),
     (90, 'positions', 50),
     (75, 'partial_0', 40),
     (75, 'partial_1', 40),
+    # round 5: 'raw' through a byte slab, 'partial_3' through 7 x 7 bit planes
+    (137, 'raw', 60),
+    (70, 'raw', 45),
+    (137, 'partial_3', 60),
+    (64, 'partial_3', 45),
 ])
 def test_abi_step_postponed_reset_and_obs_after(hip, epw, N, mode, T, lazy):
     S = 9
@@ -115,8 +120,9 @@ def test_abi_step_postponed_reset_and_obs_after(hip, epw, N, mode, T, lazy):
     assert deaths > 0 and (eats > 0 or N < 10)
 
 
+@pytest.mark.parametrize('mode', ['partial_2', 'raw', 'partial_3'])
 @pytest.mark.parametrize('lazy', [False, True])
-def test_abi_long_snakes_and_never_reset(hip, lazy):
+def test_abi_long_snakes_and_never_reset(hip, lazy, mode):
     """no reset at all: every env ends up finished and is stepped on by the one-env-per-wave code; before that, snakes
     grow (a greedy walk towards the food) so that queues longer than one word are exercised"""
     N, S, T = 96, 9, 260
@@ -153,8 +159,8 @@ def test_abi_long_snakes_and_never_reset(hip, lazy):
         ao, ah = a.copy(), a.copy()
         late = t >= T - 40
         kw = dict(call=1 + 2 * t, pre_done=None if late else prev, pre_call=2 * t, want_obs_after=True)
-        ro = o.single_step_reset(eo, ao, 'partial_2', **kw)
-        rh = h.single_step_reset(eh, ah, 'partial_2', resident=mirror, **kw)
+        ro = o.single_step_reset(eo, ao, mode, **kw)
+        rh = h.single_step_reset(eh, ah, mode, resident=mirror, **kw)
         _same(ah, ao, f'actions t={t}')
         _same(eh, eo, f'state t={t}')
         _cmp(ro, rh, t)

@@ -156,6 +156,12 @@ struct ResLds {
     static constexpr int SCR = BITS + 1216; // fused_step_env's class map (96 bytes at S = 9)
     static constexpr int BYTES = SCR + 128;
 };
+// per-wave LDS of lane_resident_step_kernel by observation: the grid / crop modes keep flat bit strings, 'raw' a byte slab
+// behind ResLds::BYTES
+constexpr int res_wave_bytes(int OBSK)
+{
+    return ResLds::BYTES + (OBSK == LR_OBS_RAW ? LR_RAW_SLAB : (OBSK == LR_OBS_GRID1 || OBSK == LR_OBS_GRID3 || OBSK == LR_OBS_CROP3) ? LR_GRID_BITS : 0);
+}
 
 // EPW envs per wave; NW = 2: crops of `obs` and of `obs_after` (EPW * 2 <= 64 pair lanes), NW = 1: `obs` only; LAZY: `envs`
 // is left alone
@@ -165,10 +171,12 @@ __global__ __launch_bounds__(256) void lane_resident_step_kernel(ResidentArgs a)
     static_assert(EPW == 16 || EPW == 32 || EPW == 64, "envs per wave");
     static_assert(EPW * NW <= 64 && (NW == 1 || NW == 2), "pair lanes");
     static_assert(OBSK == WURM_OBS_PARTIAL || OBSK == LR_OBS_GENERIC || OBSK == LR_OBS_GRID1 || OBSK == LR_OBS_GRID3 ||
-                  (OBSK == WURM_OBS_NONE && NW == 1),
-                  "partial_2, one_channel / default through bit planes, any other mode at run time (lr_obs_value), or none");
-    constexpr bool GRID = OBSK == LR_OBS_GRID1 || OBSK == LR_OBS_GRID3;
-    constexpr int GE = OBSK == LR_OBS_GRID1 ? LR_C : LR_C3;     // floats per env of a grid mode
+                  OBSK == LR_OBS_CROP3 || OBSK == LR_OBS_RAW || (OBSK == WURM_OBS_NONE && NW == 1),
+                  "partial_2, one_channel / default / partial_3 through bit planes, raw through bytes, any other mode at run time (lr_obs_value), or none");
+    constexpr bool GRID = OBSK == LR_OBS_GRID1 || OBSK == LR_OBS_GRID3 || OBSK == LR_OBS_CROP3;
+    constexpr bool RAW = OBSK == LR_OBS_RAW;
+    constexpr bool GTAB = lr_grid_tables(OBSK);
+    constexpr int GE = OBSK == LR_OBS_GRID1 ? LR_C : OBSK == LR_OBS_CROP3 ? LR_E3 : LR_C3; // floats per env of such a mode
     constexpr int S = 9, C = LR_C, C3 = LR_C3;
     constexpr int LOG_EPW = EPW == 16 ? 4 : EPW == 32 ? 5 : 6;
     constexpr int NP = EPW * NW;                 // pair lanes
@@ -181,7 +189,7 @@ __global__ __launch_bounds__(256) void lane_resident_step_kernel(ResidentArgs a)
     float4 *tab = (float4 *)res_lds;
     u64 *wint = (u64 *)(res_lds + 4096);
     // (generic observations: float -> channel / row / column, in place of tab; grid modes: behind their two tables)
-    unsigned short *lut = (unsigned short *)(res_lds + (GRID ? 8192 : 0));
+    unsigned short *lut = (unsigned short *)(res_lds + (GTAB ? 8192 : 0));
     float4 *tabB = (float4 *)(res_lds + 4096);
     if (OBSK == WURM_OBS_PARTIAL) {
         lr_build_tables(tab, wint);
@@ -189,12 +197,14 @@ __global__ __launch_bounds__(256) void lane_resident_step_kernel(ResidentArgs a)
     } else if (OBSK == LR_OBS_GENERIC || GRID) {
         lr_build_lut(lut, p.obs_mode, p.obs_n, (int)p.obs_elems);
         if (GRID) lr_build_grid_tables<OBSK>(tab, tabB);
+        if (OBSK == LR_OBS_CROP3) lr_build_wint7(wint); // (in the place of 'one_channel's second table)
         __syncthreads();
     }
 
     const long long env0 = (xcd_block(blockIdx.x, gridDim.x) * wpb + wave) * EPW;
     if (env0 >= p.N) return;
-    unsigned char *lds = res_lds + (GRID ? LR_TAB_GRID : LR_TAB) + wave * (ResLds::BYTES + (GRID ? LR_GRID_BITS : 0));
+    unsigned char *lds = res_lds + (GTAB ? LR_TAB_GRID : LR_TAB) + wave * res_wave_bytes(OBSK);
+    unsigned char *gb = lds + ResLds::BYTES;      // ('raw': the pairs' observations, one byte per float)
     const int nenv = (int)min((long long)EPW, p.N - env0);
     const bool mine = lane < nenv;                // env lanes: lane e owns env0 + e
     const long long env = env0 + lane;
@@ -240,7 +250,12 @@ __global__ __launch_bounds__(256) void lane_resident_step_kernel(ResidentArgs a)
         const u32 a_mod = (a_in >= 0 && a_in < 4) ? (u32)a_in : ((u32)(int)(a_in % 4) & 7u);
         u32 fword = 0;
         if (act) fword = rng_words(p.seed, p.call, env_id, RNG_FOOD, 0).w[0];
-        rec = lr_transition<false, false>(occ, q0, q1, q2, c, tc, L, o, food, act, make_uint4(a_small | (a_mod << 3), 0u, fword, 0u));
+        if (RAW) { // the pairs' byte slab: zero, then the env lanes leave the stepped state in it
+            for (int i = lane; i < LR_RAW_SLAB / 16; i += 64) ((uint4 *)gb)[i] = make_uint4(0, 0, 0, 0);
+            wave_lds_sync();
+        }
+        rec = lr_transition<false, false, RAW>(occ, q0, q1, q2, c, tc, L, o, food, act, make_uint4(a_small | (a_mod << 3), 0u, fword, 0u),
+                                               gb + lane * LR_C3);
     }
     const u32 rz = rec.z, rw = rec.w;
     const bool eat = (rw & 0x100u) != 0, selfc = (rw & 0x200u) != 0, edgec = (rw & 0x400u) != 0;
@@ -430,8 +445,12 @@ __global__ __launch_bounds__(256) void lane_resident_step_kernel(ResidentArgs a)
             wave_lds_sync();
             if (lane < NP) {
                 const uint4 q = io[lane]; // pair lane (which, env) = (lane >> LOG_EPW, lane & (EPW - 1))
-                if (q.z & 0x100u)
-                    lr_grid_planes<OBSK>(gbits, lane, (u64)q.x | ((u64)q.y << 32), (int)(q.z & 15u), (int)((q.z >> 4) & 15u), (int)q.w - 1);
+                if (q.z & 0x100u) {
+                    if constexpr (OBSK == LR_OBS_CROP3)
+                        lr_crop3_planes(gbits, wint, lane, (u64)q.x | ((u64)q.y << 32), (int)(q.z & 15u), (int)((q.z >> 4) & 15u), (int)q.w - 1);
+                    else
+                        lr_grid_planes<OBSK>(gbits, lane, (u64)q.x | ((u64)q.y << 32), (int)(q.z & 15u), (int)((q.z >> 4) & 15u), (int)q.w - 1);
+                }
             }
             wave_lds_sync();
             constexpr int GSG = EPW * GE / 4;   // 16-byte groups of one observation of the wave's envs
@@ -463,6 +482,45 @@ __global__ __launch_bounds__(256) void lane_resident_step_kernel(ResidentArgs a)
         }
     }
 
+    if (RAW) {
+        // 'raw' (round 5): row `lane` of the slab holds the stepped state (lr_transition); for `obs_after` row EPW + lane
+        // holds the state a finished env is rebuilt to with call + 1 (three segments, :372-376), else the stepped state again
+        if (NW == 2 && act) {
+            unsigned char *r2 = gb + (EPW + lane) * LR_C3;
+            if (fin) {
+                const S9Reset r = s9_reset_draw(p.seed, p.call + 1ull, env_id);
+                const int hc = r.b & 127, sc = (r.b >> 7) & 127, t2 = (r.b >> 14) & 127, f2 = r.a >> 2;
+                if (f2 >= 0) r2[9 * (f2 >> 3) + (f2 & 7)] = 1;
+                r2[LR_C + 9 * (hc >> 3) + (hc & 7)] = 1;
+                r2[2 * LR_C + 9 * (hc >> 3) + (hc & 7)] = 3;
+                r2[2 * LR_C + 9 * (sc >> 3) + (sc & 7)] = 2;
+                r2[2 * LR_C + 9 * (t2 >> 3) + (t2 & 7)] = 1;
+            } else {
+                lr_raw_bytes(r2, food, ny, nx, c_old, (q0 >> 2) | (q1 << 30), (q1 >> 2) | (q2 << 30), q2 >> 2, L);
+            }
+        }
+        wave_lds_sync();
+        float *ob0 = p.obs + env0 * LR_C3, *ob1 = NW == 2 ? p.obs_after + env0 * LR_C3 : nullptr;
+        if (nenv == EPW && odd == 0) {
+            constexpr int GSG = EPW * LR_C3 / 4;   // 16-byte groups of one observation of the wave's envs
+            const u32 *g4 = (const u32 *)gb;
+#pragma unroll 4
+            for (int j = lane; j < NW * GSG; j += 64) {
+                const u32 b = g4[j];
+                const bool second = NW == 2 && j >= GSG;
+                *(float4 *)((char *)(second ? ob1 : ob0) + 16u * (unsigned)(second ? j - GSG : j)) =
+                    make_float4((float)(b & 0xffu), (float)((b >> 8) & 0xffu), (float)((b >> 16) & 0xffu), (float)(b >> 24));
+            }
+        } else { // the ragged last wave, or one with an env outside the domain (fused_step_env below writes that env's rows)
+            const u64 ok = ballot(act);
+            for (int f = lane; f < NP * LR_C3; f += 64) {
+                const int pr = f / LR_C3, k2 = f - pr * LR_C3, w = pr >> LOG_EPW, e = pr & (EPW - 1);
+                if (e < nenv && ((ok >> e) & 1ull)) (w ? ob1 : ob0)[e * LR_C3 + k2] = (float)gb[f];
+            }
+        }
+        wave_lds_sync();
+    }
+
     WURM_TL(6); // crops issued; WURM_TL_STORE: drained
     if (OBSK == WURM_OBS_PARTIAL) WURM_TL_STORE(p.obs + env0 * LR_E, lane);
     // ---- envs outside the domain: the one-env-per-wave code reads and writes their state, outputs and crops itself
@@ -490,8 +548,8 @@ __global__ __launch_bounds__(256) void lane_resident_step_kernel(ResidentArgs a)
 // the shapes the resident step serves (the caller opts in per call by passing wurm_single_call.resident)
 bool lane_resident_shape(int S, int obs_mode, int obs_n)
 {
-    // every observation but 'raw' (the body values) and crops of 7 x 7 and more (lane_rollout_eligible says why)
-    return S == 9 && obs_mode != WURM_OBS_RAW && !(obs_mode == WURM_OBS_PARTIAL && (obs_n < 0 || obs_n > 2));
+    // every observation but crops of 9 x 9 and more (lane_rollout_eligible says why)
+    return S == 9 && !(obs_mode == WURM_OBS_PARTIAL && (obs_n < 0 || obs_n > 3));
 }
 
 bool lane_resident_eligible(const StepArgs &p)
@@ -536,7 +594,8 @@ static hipError_t launch_lane_resident_form(const StepArgs &p, void *resident, b
     }
     const bool crops = p.obs_mode == WURM_OBS_PARTIAL && p.obs_n == 2;
     const bool grid1 = p.obs_mode == WURM_OBS_ONE_CHANNEL, grid3 = p.obs_mode == WURM_OBS_DEFAULT;
-    const bool generic = p.obs_mode != WURM_OBS_NONE && !crops && !grid1 && !grid3;
+    const bool crop3 = p.obs_mode == WURM_OBS_PARTIAL && p.obs_n == 3, raw = p.obs_mode == WURM_OBS_RAW;
+    const bool generic = p.obs_mode != WURM_OBS_NONE && !crops && !grid1 && !grid3 && !crop3 && !raw;
     const int nw = (p.obs_mode != WURM_OBS_NONE && p.obs_after != nullptr) ? 2 : 1;
     // envs per wave (automatic unless the option WURM_RESIDENT_EPW forces it: tests and the tuning sweep)
     int epw = (int)opt.resident_epw;
@@ -544,14 +603,30 @@ static hipError_t launch_lane_resident_form(const StepArgs &p, void *resident, b
     // with the reset observation; 32 768 envs 6.3 / 5.9 / 6.3 and 7.6 / 8.4 / -
     if (epw != 16 && epw != 32 && epw != 64) epw = nw == 1 ? (p.N >= 16384 ? 32 : 16) : (p.N >= 49152 ? 32 : 16);
     if (epw * nw > 64) epw = 32;
-    const bool gridm = grid1 || grid3;
+    const int obsk = grid1 ? LR_OBS_GRID1 : grid3 ? LR_OBS_GRID3 : crop3 ? LR_OBS_CROP3 : raw ? LR_OBS_RAW : 0;
     auto go = [&](auto kernel, int e) {
         const long long waves = (p.N + e - 1) / e;
         const int wpb = waves >= 1024 ? 4 : 1;
         dim3 block(64 * wpb), grid((unsigned)((waves + wpb - 1) / wpb));
-        WURM_LAUNCH(kernel, grid, block, (size_t)((gridm ? LR_TAB_GRID : LR_TAB) + (ResLds::BYTES + (gridm ? LR_GRID_BITS : 0)) * wpb), stream, a);
+        const size_t lds_bytes = (size_t)((lr_grid_tables(obsk) ? LR_TAB_GRID : LR_TAB) + res_wave_bytes(obsk) * wpb);
+        if (lds_bytes > 65536) (void)hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        WURM_LAUNCH(kernel, grid, block, lds_bytes, stream, a);
     };
-    if (grid1) {
+    if (crop3) {
+        if (nw == 2) {
+            if (epw == 16) go(lane_resident_step_kernel<16, 2, LR_OBS_CROP3, LAZY>, 16);
+            else go(lane_resident_step_kernel<32, 2, LR_OBS_CROP3, LAZY>, 32);
+        } else if (epw == 16) go(lane_resident_step_kernel<16, 1, LR_OBS_CROP3, LAZY>, 16);
+        else if (epw == 32) go(lane_resident_step_kernel<32, 1, LR_OBS_CROP3, LAZY>, 32);
+        else go(lane_resident_step_kernel<64, 1, LR_OBS_CROP3, LAZY>, 64);
+    } else if (raw) {
+        if (nw == 2) {
+            if (epw == 16) go(lane_resident_step_kernel<16, 2, LR_OBS_RAW, LAZY>, 16);
+            else go(lane_resident_step_kernel<32, 2, LR_OBS_RAW, LAZY>, 32);
+        } else if (epw == 16) go(lane_resident_step_kernel<16, 1, LR_OBS_RAW, LAZY>, 16);
+        else if (epw == 32) go(lane_resident_step_kernel<32, 1, LR_OBS_RAW, LAZY>, 32);
+        else go(lane_resident_step_kernel<64, 1, LR_OBS_RAW, LAZY>, 64);
+    } else if (grid1) {
         if (nw == 2) {
             if (epw == 16) go(lane_resident_step_kernel<16, 2, LR_OBS_GRID1, LAZY>, 16);
             else go(lane_resident_step_kernel<32, 2, LR_OBS_GRID1, LAZY>, 32);

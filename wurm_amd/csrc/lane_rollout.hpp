@@ -85,8 +85,24 @@ constexpr u64 LR_INTERIOR = ~LR_RING;          // codes 8 r + c, r, c in 1..7
 // out: x, y = occupancy of the stepped state, z = head code before the move | sanitised action << 8,
 //      w = food code + 1 | ate << 8 | self collision << 9 | edge collision << 10 | valid << 15
 // RESET = false: the step alone (the per-call kernel of lane_resident.hpp rebuilds finished envs in the NEXT launch)
-// RAWB: the stepped (pre-reset) state also as one byte per float of the 'raw' observation (food, head, body VALUES: 243
-// bytes at `raw`, zeroed by the caller)
+// A state as one byte per float of its 'raw' observation (single_snake.py:139-140: the state itself), 243 bytes at `raw`,
+// zeroed by the caller: food code, head (hy, hx) — true coordinates, also on the ring —, the neck's code c_neck and the
+// queue of moves BEHIND the newest one (w0..w2), length L.  Body: the neck has L - 1, ... the tail 1 (walking the queue from
+// the neck); the head cell ADDS L (:258-262) — after a self collision it shows the sum with the segment it ran into.
+__device__ __forceinline__ void lr_raw_bytes(unsigned char *raw, int food, int hy, int hx, int c_neck, u32 w0, u32 w1, u32 w2, int L)
+{
+    if (food >= 0) raw[9 * (food >> 3) + (food & 7)] = 1;
+    raw[LR_C + 9 * hy + hx] = 1;
+    int code = c_neck;
+    for (int v = L - 1; v >= 1; --v) {
+        raw[2 * LR_C + 9 * (code >> 3) + (code & 7)] = (unsigned char)v;
+        code -= lr_dcode((int)(w0 & 3u));
+        w0 = (w0 >> 2) | (w1 << 30); w1 = (w1 >> 2) | (w2 << 30); w2 >>= 2;
+    }
+    raw[2 * LR_C + 9 * hy + hx] += (unsigned char)L;
+}
+
+// RAWB: the stepped (pre-reset) state also as one byte per float of the 'raw' observation (lr_raw_bytes)
 template <bool INJ, bool RESET = true, bool RAWB = false>
 __device__ __forceinline__ uint4 lr_transition(u64 &occ, u32 &q0, u32 &q1, u32 &q2, int &c, int &tc, int &L, int &o, int &food,
                                                const bool act, const uint4 &cur, unsigned char *raw = nullptr)
@@ -124,22 +140,9 @@ __device__ __forceinline__ uint4 lr_transition(u64 &occ, u32 &q0, u32 &q1, u32 &
         occ_rec = occ;
         rz = (u32)c_prev | (((u32)a_out & 0xffu) << 8);
         rw = (u32)(food + 1) | ((u32)eat << 8) | (selfc << 9) | (edge << 10) | 0x8000u;
-        if constexpr (RAWB) {
-            // single_snake.py:139-140 'raw' = the state itself.  Body: the neck has L - 1, ... the tail 1 (walking the queue
-            // of moves from the neck); the head cell ADDS L (:258-262) — after a self collision it shows the sum with the
-            // segment it ran into, on the ring after an edge collision
-            const int hy = (c_prev >> 3) + lr_dy(ai), hx = (c_prev & 7) + lr_dx(ai);
-            if (food >= 0) raw[9 * (food >> 3) + (food & 7)] = 1;
-            raw[LR_C + 9 * hy + hx] = 1;
-            int code = c_prev;
-            u32 w0 = (q0 >> 2) | (q1 << 30), w1 = (q1 >> 2) | (q2 << 30), w2 = q2 >> 2;
-            for (int v = L - 1; v >= 1; --v) {
-                raw[2 * LR_C + 9 * (code >> 3) + (code & 7)] = (unsigned char)v;
-                code -= lr_dcode((int)(w0 & 3u));
-                w0 = (w0 >> 2) | (w1 << 30); w1 = (w1 >> 2) | (w2 << 30); w2 >>= 2;
-            }
-            raw[2 * LR_C + 9 * hy + hx] += (unsigned char)L;
-        }
+        if constexpr (RAWB)
+            lr_raw_bytes(raw, food, (c_prev >> 3) + lr_dy(ai), (c_prev & 7) + lr_dx(ai), c_prev, (q0 >> 2) | (q1 << 30),
+                         (q1 >> 2) | (q2 << 30), q2 >> 2, L);
         if (RESET && (selfc | edge)) {                                  // :322-387
             const u32 r = cur.y;
             const int hc = (int)(r & 127u), sc = (int)((r >> 7) & 127u), d = (int)((r >> 21) & 3u);
