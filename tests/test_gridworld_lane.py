@@ -73,6 +73,21 @@ def test_lane_rollout_matches_the_oracle(hip, N, S, T, mode):
     assert ro['done'].sum() > 0 or S > 12
 
 
+@pytest.mark.parametrize('mode', ['default', 'raw'])
+@pytest.mark.parametrize('S,epw', [(9, 4), (9, 8), (9, 16), (9, 32), (9, 64), (12, 64), (20, 32), (7, 64)])
+def test_every_envs_per_wave_of_the_image_modes(hip, S, epw, mode):
+    """WURM_GRIDWORLD_LANE_EPW pins the envs per wave: runs that fit the 16 KB byte slab are composed in LDS, the others
+    (12 x 12 at 64 envs per wave, 20 x 20 at 32) take the fill-and-patch form; ragged and odd batches in both"""
+    from wurm_amd._lib import knobs
+    N, T = 3 * epw + 5, 18
+    rng = np.random.RandomState(S * 64 + epw)
+    start = (S // 2, S // 2)
+    envs = _fresh(OracleBackend(seed=8), N, S, start)
+    actions = rng.randint(0, 4, size=(T, N)).astype(np.int64)
+    with knobs(WURM_GRIDWORLD_LANE_EPW=epw):
+        _both(hip, envs, actions, start, mode, seed=5, call=3)
+
+
 @pytest.mark.parametrize('dtype', [np.int32, np.int64])
 def test_action_dtypes_and_negative_actions(hip, dtype):
     """actions outside 0..3 wrap like the reference's `actions % 4` on the tensor would — the C-ABI takes them as they

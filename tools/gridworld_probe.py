@@ -4,7 +4,7 @@ from wurm_amd.envs import SimpleGridworld
 from wurm_amd import _lib
 dev = torch.device('cuda:0')
 for mode, T in (('default', 16), ('raw', 16), ('positions', 64)):
-    for knob, epw, var in ((0, -1, 0), (1 << 40, -1, 0)):
+    for knob, epw, var in ((0, -1, 0), (0, -1, 1), (0, 32, 0), (0, 32, 1), (0, -1, 0), (0, -1, 1), (1 << 40, -1, 0)):
         if mode == 'positions' and epw not in (64, -1):
             continue
         with _lib.knobs(WURM_LANE_ROLLOUT_MIN_ENVS=knob, WURM_GRIDWORLD_LANE_EPW=epw, WURM_GRID_ROTATE=var):

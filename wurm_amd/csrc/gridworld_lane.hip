@@ -10,10 +10,12 @@
 //     one-env-per-wave kernels make (single_snake.hip: step_core / reset_core / add_food): the free interior cells are all
 //     interior cells but the agent's, so "the K-th free cell in row-major order, K = mulhi(word, n_free)" is the interior
 //     cell of index K, shifted by one behind the agent's — no mask, no ballot, no rank select;
-//   * the observation of the wave's 64 envs is one contiguous run (obs is (T, N, ...): consecutive envs are adjacent) that
-//     is black / zero but for at most two floats per env: the wave fills the run with 16-byte stores (1 KB per wave
-//     instruction, no address arithmetic beyond an add) and each lane then sets its own two floats — stores of one wave to
-//     one address arrive in order.  Bound: the store stream, 12 S^2 bytes per env-step for 'default'.
+//   * the observation of the wave's envs is one contiguous run (obs is (T, N, ...): consecutive envs are adjacent) that
+//     is black / zero but for at most two floats per env: the run is kept as one BYTE per float in LDS (all zero; the env
+//     lanes set their two bytes, and clear them after the step) and goes out as 4 bytes -> one 16-byte store, 1 KB per
+//     wave instruction; the state is read once, coalesced, and actions are loaded four steps ahead.  (Runs beyond 16 KB —
+//     large grids — are zero-filled and patched instead, 7 % slower.)  Bound: the store stream, 12 S^2 bytes per
+//     env-step for 'default'.
 // Any other env (hand-made states: several agents or foods, other values) is left untouched and marked
 // done[0][env] = GRID_SKIPPED; the one-env-per-wave rollout_kernel rolls it out in a second launch (only_flagged), exactly as
 // behind the clock-grid kernels (grid_rollout.hip).  RNG mode only (recorded outcomes take the generic kernel).
@@ -63,6 +65,7 @@ template <int OBS, int EPW>
 __global__ __launch_bounds__(256) void gridworld_lane_rollout_kernel(StepArgs p)
 {
     __shared__ GridLaneScan scans[4];
+    extern __shared__ __attribute__((aligned(16))) unsigned char gwl_lds[];
     const int lane = (int)(threadIdx.x & 63u), wave = uniform((int)(threadIdx.x >> 6)), wpb = (int)(blockDim.x >> 6);
     const long long wblock = xcd_block(blockIdx.x, gridDim.x) * wpb + wave; // EPW consecutive envs per wave
     const long long env0 = wblock * EPW;
@@ -122,6 +125,13 @@ __global__ __launch_bounds__(256) void gridworld_lane_rollout_kernel(StepArgs p)
     const long long elems = p.obs_elems;                 // floats per env of an observation
     const int run = nv * (int)elems;                     // floats of the wave's run per step (<= 64 * 3 * 64 * 64)
     const bool obs16 = (((unsigned long long)p.obs) & 15ull) == 0;
+    // image modes: the wave's run of one step as bytes (p.lds_per_wave = its size, 0: it does not fit), zeroed once
+    unsigned char *slab = nullptr;
+    if ((OBS == WURM_OBS_DEFAULT || OBS == WURM_OBS_RAW) && p.lds_per_wave > 0) {
+        slab = gwl_lds + wave * p.lds_per_wave;
+        for (int i = lane; i < p.lds_per_wave / 16; i += 64) ((uint4 *)slab)[i] = make_uint4(0, 0, 0, 0);
+        wave_lds_sync();
+    }
     u64 call = p.call;
     long long a_cur[GWL_TC], a_nxt[GWL_TC];
 #pragma unroll
@@ -162,29 +172,61 @@ __global__ __launch_bounds__(256) void gridworld_lane_rollout_kernel(StepArgs p)
             // ---- the observation of the stepped, un-reset state (:202)
             if (OBS == WURM_OBS_DEFAULT || OBS == WURM_OBS_RAW) {
                 float *const blk = p.obs + (t * p.N + env0) * elems; // (wave-uniform)
-                // the run is zeros but for two floats per env; envs the generic kernel takes are written by it afterwards
-                if ((((unsigned long long)blk) & 15ull) == 0) {
-                    const float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                    const int n4 = run >> 2;
-                    float4 *b4 = (float4 *)blk;
-#pragma unroll 4
-                    for (int i = lane; i < n4; i += 64) b4[i] = z;
-                    for (int i = (n4 << 2) + lane; i < run; i += 64) blk[i] = 0.0f;
-                } else { // (a batch whose observation block does not start on a 16-byte boundary: ragged N)
-                    for (int i = lane; i < run; i += 64) blk[i] = 0.0f;
-                }
+                // where the two floats per env that are not zero go: 'raw' is the state itself (food plane, agent plane);
+                // 'default' (:88-109) a black image, food red, agent green, the border ring black
+                int of = -1, oh = -1;
                 if (act) {
-                    float *const o = blk + (long long)slot * elems;
-                    if (OBS == WURM_OBS_RAW) { // clone of the state: food plane, agent plane
-                        if (fc >= 0) o[fc] = 1.0f;
-                        if (hc >= 0) o[C + hc] = 1.0f;
-                    } else { // :88-109 black image, food red, agent green, the border ring black
+                    if (OBS == WURM_OBS_RAW) {
+                        of = fc;
+                        oh = hc >= 0 ? C + hc : -1;
+                    } else {
                         if (fc >= 0) {
                             const int y = div_size(fc, g.rcpS), x = fc - y * S;
-                            if (y >= 1 && y <= S - 2 && x >= 1 && x <= S - 2) o[fc] = 1.0f;
+                            if (y >= 1 && y <= S - 2 && x >= 1 && x <= S - 2) of = fc;
                         }
-                        if (hc >= 0 && !edge) o[C + hc] = 1.0f; // (edge <=> the agent is not on an interior cell)
+                        if (hc >= 0 && !edge) oh = C + hc;       // (edge <=> the agent is not on an interior cell)
                     }
+                }
+                if (slab != nullptr) {
+                    // composed in LDS, one byte per float (all zero but the bytes of this step, cleared again below), then
+                    // 4 bytes -> 16-byte store: every byte of the run is written once (a fill followed by scattered
+                    // 4-byte stores cost 9-13 % of the launch, tools/gridworld_probe.py)
+                    unsigned char *const mine_b = slab + slot * (int)elems;
+                    if (of >= 0) mine_b[of] = 1;
+                    if (oh >= 0) mine_b[oh] = 1;
+                    wave_lds_sync();
+                    if ((((unsigned long long)blk) & 15ull) == 0) {
+                        const int n4 = run >> 2;
+                        float4 *b4 = (float4 *)blk;
+                        const u32 *s4 = (const u32 *)slab;
+#pragma unroll 4
+                        for (int i = lane; i < n4; i += 64) {
+                            const u32 b = s4[i];
+                            b4[i] = make_float4((float)(b & 0xffu), (float)((b >> 8) & 0xffu), (float)((b >> 16) & 0xffu), (float)(b >> 24));
+                        }
+                        for (int i = (n4 << 2) + lane; i < run; i += 64) blk[i] = (float)slab[i];
+                    } else { // (a batch whose observation block does not start on a 16-byte boundary: ragged N)
+                        for (int i = lane; i < run; i += 64) blk[i] = (float)slab[i];
+                    }
+                    wave_lds_sync();
+                    if (of >= 0) mine_b[of] = 0;
+                    if (oh >= 0) mine_b[oh] = 0;
+                } else {
+                    // (a run that does not fit the LDS budget: large grids) zero fill of the run, then the two floats per env —
+                    // stores of one wave to one address arrive in order; envs the generic kernel takes are written by it afterwards
+                    if ((((unsigned long long)blk) & 15ull) == 0) {
+                        const float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                        const int n4 = run >> 2;
+                        float4 *b4 = (float4 *)blk;
+#pragma unroll 4
+                        for (int i = lane; i < n4; i += 64) b4[i] = z;
+                        for (int i = (n4 << 2) + lane; i < run; i += 64) blk[i] = 0.0f;
+                    } else {
+                        for (int i = lane; i < run; i += 64) blk[i] = 0.0f;
+                    }
+                    float *const o = blk + (long long)slot * elems;
+                    if (of >= 0) o[of] = 1.0f;
+                    if (oh >= 0) o[oh] = 1.0f;
                 }
             } else if (OBS == WURM_OBS_POSITIONS) { // argmax of the agent and food planes (0 if empty)
                 if (act) {
@@ -233,23 +275,27 @@ bool gridworld_lane_eligible(const StepArgs &p)
            p.obs_mode == WURM_OBS_NONE;
 }
 
+constexpr int GWL_SLAB_MAX = 16384; // bytes per wave of the image modes' byte slab (4 waves per workgroup: 64 KB)
+
 template <int OBS, int EPW>
-static void launch_epw(const StepArgs &p, hipStream_t stream)
+static void launch_epw(const StepArgs &p0, hipStream_t stream)
 {
+    StepArgs p = p0;
     const long long waves = (p.N + EPW - 1) / EPW;
     const int wpb = 4;
     const dim3 block(64 * wpb), grid((unsigned)((waves + wpb - 1) / wpb));
-    WURM_LAUNCH((gridworld_lane_rollout_kernel<OBS, EPW>), grid, block, 0, stream, p);
+    const long long slab = (OBS == WURM_OBS_DEFAULT || OBS == WURM_OBS_RAW) ? ((EPW * p.obs_elems + 15) & ~15ll) : 0;
+    p.lds_per_wave = slab <= GWL_SLAB_MAX ? (int)slab : 0;
+    WURM_LAUNCH((gridworld_lane_rollout_kernel<OBS, EPW>), grid, block, (size_t)p.lds_per_wave * wpb, stream, p);
 }
 
 template <int OBS>
 static void launch_image(const StepArgs &p, hipStream_t stream)
 {
-    // envs per wave of the image modes (WURM_GRIDWORLD_LANE_EPW pins it).  Measured at 65 536 x 9 x 9 'default'
-    // (tools/gridworld_probe.py): 16-step launch 0.233 / 0.245 / 0.245 / 0.275 ms at 8 / 16 / 32 / 64, 64-step launch
-    // 0.917 / 0.894 / 0.891 / 0.967 ms
+    // envs per wave of the image modes (WURM_GRIDWORLD_LANE_EPW pins it).  Measured at 65 536 x 9 x 9 (tools/gridworld_probe.py,
+    // one box): 'default' 16-step launch 0.299 / 0.275 / 0.263 ms at 8 / 16 / 32, 'raw' 0.203 / 0.194 / 0.192 ms
     long long epw = opt.gridworld_lane_epw;
-    if (epw != 4 && epw != 8 && epw != 16 && epw != 32 && epw != 64) epw = p.N >= 131072 ? 32 : p.N >= 32768 ? 16 : 8;
+    if (epw != 4 && epw != 8 && epw != 16 && epw != 32 && epw != 64) epw = p.N >= 65536 ? 32 : p.N >= 16384 ? 16 : 8;
     switch (epw) {
     case 4: launch_epw<OBS, 4>(p, stream); break;
     case 8: launch_epw<OBS, 8>(p, stream); break;
