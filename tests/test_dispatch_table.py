@@ -110,6 +110,10 @@ def test_grid_rows_in_an_env_dependent_order(hip):
     """WURM_GRID_ROTATE = 1 (off by default): the clock-grid kernels start every env's observation rows at an env-dependent
     row — the same bytes in another order (tools/placement_probe.py)"""
     from wurm_amd._lib import knobs
+    for k in (2, 4, 256):   # (round 5: the coarser skews, start row (env % k) * iters / k — profiles/r05_placement_probe.txt)
+        with knobs(WURM_GRID_ROTATE=k):
+            test_rollout_rows(hip, 20, 12, 'default', 0, 'grid_rollout')
+            test_step_rows(hip, 36, 8, 'default', 0, 0, 'grid_step')
     with knobs(WURM_GRID_ROTATE=1):
         test_rollout_rows(hip, 20, 12, 'default', 0, 'grid_rollout')
         test_rollout_rows(hip, 36, 9, 'raw', 0, 'grid_rollout')

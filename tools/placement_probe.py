@@ -46,6 +46,7 @@ for j in range(8):
     p = rot[-1][1]['observations'].data_ptr()
     rot = min(t for t, _ in rot)
     same = min(one(0)[0] for _ in range(3))
+    skews = {k: min(one(k)[0] for _ in range(3)) for k in (2, 4, 256)} if not CFG4 else {}
     x = torch.empty(numel, dtype=torch.float32, device=dev)   # takes that block out of the cache: the next launches get another
     assert x.data_ptr() == p
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -54,5 +55,7 @@ for j in range(8):
         e0.record(); x.fill_(0.5); e1.record(); torch.cuda.synchronize()
         fills.append(e0.elapsed_time(e1))
     held.append(x)
-    print(f'block {j} at 0x{p:x}: rollout, every env\'s rows in the same order {same:.3f} ms, rows started at an env-dependent row {rot:.3f} ms;   '
+    print(f'block {j} at 0x{p:x}: rollout, every env\'s rows in the same order {same:.3f} ms, rows started at an env-dependent row {rot:.3f} ms, '
+          + ''.join(f'skew by id mod {k} {v:.3f} ms, ' for k, v in skews.items()) +
+          f'  '
           f'linear fill of the same block {min(fills):.3f} ms = {numel * 4 / min(fills) / 1e9:.2f} TB/s', flush=True)

@@ -245,7 +245,12 @@ __device__ __forceinline__ Grid make_grid(const StepArgs &p, int wave, long long
     g.lane = (int)(threadIdx.x & 63u);
     g.rcpS = 1.0f / (float)p.S;
     g.ex = (cell_t *)grid_lds_raw + wave * (g.iters * 256);
-    g.rot = (p.grid_rotate && env >= 0) ? (int)((unsigned long long)env % (unsigned)g.iters) : 0;
+    // WURM_GRID_ROTATE: 0 = every env's rows in the same order (default), 1 = start row env % iters, k >= 2 = the coarser
+    // skew (env % k) * iters / k — k start rows spread over the env's image by id modulo k (round 5 probe: k = 2, 4, 256)
+    g.rot = 0;
+    if (p.grid_rotate == 1 && env >= 0) g.rot = (int)((unsigned long long)env % (unsigned)g.iters);
+    else if (p.grid_rotate >= 2 && env >= 0)
+        g.rot = (int)(((unsigned long long)env % (unsigned)p.grid_rotate) * (unsigned)g.iters / (unsigned)p.grid_rotate);
     return g;
 }
 
@@ -792,7 +797,7 @@ static bool grid_aligned(const StepArgs &p)
 hipError_t launch_grid_rollout(const StepArgs &p_in, hipStream_t stream)
 {
     StepArgs p = p_in;
-    p.grid_rotate = opt.grid_rotate != 0;
+    p.grid_rotate = (int)opt.grid_rotate;
     const int C = p.S * p.S, iters = (C + 255) >> 8;
     const int wpb = p.N <= 4096 ? 1 : 4;
     dim3 block(64 * wpb), grid((unsigned)((p.N + wpb - 1) / wpb));
@@ -813,7 +818,7 @@ hipError_t launch_grid_rollout(const StepArgs &p_in, hipStream_t stream)
 hipError_t launch_grid_step(const StepArgs &p_in, hipStream_t stream)
 {
     StepArgs p = p_in;
-    p.grid_rotate = opt.grid_rotate != 0;
+    p.grid_rotate = (int)opt.grid_rotate;
     const int C = p.S * p.S, iters = (C + 255) >> 8;
     const int wpb = p.N <= 4096 ? 1 : 4;
     dim3 block(64 * wpb), grid((unsigned)((p.N + wpb - 1) / wpb));
