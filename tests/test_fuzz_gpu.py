@@ -14,7 +14,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 
 @pytest.mark.parametrize('kind,seed,cases', [('single', 101, 800), ('fused', 106, 700), ('grid', 102, 300), ('multi', 103, 800),
                                              ('lean', 104, 500), ('lane', 107, 1200), ('policy', 105, 150), ('resident', 108, 1000),
-                                             ('multi_resident', 109, 500), ('multi_group', 110, 400)])
+                                             ('multi_resident', 109, 500), ('multi_group', 110, 400), ('grid_lane', 111, 600)])
 def test_random_cases(kind, seed, cases):
     import fuzz_parity
     rng = np.random.RandomState(seed)

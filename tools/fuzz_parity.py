@@ -128,7 +128,8 @@ def fuzz_resident(rng):
     S = int(rng.choice([9, 9, 9, 12, 14, 20, 25, 36]))
     if S == 9:    # lane_resident.hpp: 32 bytes per env
         N = int(rng.choice([1, 3, 15, 16, 17, 31, 33, 63, 64, 65, 100, 129, 200, 257]))
-        mode = ['partial_2', 'partial_2', 'none', 'one_channel', 'one_channel', 'default', 'positions', 'partial_0', 'partial_1'][rng.randint(9)]
+        mode = ['partial_2', 'partial_2', 'none', 'one_channel', 'one_channel', 'default', 'positions', 'partial_0', 'partial_1',
+                'raw', 'raw', 'partial_3', 'partial_3'][rng.randint(13)]
     else:         # grid_rollout.hip: the clock grid + a record per env, every observation mode
         N = int(rng.randint(1, 24))
         mode = ['default', 'raw', 'one_channel', 'positions', f'partial_{rng.randint(1, 7)}', 'none'][rng.randint(6)]
@@ -227,10 +228,11 @@ def fuzz_lane(rng):
     hand-edited states between launches (they must fall back to the generic path inside the launch)."""
     epw = int(rng.choice([4, 8, 16, 32, 64]))
     N = int(rng.choice([1, 3, epw - 1, epw, epw + 1, 2 * epw + 5, 3 * epw, 200]))
-    # (round 4: one_channel / default through bit planes, positions / partial_0 / partial_1 float by float; partial_3 is routed
-    # to the one-env-per-wave kernels inside the same entry point)
+    # (round 4: one_channel / default through bit planes, positions / partial_0 / partial_1 float by float; round 5: partial_3
+    # through 7 x 7 bit planes, raw through a byte slab; partial_4 is routed to the one-env-per-wave kernels inside the same
+    # entry point)
     mode = ['partial_2', 'partial_2', 'none', 'one_channel', 'one_channel', 'default', 'default', 'positions', 'partial_0',
-            'partial_1', 'partial_3'][rng.randint(11)]
+            'partial_1', 'partial_3', 'partial_3', 'raw', 'raw', 'partial_4'][rng.randint(15)]
     seed, off = int(rng.randint(1 << 30)), int(rng.randint(1 << 40))
     desc = f'lane epw={epw} N={N} mode={mode} seed={seed} off={off}'
     if os.environ.get('WURM_FUZZ_VERBOSE'):
@@ -320,6 +322,60 @@ def fuzz_grid(rng):
     for k in ro:
         same(ro[k], rh[k], f'{desc} {k}')
     same(eo, eh, desc + ' state')
+    return desc
+
+
+def fuzz_grid_lane(rng):
+    """SimpleGridworld rollouts through the one-env-per-lane kernel (gridworld_lane.hip), forced at small batch sizes: every
+    envs-per-wave of the image modes (runs composed in LDS and runs beyond the slab budget), ragged and odd batches, chained
+    launches, hand-made states between launches that must go to the one-env-per-wave kernel in the second launch (two
+    foods, no agent, food under the agent) and ones that stay in the domain (no food, food or agent on the border ring)."""
+    S = int(rng.choice([5, 7, 9, 9, 9, 12, 20, 33, 64]))
+    epw = int(rng.choice([-1, 4, 8, 16, 32, 64]))
+    N = int(rng.choice([1, 3, 63, 64, 65, 131, 200, 257])) if S <= 20 else int(rng.randint(1, 40))
+    mode = ['default', 'default', 'raw', 'raw', 'positions', 'none'][rng.randint(6)]
+    start = (int(rng.randint(1, S - 1)), int(rng.randint(1, S - 1)))
+    seed, off = int(rng.randint(1 << 30)), int(rng.randint(1 << 40))
+    desc = f'grid_lane S={S} N={N} epw={epw} mode={mode} start={start} seed={seed} off={off}'
+    if os.environ.get('WURM_FUZZ_VERBOSE'):
+        print('start:', desc, flush=True)
+    o, h = OracleBackend(seed, off), HipBackend(seed, off)
+    eo, eh = np.zeros((N, 2, S, S), np.float32), np.zeros((N, 2, S, S), np.float32)
+    o.grid_reset(eo, np.ones(N), start, 'none'); h.grid_reset(eh, np.ones(N), start, 'none')
+    o.call = h.call = int(rng.randint(1 << 50))
+    old = {'WURM_LANE_ROLLOUT_MIN_ENVS': _lib.set_option('WURM_LANE_ROLLOUT_MIN_ENVS', 0),
+           'WURM_GRIDWORLD_LANE_EPW': _lib.set_option('WURM_GRIDWORLD_LANE_EPW', epw)}
+    try:
+        for launch in range(int(rng.randint(1, 4))):
+            T = int(rng.choice([1, 2, 3, 4, 5, 8, 17, 40, 90]))
+            a = rng.randint(0, 4, (T, N)).astype(np.int64 if rng.rand() < 0.7 else np.int32)
+            if rng.rand() < 0.3:
+                wild = rng.rand(T, N) < 0.2
+                a[wild] = rng.randint(-50, 50, int(wild.sum()))
+            ro, rh = o.grid_rollout(eo, a.copy(), start, mode), h.grid_rollout(eh, a.copy(), start, mode)
+            assert _lib.lib().wurm_single_last_route().decode() == 'gridworld_lane', desc
+            for k in ro:
+                same(ro[k], rh[k], f'{desc} launch {launch} T={T} {k}')
+            same(eo, eh, f'{desc} launch {launch} state')
+            for _ in range(int(rng.randint(0, 4))):   # hand-made states for the next launch
+                i, kind = int(rng.randint(N)), int(rng.randint(6))
+                y, x = int(rng.randint(1, S - 1)), int(rng.randint(1, S - 1))
+                if kind == 0:
+                    eo[i, 0, y, x] = 1                                   # (maybe) a second food
+                elif kind == 1:
+                    eo[i, 1] = 0                                         # no agent
+                elif kind == 2:
+                    eo[i, 0] = eo[i, 1]                                  # the food under the agent
+                elif kind == 3:
+                    eo[i, 0] = 0                                         # no food
+                elif kind == 4:
+                    eo[i, 0] = 0; eo[i, 0, 0, x] = 1                     # the only food on the border ring
+                else:
+                    eo[i, 1] = 0; eo[i, 1, y, 0] = 1                     # the agent on the border ring
+                eh[i] = eo[i]
+    finally:
+        for k, v in old.items():
+            _lib.set_option(k, v)
     return desc
 
 
@@ -723,11 +779,11 @@ def fuzz_single_mirror_class(rng):
 
 
 FAMILIES = {'single': fuzz_single, 'fused': fuzz_fused, 'resident': fuzz_resident, 'lean': fuzz_lean, 'lane': fuzz_lane,
-            'policy': fuzz_policy, 'grid': fuzz_grid, 'multi': fuzz_multi, 'multi_resident': fuzz_multi_resident,
+            'policy': fuzz_policy, 'grid': fuzz_grid, 'grid_lane': fuzz_grid_lane, 'multi': fuzz_multi, 'multi_resident': fuzz_multi_resident,
             'multi_group': fuzz_multi_group, 'multi_mirror_class': fuzz_multi_mirror_class,
             'single_mirror_class': fuzz_single_mirror_class}
-WEIGHTS = {'single': 0.09, 'fused': 0.09, 'resident': 0.13, 'lean': 0.05, 'lane': 0.15, 'policy': 0.03, 'grid': 0.04,
-           'multi': 0.11, 'multi_resident': 0.09, 'multi_group': 0.14, 'multi_mirror_class': 0.08, 'single_mirror_class': 0.08}
+WEIGHTS = {'single': 0.08, 'fused': 0.08, 'resident': 0.13, 'lean': 0.04, 'lane': 0.15, 'policy': 0.03, 'grid': 0.03, 'grid_lane': 0.07,
+           'multi': 0.10, 'multi_resident': 0.08, 'multi_group': 0.12, 'multi_mirror_class': 0.07, 'single_mirror_class': 0.07}
 
 
 def library_sha256():
