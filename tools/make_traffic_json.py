@@ -72,9 +72,9 @@ detail = {
     'resident_step_65536x9_default_reset_obs': traffic('void wurm::lane_resident_step_kernel<32, 2, -3, true>', 131072),
     'rollout_65536x9_raw_chunk32': traffic('void wurm::lane_rollout_kernel<32, -5, false>', 131072),
     'rollout_65536x9_partial_3_chunk32': traffic('void wurm::lane_rollout_kernel<32, -4, false>', 131072),
-    # round 5: SimpleGridworld one env per lane (16 envs per wave at this batch size): zero fill + two floats per env
-    'rollout_65536x9_gridworld_default_chunk16': traffic('void wurm::(anonymous namespace)::gridworld_lane_rollout_kernel<0, 16>', 262144),
-    'rollout_65536x9_gridworld_raw_chunk16': traffic('void wurm::(anonymous namespace)::gridworld_lane_rollout_kernel<1, 16>', 262144),
+    # round 5: SimpleGridworld one env per lane (32 envs per wave at this batch size): zero fill + two floats per env
+    'rollout_65536x9_gridworld_default_chunk16': traffic('void wurm::(anonymous namespace)::gridworld_lane_rollout_kernel<0, 32>', 131072),
+    'rollout_65536x9_gridworld_raw_chunk16': traffic('void wurm::(anonymous namespace)::gridworld_lane_rollout_kernel<1, 32>', 131072),
     'multi_rollout_cfg4prime_4096x25_k4_partial5_chunk16': traffic('void wurm::multi_rollout_kernel<false, false, 4>', 262144),
     'fused_step_512x9_partial2': traffic('void wurm::fused_step_kernel<2, true>', 32768),
     'fused_step_8192x9_partial2': traffic('void wurm::fused_step_kernel<2, true>', 524288),
