@@ -585,7 +585,8 @@ def extra_measurements(device):
         out[key] = {'value': env.num_envs * chunk / (q(0.5) * 1e-3), 'ms_p10': round(q(0.1), 4), 'ms_p50': round(q(0.5), 4),
                     'ms_p90': round(q(0.9), 4), 'ms_min': round(times[0], 4), 'ms_max': round(times[-1], 4),
                     'allocations': n_blocks, 'batch_steps_per_launch': chunk}
-        del held
+        del held, o
+        torch.cuda.empty_cache()        # (the blocks go back to the driver: nothing measured later sees this extra's allocations)
         return out[key]
 
     per_call, rollout, alloc_spread = guarded(per_call), guarded(rollout), guarded(alloc_spread)
@@ -701,9 +702,6 @@ def extra_measurements(device):
             lambda c: (c, 8192), 4, 16, 6, 'BASELINE configs[4]: SingleSnake 8192x36x36 default-RGB obs, fused rollout, 16 '
             'batch-steps per launch (15 552 B of observation per env-step)', traffic_key='rollout_cfg5_8192x36_default_chunk16')
 
-    alloc_spread('rollout_cfg5_alloc_spread', lambda: SingleSnake(8192, 36, observation_mode='default', device=device, seed=0),
-                 lambda c: (c, 8192), 4, 16, 10, 'BASELINE configs[4], the 16-step launch over 10 fresh output allocations (2 GB each)')
-
     # ---- cfg3 (65 536 x 9 x 9) in the other observation modes (the reference's constructor default is one_channel)
     for mode in ('one_channel', 'default', 'raw', 'partial_3'):
         rollout(f'rollout_65536x9_{mode}', lambda: SingleSnake(65536, SIZE, observation_mode=mode, device=device, seed=0),
@@ -769,8 +767,6 @@ def extra_measurements(device):
     rollout('rollout_cfg3_65536', lambda: SingleSnake(65536, SIZE, observation_mode=OBS_MODE, device=device, seed=0),
             lambda c: (c, 65536), 4, 64, 8, 'BASELINE configs[2] whole (65536 envs) on ONE GPU, fused rollout, 64 batch-steps per launch',
             traffic_key='rollout_65536x9_chunk64')
-    alloc_spread('rollout_cfg3_alloc_spread', lambda: SingleSnake(65536, SIZE, observation_mode=OBS_MODE, device=device, seed=0),
-                 lambda c: (c, 65536), 4, 64, 10, 'BASELINE configs[2] whole on one GPU, the 64-step launch over 10 fresh output allocations')
     for mode, steps in (('default', 16), ('raw', 16), ('positions', 64)):
         rollout(f'rollout_65536x9_gridworld_{mode}',
                 lambda: SimpleGridworld(65536, 9, start_location=(4, 4), observation_mode=mode, device=device, seed=0),
@@ -801,6 +797,12 @@ def extra_measurements(device):
     per_call('per_call_512', lambda: SingleSnake(N, SIZE, observation_mode=OBS_MODE, device=device, seed=0), a1, same, T,
              "cfg2 per call in the reference's own call form: `obs, r, d, info = env.step(a); env.reset(d)`", reset_kw={})
     out['host_calibration_after'] = host_calibration(device)
+    # ---- LAST (they leave 20 GB of cached blocks behind, which changes where every later output lands: measured, the cfg4
+    # per-call loop went from 34 to 39-41 us behind them): the launch time of the HBM-bound rollouts by output allocation
+    alloc_spread('rollout_cfg5_alloc_spread', lambda: SingleSnake(8192, 36, observation_mode='default', device=device, seed=0),
+                 lambda c: (c, 8192), 4, 16, 10, 'BASELINE configs[4], the 16-step launch over 10 fresh output allocations (2 GB each)')
+    alloc_spread('rollout_cfg3_alloc_spread', lambda: SingleSnake(65536, SIZE, observation_mode=OBS_MODE, device=device, seed=0),
+                 lambda c: (c, 65536), 4, 64, 10, 'BASELINE configs[2] whole on one GPU, the 64-step launch over 10 fresh output allocations')
     return out
 
 
