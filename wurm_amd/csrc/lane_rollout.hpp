@@ -184,8 +184,8 @@ __device__ __forceinline__ void lr_build_tables(float4 *tab, u64 *wint)
 // constructor default: single_snake.py:55-65), 'positions' (4) and 'partial_n' with n != 2 (3 (2n+1)^2) — written FLOAT BY
 // FLOAT from the step records: lane = one float of a step's row of EPW consecutive observations (256 contiguous bytes per
 // store instruction), its (channel, row, column) read from a workgroup table, its value a function of the record's
-// occupancy mask / head / food codes (single_snake.py:104-195).  'raw' needs the body VALUES and stays with the
-// one-env-per-wave kernels.
+// occupancy mask / head / food codes (single_snake.py:104-195).  ('raw' needs the body VALUES: LR_OBS_RAW below, round 5;
+// 'default' / 'one_channel' / 'partial_3' have their own bit-plane forms since.)
 constexpr int LR_OBS_GENERIC = -1; // OBSK of lane_rollout_kernel: p.obs_mode / p.obs_n at run time
 
 // lut[r] = channel | a << 2 | b << 6 of float r of one env's observation: (a, b) = (row, column) of the grid for the grid
