@@ -201,7 +201,7 @@ class MultiSnake(object):
     _chk_has_after = False
     _chk_armed_at, _chk_void_at = 1 << 62, -1
     _check_calls = _check_step = 0
-    _rewards_t = _boost_t = _mc_mode = _info = None
+    _rewards_t = _boost_t = _mc_mode = _info = _rewards_src = None
     _rewards_at = _boost_at = 0
     _slab = None            # (out_f32, out_u8) of the current output slab
     _mc_ready = False
@@ -393,7 +393,7 @@ class MultiSnake(object):
     _DERIVED = ('_mc', '_sl', '_mc_addr', '_fs', '_pend', '_cfg_cache', '_mc_cfg', '_mc_ready', '_mc_mode', '_mirror',
                 '_mirror_off', '_lazy_mirror', '_mirror_why', '_watched', '_write_outs', '_touches', '_chk', '_chk_has_after',
                 '_chk_armed_at', '_chk_void_at', '_check_calls', '_check_step', '_slab', '_stor', '_keys', '_get_device',
-                '_rewards_t', '_boost_t', '_rewards_at', '_boost_at', '_info', '_cfg_dirty')
+                '_rewards_t', '_boost_t', '_rewards_at', '_boost_at', '_rewards_src', '_info', '_cfg_dirty')
 
     def __getstate__(self):
         self._state()   # (applies a postponed reset, writes a lazy mirror out)
@@ -477,6 +477,8 @@ class MultiSnake(object):
         st = self._fs.steps
         if self._rewards_at != st:  # (the env-major block at the start of the last step's packed floats)
             self._rewards_t, self._rewards_at = self._slab[0][self._fs.slot - 1].view(-1)[:self.num_envs * self.num_snakes], st
+        elif self._rewards_t is None:  # (after a rollout: its last step's (K, N) block, env-major on demand)
+            self._rewards_t, self._rewards_src = self._rewards_src.t().reshape(-1), None
         return self._rewards_t
 
     @rewards.setter
@@ -976,8 +978,11 @@ class MultiSnake(object):
                 _lib.u64(self._next_call(2 * T)), _lib.i64(self.env_offset), None, None, _lib.stream_ptr(self.device.index))
         _lib.check(rc, 'MultiSnake.rollout')
         if T > 0:
-            self.rewards = out_f[-1, 0].t().reshape(-1)
-        self._env_lifetimes.zero_()
+            # (reference :105: env-major; the last step's rewards are agent-major here — transposed when somebody asks for
+            # the attribute, not by a kernel between two rollout launches)
+            self._rewards_src, self._rewards_t, self._rewards_at = out_f[-1, 0], None, self._fs.steps
+        if self._lifetimes_touched:  # (else it is all zeros already: env_lifetimes' docstring)
+            self._env_lifetimes.zero_()
         if self._half:
             obs = obs.to(torch.half) if obs is not None else None
             out_h = out_f[:, 1:].to(torch.half)
