@@ -144,6 +144,12 @@ def test_gridworld_calls_are_generic_and_large_rollouts_take_the_lane_row(hip):
         with knobs(WURM_LANE_ROLLOUT_MIN_ENVS=min_envs):
             h.grid_rollout(envs, np.zeros((3, 16), np.int64), (4, 4), mode)
             assert _route() == row, (mode, min_envs)
+    for mode, min_envs, row in [('default', 0, 'gridworld_lane_step'), ('raw', 0, 'gridworld_lane_step'),
+                                ('positions', 0, 'gridworld_lane_step'), ('none', 0, 'gridworld_lane_step'),
+                                ('default', 17, 'generic'), ('default', 16, 'gridworld_lane_step')]:
+        with knobs(WURM_LANE_STEP_MIN_ENVS=min_envs):  # (the per-call step: 12 288 envs and more by default)
+            h.grid_step(envs, np.zeros(16, np.int64), mode)
+            assert _route() == row, (mode, min_envs)
     with knobs(WURM_LANE_ROLLOUT_MIN_ENVS=0):  # recorded outcomes: the one-env-per-wave kernel consumes them
         h.grid_rollout(envs, np.zeros((3, 16), np.int64), (4, 4), 'default', inject_food=np.zeros((3, 16), np.int32),
                        inject_reset=np.zeros((3, 16), np.int32))

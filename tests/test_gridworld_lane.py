@@ -186,3 +186,128 @@ def test_a_large_batch_at_the_default_threshold(hip):
     from wurm_amd import _lib
     assert _lib.lib().wurm_get_option(b'WURM_LANE_ROLLOUT_MIN_ENVS') <= N
     _both(hip, envs, actions, (4, 4), 'default', min_envs=_lib.lib().wurm_get_option(b'WURM_LANE_ROLLOUT_MIN_ENVS'))
+
+
+# ---- the per-call step of large batches (gridworld_lane_step_kernel): wurm_grid_step_reset's deferred form and the plain step
+
+def _cmp_step(ro, rh, t):
+    for k in ro:
+        _same(ro[k], rh[k], f'{k} t={t}')
+
+
+@pytest.mark.parametrize('mode', ['default', 'raw', 'positions', 'none'])
+@pytest.mark.parametrize('N,S,epw', [(200, 9, -1), (131, 9, 32), (65, 9, 64), (70, 5, 4), (33, 12, 16), (9, 30, -1), (257, 7, 8), (6, 40, -1)])
+def test_per_call_step_with_the_postponed_reset(hip, N, S, epw, mode):
+    """`step(a); reset(done)` as one launch per iteration in the deferred form: the previous call's done flags rebuild envs
+    in front of the step (pre_call), the reset observation of THIS call's finished envs comes back as obs_after (call + 1)
+    without being stored; every third call without obs_after, every fourth without the postponed reset (finished envs are
+    stepped again: an agent on the ring walks on, or off the grid and vanishes — that env goes to the one-env-per-wave kernel
+    from then on), hand-made states in between"""
+    from wurm_amd._lib import knobs
+    T = 60
+    rng = np.random.RandomState(N + S)
+    start = (S // 2, S // 2)
+    o, h = OracleBackend(seed=12, env_offset=77), hip(seed=12, env_offset=77)
+    eo = _fresh(o, N, S, start)
+    eh = eo.copy()
+    prev = None
+    deaths = lane_calls = 0
+    with knobs(WURM_LANE_STEP_MIN_ENVS=0, WURM_GRIDWORLD_LANE_EPW=epw):
+        for t in range(T):
+            a = rng.randint(-3, 9, size=N).astype(np.int64 if t % 2 else np.int32)
+            ao, ah = a.copy(), a.copy()
+            kw = dict(call=1 + 2 * t, pre_done=prev, pre_call=2 * t, want_obs_after=(t % 3 != 1), grid=start)
+            ro = o.single_step_reset(eo, ao, mode, **kw)
+            rh = h.single_step_reset(eh, ah, mode, **kw)
+            lane_calls += _route() == 'gridworld_lane_step'
+            _same(ah, ao, f'actions t={t}')
+            _same(eh, eo, f'state t={t}')
+            _cmp_step(ro, rh, t)
+            deaths += int(ro['done'].sum())
+            prev = ro['done'] if t % 4 != 3 else None
+            if t % 9 == 5:   # hand-made states: two foods, no food, the food under the agent, the only food on the ring
+                eo[0, 0, 1, 1] = 1
+                eo[1 % N, 0] = 0
+                eo[2 % N, 0] = eo[2 % N, 1]
+                eo[N - 1, 0] = 0
+                eo[N - 1, 0, 0, 2] = 1
+                eh[...] = eo
+    assert deaths > 0 or S > 12
+    # 30 x 30 'default' fits the 16 KB byte slab at four envs per wave; 40 x 40 'default' (4 x 19 200 bytes) at none: those
+    # calls stay with the one-env-per-wave kernel
+    assert lane_calls == (0 if (S == 40 and mode == 'default') else T)
+
+
+def test_per_call_plain_step_and_the_immediate_form(hip):
+    """the plain wurm_grid_step (no reset in the call) takes the lane kernel too; the immediate form (post_reset: the rebuilt
+    state is stored by the same launch) stays with the one-env-per-wave kernel"""
+    from wurm_amd._lib import knobs
+    N, S, start = 150, 9, (4, 4)
+    rng = np.random.RandomState(4)
+    o, h = OracleBackend(seed=3), hip(seed=3)
+    eo = _fresh(o, N, S, start)
+    eh = eo.copy()
+    o.call = h.call = 1
+    with knobs(WURM_LANE_STEP_MIN_ENVS=0):
+        for t in range(30):
+            a = rng.randint(0, 4, size=N).astype(np.int64)
+            ro, rh = o.grid_step(eo, a.copy(), 'default'), h.grid_step(eh, a.copy(), 'default')
+            assert _route() == 'gridworld_lane_step'
+            for x, y in zip(ro, rh):
+                _same(x, y, f'plain step t={t}')
+            _same(eo, eh, f'state t={t}')
+            o.call = h.call = 1000 + t
+            o.grid_reset(eo, ro[2], start, 'none'); h.grid_reset(eh, rh[2], start, 'none')
+        for t in range(20):
+            a = rng.randint(0, 4, size=N).astype(np.int64)
+            kw = dict(call=5000 + 2 * t, post_reset=True, want_obs_after=True, grid=start)
+            ro = o.single_step_reset(eo, a.copy(), 'raw', **kw)
+            rh = h.single_step_reset(eh, a.copy(), 'raw', **kw)
+            assert _route() == 'generic'
+            _cmp_step(ro, rh, t)
+            _same(eo, eh, f'state t={t}')
+    kw = dict(call=9001, pre_done=None, pre_call=9000, want_obs_after=True, grid=start)   # below the threshold: generic
+    h.single_step_reset(eh, rng.randint(0, 4, size=N).astype(np.int64), 'default', **kw)
+    assert _route() == 'generic'
+
+
+def test_class_loop_at_the_default_threshold():
+    """SimpleGridworld(16 384 envs) through the unchanged per-call loop `env.step(a); env.reset(done)` and a rollout: the C
+    step machine's launches take the lane kernel (12 288 envs and more) — compared with the same loop on the
+    one-env-per-wave kernels (themselves compared with the oracle above and in tests/test_hip_fused_step.py): identical
+    outputs and state, also across an in-place edit of the state the caller holds"""
+    import torch
+    from wurm_amd import _lib
+    from wurm_amd._lib import knobs
+    from wurm_amd.envs import SimpleGridworld
+    N, S, T, start, seed = 16384, 9, 40, (4, 4), 21
+    g = torch.Generator(device='cuda:0').manual_seed(3)
+    acts = torch.randint(0, 4, (T, N), generator=g, device='cuda:0')
+
+    def loop(min_envs, want_route):
+        routes, outs = set(), []
+        with knobs(WURM_LANE_STEP_MIN_ENVS=min_envs, WURM_LANE_ROLLOUT_MIN_ENVS=min_envs):
+            env = SimpleGridworld(N, S, start_location=start, observation_mode='default', device='cuda:0', seed=seed)
+            for t in range(T):
+                obs, r, d, info = env.step(acts[t].clone())
+                routes.add(_lib.lib().wurm_single_last_route().decode())
+                back = env.reset(d) if t % 3 else env.reset(d, return_observations=False)
+                outs.append([x.clone() for x in (obs, r, d, info['edge_collision'])] + ([back.clone()] if back is not None else []))
+                if t == 17:
+                    e = env.envs
+                    e[5, 0] = 0
+                    e[5, 0, 2, 6] = 1        # the food of env 5 moves; version counter bumps
+                    del e
+                if t == 25:
+                    ro = env.rollout(acts[:3].clone())
+                    outs.append([ro['observations'].clone(), ro['rewards'].clone(), ro['dones'].clone()])
+            outs.append([env.envs.clone()])
+        assert routes == want_route, routes
+        return outs
+
+    a, b = loop(None, {'gridworld_lane_step'}), loop(1 << 40, {'generic'})
+    assert len(a) == len(b)
+    for k, (x, y) in enumerate(zip(a, b)):
+        assert len(x) == len(y)
+        for i, (u, v) in enumerate(zip(x, y)):
+            assert torch.equal(u, v), f'record {k} output {i}'

@@ -344,6 +344,7 @@ def fuzz_grid_lane(rng):
     o.grid_reset(eo, np.ones(N), start, 'none'); h.grid_reset(eh, np.ones(N), start, 'none')
     o.call = h.call = int(rng.randint(1 << 50))
     old = {'WURM_LANE_ROLLOUT_MIN_ENVS': _lib.set_option('WURM_LANE_ROLLOUT_MIN_ENVS', 0),
+           'WURM_LANE_STEP_MIN_ENVS': _lib.set_option('WURM_LANE_STEP_MIN_ENVS', 0),
            'WURM_GRIDWORLD_LANE_EPW': _lib.set_option('WURM_GRIDWORLD_LANE_EPW', epw)}
     try:
         for launch in range(int(rng.randint(1, 4))):
@@ -373,6 +374,21 @@ def fuzz_grid_lane(rng):
                 else:
                     eo[i, 1] = 0; eo[i, 1, y, 0] = 1                     # the agent on the border ring
                 eh[i] = eo[i]
+        # ... and the per-call step of the same file (gridworld_lane_step_kernel): the deferred form with / without the reset
+        # observation, iterations without any reset, from whatever state the launches above left
+        call, prev, prev_call = int(rng.randint(1 << 40)) * 2, None, None
+        for t in range(int(rng.randint(0, 25))):
+            a = rng.randint(0, 4, N).astype(np.int64 if rng.rand() < 0.7 else np.int32)
+            style = int(rng.randint(1, 4))   # 1: deferred reset, 2: deferred + obs_after, 3: no reset at all
+            kw = dict(call=call, grid=start)
+            if style in (1, 2):
+                kw.update(pre_done=prev, pre_call=prev_call, want_obs_after=(style == 2))
+            ro, rh = o.single_step_reset(eo, a.copy(), mode, **kw), h.single_step_reset(eh, a.copy(), mode, **kw)
+            same(eo, eh, f'{desc} per call t={t} style={style} state')
+            for k in ro:
+                same(ro[k], rh[k], f'{desc} per call t={t} style={style} {k}')
+            prev, prev_call = (None, None) if style == 3 else (ro['done'], call + 1)
+            call += 2
     finally:
         for k, v in old.items():
             _lib.set_option(k, v)

@@ -261,6 +261,190 @@ __global__ __launch_bounds__(256) void gridworld_lane_rollout_kernel(StepArgs p)
     }
 }
 
+
+// ---- the per-call step (`obs, r, d, info = env.step(a); env.reset(d)`, one launch per iteration) for large batches: the same
+// lane-per-env transition under fused_step_kernel's contract without post_reset (single_snake.hip: fused_step_env) — an env
+// flagged in p.done_in is rebuilt in front of the step with call = p.pre_call, the step uses p.call, p.obs is the stepped
+// state's observation, p.obs_after (nullable) what reset(done) will return: the observation once finished envs are rebuilt
+// with call + 1 — not stored, the next launch's postponed reset recreates it from the same counters.  Also serves the plain
+// wurm_grid_step (no done_in, no obs_after).  Envs outside the domain: GRID_SKIPPED, the one-env-per-wave kernel in a
+// second launch.
+__device__ __forceinline__ bool gwl_interior(const GridLaneGeo &g, int c)
+{
+    if (c < 0) return false;
+    const int y = div_size(c, g.rcpS), x = c - y * g.S;
+    return y >= 1 && y <= g.S - 2 && x >= 1 && x <= g.S - 2;
+}
+
+// the wave's run of one image observation: bytes of `slab` (zero but for the bytes at of / oh of this lane's env) -> floats
+template <int OBS>
+__device__ __forceinline__ void gwl_emit_image(const GridLaneGeo &g, float *blk, unsigned char *slab, int slot, int elems, int run,
+                                               int lane, bool act, int hc, int fc)
+{
+    int of = -1, oh = -1;
+    if (act) {
+        if (OBS == WURM_OBS_RAW) { of = fc; oh = hc >= 0 ? g.C + hc : -1; }
+        else { of = gwl_interior(g, fc) ? fc : -1; oh = gwl_interior(g, hc) ? g.C + hc : -1; }
+    }
+    unsigned char *const mine_b = slab + slot * elems;
+    if (of >= 0) mine_b[of] = 1;
+    if (oh >= 0) mine_b[oh] = 1;
+    wave_lds_sync();
+    if ((((unsigned long long)blk) & 15ull) == 0) {
+        const int n4 = run >> 2;
+        float4 *b4 = (float4 *)blk;
+        const u32 *s4 = (const u32 *)slab;
+#pragma unroll 4
+        for (int i = lane; i < n4; i += 64) {
+            const u32 b = s4[i];
+            b4[i] = make_float4((float)(b & 0xffu), (float)((b >> 8) & 0xffu), (float)((b >> 16) & 0xffu), (float)(b >> 24));
+        }
+        for (int i = (n4 << 2) + lane; i < run; i += 64) blk[i] = (float)slab[i];
+    } else {
+        for (int i = lane; i < run; i += 64) blk[i] = (float)slab[i];
+    }
+    wave_lds_sync();
+    if (of >= 0) mine_b[of] = 0;
+    if (oh >= 0) mine_b[oh] = 0;
+}
+
+__device__ __forceinline__ void gwl_emit_positions(const GridLaneGeo &g, float *o, bool obs16, int hc, int fc)
+{
+    const int h = hc < 0 ? 0 : hc, f = fc < 0 ? 0 : fc;
+    const int hy = div_size(h, g.rcpS), fy = div_size(f, g.rcpS);
+    const float4 v = make_float4((float)hy, (float)(h - hy * g.S), (float)fy, (float)(f - fy * g.S));
+    if (obs16) *(float4 *)o = v;
+    else { o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
+}
+
+template <int OBS, int EPW>
+__global__ __launch_bounds__(256) void gridworld_lane_step_kernel(StepArgs p)
+{
+    __shared__ GridLaneScan scans[4];
+    extern __shared__ __attribute__((aligned(16))) unsigned char gwl_lds[];
+    const int lane = (int)(threadIdx.x & 63u), wave = uniform((int)(threadIdx.x >> 6)), wpb = (int)(blockDim.x >> 6);
+    const long long env0 = (xcd_block(blockIdx.x, gridDim.x) * wpb + wave) * EPW;
+    if (env0 >= p.N) return;
+    const int slot = lane & (EPW - 1);
+    const long long env = env0 + slot;
+    const bool present = env < p.N && lane < EPW;
+    const int nv = (int)min((long long)EPW, p.N - env0);
+    GridLaneGeo g;
+    g.S = p.S; g.C = p.S * p.S; g.I = p.S - 2;
+    g.rcpS = 1.0f / (float)g.S;
+    g.rcpI = g.I > 0 ? 1.0f / (float)g.I : 1.0f;
+    const int S = g.S, C = g.C;
+
+    // ---- the state: as the rollout kernel's prologue
+    GridLaneScan &sc = scans[wave];
+    sc.cnt[0][lane] = 0; sc.cnt[1][lane] = 0; sc.pos[0][lane] = -1; sc.pos[1][lane] = -1; sc.bad[lane] = 0;
+    wave_lds_sync();
+    float *const env_run = p.envs + env0 * 2 * C;
+    {
+        const int total = nv * 2 * C;
+        const unsigned per_env = 2u * (unsigned)C;
+        auto note = [&](int i, float v) {
+            if (v != 0.0f) {
+                const unsigned e = (unsigned)i / per_env, r = (unsigned)i - e * per_env;
+                const int plane = r >= (unsigned)C ? 1 : 0;
+                atomicAdd(&sc.cnt[plane][e], 1);
+                sc.pos[plane][e] = (int)r - plane * C;
+                if (v != 1.0f) sc.bad[e] = 1;
+            }
+        };
+        if ((((unsigned long long)env_run) & 15ull) == 0) {
+            const int n4 = total >> 2;
+            const float4 *r4 = (const float4 *)env_run;
+#pragma unroll 4
+            for (int i = lane; i < n4; i += 64) {
+                const float4 v = r4[i];
+                if (v.x != 0.0f || v.y != 0.0f || v.z != 0.0f || v.w != 0.0f) {
+                    note(4 * i, v.x); note(4 * i + 1, v.y); note(4 * i + 2, v.z); note(4 * i + 3, v.w);
+                }
+            }
+            for (int i = (n4 << 2) + lane; i < total; i += 64) note(i, env_run[i]);
+        } else {
+            for (int i = lane; i < total; i += 64) note(i, env_run[i]);
+        }
+    }
+    // (independent of the scan: requested while it is in flight)
+    long long a = 0;
+    int pre_byte = 0;
+    if (present) {
+        a = load_action(p.actions, p.act_dtype, env);
+        pre_byte = p.done_in != nullptr ? (int)p.done_in[env] : 0;
+    }
+    unsigned char *slab = nullptr;
+    if ((OBS == WURM_OBS_DEFAULT || OBS == WURM_OBS_RAW) && p.lds_per_wave > 0) {
+        slab = gwl_lds + wave * p.lds_per_wave;
+        for (int i = lane; i < p.lds_per_wave / 16; i += 64) ((uint4 *)slab)[i] = make_uint4(0, 0, 0, 0);
+    }
+    wave_lds_sync();
+    const int nf = sc.cnt[0][slot], nh = sc.cnt[1][slot], bad = sc.bad[slot];
+    int fc = sc.pos[0][slot], hc = sc.pos[1][slot];
+    float *const envp = env_run + (long long)slot * 2 * C;
+    const bool act = present && !bad && nh == 1 && nf <= 1 && hc != fc;
+    if (present && !act) p.done[env] = GRID_SKIPPED; // the one-env-per-wave kernel takes this env (second launch, only_flagged)
+    const int hc0 = hc, fc0 = fc;
+    const u64 env_id = (u64)(p.env_offset + env);
+    const int start = p.start_y * S + p.start_x;
+
+    // ---- the postponed reset (simple_gridworld.py:225-268 with call = pre_call): whatever the env held
+    const bool pre = act && pre_byte != 0;
+    if (ballot(pre) != 0) {
+        const u32 word = rng_words(p.seed, p.pre_call, env_id, RNG_RESET, 0).w[3];
+        if (pre) { hc = start; fc = free_interior_cell(g, start, word); }
+    }
+    // ---- the step (:135-202)
+    const int ai = (int)(((a % 4) + 4) % 4);
+    int newhead = -1, ny = -1, nx = -1;
+    if (hc >= 0) {
+        const int hy = div_size(hc, g.rcpS), hx = hc - hy * S;
+        ny = hy - tap_y(ai);
+        nx = hx - tap_x(ai);
+        if (ny >= 0 && ny < S && nx >= 0 && nx < S) newhead = ny * S + nx;
+    }
+    const bool eat = act && newhead >= 0 && newhead == fc;
+    hc = newhead;
+    if (ballot(eat) != 0) {
+        const u32 word = rng_words(p.seed, p.call, env_id, RNG_FOOD, 0).w[0];
+        if (eat) fc = free_interior_cell(g, hc, word);
+    }
+    const bool edge = !(newhead >= 0 && ny >= 1 && ny <= S - 2 && nx >= 1 && nx <= S - 2);
+    if (act) {
+        p.reward[env] = eat ? 1.0f : 0.0f;
+        p.done[env] = (uint8_t)edge;
+        p.edgec[env] = (uint8_t)edge;
+        if (p.done_copy) p.done_copy[env] = (uint8_t)edge;
+    }
+    // ---- observations: of the stepped state, and (obs_after) of that state once a finished env is rebuilt with call + 1
+    const int elems = (int)p.obs_elems, run = nv * elems;
+    const bool obs16 = (((unsigned long long)p.obs) & 15ull) == 0 && (((unsigned long long)p.obs_after) & 15ull) == 0;
+    if (OBS == WURM_OBS_DEFAULT || OBS == WURM_OBS_RAW)
+        gwl_emit_image<OBS>(g, p.obs + env0 * elems, slab, slot, elems, run, lane, act, hc, fc);
+    else if (OBS == WURM_OBS_POSITIONS && act)
+        gwl_emit_positions(g, p.obs + env * 4, obs16, hc, fc);
+    if (p.obs_after != nullptr && OBS != WURM_OBS_NONE) {
+        int h2 = hc, f2 = fc;
+        const bool fin = act && edge;
+        if (ballot(fin) != 0) {
+            const u32 word = rng_words(p.seed, p.call + 1ull, env_id, RNG_RESET, 0).w[3];
+            if (fin) { h2 = start; f2 = free_interior_cell(g, start, word); }
+        }
+        if (OBS == WURM_OBS_DEFAULT || OBS == WURM_OBS_RAW)
+            gwl_emit_image<OBS>(g, p.obs_after + env0 * elems, slab, slot, elems, run, lane, act, h2, f2);
+        else if (OBS == WURM_OBS_POSITIONS && act)
+            gwl_emit_positions(g, p.obs_after + env * 4, obs16, h2, f2);
+    }
+    // ---- the stepped state back (the rebuilt one is not stored: no post_reset here)
+    if (act) {
+        if (fc0 >= 0 && fc0 != fc) envp[fc0] = 0.0f;
+        if (hc0 != hc) envp[C + hc0] = 0.0f;
+        if (fc >= 0 && fc != fc0) envp[fc] = 1.0f;
+        if (hc >= 0 && hc != hc0) envp[C + hc] = 1.0f;
+    }
+}
+
 } // namespace
 
 // SimpleGridworld rollouts this translation unit takes: RNG mode, a start location, 'default' / 'raw' / 'positions' or no
@@ -314,6 +498,68 @@ hipError_t launch_gridworld_lane_rollout(const StepArgs &p0, hipStream_t stream)
     case WURM_OBS_RAW: launch_image<WURM_OBS_RAW>(p, stream); break;
     case WURM_OBS_POSITIONS: launch_epw<WURM_OBS_POSITIONS, 64>(p, stream); break;
     default: launch_epw<WURM_OBS_NONE, 64>(p, stream); break;
+    }
+    return hipGetLastError();
+}
+
+// envs per wave of the per-call kernel: by batch size, halved until an image mode's run fits the byte slab; 0: none does
+static int gridworld_lane_step_epw(const StepArgs &p)
+{
+    // (one launch per call is a chain of latencies, not a stream: fewer envs per wave than the rollout.  Measured per
+    // iteration of `step; reset` at 4 / 8 / 16 / 32 envs per wave, tools/gridworld_percall_probe.py: 65 536 x 9 x 9 'default'
+    // 40.2 / 42.9 / 40.9 / 44.8 us (one env per wave 50.6), 'positions' 21.9 / 19.9 / 20.6 / 24.9 (38.2); 16 384 envs
+    // 'default' 17.3 / 19.2 / 21.7 / 26.6 (18.1))
+    long long epw = opt.gridworld_lane_epw;
+    if (epw != 4 && epw != 8 && epw != 16 && epw != 32 && epw != 64) epw = p.N >= 65536 ? 16 : p.N >= 32768 ? 8 : 4;
+    if (p.obs_mode == WURM_OBS_DEFAULT || p.obs_mode == WURM_OBS_RAW)
+        while (epw >= 4 && ((epw * p.obs_elems + 15) & ~15ll) > GWL_SLAB_MAX) epw >>= 1;
+    return epw >= 4 ? (int)epw : 0;
+}
+
+// the per-call step this translation unit takes (K_STEP / K_FUSED of SimpleGridworld): RNG mode, no immediate reset, batches
+// from WURM_LANE_STEP_MIN_ENVS on, a start location whenever a reset is part of the call
+bool gridworld_lane_step_eligible(const StepArgs &p)
+{
+    if (p.inject_food || p.inject_reset || p.inject_pre_reset || p.post_reset || p.only_flagged || p.S < 5 || p.S > 64) return false;
+    if (p.N < opt.lane_step_min_envs) return false;
+    if ((p.done_in != nullptr || p.obs_after != nullptr) &&
+        (p.start_y < 0 || p.start_x < 0 || p.start_y >= p.S || p.start_x >= p.S)) return false;
+    if (!(p.obs_mode == WURM_OBS_DEFAULT || p.obs_mode == WURM_OBS_RAW || p.obs_mode == WURM_OBS_POSITIONS ||
+          p.obs_mode == WURM_OBS_NONE)) return false;
+    return gridworld_lane_step_epw(p) != 0;
+}
+
+template <int OBS, int EPW>
+static void launch_step_epw(const StepArgs &p0, hipStream_t stream)
+{
+    StepArgs p = p0;
+    const long long waves = (p.N + EPW - 1) / EPW;
+    const int wpb = 4;
+    const dim3 block(64 * wpb), grid((unsigned)((waves + wpb - 1) / wpb));
+    p.lds_per_wave = (OBS == WURM_OBS_DEFAULT || OBS == WURM_OBS_RAW) ? (int)((EPW * p.obs_elems + 15) & ~15ll) : 0;
+    WURM_LAUNCH((gridworld_lane_step_kernel<OBS, EPW>), grid, block, (size_t)p.lds_per_wave * wpb, stream, p);
+}
+
+template <int OBS>
+static void launch_step_obs(const StepArgs &p, hipStream_t stream)
+{
+    switch (gridworld_lane_step_epw(p)) {
+    case 4: launch_step_epw<OBS, 4>(p, stream); break;
+    case 8: launch_step_epw<OBS, 8>(p, stream); break;
+    case 16: launch_step_epw<OBS, 16>(p, stream); break;
+    case 32: launch_step_epw<OBS, 32>(p, stream); break;
+    default: launch_step_epw<OBS, 64>(p, stream); break;
+    }
+}
+
+hipError_t launch_gridworld_lane_step(const StepArgs &p, hipStream_t stream)
+{
+    (void)hipGetLastError();
+    switch (p.obs_mode) {
+    case WURM_OBS_DEFAULT: launch_step_obs<WURM_OBS_DEFAULT>(p, stream); break;
+    case WURM_OBS_RAW: launch_step_obs<WURM_OBS_RAW>(p, stream); break;
+    case WURM_OBS_POSITIONS: launch_step_obs<WURM_OBS_POSITIONS>(p, stream); break;
+    default: launch_step_obs<WURM_OBS_NONE>(p, stream); break;
     }
     return hipGetLastError();
 }

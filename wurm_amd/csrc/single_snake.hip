@@ -1647,9 +1647,10 @@ static int pick_cpl(int S)
 //   rollout          | snake, S = 10 / 11, RNG mode, partial_n (n <= 3) or none                       | R_LEAN        rollout_lean_kernel
 //   rollout          | snake, S <= 11, RNG mode, partial_n (n <= 6) / none                            | R_GENERIC_PARTIAL / R_GENERIC_NONE (mode as template argument)
 //   rollout          | gridworld, RNG mode, N >= lane_rollout_min_envs, gridworld_lane_eligible        | R_GRIDWORLD_LANE gridworld_lane.hip (+ generic for the rest)
+//   step / fused     | gridworld, RNG mode, no immediate reset, N >= lane_step_min_envs                | R_GRIDWORLD_LANE_STEP gridworld_lane.hip (+ generic for the rest)
 //   rollout          | otherwise                                                                      | R_GENERIC
 // (the resident 9 x 9 step, lane_resident.hpp, is chosen by fused_entry: it needs the caller's mirror)
-enum Route { R_GENERIC, R_GRID_STEP, R_LANE_STEP, R_GRID_ROLLOUT, R_LANE_ROLLOUT, R_S9_INJ, R_S9, R_LEAN, R_GENERIC_PARTIAL, R_GENERIC_NONE, R_LANE_RESIDENT, R_GRIDWORLD_LANE };
+enum Route { R_GENERIC, R_GRID_STEP, R_LANE_STEP, R_GRID_ROLLOUT, R_LANE_ROLLOUT, R_S9_INJ, R_S9, R_LEAN, R_GENERIC_PARTIAL, R_GENERIC_NONE, R_LANE_RESIDENT, R_GRIDWORLD_LANE, R_GRIDWORLD_LANE_STEP };
 static thread_local Route last_route = R_GENERIC; // (wurm_single_last_route: the route of the CALLING THREAD's last launch — a diagnostic the tests and bench.py name a launch by; no state that a later call depends on)
 
 static const char *route_name(Route r)
@@ -1666,6 +1667,7 @@ static const char *route_name(Route r)
     case R_GENERIC_NONE: return "rollout_generic_none";
     case R_LANE_RESIDENT: return "lane_resident";
     case R_GRIDWORLD_LANE: return "gridworld_lane";
+    case R_GRIDWORLD_LANE_STEP: return "gridworld_lane_step";
     default: return "generic";
     }
 }
@@ -1677,6 +1679,7 @@ static Route route_of(Kind kind, bool snake, int cpl, const StepArgs &p)
         (p.N * (long long)p.S * p.S >= opt.grid_step_min_cells || p.resident != nullptr)) return R_GRID_STEP;
     if (snake && cpl == 2 && stepish && p.N >= opt.lane_step_min_envs && lane_step_eligible(p)) return R_LANE_STEP;
     if (kind == K_ROLLOUT && !snake && gridworld_lane_eligible(p)) return R_GRIDWORLD_LANE;
+    if (stepish && !snake && gridworld_lane_step_eligible(p)) return R_GRIDWORLD_LANE_STEP;
     if (kind != K_ROLLOUT || !snake) return R_GENERIC;
     if (cpl >= 4) return grid_rollout_eligible(p) ? R_GRID_ROLLOUT : R_GENERIC;
     if (p.N >= opt.lane_rollout_min_envs && lane_rollout_eligible(p)) return R_LANE_ROLLOUT;
@@ -1726,6 +1729,14 @@ static hipError_t launch_one(Kind kind, const StepArgs &p, dim3 grid, dim3 block
             hipError_t err = launch_gridworld_lane_rollout(p, st);
             if (err != hipSuccess) return err;
             WURM_LAUNCH((rollout_kernel<CPL, SNAKE>), grid, block, lds, st, q); // (the envs outside the lane kernel's domain)
+        }
+        break;
+    case R_GRIDWORLD_LANE_STEP:
+        if constexpr (!SNAKE) {
+            hipError_t err = launch_gridworld_lane_step(p, st);
+            if (err != hipSuccess) return err;
+            if (kind == K_STEP) WURM_LAUNCH((step_kernel<CPL, SNAKE>), grid, block, lds, st, q);
+            else WURM_LAUNCH((fused_step_kernel<CPL, SNAKE>), grid, block, lds, st, q);
         }
         break;
     case R_S9_INJ:

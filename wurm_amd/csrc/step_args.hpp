@@ -62,6 +62,9 @@ bool grid_step_eligible(const StepArgs &p);
 // GRID_SKIPPED in the same way
 bool gridworld_lane_eligible(const StepArgs &p);
 hipError_t launch_gridworld_lane_rollout(const StepArgs &p, hipStream_t stream);
+// ... and the per-call step of large batches under fused_step_kernel's contract (K_STEP / K_FUSED)
+bool gridworld_lane_step_eligible(const StepArgs &p);
+hipError_t launch_gridworld_lane_step(const StepArgs &p, hipStream_t stream);
 hipError_t launch_grid_step(const StepArgs &p, hipStream_t stream);
 
 // one-env-per-LANE rollout for large batches of 9 x 9 SingleSnake (lane_rollout.hip / lane_rollout.hpp); envs outside its
