@@ -1012,6 +1012,34 @@ __global__ __launch_bounds__(256) void rollout_kernel(StepArgs p)
     rollout_generic<CPL, SNAKE, OBSK, INJ>(p, env, envp, g, e, lds);
 }
 
+// ---- the envs a grid / lane kernel left to the one-env-per-wave code (done[env] == GRID_SKIPPED; for a rollout the flag is in
+// done[0][env]): ONE WAVE PER 64 ENVS reads their flags — one coalesced load, one ballot — and serves the flagged ones in
+// turn.  Launching the one-env-per-wave kernels for EVERY env just to read its flag (only_flagged, rounds 3-5) cost 3.9 us at
+// 8 192 envs and 6.8-9 us at 65 536: a fifth of the per-call step of 8 192 x 36 x 36 that it stood behind.
+// ROLL: rollout_kernel's body; else fused_step_env (which is step_kernel's body when the call carries no reset).
+template <int CPL, bool SNAKE, bool ROLL>
+__global__ __launch_bounds__(256) void flagged_kernel(StepArgs p)
+{
+    const int wave = uniform((int)(threadIdx.x >> 6)), wpb = (int)(blockDim.x >> 6), lane = (int)(threadIdx.x & 63u);
+    const long long base = ((long long)blockIdx.x * wpb + wave) * 64;
+    if (base >= p.N) return;
+    const bool flag = base + lane < p.N && p.done[base + lane] == GRID_SKIPPED;
+    signed char *lds = wurm_lds + wave * p.lds_per_wave;
+    for (u64 m = ballot(flag); m != 0; m &= m - 1) {
+        const long long env = base + first_bit(m);
+        if constexpr (ROLL) {
+            const Geo g = make_geo<CPL>(p.S);
+            float *envp = p.envs + env * (SNAKE ? 3 : 2) * g.C;
+            Env<CPL> e;
+            load_state<CPL, SNAKE>(envp, g, e);
+            rollout_generic<CPL, SNAKE, -1, true>(p, env, envp, g, e, lds);
+        } else {
+            fused_step_env<CPL, SNAKE>(p, env, lds);
+        }
+        wave_lds_sync(); // (the next env reuses the wave's LDS)
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- lean rollout
 // The headline shape — SingleSnake on a grid of at most 128 cells (S <= 11), partial_n crop of at most 64 window
 // cells (n <= 3) or no observation, RNG mode — runs 512 envs as 512 lone waves on 1024 SIMDs: nothing hides
@@ -1700,15 +1728,15 @@ static hipError_t launch_one(Kind kind, const StepArgs &p, dim3 grid, dim3 block
     (void)hipGetLastError(); // drop any stale error left by earlier runtime calls of this thread
     const Route route = route_of(kind, SNAKE, CPL, p);
     last_route = route;
-    StepArgs q = p;
-    q.only_flagged = 1; // (the generic kernel behind a grid kernel: only the envs that one could not take)
+    // (the one-env-per-wave code behind a grid / lane kernel, for the envs that one could not take: flagged_kernel, a wave per 64 envs)
+    const unsigned wpb_f = block.x / 64u;
+    const dim3 fgrid((unsigned)((p.N + 64ll * wpb_f - 1) / (64ll * wpb_f)));
     switch (route) {
     case R_GRID_STEP:
         if constexpr (SNAKE && CPL >= 4) {
             hipError_t err = launch_grid_step(p, st);
             if (err != hipSuccess) return err;
-            if (kind == K_STEP) WURM_LAUNCH((step_kernel<CPL, SNAKE>), grid, block, lds, st, q);
-            else WURM_LAUNCH((fused_step_kernel<CPL, SNAKE>), grid, block, lds, st, q);
+            WURM_LAUNCH((flagged_kernel<CPL, SNAKE, false>), fgrid, block, lds, st, p);
         }
         break;
     case R_LANE_STEP:
@@ -1718,7 +1746,7 @@ static hipError_t launch_one(Kind kind, const StepArgs &p, dim3 grid, dim3 block
         if constexpr (SNAKE && CPL >= 4) {
             hipError_t err = launch_grid_rollout(p, st);
             if (err != hipSuccess) return err;
-            WURM_LAUNCH((rollout_kernel<CPL, SNAKE>), grid, block, lds, st, q);
+            WURM_LAUNCH((flagged_kernel<CPL, SNAKE, true>), fgrid, block, lds, st, p);
         }
         break;
     case R_LANE_ROLLOUT:
@@ -1728,15 +1756,14 @@ static hipError_t launch_one(Kind kind, const StepArgs &p, dim3 grid, dim3 block
         if constexpr (!SNAKE) {
             hipError_t err = launch_gridworld_lane_rollout(p, st);
             if (err != hipSuccess) return err;
-            WURM_LAUNCH((rollout_kernel<CPL, SNAKE>), grid, block, lds, st, q); // (the envs outside the lane kernel's domain)
+            WURM_LAUNCH((flagged_kernel<CPL, SNAKE, true>), fgrid, block, lds, st, p); // (the envs outside the lane kernel's domain)
         }
         break;
     case R_GRIDWORLD_LANE_STEP:
         if constexpr (!SNAKE) {
             hipError_t err = launch_gridworld_lane_step(p, st);
             if (err != hipSuccess) return err;
-            if (kind == K_STEP) WURM_LAUNCH((step_kernel<CPL, SNAKE>), grid, block, lds, st, q);
-            else WURM_LAUNCH((fused_step_kernel<CPL, SNAKE>), grid, block, lds, st, q);
+            WURM_LAUNCH((flagged_kernel<CPL, SNAKE, false>), fgrid, block, lds, st, p);
         }
         break;
     case R_S9_INJ:
