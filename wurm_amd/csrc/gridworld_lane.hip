@@ -17,7 +17,7 @@
 //     large grids — are zero-filled and patched instead, 7 % slower.)  Bound: the store stream, 12 S^2 bytes per
 //     env-step for 'default'.
 // Any other env (hand-made states: several agents or foods, other values) is left untouched and marked
-// done[0][env] = GRID_SKIPPED; the one-env-per-wave rollout_kernel rolls it out in a second launch (only_flagged), exactly as
+// done[0][env] = GRID_SKIPPED; the one-env-per-wave code rolls it out in a second launch (flagged_kernel), exactly as
 // behind the clock-grid kernels (grid_rollout.hip).  RNG mode only (recorded outcomes take the generic kernel).
 // Integer / index work: no MFMA.
 #include "options.hpp"
