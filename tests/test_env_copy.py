@@ -97,3 +97,70 @@ def test_copies_continue_identically_on_the_gpu():
         menv.reset(x[2]['__all__']); m2.reset(y[2]['__all__'])
     for name in ('foods', 'heads', 'bodies', 'dones', 'orientations', 'agent_colours'):
         assert torch.equal(getattr(menv, name), getattr(m2, name)), name
+
+
+def test_alias_free_discounts_the_storage_wrapper():
+    """torch keeps a storage's Python wrapper alive on the StorageImpl once `untyped_storage()`, `deepcopy`,
+    `pickle` or `is_shared()` has made it, and the wrapper owns a reference of the storage — `wurm_torch_alias_free` must not
+    take it for a caller's alias (it did: `use_count() == 1`), while a real view still counts."""
+    import ctypes
+    import gc
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'wurm_amd', 'libwurm_torchinfo.so')
+    if not os.path.exists(path):
+        pytest.skip('libwurm_torchinfo.so not built')
+    fn = ctypes.PyDLL(path).wurm_torch_alias_free
+    fn.argtypes, fn.restype = [ctypes.py_object], ctypes.c_int
+    makers = [lambda t: None, lambda t: copy.deepcopy(t), lambda t: pickle.dumps(t), lambda t: t.is_shared(),
+              lambda t: t.untyped_storage()]
+    for make in makers:
+        t, u = torch.zeros(12), torch.zeros(3)
+        make(t)
+        gc.collect()
+        assert fn((t, u)) == 1, make
+        v = t[2:5]
+        assert fn((t, u)) == 0 and fn((u, t)) == 0        # a view is a holder, wrapper or not
+        del v
+        assert fn((t, u)) == 1
+    assert fn([torch.zeros(1)]) == -1 and fn((1,)) == -1
+
+
+@pytest.mark.gpu
+def test_a_copied_env_still_postpones_its_resets():
+    """... and with it the whole point: `step; reset(d)` stays ONE launch per iteration on the source and on the
+    copy after copy.deepcopy / pickle (both touch the state storages' Python wrappers)."""
+    from wurm_amd import _lib
+    from wurm_amd.envs import MultiSnake, SingleSnake
+    count = _lib.lib().wurm_launch_count
+    env = SingleSnake(256, 9, observation_mode='partial_2', device='cuda:0', seed=3)
+    acts = torch.randint(4, (40, 256)).cuda()
+    K = 2
+    menv = MultiSnake(64, K, 12, device='cuda:0', seed=5)
+    macts = torch.randint(8, (40, K, 64)).cuda()
+    keys = ['agent_%d' % i for i in range(K)]
+
+    def loop_single(e, t0):
+        for t in range(t0, t0 + 4):
+            d = e.step(acts[t].clone())[2]
+            e.reset(d, return_observations=False)
+        n0 = count()
+        for t in range(t0 + 4, t0 + 10):
+            d = e.step(acts[t].clone())[2]
+            e.reset(d, return_observations=False)
+        return (count() - n0) / 6
+
+    def loop_multi(e, t0):
+        for t in range(t0, t0 + 4):
+            d = e.step(dict(zip(keys, macts[t])))[2]
+            e.reset(d['__all__'], return_observations=False)
+        n0 = count()
+        for t in range(t0 + 4, t0 + 10):
+            d = e.step(dict(zip(keys, macts[t])))[2]
+            e.reset(d['__all__'], return_observations=False)
+        return (count() - n0) / 6
+
+    assert loop_single(env, 0) == 1.0 and loop_multi(menv, 0) == 1.0
+    for clone in (copy.deepcopy, lambda e: pickle.loads(pickle.dumps(e))):
+        e2, m2 = clone(env), clone(menv)
+        assert loop_single(env, 10) == 1.0 and loop_single(e2, 10) == 1.0, clone
+        assert loop_multi(menv, 10) == 1.0 and loop_multi(m2, 10) == 1.0, clone

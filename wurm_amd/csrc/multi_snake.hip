@@ -102,6 +102,7 @@ struct Ctx {
 };
 
 extern __shared__ __attribute__((aligned(16))) unsigned char wurm_multi_lds[];
+__host__ __device__ inline int multi_layout(MultiArgs &p, bool need_img, int need_snap); // (host side, below)
 
 __device__ __forceinline__ u64 border_bits(const Ctx &cx); // (with the grouped 'full' writer below)
 __device__ __forceinline__ Ctx make_ctx(const MultiArgs &p, int wave, int base_off = 0, bool want_ring = false)
@@ -2332,12 +2333,20 @@ __global__ __launch_bounds__(256) void multi_observe_wg_kernel(MultiArgs p)
 // injected-outcome branches of the step and of the reset, their nine pointers and three running offsets fold away, which
 // matters in a kernel whose uniform state does not fit the scalar registers (profiles/r05_kernel_resources.txt).
 // OBS >= 0: the observation mode is a compile-time constant too (the other modes' writers and their loop invariants go).
-template <bool TWO, bool INJ, int OBS = -1>
+template <bool TWO, bool INJ, int OBS = -1, int KT = 0, int ST = 0, int NT = -1>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void multi_rollout_kernel(MultiArgs p_in)
 {
     MultiArgs p = p_in;
     if (!INJ) p.has_inj = p.has_rinj = 0;
     if (OBS >= 0) p.obs_mode = OBS;
+    // KT / ST / NT > 0: the number of snakes, the grid size and the crop radius are compile-time constants too (the shapes of
+    // the reference's own experiments): every loop over snakes, rows of 64 cells and window cells has a known trip count
+    if (KT > 0) p.K = KT;
+    if (ST > 0) p.S = ST;
+    if (NT >= 0) p.obs_n = NT;
+    if (OBS == WURM_OBS_PARTIAL && NT >= 0) p.obs_elems = 3ll * (2 * NT + 1) * (2 * NT + 1);
+    if (!TWO && KT > 0 && ST > 0 && (OBS == WURM_OBS_PARTIAL || OBS == WURM_OBS_NONE))
+        (void)multi_layout(p, OBS == WURM_OBS_PARTIAL, 0); // (the LDS offsets multi_launch worked out, as constants)
     const int wave = uniform((int)(threadIdx.x >> 6)), wpb = TWO ? 1 : (int)(blockDim.x >> 6);
     const long long env = xcd_block(blockIdx.x, gridDim.x) * wpb + (TWO ? 0 : wave);
     if (env >= p.N) return;
@@ -3057,7 +3066,7 @@ __global__ void multi_colours_kernel(short *colours, long long N, int K, int fix
 
 // ------------------------------------------------------------------------------------------------ host side
 
-static int multi_layout(MultiArgs &p, bool need_img, int need_snap)
+__host__ __device__ inline int multi_layout(MultiArgs &p, bool need_img, int need_snap)
 {
     const int C = p.S * p.S, K = p.K;
     int off = 12 * K;                      // hcell, lmax, tclk
@@ -3243,6 +3252,10 @@ static int multi_launch(MKind kind, MultiArgs &p, void *stream)
     hipStream_t st = (hipStream_t)stream;
     (void)hipGetLastError();
     const bool rng = !p.has_inj && !p.has_rinj;
+    // the shape of the reference's multi-agent experiments (experiments/multiagent.py:79-86: 4 snakes on 25 x 25, partial_5)
+    // has kernels with K, S and the crop radius as constants (WURM_MULTI_SHAPE_KERNELS = 0: the generic ones)
+    const bool shape_4_25_5 = kind == MK_ROLLOUT && rng && opt.multi_shape_kernels != 0 && p.obs_mode == WURM_OBS_PARTIAL &&
+                              p.K == 4 && p.S == 25 && p.obs_n == 5;
     const void *kstep = !rng ? (const void *)multi_step_kernel<true, -1>
                       : p.obs_mode == WURM_OBS_DEFAULT ? (const void *)multi_step_kernel<false, WURM_OBS_DEFAULT>
                       : p.obs_mode == WURM_OBS_PARTIAL ? (const void *)multi_step_kernel<false, WURM_OBS_PARTIAL>
@@ -3252,6 +3265,7 @@ static int multi_launch(MKind kind, MultiArgs &p, void *stream)
                    : kind == MK_OBSERVE ? (const void *)multi_observe_kernel
                    : kind == MK_CHECK ? (const void *)multi_check_kernel
                    : (p.has_inj || p.has_rinj) ? (const void *)multi_rollout_kernel<false, true>
+                   : shape_4_25_5 ? (const void *)multi_rollout_kernel<false, false, WURM_OBS_PARTIAL, 4, 25, 5>
                    : p.obs_mode == WURM_OBS_PARTIAL ? (const void *)multi_rollout_kernel<false, false, WURM_OBS_PARTIAL>
                    : p.obs_mode == WURM_OBS_NONE ? (const void *)multi_rollout_kernel<false, false, WURM_OBS_NONE>
                    : (const void *)multi_rollout_kernel<false, false>;
@@ -3268,6 +3282,7 @@ static int multi_launch(MKind kind, MultiArgs &p, void *stream)
     case MK_CHECK: WURM_LAUNCH(multi_check_kernel, grid, block, shmem, st, p); break;
     case MK_ROLLOUT:
         if (p.has_inj || p.has_rinj) WURM_LAUNCH((multi_rollout_kernel<false, true>), grid, block, shmem, st, p);
+        else if (shape_4_25_5) WURM_LAUNCH((multi_rollout_kernel<false, false, WURM_OBS_PARTIAL, 4, 25, 5>), grid, block, shmem, st, p);
         else if (p.obs_mode == WURM_OBS_PARTIAL) WURM_LAUNCH((multi_rollout_kernel<false, false, WURM_OBS_PARTIAL>), grid, block, shmem, st, p);
         else if (p.obs_mode == WURM_OBS_NONE) WURM_LAUNCH((multi_rollout_kernel<false, false, WURM_OBS_NONE>), grid, block, shmem, st, p);
         else WURM_LAUNCH((multi_rollout_kernel<false, false>), grid, block, shmem, st, p);

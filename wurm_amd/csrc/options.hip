@@ -10,7 +10,7 @@
 
 namespace wurm {
 
-constexpr Options DEFAULTS = {1ll << 20, 12288, 6144, -1, -1, -1, 12, 0, 2048, 0, -1, 0, 0, -1};
+constexpr Options DEFAULTS = {1ll << 20, 12288, 6144, -1, -1, -1, 12, 0, 2048, 0, -1, 0, 0, 1, -1};
 // PROCESS-WIDE: every env object and every thread of the process sees the same knobs (documented in include/wurm_hip.h);
 // the launch counter is a diagnostic that concurrent launchers may bump at the same time, hence atomic.
 Options opt = DEFAULTS;
@@ -37,6 +37,7 @@ const Entry table[] = {
     {"WURM_MULTI_GROUP_STEP_WPB", &Options::multi_group_step_wpb},
     {"WURM_MULTI_GROUP_SHAPE", &Options::multi_group_shape},
     {"WURM_GRID_ROTATE", &Options::grid_rotate},
+    {"WURM_MULTI_SHAPE_KERNELS", &Options::multi_shape_kernels},
     {"WURM_GRIDWORLD_LANE_EPW", &Options::gridworld_lane_epw},
 };
 

@@ -20,6 +20,7 @@ struct Options {
     long long multi_group_step_wpb;  // WURM_MULTI_GROUP_STEP_WPB  per-call step: envs per workgroup of the grouped writer (-1 auto, 0 off)
     long long multi_group_shape;     // WURM_MULTI_GROUP_SHAPE     100 G + 10 W + waves per SIMD of that kernel (0 = automatic)
     long long grid_rotate;           // WURM_GRID_ROTATE           clock-grid kernels: observation rows start at an env-dependent row (0 = off; 1: env % rows, k >= 2: (env % k) * rows / k; measured no better)
+    long long multi_shape_kernels;   // WURM_MULTI_SHAPE_KERNELS   MultiSnake: kernels with K, S and the crop radius compiled in for the reference's experiment shapes (1; 0 = the generic kernels)
     long long gridworld_lane_epw;    // WURM_GRIDWORLD_LANE_EPW    SimpleGridworld lane rollout, image modes: envs per wave (4..64; -1 = by batch size)
 };
 

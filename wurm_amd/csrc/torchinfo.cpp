@@ -73,9 +73,14 @@ PyObject *wurm_torch_row_views(PyObject *obj, long long lead, long long lo, long
         return nullptr;
     }
 }
-/* 1 if every tensor of the tuple is the ONLY tensor on its storage (nobody else holds the state tensor, a view of it, or a
- * storage handle), 0 if some storage is shared, -1 if the argument is not a tuple of tensors.  The host classes postpone
- * `reset(done)` only while that holds (wurm_amd/envs/_fast_step.py: _alias_free). */
+/* 1 if every tensor of the tuple is the ONLY tensor on its storage (nobody else holds the state tensor or a view of it),
+ * 0 if some storage is shared, -1 if the argument is not a tuple of tensors.  The host classes postpone `reset(done)` only
+ * while that holds (wurm_amd/envs/_fast_step.py: _alias_free).
+ * The storage's own Python wrapper is not a holder: once `t.untyped_storage()`, `copy.deepcopy(t)`, `pickle.dumps(t)` or
+ * `t.is_shared()` has created it, torch keeps it alive on the StorageImpl (PyObject preservation) and it owns one
+ * reference of the storage for good — use_count() == 2 with nobody else there (with the bare `== 1` test a
+ * deepcopy of an env switched the postponed reset off on both objects for ever).  So the wrapper's reference is discounted,
+ * which is also what the Python twin does (`_storage_use_count(...) <= 2` with its own handle kept). */
 int wurm_torch_alias_free(PyObject *seq)
 {
     if (!PyTuple_Check(seq)) return -1;
@@ -85,7 +90,9 @@ int wurm_torch_alias_free(PyObject *seq)
         if (!THPVariable_CheckExact(o)) return -1;
         const at::Tensor &t = THPVariable_Unpack(o);
         if (!t.defined() || !t.has_storage()) return -1;
-        if (t.unsafeGetTensorImpl()->unsafe_storage().use_count() != 1) return 0;
+        const c10::Storage &st = t.unsafeGetTensorImpl()->unsafe_storage();
+        const size_t wrapper = st.unsafeGetStorageImpl()->pyobj_slot()->load_pyobj() != nullptr ? 1 : 0;
+        if (st.use_count() != 1 + wrapper) return 0;
     }
     return 1;
 }
