@@ -9,7 +9,9 @@ mode, start location or configuration of a logical operation — and any use of 
 
 Used by tests/test_protocol_enumeration.py (short sequences, every configuration) and tools/protocol_enumerate.py (length 6).
 """
+import copy
 import itertools
+import pickle
 
 import torch
 
@@ -124,6 +126,59 @@ class SingleDriver(object):
 
     def read_done(self):
         return pack(self.env.done)
+
+    # ---- EXTRA: the events VERDICT r05's probe added (outside the base alphabet; tests enumerate the sequences that
+    # contain at least one of them)
+    EXTRA = ('edit_temp', 'drop_alias', 'hold_slice', 'deepcopy', 'pickle', 'clear_done', 'reset_flat', 'assign_done',
+             'step_i32', 'step_strided')
+
+    def edit_temp(self):
+        """an in-place edit through a temporary: `env.envs[i, ...] = v`, no alias kept"""
+        self.k += 1
+        self.env.envs[1, 0, 1, 1 + self.k % 3] = float(60 + self.k % 30)
+        return None
+
+    def drop_alias(self):
+        self.alias = None
+        return None
+
+    def hold_slice(self):
+        self.alias = self.env.envs[:, 0:1]      # a view of one channel: edit_alias writes through it
+        return pack(self.alias)
+
+    def deepcopy(self):
+        self.env = copy.deepcopy(self.env)
+        return None
+
+    def pickle(self):
+        self.env = pickle.loads(pickle.dumps(self.env))
+        return None
+
+    def clear_done(self):
+        if self.d is None:
+            return SKIP
+        self.d.zero_()
+        return None
+
+    def reset_flat(self):
+        return SKIP if self.d is None else pack(self.env.reset(self.d.view(-1)))
+
+    def assign_done(self):
+        self.k += 1
+        self.env.done = torch.tensor([(self.k + i) % 2 == 0 for i in range(N_ENVS)])
+        return None
+
+    def step_i32(self):
+        a = self._actions(N_ENVS).to(torch.int32)
+        out = self.env.step(a)
+        self.d = out[2]
+        return pack(out), pack(a)
+
+    def step_strided(self):
+        a = self._actions(N_ENVS, 2)[:, 0]       # non-contiguous
+        out = self.env.step(a)
+        self.d = out[2]
+        return pack(out), pack(a)
 
     def final(self):
         return pack(self.env.envs), int(self.env._call)
@@ -267,6 +322,90 @@ class MultiDriver(object):
     def read_rewards(self):
         return pack((self.env.rewards, self.env.boost_this_step))
 
+    # ---- EXTRA (VERDICT r05's probe; round 6: what reset(done) returns, kept or dropped — _LazyResetObs)
+    EXTRA = ('reset_d_drop', 'reset_d_keep', 'read_kept', 'edit_temp', 'drop_alias', 'deepcopy', 'pickle', 'clear_done',
+             'assign_orient', 'assign_heads', 'edit_dones', 'boost', 'food_rate', 'death_prob', 'colour_mode', 'step_split',
+             'set_boost_t')
+    kept = None
+
+    def reset_d_drop(self):
+        if self.d is None:
+            return SKIP
+        self.env.reset(self.d)                   # (the returned dict dies here, as in experiments/speeds.py:33)
+        return None
+
+    def reset_d_keep(self):
+        if self.d is None:
+            return SKIP
+        self.kept = self.env.reset(self.d)       # held, not looked at
+        return None
+
+    def read_kept(self):
+        return SKIP if self.kept is None else pack(dict(self.kept.items()))
+
+    def edit_temp(self):
+        self.k += 1
+        self.env.bodies[1, 0, 0, 1 + self.k % 3] = float(60 + self.k % 30)
+        return None
+
+    def drop_alias(self):
+        self.alias = None
+        return None
+
+    def deepcopy(self):
+        self.env = copy.deepcopy(self.env)
+        return None
+
+    def pickle(self):
+        self.env = pickle.loads(pickle.dumps(self.env))
+        return None
+
+    def clear_done(self):
+        if self.d is None:
+            return SKIP
+        self.d.zero_()
+        return None
+
+    def assign_orient(self):
+        self.k += 1
+        self.env.orientations = (self.env.orientations + self.k) % 4
+        return None
+
+    def assign_heads(self):
+        self.env.heads = self.env.heads.clone()
+        return None
+
+    def edit_dones(self):
+        self.env.dones[0] = True
+        return None
+
+    def boost(self):
+        self.env.boost = not self.env.boost
+        return None
+
+    def food_rate(self):
+        self.env.food_rate = 0.25 if self.env.food_rate != 0.25 else 5e-4
+        return None
+
+    def death_prob(self):
+        self.env.food_on_death_prob = 0.9 if self.env.food_on_death_prob != 0.9 else 0.5
+        return None
+
+    def colour_mode(self):
+        self.env.colour_mode = 'fixed' if self.env.colour_mode == 'random' else 'random'
+        return None
+
+    def step_split(self):
+        """K separately allocated action tensors (a policy that emits one tensor per agent, experiments/multiagent.py)"""
+        a = self._actions(M_K, M_N)
+        out = self.env.step({'agent_%d' % i: a[i].clone() for i in range(M_K)})
+        self.d = out[2]['__all__']
+        return pack(out)
+
+    def set_boost_t(self):
+        self.env.boost_this_step = ~self.env.boost_this_step
+        return None
+
     def final(self):
         e = self.env
         return pack((e.foods, e.heads, e.bodies, e.dones, e.orientations, e.agent_colours)), int(e._call)
@@ -284,9 +423,13 @@ def install_multi(monkeypatch, rollout_keeps_mirror=True, machine='python'):
     return sim
 
 
-def make_multi(mirror, twin=False):
+def make_multi(mirror, twin=False, lazy_obs=False):
+    """lazy_obs: the object under test starts as one whose caller has been discarding what reset(done) returns
+    (MultiSnake._lazy_obs_mode: reset hands out a _LazyResetObs and the steps do not precompute it)"""
     from wurm_amd.envs import MultiSnake
     env = MultiSnake(M_N, M_K, M_S, device='cpu', seed=1, lazy_reset=not twin, resident_mirror=False if twin else mirror)
+    if lazy_obs and not twin:
+        env._lazy_obs_mode = True
     return MultiDriver(env, twin)
 
 

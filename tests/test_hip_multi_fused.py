@@ -241,3 +241,95 @@ def test_class_loop_under_inference_mode():
             env.reset(dones['__all__'], return_observations=bool(t % 2))
             o.multi_reset(st, r['all_done'], cfg)
     _same(env.bodies.cpu().numpy(), st['bodies'], 'final bodies')
+
+
+@pytest.mark.gpu
+def test_reading_a_state_attribute_does_not_cost_the_one_call_step_for_ever(monkeypatch):
+    """`env.heads` read once (experiments/multiagent.py:531 does, for its heat maps) left the tensor on the watch
+    list and every later step went the long way round (`_slow_step`: the version checks, the stacking test ...).  An alias
+    the caller has dropped is pruned by the next step; one it keeps is watched as before — and the trajectories are those
+    of an env nobody looked at."""
+    import torch
+    from wurm_amd.envs import MultiSnake
+    N, K, S = 64, 2, 12
+    g = torch.Generator().manual_seed(3)
+    tape = torch.randint(8, (40, K, N), generator=g).cuda()
+    keys = ['agent_%d' % i for i in range(K)]
+    slow = []
+    real = MultiSnake._slow_step
+    monkeypatch.setattr(MultiSnake, '_slow_step', lambda self, a: (slow.append(1), real(self, a))[1])
+    env, ref = MultiSnake(N, K, S, device='cuda:0', seed=9), MultiSnake(N, K, S, device='cuda:0', seed=9)
+
+    def it(e, t):
+        o = e.step(dict(zip(keys, tape[t].unbind(0))))
+        e.reset(o[2]['__all__'], return_observations=False)
+        return o
+    for t in range(4):
+        it(env, t), it(ref, t)
+    n0 = len(slow)
+    it(env, 4), it(ref, 4)
+    assert len(slow) == n0                                  # two fast steps
+    assert float(env.heads.sum()) == float(ref.heads.sum())  # both looked at, both dropped
+    n1 = len(slow)
+    for t in range(5, 15):
+        a, b = it(env, t), it(ref, t)
+    assert len(slow) - n1 <= 2                              # (at most the one step per env that finds the alias gone)
+    h = env.heads                                           # kept: watched, slow, correct
+    n2 = len(slow)
+    for t in range(15, 20):
+        a, b = it(env, t), it(ref, t)
+        assert all(torch.equal(a[0][k], b[0][k]) for k in a[0]) and all(torch.equal(a[1][k], b[1][k]) for k in a[1])
+    assert len(slow) - n2 == 5
+    del h
+    for t in range(20, 30):
+        a, b = it(env, t), it(ref, t)
+        assert all(torch.equal(a[0][k], b[0][k]) for k in a[0])
+    assert len(slow) - n2 <= 6
+    for name in ('foods', 'heads', 'bodies', 'dones', 'orientations'):
+        assert torch.equal(getattr(env, name), getattr(ref, name)), name
+
+
+@pytest.mark.gpu
+def test_a_caller_that_discards_what_reset_returns_stops_paying_for_it():
+    """experiments/speeds.py:30-38: `env.step(a); env.reset(done['__all__'])` — the K observations reset returns (:834-836)
+    are dropped.  After three such iterations the steps stop writing them (`want_obs_after` off, reset hands out a
+    _LazyResetObs); a caller that then keeps or reads one gets exactly what an eager reset returns, and the env goes back to
+    precomputing.  One launch per iteration throughout; trajectories equal to an env with `lazy_reset=False`."""
+    import torch
+    from wurm_amd import _lib
+    from wurm_amd.envs import MultiSnake
+    from wurm_amd.envs.multi_snake import _LazyResetObs
+    N, K, S = 96, 3, 12
+    g = torch.Generator().manual_seed(5)
+    tape = torch.randint(8, (40, K, N), generator=g).cuda()
+    keys = ['agent_%d' % i for i in range(K)]
+    kw = dict(device='cuda:0', seed=21, respawn_mode='any', food_mode='random_rate', food_rate=2.5e-3)
+    env, ref = MultiSnake(N, K, S, **kw), MultiSnake(N, K, S, lazy_reset=False, resident_mirror=False, **kw)
+    count = _lib.lib().wurm_launch_count
+    acts = lambda t: dict(zip(keys, tape[t].unbind(0)))   # noqa: E731
+    for t in range(8):                                    # dropped: the lazy form sets in
+        a = env.step(acts(t)); env.reset(a[2]['__all__'])
+        b = ref.step(acts(t)); ref.reset(b[2]['__all__'])
+        assert all(torch.equal(a[0][k], b[0][k]) for k in a[0])
+    assert env._lazy_obs_mode and not env._fs.want_obs_after
+    n0 = count()
+    for t in range(8, 12):
+        a = env.step(acts(t)); env.reset(a[2]['__all__'])
+    assert count() - n0 == 4                              # one launch per iteration, no second observation stream
+    for t in range(8, 12):
+        b = ref.step(acts(t)); ref.reset(b[2]['__all__'])
+    a = env.step(acts(12)); kept = env.reset(a[2]['__all__'])            # kept, not looked at ...
+    b = ref.step(acts(12)); want = ref.reset(b[2]['__all__'])
+    assert type(kept) is _LazyResetObs and kept._env is not None
+    a = env.step(acts(13)); b = ref.step(acts(13))                       # ... across the next step: filled in front of it
+    assert kept._env is None and list(kept) == list(want) and all(torch.equal(kept[k], want[k]) for k in want)
+    assert all(torch.equal(a[0][k], b[0][k]) for k in a[0]) and not env._lazy_obs_mode
+    r1, r2 = env.reset(a[2]['__all__']), ref.reset(b[2]['__all__'])     # read at once: an ordinary dict again soon
+    assert all(torch.equal(r1[k], r2[k]) for k in r2)
+    for t in range(14, 24):
+        a = env.step(acts(t)); r1 = env.reset(a[2]['__all__'])
+        b = ref.step(acts(t)); r2 = ref.reset(b[2]['__all__'])
+        assert all(torch.equal(a[0][k], b[0][k]) for k in a[0]) and all(torch.equal(r1[k], r2[k]) for k in r2)
+    assert not env._lazy_obs_mode                                        # (a caller that reads it is a caller that reads it)
+    for name in ('foods', 'heads', 'bodies', 'dones', 'orientations', 'agent_colours'):
+        assert torch.equal(getattr(env, name), getattr(ref, name)), name

@@ -409,3 +409,46 @@ def test_reference_test_access_patterns_never_step_on_a_stale_mirror(env_and_log
     env.reset(d['__all__'], return_observations=False)     # the step's own flags: postponed, nothing written
     step()
     assert _steps(log)[-1]['pending'] and _steps(log)[-1]['valid']
+
+
+def test_a_dropped_alias_gives_the_fast_path_back(env_and_log):
+    """one read of `env.heads` (experiments/multiagent.py:531) put the tensor on the watch list for ever, and
+    `step` takes its one-C-call path only while that list is empty.  Once the caller has let go of the tensor nothing is
+    left to watch (the GPU twin of this test counts the slow steps: tests/test_hip_multi_fused.py)."""
+    env, log = env_and_log
+    for t in range(3):
+        _step(env)
+    assert float(env.heads.sum()) >= 0.0               # read and dropped at once
+    assert env._watched
+    _step(env)
+    assert not env._watched and _steps(log)[-1]['valid']
+    h = env.heads                                      # held: watched for as long as the caller holds it
+    for t in range(4):
+        _step(env)
+    assert env._watched and _steps(log)[-1]['valid']
+    h[0, 0, 2, 2] = 1.0                                # an edit made before the alias is dropped is not forgotten
+    del h
+    _step(env)
+    assert not _steps(log)[-1]['valid'] and not env._watched
+    _step(env)
+    assert _steps(log)[-1]['valid']
+
+
+def test_an_assigned_info_lasts_until_the_next_step(env_and_log):
+    """reference multi_snake.py:729 rebinds `self.info` in every step (the fast path kept a user's dict)"""
+    env, log = env_and_log
+    _step(env); _step(env)
+    mine = {'x': 1}
+    env.info = mine
+    assert env.info is mine
+    out = _step(env)
+    assert env.info is not mine and env.info is out[3]
+
+
+def test_sanitize_movements_is_the_reference_formula(env_and_log):
+    """reference multi_snake.py:336-339 (public; its own step calls it at :493)"""
+    env, _ = env_and_log
+    mv = torch.tensor([0, 1, 2, 3, 0, 1, 2, 3])
+    ori = torch.tensor([0, 1, 2, 3, 1, 2, 3, 0])
+    got = env.sanitize_movements(movements=mv, orientations=ori)
+    assert got.tolist() == [2, 3, 0, 1, 0, 1, 2, 3] and got.dtype == torch.long

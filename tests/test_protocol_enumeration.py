@@ -88,6 +88,56 @@ def test_multi_snake_every_sequence_up_to_3(monkeypatch, mirror, keep, machine):
     _run_all(lambda twin=False: pe.make_multi(mirror, twin), pe.MultiDriver.EVENTS, 3, MULTI_REGRESSIONS)
 
 
+def _with_extra(events, extra, max_len, first=None):
+    """every sequence over events + extra of length <= max_len that contains at least one of `extra` (length max_len: only
+    those that start with `first`, if given — most of the extra events need a step in front of them to mean anything)"""
+    allev = tuple(events) + tuple(extra)
+    xs = set(extra)
+    for L in range(1, max_len + 1):
+        for seq in itertools.product(allev, repeat=L):
+            if L == max_len and first is not None and seq[0] != first:
+                continue
+            if xs.intersection(seq):
+                yield seq
+
+
+# VERDICT r05's probe — caller events outside the base alphabet (edit through a temporary, dropped alias, held slice,
+# deepcopy / pickle mid-sequence, cleared / reshaped / assigned done, int32 and strided actions; MultiSnake: assigned
+# orientations / heads, edited dones, dynamics attributes, separately allocated actions) — and round 6's reset-observation
+# events (kept / dropped / read later).  Here: length <= 2 whole, length 3 behind a step; tools/protocol_enumerate.py
+# --extra runs length 4 (profiles/r06_protocol_enumeration_extra.json).
+@pytest.mark.parametrize('kind,mirror,machine', [('single', None, 'python'), ('single', 'lazy', 'c+torchinfo'),
+                                                 ('grid', False, 'python'), ('grid', False, 'c+torchinfo')])
+def test_extra_events_single(monkeypatch, kind, mirror, machine):
+    _machine_or_skip(machine)
+    pe.install_single(monkeypatch, kind, machine)
+    drv = pe.SingleDriver if kind == 'single' else pe.GridDriver
+    seqs = list(_with_extra(drv.EVENTS, drv.EXTRA, 3, first='step'))
+    _run_all(lambda twin=False: pe.make_single(kind, mirror, twin), (), 0, seqs)
+
+
+MULTI_EXTRA_REGRESSIONS = [
+    ('step', 'reset_d_keep', 'step', 'read_kept'),               # held across the next step: filled in front of it
+    ('step', 'reset_d_keep', 'mode', 'read_kept'),               # the mode the reset was called in
+    ('step', 'reset_d_keep', 'look', 'edit_alias', 'read_kept'),
+    ('step', 'reset_d_keep', 'rollout', 'read_kept'),
+    ('step', 'reset_d_keep', 'deepcopy', 'step', 'read_kept'),
+    ('step', 'reset_d_drop', 'step', 'reset_d_keep', 'reset_none', 'read_kept'),
+    ('step', 'reset_d_keep', 'respawn', 'step', 'read_kept'),
+    ('step', 'reset_d_drop', 'step', 'reset_d_drop', 'step', 'reset_d_drop', 'step', 'reset_d_drop', 'step', 'reset_d_keep',
+     'step', 'read_kept', 'reset_d_keep', 'step', 'read_kept'),  # the adaptive rule itself: into the lazy form and out again
+]
+
+
+@pytest.mark.parametrize('mirror,lazy_obs,machine', [(None, False, 'python'), (None, True, 'python'), ('lazy', True, 'python'),
+                                                     (None, True, 'c+torchinfo'), (False, True, 'c')])
+def test_extra_events_multi(monkeypatch, mirror, lazy_obs, machine):
+    _machine_or_skip(machine)
+    pe.install_multi(monkeypatch, rollout_keeps_mirror=True, machine=machine)
+    seqs = list(_with_extra(pe.MultiDriver.EVENTS, pe.MultiDriver.EXTRA, 3, first='step')) + MULTI_EXTRA_REGRESSIONS
+    _run_all(lambda twin=False: pe.make_multi(mirror, twin, lazy_obs), (), 0, seqs)
+
+
 def test_the_harness_sees_a_wrong_counter_and_a_stale_mirror(monkeypatch):
     """the simulator must make protocol mistakes VISIBLE: a deferred reset applied with another counter, and a step on a
     mirror that was not invalidated after a foreign write, both change what the caller sees"""
@@ -117,3 +167,20 @@ def test_the_harness_sees_a_wrong_counter_and_a_stale_mirror(monkeypatch):
     r = pe.run_sequence(stale_mirror, lambda: stale_mirror(True), seq)
     assert r is not None and r is not pe.SKIP
     assert isinstance(sim, ps.SimSingle) and torch is not None
+
+
+def test_the_harness_sees_a_reset_observation_that_was_not_filled_in_time(monkeypatch):
+    """round 6 (_LazyResetObs): what reset(done) returned must be filled in front of the next state change while the caller
+    holds it — and the enumeration above must be able to tell when it is not"""
+    from wurm_amd.envs import multi_snake as ms
+    pe.install_multi(monkeypatch, True, 'python')
+    d = pe.make_multi(None, False, True)
+    d.step(); d.reset_d_keep()
+    assert type(d.kept) is ms._LazyResetObs and d.kept._env is not None
+    d.step()
+    assert d.kept._env is None and len(dict.keys(d.kept)) == pe.M_K and not d.env._lazy_obs_mode
+    seq = ('step', 'reset_d_keep', 'step', 'read_kept')
+    assert pe.run_sequence(lambda: pe.make_multi(None, False, True), lambda: pe.make_multi(None, True), seq) is None
+    monkeypatch.setattr(ms.MultiSnake, '_reset_obs_bookkeeping', lambda self: None)
+    r = pe.run_sequence(lambda: pe.make_multi(None, False, True), lambda: pe.make_multi(None, True), seq)
+    assert r is not None and r is not pe.SKIP

@@ -104,6 +104,27 @@ struct Ctx {
 extern __shared__ __attribute__((aligned(16))) unsigned char wurm_multi_lds[];
 __host__ __device__ inline int multi_layout(MultiArgs &p, bool need_img, int need_snap); // (host side, below)
 
+// Shape-specialised kernels (round 6).  KT / ST / NT > 0: the number of snakes, the grid size and the crop radius are
+// compile-time constants — the shapes of the reference's own experiments (4 snakes on 25 x 25 with partial_5 crops:
+// experiments/multiagent.py:79-86, tests/test_multi_snake_env.py:100-104; 10 snakes on 36 x 36: experiments/speeds.py) — so
+// every loop over snakes, rows of 64 cells and window cells has a known trip count, the divisions by S are by a constant and
+// the LDS offsets multi_launch worked out are immediates.  Same source, same results (tests/test_multi_shape_kernels.py
+// compares the two bit for bit); the generic kernels serve every other shape.  WURM_MULTI_SHAPE_KERNELS = 0 switches them off.
+constexpr int SNAP_MAX_SNAKES = 10; // observe_full_snap: 10 mask bits, and owner + 1 <= 11 fits the 4 owner bits
+template <int OBS, int KT, int ST, int NT>
+__device__ __forceinline__ void shape_constants(MultiArgs &p, bool layout, int snap_buffers = -1)
+{
+    if (KT > 0) p.K = KT;
+    if (ST > 0) p.S = ST;
+    if (NT >= 0) p.obs_n = NT;
+    if (OBS == WURM_OBS_PARTIAL && NT >= 0) p.obs_elems = 3ll * (2 * NT + 1) * (2 * NT + 1);
+    if (OBS == WURM_OBS_DEFAULT && ST > 0) p.obs_elems = 3ll * ST * ST;
+    if (layout && KT > 0 && ST > 0 && OBS >= 0) {
+        const int snap = snap_buffers >= 0 ? snap_buffers : (OBS == WURM_OBS_DEFAULT && KT <= SNAP_MAX_SNAKES) ? 1 : 0;
+        (void)multi_layout(p, OBS == WURM_OBS_PARTIAL, snap);
+    }
+}
+
 __device__ __forceinline__ u64 border_bits(const Ctx &cx); // (with the grouped 'full' writer below)
 __device__ __forceinline__ Ctx make_ctx(const MultiArgs &p, int wave, int base_off = 0, bool want_ring = false)
 {
@@ -678,7 +699,6 @@ __device__ __forceinline__ void observe_full(const Ctx &cx, const MultiArgs &p, 
 // store queue would drain while the wave computes — no gain: the waves of a launch stall on the store path together.)
 // 16-bit class code of a cell: body mask of snakes 0..9 | (head owner + 1) << 10 | food << 14 | border << 15
 constexpr int SNAP_OWNER_SHIFT = 10;
-constexpr int SNAP_MAX_SNAKES = 10; // 10 mask bits, and owner + 1 <= 11 fits the 4 owner bits
 
 // class code of every cell of the env in LDS -> snap[] (executed by the wave that owns the env's state)
 __device__ __forceinline__ void snap_write(const Ctx &cx, int hc, unsigned short *snap)
@@ -1439,12 +1459,14 @@ __device__ __forceinline__ void grp_emit_group(const MultiArgs &p, float *obs, l
 // workgroup first step their envs, then write the observations TOGETHER — wave w writes agent w's view of all the
 // workgroup's envs, one linear run (class codes + colour table: see multi_rollout_group_kernel).
 // INJ / OBS: as multi_rollout_kernel — a launch that draws its own random outcomes, with the observation mode a constant.
-template <bool INJ = true, int OBS = -1>
-__global__ __launch_bounds__(512) void multi_step_kernel(MultiArgs p_in)
+// (a shape-specialised instantiation keeps to 128 VGPRs: 4 096 envs are one round of waves at 4 per SIMD, not two at 3)
+template <bool INJ = true, int OBS = -1, int KT = 0, int ST = 0, int NT = -1>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(KT > 0 ? 4 : 1))) void multi_step_kernel(MultiArgs p_in)
 {
     MultiArgs p = p_in;
     if (!INJ) p.has_inj = p.has_rinj = 0;
     if (OBS >= 0) p.obs_mode = OBS;
+    shape_constants<OBS, KT, ST, NT>(p, true);
     const int wave = (int)(threadIdx.x >> 6), wpb = (int)(blockDim.x >> 6);
     const long long env0 = xcd_block(blockIdx.x, gridDim.x) * wpb, env = env0 + wave;
     const bool grouped = p.grp_emit != 0;
@@ -1717,11 +1739,13 @@ __device__ __forceinline__ void wg_observe_snap(const Ctx &cx, const MultiArgs &
     __syncthreads();
 }
 
-template <bool INJ = true>   // (INJ = false: as multi_rollout_kernel — the launch draws its own random outcomes)
+template <bool INJ = true, int OBS = -1, int KT = 0, int ST = 0>   // (INJ = false: as multi_rollout_kernel — the launch draws its own random outcomes)
 __global__ __launch_bounds__(256) void multi_step_wg_kernel(MultiArgs p_in)
 {
     MultiArgs p = p_in;
     if (!INJ) p.has_inj = p.has_rinj = 0;
+    if (OBS >= 0) p.obs_mode = OBS;
+    shape_constants<OBS, KT, ST, -1>(p, true);
     const int tid = (int)threadIdx.x, nth = (int)blockDim.x, wave = uniform(tid >> 6);
     const long long env = xcd_block(blockIdx.x, gridDim.x);
     if (env >= p.N) return; // the whole workgroup: the barriers below see every wave or none
@@ -2339,14 +2363,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void m
     MultiArgs p = p_in;
     if (!INJ) p.has_inj = p.has_rinj = 0;
     if (OBS >= 0) p.obs_mode = OBS;
-    // KT / ST / NT > 0: the number of snakes, the grid size and the crop radius are compile-time constants too (the shapes of
-    // the reference's own experiments): every loop over snakes, rows of 64 cells and window cells has a known trip count
-    if (KT > 0) p.K = KT;
-    if (ST > 0) p.S = ST;
-    if (NT >= 0) p.obs_n = NT;
-    if (OBS == WURM_OBS_PARTIAL && NT >= 0) p.obs_elems = 3ll * (2 * NT + 1) * (2 * NT + 1);
-    if (!TWO && KT > 0 && ST > 0 && (OBS == WURM_OBS_PARTIAL || OBS == WURM_OBS_NONE))
-        (void)multi_layout(p, OBS == WURM_OBS_PARTIAL, 0); // (the LDS offsets multi_launch worked out, as constants)
+    shape_constants<OBS, KT, ST, NT>(p, !TWO && (OBS == WURM_OBS_PARTIAL || OBS == WURM_OBS_NONE), 0);
     const int wave = uniform((int)(threadIdx.x >> 6)), wpb = TWO ? 1 : (int)(blockDim.x >> 6);
     const long long env = xcd_block(blockIdx.x, gridDim.x) * wpb + (TWO ? 0 : wave);
     if (env >= p.N) return;
@@ -2491,6 +2508,25 @@ constexpr int GRP_MAX_SNAKES = 5;   // 3 bits per agent in a 16-bit word (double
 constexpr int GRP_MAX_SNAKES32 = 10; // ... in a 32-bit word (single-buffered: 4 bytes per cell is what the LDS has room for once)
 constexpr int GRP_TAB_BYTES = 128;  // float tab[3][8] at the start of the workgroup's LDS
 constexpr int GRP_CODE_SLACK = 640;  // bytes the writers may READ behind the last code array (grp_emit_cells: 5 x 64 codes)
+
+// LDS of multi_rollout_group_kernel with G envs per workgroup: the colour table, the envs' blocks (multi_layout), the class
+// code buffers (two of 16-bit words, WIDE: one of 32-bit words), the per-step output rows and the snakes' saved scalars.
+// Fills in p's offsets; returns the total (the writers read up to GRP_CODE_SLACK bytes past a code array: what lies behind
+// the last one must be this LDS).
+__host__ __device__ inline int group_layout(MultiArgs &p, int G, bool wide)
+{
+    const int lds_env = multi_layout(p, false, 0), C = p.S * p.S;
+    p.grp_code_bytes = ((wide ? 4 : 2) * C + 15) & ~15;
+    const int nbuf = wide ? 1 : 2;
+    p.grp_out_bytes = (16 * p.K + 1 + 15) & ~15;
+    const int save_bytes = 32 * p.K; // grp_save: 8 ints per snake
+    const int slack0 = (wide ? 2 : 1) * GRP_CODE_SLACK - G * (nbuf * p.grp_out_bytes + save_bytes), slack = slack0 > 0 ? slack0 : 0;
+    p.grp_env0 = GRP_TAB_BYTES;
+    p.grp_codes = p.grp_env0 + G * lds_env;
+    p.grp_outs = p.grp_codes + nbuf * G * p.grp_code_bytes;
+    p.grp_save = p.grp_outs + nbuf * G * p.grp_out_bytes;
+    return GRP_TAB_BYTES + G * (lds_env + nbuf * p.grp_code_bytes + nbuf * p.grp_out_bytes + save_bytes) + slack;
+}
 
 // (sum over a < K of 8^a): a 3-bit value replicated into the K agents' fields
 __device__ __forceinline__ u32 grp_rep(int K) { return (u32)(((1ull << (3 * K)) - 1ull) / 7ull); }
@@ -2711,12 +2747,18 @@ __device__ __forceinline__ void grp_restore(const int *sv, int lane, int K, Snak
 // step t - 1 before they write the codes of step t (a second barrier per step; the transition itself still runs beside the
 // writers: the speeds.py shape, 10 snakes on 36 x 36, has 41 KB of LDS per env with one 32-bit buffer and four envs per CU).
 // INJ = false: as multi_rollout_kernel — the launch draws its own random outcomes, the injected-outcome branches fold away.
-template <int G, int W, int EPS, int OCC, bool WIDE = false, bool INJ = true>
+template <int G, int W, int EPS, int OCC, bool WIDE = false, bool INJ = true, int KT = 0, int ST = 0>
 __global__ __launch_bounds__(64 * (G / EPS + W)) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void multi_rollout_group_kernel(MultiArgs p_in)
 {
     MultiArgs p = p_in;
     if (!INJ) p.has_inj = p.has_rinj = 0;
     p.obs_mode = WURM_OBS_DEFAULT; // (what multi_group_shape requires: a constant here)
+    if (KT > 0 && ST > 0) { // (shape_constants: K, S and with them the whole LDS layout of the group as constants)
+        p.K = KT;
+        p.S = ST;
+        p.obs_elems = 3ll * ST * ST;
+        (void)group_layout(p, G, WIDE);
+    }
     typedef typename std::conditional<WIDE, u32, unsigned short>::type CT;
     constexpr int NSW = G / EPS; // stepper waves
     // SHARE: the (agent, env) blocks of a step are handed out by an LDS counter and the steppers take some too
@@ -3105,7 +3147,8 @@ static bool allow_lds(const void *kernel, size_t bytes)
     return hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess;
 }
 
-struct GroupShape { int G, W, eps, occ; const void *fn; const void *fn_rng; }; // fn_rng: the INJ = false instantiation where one is compiled
+// fn_rng: the INJ = false instantiation where one is compiled; fn_shape: that with K = sk and S = ss compiled in (shape_constants)
+struct GroupShape { int G, W, eps, occ; const void *fn; const void *fn_rng; const void *fn_shape = nullptr; int sk = 0, ss = 0; };
 
 // The shape of multi_rollout_group_kernel that serves this rollout ('full' observations of at most 10 snakes, several steps,
 // a large batch), or nullptr; q: p with the kernel's LDS layout filled in, bytes: its dynamic LDS.
@@ -3117,20 +3160,13 @@ static const GroupShape *multi_group_shape(const MultiArgs &p, MultiArgs &q, siz
         const bool wide = p.K > GRP_MAX_SNAKES; // 32-bit class words, one buffer
         // large batches: G consecutive envs per workgroup, one linear observation run per agent (multi_rollout_group_kernel)
         q = p;
-        const int lds_env = multi_layout(q, false, 0), C = p.S * p.S;
-        q.grp_code_bytes = ((wide ? 4 : 2) * C + 15) & ~15;
-        const int nbuf = wide ? 1 : 2;
-        q.grp_out_bytes = (16 * p.K + 1 + 15) & ~15;
-        const int save_bytes = 32 * p.K; // grp_save: 8 ints per snake
-        // (the writers read up to GRP_CODE_SLACK bytes past a code array: what lies behind the last one must be this LDS)
-        auto slack = [&](int G) { return std::max(0, (wide ? 2 : 1) * GRP_CODE_SLACK - G * (nbuf * q.grp_out_bytes + save_bytes)); };
-        auto total = [&](int G) {
-            return GRP_TAB_BYTES + G * (lds_env + nbuf * q.grp_code_bytes + nbuf * q.grp_out_bytes + save_bytes) + slack(G);
-        };
+        auto total = [&](int G) { MultiArgs t = p; return group_layout(t, G, wide); };
         // shape: G envs, W writer waves, EPS envs per stepper wave, OCC waves per SIMD (option WURM_MULTI_GROUP_SHAPE =
         // 1000 G + 100 W + 10 EPS + OCC picks one of the compiled shapes; 0 = automatic: the first that fits)
         typedef GroupShape Shape;
         static const Shape wide_shapes[] = { // 6 .. 10 snakes (the first that fits)
+            // (no shape-specialised form: with 10 snakes' loops unrolled the kernel spills 89 VGPRs at its 128 and measured 0.657 ms
+            // per 4 steps of the speeds.py shape against 0.616 — profiles/r06_shape_kernels_ab.txt)
             {4, 10, 1, 4, (const void *)multi_rollout_group_kernel<4, 10, 1, 4, true>, (const void *)multi_rollout_group_kernel<4, 10, 1, 4, true, false>},
             {4, 5, 1, 4, (const void *)multi_rollout_group_kernel<4, 5, 1, 4, true>, nullptr},
             {2, 10, 1, 4, (const void *)multi_rollout_group_kernel<2, 10, 1, 4, true>, nullptr},
@@ -3141,7 +3177,8 @@ static const GroupShape *multi_group_shape(const MultiArgs &p, MultiArgs &q, siz
             // 8 / 4 / 1 / 6 — a writer per agent, 6 waves per SIMD at 80 VGPRs with 130 bytes of scratch — 0.44-0.51 / 1.57-1.81
             // depending on the box and on how the allocator spills; 4 / 4 / 1 / 4: 0.51 / 1.66; 8 / 4 / 2 / 4: 1.79 per 64;
             // the two-wave kernel of round 3: 0.55 / 1.73-2.15 — profiles/r04_multi_group_probe.txt)
-            {8, 2, 1, 5, (const void *)multi_rollout_group_kernel<8, 2, 1, 5>, (const void *)multi_rollout_group_kernel<8, 2, 1, 5, false, false>},
+            {8, 2, 1, 5, (const void *)multi_rollout_group_kernel<8, 2, 1, 5>, (const void *)multi_rollout_group_kernel<8, 2, 1, 5, false, false>,
+             (const void *)multi_rollout_group_kernel<8, 2, 1, 5, false, false, 4, 25>, 4, 25}, // BASELINE configs[3]
             {8, 4, 1, 6, (const void *)multi_rollout_group_kernel<8, 4, 1, 6>, (const void *)multi_rollout_group_kernel<8, 4, 1, 6, false, false>},
             {4, 4, 1, 4, (const void *)multi_rollout_group_kernel<4, 4, 1, 4>, (const void *)multi_rollout_group_kernel<4, 4, 1, 4, false, false>},
             {8, 4, 2, 4, (const void *)multi_rollout_group_kernel<8, 4, 2, 4>, nullptr},
@@ -3160,10 +3197,7 @@ static const GroupShape *multi_group_shape(const MultiArgs &p, MultiArgs &q, siz
         }
         if (!sh) return nullptr;
         const int G = sh->G;
-        q.grp_env0 = GRP_TAB_BYTES;
-        q.grp_codes = q.grp_env0 + G * lds_env;
-        q.grp_outs = q.grp_codes + nbuf * G * q.grp_code_bytes;
-        q.grp_save = q.grp_outs + nbuf * G * q.grp_out_bytes;
+        (void)group_layout(q, G, wide);
         bytes = (size_t)total(G);
         return sh;
     }
@@ -3183,7 +3217,9 @@ static int multi_launch(MKind kind, MultiArgs &p, void *stream)
         if (const GroupShape *sh = multi_group_shape(p, q, bytes)) {
             const dim3 gg((unsigned)((p.N + sh->G - 1) / sh->G)), bb(64 * (sh->G / sh->eps + sh->W));
             (void)hipGetLastError();
-            const void *kfn = (!p.has_inj && !p.has_rinj && sh->fn_rng) ? sh->fn_rng : sh->fn;
+            const bool rng_g = !p.has_inj && !p.has_rinj;
+            const void *kfn = (rng_g && opt.multi_shape_kernels != 0 && sh->fn_shape && p.K == sh->sk && p.S == sh->ss) ? sh->fn_shape
+                            : (rng_g && sh->fn_rng) ? sh->fn_rng : sh->fn;
             if (!allow_lds(kfn, bytes)) return WURM_ERR_HIP;
             q.grp_variant = (int)opt.multi_group_variant;
             void *args[] = {&q};
@@ -3219,7 +3255,10 @@ static int multi_launch(MKind kind, MultiArgs &p, void *stream)
         (void)hipGetLastError();
         const dim3 g((unsigned)p.N), b(256);
         p.grp_variant = (int)opt.multi_group_variant;
-        const void *kwg = (p.has_inj || p.has_rinj) ? (const void *)multi_step_wg_kernel<true> : (const void *)multi_step_wg_kernel<false>;
+        const void *kwg = (p.has_inj || p.has_rinj) ? (const void *)multi_step_wg_kernel<true>
+                        : (kind == MK_STEP && opt.multi_shape_kernels != 0 && snap && p.K == 10 && p.S == 36)
+                              ? (const void *)multi_step_wg_kernel<false, WURM_OBS_DEFAULT, 10, 36> // experiments/speeds.py
+                              : (const void *)multi_step_wg_kernel<false>;
         const void *kf = kind == MK_STEP ? kwg
                        : kind == MK_RESET ? (const void *)multi_reset_wg_kernel : (const void *)multi_observe_wg_kernel;
         if (!allow_lds(kf, (size_t)lds)) return WURM_ERR_HIP;
@@ -3254,9 +3293,11 @@ static int multi_launch(MKind kind, MultiArgs &p, void *stream)
     const bool rng = !p.has_inj && !p.has_rinj;
     // the shape of the reference's multi-agent experiments (experiments/multiagent.py:79-86: 4 snakes on 25 x 25, partial_5)
     // has kernels with K, S and the crop radius as constants (WURM_MULTI_SHAPE_KERNELS = 0: the generic ones)
-    const bool shape_4_25_5 = kind == MK_ROLLOUT && rng && opt.multi_shape_kernels != 0 && p.obs_mode == WURM_OBS_PARTIAL &&
-                              p.K == 4 && p.S == 25 && p.obs_n == 5;
+    const bool shape_4_25 = rng && opt.multi_shape_kernels != 0 && p.K == 4 && p.S == 25;
+    const bool shape_4_25_5 = shape_4_25 && p.obs_mode == WURM_OBS_PARTIAL && p.obs_n == 5;
     const void *kstep = !rng ? (const void *)multi_step_kernel<true, -1>
+                      : shape_4_25_5 ? (const void *)multi_step_kernel<false, WURM_OBS_PARTIAL, 4, 25, 5>
+                      : shape_4_25 && p.obs_mode == WURM_OBS_DEFAULT ? (const void *)multi_step_kernel<false, WURM_OBS_DEFAULT, 4, 25>
                       : p.obs_mode == WURM_OBS_DEFAULT ? (const void *)multi_step_kernel<false, WURM_OBS_DEFAULT>
                       : p.obs_mode == WURM_OBS_PARTIAL ? (const void *)multi_step_kernel<false, WURM_OBS_PARTIAL>
                       : (const void *)multi_step_kernel<false, WURM_OBS_NONE>;
@@ -3265,7 +3306,7 @@ static int multi_launch(MKind kind, MultiArgs &p, void *stream)
                    : kind == MK_OBSERVE ? (const void *)multi_observe_kernel
                    : kind == MK_CHECK ? (const void *)multi_check_kernel
                    : (p.has_inj || p.has_rinj) ? (const void *)multi_rollout_kernel<false, true>
-                   : shape_4_25_5 ? (const void *)multi_rollout_kernel<false, false, WURM_OBS_PARTIAL, 4, 25, 5>
+                   : kind == MK_ROLLOUT && shape_4_25_5 ? (const void *)multi_rollout_kernel<false, false, WURM_OBS_PARTIAL, 4, 25, 5>
                    : p.obs_mode == WURM_OBS_PARTIAL ? (const void *)multi_rollout_kernel<false, false, WURM_OBS_PARTIAL>
                    : p.obs_mode == WURM_OBS_NONE ? (const void *)multi_rollout_kernel<false, false, WURM_OBS_NONE>
                    : (const void *)multi_rollout_kernel<false, false>;

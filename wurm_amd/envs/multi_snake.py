@@ -33,6 +33,8 @@ tensors the caller holds are watched for in-place edits (DESIGN.md §5, §7 devi
 """
 import ctypes
 import os
+import sys
+import weakref
 from collections import namedtuple, OrderedDict
 from typing import Dict, Optional, Tuple
 
@@ -147,6 +149,42 @@ for _name in ('__contains__', '__iter__', '__len__', '__eq__', '__ne__', '__repr
     setattr(_LazyInfo, _name, _filling(_name))
 
 
+class _LazyResetObs(dict):
+    """What `reset(done)` returns once the caller has been seen to DISCARD it (experiments/speeds.py:30-38 does: `env.reset(
+    done['__all__'])` as a statement): the K observations of the reference's return value (:834-836) are not worth a second
+    observation stream out of every step launch for a caller that drops them.  The dict fills itself — the postponed reset
+    applied, `_observe` of the mode the reset was called in — the first time anything reads it; and if the caller still
+    holds it when the state is about to change (the next step, anything that flushes the postponed reset) the env fills it
+    first, so it always holds what the reference would have returned.  Either way the env goes back to precomputing."""
+    __slots__ = ('_env', '_mode', '__weakref__')
+
+    def __init__(self, env, mode):
+        dict.__init__(self)
+        self._env, self._mode = env, mode
+
+    def _fill(self):
+        env = self._env
+        if env is not None:
+            self._env = None
+            env._settle_reset_obs(self)
+
+    def __missing__(self, key):
+        if self._env is None:
+            raise KeyError(key)
+        self._fill()
+        return dict.__getitem__(self, key)
+
+    def __reduce__(self):
+        self._fill()
+        return (dict, (dict(self),))
+
+
+for _name in ('__contains__', '__iter__', '__len__', '__eq__', '__ne__', '__repr__', '__setitem__', '__delitem__', '__or__',
+              '__ror__', '__ior__', '__reversed__', 'get', 'keys', 'values', 'items', 'copy', 'pop', 'popitem', 'setdefault',
+              'update', 'clear'):
+    setattr(_LazyResetObs, _name, _filling(_name))
+
+
 class _Dynamic(object):
     """Attribute of MultiSnake that callers assign after construction (reference tests/test_multi_snake_env.py:180,288,
     401-403,618; experiments/multiagent.py:340,345 anneal `food_rate` / `food_on_death_prob` every step).  The reference reads
@@ -205,6 +243,12 @@ class MultiSnake(object):
     _rewards_at = _boost_at = 0
     _slab = None            # (out_f32, out_u8) of the current output slab
     _mc_ready = False
+    # what reset(done) returned last / whether the caller keeps it (module docstring: "discarded reset observations")
+    _reset_obs_probe = None  # the precomputed dict the last reset(done) handed out: looked at by the next step
+    _reset_obs_drops = 0     # consecutive resets whose returned dict nobody held at the next step
+    _RESET_OBS_DROPS = 3     # ... this many: reset(done) returns a _LazyResetObs and the steps stop precomputing
+    _lazy_obs_mode = False
+    _lazy_obs_ref = None     # weak reference to the _LazyResetObs of the postponed reset, while it may still need filling
 
     @property
     def _state_dirty(self):
@@ -393,7 +437,8 @@ class MultiSnake(object):
     _DERIVED = ('_mc', '_sl', '_mc_addr', '_fs', '_pend', '_cfg_cache', '_mc_cfg', '_mc_ready', '_mc_mode', '_mirror',
                 '_mirror_off', '_lazy_mirror', '_mirror_why', '_watched', '_write_outs', '_touches', '_chk', '_chk_has_after',
                 '_chk_armed_at', '_chk_void_at', '_check_calls', '_check_step', '_slab', '_stor', '_keys', '_get_device',
-                '_rewards_t', '_boost_t', '_rewards_at', '_boost_at', '_rewards_src', '_info', '_cfg_dirty')
+                '_rewards_t', '_boost_t', '_rewards_at', '_boost_at', '_rewards_src', '_info', '_cfg_dirty',
+                '_reset_obs_probe', '_reset_obs_drops', '_lazy_obs_mode', '_lazy_obs_ref')
 
     def __getstate__(self):
         self._state()   # (applies a postponed reset, writes a lazy mirror out)
@@ -521,6 +566,41 @@ class MultiSnake(object):
         fs = self._fs
         fs.pending = False
         self._launch_reset(self._pend, None, _lib.OBS_NONE, 0, fs.pend_call, None)
+        if self._lazy_obs_ref is not None:   # the dict that reset returned, if the caller still holds it: filled NOW, while
+            lz = self._lazy_obs_ref()        # the state is what the reset left
+            if lz is not None:
+                lz._fill()
+            self._lazy_obs_ref = None
+
+    def _settle_reset_obs(self, lz):
+        """fills the _LazyResetObs `lz`: the postponed reset applied (if it still is postponed), then the observation of the
+        mode that reset was called in — what the reference's reset returned (:834-836).  The caller reads, or still holds,
+        what reset returns after all: back to precomputing it in the step launch."""
+        self._lazy_obs_ref = None
+        if self._pending:
+            self._flush()
+        obs = self._observe(lz._mode)
+        dict.update(lz, obs)
+        self._lazy_obs_mode = False
+        self._reset_obs_drops = -(1 << 20)   # (no flapping: a caller that reads it once is a caller that reads it)
+        self._fs.want_obs_after = True
+
+    def _reset_obs_bookkeeping(self):
+        """in front of a step: did the caller keep what the last reset(done) returned?"""
+        probe, self._reset_obs_probe = self._reset_obs_probe, None
+        if probe is not None:
+            # the references of a dict nobody else holds: the slab's list of precomputed dicts, `probe`, getrefcount's argument
+            if sys.getrefcount(probe) <= 3:
+                self._reset_obs_drops += 1
+                if self._reset_obs_drops >= self._RESET_OBS_DROPS and not self._half:
+                    self._lazy_obs_mode = True
+            else:
+                self._reset_obs_drops = min(self._reset_obs_drops, 0)
+        if self._lazy_obs_ref is not None:
+            lz = self._lazy_obs_ref()
+            self._lazy_obs_ref = None
+            if lz is not None:
+                lz._fill()   # still held: the state is about to change
 
     # ---- the resident mirror (include/wurm_hip.h: wurm_multi_call.resident; protocol as in envs/_fast_step.py)
 
@@ -711,6 +791,13 @@ class MultiSnake(object):
 
     # ------------------------------------------------------------------ observations
 
+    def sanitize_movements(self, movements: torch.Tensor, orientations: torch.Tensor) -> torch.Tensor:
+        """reference :336-339: a move straight back into the snake's own neck (movement == stored orientation) becomes the
+        opposite direction.  A helper of the reference's `step` (:493) that callers can reach; here the step kernel does it
+        itself (multi_snake.hip: multi_step_body), so this is the same three torch ops for whoever calls it."""
+        mask = orientations == movements
+        return (movements + (mask * 2).long()).fmod(4)
+
     def _observe(self, mode: str = None) -> Dict[str, torch.Tensor]:
         """reference :283-334"""
         if mode is None:
@@ -834,9 +921,18 @@ class MultiSnake(object):
     def step(self, actions: Dict[str, torch.Tensor]) -> Tuple[Dict[str, torch.Tensor], dict, dict, dict]:
         """reference :462-731.  One launch (wurm_multi_step_slot) from the step machine; the four dicts it returns were
         built when the output slab was."""
+        if self._reset_obs_probe is not None or self._lazy_obs_ref is not None:
+            self._reset_obs_bookkeeping()
+        if self._watched and self._alias_free():
+            # The caller read a state attribute earlier (experiments/multiagent.py:531 reads `env.heads`) and has let go of
+            # the tensor since: nothing can edit the state behind the machine's back any more, so nothing is left to watch —
+            # after one last look at the version counters (an edit made before the alias was dropped must not be forgotten)
+            self._watch_ok()
+            self._watched = ()
         if not (self._watched or self._lifetimes_touched or self._half):
             out = self._fs.step_multi(actions)
             if out.__class__ is tuple:
+                self._info = None  # (reference :729 rebinds `self.info` every step: an assigned one does not outlive it)
                 return out
         return self._slow_step(actions)
 
@@ -1078,13 +1174,24 @@ class MultiSnake(object):
             # (the machine checks that `done` is the very tensor the last step returned, unmodified, that nothing has consumed a
             # counter since, and that nobody else holds a state tensor: _alias_free / wurm_torch_alias_free)
             if fs.last_fresh:
-                obs = fs.reset_lazy(done, return_observations)
-                if obs is not NotImplemented:
-                    # env_lifetimes is all zeros here (nobody has asked for it): `env_lifetimes[done] = 0` (:797) is a no-op
-                    self._chk_has_after = had_after  # the launch also left the masks of the state this reset produces
-                    if obs is not None and self._half:
-                        obs = OrderedDict((k, v.to(torch.half)) for k, v in obs.items())
-                    return obs
+                if return_observations and self._lazy_obs_mode:
+                    # the caller has been discarding what reset returns: postponed without the precomputed observation; the
+                    # dict fills itself if it is looked at after all (_LazyResetObs)
+                    if fs.reset_lazy(done, False) is None:
+                        self._chk_has_after = False
+                        lz = _LazyResetObs(self, self.observation_mode)
+                        self._lazy_obs_ref = weakref.ref(lz)
+                        return lz
+                else:
+                    obs = fs.reset_lazy(done, return_observations)
+                    if obs is not NotImplemented:
+                        # env_lifetimes is all zeros here (nobody has asked for it): `env_lifetimes[done] = 0` (:797) is a no-op
+                        self._chk_has_after = had_after  # the launch also left the masks of the state this reset produces
+                        if obs is not None:
+                            self._reset_obs_probe = obs
+                            if self._half:
+                                obs = OrderedDict((k, v.to(torch.half)) for k, v in obs.items())
+                        return obs
         if done is None:
             done = self._norm('dones', (self.num_envs * self.num_snakes,), torch.bool) \
                 .view(self.num_envs, self.num_snakes).all(dim=1)
