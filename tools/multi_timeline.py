@@ -18,6 +18,7 @@ ap.add_argument('--snakes', type=int, default=4)
 ap.add_argument('--size', type=int, default=25)
 ap.add_argument('--iters', type=int, default=24)
 ap.add_argument('--rollout', type=int, default=0, help='fused rollout of this many steps with the training dynamics and partial_5 (cfg4-prime): per-segment TOTALS over the launch')
+ap.add_argument('--train', action='store_true', help="per call with the reference's training dynamics and partial_5 crops (cfg4-prime): multi_step_kernel's plain path")
 ap.add_argument('--speeds', action='store_true', help="experiments/speeds.py's env: boost, respawn_mode='any' (one env per workgroup at 10 x 36 x 36)")
 args = ap.parse_args()
 if 'timeline' not in os.environ.get('WURM_HIP_LIBRARY', ''):
@@ -53,6 +54,12 @@ if args.rollout:
         print(f'  {name:>20s}  mean {c.mean():8.0f}  p90 {np.percentile(c, 90):8.0f}   {100 * c.mean() / life.mean():5.1f} %')
     print(f'  per step: mean {life.mean():.0f}  p90 {np.percentile(life, 90):.0f}')
     sys.exit(0)
+if args.train:
+    kw = dict(observation_mode='partial_5', food_mode='random_rate', respawn_mode='any', boost_cost_prob=0.25,
+              food_on_death_prob=0.33, food_rate=2.5e-4)
+    names = ['entry', 'loaded (mirror + inputs)', 'reset applied, inputs', 'prologue / boost phase', 'phase', 'death / delete',
+             'food placed', 'body done', 'outputs', 'state stored', 'cell codes + counts', '-', 'crops issued', 'pixel table', '-', 'drained']
+    order = [0, 1, 2, 3, 4, 5, 10, 6, 7, 8, 9, 13, 12, 15]
 env = MultiSnake(N, K, S, device=torch.device('cuda:0'), seed=0, **kw)
 if args.speeds:  # multi_step_wg_kernel stamps fewer points
     order = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 12, 15]
@@ -76,6 +83,6 @@ life = st[:, 15] - st[:, 0]
 print(f'multi_step_kernel, {N} x {S} x {S} x {K}: {len(st)} wave samples; 10 ns ticks')
 for a, b in zip(idx[:-1], idx[1:]):
     c = st[:, b] - st[:, a]
-    print(f'  {names[a]:>13s} -> {names[b]:13s} p10 {int(np.percentile(c, 10)):6d}  p50 {int(np.median(c)):6d}  p90 {int(np.percentile(c, 90)):6d}  '
+    print(f'  {names[a]:>24s} -> {names[b]:24s} p10 {int(np.percentile(c, 10)):6d}  p50 {int(np.median(c)):6d}  p90 {int(np.percentile(c, 90)):6d}  '
           f'max {int(c.max()):6d}   {100.0 * np.median(c) / np.median(life):5.1f} % of p50 life')
 print(f'  wave lifetime: p10 {int(np.percentile(life, 10))}  p50 {int(np.median(life))}  p90 {int(np.percentile(life, 90))}  max {int(life.max())}')

@@ -1550,6 +1550,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(KT > 0 ? 4 
     WURM_TLS(cx, 8);
     clean = from_mirror || rebuild || plain; // lds_check sees everything there is to check
     if (!solo) store_state();
+    WURM_TLS(cx, 9);
     }
     if (solo) { // every wave for itself: its env's class codes -> its K agents' views (no barrier)
         WURM_TLS(cx, 9);
@@ -1602,6 +1603,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(KT > 0 ? 4 
         return;
     }
     if (p.obs_mode != WURM_OBS_NONE) observe(cx, p, p.obs, env, sn);
+#ifdef WURM_TIMELINE
+    WURM_TLS(cx, 12);
+    if (p.obs_after == nullptr && p.obs_mode != WURM_OBS_NONE) WURM_TLS_STORE(cx, p.obs + env * p.obs_elems);
+#endif
     if (p.obs_after == nullptr || p.obs_mode == WURM_OBS_NONE) return;
     const bool touched = reset_for_obs_after(cx, p, env, sn, r);
     if (p.err_after != nullptr) {
@@ -2156,6 +2161,14 @@ __device__ __forceinline__ void multi_reset_grid(const Ctx &cx, const MultiArgs 
             Words w = rng_words(p.seed, call, env_id, RNG_SPAWN, (u32)K);
             dnew = (int)(w.w[1] >> 30);
             if (had_map) {
+                cell = respawn_cell_codes(cx, cx.hmap, w.w[0]);
+            } else if (p.obs_mode == WURM_OBS_PARTIAL) {
+                // no map of this state yet (the postponed reset in front of a per-call step: the launch has just loaded the
+                // env): one scan builds it — 4 100 cycles + 2 500 for the search, where build_occ + spawn_cells + rank_select
+                // below took 23 000 in every env with a dead snake, and the launch ends with its slowest wave
+                // (profiles/r06_kernel_timeline_multi.txt).  hmap is the crops' map of cell codes in such a launch anyway (the one-env-per-
+                // workgroup kernels, which keep flags in it, never write crops).
+                (void)cell_codes(cx, sn.hc, cx.hmap, cx.has_ring ? cx.ring : border_bits(cx));
                 cell = respawn_cell_codes(cx, cx.hmap, w.w[0]);
             } else if ((C & 7) == 0) {
                 cell = respawn_cell_rows(cx, sn.hc, w.w[0]);
