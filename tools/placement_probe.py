@@ -42,11 +42,13 @@ numel = 16 * 4 * 4096 * 3 * 25 * 25 if CFG4 else 16 * 8192 * 3 * 36 * 36
 held = []
 for j in range(8):
     # both forms into the SAME block (results are dropped: the caching allocator hands the block back), three launches each
-    rot = [one(1) for _ in range(3)]
-    p = rot[-1][1]['observations'].data_ptr()
-    rot = min(t for t, _ in rot)
-    same = min(one(0)[0] for _ in range(3))
-    skews = {k: min(one(k)[0] for _ in range(3)) for k in (2, 4, 256)} if not CFG4 else {}
+    first = [one(0 if '--swap' in sys.argv else 1) for _ in range(3)]   # (--swap: the other form takes the fresh block first)
+    p = first[-1][1]['observations'].data_ptr()
+    first = min(t for t, _ in first)
+    second = min(one(1 if '--swap' in sys.argv else 0)[0] for _ in range(3))
+    rot, same = (second, first) if '--swap' in sys.argv else (first, second)
+    again = min(one(1)[0] for _ in range(3))
+    skews = {k: min(one(k)[0] for _ in range(3)) for k in ((-1,) if '--linear' in sys.argv else (2, 4, 256))} if not CFG4 else {}
     x = torch.empty(numel, dtype=torch.float32, device=dev)   # takes that block out of the cache: the next launches get another
     assert x.data_ptr() == p
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -55,7 +57,7 @@ for j in range(8):
         e0.record(); x.fill_(0.5); e1.record(); torch.cuda.synchronize()
         fills.append(e0.elapsed_time(e1))
     held.append(x)
-    print(f'block {j} at 0x{p:x}: rollout, every env\'s rows in the same order {same:.3f} ms, rows started at an env-dependent row {rot:.3f} ms, '
-          + ''.join(f'skew by id mod {k} {v:.3f} ms, ' for k, v in skews.items()) +
+    print(f'block {j} at 0x{p:x}: rollout, every env\'s rows in the same order {same:.3f} ms, rows started at an env-dependent row {rot:.3f} ms (again, last: {again:.3f}), '
+          + ''.join((f'plane by plane front to back {v:.3f} ms, ' if k < 0 else f'skew by id mod {k} {v:.3f} ms, ') for k, v in skews.items()) +
           f'  '
           f'linear fill of the same block {min(fills):.3f} ms = {numel * 4 / min(fills) / 1e9:.2f} TB/s', flush=True)
