@@ -41,6 +41,7 @@ extern "C" {
 #define WURM_ERR_UNSUPPORTED (-2) /* -> NotImplementedError         */
 #define WURM_ERR_HIP (-3)         /* a HIP launch failed            */
 #define WURM_ERR_DTYPE (-4)       /* -> TypeError                   */
+#define WURM_MIRROR_REFUSED 1     /* wurm_grid_step_reset only: the call ran; the mirror it was asked to build was refused */
 
 /* observation modes: single_snake.py:130-195, simple_gridworld.py:111-133, multi_snake.py:283-334 */
 #define WURM_OBS_DEFAULT 0     /* RGB/255, (N,3,S,S)  (MultiSnake: 'full', per agent)         */
@@ -143,11 +144,15 @@ typedef struct wurm_single_call {
     int actions_dtype, obs_mode, obs_n, size;
     int post_reset;                  /* != 0: envs that finished are rebuilt (call + 1) and STORED after `obs`   */
     int start_y, start_x;            /* SimpleGridworld start location (simple_gridworld.py:254-262)             */
-    void *resident;                  /* nullable in/out, SingleSnake only: wurm_single_resident_bytes() bytes the
-                                        caller owns — a compact mirror of `envs` that the step reads INSTEAD of envs
-                                        and keeps current (envs itself is still written every call)               */
+    void *resident;                  /* nullable in/out: wurm_single_resident_bytes() (SimpleGridworld:
+                                        wurm_grid_resident_bytes()) bytes the caller owns — a compact mirror of `envs` that
+                                        the step reads INSTEAD of envs and keeps current (envs itself is still written
+                                        every call)                                                                */
     int resident_valid;              /* != 0: nothing but calls that were given `resident` has written envs since
-                                        the mirror was last maintained; 0: it is rebuilt from envs first          */
+                                        the mirror was last maintained; 0: it is rebuilt from envs first.
+                                        SimpleGridworld also knows 2 = REFUSED: the launch that built the mirror found envs
+                                        outside the lane kernel's domain; the planes stay the state and the mirror unused
+                                        until the caller clears the field again (wurm_grid_resident_bytes)          */
     int resident_lazy;               /* != 0: the step does not write envs at all; envs is brought up to date by
                                         wurm_single_resident_flush (call it before anything else reads or writes
                                         envs, and before clearing resident_valid)                                 */
@@ -190,6 +195,24 @@ int wurm_single_resident_flush(const wurm_single_call *c, void *stream);
 
 /* The same for SimpleGridworld (simple_gridworld.py:135-202,225-268). */
 int wurm_grid_step_reset(const wurm_single_call *c, void *stream);
+
+/* SimpleGridworld's mirror (round 6; wurm_amd/csrc/gridworld_lane.hip): 16 bytes of header + one 32-bit record per env (agent
+ * cell | food cell << 16) — an env in the reference's own invariant IS two cell indices, so with the mirror the per-call
+ * step of a large batch neither scans the (N,2,S,S) planes nor (while the mirror is lazy) writes them, and it is ONE launch:
+ * the lane kernel's domain (at most one agent, at most one food, values 0 / 1) is closed under this library's own launches,
+ * so once a launch has built the mirror without meeting an env outside it, none can appear until something else writes the
+ * state — which is when the caller clears resident_valid.  The launch that BUILDS the mirror (resident_valid == 0) reads
+ * that verdict back synchronously (4 bytes, one stream synchronisation): resident_valid becomes 1, or 2 = refused (then the
+ * planes are the state, every call takes the two-launch path, and the mirror is tried again when the caller clears the
+ * field).  Served: 5 <= size <= 64, observation default / raw / positions / none, from WURM_LANE_STEP_MIN_ENVS envs on
+ * (WURM_RESIDENT_MIN_ENVS overrides); wurm_grid_resident_size: without the batch-size threshold.  Protocol otherwise as
+ * wurm_single_resident_bytes: wurm_grid_step_slot maintains c->resident_valid (wurm_grid_step_reset, whose block is const,
+ * returns WURM_MIRROR_REFUSED instead of WURM_OK from the call that was to build the mirror: the caller sets the field to 2),
+ * the caller clears it whenever anything else writes envs, and wurm_grid_resident_flush writes envs from a lazy valid mirror
+ * (a no-op otherwise).  0 also for an image observation whose run of four envs exceeds the lane kernel's 16 KB byte slab. */
+int64_t wurm_grid_resident_bytes(int64_t num_envs, int size, int obs_mode);
+int64_t wurm_grid_resident_size(int64_t num_envs, int size, int obs_mode);
+int wurm_grid_resident_flush(const wurm_single_call *c, void *stream);
 
 /* Caller-allocated output slabs holding the fresh output tensors of the next `steps` step() calls (the host classes
  * carve the tensors they return out of them; a slab is never written twice).  Layouts: obs, obs_after

@@ -94,7 +94,7 @@ class HipBackend(object):
         N, _, S, _ = envs.shape
         m, n = _lib.parse_obs_mode(mode)
         lazy = resident is not None and bool(resident.get('lazy'))
-        if lazy and resident.get('valid') and resident.get('envs_dev') is not None:
+        if lazy and resident.get('valid') == 1 and resident.get('envs_dev') is not None:
             e = resident['envs_dev']  # stale by design; the mirror describes the state
         else:
             e = self._t(envs)
@@ -117,6 +117,8 @@ class HipBackend(object):
         c.start_y, c.start_x = (-1, -1) if grid is None else grid
         if resident is not None:
             nbytes = 32 * N if S == 9 else N * ((((S * S + 255) >> 8) * 512) + 48)  # (lane_resident.hpp / grid_rollout.hip)
+            if grid is not None:
+                nbytes = 16 + 4 * N                                                 # (gridworld_lane.hip: header + records)
             if resident.get('buf') is None or resident['buf'].numel() != nbytes:
                 resident['buf'], resident['valid'] = self._empty((nbytes,), torch.uint8), 0
             c.resident, c.resident_valid = _lib.ptr(resident['buf']), int(resident.get('valid', 0))
@@ -124,18 +126,25 @@ class HipBackend(object):
         import ctypes
         fn = self.lib.wurm_single_step_reset if grid is None else self.lib.wurm_grid_step_reset
         rc = fn(ctypes.addressof(c), self._stream())
-        _lib.check(rc, 'wurm_single_step_reset')
+        refused = grid is not None and resident is not None and rc == 1   # WURM_MIRROR_REFUSED: the call ran
+        _lib.check(0 if refused else rc, 'wurm_single_step_reset')
         if resident is not None:
+            served = int(self.lib.wurm_single_resident_size(_lib.i64(N), S, m, n)) > 0 if grid is None else \
+                (int(self.lib.wurm_grid_resident_size(_lib.i64(N), S, m)) > 0 and
+                 N >= int(self.lib.wurm_get_option(b'WURM_LANE_STEP_MIN_ENVS')))
+            was = int(resident.get('valid', 0))
             resident['valid'] = int(inject_food is None and inject_reset is None and inject_pre_reset is None and
-                                    not post_reset and grid is None and
-                                    int(self.lib.wurm_single_resident_size(_lib.i64(N), S, m, n)) > 0)
+                                    not post_reset and served)
+            if grid is not None and resident['valid'] and (refused or was == 2):
+                resident['valid'] = 2          # (stays refused until the caller clears it: include/wurm_hip.h)
+            flush = self.lib.wurm_single_resident_flush if grid is None else self.lib.wurm_grid_resident_flush
             if lazy:
                 resident['envs_dev'] = e
                 c.resident_valid = resident['valid']
                 if resident.get('sync', True):
-                    _lib.check(self.lib.wurm_single_resident_flush(ctypes.addressof(c), self._stream()), 'flush')
+                    _lib.check(flush(ctypes.addressof(c), self._stream()), 'flush')
         torch.cuda.synchronize()
-        if not lazy or resident.get('sync', True) or not resident['valid']:  # (not valid: the call wrote envs itself)
+        if not lazy or resident.get('sync', True) or resident['valid'] != 1:  # (not valid: the call wrote envs itself)
             envs[...] = e.cpu().numpy()
         actions[...] = a.cpu().numpy()
         assert torch.equal(copy, done), 'done_copy != done'

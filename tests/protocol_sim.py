@@ -203,11 +203,23 @@ class SimSingle(object):
 
     def wurm_single_resident_flush(self, c_addr, stream):
         c = _lib.SingleCall.from_address(_addr(c_addr))
-        if c.resident and c.resident_lazy and c.resident_valid:
+        if c.resident and c.resident_lazy and c.resident_valid == 1:
             self.calls.append('flush')
             N = c.num_envs
             self.write_state(c.envs, N, c.size, [int(x) for x in mem(c.resident, N, np.uint64)])
         return 0
+
+    # SimpleGridworld's mirror (round 6): same protocol, plus resident_valid == 2 — REFUSED: the launch that built the mirror
+    # found envs it cannot describe, the planes stay the state (`refuse_builds`: every build of this simulator ends that way)
+    refuse_builds = False
+
+    def wurm_grid_resident_bytes(self, N, S, m):
+        return 8 * _int(N) if (self.mirror_auto and self.C == 2) else 0
+
+    def wurm_grid_resident_size(self, N, S, m):
+        return 8 * _int(N) if self.C == 2 else 0
+
+    wurm_grid_resident_flush = wurm_single_resident_flush
 
     def _actions(self, actions, dtype, count):
         return mem(actions, count, np.int64 if dtype == 0 else np.int32)
@@ -231,7 +243,8 @@ class SimSingle(object):
             return -3
         assert 0 <= slot < sl.steps
         start = b'%d,%d' % (c.start_y, c.start_x) if self.C == 2 else b''
-        from_mirror = bool(c.resident) and bool(c.resident_valid)
+        from_mirror = bool(c.resident) and c.resident_valid == 1
+        refused = bool(c.resident) and (c.resident_valid == 2 or (self.refuse_builds and not from_mirror))
         self.calls.append('step')
         toks = [int(x) for x in mem(c.resident, N, np.uint64)] if from_mirror else self.read_state(c.envs, N, S)
         if pending:
@@ -263,12 +276,14 @@ class SimSingle(object):
             for e, h in enumerate(new):
                 # only the mirror-resident kernel computes them; a finished env is never vouched for
                 cm[e] = 0xFFFFFFFF if (dn[e] or not c.resident) else check_err(h)
-        if c.resident:
+        if c.resident and not refused:
             mem(c.resident, N, np.uint64)[:] = np.array(new, dtype=np.uint64)
             c.resident_valid = 1
-            if not c.resident_lazy:
+            if not c.resident_lazy or (self.C == 2 and not from_mirror):   # (SimpleGridworld: a launch that BUILDS the mirror writes the planes whatever `lazy` says)
                 self.write_state(c.envs, N, S, new)
         else:
+            if refused:
+                c.resident_valid = 2
             self.write_state(c.envs, N, S, new)
         return 0
 

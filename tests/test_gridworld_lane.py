@@ -311,3 +311,143 @@ def test_class_loop_at_the_default_threshold():
         assert len(x) == len(y)
         for i, (u, v) in enumerate(zip(x, y)):
             assert torch.equal(u, v), f'record {k} output {i}'
+
+
+# ---- round 6: the per-call step on the caller's mirror (wurm_grid_resident_bytes: one 32-bit record per env) ----
+
+@pytest.mark.parametrize('mode', ['default', 'raw', 'positions', 'none'])
+@pytest.mark.parametrize('N,S,lazy', [(200, 9, True), (131, 9, False), (70, 5, True), (33, 12, True), (9, 30, False), (257, 7, True)])
+def test_per_call_step_on_the_mirror(hip, N, S, lazy, mode):
+    """`step(a); reset(done)` on SimpleGridworld's mirror, against the oracle every call: the launch that builds the mirror scans
+    the planes (two launches), every later one reads the records and is ONE launch (wurm_launch_count), lazy or eager; every
+    fourth call comes without the postponed reset, so finished envs are stepped again and agents walk off the grid — an env
+    without an agent is in the lane kernel's domain now (simple_gridworld.py:153-162 on an all-zero head plane)"""
+    from wurm_amd import _lib
+    from wurm_amd._lib import knobs
+    T = 48
+    rng = np.random.RandomState(N * 7 + S)
+    start = (S // 2, S // 2)
+    o, h = OracleBackend(seed=12, env_offset=77), hip(seed=12, env_offset=77)
+    eo = _fresh(o, N, S, start)
+    eh = eo.copy()
+    res = {'lazy': lazy, 'sync': True}
+    prev = None
+    count = _lib.lib().wurm_launch_count
+    gone = 0
+    with knobs(WURM_LANE_STEP_MIN_ENVS=0):
+        for t in range(T):
+            a = rng.randint(-3, 9, size=N).astype(np.int64 if t % 2 else np.int32)
+            ao, ah = a.copy(), a.copy()
+            kw = dict(call=1 + 2 * t, pre_done=prev, pre_call=2 * t, want_obs_after=(t % 3 != 1), grid=start)
+            ro = o.single_step_reset(eo, ao, mode, **kw)
+            n0, was = count(), res.get('valid', 0)
+            rh = h.single_step_reset(eh, ah, mode, resident=res, **kw)
+            assert _route() == 'gridworld_lane_step' and res['valid'] == 1
+            # (the flush of a lazy mirror the harness asks for is a launch of its own)
+            assert count() - n0 == (1 if was == 1 else 2) + (1 if lazy else 0), (t, was, count() - n0)
+            _same(ah, ao, f'actions t={t}')
+            _same(eh, eo, f'state t={t}')
+            _cmp_step(ro, rh, t)
+            gone += int((eo[:, 1].reshape(N, -1).sum(1) == 0).sum())
+            prev = ro['done'] if t % 4 != 3 else None
+    assert gone > 0 or S > 12   # agents did walk off
+
+
+def test_hand_made_states_refuse_the_mirror(hip):
+    """an env outside the lane kernel's domain (two foods; the food under the agent; no food with the agent on the ring) in the planes the
+    mirror is built from: the call is served as ever (lane kernel + the one-env-per-wave kernel for that env), returns
+    WURM_MIRROR_REFUSED, and the mirror stays unused — results equal to the oracle's throughout — until the caller clears
+    resident_valid after repairing the state, when it is built and used"""
+    from wurm_amd import _lib
+    from wurm_amd._lib import knobs
+    N, S, start, mode = 150, 9, (4, 4), 'default'
+    rng = np.random.RandomState(2)
+    o, h = OracleBackend(seed=5), hip(seed=5)
+    eo = _fresh(o, N, S, start)
+    eo[3, 0, 2, 2] = 1; eo[3, 0, 6, 6] = 1          # two foods
+    eo[40, 0] = eo[40, 1]                            # the food under the agent
+    eo[77, 0] = 0; eo[77, 0, 1, 1] = 1; eo[77, 0, 7, 7] = 1   # two foods again, elsewhere
+    eh = eo.copy()
+    res = {'lazy': True, 'sync': False}
+    prev = None
+    count = _lib.lib().wurm_launch_count
+    with knobs(WURM_LANE_STEP_MIN_ENVS=0):
+        for t in range(12):
+            a = rng.randint(0, 4, size=N).astype(np.int64)
+            kw = dict(call=1 + 2 * t, pre_done=prev, pre_call=2 * t, want_obs_after=True, grid=start)
+            ro = o.single_step_reset(eo, a.copy(), mode, **kw)
+            n0 = count()
+            rh = h.single_step_reset(eh, a.copy(), mode, resident=res, **kw)
+            assert res['valid'] == 2 and count() - n0 == 2
+            _same(eh, eo, f'state t={t}')
+            _cmp_step(ro, rh, t)
+            prev = ro['done']
+        for e in (eo, eh):                            # the caller repairs the three envs and says so
+            for i in (3, 40, 77):
+                e[i] = 0
+                e[i, 1, 4, 4] = 1
+                e[i, 0, 2, 5] = 1
+        res['valid'] = 0
+        for t in range(12, 30):
+            a = rng.randint(0, 4, size=N).astype(np.int64)
+            kw = dict(call=1 + 2 * t, pre_done=prev, pre_call=2 * t, want_obs_after=True, grid=start)
+            ro = o.single_step_reset(eo, a.copy(), mode, **kw)
+            n0 = count()
+            res['sync'] = t % 5 == 4                 # (lazy: the planes are written out only when somebody looks)
+            rh = h.single_step_reset(eh, a.copy(), mode, resident=res, **kw)
+            assert res['valid'] == 1 and count() - n0 == (2 if t == 12 else 1) + (1 if res['sync'] else 0)
+            _cmp_step(ro, rh, t)
+            if res['sync']:
+                _same(eh, eo, f'state t={t}')
+            prev = ro['done']
+
+
+def test_class_loop_on_the_mirror():
+    """SimpleGridworld(16 384 envs) through `env.step(a); env.reset(done)`: ONE launch per iteration on the mirror
+    (mirror_state: lazy, current), equal outputs and state to the same loop with resident_mirror=False; a look at the state
+    writes it out, a rollout and an eager reset go through the planes, an in-place edit that makes an env hand-made is served
+    (the mirror refused) and healed again"""
+    import torch
+    from wurm_amd import _lib
+    from wurm_amd.envs import SimpleGridworld
+    N, S, T, start, seed = 16384, 9, 60, (4, 4), 33
+    g = torch.Generator(device='cuda:0').manual_seed(4)
+    acts = torch.randint(0, 4, (T, N), generator=g, device='cuda:0')
+    count = _lib.lib().wurm_launch_count
+
+    def loop(mirror):
+        env = SimpleGridworld(N, S, start_location=start, observation_mode='default', device='cuda:0', seed=seed,
+                              resident_mirror=mirror)
+        outs, per_iter = [], []
+        for t in range(T):
+            n0 = count()
+            obs, r, d, info = env.step(acts[t].clone())
+            # (both forms of the reset between t = 22 and 38; switching between them costs an eager reset each time)
+            back = env.reset(d) if (t % 3 or not 22 <= t < 38) else env.reset(d, return_observations=False)
+            per_iter.append(count() - n0)
+            outs.append([x.clone() for x in (obs, r, d, info['edge_collision'])] + ([back.clone()] if back is not None else []))
+            if t == 20:
+                outs.append([env.envs.clone()])                    # a look: written out, then eager while held? (dropped at once)
+            if t == 30:
+                ro = env.rollout(acts[:3].clone())
+                outs.append([ro['observations'].clone(), ro['dones'].clone()])
+            if t == 40:
+                e = env.envs
+                e[7, 0, 1, 1] = 1; e[7, 0, 1, 2] = 1             # env 7 gets extra foods: outside the domain
+                del e
+            if t == 45:
+                e = env.envs
+                e[7, 0] = 0; e[7, 0, 3, 3] = 1
+                del e
+        outs.append([env.envs.clone()])
+        return outs, per_iter, env.mirror_state()
+
+    (a, pa, ma), (b, pb, mb) = loop(None), loop(False)
+    assert ma['state'] in ('lazy', 'eager') and ma['bytes'] == 16 + 4 * N and mb['state'] == 'off'
+    assert pa[5:20] == [1] * 15 and pa[52:] == [1] * 8, pa     # one launch per iteration in the steady state
+    assert min(pb[5:20]) == 2                                   # (without the mirror: lane kernel + the flag pass)
+    assert len(a) == len(b)
+    for k, (x, y) in enumerate(zip(a, b)):
+        assert len(x) == len(y)
+        for i, (u, v) in enumerate(zip(x, y)):
+            assert torch.equal(u, v), f'record {k} output {i}'

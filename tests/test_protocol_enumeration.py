@@ -72,11 +72,16 @@ def test_single_snake_every_sequence_up_to_3(monkeypatch, mirror, machine):
     _run_all(lambda twin=False: pe.make_single('single', mirror, twin), pe.SingleDriver.EVENTS, 3, SINGLE_REGRESSIONS)
 
 
-@pytest.mark.parametrize('machine', ['python', 'c', 'c+torchinfo'])
-def test_gridworld_every_sequence_up_to_3(monkeypatch, machine):
+@pytest.mark.parametrize('mirror,refuse,machine', [(False, False, 'python'), (False, False, 'c'), (False, False, 'c+torchinfo'),
+                                                   (None, False, 'python'), ('lazy', False, 'python'), ('eager', False, 'python'),
+                                                   ('lazy', False, 'c+torchinfo'), (None, True, 'python'), ('lazy', True, 'c+torchinfo')])
+def test_gridworld_every_sequence_up_to_3(monkeypatch, mirror, refuse, machine):
+    """(round 6: SimpleGridworld's mirror — wurm_grid_resident_bytes; refuse: every launch that builds it reports envs outside
+    the lane kernel's domain, resident_valid == 2, and the planes stay the state)"""
     _machine_or_skip(machine)
-    pe.install_single(monkeypatch, 'grid', machine)
-    _run_all(lambda twin=False: pe.make_single('grid', False, twin), pe.GridDriver.EVENTS, 3, GRID_REGRESSIONS)
+    sim = pe.install_single(monkeypatch, 'grid', machine)
+    sim.refuse_builds = refuse
+    _run_all(lambda twin=False: pe.make_single('grid', mirror, twin), pe.GridDriver.EVENTS, 3, GRID_REGRESSIONS)
 
 
 @pytest.mark.parametrize('mirror,keep,machine', [(False, True, 'python'), ('lazy', True, 'python'), ('eager', True, 'python'),
@@ -107,7 +112,7 @@ def _with_extra(events, extra, max_len, first=None):
 # events (kept / dropped / read later).  Here: length <= 2 whole, length 3 behind a step; tools/protocol_enumerate.py
 # --extra runs length 4 (profiles/r06_protocol_enumeration_extra.json).
 @pytest.mark.parametrize('kind,mirror,machine', [('single', None, 'python'), ('single', 'lazy', 'c+torchinfo'),
-                                                 ('grid', False, 'python'), ('grid', False, 'c+torchinfo')])
+                                                 ('grid', None, 'python'), ('grid', 'lazy', 'c+torchinfo')])
 def test_extra_events_single(monkeypatch, kind, mirror, machine):
     _machine_or_skip(machine)
     pe.install_single(monkeypatch, kind, machine)

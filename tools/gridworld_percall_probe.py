@@ -12,9 +12,10 @@ T = 200
 for N in (16384, 65536):
     acts = torch.randint(4, (T + 10, N), device=dev)
     for mode in ('default', 'raw', 'positions'):
-        for lane, epw in ((True, 4), (True, 8), (True, 16), (True, 32), (True, 64), (False, -1)):
+        for lane, epw, mirror in ((True, 4, None), (True, 8, None), (True, 16, None), (True, 32, None), (True, 64, None), (True, 4, False), (True, 16, False),
+                                  (False, -1, False)):
             with _lib.knobs(WURM_LANE_STEP_MIN_ENVS=0 if lane else 1 << 40, WURM_GRIDWORLD_LANE_EPW=epw):
-                env = SimpleGridworld(N, 9, start_location=(4, 4), observation_mode=mode, device=dev, seed=0)
+                env = SimpleGridworld(N, 9, start_location=(4, 4), observation_mode=mode, device=dev, seed=0, resident_mirror=mirror)
                 for t in range(10):
                     _, _, d, _ = env.step(acts[t]); env.reset(d)
                 ts = []
@@ -24,6 +25,10 @@ for N in (16384, 65536):
                         _, _, d, _ = env.step(acts[t]); env.reset(d)
                     torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) / T)
                 ts.sort()
-                print(f'N {N:6d} {mode:10s} epw {epw:2d} {_lib.lib().wurm_single_last_route().decode():20s} {ts[1] * 1e6:7.2f} us per iteration  '
+                n0 = _lib.lib().wurm_launch_count()
+                for t in range(10, 20):
+                    _, _, d, _ = env.step(acts[t]); env.reset(d)
+                launches = (_lib.lib().wurm_launch_count() - n0) / 10
+                print(f'N {N:6d} {mode:10s} epw {epw:2d} mirror {env.mirror_state()["state"]:5s} launches {launches:.1f} {_lib.lib().wurm_single_last_route().decode():20s} {ts[1] * 1e6:7.2f} us per iteration  '
                       f'{N / ts[1]:.3e} env-steps/s', flush=True)
                 del env

@@ -53,6 +53,8 @@ __device__ __forceinline__ int free_interior_cell(const GridLaneGeo &g, int take
 // EPW consecutive envs per wave: 64 where a step writes a few bytes per env (positions / none), fewer for the image modes
 // where the batch is small — there the wave's job is the store stream of its run; lanes >= EPW repeat the arithmetic of
 // lane % EPW and only help with the loads and the fill
+constexpr int GWL_MIRROR_HEADER = 16;      // bytes in front of the records: word 0 = envs the building launch could not describe
+constexpr u32 GWL_REC_BAD = 0xfffefffeu;   // record of an env outside the domain (never in a mirror the library reports valid)
 constexpr int GWL_TC = 4; // steps whose actions are loaded ahead (the load latency is paid once per GWL_TC steps, under the fill)
 
 struct GridLaneScan {   // per wave: what the coalesced pass over the wave's run of the state found, per env
@@ -116,7 +118,9 @@ __global__ __launch_bounds__(256) void gridworld_lane_rollout_kernel(StepArgs p)
     const int nf = sc.cnt[0][slot], nh = sc.cnt[1][slot], bad = sc.bad[slot];
     int fc = sc.pos[0][slot], hc = sc.pos[1][slot];
     float *const envp = env_run + (long long)slot * 2 * C;
-    const bool act = present && !bad && nh == 1 && nf <= 1 && hc != fc;
+    // (round 6: an env WITHOUT an agent is in the domain too — an agent that walked off the grid, :153-162 with an all-zero
+    // head plane: nothing moves, no reward, done — so that the domain is closed under every step, not only step + reset)
+    const bool act = present && !bad && nh <= 1 && nf <= 1 && (hc != fc || hc < 0);
     if (present && !act) p.done[env] = GRID_SKIPPED; // rollout_kernel takes this env (second launch, only_flagged; T >= 1: eligible())
     const int hc0 = hc, fc0 = fc;
     const u64 env_id = (u64)(p.env_offset + env);
@@ -255,7 +259,7 @@ __global__ __launch_bounds__(256) void gridworld_lane_rollout_kernel(StepArgs p)
     // ---- write the state back: the cells that held something at the start, then the cells that do now
     if (act && p.T > 0) {
         if (fc0 >= 0 && fc0 != fc) envp[fc0] = 0.0f;
-        if (hc0 != hc) envp[C + hc0] = 0.0f;
+        if (hc0 >= 0 && hc0 != hc) envp[C + hc0] = 0.0f;
         if (fc >= 0 && fc != fc0) envp[fc] = 1.0f;
         if (hc >= 0 && hc != hc0) envp[C + hc] = 1.0f;
     }
@@ -335,12 +339,19 @@ __global__ __launch_bounds__(256) void gridworld_lane_step_kernel(StepArgs p)
     g.rcpI = g.I > 0 ? 1.0f / (float)g.I : 1.0f;
     const int S = g.S, C = g.C;
 
-    // ---- the state: as the rollout kernel's prologue
-    GridLaneScan &sc = scans[wave];
-    sc.cnt[0][lane] = 0; sc.cnt[1][lane] = 0; sc.pos[0][lane] = -1; sc.pos[1][lane] = -1; sc.bad[lane] = 0;
-    wave_lds_sync();
+    // ---- the state: the caller's mirror when it describes it (wurm_single_call.resident, SimpleGridworld: 16 bytes of header
+    // and one 32-bit record per env — agent cell | food cell << 16, 0xffff = none, GWL_REC_BAD = outside the domain), else
+    // one coalesced pass over the wave's run of the planes as in the rollout kernel's prologue
+    const bool mirrored = p.resident != nullptr, from_mirror = mirrored && p.resident_valid != 0;
+    u32 *const recs = mirrored ? (u32 *)((unsigned char *)p.resident + GWL_MIRROR_HEADER) : nullptr;
     float *const env_run = p.envs + env0 * 2 * C;
-    {
+    GridLaneScan &sc = scans[wave];
+    u32 rec = 0xffffffffu;
+    if (from_mirror) {
+        if (present) rec = recs[env];
+    } else {
+        sc.cnt[0][lane] = 0; sc.cnt[1][lane] = 0; sc.pos[0][lane] = -1; sc.pos[1][lane] = -1; sc.bad[lane] = 0;
+        wave_lds_sync();
         const int total = nv * 2 * C;
         const unsigned per_env = 2u * (unsigned)C;
         auto note = [&](int i, float v) {
@@ -380,11 +391,23 @@ __global__ __launch_bounds__(256) void gridworld_lane_step_kernel(StepArgs p)
         for (int i = lane; i < p.lds_per_wave / 16; i += 64) ((uint4 *)slab)[i] = make_uint4(0, 0, 0, 0);
     }
     wave_lds_sync();
-    const int nf = sc.cnt[0][slot], nh = sc.cnt[1][slot], bad = sc.bad[slot];
-    int fc = sc.pos[0][slot], hc = sc.pos[1][slot];
+    int fc, hc;
+    bool act;
+    if (from_mirror) {
+        hc = (int)(short)(rec & 0xffffu);
+        fc = (int)(short)(rec >> 16);
+        act = present && rec != GWL_REC_BAD;
+    } else {
+        const int nf = sc.cnt[0][slot], nh = sc.cnt[1][slot], bad = sc.bad[slot];
+        fc = sc.pos[0][slot]; hc = sc.pos[1][slot];
+        act = present && !bad && nh <= 1 && nf <= 1 && (hc != fc || hc < 0); // (no agent: in the domain — see the rollout kernel)
+    }
     float *const envp = env_run + (long long)slot * 2 * C;
-    const bool act = present && !bad && nh == 1 && nf <= 1 && hc != fc;
     if (present && !act) p.done[env] = GRID_SKIPPED; // the one-env-per-wave kernel takes this env (second launch, only_flagged)
+    if (mirrored && !from_mirror) { // a launch that builds the mirror counts what it cannot describe (the header's first word)
+        const u64 odd = ballot(present && !act);
+        if (odd != 0 && lane == 0) atomicAdd((int *)p.resident, popc64(odd));
+    }
     const int hc0 = hc, fc0 = fc;
     const u64 env_id = (u64)(p.env_offset + env);
     const int start = p.start_y * S + p.start_x;
@@ -436,12 +459,43 @@ __global__ __launch_bounds__(256) void gridworld_lane_step_kernel(StepArgs p)
         else if (OBS == WURM_OBS_POSITIONS && act)
             gwl_emit_positions(g, p.obs_after + env * 4, obs16, h2, f2);
     }
-    // ---- the stepped state back (the rebuilt one is not stored: no post_reset here)
-    if (act) {
+    // ---- the stepped state back (the rebuilt one is not stored: no post_reset here): the record, and the four cells of the
+    // planes that changed — unless the mirror is lazy and was current (a launch that builds it always writes the planes)
+    if (mirrored && present) recs[env] = act ? (((u32)hc & 0xffffu) | ((u32)fc << 16)) : GWL_REC_BAD;
+    if (act && !(from_mirror && p.resident_lazy)) {
         if (fc0 >= 0 && fc0 != fc) envp[fc0] = 0.0f;
-        if (hc0 != hc) envp[C + hc0] = 0.0f;
+        if (hc0 >= 0 && hc0 != hc) envp[C + hc0] = 0.0f;
         if (fc >= 0 && fc != fc0) envp[fc] = 1.0f;
         if (hc >= 0 && hc != hc0) envp[C + hc] = 1.0f;
+    }
+}
+
+// the planes from the mirror's records (a lazy mirror being written out): the wave's run of EPW envs zero-filled with
+// 16-byte stores, then the two cells of each env
+template <int EPW>
+__global__ __launch_bounds__(256) void gridworld_lane_flush_kernel(StepArgs p)
+{
+    const int lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6), wpb = (int)(blockDim.x >> 6);
+    const long long env0 = ((long long)blockIdx.x * wpb + wave) * EPW;
+    if (env0 >= p.N) return;
+    const int C = p.S * p.S, nv = (int)min((long long)EPW, p.N - env0), total = nv * 2 * C;
+    const u32 *const recs = (const u32 *)((const unsigned char *)p.resident + GWL_MIRROR_HEADER);
+    float *const run = p.envs + env0 * 2 * C;
+    const u32 rec = lane < nv ? recs[env0 + lane] : GWL_REC_BAD;
+    if ((((unsigned long long)run) & 15ull) == 0) {
+        const int n4 = total >> 2;
+        for (int i = lane; i < n4; i += 64) ((float4 *)run)[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        for (int i = (n4 << 2) + lane; i < total; i += 64) run[i] = 0.0f;
+    } else {
+        for (int i = lane; i < total; i += 64) run[i] = 0.0f;
+    }
+    __builtin_amdgcn_s_waitcnt(0); // (the patches below land behind the fill: same wave, same addresses, in order)
+    wave_lds_sync();
+    if (lane < nv && rec != GWL_REC_BAD) {
+        const int hc = (int)(short)(rec & 0xffffu), fc = (int)(short)(rec >> 16);
+        float *const envp = run + (long long)lane * 2 * C;
+        if (fc >= 0) envp[fc] = 1.0f;
+        if (hc >= 0) envp[C + hc] = 1.0f;
     }
 }
 
@@ -509,8 +563,15 @@ static int gridworld_lane_step_epw(const StepArgs &p)
     // iteration of `step; reset` at 4 / 8 / 16 / 32 envs per wave, tools/gridworld_percall_probe.py: 65 536 x 9 x 9 'default'
     // 40.2 / 42.9 / 40.9 / 44.8 us (one env per wave 50.6), 'positions' 21.9 / 19.9 / 20.6 / 24.9 (38.2); 16 384 envs
     // 'default' 17.3 / 19.2 / 21.7 / 26.6 (18.1))
+    // On the mirror (round 6) the launch neither scans nor writes the planes — a pure writer of its run: 65 536 x 9 x 9 'default'
+    // with the reset observation 27.3 / 27.9 / 27.4 / 24.1 / 26.2 us at 4 / 8 / 16 / 32 / 64 (without the mirror, two launches:
+    // 36.2), 'raw' 20.7 / 19.6 / 19.5 / 19.5 / 18.3; 16 384 envs 'default' 10.8 / 10.6 / 10.6 / 11.3 / 13.3
+    // (profiles/r06_gridworld_percall_mirror.txt)
     long long epw = opt.gridworld_lane_epw;
-    if (epw != 4 && epw != 8 && epw != 16 && epw != 32 && epw != 64) epw = p.N >= 65536 ? 16 : p.N >= 32768 ? 8 : 4;
+    if (epw != 4 && epw != 8 && epw != 16 && epw != 32 && epw != 64) {
+        if (p.resident != nullptr && p.resident_valid) epw = p.N >= 65536 ? 32 : p.N >= 16384 ? 16 : 8;
+        else epw = p.N >= 65536 ? 16 : p.N >= 32768 ? 8 : 4;
+    }
     if (p.obs_mode == WURM_OBS_DEFAULT || p.obs_mode == WURM_OBS_RAW)
         while (epw >= 4 && ((epw * p.obs_elems + 15) & ~15ll) > GWL_SLAB_MAX) epw >>= 1;
     return epw >= 4 ? (int)epw : 0;
@@ -550,6 +611,25 @@ static void launch_step_obs(const StepArgs &p, hipStream_t stream)
     case 32: launch_step_epw<OBS, 32>(p, stream); break;
     default: launch_step_epw<OBS, 64>(p, stream); break;
     }
+}
+
+// the mirror of the per-call step (wurm_single_call.resident of a SimpleGridworld): GWL_MIRROR_HEADER bytes + one record per env;
+// 0 where the per-call lane kernel does not serve the shape (an image observation whose run of four envs exceeds the byte slab)
+long long gridworld_resident_bytes(long long N, int S, int obs_mode, long long obs_elems)
+{
+    if (N <= 0) return 0;
+    StepArgs p = {};
+    p.N = N; p.S = S; p.obs_mode = obs_mode; p.obs_elems = obs_elems;
+    return gridworld_lane_step_epw(p) != 0 ? GWL_MIRROR_HEADER + 4 * N : 0;
+}
+
+hipError_t launch_gridworld_lane_flush(const StepArgs &p, hipStream_t stream)
+{
+    (void)hipGetLastError();
+    constexpr int EPW = 16, wpb = 4;
+    const long long waves = (p.N + EPW - 1) / EPW;
+    WURM_LAUNCH((gridworld_lane_flush_kernel<EPW>), dim3((unsigned)((waves + wpb - 1) / wpb)), dim3(64 * wpb), 0, stream, p);
+    return hipGetLastError();
 }
 
 hipError_t launch_gridworld_lane_step(const StepArgs &p, hipStream_t stream)

@@ -3190,10 +3190,14 @@ static const GroupShape *multi_group_shape(const MultiArgs &p, MultiArgs &q, siz
             // 8 / 4 / 1 / 6 — a writer per agent, 6 waves per SIMD at 80 VGPRs with 130 bytes of scratch — 0.44-0.51 / 1.57-1.81
             // depending on the box and on how the allocator spills; 4 / 4 / 1 / 4: 0.51 / 1.66; 8 / 4 / 2 / 4: 1.79 per 64;
             // the two-wave kernel of round 3: 0.55 / 1.73-2.15 — profiles/r04_multi_group_probe.txt)
-            {8, 2, 1, 5, (const void *)multi_rollout_group_kernel<8, 2, 1, 5>, (const void *)multi_rollout_group_kernel<8, 2, 1, 5, false, false>,
-             (const void *)multi_rollout_group_kernel<8, 2, 1, 5, false, false, 4, 25>, 4, 25}, // BASELINE configs[3]
+            {8, 2, 1, 5, (const void *)multi_rollout_group_kernel<8, 2, 1, 5>, (const void *)multi_rollout_group_kernel<8, 2, 1, 5, false, false>},
             {8, 4, 1, 6, (const void *)multi_rollout_group_kernel<8, 4, 1, 6>, (const void *)multi_rollout_group_kernel<8, 4, 1, 6, false, false>},
-            {4, 4, 1, 4, (const void *)multi_rollout_group_kernel<4, 4, 1, 4>, (const void *)multi_rollout_group_kernel<4, 4, 1, 4, false, false>},
+            // (round 6) BASELINE configs[3] — 4 snakes on 25 x 25 — takes THIS shape with K and S compiled in: 121 VGPRs, no
+            // spilled VGPR, no scratch, and per 16- / 64-step launch on two boxes 0.4035 / 0.4278 and - / 1.5335 ms, against
+            // 0.4135 / 0.4316 and - / 1.5306 for 8 / 2 / 1 / 5 specialised (34 spilled VGPRs, 140 bytes of scratch) and
+            // 0.4305 / 0.4386 and - / 1.5724 for the generic 8 / 2 / 1 / 5 that shipped in round 5 (profiles/r06_group_shapes.txt)
+            {4, 4, 1, 4, (const void *)multi_rollout_group_kernel<4, 4, 1, 4>, (const void *)multi_rollout_group_kernel<4, 4, 1, 4, false, false>,
+             (const void *)multi_rollout_group_kernel<4, 4, 1, 4, false, false, 4, 25>, 4, 25},
             {8, 4, 2, 4, (const void *)multi_rollout_group_kernel<8, 4, 2, 4>, nullptr},
         };
         const Shape *sh = nullptr;
@@ -3202,8 +3206,12 @@ static const GroupShape *multi_group_shape(const MultiArgs &p, MultiArgs &q, siz
             if (total(c.G) > LDS_MAX_BYTES) continue;
             if (opt.multi_group_shape == 0 || 1000 * c.G + 100 * c.W + 10 * c.eps + c.occ == opt.multi_group_shape) { sh = &c; break; }
         }
+        // a shape whose specialised form serves this launch comes first (multi_launch takes fn_shape under the same conditions)
+        if (!wide && opt.multi_group_shape == 0 && opt.multi_shape_kernels != 0 && !p.has_inj && !p.has_rinj)
+            for (const Shape &c : shapes)
+                if (c.fn_shape && c.sk == p.K && c.ss == p.S && total(c.G) <= LDS_MAX_BYTES) { sh = &c; break; }
         for (const Shape &c : shapes) {
-            if (wide) break;
+            if (wide || sh) break;
             const bool fits = total(c.G) <= LDS_MAX_BYTES;
             if (opt.multi_group_shape ? (1000 * c.G + 100 * c.W + 10 * c.eps + c.occ == opt.multi_group_shape && fits)
                                       : (fits && (c.G == 4 || 2 * total(8) <= LDS_MAX_BYTES))) { sh = &c; break; }

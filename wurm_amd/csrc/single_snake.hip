@@ -1763,7 +1763,11 @@ static hipError_t launch_one(Kind kind, const StepArgs &p, dim3 grid, dim3 block
         if constexpr (!SNAKE) {
             hipError_t err = launch_gridworld_lane_step(p, st);
             if (err != hipSuccess) return err;
-            WURM_LAUNCH((flagged_kernel<CPL, SNAKE, false>), fgrid, block, lds, st, p);
+            // (a mirror that was current describes every env — the library reports a mirror valid only if the launch that
+            // built it found nothing outside the lane kernel's domain, and that domain is closed under the library's own
+            // launches — so nothing can be flagged: ONE launch per call)
+            if (!(p.resident != nullptr && p.resident_valid))
+                WURM_LAUNCH((flagged_kernel<CPL, SNAKE, false>), fgrid, block, lds, st, p);
         }
         break;
     case R_S9_INJ:
@@ -1991,6 +1995,42 @@ static int fused_entry(bool snake, const wurm_single_call *c, void *stream, int 
             if (err != hipSuccess) return WURM_ERR_HIP;
         }
     }
+    if (!snake && c->resident != nullptr && N > 0) {
+        // SimpleGridworld's mirror (gridworld_lane.hip): one record per env.  resident_valid: 0 = build it in this launch,
+        // 1 = current, 2 = refused (the launch that built it found envs outside the lane kernel's domain: the planes stay
+        // the state until the caller clears resident_valid again).
+        if (no_mask() != WURM_OK) return WURM_ERR_HIP;
+        if (c->resident_valid != 2 && gridworld_lane_step_eligible(p)) {
+            p.resident = c->resident;
+            p.resident_valid = c->resident_valid == 1;
+            p.resident_lazy = c->resident_lazy != 0;
+            if (!p.resident_valid && hipMemsetAsync(c->resident, 0, 16, (hipStream_t)stream) != hipSuccess) return WURM_ERR_HIP;
+            rc = launch<false>(resets ? K_FUSED : K_STEP, p, stream);
+            if (rc != WURM_OK) { if (mirror_state) *mirror_state = 0; return rc; }
+            int state = 1;
+            if (!p.resident_valid) {
+                // the launch built the mirror (and wrote the planes whatever `lazy` says): valid only if it could describe every
+                // env.  One synchronous 4-byte read per BUILD — the first step of an env object, and the step after something
+                // else wrote the state — is what lets every other call be a single launch
+                int odd = 0;
+                if (hipMemcpyAsync(&odd, c->resident, 4, hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess ||
+                    hipStreamSynchronize((hipStream_t)stream) != hipSuccess)
+                    return WURM_ERR_HIP;
+                if (odd != 0) state = 2;
+            }
+            if (mirror_state) *mirror_state = state;
+            return WURM_OK;
+        }
+        // this call cannot use the mirror: a lazy one is written out to envs before the ordinary kernels read them
+        if (c->resident_lazy && c->resident_valid == 1) {
+            StepArgs q = p;
+            q.resident = c->resident;
+            if (launch_gridworld_lane_flush(q, (hipStream_t)stream) != hipSuccess) return WURM_ERR_HIP;
+        }
+        if (mirror_state) *mirror_state = c->resident_valid == 2 ? 2 : 0;
+        const Kind kind_g = resets ? K_FUSED : K_STEP;
+        return launch<false>(kind_g, p, stream);
+    }
     if (!(snake && c->resident != nullptr && N > 0) && no_mask() != WURM_OK) return WURM_ERR_HIP;
     if (mirror_state) *mirror_state = 0;
     // nothing to rebuild and no second observation: the plain step kernel (lighter on registers for large grids)
@@ -2033,9 +2073,38 @@ int64_t wurm_single_resident_bytes(int64_t num_envs, int size, int obs_mode, int
     return big ? wurm_single_resident_size(num_envs, size, obs_mode, obs_n) : 0;
 }
 
+int64_t wurm_grid_resident_size(int64_t num_envs, int size, int obs_mode)
+{
+    if (num_envs <= 0 || size < 5 || size > 64) return 0;
+    if (!(obs_mode == WURM_OBS_DEFAULT || obs_mode == WURM_OBS_RAW || obs_mode == WURM_OBS_POSITIONS || obs_mode == WURM_OBS_NONE)) return 0;
+    return gridworld_resident_bytes(num_envs, size, obs_mode, obs_elems(false, obs_mode, 0, size));
+}
+
+int64_t wurm_grid_resident_bytes(int64_t num_envs, int size, int obs_mode)
+{
+    const long long e = opt.resident_min_envs; // -1: where the per-call lane kernel takes over
+    return num_envs >= (e >= 0 ? e : opt.lane_step_min_envs) ? wurm_grid_resident_size(num_envs, size, obs_mode) : 0;
+}
+
+int wurm_grid_resident_flush(const wurm_single_call *c, void *stream)
+{
+    if (!c) return WURM_ERR_INVALID_ARG;
+    if (!c->resident || !c->resident_lazy || c->resident_valid != 1 || c->num_envs <= 0) return WURM_OK;
+    if (!c->envs) return WURM_ERR_INVALID_ARG;
+    StepArgs p = {};
+    p.envs = c->envs; p.N = c->num_envs; p.S = c->size; p.resident = c->resident;
+    return launch_gridworld_lane_flush(p, (hipStream_t)stream) == hipSuccess ? WURM_OK : WURM_ERR_HIP;
+}
+
 int wurm_single_step_reset(const wurm_single_call *c, void *stream) { return fused_entry(true, c, stream); }
 
-int wurm_grid_step_reset(const wurm_single_call *c, void *stream) { return fused_entry(false, c, stream); }
+int wurm_grid_step_reset(const wurm_single_call *c, void *stream)
+{
+    int mirror = -1;
+    const int rc = fused_entry(false, c, stream, &mirror);
+    // (the block is const here: a caller that keeps the mirror learns of a refusal from the return value)
+    return (rc == WURM_OK && c && c->resident && c->resident_valid == 0 && mirror == 2) ? WURM_MIRROR_REFUSED : rc;
+}
 
 static int step_slot(bool snake, wurm_single_call *c, const wurm_single_slabs *s, int64_t slot, void *actions,
                      int actions_dtype, uint64_t call, int apply_pending, uint64_t pre_call, int want_obs_after,
@@ -2061,7 +2130,7 @@ static int step_slot(bool snake, wurm_single_call *c, const wurm_single_slabs *s
     }
     int mirror = -1;
     const int rc = fused_entry(snake, c, stream, &mirror);
-    if (c->resident && mirror >= 0) c->resident_valid = (rc == WURM_OK && mirror == 1) ? 1 : 0;
+    if (c->resident && mirror >= 0) c->resident_valid = rc != WURM_OK ? 0 : mirror; // (2: SimpleGridworld's mirror refused)
     return rc;
 }
 

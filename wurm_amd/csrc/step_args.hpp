@@ -65,6 +65,9 @@ hipError_t launch_gridworld_lane_rollout(const StepArgs &p, hipStream_t stream);
 // ... and the per-call step of large batches under fused_step_kernel's contract (K_STEP / K_FUSED)
 bool gridworld_lane_step_eligible(const StepArgs &p);
 hipError_t launch_gridworld_lane_step(const StepArgs &p, hipStream_t stream);
+// ... on the caller's mirror of the state (p.resident: a header + one 32-bit record per env, gridworld_lane.hip)
+long long gridworld_resident_bytes(long long N, int S, int obs_mode, long long obs_elems);
+hipError_t launch_gridworld_lane_flush(const StepArgs &p, hipStream_t stream);
 hipError_t launch_grid_step(const StepArgs &p, hipStream_t stream);
 
 // one-env-per-LANE rollout for large batches of 9 x 9 SingleSnake (lane_rollout.hip / lane_rollout.hpp); envs outside its

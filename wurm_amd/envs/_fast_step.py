@@ -236,6 +236,9 @@ def _make_stepper(name, blk_addr, slabs_addr):
 
 
 class FastStepMixin(object):
+    # the library's mirror entry points of the class: size with / without the batch-size threshold, flush
+    _RESIDENT_FNS = ('wurm_single_resident_bytes', 'wurm_single_resident_size', 'wurm_single_resident_flush')
+
     def _fast_init(self):
         N = self.num_envs
         c = self._c = _lib.SingleCall()
@@ -406,7 +409,8 @@ class FastStepMixin(object):
         c = self._c
         if c.resident_valid and c.resident:
             # a loop in which (nearly) every step is followed by something that writes the state some other way — an eager
-            # reset, a rollout — rebuilds the mirror every step for nothing: switch it off for this env object
+            # reset, a rollout — rebuilds the mirror every step for nothing (SimpleGridworld: with a synchronous read of the
+            # build's verdict each time, and 2 = refused again while a hand-made env stays): switch it off for this env object
             self._touches += 1
             if self._resident_policy is None and self._touches >= 8 and \
                     2 * self._touches >= self._fs.steps - self._mirror_step0:
@@ -419,10 +423,10 @@ class FastStepMixin(object):
     def _write_out(self):
         """`envs` from a lazy mirror (which stays current)"""
         c = self._c
-        if c.resident_valid and c.resident and c.resident_lazy:
-            rc = _lib.call(self.device.index, _lib.lib().wurm_single_resident_flush, ctypes.addressof(c),
+        if c.resident_valid == 1 and c.resident and c.resident_lazy:   # (2: SimpleGridworld's mirror refused — the planes are the state)
+            rc = _lib.call(self.device.index, getattr(_lib.lib(), self._RESIDENT_FNS[2]), ctypes.addressof(c),
                            _lib.stream_ptr(self.device.index))
-            _lib.check(rc, 'wurm_single_resident_flush')
+            _lib.check(rc, self._RESIDENT_FNS[2])
             # a caller that keeps looking at the state (check_consistency() every step, experiments/main.py:214-215) pays
             # a whole-state write per look in the lazy form: from the second one on the steps write `envs` themselves
             self._write_outs += 1
@@ -468,10 +472,10 @@ class FastStepMixin(object):
         self._touch()
         self._mirror_key = key
         nbytes = 0
-        if self._CHANNELS == 3 and not self._mirror_off:
-            size_fn = _lib.lib().wurm_single_resident_bytes if self._resident_policy is None else \
-                _lib.lib().wurm_single_resident_size
-            nbytes = int(size_fn(_lib.i64(self.num_envs), self.size, m, n))
+        if not self._mirror_off:
+            size_fn = getattr(_lib.lib(), self._RESIDENT_FNS[0 if self._resident_policy is None else 1])
+            args = (m, n) if self._CHANNELS == 3 else (m,)   # (SimpleGridworld's observations have no crop radius)
+            nbytes = int(size_fn(_lib.i64(self.num_envs), self.size, *args))
             if not self._mirror_off:
                 self._mirror_why = ('shape / observation mode not served by the mirror kernels, or batch below the threshold'
                                     if nbytes == 0 else 'on')
@@ -493,8 +497,12 @@ class FastStepMixin(object):
         keyword: None = automatic); `current`: the mirror describes the state (False: the next step rebuilds it)."""
         c = self._c
         on = bool(c.resident) and self._mirror is not None
-        return {'state': 'off' if not on else ('lazy' if c.resident_lazy else 'eager'), 'why': self._mirror_why,
-                'policy': self._resident_policy, 'current': bool(on and c.resident_valid),
+        why = self._mirror_why
+        if on and c.resident_valid == 2:
+            why = ("refused: the launch that built it found envs outside the lane kernel's domain (hand-made states) — the "
+                   'state tensor is stepped as it is, two launches per call, until something writes the state again')
+        return {'state': 'off' if not on else ('lazy' if c.resident_lazy else 'eager'), 'why': why,
+                'policy': self._resident_policy, 'current': bool(on and c.resident_valid == 1),
                 'bytes': int(self._mirror.numel()) if on else 0}
 
     def _step_check_mask(self):

@@ -21,6 +21,7 @@ class SimpleGridworld(FastStepMixin):
 
     _CHANNELS = 2
     _STEP_SLOT = 'wurm_grid_step_slot'
+    _RESIDENT_FNS = ('wurm_grid_resident_bytes', 'wurm_grid_resident_size', 'wurm_grid_resident_flush')
 
     spec = Spec(float('inf'))
 
@@ -37,8 +38,8 @@ class SimpleGridworld(FastStepMixin):
                  env_offset: int = 0,
                  lazy_reset: bool = True,
                  resident_mirror=None):
-        # (`resident_mirror`: accepted like SingleSnake's; the two-channel gridworld state has no mirror kernels yet,
-        # so `env.mirror_state()` reports 'off' whatever is asked for)
+        # (`resident_mirror`: as SingleSnake's — large batches step on a mirror of one 32-bit record per env,
+        # wurm_grid_resident_bytes, include/wurm_hip.h; `env.mirror_state()` tells what is in effect)
         self._resident_policy = resident_mirror
         self.num_envs = num_envs
         self.size = size
