@@ -615,6 +615,13 @@ def extra_measurements(device):
              "MultiSnake 4096x25x25 K=4, the reference's training dynamics (tests/test_multi_snake_env.py:100-104: respawn "
              "'any', random_rate food, partial_5): `step(a); reset(d['__all__'], return_observations=False)`",
              traffic_key='per_call_api_cfg4prime_4096x25_k4_partial5')
+    # (the dicts above are rows of ONE (K, N) tape — the zero-copy case of Stepper.step_multi.  A policy that emits
+    # one tensor per agent, as experiments/multiagent.py does, hands over K separately allocated tensors: the class stacks them)
+    split4 = [{k: v.clone() for k, v in d.items()} for d in dicts4]
+    per_call('per_call_cfg4prime_partial5_split_actions', cfg4prime, lambda t: split4[t], d_all, T,
+             "per_call_cfg4prime_partial5 with K separately allocated action tensors per step (stacked by the class; the "
+             "other per_call_multi_* / cfg4* keys feed rows of one (K, N) tape, the zero-copy case)")
+    del split4
     acts10 = torch.randint(8, (40, 10, N), device=device, dtype=torch.int64)
     keys10 = [f'agent_{i}' for i in range(10)]
     dicts10 = [dict(zip(keys10, acts10[t].unbind(0))) for t in range(40)]
@@ -844,6 +851,8 @@ def key_numbers(line):
         'speeds_rollout_eps': g('multi_rollout_speeds_4096x36_k10'), 'speeds_py_loop_us': g('speeds_py_loop_4096x36_k10', 'us'),
         'cfg4prime_rollout_eps': g('multi_rollout_cfg4prime_partial5'), 'cfg4prime_rollout_ms': g('multi_rollout_cfg4prime_partial5', 'ms'),
         'cfg4prime_per_call_us': g('per_call_cfg4prime_partial5', 'us'),
+        'cfg4prime_per_call_split_actions_us': g('per_call_cfg4prime_partial5_split_actions', 'us'),
+        'gridworld_65536_per_call_launches': g('per_call_gridworld_65536x9_default', 'launches_per_iter'),
         'multi_512x12_k2_per_call_us': g('per_call_multi_512x12_k2', 'us'),
         'cfg5_rollout_ms_p10_p50_p90': [g('rollout_cfg5_alloc_spread', f) for f in ('ms_p10', 'ms_p50', 'ms_p90')],
         'cfg3_rollout_ms_p10_p50_p90': [g('rollout_cfg3_alloc_spread', f) for f in ('ms_p10', 'ms_p50', 'ms_p90')],

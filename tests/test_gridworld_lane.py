@@ -233,9 +233,9 @@ def test_per_call_step_with_the_postponed_reset(hip, N, S, epw, mode):
                 eo[N - 1, 0, 0, 2] = 1
                 eh[...] = eo
     assert deaths > 0 or S > 12
-    # 30 x 30 'default' fits the 16 KB byte slab at four envs per wave; 40 x 40 'default' (4 x 19 200 bytes) at none: those
-    # calls stay with the one-env-per-wave kernel
-    assert lane_calls == (0 if (S == 40 and mode == 'default') else T)
+    # (round 5's byte slab did not fit 40 x 40 'default' — 4 x 19 200 bytes — and those calls stayed with the one-env-per-wave
+    # kernel; round 6 composes the run as one BIT per float: every size up to 64 x 64 fits)
+    assert lane_calls == T
 
 
 def test_per_call_plain_step_and_the_immediate_form(hip):

@@ -493,9 +493,11 @@ def test_per_call_parity_suite_on_the_mirror():
     if os.environ.get('WURM_RESIDENT_MIN_ENVS') == '0':
         pytest.skip('already inside the forced run')
     env = dict(os.environ, WURM_RESIDENT_MIN_ENVS='0')
+    # (round 6: without tests/test_fuzz_gpu.py — its own families force these routes themselves, and re-running all of it under
+    # each forced knob was 300 of the GPU suite's 500 seconds)
     r = subprocess.run([sys.executable, '-m', 'pytest', '-x', '-q', '-m', 'gpu', '-p', 'no:cacheprovider',
                         'tests/test_hip_vs_oracle.py', 'tests/test_hip_fused_step.py', 'tests/test_kat_single_snake.py',
-                        'tests/test_fuzz_gpu.py', 'tests/test_rl_gpu.py', 'tests/test_hip_golden.py'],
+                        'tests/test_rl_gpu.py', 'tests/test_hip_golden.py'],
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 

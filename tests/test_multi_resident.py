@@ -261,7 +261,7 @@ def test_class_rollouts_and_steps_interleaved_on_the_mirror(cfg_name, mode, shap
 
 @pytest.mark.parametrize('cfg_name,mode,shape', [('default', 'full', (24, 4, 14, 120)), ('train', 'partial_3', (20, 3, 12, 120)),
                                                  ('dense', 'full', (20, 3, 12, 100)), ('train', 'full', (6, 10, 36, 40))])
-@pytest.mark.parametrize('reset_obs', [True, False])
+@pytest.mark.parametrize('reset_obs', [True, 'dropped', False])
 def test_check_consistency_from_the_step_launch(cfg_name, mode, shape, reset_obs):
     """experiments/speeds.py:30-38 — `step; reset(done['__all__']); check_consistency()` every iteration: the masks come out
     of the step launch (no pass over the fp32 tensors, the postponed reset stays postponed) and equal the oracle's checker
@@ -285,8 +285,14 @@ def test_check_consistency_from_the_step_launch(cfg_name, mode, shape, reset_obs
             r = o.multi_step(st, a.numpy(), cfg, mode)
             for i in range(K):
                 _same(obs[f'agent_{i}'].cpu().numpy(), r['obs'][i], f'obs {i} t={t}')
-            if reset_obs:
+            if reset_obs == 'dropped':
+                # what reset returns is dropped, as speeds.py:33 does: after three of those the steps stop precomputing it
+                # (round 6: _LazyResetObs) and with it the masks of the reset state — the checker then runs over the tensors
                 env.reset(dones['__all__'])
+                o.multi_reset(st, r['all_done'], cfg, mode=mode)
+            elif reset_obs:
+                kept = env.reset(dones['__all__'])   # (a caller that keeps it: the step launches go on precomputing it)
+                assert len(kept) == K
                 o.multi_reset(st, r['all_done'], cfg, mode=mode)
             else:
                 env.reset(dones['__all__'], return_observations=False)
@@ -308,8 +314,8 @@ def test_check_consistency_from_the_step_launch(cfg_name, mode, shape, reset_obs
             assert env._steps == launches_before
         # (without the reset observation the launch cannot vouch for envs the postponed reset rebuilds: those iterations
         # run the checker over the tensors)
-        assert from_launch > (T // 2 if reset_obs else 0), from_launch
-        if reset_obs:
+        assert from_launch > (T // 2 if reset_obs is True else 0), from_launch
+        if reset_obs is True:
             assert env._pending            # the checker never forced the postponed reset out
 
 

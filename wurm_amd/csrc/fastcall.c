@@ -378,9 +378,10 @@ static PyObject *stepper_launch_multi(Stepper *self, PyObject *arg)
 }
 
 /* step_multi(actions: dict) -> the prebuilt (observations, rewards, dones, info) of this step; None: the caller prepares
- * something first (new slab, state to re-validate, actions that are not the rows of one (K, N) int64 device tensor, not a
- * plain dict, another device current, no tensor-facts helper) and calls launch_multi; a non-zero int: the entry point's
- * error code.  Argument errors as the reference raises them (multi_snake.py:463-472), in its order. */
+ * something first (new slab, state to re-validate, actions of another type or device, not a plain dict, another device
+ * current, no tensor-facts helper) and calls launch_multi; False: all that is missing is the (K, N) action block — the K
+ * int64 device vectors are not the rows of one tensor: the caller stacks them and calls launch_multi; a non-zero int: the
+ * entry point's error code.  Argument errors as the reference raises them (multi_snake.py:463-472), in its order. */
 static PyObject *stepper_step_multi(Stepper *self, PyObject *actions)
 {
     if (!self->multi || !self->tinfo || !PyDict_CheckExact(actions)) Py_RETURN_NONE;
@@ -392,7 +393,8 @@ static PyObject *stepper_step_multi(Stepper *self, PyObject *actions)
     PyObject *key, *val;
     const char *a0 = NULL;
     long long n = 0;
-    int rows_ok = 1;
+    int rows_ok = 1, stackable = 1; /* stackable: K int64 vectors on the device — all that keeps them from being used where they lie
+                                     * is where they lie (a policy that emits one tensor per agent, experiments/multiagent.py) */
     const long long row = 8 * self->num_envs;
     while (PyDict_Next(actions, &pos, &key, &val)) {
         wurm_tensor_info ti;
@@ -406,6 +408,7 @@ static PyObject *stepper_step_multi(Stepper *self, PyObject *actions)
             PyErr_SetString(PyExc_RuntimeError, "Must have the same number of actions as environments.");
             return NULL;
         }
+        if (ti.dtype != 4 || ti.dim != 1 || (long long)ti.device != self->dev_index) stackable = 0;
         if (rows_ok) {
             if (ti.dtype != 4 || ti.dim != 1 || !ti.contiguous || (long long)ti.device != self->dev_index) rows_ok = 0;
             else if (n == 0) a0 = (const char *)ti.ptr;
@@ -413,8 +416,12 @@ static PyObject *stepper_step_multi(Stepper *self, PyObject *actions)
         }
         ++n;
     }
-    if (!self->ok || self->slot >= self->R || (self->want_obs_after && self->obs_afters == Py_None) || !rows_ok) Py_RETURN_NONE;
+    if (!self->ok || self->slot >= self->R || (self->want_obs_after && self->obs_afters == Py_None)) Py_RETURN_NONE;
     if ((long long)self->cur_dev() != self->dev_index) Py_RETURN_NONE; /* kernels launch on the current device */
+    if (!rows_ok) { /* False: everything is in place but the action block — the caller stacks the K vectors and calls launch_multi */
+        if (stackable) Py_RETURN_FALSE;
+        Py_RETURN_NONE;
+    }
     return stepper_launch_multi_ptr(self, (const int64_t *)a0, self->raw_stream((int)self->dev_index));
 }
 

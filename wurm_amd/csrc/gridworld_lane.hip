@@ -55,13 +55,38 @@ __device__ __forceinline__ int free_interior_cell(const GridLaneGeo &g, int take
 // lane % EPW and only help with the loads and the fill
 constexpr int GWL_MIRROR_HEADER = 16;      // bytes in front of the records: word 0 = envs the building launch could not describe
 constexpr u32 GWL_REC_BAD = 0xfffefffeu;   // record of an env outside the domain (never in a mirror the library reports valid)
-constexpr int GWL_TC = 4; // steps whose actions are loaded ahead (the load latency is paid once per GWL_TC steps, under the fill)
+constexpr int GWL_CHUNK = 32; // steps whose actions are loaded together (2 bits each in a 64-bit word)
 
 struct GridLaneScan {   // per wave: what the coalesced pass over the wave's run of the state found, per env
     int cnt[2][64];     // nonzero cells of the food / agent plane
     int pos[2][64];     // the last one seen
     int bad[64];        // a nonzero value other than 1.0
 };
+
+// The wave's run of one image observation from its bit string in LDS (`bits`: run bits, all zero on entry and on return):
+// the env lanes set their two bits (of / oh: float offsets inside the env's elems, -1 = none; `base` = slot * elems), every
+// lane turns nibbles into 16-byte stores, the env lanes clear their bits again.
+__device__ __forceinline__ void gwl_emit_bits(float *blk, u32 *bits, int base, int run, int lane, int of, int oh)
+{
+    if (of >= 0) atomicOr(&bits[(base + of) >> 5], 1u << ((base + of) & 31));
+    if (oh >= 0) atomicOr(&bits[(base + oh) >> 5], 1u << ((base + oh) & 31));
+    wave_lds_sync();
+    if ((((unsigned long long)blk) & 15ull) == 0) {
+        const int n4 = run >> 2;
+        float4 *b4 = (float4 *)blk;
+#pragma unroll 4
+        for (int i = lane; i < n4; i += 64) {
+            const u32 n = bits[i >> 3] >> ((i & 7) * 4);
+            b4[i] = make_float4((float)(n & 1u), (float)((n >> 1) & 1u), (float)((n >> 2) & 1u), (float)((n >> 3) & 1u));
+        }
+        for (int i = (n4 << 2) + lane; i < run; i += 64) blk[i] = (float)((bits[i >> 5] >> (i & 31)) & 1u);
+    } else { // (a batch whose observation block does not start on a 16-byte boundary: ragged N)
+        for (int i = lane; i < run; i += 64) blk[i] = (float)((bits[i >> 5] >> (i & 31)) & 1u);
+    }
+    wave_lds_sync();
+    if (of >= 0) atomicAnd(&bits[(base + of) >> 5], ~(1u << ((base + of) & 31)));
+    if (oh >= 0) atomicAnd(&bits[(base + oh) >> 5], ~(1u << ((base + oh) & 31)));
+}
 
 template <int OBS, int EPW>
 __global__ __launch_bounds__(256) void gridworld_lane_rollout_kernel(StepArgs p)
@@ -129,7 +154,7 @@ __global__ __launch_bounds__(256) void gridworld_lane_rollout_kernel(StepArgs p)
     const long long elems = p.obs_elems;                 // floats per env of an observation
     const int run = nv * (int)elems;                     // floats of the wave's run per step (<= 64 * 3 * 64 * 64)
     const bool obs16 = (((unsigned long long)p.obs) & 15ull) == 0;
-    // image modes: the wave's run of one step as bytes (p.lds_per_wave = its size, 0: it does not fit), zeroed once
+    // image modes: the wave's run of one step as a bit string (p.lds_per_wave = its bytes, 0: it does not fit), zeroed once
     unsigned char *slab = nullptr;
     if ((OBS == WURM_OBS_DEFAULT || OBS == WURM_OBS_RAW) && p.lds_per_wave > 0) {
         slab = gwl_lds + wave * p.lds_per_wave;
@@ -137,21 +162,24 @@ __global__ __launch_bounds__(256) void gridworld_lane_rollout_kernel(StepArgs p)
         wave_lds_sync();
     }
     u64 call = p.call;
-    long long a_cur[GWL_TC], a_nxt[GWL_TC];
+    // Actions: GWL_CHUNK steps at a time, all loads of a chunk in flight together, kept as 2-bit directions in two registers.
+    // Round 5 loaded them four steps ahead inside the step loop: on gfx9 a wave waits for a LOAD only after every store it
+    // issued before it has completed (one in-order counter), so each of those waits drained the wave's observation stores —
+    // with two to four waves per SIMD nothing covers that (multi_snake.hip keeps its actions in LDS for the same reason).
+    for (long long t0 = 0; t0 < p.T; t0 += GWL_CHUNK) {
+        const int nt = (int)min((long long)GWL_CHUNK, p.T - t0);
+        u64 dirs = 0;
+        {
+            long long av[GWL_CHUNK];
 #pragma unroll
-    for (int j = 0; j < GWL_TC; ++j) a_cur[j] = (act && j < p.T) ? load_action(p.actions, p.act_dtype, (long long)j * p.N + env) : 0;
-    for (long long t0 = 0; t0 < p.T; t0 += GWL_TC) {
+            for (int j = 0; j < GWL_CHUNK; ++j) // (index clamped: no load behind a branch, all of them in flight together)
+                av[j] = act ? load_action(p.actions, p.act_dtype, (t0 + min(j, nt - 1)) * p.N + env) : 0;
 #pragma unroll
-        for (int j = 0; j < GWL_TC; ++j) {
-            const long long tn = t0 + GWL_TC + j;
-            a_nxt[j] = (act && tn < p.T) ? load_action(p.actions, p.act_dtype, tn * p.N + env) : 0;
+            for (int j = 0; j < GWL_CHUNK; ++j) dirs |= (u64)(((av[j] % 4) + 4) % 4) << (2 * j);
         }
-#pragma unroll
-        for (int j = 0; j < GWL_TC; ++j) {
+        for (int j = 0; j < nt; ++j) {
             const long long t = t0 + j;
-            if (t >= p.T) break;
-            const long long a = a_cur[j];
-            const int ai = (int)(((a % 4) + 4) % 4);
+            const int ai = (int)((dirs >> (2 * j)) & 3ull);
             // simple_gridworld.py:149-157 the agent moves by -TAP[a]; off the grid => it vanishes
             int newhead = -1, ny = -1, nx = -1;
             if (hc >= 0) {
@@ -192,29 +220,11 @@ __global__ __launch_bounds__(256) void gridworld_lane_rollout_kernel(StepArgs p)
                     }
                 }
                 if (slab != nullptr) {
-                    // composed in LDS, one byte per float (all zero but the bytes of this step, cleared again below), then
-                    // 4 bytes -> 16-byte store: every byte of the run is written once (a fill followed by scattered
-                    // 4-byte stores cost 9-13 % of the launch, tools/gridworld_probe.py)
-                    unsigned char *const mine_b = slab + slot * (int)elems;
-                    if (of >= 0) mine_b[of] = 1;
-                    if (oh >= 0) mine_b[oh] = 1;
-                    wave_lds_sync();
-                    if ((((unsigned long long)blk) & 15ull) == 0) {
-                        const int n4 = run >> 2;
-                        float4 *b4 = (float4 *)blk;
-                        const u32 *s4 = (const u32 *)slab;
-#pragma unroll 4
-                        for (int i = lane; i < n4; i += 64) {
-                            const u32 b = s4[i];
-                            b4[i] = make_float4((float)(b & 0xffu), (float)((b >> 8) & 0xffu), (float)((b >> 16) & 0xffu), (float)(b >> 24));
-                        }
-                        for (int i = (n4 << 2) + lane; i < run; i += 64) blk[i] = (float)slab[i];
-                    } else { // (a batch whose observation block does not start on a 16-byte boundary: ragged N)
-                        for (int i = lane; i < run; i += 64) blk[i] = (float)slab[i];
-                    }
-                    wave_lds_sync();
-                    if (of >= 0) mine_b[of] = 0;
-                    if (oh >= 0) mine_b[oh] = 0;
+                    // composed in LDS as one BIT per float (round 6; all zero but the bits of this step, cleared again below), then
+                    // a nibble -> one 16-byte store: every byte of the run is written once, by whole 16-byte stores (a fill
+                    // followed by scattered 4-byte stores cost 9-13 % of the launch, tools/gridworld_probe.py), and the wave
+                    // keeps 1 KB of LDS instead of the 8-16 KB of round 5's byte slab, which held the kernel at 8 waves per CU
+                    gwl_emit_bits(blk, (u32 *)slab, slot * (int)elems, run, lane, of, oh);
                 } else {
                     // (a run that does not fit the LDS budget: large grids) zero fill of the run, then the two floats per env —
                     // stores of one wave to one address arrive in order; envs the generic kernel takes are written by it afterwards
@@ -253,8 +263,6 @@ __global__ __launch_bounds__(256) void gridworld_lane_rollout_kernel(StepArgs p)
             }
             call += 2;
         }
-#pragma unroll
-        for (int j = 0; j < GWL_TC; ++j) a_cur[j] = a_nxt[j];
     }
     // ---- write the state back: the cells that held something at the start, then the cells that do now
     if (act && p.T > 0) {
@@ -280,7 +288,7 @@ __device__ __forceinline__ bool gwl_interior(const GridLaneGeo &g, int c)
     return y >= 1 && y <= g.S - 2 && x >= 1 && x <= g.S - 2;
 }
 
-// the wave's run of one image observation: bytes of `slab` (zero but for the bytes at of / oh of this lane's env) -> floats
+// the wave's run of one image observation: the bit string `slab` (zero but for the bits at of / oh of this lane's env) -> floats
 template <int OBS>
 __device__ __forceinline__ void gwl_emit_image(const GridLaneGeo &g, float *blk, unsigned char *slab, int slot, int elems, int run,
                                                int lane, bool act, int hc, int fc)
@@ -290,26 +298,7 @@ __device__ __forceinline__ void gwl_emit_image(const GridLaneGeo &g, float *blk,
         if (OBS == WURM_OBS_RAW) { of = fc; oh = hc >= 0 ? g.C + hc : -1; }
         else { of = gwl_interior(g, fc) ? fc : -1; oh = gwl_interior(g, hc) ? g.C + hc : -1; }
     }
-    unsigned char *const mine_b = slab + slot * elems;
-    if (of >= 0) mine_b[of] = 1;
-    if (oh >= 0) mine_b[oh] = 1;
-    wave_lds_sync();
-    if ((((unsigned long long)blk) & 15ull) == 0) {
-        const int n4 = run >> 2;
-        float4 *b4 = (float4 *)blk;
-        const u32 *s4 = (const u32 *)slab;
-#pragma unroll 4
-        for (int i = lane; i < n4; i += 64) {
-            const u32 b = s4[i];
-            b4[i] = make_float4((float)(b & 0xffu), (float)((b >> 8) & 0xffu), (float)((b >> 16) & 0xffu), (float)(b >> 24));
-        }
-        for (int i = (n4 << 2) + lane; i < run; i += 64) blk[i] = (float)slab[i];
-    } else {
-        for (int i = lane; i < run; i += 64) blk[i] = (float)slab[i];
-    }
-    wave_lds_sync();
-    if (of >= 0) mine_b[of] = 0;
-    if (oh >= 0) mine_b[oh] = 0;
+    gwl_emit_bits(blk, (u32 *)slab, slot * elems, run, lane, of, oh);
 }
 
 __device__ __forceinline__ void gwl_emit_positions(const GridLaneGeo &g, float *o, bool obs16, int hc, int fc)
@@ -513,7 +502,18 @@ bool gridworld_lane_eligible(const StepArgs &p)
            p.obs_mode == WURM_OBS_NONE;
 }
 
-constexpr int GWL_SLAB_MAX = 16384; // bytes per wave of the image modes' byte slab (4 waves per workgroup: 64 KB)
+constexpr int GWL_SLAB_MAX = 16384; // bytes per wave of the image modes' bit string (one bit per float of the wave's run; 4 waves per workgroup: 64 KB)
+// bytes of the bit string of a run of `floats` floats, in whole 16-byte pieces (the kernels zero it with 16-byte LDS stores)
+static long long gwl_slab_bytes(long long floats) { return (((floats + 31) / 32) * 4 + 15) & ~15ll; }
+
+// The slabs of a workgroup's four waves can reach 64 KB of DYNAMIC LDS, and the kernels keep 5 KB of static scan state beside
+// them: past the 64 KB a launch gets by default the kernel is opted into the larger budget, as lane_rollout's launcher does
+// (it only worked because the runtime does not enforce the opt-in on a 160 KB part).
+static void gwl_allow_lds(const void *kernel, size_t dynamic_bytes)
+{
+    if (dynamic_bytes + sizeof(GridLaneScan) * 4 > 65536)
+        (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dynamic_bytes);
+}
 
 template <int OBS, int EPW>
 static void launch_epw(const StepArgs &p0, hipStream_t stream)
@@ -522,8 +522,9 @@ static void launch_epw(const StepArgs &p0, hipStream_t stream)
     const long long waves = (p.N + EPW - 1) / EPW;
     const int wpb = 4;
     const dim3 block(64 * wpb), grid((unsigned)((waves + wpb - 1) / wpb));
-    const long long slab = (OBS == WURM_OBS_DEFAULT || OBS == WURM_OBS_RAW) ? ((EPW * p.obs_elems + 15) & ~15ll) : 0;
+    const long long slab = (OBS == WURM_OBS_DEFAULT || OBS == WURM_OBS_RAW) ? gwl_slab_bytes(EPW * p.obs_elems) : 0;
     p.lds_per_wave = slab <= GWL_SLAB_MAX ? (int)slab : 0;
+    gwl_allow_lds((const void *)gridworld_lane_rollout_kernel<OBS, EPW>, (size_t)p.lds_per_wave * wpb);
     WURM_LAUNCH((gridworld_lane_rollout_kernel<OBS, EPW>), grid, block, (size_t)p.lds_per_wave * wpb, stream, p);
 }
 
@@ -533,7 +534,10 @@ static void launch_image(const StepArgs &p, hipStream_t stream)
     // envs per wave of the image modes (WURM_GRIDWORLD_LANE_EPW pins it).  Measured at 65 536 x 9 x 9 (tools/gridworld_probe.py,
     // one box): 'default' 16-step launch 0.299 / 0.275 / 0.263 ms at 8 / 16 / 32, 'raw' 0.203 / 0.194 / 0.192 ms
     long long epw = opt.gridworld_lane_epw;
-    if (epw != 4 && epw != 8 && epw != 16 && epw != 32 && epw != 64) epw = p.N >= 65536 ? 32 : p.N >= 16384 ? 16 : 8;
+    // round 6 (the run as a bit string, 1-2 KB of LDS per wave instead of 8-16 KB; profiles/r06_gridworld_rollout.txt): 'default'
+    // 0.298 / 0.266 / 0.253 / 0.247 ms at 8 / 16 / 32 / 64 per 16 steps and 1.00 / 0.96 / 0.85 / 0.81 per 64 (one env per wave: 0.34
+    // and 0.92), 'raw' 0.206 / 0.188 / 0.184 / 0.184
+    if (epw != 4 && epw != 8 && epw != 16 && epw != 32 && epw != 64) epw = p.N >= 65536 ? 64 : p.N >= 32768 ? 32 : p.N >= 16384 ? 16 : 8;
     switch (epw) {
     case 4: launch_epw<OBS, 4>(p, stream); break;
     case 8: launch_epw<OBS, 8>(p, stream); break;
@@ -556,7 +560,7 @@ hipError_t launch_gridworld_lane_rollout(const StepArgs &p0, hipStream_t stream)
     return hipGetLastError();
 }
 
-// envs per wave of the per-call kernel: by batch size, halved until an image mode's run fits the byte slab; 0: none does
+// envs per wave of the per-call kernel: by batch size, halved until the bit string of an image mode's run fits the LDS budget; 0: none does (never, up to 64 x 64)
 static int gridworld_lane_step_epw(const StepArgs &p)
 {
     // (one launch per call is a chain of latencies, not a stream: fewer envs per wave than the rollout.  Measured per
@@ -573,7 +577,7 @@ static int gridworld_lane_step_epw(const StepArgs &p)
         else epw = p.N >= 65536 ? 16 : p.N >= 32768 ? 8 : 4;
     }
     if (p.obs_mode == WURM_OBS_DEFAULT || p.obs_mode == WURM_OBS_RAW)
-        while (epw >= 4 && ((epw * p.obs_elems + 15) & ~15ll) > GWL_SLAB_MAX) epw >>= 1;
+        while (epw >= 4 && gwl_slab_bytes(epw * p.obs_elems) > GWL_SLAB_MAX) epw >>= 1;
     return epw >= 4 ? (int)epw : 0;
 }
 
@@ -597,7 +601,8 @@ static void launch_step_epw(const StepArgs &p0, hipStream_t stream)
     const long long waves = (p.N + EPW - 1) / EPW;
     const int wpb = 4;
     const dim3 block(64 * wpb), grid((unsigned)((waves + wpb - 1) / wpb));
-    p.lds_per_wave = (OBS == WURM_OBS_DEFAULT || OBS == WURM_OBS_RAW) ? (int)((EPW * p.obs_elems + 15) & ~15ll) : 0;
+    p.lds_per_wave = (OBS == WURM_OBS_DEFAULT || OBS == WURM_OBS_RAW) ? (int)gwl_slab_bytes(EPW * p.obs_elems) : 0;
+    gwl_allow_lds((const void *)gridworld_lane_step_kernel<OBS, EPW>, (size_t)p.lds_per_wave * wpb);
     WURM_LAUNCH((gridworld_lane_step_kernel<OBS, EPW>), grid, block, (size_t)p.lds_per_wave * wpb, stream, p);
 }
 
@@ -614,7 +619,7 @@ static void launch_step_obs(const StepArgs &p, hipStream_t stream)
 }
 
 // the mirror of the per-call step (wurm_single_call.resident of a SimpleGridworld): GWL_MIRROR_HEADER bytes + one record per env;
-// 0 where the per-call lane kernel does not serve the shape (an image observation whose run of four envs exceeds the byte slab)
+// 0 where the per-call lane kernel does not serve the shape (an image observation whose run of four envs exceeds the LDS budget of its bit string: none up to 64 x 64)
 long long gridworld_resident_bytes(long long N, int S, int obs_mode, long long obs_elems)
 {
     if (N <= 0) return 0;

@@ -1679,7 +1679,12 @@ static int pick_cpl(int S)
 //   rollout          | otherwise                                                                      | R_GENERIC
 // (the resident 9 x 9 step, lane_resident.hpp, is chosen by fused_entry: it needs the caller's mirror)
 enum Route { R_GENERIC, R_GRID_STEP, R_LANE_STEP, R_GRID_ROLLOUT, R_LANE_ROLLOUT, R_S9_INJ, R_S9, R_LEAN, R_GENERIC_PARTIAL, R_GENERIC_NONE, R_LANE_RESIDENT, R_GRIDWORLD_LANE, R_GRIDWORLD_LANE_STEP };
-static thread_local Route last_route = R_GENERIC; // (wurm_single_last_route: the route of the CALLING THREAD's last launch — a diagnostic the tests and bench.py name a launch by; no state that a later call depends on)
+// (wurm_single_last_route: the route of the CALLING THREAD's last launch — a diagnostic the tests and bench.py name a launch by; no
+// state that a later call depends on.  One object for both translation units of this file: see WURM_TU_GRID below.)
+extern thread_local Route last_route;
+#ifndef WURM_TU_GRID
+thread_local Route last_route = R_GENERIC;
+#endif
 
 static const char *route_name(Route r)
 {
@@ -1808,8 +1813,11 @@ static hipError_t launch_one(Kind kind, const StepArgs &p, dim3 grid, dim3 block
     return hipGetLastError();
 }
 
+// This file is compiled TWICE (round 6: the build's longest translation unit, 4.7 of its 6 minutes): as itself with the
+// SingleSnake half of the kernels — launch<true> — and everything else in it, and through single_grid.hip (WURM_TU_GRID) with
+// the SimpleGridworld half — launch<false>, which this unit then only declares.  Same source, two compilers at once.
 template <bool SNAKE>
-static int launch(Kind kind, StepArgs p, void *stream)
+int launch(Kind kind, StepArgs p, void *stream)
 {
     if (p.N == 0) return WURM_OK;
     const int cpl = pick_cpl(p.S);
@@ -1833,6 +1841,12 @@ static int launch(Kind kind, StepArgs p, void *stream)
     }
     return err == hipSuccess ? WURM_OK : WURM_ERR_HIP;
 }
+
+#ifdef WURM_TU_GRID
+template int launch<false>(Kind, StepArgs, void *);
+} // namespace wurm
+#else
+extern template int launch<false>(Kind, StepArgs, void *);
 
 static long long obs_elems(bool snake, int mode, int n, int S)
 {
@@ -2287,6 +2301,7 @@ int wurm_grid_rollout(float *envs, const void *actions, int actions_dtype, float
 }
 
 } // extern "C"
+#endif // WURM_TU_GRID
 
 #else
 } // namespace wurm

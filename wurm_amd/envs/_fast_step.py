@@ -129,15 +129,16 @@ class PyStepper(object):
 
     def step_multi(self, actions):
         """MultiSnake.step(actions: dict): the prebuilt (observations, rewards, dones, info) of this step; None: the caller
-        has to prepare something first (as `step`; also: the K action tensors are not the rows of one (K, N) int64 tensor
-        on the device — the caller stacks them) and calls launch_multi; a non-zero int: the entry point's error code.
+        has to prepare something first (as `step`; also: action tensors of another type or device) and calls launch_multi;
+        False: everything is in place but the action block — K int64 device vectors that are not the rows of one (K, N)
+        tensor: the caller stacks them and calls launch_multi; a non-zero int: the entry point's error code.
         Argument errors as the reference raises them (multi_snake.py:463-472)."""
         if actions.__class__ is not dict:
             return None  # (an OrderedDict may iterate in another order than its dict storage: the caller's generic path)
         if len(actions) != self.num_agents:
             raise RuntimeError('Must have a Tensor of actions for each snake')
         a_ptr, row, n = 0, 8 * self.num_envs, 0
-        rows_ok = True
+        rows_ok = stackable = True
         for act in actions.values():
             dt = act.dtype
             if dt is not self.dt_i64 and dt is not self.dt_i32 and dt is not self.dt_i16:
@@ -145,6 +146,8 @@ class PyStepper(object):
                                 '{torch.ShortTensor, torch.IntTensor, torch.LongTensor}')
             if act.size(0) != self.num_envs:
                 raise RuntimeError('Must have the same number of actions as environments.')
+            if dt is not self.dt_i64 or act.dim() != 1 or act.get_device() != self.dev_index:
+                stackable = False
             if rows_ok:
                 if dt is not self.dt_i64 or act.dim() != 1 or not act.is_contiguous() or act.get_device() != self.dev_index:
                     rows_ok = False
@@ -156,10 +159,12 @@ class PyStepper(object):
                         rows_ok = False
             n += 1
         i = self.slot
-        if not self.ok or i >= self.R or (self.want_obs_after and self.obs_afters is None) or not rows_ok:
+        if not self.ok or i >= self.R or (self.want_obs_after and self.obs_afters is None):
             return None
         if self.get_device() != self.dev_index:
             return None
+        if not rows_ok:   # False: all that is missing is the (K, N) action block (the caller stacks the K vectors)
+            return False if stackable else None
         return self.launch_multi(a_ptr)
 
     def launch_multi(self, a_ptr):

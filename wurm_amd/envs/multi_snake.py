@@ -249,6 +249,7 @@ class MultiSnake(object):
     _RESET_OBS_DROPS = 3     # ... this many: reset(done) returns a _LazyResetObs and the steps stop precomputing
     _lazy_obs_mode = False
     _lazy_obs_ref = None     # weak reference to the _LazyResetObs of the postponed reset, while it may still need filling
+    _abuf = None             # (K, N) int64: the action block of a step whose K action tensors had to be stacked
 
     @property
     def _state_dirty(self):
@@ -438,7 +439,7 @@ class MultiSnake(object):
                 '_mirror_off', '_lazy_mirror', '_mirror_why', '_watched', '_write_outs', '_touches', '_chk', '_chk_has_after',
                 '_chk_armed_at', '_chk_void_at', '_check_calls', '_check_step', '_slab', '_stor', '_keys', '_get_device',
                 '_rewards_t', '_boost_t', '_rewards_at', '_boost_at', '_rewards_src', '_info', '_cfg_dirty',
-                '_reset_obs_probe', '_reset_obs_drops', '_lazy_obs_mode', '_lazy_obs_ref')
+                '_reset_obs_probe', '_reset_obs_drops', '_lazy_obs_mode', '_lazy_obs_ref', '_abuf')
 
     def __getstate__(self):
         self._state()   # (applies a postponed reset, writes a lazy mirror out)
@@ -930,7 +931,17 @@ class MultiSnake(object):
             self._watch_ok()
             self._watched = ()
         if not (self._watched or self._lifetimes_touched or self._half):
-            out = self._fs.step_multi(actions)
+            fs = self._fs
+            out = fs.step_multi(actions)
+            if out is False:
+                # K int64 device vectors that are not the rows of one tensor (a policy that emits one tensor per agent,
+                # experiments/multiagent.py:285-300): stacked into this object's own (K, N) block — reference :492 — and
+                # launched; the stream orders the block's reuse behind the previous launch
+                buf = self._abuf
+                if buf is None:
+                    buf = self._abuf = torch.empty((self.num_snakes, self.num_envs), dtype=torch.long, device=self.device)
+                torch.stack(tuple(actions.values()), out=buf)
+                out = fs.launch_multi(buf.data_ptr())
             if out.__class__ is tuple:
                 self._info = None  # (reference :729 rebinds `self.info` every step: an assigned one does not outlive it)
                 return out
