@@ -780,12 +780,21 @@ def extra_measurements(device):
                 lambda c: (c, 65536), 4, steps, 8, f'SimpleGridworld 65 536 x 9 x 9, observation_mode={mode!r}, fused rollout of '
                 f'{steps} batch-steps per launch (one env per lane, gridworld_lane.hip)',
                 traffic_key=f'rollout_65536x9_gridworld_{mode}_chunk16')
+    rollout('rollout_65536x9_gridworld_default_64steps',
+            lambda: SimpleGridworld(65536, 9, start_location=(4, 4), observation_mode='default', device=device, seed=0),
+            lambda c: (c, 65536), 4, 64, 4, "SimpleGridworld 65 536 x 9 x 9 'default', fused rollout of 64 batch-steps per launch (4.1 GB of "
+            'observations: what a launch costs besides its steps is a quarter of what it is at 16)')
     N, T = 65536, 200
     acts = torch.randint(4, (T + 10, N), device=device, dtype=torch.int64)
+    per_call('per_call_gridworld_65536x9_default_no_reset_obs',
+             lambda: SimpleGridworld(N, 9, start_location=(4, 4), observation_mode='default', device=device, seed=0),
+             a1, same, T, "... `env.step(a); env.reset(d, return_observations=False)`: one observation stream (63.7 MB per call) "
+             'instead of two')
     per_call('per_call_gridworld_65536x9_default',
              lambda: SimpleGridworld(N, 9, start_location=(4, 4), observation_mode='default', device=device, seed=0),
              a1, same, T, 'SimpleGridworld 65 536 x 9 x 9 default observation through `env.step(a); env.reset(d)` (one env per '
-             'lane from 12 288 envs: gridworld_lane_step_kernel)', reset_kw={})
+             'lane from 12 288 envs: gridworld_lane_step_kernel; round 6: on the mirror of one record per env, ONE launch per call; 127 MB of '
+             'observations per call with the one reset returns)', reset_kw={})
     per_call('per_call_cfg3_no_mirror', lambda: SingleSnake(N, SIZE, observation_mode=OBS_MODE, device=device, seed=0,
                                                              resident_mirror=False), a1, same, T,
              '`env.step(a); env.reset(d)` at 65 536 envs with the mirror switched off: lane_step_kernel reads the whole (N,3,9,9) '
@@ -840,6 +849,8 @@ def key_numbers(line):
         'gridworld_65536_default_eps': g('rollout_65536x9_gridworld_default'), 'gridworld_65536_default_ms': g('rollout_65536x9_gridworld_default', 'ms'),
         'gridworld_65536_default_frac_real': g('rollout_65536x9_gridworld_default', 'frac_real'),
         'gridworld_65536_per_call_us': g('per_call_gridworld_65536x9_default', 'us'),
+        'gridworld_65536_per_call_no_reset_obs_us': g('per_call_gridworld_65536x9_default_no_reset_obs', 'us'),
+        'gridworld_65536_default_64steps_ms': g('rollout_65536x9_gridworld_default_64steps', 'ms'),
         'cfg3_raw_eps': g('rollout_65536x9_raw'), 'cfg3_partial3_eps': g('rollout_65536x9_partial_3'),
         'per_call_cfg3_raw_us': g('per_call_cfg3_raw', 'us'), 'per_call_cfg3_partial3_us': g('per_call_cfg3_partial_3', 'us'),
         'cfg1_per_call_us': g('per_call_cfg1_gridworld_64x9', 'us'), 'cfg1_machine': g('per_call_cfg1_gridworld_64x9', 'machine'),

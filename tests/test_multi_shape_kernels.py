@@ -62,6 +62,8 @@ def _routes(kind, N, K, S, T, kw, group_min_envs=None):
     ('percall', 301, 4, 25, 12, dict(observation_mode='partial_5', **TRAIN), None),   # multi_step_kernel<.., PARTIAL, 4, 25, 5>
     ('percall', 301, 4, 25, 12, dict(), None),                                         # multi_step_kernel<.., DEFAULT, 4, 25>
     ('percall', 301, 4, 25, 12, dict(boost=True, **TRAIN), None),
+    ('percall', 301, 2, 12, 20, dict(), None),                                         # multi_step_kernel<.., DEFAULT, 2, 12>
+    ('percall', 77, 2, 12, 20, dict(**TRAIN), None),
     ('percall', 2051, 4, 25, 6, dict(**TRAIN), None),                                  # ... in the grouped-writer form (>= 2048 envs)
     ('rollout', 83, 4, 25, 10, dict(**TRAIN), 0),                                      # multi_rollout_group_kernel<8,2,1,5,..,4,25>, ragged group
     ('percall', 37, 10, 36, 8, dict(boost=True, **TRAIN), None),                       # multi_step_wg_kernel<.., DEFAULT, 10, 36>

@@ -63,6 +63,45 @@ struct GridLaneScan {   // per wave: what the coalesced pass over the wave's run
     int bad[64];        // a nonzero value other than 1.0
 };
 
+// One coalesced pass over the wave's run of (nv, 2, S, S) floats; the few nonzero floats report to LDS.  SIXTEEN 16-byte loads
+// per lane in flight at a time (round 6): with one to four waves per SIMD the pass is a chain of memory round trips — at four
+// in flight (round 5) the 41 KB of 64 envs of 9 x 9 took ten of them, 25-30 us of every launch: a 1-step launch of 65 536
+// envs without observations took 36.8 us, a 16-step 'default' launch 55 us before its steady state (tools/gridworld_fixed_cost.py).
+__device__ __forceinline__ void gwl_scan_run(GridLaneScan &sc, const float *env_run, int nv, int C, int lane)
+{
+    const int total = nv * 2 * C;
+    const unsigned per_env = 2u * (unsigned)C;
+    auto note = [&](int i, float v) {
+        if (v != 0.0f) {
+            const unsigned e = (unsigned)i / per_env, r = (unsigned)i - e * per_env;
+            const int plane = r >= (unsigned)C ? 1 : 0;
+            atomicAdd(&sc.cnt[plane][e], 1);
+            sc.pos[plane][e] = (int)r - plane * C;
+            if (v != 1.0f) sc.bad[e] = 1;
+        }
+    };
+    if ((((unsigned long long)env_run) & 15ull) == 0) {
+        const int n4 = total >> 2;
+        const float4 *r4 = (const float4 *)env_run;
+        constexpr int U = 16;
+        for (int i0 = 0; i0 < n4; i0 += 64 * U) {
+            float4 v[U];
+#pragma unroll
+            for (int j = 0; j < U; ++j) v[j] = r4[min(i0 + lane + 64 * j, n4 - 1)]; // (clamped, unconditional: all in flight together)
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                const int i = i0 + lane + 64 * j;
+                if (i < n4 && (v[j].x != 0.0f || v[j].y != 0.0f || v[j].z != 0.0f || v[j].w != 0.0f)) {
+                    note(4 * i, v[j].x); note(4 * i + 1, v[j].y); note(4 * i + 2, v[j].z); note(4 * i + 3, v[j].w);
+                }
+            }
+        }
+        for (int i = (n4 << 2) + lane; i < total; i += 64) note(i, env_run[i]);
+    } else {
+        for (int i = lane; i < total; i += 64) note(i, env_run[i]);
+    }
+}
+
 // The wave's run of one image observation from its bit string in LDS (`bits`: run bits, all zero on entry and on return):
 // the env lanes set their two bits (of / oh: float offsets inside the env's elems, -1 = none; `base` = slot * elems), every
 // lane turns nibbles into 16-byte stores, the env lanes clear their bits again.
@@ -112,33 +151,7 @@ __global__ __launch_bounds__(256) void gridworld_lane_rollout_kernel(StepArgs p)
     sc.cnt[0][lane] = 0; sc.cnt[1][lane] = 0; sc.pos[0][lane] = -1; sc.pos[1][lane] = -1; sc.bad[lane] = 0;
     wave_lds_sync();
     float *const env_run = p.envs + env0 * 2 * C;
-    {
-        const int total = nv * 2 * C;
-        const unsigned per_env = 2u * (unsigned)C;
-        auto note = [&](int i, float v) {
-            if (v != 0.0f) {
-                const unsigned e = (unsigned)i / per_env, r = (unsigned)i - e * per_env;
-                const int plane = r >= (unsigned)C ? 1 : 0;
-                atomicAdd(&sc.cnt[plane][e], 1);
-                sc.pos[plane][e] = (int)r - plane * C;
-                if (v != 1.0f) sc.bad[e] = 1;
-            }
-        };
-        if ((((unsigned long long)env_run) & 15ull) == 0) {
-            const int n4 = total >> 2;
-            const float4 *r4 = (const float4 *)env_run;
-#pragma unroll 4
-            for (int i = lane; i < n4; i += 64) {
-                const float4 v = r4[i];
-                if (v.x != 0.0f || v.y != 0.0f || v.z != 0.0f || v.w != 0.0f) {
-                    note(4 * i, v.x); note(4 * i + 1, v.y); note(4 * i + 2, v.z); note(4 * i + 3, v.w);
-                }
-            }
-            for (int i = (n4 << 2) + lane; i < total; i += 64) note(i, env_run[i]);
-        } else {
-            for (int i = lane; i < total; i += 64) note(i, env_run[i]);
-        }
-    }
+    gwl_scan_run(sc, env_run, nv, C, lane);
     wave_lds_sync();
     const int nf = sc.cnt[0][slot], nh = sc.cnt[1][slot], bad = sc.bad[slot];
     int fc = sc.pos[0][slot], hc = sc.pos[1][slot];
@@ -341,31 +354,7 @@ __global__ __launch_bounds__(256) void gridworld_lane_step_kernel(StepArgs p)
     } else {
         sc.cnt[0][lane] = 0; sc.cnt[1][lane] = 0; sc.pos[0][lane] = -1; sc.pos[1][lane] = -1; sc.bad[lane] = 0;
         wave_lds_sync();
-        const int total = nv * 2 * C;
-        const unsigned per_env = 2u * (unsigned)C;
-        auto note = [&](int i, float v) {
-            if (v != 0.0f) {
-                const unsigned e = (unsigned)i / per_env, r = (unsigned)i - e * per_env;
-                const int plane = r >= (unsigned)C ? 1 : 0;
-                atomicAdd(&sc.cnt[plane][e], 1);
-                sc.pos[plane][e] = (int)r - plane * C;
-                if (v != 1.0f) sc.bad[e] = 1;
-            }
-        };
-        if ((((unsigned long long)env_run) & 15ull) == 0) {
-            const int n4 = total >> 2;
-            const float4 *r4 = (const float4 *)env_run;
-#pragma unroll 4
-            for (int i = lane; i < n4; i += 64) {
-                const float4 v = r4[i];
-                if (v.x != 0.0f || v.y != 0.0f || v.z != 0.0f || v.w != 0.0f) {
-                    note(4 * i, v.x); note(4 * i + 1, v.y); note(4 * i + 2, v.z); note(4 * i + 3, v.w);
-                }
-            }
-            for (int i = (n4 << 2) + lane; i < total; i += 64) note(i, env_run[i]);
-        } else {
-            for (int i = lane; i < total; i += 64) note(i, env_run[i]);
-        }
+        gwl_scan_run(sc, env_run, nv, C, lane);
     }
     // (independent of the scan: requested while it is in flight)
     long long a = 0;

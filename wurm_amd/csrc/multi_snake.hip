@@ -3319,6 +3319,9 @@ static int multi_launch(MKind kind, MultiArgs &p, void *stream)
     const void *kstep = !rng ? (const void *)multi_step_kernel<true, -1>
                       : shape_4_25_5 ? (const void *)multi_step_kernel<false, WURM_OBS_PARTIAL, 4, 25, 5>
                       : shape_4_25 && p.obs_mode == WURM_OBS_DEFAULT ? (const void *)multi_step_kernel<false, WURM_OBS_DEFAULT, 4, 25>
+                      // (the reference's own test shape, tests/test_multi_snake_env.py:340: 512 envs of 2 snakes on 12 x 12)
+                      : rng && opt.multi_shape_kernels != 0 && p.K == 2 && p.S == 12 && p.obs_mode == WURM_OBS_DEFAULT
+                            ? (const void *)multi_step_kernel<false, WURM_OBS_DEFAULT, 2, 12>
                       : p.obs_mode == WURM_OBS_DEFAULT ? (const void *)multi_step_kernel<false, WURM_OBS_DEFAULT>
                       : p.obs_mode == WURM_OBS_PARTIAL ? (const void *)multi_step_kernel<false, WURM_OBS_PARTIAL>
                       : (const void *)multi_step_kernel<false, WURM_OBS_NONE>;

@@ -880,10 +880,17 @@ class MultiSnake(object):
         # torch's allocator, and one call's outputs (123 MB at cfg4 'full': one step per slab) then stay in the 256 MB
         # Infinity Cache; a slab of several such steps would stream to HBM (measured: 39 against 35 us per iteration at cfg4)
         R = max(1, min(64, (64 << 20) // max(per_step, 1)))
-        of = torch.empty((R, 6 * K, N), dtype=torch.float32, device=dev)
+        # TWO allocations for the slab's four blocks (round 6: four torch.empty were 10 of the 28 us a step of cfg4 'full' — one
+        # step per slab — cost on the host, which is what bounded that loop): one block of floats (rewards / food / sizes,
+        # observations, reset observations; each part on a 256-byte boundary) and the flags on their own — their version
+        # counter is what proves `dones['__all__']` unmodified, and an in-place edit of an observation must not touch it
+        n_of, n_obs = R * 6 * K * N, R * K * N * elems
+        n_of_pad, n_obs_pad = (n_of + 63) & ~63, (n_obs + 63) & ~63
+        floats = torch.empty(n_of_pad + n_obs_pad + (n_obs if want_after else 0), dtype=torch.float32, device=dev)
+        of = floats[:n_of].view(R, 6 * K, N)
+        obs = floats[n_of_pad:n_of_pad + n_obs].view((R, K, N) + inner)
+        after = floats[n_of_pad + n_obs_pad:].view((R, K, N) + inner) if want_after else None
         ob = torch.empty((R, 7 * K + 1, N), dtype=torch.bool, device=dev)
-        obs = torch.empty((R, K, N) + inner, dtype=torch.float32, device=dev)
-        after = torch.empty((R, K, N) + inner, dtype=torch.float32, device=dev) if want_after else None
         sl = self._sl
         sl.out_f32, sl.out_u8, sl.obs, sl.steps, sl.obs_elems = of.data_ptr(), ob.data_ptr(), obs.data_ptr(), R, elems
         sl.obs_after = after.data_ptr() if after is not None else None
