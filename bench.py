@@ -794,7 +794,7 @@ def extra_measurements(device):
              lambda: SimpleGridworld(N, 9, start_location=(4, 4), observation_mode='default', device=device, seed=0),
              a1, same, T, 'SimpleGridworld 65 536 x 9 x 9 default observation through `env.step(a); env.reset(d)` (one env per '
              'lane from 12 288 envs: gridworld_lane_step_kernel; round 6: on the mirror of one record per env, ONE launch per call; 127 MB of '
-             'observations per call with the one reset returns)', reset_kw={})
+             'observations per call with the one reset returns)', reset_kw={}, traffic_key='gridworld_step_65536x9_default_reset_obs')
     per_call('per_call_cfg3_no_mirror', lambda: SingleSnake(N, SIZE, observation_mode=OBS_MODE, device=device, seed=0,
                                                              resident_mirror=False), a1, same, T,
              '`env.step(a); env.reset(d)` at 65 536 envs with the mirror switched off: lane_step_kernel reads the whole (N,3,9,9) '

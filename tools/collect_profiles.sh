@@ -2,7 +2,7 @@
 # Re-creates the artefacts under profiles/ on the GPU box (run through gpurun from the repo root):
 #   bash tools/collect_profiles.sh <tag>      ->  gpurun_out/profiles_<tag>/
 # rocprofv3 is always given the program itself after `--` and counters are collected in their own passes.
-TAG=${1:-r05}
+TAG=${1:-r06}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/profiles_$TAG
 mkdir -p $OUT

@@ -62,9 +62,11 @@ detail = {
     'rollout_cfg5_8192x36_default_chunk16': traffic('void wurm::(anonymous namespace)::grid_rollout_kernel<true>', 524288),
     # round 4: G envs per workgroup (multi_rollout_group_kernel): cfg4 512 workgroups of 8 steppers + 4 writers, the speeds.py
     # shape 1024 workgroups of 4 + 10
-    'multi_rollout_cfg4_4096x25_k4_full_chunk16': traffic('void wurm::multi_rollout_group_kernel<8, 2, 1, 5, false, false>', 327680) or
-                                                  traffic('void wurm::multi_rollout_group_kernel<8, 4, 1, 6, false, false>', 393216),
-    'multi_rollout_speeds_4096x36_k10_chunk4': traffic('void wurm::multi_rollout_group_kernel<4, 10, 1, 4, true, false>', 917504),
+    # (round 6: 4 envs + 4 writers per workgroup with K and S compiled in: 1024 workgroups of 512 threads)
+    'multi_rollout_cfg4_4096x25_k4_full_chunk16': traffic('void wurm::multi_rollout_group_kernel<4, 4, 1, 4, false, false, 4, 25>', 524288) or
+                                                  traffic('void wurm::multi_rollout_group_kernel<8, 2, 1, 5, false, false', 327680) or
+                                                  traffic('void wurm::multi_rollout_group_kernel<8, 4, 1, 6, false, false', 393216),
+    'multi_rollout_speeds_4096x36_k10_chunk4': traffic('void wurm::multi_rollout_group_kernel<4, 10, 1, 4, true, false', 917504),
     # round 4: one_channel / default of 65 536 x 9 x 9 through the lane kernels (bit planes): rollout, and per call (reference form)
     'rollout_65536x9_one_channel_chunk32': traffic('void wurm::lane_rollout_kernel<32, -2, false>', 131072),
     'rollout_65536x9_default_chunk32': traffic('void wurm::lane_rollout_kernel<32, -3, false>', 131072),
@@ -73,9 +75,13 @@ detail = {
     'rollout_65536x9_raw_chunk32': traffic('void wurm::lane_rollout_kernel<32, -5, false>', 131072),
     'rollout_65536x9_partial_3_chunk32': traffic('void wurm::lane_rollout_kernel<32, -4, false>', 131072),
     # round 5: SimpleGridworld one env per lane (32 envs per wave at this batch size): zero fill + two floats per env
-    'rollout_65536x9_gridworld_default_chunk16': traffic('void wurm::(anonymous namespace)::gridworld_lane_rollout_kernel<0, 32>', 131072),
-    'rollout_65536x9_gridworld_raw_chunk16': traffic('void wurm::(anonymous namespace)::gridworld_lane_rollout_kernel<1, 32>', 131072),
-    'multi_rollout_cfg4prime_4096x25_k4_partial5_chunk16': traffic('void wurm::multi_rollout_kernel<false, false, 4>', 262144),
+    # (round 6: 64 envs per wave at this batch size, the run composed as a bit string)
+    'rollout_65536x9_gridworld_default_chunk16': traffic('void wurm::(anonymous namespace)::gridworld_lane_rollout_kernel<0, 64>', 65536),
+    'rollout_65536x9_gridworld_raw_chunk16': traffic('void wurm::(anonymous namespace)::gridworld_lane_rollout_kernel<1, 64>', 65536),
+    # round 6: the per-call step of SimpleGridworld on its mirror (one record per env), reference form (two observations per call)
+    'gridworld_step_65536x9_default_reset_obs': traffic('void wurm::(anonymous namespace)::gridworld_lane_step_kernel<0, 32>', 131072),
+    # (round 6: K, S and the crop radius compiled in — multi_rollout_kernel<false, false, 4, 4, 25, 5>)
+    'multi_rollout_cfg4prime_4096x25_k4_partial5_chunk16': traffic('void wurm::multi_rollout_kernel<false, false, 4', 262144),
     'fused_step_512x9_partial2': traffic('void wurm::fused_step_kernel<2, true>', 32768),
     'fused_step_8192x9_partial2': traffic('void wurm::fused_step_kernel<2, true>', 524288),
     'fused_step_65536x9_partial2': traffic('void wurm::fused_step_kernel<2, true>', 4194304),
@@ -87,10 +93,10 @@ detail = {
     # multi_step_kernel<INJ, OBS> (round 5: one instantiation per observation family).  Dispatch order of <false, 0> ('full')
     # at this grid: 20 launches of cfg4 on the resident mirror (lazy), 20 with the mirror switched off; the second ten of
     # each.  <false, 4> (partial_n): the 20 launches of cfg4', the second ten
-    'multi_step_cfg4_4096x25_k4_full': traffic('void wurm::multi_step_kernel<false, 0>', 262144, (1, 4)),
-    'multi_step_cfg4_4096x25_k4_full_no_mirror': traffic('void wurm::multi_step_kernel<false, 0>', 262144, (3, 4)),
-    'per_call_api_cfg4prime_4096x25_k4_partial5': traffic('void wurm::multi_step_kernel<false, 4>', 262144, (1, 2)),
-    'per_call_api_speeds_4096x36_k10': traffic('void wurm::multi_step_wg_kernel<false>', 1048576) or traffic('wurm::multi_step_wg_kernel', 1048576),
+    'multi_step_cfg4_4096x25_k4_full': traffic('void wurm::multi_step_kernel<false, 0', 262144, (1, 4)),
+    'multi_step_cfg4_4096x25_k4_full_no_mirror': traffic('void wurm::multi_step_kernel<false, 0', 262144, (3, 4)),
+    'per_call_api_cfg4prime_4096x25_k4_partial5': traffic('void wurm::multi_step_kernel<false, 4', 262144, (1, 2)),
+    'per_call_api_speeds_4096x36_k10': traffic('void wurm::multi_step_wg_kernel<false', 1048576) or traffic('wurm::multi_step_wg_kernel', 1048576),
     # dispatch order: 30 launches on the resident mirror (lazy: the fp32 state is neither read nor written), then 30 without
     'grid_step_8192x36_default': traffic('void wurm::(anonymous namespace)::grid_step_kernel<true>', 524288, (0, 2)),
     'grid_step_8192x36_default_no_mirror': traffic('void wurm::(anonymous namespace)::grid_step_kernel<true>', 524288, (1, 2)),

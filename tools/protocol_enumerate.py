@@ -25,6 +25,10 @@ def _configs():
             out.append(('single', mirror, machine))
     for machine in ('python', 'c', 'c+torchinfo'):
         out.append(('grid', False, machine))
+    for mirror in ('lazy', 'eager', None):                     # round 6: SimpleGridworld's mirror, built valid / refused
+        out.append(('grid', mirror, 'python'))
+        out.append(('grid', mirror, 'c+torchinfo'))
+        out.append(('grid', mirror, 'refuse/c+torchinfo'))
     for machine in ('python', 'c', 'c+torchinfo'):
         for mirror in (False, 'lazy', 'eager', None):
             out.append(('multi', mirror, 'keep/' + machine))
@@ -34,24 +38,29 @@ def _configs():
 
 
 def _work(job):
-    (kind, mirror, machine), length, prefix = job
+    (kind, mirror, machine), length, prefix, extra = job
     import pytest
     from tests import protocol_enum as pe
     mpatch = pytest.MonkeyPatch()
     try:
         if kind == 'multi':
             keep, mach = machine.split('/')
-            pe.install_multi(mpatch, rollout_keeps_mirror=keep == 'keep', machine=mach)
-            events = pe.MultiDriver.EVENTS
-            make = lambda twin=False: pe.make_multi(mirror, twin)  # noqa: E731
+            pe.install_multi(mpatch, rollout_keeps_mirror=keep != 'nokeep', machine=mach)
+            drv = pe.MultiDriver
+            make = lambda twin=False: pe.make_multi(mirror, twin, lazy_obs=keep == 'lazyobs')  # noqa: E731
         else:
-            pe.install_single(mpatch, kind, machine)
-            events = pe.SingleDriver.EVENTS if kind == 'single' else pe.GridDriver.EVENTS
+            sim = pe.install_single(mpatch, kind, machine.split('/')[-1])
+            sim.refuse_builds = machine.startswith('refuse/')
+            drv = pe.SingleDriver if kind == 'single' else pe.GridDriver
             make = lambda twin=False: pe.make_single(kind, mirror, twin)  # noqa: E731
+        events = tuple(drv.EVENTS) + (tuple(drv.EXTRA) if extra else ())
+        xs = set(drv.EXTRA)
         n = skipped = 0
         bad = []
         for rest in itertools.product(events, repeat=length - len(prefix)):
             seq = tuple(prefix) + rest
+            if extra and not xs.intersection(seq):
+                continue   # (--extra: only the sequences that contain an event outside the base alphabet; the rest is the base run)
             r = pe.run_sequence(make, lambda: make(True), seq)
             n += 1
             if r is pe.SKIP:
@@ -70,22 +79,28 @@ def main():
     ap.add_argument('--machines', default=None, help="comma list restricting the step machines, e.g. 'python'")
     ap.add_argument('--procs', type=int, default=os.cpu_count())
     ap.add_argument('--out', default=None)
+    ap.add_argument('--extra', action='store_true', help="the events outside the base alphabet (tests/protocol_enum.py: EXTRA): every "
+                    'sequence that contains at least one of them; MultiSnake also started in the lazy-observation form')
     args = ap.parse_args()
     from tests import protocol_enum as pe
     jobs = []
-    for cfg in _configs():
+    configs = _configs()
+    if args.extra:   # MultiSnake as an object whose caller has been dropping what reset(done) returns (_LazyResetObs)
+        configs += [('multi', None, 'lazyobs/python'), ('multi', 'lazy', 'lazyobs/c+torchinfo'), ('multi', False, 'lazyobs/c')]
+    for cfg in configs:
         if args.only and cfg[0] != args.only:
             continue
         if args.machines and cfg[2].split('/')[-1] not in args.machines.split(','):
             continue
-        events = pe.MultiDriver.EVENTS if cfg[0] == 'multi' else (pe.SingleDriver.EVENTS if cfg[0] == 'single' else pe.GridDriver.EVENTS)
+        drv = pe.MultiDriver if cfg[0] == 'multi' else (pe.SingleDriver if cfg[0] == 'single' else pe.GridDriver)
+        events = tuple(drv.EVENTS) + (tuple(drv.EXTRA) if args.extra else ())
         for L in range(1, args.length + 1):
-            if L <= 3:
-                jobs.append((cfg, L, ()))
+            if L <= (2 if args.extra else 3):
+                jobs.append((cfg, L, (), args.extra))
             else:  # split by the first two events; a sequence that does not start with a step cannot have deferred anything,
                    # but it can have looked at / assigned the state first: all of them are run
                 for p in itertools.product(events, repeat=2):
-                    jobs.append((cfg, L, p))
+                    jobs.append((cfg, L, p, args.extra))
     t0 = time.time()
     totals = {}
     failures = []
