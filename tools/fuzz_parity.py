@@ -376,23 +376,52 @@ def fuzz_grid_lane(rng):
                 eh[i] = eo[i]
         # ... and the per-call step of the same file (gridworld_lane_step_kernel): the deferred form with / without the reset
         # observation, iterations without any reset, from whatever state the launches above left
+        # (round 6) half of the cases on the caller's mirror of one record per env (wurm_grid_resident_bytes), lazy or eager,
+        # written out only now and then; hand-made states in between (some outside the lane kernel's domain: the mirror is then
+        # refused, resident_valid == 2, until the next edit clears it)
         call, prev, prev_call = int(rng.randint(1 << 40)) * 2, None, None
+        res = {'lazy': bool(rng.rand() < 0.6), 'sync': True} if rng.rand() < 0.5 else None
+        synced = True
         for t in range(int(rng.randint(0, 25))):
             a = rng.randint(0, 4, N).astype(np.int64 if rng.rand() < 0.7 else np.int32)
             style = int(rng.randint(1, 4))   # 1: deferred reset, 2: deferred + obs_after, 3: no reset at all
             kw = dict(call=call, grid=start)
             if style in (1, 2):
                 kw.update(pre_done=prev, pre_call=prev_call, want_obs_after=(style == 2))
-            ro, rh = o.single_step_reset(eo, a.copy(), mode, **kw), h.single_step_reset(eh, a.copy(), mode, **kw)
-            same(eo, eh, f'{desc} per call t={t} style={style} state')
+            if res is not None:
+                res['sync'] = bool(rng.rand() < 0.5)
+                kw['resident'] = res
+            ro = o.single_step_reset(eo, a.copy(), mode, **{k: v for k, v in kw.items() if k != 'resident'})
+            rh = h.single_step_reset(eh, a.copy(), mode, **kw)
+            synced = res is None or not res['lazy'] or res['sync'] or res.get('valid') != 1
+            if synced:
+                same(eo, eh, f'{desc} per call t={t} style={style} state (mirror {res})')
             for k in ro:
-                same(ro[k], rh[k], f'{desc} per call t={t} style={style} {k}')
+                same(ro[k], rh[k], f'{desc} per call t={t} style={style} {k} (mirror {res})')
             prev, prev_call = (None, None) if style == 3 else (ro['done'], call + 1)
             call += 2
+            if synced and rng.rand() < 0.2:   # the caller edits the state it can see, and says so
+                i, kind = int(rng.randint(N)), int(rng.randint(4))
+                y, x = int(rng.randint(1, S - 1)), int(rng.randint(1, S - 1))
+                if kind == 0:
+                    eo[i, 0, y, x] = 1
+                elif kind == 1:
+                    eo[i, 1] = 0
+                elif kind == 2:
+                    eo[i, 0] = eo[i, 1]
+                else:
+                    eo[i, 0] = 0
+                eh[i] = eo[i]
+                if res is not None:
+                    res['valid'] = 0
     finally:
         for k, v in old.items():
             _lib.set_option(k, v)
     return desc
+
+
+# (round 6) the shapes with kernels of their own — K, S and the crop radius compiled in (multi_snake.hip: shape_constants)
+SPECIAL_SHAPES = [(4, 25, 'partial_5'), (4, 25, 'full'), (10, 36, 'full'), (2, 12, 'full')]
 
 
 def fuzz_multi(rng):
@@ -400,8 +429,10 @@ def fuzz_multi(rng):
     K = int(rng.choice([1, 2, 2, 3, 4, 4, 5, 8, 10, 16]))
     while 2 * K * S * S + 8 * S * S > 60000:
         K = max(1, K // 2)
-    N, T = int(rng.randint(1, 20 if S <= 18 else 6)), int(rng.randint(5, 60 if S <= 18 else 25))
     mode = ['full', f'partial_{rng.randint(1, 6)}'][rng.randint(2)]
+    if rng.rand() < 0.3:
+        K, S, mode = SPECIAL_SHAPES[rng.randint(len(SPECIAL_SHAPES))]
+    N, T = int(rng.randint(1, 20 if S <= 18 else 6)), int(rng.randint(5, 60 if S <= 18 else 25))
     cfg = dict(boost=bool(rng.rand() < 0.8), food_on_death_prob=float(rng.choice([0.0, 0.2, 0.5, 0.9, 1.0])),
                boost_cost_prob=float(rng.choice([0.0, 0.25, 0.5, 1.0])), food_mode=['only_one', 'random_rate'][rng.randint(2)],
                food_rate=float(rng.choice([5e-4, 5e-3, 5e-2])), reward_on_death=float(rng.choice([-1, -2, 0])),
@@ -450,8 +481,10 @@ def fuzz_multi_resident(rng):
     K = int(rng.choice([1, 2, 2, 3, 4, 4, 5, 8, 10, 16]))
     while 2 * K * S * S + 8 * S * S > 60000:
         K = max(1, K // 2)
-    N, T = int(rng.randint(1, 20 if S <= 18 else 6)), int(rng.randint(5, 60 if S <= 18 else 25))
     mode = ['full', f'partial_{rng.randint(1, 6)}', 'none'][rng.randint(3)]
+    if rng.rand() < 0.3:
+        K, S, mode = SPECIAL_SHAPES[rng.randint(len(SPECIAL_SHAPES))]
+    N, T = int(rng.randint(1, 20 if S <= 18 else 6)), int(rng.randint(5, 60 if S <= 18 else 25))
     cfg = dict(boost=bool(rng.rand() < 0.8), food_on_death_prob=float(rng.choice([0.0, 0.2, 0.5, 0.9, 1.0])),
                boost_cost_prob=float(rng.choice([0.0, 0.25, 0.5, 1.0])), food_mode=['only_one', 'random_rate'][rng.randint(2)],
                food_rate=float(rng.choice([5e-4, 5e-3, 5e-2])), reward_on_death=float(rng.choice([-1, -2, 0])),
@@ -526,6 +559,8 @@ def fuzz_multi_group(rng):
     S = int(rng.choice([8, 10, 12, 14, 18, 25, 27, 30, 36]))
     while 2 * K * S * S + 8 * S * S > 60000:
         S -= 4
+    if rng.rand() < 0.3:
+        K, S = [(4, 25), (10, 36), (2, 12)][rng.randint(3)]
     N = int(rng.choice([1, 3, 7, 8, 9, 15, 16, 17, 33])) if S <= 18 else int(rng.randint(1, 12))
     cfg = dict(boost=bool(rng.rand() < 0.8), food_on_death_prob=float(rng.choice([0.0, 0.2, 0.5, 0.9, 1.0])),
                boost_cost_prob=float(rng.choice([0.0, 0.25, 0.5, 1.0])), food_mode=['only_one', 'random_rate'][rng.randint(2)],
