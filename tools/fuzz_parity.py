@@ -394,10 +394,11 @@ def fuzz_grid_lane(rng):
             ro = o.single_step_reset(eo, a.copy(), mode, **{k: v for k, v in kw.items() if k != 'resident'})
             rh = h.single_step_reset(eh, a.copy(), mode, **kw)
             synced = res is None or not res['lazy'] or res['sync'] or res.get('valid') != 1
+            how = 'no mirror' if res is None else f"mirror lazy={res['lazy']} valid={res.get('valid')} sync={res['sync']}"
             if synced:
-                same(eo, eh, f'{desc} per call t={t} style={style} state (mirror {res})')
+                same(eo, eh, f'{desc} per call t={t} style={style} state ({how})')
             for k in ro:
-                same(ro[k], rh[k], f'{desc} per call t={t} style={style} {k} (mirror {res})')
+                same(ro[k], rh[k], f'{desc} per call t={t} style={style} {k} ({how})')
             prev, prev_call = (None, None) if style == 3 else (ro['done'], call + 1)
             call += 2
             if synced and rng.rand() < 0.2:   # the caller edits the state it can see, and says so
