@@ -290,6 +290,17 @@ int wurm_grid_rollout(float *envs, const void *actions, int actions_dtype, float
                       int64_t num_steps, int start_y, int start_x, uint64_t seed, uint64_t call0,
                       int64_t env_offset, const int32_t *inject_food, const int32_t *inject_reset, void *stream);
 
+/* wurm_grid_rollout (RNG mode) for a caller that keeps SimpleGridworld's mirror (wurm_grid_resident_bytes; *resident_valid and
+ * resident_lazy as the fields of wurm_single_call): where the one-env-per-lane kernel serves the launch, the state comes from
+ * the records when *resident_valid == 1 — no scan of the planes, no flag pass behind the launch, and (lazy) no write to the
+ * planes — and the records describe the final state afterwards.  A launch that BUILDS the mirror reads its verdict back
+ * (one stream synchronisation): *resident_valid = 1, or 2 = refused.  Any other launch runs wurm_grid_rollout on the planes
+ * after writing a lazy valid mirror out, and leaves *resident_valid = 0 (2 stays 2).  resident == NULL: wurm_grid_rollout. */
+int wurm_grid_rollout_resident(float *envs, const void *actions, int actions_dtype, float *reward, uint8_t *done,
+                               uint8_t *edge_collision, float *obs, int obs_mode, int obs_n, int64_t num_envs, int size,
+                               int64_t num_steps, int start_y, int start_x, uint64_t seed, uint64_t call0, int64_t env_offset,
+                               void *resident, int *resident_valid, int resident_lazy, void *stream);
+
 /* ------------------------------------------------------------------------------------------- MultiSnake */
 
 /* Dynamics parameters of MultiSnake (attributes the reference lets callers change after construction,

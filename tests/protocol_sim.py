@@ -321,6 +321,45 @@ class SimSingle(object):
         return self._rollout(_addr(envs), actions, dtype, _addr(reward), _addr(done), None, _addr(edgec), obs, m, n,
                              N, S, T, call0, off, b'%d,%d' % (_int(sy), _int(sx)))
 
+    rollout_serves_mirror = True   # False: a batch / observation the lane rollout does not serve (the library's fallback)
+
+    def wurm_grid_rollout_resident(self, envs, actions, dtype, reward, done, edgec, obs, m, n, N, S, T, sy, sx, seed, call0, off,
+                                   resident, valid_addr, lazy, stream):
+        """round 6: the rollout on SimpleGridworld's mirror — the state from the records when they are current, the records
+        current afterwards, the planes written unless (lazy and the records were current); a launch that builds the mirror may
+        refuse it (2); the fallback writes a lazy valid mirror out first and leaves the mirror stale"""
+        Ni, Si, lazy = _int(N), _int(S), _int(lazy)
+        valid = ctypes.c_int.from_address(_addr(valid_addr))
+        start = b'%d,%d' % (_int(sy), _int(sx))
+        args = (actions, dtype, _addr(reward), _addr(done), None, _addr(edgec), obs, m, n, N, S, T, call0, off, start)
+        mir = mem(resident, Ni, np.uint64)
+        if valid.value != 2 and self.rollout_serves_mirror and _int(T) > 0:
+            from_mirror = valid.value == 1
+            self.calls.append('rollout_resident')
+            planes = mem(_addr(envs), Ni * self.C * Si * Si * 4)
+            held = None
+            if from_mirror:
+                # (the stand-in rolls out in the planes' memory: the records' state is brought there — and, lazy, what the
+                # planes held is put back afterwards: the library does not write them)
+                if lazy:
+                    held = bytes(planes)
+                self.write_state(_addr(envs), Ni, Si, [int(x) for x in mir])
+            rc = self._rollout(_addr(envs), *args)
+            if self.refuse_builds and not from_mirror:
+                valid.value = 2          # (a build that met envs it cannot describe: the planes are the state)
+            else:
+                mir[:] = np.array(self.read_state(_addr(envs), Ni, Si), dtype=np.uint64)
+                valid.value = 1
+                if held is not None:
+                    planes[:] = np.frombuffer(held, dtype=np.uint8)
+            return rc
+        if lazy and valid.value == 1:
+            self.calls.append('flush')
+            self.write_state(_addr(envs), Ni, Si, [int(x) for x in mir])
+        if valid.value != 2:
+            valid.value = 0
+        return self._rollout(_addr(envs), *args)
+
 
 _STEP_SLOT_T = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
                                 ctypes.c_int, ctypes.c_uint64, ctypes.c_int, ctypes.c_uint64, ctypes.c_int, ctypes.c_void_p)

@@ -451,3 +451,139 @@ def test_class_loop_on_the_mirror():
         assert len(x) == len(y)
         for i, (u, v) in enumerate(zip(x, y)):
             assert torch.equal(u, v), f'record {k} output {i}'
+
+
+def test_class_rollouts_and_steps_interleaved_on_the_mirror():
+    """round 6: `env.rollout()` of a large SimpleGridworld batch reads and keeps the mirror of the per-call step
+    (wurm_grid_rollout_resident): rollouts and `step; reset(done)` iterations interleaved stay ONE launch each, a look at the
+    state in between writes the lazy mirror out, a hand-made env is served (the mirror refused until the next edit) — every
+    output and the state equal to the same sequence with resident_mirror=False"""
+    import torch
+    from wurm_amd import _lib
+    from wurm_amd.envs import SimpleGridworld
+    N, S, start, seed = 16384, 9, (4, 4), 17
+    g = torch.Generator(device='cuda:0').manual_seed(9)
+    tape = torch.randint(0, 4, (12, 5, N), generator=g, device='cuda:0')
+    acts = torch.randint(0, 4, (40, N), generator=g, device='cuda:0')
+    count = _lib.lib().wurm_launch_count
+
+    def run(mirror):
+        env = SimpleGridworld(N, S, start_location=start, observation_mode='default', device='cuda:0', seed=seed,
+                              resident_mirror=mirror)
+        outs, launches = [], []
+        k = 0
+        for i in range(12):
+            for j in range(2):   # two launches in a row: the second finds the mirror current, whatever came before the first
+                n0 = count()
+                ro = env.rollout(tape[i].clone(), return_observations=((i + j) % 2 == 0))
+                if j == 1:
+                    launches.append(count() - n0)
+                outs.append([ro['rewards'].clone(), ro['dones'].clone()] +
+                            ([ro['observations'].clone()] if ro['observations'] is not None else []))
+            for _ in range(3):
+                obs, r, d, info = env.step(acts[k].clone()); k += 1
+                back = env.reset(d)
+                outs.append([obs.clone(), r.clone(), d.clone(), back.clone()])
+            if i == 4:
+                outs.append([env.envs.clone()])
+            if i == 7:
+                e = env.envs
+                e[11, 0, 1, 1] = 1; e[11, 0, 1, 2] = 1          # extra foods: outside the lane kernel's domain
+                del e
+            if i == 9:
+                e = env.envs
+                e[11, 0] = 0; e[11, 0, 3, 3] = 1
+                del e
+        outs.append([env.envs.clone()])
+        return outs, launches, env.mirror_state()
+
+    (a, la, ma), (b, lb, mb) = run(None), run(False)
+    assert ma['state'] != 'off' and mb['state'] == 'off'
+    # on the mirror: no flag pass behind the rollout kernel (launch 8 follows the hand-made env: refused, two launches)
+    assert la[:8] == [1] * 8 and la[8] == 2 and la[10:] == [1, 1], la
+    assert min(lb) == 2, lb
+    assert len(a) == len(b)
+    for k, (x, y) in enumerate(zip(a, b)):
+        assert len(x) == len(y)
+        for i, (u, v) in enumerate(zip(x, y)):
+            assert torch.equal(u, v), f'record {k} output {i}'
+
+
+@pytest.mark.parametrize('mode', ['default', 'raw', 'positions', 'none'])
+@pytest.mark.parametrize('N,S,lazy', [(200, 9, True), (131, 9, False), (70, 5, True), (33, 12, True)])
+def test_rollout_on_the_mirror_matches_the_oracle(N, S, lazy, mode):
+    """wurm_grid_rollout_resident through the C ABI against the oracle: chained launches on the mirror (the first builds it),
+    lazy (the planes written out by wurm_grid_resident_flush at the end) and eager, a hand-made env in between (refused, then
+    rebuilt after the repair)"""
+    import ctypes
+    import torch
+    from wurm_amd import _lib
+    from wurm_amd._lib import knobs
+    rng = np.random.RandomState(N + 3 * S)
+    start = (S // 2, S // 2)
+    o = OracleBackend(seed=21, env_offset=5)
+    eo = _fresh(o, N, S, start)
+    dev = torch.device('cuda:0')
+    e_dev = torch.from_numpy(eo.copy()).to(dev)
+    l = _lib.lib()
+    m, n = _lib.parse_obs_mode(mode)
+    res = torch.zeros(16 + 4 * N, dtype=torch.uint8, device=dev)
+    valid = ctypes.c_int(0)
+    call = 100
+    stream = _lib.stream_ptr(0)
+    with knobs(WURM_LANE_ROLLOUT_MIN_ENVS=0, WURM_LANE_STEP_MIN_ENVS=0):
+        assert l.wurm_grid_resident_size(_lib.i64(N), S, m) == 16 + 4 * N
+        for launch in range(7):
+            T = int(rng.choice([1, 3, 8, 20]))
+            a = rng.randint(-2, 7, size=(T, N)).astype(np.int64)
+            o.call = call
+            ro = o.grid_rollout(eo, a.copy(), start, mode)
+            a_dev = torch.from_numpy(a.copy()).to(dev)
+            shape = _o_shape(mode, N, S)
+            obs = torch.empty((T,) + shape, dtype=torch.float32, device=dev) if shape else None
+            reward = torch.empty((T, N), dtype=torch.float32, device=dev)
+            done = torch.empty((T, N), dtype=torch.uint8, device=dev)
+            edge = torch.empty((T, N), dtype=torch.uint8, device=dev)
+            was = valid.value
+            n0 = l.wurm_launch_count()
+            rc = l.wurm_grid_rollout_resident(_lib.ptr(e_dev), _lib.ptr(a_dev), _lib.ACT_I64, _lib.ptr(reward), _lib.ptr(done),
+                                              _lib.ptr(edge), _lib.ptr(obs), m, n, _lib.i64(N), S, _lib.i64(T), start[0], start[1],
+                                              _lib.u64(21), _lib.u64(call), _lib.i64(5), _lib.ptr(res), ctypes.addressof(valid),
+                                              int(lazy), stream)
+            assert rc == 0 and _route() == 'gridworld_lane'
+            assert l.wurm_launch_count() - n0 == (1 if was == 1 else 2)
+            call += 2 * T
+            _same(ro['reward'], reward.cpu().numpy(), f'reward launch {launch}')
+            _same(ro['done'], done.cpu().numpy(), f'done launch {launch}')
+            if obs is not None:
+                _same(ro['obs'], obs.cpu().numpy(), f'obs launch {launch}')
+            if launch == 2:          # a hand-made env: written into the planes the caller can see (flushed first), mirror cleared
+                _flush(l, e_dev, res, valid, lazy, N, S, stream)
+                _same(eo, e_dev.cpu().numpy(), 'state before the edit')
+                eo[1 % N, 0, 1, 1] = 1; eo[1 % N, 0, 2, 2] = 1; eo[1 % N, 0, 3, 3] = 1
+                e_dev.copy_(torch.from_numpy(eo))
+                valid.value = 0
+            elif launch == 3:
+                assert valid.value == 2          # refused; the planes are the state
+                _same(eo, e_dev.cpu().numpy(), 'state while refused')
+                eo[1 % N, 0] = 0; eo[1 % N, 0, 2, 2] = 1
+                e_dev.copy_(torch.from_numpy(eo))
+                valid.value = 0
+            elif launch > 3:
+                assert valid.value == 1
+        _flush(l, e_dev, res, valid, lazy, N, S, stream)
+        _same(eo, e_dev.cpu().numpy(), 'final state')
+
+
+def _o_shape(mode, N, S):
+    from oracle import oracle as _orc
+    return tuple(_orc.grid_obs_shape(mode, N, S)) if _orc.grid_obs_shape(mode, N, S) else None
+
+
+def _flush(l, e_dev, res, valid, lazy, N, S, stream):
+    import ctypes
+    from wurm_amd import _lib
+    c = _lib.SingleCall()
+    c.envs, c.num_envs, c.size = _lib.ptr(e_dev), N, S
+    c.resident, c.resident_valid, c.resident_lazy = _lib.ptr(res), valid.value, int(lazy)
+    _lib.check(l.wurm_grid_resident_flush(ctypes.addressof(c), stream), 'flush')

@@ -146,20 +146,37 @@ __global__ __launch_bounds__(256) void gridworld_lane_rollout_kernel(StepArgs p)
     g.rcpI = g.I > 0 ? 1.0f / (float)g.I : 1.0f;
     const int S = g.S, C = g.C;
 
-    // ---- the state: one coalesced pass over the wave's run of (nv, 2, S, S) floats; the few nonzero floats report to LDS
+    // ---- the state: the caller's mirror when it describes it (wurm_grid_rollout_resident; the records of the per-call step:
+    // gridworld_lane_step_kernel), else one coalesced pass over the wave's run of (nv, 2, S, S) floats; the few nonzero
+    // floats report to LDS
+    const bool mirrored = p.resident != nullptr, from_mirror = mirrored && p.resident_valid != 0;
+    u32 *const recs = mirrored ? (u32 *)((unsigned char *)p.resident + GWL_MIRROR_HEADER) : nullptr;
     GridLaneScan &sc = scans[wave];
-    sc.cnt[0][lane] = 0; sc.cnt[1][lane] = 0; sc.pos[0][lane] = -1; sc.pos[1][lane] = -1; sc.bad[lane] = 0;
-    wave_lds_sync();
     float *const env_run = p.envs + env0 * 2 * C;
-    gwl_scan_run(sc, env_run, nv, C, lane);
-    wave_lds_sync();
-    const int nf = sc.cnt[0][slot], nh = sc.cnt[1][slot], bad = sc.bad[slot];
-    int fc = sc.pos[0][slot], hc = sc.pos[1][slot];
+    int fc, hc;
+    bool act;
+    if (from_mirror) {
+        const u32 rec = present ? recs[env] : 0xffffffffu;
+        hc = (int)(short)(rec & 0xffffu);
+        fc = (int)(short)(rec >> 16);
+        act = present && rec != GWL_REC_BAD;
+    } else {
+        sc.cnt[0][lane] = 0; sc.cnt[1][lane] = 0; sc.pos[0][lane] = -1; sc.pos[1][lane] = -1; sc.bad[lane] = 0;
+        wave_lds_sync();
+        gwl_scan_run(sc, env_run, nv, C, lane);
+        wave_lds_sync();
+        const int nf = sc.cnt[0][slot], nh = sc.cnt[1][slot], bad = sc.bad[slot];
+        fc = sc.pos[0][slot]; hc = sc.pos[1][slot];
+        // (round 6: an env WITHOUT an agent is in the domain too — an agent that walked off the grid, :153-162 with an all-zero
+        // head plane: nothing moves, no reward, done — so that the domain is closed under every step, not only step + reset)
+        act = present && !bad && nh <= 1 && nf <= 1 && (hc != fc || hc < 0);
+    }
     float *const envp = env_run + (long long)slot * 2 * C;
-    // (round 6: an env WITHOUT an agent is in the domain too — an agent that walked off the grid, :153-162 with an all-zero
-    // head plane: nothing moves, no reward, done — so that the domain is closed under every step, not only step + reset)
-    const bool act = present && !bad && nh <= 1 && nf <= 1 && (hc != fc || hc < 0);
     if (present && !act) p.done[env] = GRID_SKIPPED; // rollout_kernel takes this env (second launch, only_flagged; T >= 1: eligible())
+    if (mirrored && !from_mirror) { // a launch that builds the mirror counts what it cannot describe (the header's first word)
+        const u64 odd = ballot(present && !act);
+        if (odd != 0 && lane == 0) atomicAdd((int *)p.resident, popc64(odd));
+    }
     const int hc0 = hc, fc0 = fc;
     const u64 env_id = (u64)(p.env_offset + env);
     const int start = p.start_y * S + p.start_x;
@@ -277,8 +294,10 @@ __global__ __launch_bounds__(256) void gridworld_lane_rollout_kernel(StepArgs p)
             call += 2;
         }
     }
-    // ---- write the state back: the cells that held something at the start, then the cells that do now
-    if (act && p.T > 0) {
+    // ---- write the state back: the record, and — unless the mirror is lazy and was current — the cells of the planes that
+    // held something at the start, then the cells that do now
+    if (mirrored && present) recs[env] = act ? (((u32)hc & 0xffffu) | ((u32)fc << 16)) : GWL_REC_BAD;
+    if (act && p.T > 0 && !(from_mirror && p.resident_lazy)) {
         if (fc0 >= 0 && fc0 != fc) envp[fc0] = 0.0f;
         if (hc0 >= 0 && hc0 != hc) envp[C + hc0] = 0.0f;
         if (fc >= 0 && fc != fc0) envp[fc] = 1.0f;

@@ -1761,7 +1761,8 @@ static hipError_t launch_one(Kind kind, const StepArgs &p, dim3 grid, dim3 block
         if constexpr (!SNAKE) {
             hipError_t err = launch_gridworld_lane_rollout(p, st);
             if (err != hipSuccess) return err;
-            WURM_LAUNCH((flagged_kernel<CPL, SNAKE, true>), fgrid, block, lds, st, p); // (the envs outside the lane kernel's domain)
+            if (!(p.resident != nullptr && p.resident_valid)) // (a mirror that was current describes every env: see R_GRIDWORLD_LANE_STEP)
+                WURM_LAUNCH((flagged_kernel<CPL, SNAKE, true>), fgrid, block, lds, st, p); // (the envs outside the lane kernel's domain)
         }
         break;
     case R_GRIDWORLD_LANE_STEP:
@@ -2297,6 +2298,58 @@ int wurm_grid_rollout(float *envs, const void *actions, int actions_dtype, float
     p.obs_elems = obs_elems(false, obs_mode, obs_n, size); p.N = num_envs; p.S = size; p.T = num_steps;
     p.start_y = start_y; p.start_x = start_x; p.seed = seed; p.call = call0; p.env_offset = env_offset;
     p.inject_food = inject_food; p.inject_reset = inject_reset;
+    return launch<false>(K_ROLLOUT, p, stream);
+}
+
+/* wurm_grid_rollout (RNG mode) for a caller that keeps SimpleGridworld's mirror (wurm_grid_resident_bytes; meaning of
+ * *resident_valid / resident_lazy as in wurm_single_call): where the lane kernel serves the launch the state is read from the
+ * records when *resident_valid == 1 — no scan of the planes, no flag pass behind the launch — and the records describe the final
+ * state afterwards; the planes are written unless the mirror is lazy and was current.  A launch that builds the mirror reads
+ * its verdict back (one stream synchronisation): *resident_valid = 1, or 2 = refused.  Any other launch (a batch or
+ * observation the lane kernel does not serve, a refused mirror) runs wurm_grid_rollout on the planes, after writing a lazy
+ * valid mirror out; *resident_valid is then 0 (2 stays 2). */
+int wurm_grid_rollout_resident(float *envs, const void *actions, int actions_dtype, float *reward, uint8_t *done,
+                               uint8_t *edge_collision, float *obs, int obs_mode, int obs_n, int64_t num_envs, int size,
+                               int64_t num_steps, int start_y, int start_x, uint64_t seed, uint64_t call0, int64_t env_offset,
+                               void *resident, int *resident_valid, int resident_lazy, void *stream)
+{
+    if (!resident || !resident_valid)
+        return wurm_grid_rollout(envs, actions, actions_dtype, reward, done, edge_collision, obs, obs_mode, obs_n, num_envs, size,
+                                 num_steps, start_y, start_x, seed, call0, env_offset, nullptr, nullptr, stream);
+    int rc = check_common(false, envs, num_envs, size, obs, obs_mode, obs_n, actions_dtype);
+    if (rc) return rc;
+    if (num_steps < 0) return WURM_ERR_INVALID_ARG;
+    if (size <= 4) return WURM_ERR_UNSUPPORTED;
+    if (start_y < 0 || start_x < 0 || start_y >= size || start_x >= size) return WURM_ERR_UNSUPPORTED;
+    if (num_envs > 0 && num_steps > 0 && (!actions || !reward || !done || !edge_collision)) return WURM_ERR_INVALID_ARG;
+    if (num_steps == 0 || num_envs == 0) return WURM_OK;
+    StepArgs p = {};
+    p.envs = envs; p.actions = const_cast<void *>(actions); p.act_dtype = actions_dtype; p.reward = reward;
+    p.done = done; p.edgec = edge_collision; p.obs = obs; p.obs_mode = obs_mode; p.obs_n = obs_n;
+    p.obs_elems = obs_elems(false, obs_mode, obs_n, size); p.N = num_envs; p.S = size; p.T = num_steps;
+    p.start_y = start_y; p.start_x = start_x; p.seed = seed; p.call = call0; p.env_offset = env_offset;
+    if (*resident_valid != 2 && gridworld_lane_eligible(p)) {
+        p.resident = resident;
+        p.resident_valid = *resident_valid == 1;
+        p.resident_lazy = resident_lazy != 0;
+        if (!p.resident_valid && hipMemsetAsync(resident, 0, 16, (hipStream_t)stream) != hipSuccess) return WURM_ERR_HIP;
+        rc = launch<false>(K_ROLLOUT, p, stream);
+        if (rc != WURM_OK) { *resident_valid = 0; return rc; }
+        if (!p.resident_valid) { // the launch built the mirror: valid only if it could describe every env (see fused_entry)
+            int odd = 0;
+            if (hipMemcpyAsync(&odd, resident, 4, hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess ||
+                hipStreamSynchronize((hipStream_t)stream) != hipSuccess)
+                return WURM_ERR_HIP;
+            *resident_valid = odd != 0 ? 2 : 1;
+        }
+        return WURM_OK;
+    }
+    if (resident_lazy && *resident_valid == 1) {
+        StepArgs q = p;
+        q.resident = resident;
+        if (launch_gridworld_lane_flush(q, (hipStream_t)stream) != hipSuccess) return WURM_ERR_HIP;
+    }
+    if (*resident_valid != 2) *resident_valid = 0;
     return launch<false>(K_ROLLOUT, p, stream);
 }
 

@@ -5,6 +5,8 @@ iteration, see wurm_amd/envs/_fast_step.py."""
 from collections import namedtuple
 from typing import Tuple
 
+import ctypes
+
 import torch
 
 from wurm_amd import _lib
@@ -179,7 +181,6 @@ class SimpleGridworld(FastStepMixin):
             raise RuntimeError('rollout actions must be a contiguous device tensor')
         if self.start_location is None:
             raise NotImplementedError("Haven't implemented random starting locations")
-        envs = self._state()
         T, N = actions.shape
         if return_observations:
             m, n = _lib.parse_obs_mode(self.observation_mode)
@@ -188,11 +189,33 @@ class SimpleGridworld(FastStepMixin):
             m, n, obs = _lib.OBS_NONE, 0, None
         reward = torch.empty((T, N), dtype=torch.float32, device=self.device)
         flags = torch.empty((2, T, N), dtype=torch.bool, device=self.device)
-        rc = _lib.call(self.device.index, _lib.lib().wurm_grid_rollout, 
-            _lib.ptr(envs), _lib.ptr(actions), _lib.ACT_I64 if actions.dtype == torch.long else _lib.ACT_I32,
-            _lib.ptr(reward), _lib.ptr(flags[0]), _lib.ptr(flags[1]), _lib.ptr(obs), m, n, _lib.i64(N), self.size,
-            _lib.i64(T), int(self.start_location[0]), int(self.start_location[1]), _lib.u64(self.seed),
-            _lib.u64(self._next_call(2 * T)), _lib.i64(self.env_offset), None, None, _lib.stream_ptr(self.device.index))
+        dt = _lib.ACT_I64 if actions.dtype == torch.long else _lib.ACT_I32
+        # The mirror (round 6; large batches: wurm_grid_resident_bytes): the launch reads the records instead of scanning the
+        # planes when they describe the state, keeps them current, and — lazy — does not write the planes; no flag pass
+        # behind it (wurm_grid_rollout_resident).  Same protocol as step(): a postponed reset is applied first, a watched
+        # tensor is checked for in-place edits, nothing is "touched".
+        if self._fs.pending:
+            self._flush()
+        self._mirror_sync()
+        self._setup_mirror(*_lib.parse_obs_mode(self.observation_mode))
+        c = self._c
+        if c.resident and T > 0:
+            envs = self._checked(self._envs)
+            self._fs.last_fresh = False
+            valid = ctypes.c_int(c.resident_valid)
+            rc = _lib.call(self.device.index, _lib.lib().wurm_grid_rollout_resident,
+                _lib.ptr(envs), _lib.ptr(actions), dt, _lib.ptr(reward), _lib.ptr(flags[0]), _lib.ptr(flags[1]), _lib.ptr(obs),
+                m, n, _lib.i64(N), self.size, _lib.i64(T), int(self.start_location[0]), int(self.start_location[1]),
+                _lib.u64(self.seed), _lib.u64(self._next_call(2 * T)), _lib.i64(self.env_offset), c.resident,
+                ctypes.addressof(valid), int(c.resident_lazy), _lib.stream_ptr(self.device.index))
+            c.resident_valid = valid.value if rc == _lib.OK else 0
+        else:
+            envs = self._state()
+            rc = _lib.call(self.device.index, _lib.lib().wurm_grid_rollout,
+                _lib.ptr(envs), _lib.ptr(actions), dt,
+                _lib.ptr(reward), _lib.ptr(flags[0]), _lib.ptr(flags[1]), _lib.ptr(obs), m, n, _lib.i64(N), self.size,
+                _lib.i64(T), int(self.start_location[0]), int(self.start_location[1]), _lib.u64(self.seed),
+                _lib.u64(self._next_call(2 * T)), _lib.i64(self.env_offset), None, None, _lib.stream_ptr(self.device.index))
         _lib.check(rc, 'SimpleGridworld.rollout')
         self._done_all_false()
         return {'observations': obs, 'rewards': reward, 'dones': flags[0], 'edge_collision': flags[1]}
