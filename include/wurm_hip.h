@@ -118,6 +118,17 @@ int wurm_single_rollout(float *envs, void *actions, int actions_dtype, float *re
                         int64_t num_envs, int size, int64_t num_steps, uint64_t seed, uint64_t call0,
                         int64_t env_offset, const int32_t *inject_food, const int32_t *inject_reset, void *stream);
 
+/* wurm_single_rollout (RNG mode) for a caller that keeps the mirror of wurm_single_call.resident (wurm_single_resident_bytes;
+ * *resident_valid / resident_lazy as the fields of wurm_single_call).  Grids of 12 x 12 and larger: an env the mirror's record
+ * describes is read from its clock grid (2 bytes per cell instead of 12) and written back there — the planes only while the
+ * mirror is not lazy — and *resident_valid = 1 afterwards (round 6: a 16-step launch of BASELINE configs[4] no longer reads
+ * 127 MB of planes).  9 x 9 and every launch the clock-grid rollout does not serve: wurm_single_rollout on the planes after
+ * writing a lazy valid mirror out; *resident_valid = 0.  resident == NULL: wurm_single_rollout. */
+int wurm_single_rollout_resident(float *envs, void *actions, int actions_dtype, float *reward, uint8_t *done,
+                                 uint8_t *self_collision, uint8_t *edge_collision, float *obs, int obs_mode, int obs_n,
+                                 int64_t num_envs, int size, int64_t num_steps, uint64_t seed, uint64_t call0,
+                                 int64_t env_offset, void *resident, int *resident_valid, int resident_lazy, void *stream);
+
 /* Arguments of wurm_single_step_reset / wurm_grid_step_reset (a HOST struct of device pointers and sizes; the fields
  * shared with wurm_single_step / wurm_single_reset mean the same). */
 typedef struct wurm_single_call {

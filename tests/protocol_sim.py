@@ -328,10 +328,19 @@ class SimSingle(object):
         """round 6: the rollout on SimpleGridworld's mirror — the state from the records when they are current, the records
         current afterwards, the planes written unless (lazy and the records were current); a launch that builds the mirror may
         refuse it (2); the fallback writes a lazy valid mirror out first and leaves the mirror stale"""
-        Ni, Si, lazy = _int(N), _int(S), _int(lazy)
-        valid = ctypes.c_int.from_address(_addr(valid_addr))
         start = b'%d,%d' % (_int(sy), _int(sx))
         args = (actions, dtype, _addr(reward), _addr(done), None, _addr(edgec), obs, m, n, N, S, T, call0, off, start)
+        return self._rollout_resident(envs, args, N, S, T, resident, valid_addr, lazy)
+
+    def wurm_single_rollout_resident(self, envs, actions, dtype, reward, done, selfc, edgec, obs, m, n, N, S, T, seed, call0, off,
+                                     resident, valid_addr, lazy, stream):
+        """... and SingleSnake's (grids of 12 x 12 and larger keep the mirror: rollout_serves_mirror; 9 x 9: the fallback)"""
+        args = (actions, dtype, _addr(reward), _addr(done), _addr(selfc), _addr(edgec), obs, m, n, N, S, T, call0, off, b'')
+        return self._rollout_resident(envs, args, N, S, T, resident, valid_addr, lazy)
+
+    def _rollout_resident(self, envs, args, N, S, T, resident, valid_addr, lazy):
+        Ni, Si, lazy = _int(N), _int(S), _int(lazy)
+        valid = ctypes.c_int.from_address(_addr(valid_addr))
         mir = mem(resident, Ni, np.uint64)
         if valid.value != 2 and self.rollout_serves_mirror and _int(T) > 0:
             from_mirror = valid.value == 1

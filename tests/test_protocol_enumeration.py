@@ -64,11 +64,16 @@ MULTI_REGRESSIONS = [
 ]
 
 
-@pytest.mark.parametrize('mirror,machine', [(False, 'python'), ('lazy', 'python'), ('eager', 'python'), (None, 'python'),
-                                            (None, 'c'), (None, 'c+torchinfo'), ('lazy', 'c+torchinfo')])
-def test_single_snake_every_sequence_up_to_3(monkeypatch, mirror, machine):
+@pytest.mark.parametrize('mirror,machine,keeps', [(False, 'python', True), ('lazy', 'python', True), ('eager', 'python', True),
+                                                  (None, 'python', True), (None, 'c', True), (None, 'c+torchinfo', True),
+                                                  ('lazy', 'c+torchinfo', True), ('lazy', 'python', False),
+                                                  (None, 'c+torchinfo', False)])
+def test_single_snake_every_sequence_up_to_3(monkeypatch, mirror, machine, keeps):
+    """(keeps — round 6: `rollout` on the mirror, wurm_single_rollout_resident: grids of 12 x 12 and larger keep the mirror current;
+    False: the library's fallback for 9 x 9 — a lazy mirror written out first, the mirror stale afterwards)"""
     _machine_or_skip(machine)
-    pe.install_single(monkeypatch, 'single', machine)
+    sim = pe.install_single(monkeypatch, 'single', machine)
+    sim.rollout_serves_mirror = keeps
     _run_all(lambda twin=False: pe.make_single('single', mirror, twin), pe.SingleDriver.EVENTS, 3, SINGLE_REGRESSIONS)
 
 

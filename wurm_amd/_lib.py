@@ -21,7 +21,7 @@ ACT_I64, ACT_I32 = 0, 1
 # every symbol include/wurm_hip.h declares (tests/test_abi.py checks the header against this list and the .so)
 SYMBOLS = [
     'wurm_version', 'wurm_set_option', 'wurm_get_option', 'wurm_reset_option', 'wurm_launch_count', 'wurm_single_last_route', 'wurm_single_obs_elems', 'wurm_grid_obs_elems',
-    'wurm_single_step', 'wurm_single_reset', 'wurm_single_observe', 'wurm_single_rollout', 'wurm_single_check',
+    'wurm_single_step', 'wurm_single_reset', 'wurm_single_observe', 'wurm_single_rollout', 'wurm_single_rollout_resident', 'wurm_single_check',
     'wurm_single_step_reset', 'wurm_single_resident_bytes', 'wurm_single_resident_size', 'wurm_single_resident_flush', 'wurm_grid_step_reset', 'wurm_grid_resident_bytes', 'wurm_grid_resident_size', 'wurm_grid_resident_flush', 'wurm_single_step_slot', 'wurm_grid_step_slot',
     'wurm_grid_step', 'wurm_grid_reset', 'wurm_grid_observe', 'wurm_grid_rollout', 'wurm_grid_rollout_resident',
     'wurm_multi_obs_elems', 'wurm_multi_step', 'wurm_multi_step_reset', 'wurm_multi_step_packed', 'wurm_multi_step_slot', 'wurm_multi_resident_bytes', 'wurm_multi_resident_size', 'wurm_multi_resident_flush', 'wurm_multi_reset', 'wurm_multi_observe', 'wurm_multi_check',

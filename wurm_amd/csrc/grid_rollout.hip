@@ -544,8 +544,35 @@ __global__ __launch_bounds__(256) void grid_rollout_kernel(StepArgs p)
     float *envp = p.envs + env * 3 * g.C;
     const u64 env_id = (u64)(p.env_offset + env);
     Snk s;
-    if (!grid_load<VEC>(g, envp, s)) { // outside the domain: rollout_kernel takes this env (second launch, only_flagged)
-        if (lane == 0) p.done[env] = GRID_SKIPPED;
+    // (round 6) the caller's mirror of the per-call step (wurm_single_rollout_resident; grid_step_kernel's records and clock
+    // grids): an env its record describes comes from there — 2 bytes per cell instead of 12 — and goes back there; the
+    // planes are written only while the mirror is not lazy.  An env the record does not describe is read from the planes
+    // as ever (they are authoritative for it), one that finished in the last per-call step and was not rebuilt is outside
+    // the domain (its last state written out first if the mirror is lazy).
+    const bool mirrored = p.resident != nullptr, lazy = mirrored && p.resident_lazy != 0;
+    cell_t *const mgrid = mirrored ? mirror_grid(p, g, env) : nullptr;
+    int *const mrec = mirrored ? mirror_rec(p, g, env) : nullptr;
+    bool from_rec = false;
+    if (mirrored && p.resident_valid) {
+        int hb = 0;
+        const int flags = mirror_load_rec(g, mrec, s, hb);
+        if ((flags & (MR_ACT | MR_TERMINAL)) == MR_ACT) {
+            mirror_load_grid(g, mgrid);
+            from_rec = true;
+        } else if (flags & MR_ACT) {
+            if (lazy) {
+                mirror_load_grid(g, mgrid);
+                grid_observe<VEC>(g, view_of(s, hb), envp, WURM_OBS_RAW, 0);
+            }
+            if (lane == 0) { mrec[9] = 0; p.done[env] = GRID_SKIPPED; }
+            return;
+        }
+    }
+    if (!from_rec && !grid_load<VEC>(g, envp, s)) { // outside the domain: rollout_kernel takes this env (second launch, only_flagged)
+        if (lane == 0) {
+            if (mirrored) mrec[9] = 0;
+            p.done[env] = GRID_SKIPPED;
+        }
         return;
     }
 
@@ -601,12 +628,19 @@ __global__ __launch_bounds__(256) void grid_rollout_kernel(StepArgs p)
         }
     }
 
+    // ---- the mirror: the grid whole, the record (every done env was reset: never terminal here)
+    if (mirrored) {
+        mirror_store_grid(g, mgrid);
+        mirror_store_rec(g, mrec, s, s.L, MR_ACT);
+        if (lazy) return; // (the planes are written out by wurm_single_resident_flush when something looks at them)
+    }
     // ---- back to the reference layout (every done env was reset: the head is on the grid, inside the ring).
     // Only what may differ from HBM is written: a cell whose clock is not 0 has held a body value or the food since the
     // load (clocks and markers only ever overwrite each other; nothing is cleared to 0 but by a re-base), the head and
-    // food planes hold a single 1 each.  After a re-base that bookkeeping is gone and the state is stored whole.
+    // food planes hold a single 1 each.  After a re-base that bookkeeping is gone and the state is stored whole — as is
+    // the state of an env that came from the mirror (its clocks say nothing about what the planes hold).
     wave_lds_sync();
-    if (rebased) {
+    if (rebased || from_rec) {
         grid_observe<VEC>(g, view_of(s, s.L), envp, WURM_OBS_RAW, 0);
         return;
     }

@@ -2301,6 +2301,50 @@ int wurm_grid_rollout(float *envs, const void *actions, int actions_dtype, float
     return launch<false>(K_ROLLOUT, p, stream);
 }
 
+/* wurm_single_rollout (RNG mode) for a caller that keeps the mirror of wurm_single_call.resident: grids of 12 x 12 and larger
+ * roll out on the clock grids and records of the per-call step (grid_rollout.hip) — an env its record describes is read from
+ * the mirror (2 bytes per cell instead of 12) and written back there, the planes only while the mirror is not lazy; the
+ * mirror describes the final state afterwards (*resident_valid = 1).  9 x 9 (another mirror format, a launch that costs 11 us
+ * besides its steps) and every other case run wurm_single_rollout on the planes after writing a lazy valid mirror out;
+ * *resident_valid is then 0. */
+int wurm_single_rollout_resident(float *envs, void *actions, int actions_dtype, float *reward, uint8_t *done,
+                                 uint8_t *self_collision, uint8_t *edge_collision, float *obs, int obs_mode, int obs_n,
+                                 int64_t num_envs, int size, int64_t num_steps, uint64_t seed, uint64_t call0,
+                                 int64_t env_offset, void *resident, int *resident_valid, int resident_lazy, void *stream)
+{
+    if (!resident || !resident_valid)
+        return wurm_single_rollout(envs, actions, actions_dtype, reward, done, self_collision, edge_collision, obs, obs_mode, obs_n,
+                                   num_envs, size, num_steps, seed, call0, env_offset, nullptr, nullptr, stream);
+    int rc = check_common(true, envs, num_envs, size, obs, obs_mode, obs_n, actions_dtype);
+    if (rc) return rc;
+    if (num_steps < 0) return WURM_ERR_INVALID_ARG;
+    if (size <= 8) return WURM_ERR_UNSUPPORTED;
+    if (num_envs > 0 && num_steps > 0 && (!actions || !reward || !done || !self_collision || !edge_collision))
+        return WURM_ERR_INVALID_ARG;
+    if (num_steps == 0 || num_envs == 0) return WURM_OK;
+    StepArgs p = {};
+    p.envs = envs; p.actions = actions; p.act_dtype = actions_dtype; p.reward = reward; p.done = done;
+    p.selfc = self_collision; p.edgec = edge_collision; p.obs = obs; p.obs_mode = obs_mode; p.obs_n = obs_n;
+    p.obs_elems = obs_elems(true, obs_mode, obs_n, size); p.N = num_envs; p.S = size; p.T = num_steps; p.seed = seed;
+    p.call = call0; p.env_offset = env_offset;
+    if (grid_rollout_eligible(p) && grid_resident_eligible(p)) {
+        p.resident = resident;
+        p.resident_valid = *resident_valid != 0;
+        p.resident_lazy = resident_lazy != 0;
+        rc = launch<true>(K_ROLLOUT, p, stream);
+        *resident_valid = rc == WURM_OK ? 1 : 0;
+        return rc;
+    }
+    if (resident_lazy && *resident_valid) {
+        hipError_t err = hipSuccess;
+        if (size == 9) err = launch_lane_resident_flush(p, resident, (hipStream_t)stream);
+        else if (grid_step_eligible(p)) { StepArgs q = p; q.resident = resident; err = launch_grid_resident_flush(q, (hipStream_t)stream); }
+        if (err != hipSuccess) return WURM_ERR_HIP;
+    }
+    *resident_valid = 0;
+    return launch<true>(K_ROLLOUT, p, stream);
+}
+
 /* wurm_grid_rollout (RNG mode) for a caller that keeps SimpleGridworld's mirror (wurm_grid_resident_bytes; meaning of
  * *resident_valid / resident_lazy as in wurm_single_call): where the lane kernel serves the launch the state is read from the
  * records when *resident_valid == 1 — no scan of the planes, no flag pass behind the launch — and the records describe the final

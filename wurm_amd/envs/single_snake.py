@@ -14,6 +14,8 @@ Per-call path: one launch per `step(a); reset(done)` iteration, see wurm_amd/env
 """
 from collections import namedtuple
 
+import ctypes
+
 import torch
 
 from wurm_amd import _lib
@@ -242,7 +244,6 @@ class SingleSnake(FastStepMixin):
             raise RuntimeError('Must have the same number of actions as environments.')
         if not actions.is_contiguous() or actions.device != self.device:
             raise RuntimeError('rollout actions must be a contiguous device tensor')
-        envs = self._state()
         T, N = actions.shape
         if return_observations:
             m, n, shape = self._mode_info(self.observation_mode)
@@ -251,11 +252,38 @@ class SingleSnake(FastStepMixin):
             m, n, obs = _lib.OBS_NONE, 0, None
         reward = torch.empty((T, N), dtype=torch.float32, device=self.device)
         flags = torch.empty((3, T, N), dtype=torch.bool, device=self.device)
-        rc = _lib.call(self.device.index, _lib.lib().wurm_single_rollout, 
-            _lib.ptr(envs), _lib.ptr(actions), _lib.ACT_I64 if actions.dtype == torch.long else _lib.ACT_I32,
-            _lib.ptr(reward), _lib.ptr(flags[0]), _lib.ptr(flags[1]), _lib.ptr(flags[2]), _lib.ptr(obs), m, n,
-            _lib.i64(N), self.size, _lib.i64(T), _lib.u64(self.seed), _lib.u64(self._next_call(2 * T)),
-            _lib.i64(self.env_offset), None, None, _lib.stream_ptr(self.device.index))
+        dt = _lib.ACT_I64 if actions.dtype == torch.long else _lib.ACT_I32
+        # Grids of 12 x 12 and larger with a mirror (large batches; round 6): the launch reads the clock grids of the per-call
+        # step instead of the planes and keeps them current, lazy: without writing the planes (wurm_single_rollout_resident).
+        # Same protocol as step(): a postponed reset is applied first, a watched tensor is checked for in-place edits, nothing
+        # is "touched".  (9 x 9 has another mirror format and a launch that costs 11 us besides its steps: the library writes
+        # a lazy mirror out, rolls out on the planes and leaves the mirror stale — what _state() did on this side before.)
+        mirrored = False
+        if T > 0:
+            if self._fs.pending:
+                self._flush()
+            self._mirror_sync()
+            self._setup_mirror(*self._mode_info(self.observation_mode)[:2])
+            mirrored = bool(self._c.resident)
+        if mirrored:
+            c = self._c
+            envs = self._checked(self._envs)
+            self._fs.last_fresh = False
+            self._chk_void_at = self._fs.steps
+            valid = ctypes.c_int(c.resident_valid)
+            rc = _lib.call(self.device.index, _lib.lib().wurm_single_rollout_resident,
+                _lib.ptr(envs), _lib.ptr(actions), dt, _lib.ptr(reward), _lib.ptr(flags[0]), _lib.ptr(flags[1]),
+                _lib.ptr(flags[2]), _lib.ptr(obs), m, n, _lib.i64(N), self.size, _lib.i64(T), _lib.u64(self.seed),
+                _lib.u64(self._next_call(2 * T)), _lib.i64(self.env_offset), c.resident, ctypes.addressof(valid),
+                int(c.resident_lazy), _lib.stream_ptr(self.device.index))
+            c.resident_valid = valid.value if rc == _lib.OK else 0
+        else:
+            envs = self._state()
+            rc = _lib.call(self.device.index, _lib.lib().wurm_single_rollout,
+                _lib.ptr(envs), _lib.ptr(actions), dt,
+                _lib.ptr(reward), _lib.ptr(flags[0]), _lib.ptr(flags[1]), _lib.ptr(flags[2]), _lib.ptr(obs), m, n,
+                _lib.i64(N), self.size, _lib.i64(T), _lib.u64(self.seed), _lib.u64(self._next_call(2 * T)),
+                _lib.i64(self.env_offset), None, None, _lib.stream_ptr(self.device.index))
         _lib.check(rc, 'SingleSnake.rollout')
         self._done_all_false()  # every done env was reset
         return {'observations': obs, 'rewards': reward, 'dones': flags[0], 'self_collision': flags[1],
