@@ -43,10 +43,16 @@ ROLLOUT_ROWS = [
     (9, 70, 'partial_4', 0, 'rollout_generic_partial'), # 9 x 9 crops are outside the lane kernel's domain
     (9, 70, 'one_channel', 1 << 40, 'generic'),
     (9, 70, 'partial_4', 1 << 40, 'rollout_generic_partial'),
-    (10, 70, 'partial_2', 0, 'rollout_lean'),
-    (11, 70, 'none', 0, 'rollout_lean'),
+    (10, 70, 'partial_2', 0, 'lane_wide'),              # (round 6: 10 x 10 / 11 x 11, one env per lane on 128-bit masks)
+    (11, 70, 'none', 0, 'lane_wide'),
+    (11, 70, 'default', 0, 'lane_wide'),
+    (10, 70, 'one_channel', 0, 'lane_wide'),
+    (11, 70, 'partial_3', 0, 'lane_wide'),
+    (10, 70, 'partial_2', 1 << 40, 'rollout_lean'),
+    (11, 70, 'none', 1 << 40, 'rollout_lean'),
     (11, 70, 'partial_5', 0, 'rollout_generic_partial'),
-    (11, 70, 'default', 0, 'generic'),
+    (11, 70, 'default', 1 << 40, 'generic'),
+    (10, 70, 'raw', 0, 'generic'),                      # ('raw' / 'positions' / other crops stay with the one-env-per-wave kernels)
     (12, 40, 'partial_2', 0, 'grid_rollout'),
     (20, 12, 'default', 0, 'grid_rollout'),
 ]

@@ -14,9 +14,9 @@ constexpr int LANE_QCAP = 256;                 // entries of the non-zero queue 
 constexpr int LANE_QUEUE_BYTES = LANE_QCAP * 20; // u32 index + float4 per entry
 
 // vm: u32 [VW][EPW] bit set of body values (values 1 .. 32 * VW - 1 are in range), stat: u32 [EPW], hpos / fpos: u8 [EPW],
-// valpos: u8 [EPW][VS] cell of each body value, queue: LANE_QUEUE_BYTES of scratch (16-byte aligned).  All of the block's
+// valpos: u8 [EPW][VS] cell of each body value, queue: 20 * QCAP bytes of scratch (16-byte aligned).  All of the block's
 // EPW envs are present.
-template <int EPW, int C, int VW, int VS>
+template <int EPW, int C, int VW, int VS, int QCAP = LANE_QCAP>
 __device__ __forceinline__ void lane_load_block(const float *__restrict__ block, int lane, u32 *vm, u32 *stat,
                                                 unsigned char *hpos, unsigned char *fpos, unsigned char *valpos,
                                                 unsigned char *queue)
@@ -24,8 +24,8 @@ __device__ __forceinline__ void lane_load_block(const float *__restrict__ block,
     constexpr int C3 = 3 * C, N4 = EPW * C3 / 4, B4 = 16; // B4 loads in flight per lane
     static_assert((EPW * C3) % 4 == 0, "the block is a whole number of float4");
     const float4 *base4 = (const float4 *)block;
-    float4 *qv = (float4 *)queue;                    // [LANE_QCAP] the float4 that holds a non-zero element
-    u32 *qg = (u32 *)(queue + 16 * LANE_QCAP);       // [LANE_QCAP] its index in the block
+    float4 *qv = (float4 *)queue;                    // [QCAP] the float4 that holds a non-zero element
+    u32 *qg = (u32 *)(queue + 16 * QCAP);            // [QCAP] its index in the block
     int qn = 0; // wave-uniform
     auto drain = [&]() {
         wave_lds_sync();
@@ -71,7 +71,7 @@ __device__ __forceinline__ void lane_load_block(const float *__restrict__ block,
             const bool nz = g < N4 && any != 0;
             const u64 m = ballot(nz);
             if (m != 0) {
-                if (qn > LANE_QCAP - 64) drain();
+                if (qn > QCAP - 64) drain();
                 if (nz) {
                     const int slot = qn + rank_below(m);
                     qv[slot] = v[j];

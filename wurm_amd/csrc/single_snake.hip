@@ -1670,6 +1670,7 @@ static int pick_cpl(int S)
 //   step/reset/observe/fused | otherwise                                                              | R_GENERIC     one env per wave
 //   rollout          | snake, S >= 12, grid_rollout_eligible                                          | R_GRID_ROLLOUT
 //   rollout          | snake, S <= 11, N >= lane_rollout_min_envs, lane_rollout_eligible              | R_LANE_ROLLOUT lane_rollout.hpp (9 x 9)
+//   rollout          | snake, S = 10 / 11, N >= lane_rollout_min_envs, lane_wide_eligible              | R_LANE_WIDE   lane_wide.hpp (default, one_channel, partial_2 / 3, none)
 //   rollout          | snake, S == 9, both inject arrays, partial_n (n <= 3) or none                  | R_S9_INJ      rollout_s9_kernel<., true>
 //   rollout          | snake, S == 9, RNG mode, partial_n (n <= 3) or none                            | R_S9          rollout_s9_kernel
 //   rollout          | snake, S = 10 / 11, RNG mode, partial_n (n <= 3) or none                       | R_LEAN        rollout_lean_kernel
@@ -1678,7 +1679,7 @@ static int pick_cpl(int S)
 //   step / fused     | gridworld, RNG mode, no immediate reset, N >= lane_step_min_envs                | R_GRIDWORLD_LANE_STEP gridworld_lane.hip (+ generic for the rest)
 //   rollout          | otherwise                                                                      | R_GENERIC
 // (the resident 9 x 9 step, lane_resident.hpp, is chosen by fused_entry: it needs the caller's mirror)
-enum Route { R_GENERIC, R_GRID_STEP, R_LANE_STEP, R_GRID_ROLLOUT, R_LANE_ROLLOUT, R_S9_INJ, R_S9, R_LEAN, R_GENERIC_PARTIAL, R_GENERIC_NONE, R_LANE_RESIDENT, R_GRIDWORLD_LANE, R_GRIDWORLD_LANE_STEP };
+enum Route { R_GENERIC, R_GRID_STEP, R_LANE_STEP, R_GRID_ROLLOUT, R_LANE_ROLLOUT, R_LANE_WIDE, R_S9_INJ, R_S9, R_LEAN, R_GENERIC_PARTIAL, R_GENERIC_NONE, R_LANE_RESIDENT, R_GRIDWORLD_LANE, R_GRIDWORLD_LANE_STEP };
 // (wurm_single_last_route: the route of the CALLING THREAD's last launch — a diagnostic the tests and bench.py name a launch by; no
 // state that a later call depends on.  One object for both translation units of this file: see WURM_TU_GRID below.)
 extern thread_local Route last_route;
@@ -1693,6 +1694,7 @@ static const char *route_name(Route r)
     case R_LANE_STEP: return "lane_step";
     case R_GRID_ROLLOUT: return "grid_rollout";
     case R_LANE_ROLLOUT: return "lane_rollout";
+    case R_LANE_WIDE: return "lane_wide";
     case R_S9_INJ: return "rollout_s9_injected";
     case R_S9: return "rollout_s9";
     case R_LEAN: return "rollout_lean";
@@ -1716,6 +1718,7 @@ static Route route_of(Kind kind, bool snake, int cpl, const StepArgs &p)
     if (kind != K_ROLLOUT || !snake) return R_GENERIC;
     if (cpl >= 4) return grid_rollout_eligible(p) ? R_GRID_ROLLOUT : R_GENERIC;
     if (p.N >= opt.lane_rollout_min_envs && lane_rollout_eligible(p)) return R_LANE_ROLLOUT;
+    if (p.N >= opt.lane_rollout_min_envs && lane_wide_eligible(p)) return R_LANE_WIDE;
     const bool rng_mode = p.inject_food == nullptr && p.inject_reset == nullptr;
     const bool injected = p.inject_food != nullptr && p.inject_reset != nullptr;
     const bool small_crop_or_none = (p.obs_mode == WURM_OBS_PARTIAL && p.obs_n <= 3) || p.obs_mode == WURM_OBS_NONE;
@@ -1756,6 +1759,9 @@ static hipError_t launch_one(Kind kind, const StepArgs &p, dim3 grid, dim3 block
         break;
     case R_LANE_ROLLOUT:
         if constexpr (SNAKE && CPL == 2) return launch_lane_rollout(p, st);
+        break;
+    case R_LANE_WIDE:
+        if constexpr (SNAKE && CPL == 2) return launch_lane_wide(p, st);
         break;
     case R_GRIDWORLD_LANE:
         if constexpr (!SNAKE) {

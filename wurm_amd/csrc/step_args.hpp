@@ -75,6 +75,10 @@ hipError_t launch_grid_step(const StepArgs &p, hipStream_t stream);
 bool lane_rollout_eligible(const StepArgs &p);
 hipError_t launch_lane_rollout(const StepArgs &p, hipStream_t stream);
 
+// ... and for 10 x 10 / 11 x 11 (lane_wide.hip / lane_wide.hpp: 128-bit occupancy masks)
+bool lane_wide_eligible(const StepArgs &p);
+hipError_t launch_lane_wide(const StepArgs &p, hipStream_t stream);
+
 // per-call step of large 9 x 9 batches on a caller-owned compact mirror of the state (lane_resident.hpp, in lane_rollout.hip)
 bool lane_resident_shape(int S, int obs_mode, int obs_n);
 bool lane_resident_eligible(const StepArgs &p);
