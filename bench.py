@@ -715,6 +715,14 @@ def extra_measurements(device):
                 lambda c: (c, 65536), 4, 32, 6, f'SingleSnake 65 536 x 9 x 9 with observation_mode={mode!r}, fused rollout, 32 '
                 'batch-steps per launch', traffic_key=f'rollout_65536x9_{mode}_chunk32')
 
+    # ---- the sizes between the 9 x 9 lane kernels and the clock grids (round 6: lane_wide.hpp, one env per lane on 128-bit masks)
+    rollout('rollout_65536x10_partial_2', lambda: SingleSnake(65536, 10, observation_mode='partial_2', device=device, seed=0),
+            lambda c: (c, 65536), 4, 32, 6, 'SingleSnake 65 536 x 10 x 10 partial_2, fused rollout, 32 batch-steps per launch',
+            traffic_key='rollout_65536x10_partial_2_chunk32')
+    rollout('rollout_65536x11_default', lambda: SingleSnake(65536, 11, observation_mode='default', device=device, seed=0),
+            lambda c: (c, 65536), 4, 32, 6, 'SingleSnake 65 536 x 11 x 11 default (RGB), fused rollout, 32 batch-steps per launch',
+            traffic_key='rollout_65536x11_default_chunk32')
+
     # ---- cfg4 (BASELINE configs[3]): MultiSnake 4096 x 25 x 25, 4 agents, constructor defaults ('full' observations)
     per_call('per_call_cfg4_no_mirror', lambda: MultiSnake(4096, 4, 25, device=device, seed=0, resident_mirror=False), a4, d_all, T4,
              'cfg4 per call with the mirror switched off: the step reads foods / heads / bodies (92 MB of fp32) every call',
@@ -868,6 +876,8 @@ def key_numbers(line):
         'cfg5_rollout_ms_p10_p50_p90': [g('rollout_cfg5_alloc_spread', f) for f in ('ms_p10', 'ms_p50', 'ms_p90')],
         'cfg3_rollout_ms_p10_p50_p90': [g('rollout_cfg3_alloc_spread', f) for f in ('ms_p10', 'ms_p50', 'ms_p90')],
         'multi_512x25_k4_train_per_call_us': g('per_call_multi_512x25_k4_train_partial5', 'us'),
+        's10_partial2_eps': g('rollout_65536x10_partial_2'), 's10_partial2_frac_real': g('rollout_65536x10_partial_2', 'frac_real'),
+        's11_default_eps': g('rollout_65536x11_default'), 's11_default_frac_real': g('rollout_65536x11_default', 'frac_real'),
         'box_hbm_fill_TBps': ex.get('host_calibration_after', {}).get('hbm_fill_2GB_TBps'),
     }
 

@@ -233,12 +233,17 @@ def fuzz_lane(rng):
     # entry point)
     mode = ['partial_2', 'partial_2', 'none', 'one_channel', 'one_channel', 'default', 'default', 'positions', 'partial_0',
             'partial_1', 'partial_3', 'partial_3', 'raw', 'raw', 'partial_4'][rng.randint(15)]
+    # (round 6: a third of the cases on 10 x 10 / 11 x 11 — lane_wide.hpp: 8 / 16 / 32 envs per wave; 'default', 'one_channel',
+    # 'partial_2', 'partial_3', none through its bit planes, every other mode through the one-env-per-wave kernels)
+    S = int(rng.choice([9, 9, 10, 11]))
+    if S != 9:
+        epw = int(rng.choice([8, 16, 32]))
+        N = int(rng.choice([1, 3, epw - 1, epw, epw + 1, 2 * epw + 5, 3 * epw, 200]))
     seed, off = int(rng.randint(1 << 30)), int(rng.randint(1 << 40))
-    desc = f'lane epw={epw} N={N} mode={mode} seed={seed} off={off}'
+    desc = f'lane S={S} epw={epw} N={N} mode={mode} seed={seed} off={off}'
     if os.environ.get('WURM_FUZZ_VERBOSE'):
         print('start:', desc, flush=True)
     o, h = OracleBackend(seed, off), HipBackend(seed, off)
-    S = 9
     eo, eh = np.zeros((N, 3, S, S), np.float32), np.zeros((N, 3, S, S), np.float32)
     o.single_reset(eo, np.ones(N), 'none'); h.single_reset(eh, np.ones(N), 'none')
     o.call = h.call = int(rng.randint(1 << 50))
@@ -269,7 +274,7 @@ def fuzz_lane(rng):
                 for e in rng.randint(0, N, size=min(N, 3)):
                     kind = rng.randint(3)
                     if kind == 0:
-                        eo[e, 0, rng.randint(1, 8), rng.randint(1, 8)] = 1
+                        eo[e, 0, rng.randint(1, S - 1), rng.randint(1, S - 1)] = 1
                     elif kind == 1:
                         eo[e, 1] = 0
                     else:

@@ -74,6 +74,9 @@ detail = {
     'resident_step_65536x9_default_reset_obs': traffic('void wurm::lane_resident_step_kernel<32, 2, -3, true>', 131072),
     'rollout_65536x9_raw_chunk32': traffic('void wurm::lane_rollout_kernel<32, -5, false>', 131072),
     'rollout_65536x9_partial_3_chunk32': traffic('void wurm::lane_rollout_kernel<32, -4, false>', 131072),
+    # round 6: 10 x 10 / 11 x 11 one env per lane (lane_wide.hpp), 32 envs per wave at this batch size
+    'rollout_65536x10_partial_2_chunk32': traffic('void wurm::lane_wide_rollout_kernel<32, 10, 4, 5, false>', 131072),
+    'rollout_65536x11_default_chunk32': traffic('void wurm::lane_wide_rollout_kernel<32, 11, -3, 0, false>', 131072),
     # round 5: SimpleGridworld one env per lane (32 envs per wave at this batch size): zero fill + two floats per env
     # (round 6: 64 envs per wave at this batch size, the run composed as a bit string)
     'rollout_65536x9_gridworld_default_chunk16': traffic('void wurm::(anonymous namespace)::gridworld_lane_rollout_kernel<0, 64>', 65536),

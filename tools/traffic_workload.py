@@ -128,6 +128,14 @@ for mode in ('raw', 'partial_3'):
         env.rollout(actions[c:c + 32])
     torch.cuda.synchronize()
     del env, actions
+# measured (round 6): 10 x 10 'partial_2' and 11 x 11 'default' through the one-env-per-lane kernel of those sizes (lane_wide.hpp), 32 steps per launch
+for S, mode in ((10, 'partial_2'), (11, 'default')):
+    env = SingleSnake(num_envs=65536, size=S, observation_mode=mode, device=dev, seed=0)
+    actions = torch.randint(4, (32 * 5, 65536), device=dev, dtype=torch.int64)
+    for c in range(0, 32 * 5, 32):
+        env.rollout(actions[c:c + 32])
+    torch.cuda.synchronize()
+    del env, actions
 # measured (round 5): SimpleGridworld 65 536 x 9 x 9 through the one-env-per-lane rollout (gridworld_lane.hip), 16 steps per launch
 from wurm_amd.envs import SimpleGridworld  # noqa: E402
 for mode in ('default', 'raw'):
