@@ -7,6 +7,11 @@ import pytest
 # process or in a spawned worker that inherits the environment) must not drop __pycache__ there.
 sys.dont_write_bytecode = True
 os.environ['PYTHONDONTWRITEBYTECODE'] = '1'
+# The suite keeps the LDS clock-grid rollout covered at EVERY size it serves (12 x 12 and larger), as before round 6; which
+# sizes it takes by default depends on the observation mode (grid_rollout.hip: grid_rollout_eligible) and is tested, with the
+# parity of the kernels that take the rest, in tests/test_grid_rollout_routing.py under WURM_GRID_ROLLOUT_MIN_SIZE = -1.
+# (Read once, when the library is loaded: wurm_amd/csrc/options.hip.)
+os.environ.setdefault('WURM_GRID_ROLLOUT_MIN_SIZE', '12')
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:

@@ -62,7 +62,13 @@ def fuzz_single(rng):
     else:
         a = rng.randint(0, 4, (T, N)).astype(dtype)
         ao, ah = a.copy(), a.copy()
-        ro, rh = o.single_rollout(eo, ao, mode), h.single_rollout(eh, ah, mode)
+        # (round 6: from which size on the clock-grid rollout serves a launch depends on the observation mode — half of the cases
+        # with the shipped thresholds, half with the kernel forced from 12 x 12 on)
+        old = _lib.set_option('WURM_GRID_ROLLOUT_MIN_SIZE', 12 if rng.rand() < 0.5 else -1)
+        try:
+            ro, rh = o.single_rollout(eo, ao, mode), h.single_rollout(eh, ah, mode)
+        finally:
+            _lib.set_option('WURM_GRID_ROLLOUT_MIN_SIZE', old)
         for k in ro:
             same(ro[k], rh[k], f'{desc} rollout {k}')
         same(ao, ah, desc + ' rollout actions'); same(eo, eh, desc + ' rollout state')

@@ -827,9 +827,17 @@ __global__ __launch_bounds__(256) void grid_flush_kernel(StepArgs p)
 
 } // namespace
 
+// From which grid size on the clock-grid rollout beats the one-env-per-wave kernels it replaced depends on how much of a
+// step is observation: measured at 65 536 and 8 192 envs, 16 steps per launch (tools/grid_vs_generic_probe.py,
+// profiles/r06_grid_vs_generic.txt; ratio = clock grid / one env per wave): 'default' 1.09-1.38 at 12 / 13, 0.78-0.97 from 14
+// on; 'partial_2' 1.01-1.21 up to 16, 0.78-0.82 at 20; 'one_channel' 1.31-1.75 up to 20, 1.03-1.06 at 24.
+// WURM_GRID_ROLLOUT_MIN_SIZE >= 12 forces one threshold for every mode (tests keep the kernel covered at every size).
 bool grid_rollout_eligible(const StepArgs &p)
 {
-    return p.S >= 12 && p.S <= 64 && p.T <= (1ll << 26);
+    int min_size = (int)opt.grid_rollout_min_size;
+    if (min_size < 12)
+        min_size = p.obs_mode == WURM_OBS_ONE_CHANNEL ? 26 : (p.obs_mode == WURM_OBS_DEFAULT || p.obs_mode == WURM_OBS_RAW) ? 14 : 18;
+    return p.S >= min_size && p.S <= 64 && p.T <= (1ll << 26);
 }
 
 bool grid_step_eligible(const StepArgs &p) { return p.S >= 12 && p.S <= 64; }

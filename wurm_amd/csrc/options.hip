@@ -10,7 +10,7 @@
 
 namespace wurm {
 
-constexpr Options DEFAULTS = {1ll << 20, 12288, 6144, -1, -1, -1, 12, 0, 2048, 0, -1, 0, 0, 1, -1};
+constexpr Options DEFAULTS = {1ll << 20, 12288, 6144, -1, -1, -1, 12, 0, 2048, 0, -1, 0, 0, 1, -1, -1};
 // PROCESS-WIDE: every env object and every thread of the process sees the same knobs (documented in include/wurm_hip.h);
 // the launch counter is a diagnostic that concurrent launchers may bump at the same time, hence atomic.
 Options opt = DEFAULTS;
@@ -39,6 +39,7 @@ const Entry table[] = {
     {"WURM_GRID_ROTATE", &Options::grid_rotate},
     {"WURM_MULTI_SHAPE_KERNELS", &Options::multi_shape_kernels},
     {"WURM_GRIDWORLD_LANE_EPW", &Options::gridworld_lane_epw},
+    {"WURM_GRID_ROLLOUT_MIN_SIZE", &Options::grid_rollout_min_size},
 };
 
 const Entry *find(const char *name)

@@ -22,6 +22,7 @@ struct Options {
     long long grid_rotate;           // WURM_GRID_ROTATE           clock-grid kernels: observation rows start at an env-dependent row (0 = off; 1: env % rows, k >= 2: (env % k) * rows / k; measured no better)
     long long multi_shape_kernels;   // WURM_MULTI_SHAPE_KERNELS   MultiSnake: kernels with K, S and the crop radius compiled in for the reference's experiment shapes (1; 0 = the generic kernels)
     long long gridworld_lane_epw;    // WURM_GRIDWORLD_LANE_EPW    SimpleGridworld lane rollout, image modes: envs per wave (4..64; -1 = by batch size)
+    long long grid_rollout_min_size; // WURM_GRID_ROLLOUT_MIN_SIZE SingleSnake rollouts on LDS clock grids from this grid size on (-1 = by observation mode: 14 / 18 / 26; 12 = every size they serve)
 };
 
 extern Options opt;
