@@ -48,11 +48,12 @@ ROLLOUT_ROWS = [
     (11, 70, 'default', 0, 'lane_wide'),
     (10, 70, 'one_channel', 0, 'lane_wide'),
     (11, 70, 'partial_3', 0, 'lane_wide'),
+    (11, 70, 'positions', 0, 'lane_wide'),
     (10, 70, 'partial_2', 1 << 40, 'rollout_lean'),
     (11, 70, 'none', 1 << 40, 'rollout_lean'),
     (11, 70, 'partial_5', 0, 'rollout_generic_partial'),
     (11, 70, 'default', 1 << 40, 'generic'),
-    (10, 70, 'raw', 0, 'generic'),                      # ('raw' / 'positions' / other crops stay with the one-env-per-wave kernels)
+    (10, 70, 'raw', 0, 'generic'),                      # ('raw' and other crops stay with the one-env-per-wave kernels)
     (12, 40, 'partial_2', 0, 'grid_rollout'),           # (the suite runs with WURM_GRID_ROLLOUT_MIN_SIZE = 12: tests/conftest.py; the
     (20, 12, 'default', 0, 'grid_rollout'),             #  shipped thresholds by observation mode: tests/test_grid_rollout_routing.py)
 ]

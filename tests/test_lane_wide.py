@@ -1,6 +1,7 @@
 """GPU parity for the one-env-per-LANE rollout of 10 x 10 and 11 x 11 SingleSnake grids (`lane_wide_rollout_kernel`,
 wurm_amd/csrc/lane_wide.hpp): a 128-bit occupancy mask over the whole grid, the body as a 192-bit queue of moves, observations
-('default', 'one_channel', 'partial_2', 'partial_3', none) as bit planes expanded through a table.  Compared with the CPU oracle
+('default', 'one_channel', 'partial_2', 'partial_3', none) as bit planes expanded through a table ('positions' straight
+from the pair lanes).  Compared with the CPU oracle
 (which knows none of that) on every output of every step: every envs-per-wave setting, ragged batches, tape lengths around the
 chunk and the action batch, hostile action values, long snakes (past 64 segments: both words of the mask, all three of the
 queue), start states that must go to the generic path inside the launch, chained launches, default routing from 6 144 envs
@@ -14,7 +15,7 @@ from tests.backends import OracleBackend
 from tests.test_lane_rollout import _compare_rollout, _fresh, _route, _same, lane_path
 
 pytestmark = pytest.mark.gpu
-MODES = ['partial_2', 'partial_3', 'default', 'one_channel', 'none']
+MODES = ['partial_2', 'partial_3', 'default', 'one_channel', 'positions', 'none']
 
 
 @pytest.fixture(scope='module')
@@ -224,7 +225,7 @@ def test_large_batches_default_routing(hip, S, N, mode):
 def test_modes_the_lane_kernel_does_not_serve_keep_their_kernels(hip):
     N, T = 6400, 5
     rng = np.random.RandomState(1)
-    for S, mode in ((10, 'raw'), (11, 'positions'), (10, 'partial_4'), (11, 'partial_1')):
+    for S, mode in ((10, 'raw'), (11, 'raw'), (10, 'partial_4'), (11, 'partial_1')):
         o, h = OracleBackend(seed=2), hip(seed=2)
         envs = _fresh(o, N, S)
         o.call = h.call = 9
@@ -242,6 +243,6 @@ def test_reference_tapes_injected_through_the_lane_kernel(hip):
         assert _route() == 'lane_wide'
         for name in ('single_s10_raw', 'single_s11_partial3_i32'):
             tape = replay.load(name)
-            for mode in ('partial_2', 'default', 'one_channel', 'partial_3'):
+            for mode in ('partial_2', 'default', 'one_channel', 'partial_3', 'positions'):
                 replay.replay_single_rollout_vs_oracle(hip(), OracleBackend(), tape, mode)
                 assert _route() == 'lane_wide'

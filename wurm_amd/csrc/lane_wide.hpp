@@ -18,7 +18,7 @@
 //       (1.5), ring (-1); 'partial_n', n = 2 / 3 (:166-193): the same colours on the (2n+1)^2 window around the head, rows
 //       cut out of the 128-bit mask — OR-ed into the chunk's flat bit strings in LDS;
 //   (4) all lanes: aligned nibbles of the flat strings -> four floats through a 256-entry table -> one 16-byte store.
-// Domain: S = 10 / 11; observations 'default', 'one_channel', 'partial_2', 'partial_3', none; snakes whose body values are
+// Domain: S = 10 / 11; observations 'default', 'one_channel', 'partial_2', 'partial_3', 'positions', none; snakes whose body values are
 // exactly 1..L once each on edge-adjacent interior cells with the head on L and at most one food on a free interior cell
 // (closed under step + reset).  Any other env is left alone and rolled out by rollout_generic — the one-env-per-wave code —
 // at the end of the same launch.  Every other observation mode stays with the one-env-per-wave kernels.
@@ -54,7 +54,7 @@ struct LwGeo {
 
 // floats per env of the observation / interleaved bit planes of its flat strings
 template <int S, int OBSK, int NW>
-constexpr int lw_elems() { return OBSK == LW_OBS_GRID1 ? S * S : OBSK == LW_OBS_GRID3 ? 3 * S * S : OBSK == WURM_OBS_PARTIAL ? 3 * NW * NW : 0; }
+constexpr int lw_elems() { return OBSK == LW_OBS_GRID1 ? S * S : OBSK == LW_OBS_GRID3 ? 3 * S * S : OBSK == WURM_OBS_PARTIAL ? 3 * NW * NW : 0; } // (bit-plane modes)
 template <int OBSK>
 constexpr int lw_planes() { return OBSK == LW_OBS_GRID1 ? 4 : 2; }
 
@@ -419,8 +419,10 @@ __global__ __launch_bounds__(256) void lane_wide_rollout_kernel(StepArgs p)
     typedef LwGeo<S> G;
     static_assert(EPW == 8 || EPW == 16 || EPW == 32, "envs per wave");
     static_assert(S == 10 || S == 11, "grid size");
-    static_assert(OBSK == WURM_OBS_PARTIAL || OBSK == WURM_OBS_NONE || OBSK == LW_OBS_GRID1 || OBSK == LW_OBS_GRID3, "observation");
-    constexpr bool OBS = OBSK != WURM_OBS_NONE;
+    static_assert(OBSK == WURM_OBS_PARTIAL || OBSK == WURM_OBS_NONE || OBSK == LW_OBS_GRID1 || OBSK == LW_OBS_GRID3 ||
+                  OBSK == WURM_OBS_POSITIONS, "observation");
+    constexpr bool OBS = OBSK != WURM_OBS_NONE && OBSK != WURM_OBS_POSITIONS; // through bit planes
+    constexpr bool POS = OBSK == WURM_OBS_POSITIONS;                          // four floats per pair, straight from its lane
     constexpr int C = G::C, C3 = G::C3, E = Lds::E;
     constexpr int TC = 64 / EPW;                  // steps per chunk
     constexpr int LOG_EPW = EPW == 8 ? 3 : EPW == 16 ? 4 : 5;
@@ -567,6 +569,13 @@ __global__ __launch_bounds__(256) void lane_wide_rollout_kernel(StepArgs p)
                     const int cp = (int)(rz & 127u), ai = (int)((rz >> 8) & 3u);
                     lw_planes_of<S, OBSK, NW>(bits, wint, lane, r0, r1, cp + lw_dcell<S>(ai), (int)(rw & 0xffu) - 1);
                 }
+                if (POS && valid) { // head y, x, food y, x (:153-163: the first maximum of an empty channel is cell 0)
+                    const int cp = (int)(rz & 127u), ai = (int)((rz >> 8) & 3u), hc = cp + lw_dcell<S>(ai);
+                    const int fc = max((int)(rw & 0xffu) - 1, 0);
+                    const int hy = hc / S, fy = fc / S;
+                    float *o4 = p.obs + oi * 4;
+                    o4[0] = (float)hy; o4[1] = (float)(hc - hy * S); o4[2] = (float)fy; o4[3] = (float)(fc - fy * S);
+                }
             }
 
             // (4) all lanes: the chunk's observations, 16 bytes per lane and instruction
@@ -644,7 +653,8 @@ bool lane_wide_eligible(const StepArgs &p)
     if ((p.S != 10 && p.S != 11) || p.only_flagged) return false;
     if ((p.inject_food == nullptr) != (p.inject_reset == nullptr)) return false;
     if (p.obs_mode == WURM_OBS_PARTIAL) return p.obs_n == 2 || p.obs_n == 3;
-    return p.obs_mode == WURM_OBS_NONE || p.obs_mode == WURM_OBS_DEFAULT || p.obs_mode == WURM_OBS_ONE_CHANNEL;
+    return p.obs_mode == WURM_OBS_NONE || p.obs_mode == WURM_OBS_DEFAULT || p.obs_mode == WURM_OBS_ONE_CHANNEL ||
+           p.obs_mode == WURM_OBS_POSITIONS;
 }
 
 template <int S, int OBSK, int NW>
@@ -677,6 +687,7 @@ static hipError_t launch_lane_wide_size(const StepArgs &p, hipStream_t stream)
     if (p.obs_mode == WURM_OBS_PARTIAL && p.obs_n == 2) return launch_lane_wide_obs<S, WURM_OBS_PARTIAL, 5>(p, stream);
     if (p.obs_mode == WURM_OBS_PARTIAL && p.obs_n == 3) return launch_lane_wide_obs<S, WURM_OBS_PARTIAL, 7>(p, stream);
     if (p.obs_mode == WURM_OBS_ONE_CHANNEL) return launch_lane_wide_obs<S, LW_OBS_GRID1, 0>(p, stream);
+    if (p.obs_mode == WURM_OBS_POSITIONS) return launch_lane_wide_obs<S, WURM_OBS_POSITIONS, 0>(p, stream);
     return launch_lane_wide_obs<S, LW_OBS_GRID3, 0>(p, stream);
 }
 

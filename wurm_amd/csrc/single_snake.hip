@@ -1670,7 +1670,7 @@ static int pick_cpl(int S)
 //   step/reset/observe/fused | otherwise                                                              | R_GENERIC     one env per wave
 //   rollout          | snake, S >= 12, grid_rollout_eligible                                          | R_GRID_ROLLOUT
 //   rollout          | snake, S <= 11, N >= lane_rollout_min_envs, lane_rollout_eligible              | R_LANE_ROLLOUT lane_rollout.hpp (9 x 9)
-//   rollout          | snake, S = 10 / 11, N >= lane_rollout_min_envs, lane_wide_eligible              | R_LANE_WIDE   lane_wide.hpp (default, one_channel, partial_2 / 3, none)
+//   rollout          | snake, S = 10 / 11, N >= lane_rollout_min_envs, lane_wide_eligible              | R_LANE_WIDE   lane_wide.hpp (default, one_channel, partial_2 / 3, positions, none)
 //   rollout          | snake, S == 9, both inject arrays, partial_n (n <= 3) or none                  | R_S9_INJ      rollout_s9_kernel<., true>
 //   rollout          | snake, S == 9, RNG mode, partial_n (n <= 3) or none                            | R_S9          rollout_s9_kernel
 //   rollout          | snake, S = 10 / 11, RNG mode, partial_n (n <= 3) or none                       | R_LEAN        rollout_lean_kernel
