@@ -818,6 +818,13 @@ def extra_measurements(device):
                  f"65 536 x 9 x 9 with observation_mode={mode!r} ('one_channel' is the reference's constructor default) through "
                  '`env.step(a); env.reset(d)` (resident mirror, bit-plane writer)', reset_kw={},
                  traffic_key=f'resident_step_65536x9_{mode}_reset_obs')
+    per_call('per_call_cfg3_default_no_reset_obs', lambda: SingleSnake(N, SIZE, observation_mode='default', device=device, seed=0),
+             a1, same, T, "65 536 x 9 x 9 'default' through `env.step(a); env.reset(d, return_observations=False)` (round 6: its 16-byte "
+             'stores had come out of the compiler as four dword stores each — tools/check_split_stores.py)')
+    # ---- the sizes between 9 x 9 and the clock grids on THEIR mirror (round 6: lane_wide_resident.hpp, 48 bytes per env)
+    for S_w, mode_w in ((10, 'partial_2'), (11, 'default')):
+        per_call(f'per_call_65536x{S_w}_{mode_w}', lambda: SingleSnake(N, S_w, observation_mode=mode_w, device=device, seed=0), a1, same, T,
+                 f'65 536 x {S_w} x {S_w} {mode_w} through `env.step(a); env.reset(d)` (resident mirror, lazy)', reset_kw={})
     N, T = 512, 4000
     acts = torch.randint(4, (T + 10, N), device=device, dtype=torch.int64)
     per_call('per_call_512_no_reset_obs', lambda: SingleSnake(N, SIZE, observation_mode=OBS_MODE, device=device, seed=0),
@@ -876,6 +883,8 @@ def key_numbers(line):
         'cfg5_rollout_ms_p10_p50_p90': [g('rollout_cfg5_alloc_spread', f) for f in ('ms_p10', 'ms_p50', 'ms_p90')],
         'cfg3_rollout_ms_p10_p50_p90': [g('rollout_cfg3_alloc_spread', f) for f in ('ms_p10', 'ms_p50', 'ms_p90')],
         'multi_512x25_k4_train_per_call_us': g('per_call_multi_512x25_k4_train_partial5', 'us'),
+        'per_call_cfg3_default_no_reset_obs_us': g('per_call_cfg3_default_no_reset_obs', 'us'),
+        'per_call_s10_partial2_us': g('per_call_65536x10_partial_2', 'us'), 'per_call_s11_default_us': g('per_call_65536x11_default', 'us'),
         's10_partial2_eps': g('rollout_65536x10_partial_2'), 's10_partial2_frac_real': g('rollout_65536x10_partial_2', 'frac_real'),
         's11_default_eps': g('rollout_65536x11_default'), 's11_default_frac_real': g('rollout_65536x11_default', 'frac_real'),
         'box_hbm_fill_TBps': ex.get('host_calibration_after', {}).get('hbm_fill_2GB_TBps'),

@@ -74,7 +74,7 @@ int wurm_reset_option(const char *name);
 int64_t wurm_launch_count(void);
 
 /* Name of the row of the dispatch table (wurm_amd/csrc/single_snake.hip: route_of) that served the last SingleSnake /
- * SimpleGridworld launch of this process: "generic", "grid_step", "lane_step", "lane_resident", "grid_rollout",
+ * SimpleGridworld launch of this process: "generic", "grid_step", "lane_step", "lane_resident", "lane_wide_resident", "lane_wide", "grid_rollout",
  * "lane_rollout", "rollout_s9", "rollout_s9_injected", "rollout_lean", "rollout_generic_partial", "rollout_generic_none".
  * Diagnostic only (bench.py and tests/test_dispatch_table.py name a launch by it); a static string. */
 const char *wurm_single_last_route(void);
@@ -187,8 +187,11 @@ int wurm_single_step_reset(const wurm_single_call *c, void *stream);
 
 /* Size in bytes of the mirror of wurm_single_call.resident for this batch, 0 if the shape is not served by it (then pass
  * resident = NULL).  Served: size 9 with observation none or partial_2 from 4096 envs on (32 bytes per env,
- * wurm_amd/csrc/lane_resident.hpp), and 12 <= size <= 64 with any observation from 2^20 cells in the batch on (the 16-bit
- * clock grid of the LDS step + 48 bytes per env, grid_rollout.hip); WURM_RESIDENT_MIN_ENVS replaces both thresholds by
+ * wurm_amd/csrc/lane_resident.hpp), sizes 10 and 11 with observation default, one_channel, partial_2, partial_3, positions or
+ * none from 4096 envs on (48 bytes per env, lane_wide_resident.hpp; maintained by calls with resident_lazy != 0 only: a call with
+ * resident_lazy == 0 steps envs without the mirror and leaves it stale — wurm_single_step_slot clears resident_valid, a caller
+ * of wurm_single_step_reset does so itself), and 12 <= size <= 64 with any observation from 2^20 cells in the batch on (the 16-bit
+ * clock grid of the LDS step + 48 bytes per env, grid_rollout.hip); WURM_RESIDENT_MIN_ENVS replaces the thresholds by
  * a number of envs.  With the mirror the per-call step of a large batch does not read the (N,3,S,S) state at all.  Protocol: a call of
  * wurm_single_step_reset with `resident` given leaves the mirror current unless it had inject_* / post_reset set;
  * wurm_single_step_slot maintains c->resident_valid itself after each call, the caller only CLEARS it whenever anything

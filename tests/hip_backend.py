@@ -116,7 +116,7 @@ class HipBackend(object):
         c.actions_dtype, c.obs_mode, c.obs_n, c.size, c.post_reset = self._act(a), m, n, S, int(bool(post_reset))
         c.start_y, c.start_x = (-1, -1) if grid is None else grid
         if resident is not None:
-            nbytes = 32 * N if S == 9 else N * ((((S * S + 255) >> 8) * 512) + 48)  # (lane_resident.hpp / grid_rollout.hip)
+            nbytes = 32 * N if S == 9 else 48 * N if S in (10, 11) else N * ((((S * S + 255) >> 8) * 512) + 48)  # (lane_resident.hpp / lane_wide_resident.hpp / grid_rollout.hip)
             if grid is not None:
                 nbytes = 16 + 4 * N                                                 # (gridworld_lane.hip: header + records)
             if resident.get('buf') is None or resident['buf'].numel() != nbytes:
@@ -132,6 +132,8 @@ class HipBackend(object):
             served = int(self.lib.wurm_single_resident_size(_lib.i64(N), S, m, n)) > 0 if grid is None else \
                 (int(self.lib.wurm_grid_resident_size(_lib.i64(N), S, m)) > 0 and
                  N >= int(self.lib.wurm_get_option(b'WURM_LANE_STEP_MIN_ENVS')))
+            if grid is None and S in (10, 11) and not lazy:
+                served = False   # (include/wurm_hip.h: the mirror of 10 x 10 / 11 x 11 is maintained by lazy calls only)
             was = int(resident.get('valid', 0))
             resident['valid'] = int(inject_food is None and inject_reset is None and inject_pre_reset is None and
                                     not post_reset and served)

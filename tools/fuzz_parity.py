@@ -131,11 +131,14 @@ def fuzz_resident(rng):
     batch sizes around the envs-per-wave settings, deferred resets with and without the reset observation, iterations
     without any reset (finished envs stepped again), hostile actions, hand-edited states and calls that cannot use the
     mirror (post_reset) in between; `envs` compared whenever the lazy form writes them out."""
-    S = int(rng.choice([9, 9, 9, 12, 14, 20, 25, 36]))
+    S = int(rng.choice([9, 9, 9, 10, 11, 12, 14, 20, 25, 36]))
     if S == 9:    # lane_resident.hpp: 32 bytes per env
         N = int(rng.choice([1, 3, 15, 16, 17, 31, 33, 63, 64, 65, 100, 129, 200, 257]))
         mode = ['partial_2', 'partial_2', 'none', 'one_channel', 'one_channel', 'default', 'positions', 'partial_0', 'partial_1',
                 'raw', 'raw', 'partial_3', 'partial_3'][rng.randint(13)]
+    elif S <= 11:  # lane_wide_resident.hpp (round 6): 48 bytes per env, kept by lazy calls only; the modes it does not serve
+        N = int(rng.choice([1, 3, 15, 16, 17, 31, 33, 63, 64, 65, 100, 129, 200]))   # ('raw', 'partial_1'): no mirror at all
+        mode = ['partial_2', 'partial_2', 'none', 'one_channel', 'default', 'default', 'positions', 'partial_3', 'raw', 'partial_1'][rng.randint(10)]
     else:         # grid_rollout.hip: the clock grid + a record per env, every observation mode
         N = int(rng.randint(1, 24))
         mode = ['default', 'raw', 'one_channel', 'positions', f'partial_{rng.randint(1, 7)}', 'none'][rng.randint(6)]

@@ -8,11 +8,9 @@ from wurm_amd.envs import SingleSnake
 from wurm_amd import _lib
 dev = torch.device('cuda:0')
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
-T = 32
-for mode in ('raw', 'partial_3', 'default', 'partial_2'):
+T = int(sys.argv[2]) if len(sys.argv) > 2 else 32
+for mode in ('raw', 'partial_3', 'default', 'one_channel', 'partial_2'):
     for knob, epw in ((0, None), (0, 16), (0, 32), (0, 64), (1 << 40, None)):
-        if mode in ('default', 'partial_2') and epw is not None:
-            continue
         with _lib.knobs(WURM_LANE_ROLLOUT_MIN_ENVS=knob, WURM_LANE_ROLLOUT_EPW=epw):
             env = SingleSnake(N, 9, observation_mode=mode, device=dev, seed=0)
             acts = torch.randint(4, (7, T, N), device=dev)

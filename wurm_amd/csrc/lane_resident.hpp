@@ -454,12 +454,15 @@ __global__ __launch_bounds__(256) void lane_resident_step_kernel(ResidentArgs a)
             }
             wave_lds_sync();
             constexpr int GSG = EPW * GE / 4;   // 16-byte groups of one observation of the wave's envs
-            char *ob0 = (char *)(p.obs + env0 * GE), *ob1 = NW == 2 ? (char *)(p.obs_after + env0 * GE) : nullptr;
+            // (float4 pointers indexed by group — through `char * + 16 j` the NW = 1 instantiations of 'default', 'raw' and
+            // 'partial_3' came out with every 16-byte store split into four dword stores: 4.0 store instructions per env
+            // instead of 1.1 and 25.7 us per call of 65 536 envs instead of 15 — tools/percall_size_only.py under --pmc)
+            float4 *ob0 = (float4 *)(p.obs + env0 * GE), *ob1 = NW == 2 ? (float4 *)(p.obs_after + env0 * GE) : nullptr;
 #pragma unroll 4
             for (int j = lane; j < NW * GSG; j += 64) {
                 const float4 v = lr_grid_group<OBSK>(gbits, tab, tabB, j);
                 const bool second = NW == 2 && j >= GSG;
-                *(float4 *)((second ? ob1 : ob0) + 16u * (unsigned)(second ? j - GSG : j)) = v;
+                (second ? ob1 : ob0)[second ? j - GSG : j] = v;
             }
             wave_lds_sync();
         } else {
@@ -504,11 +507,12 @@ __global__ __launch_bounds__(256) void lane_resident_step_kernel(ResidentArgs a)
         if (nenv == EPW && odd == 0) {
             constexpr int GSG = EPW * LR_C3 / 4;   // 16-byte groups of one observation of the wave's envs
             const u32 *g4 = (const u32 *)gb;
+            float4 *o40 = (float4 *)ob0, *o41 = (float4 *)ob1;
 #pragma unroll 4
             for (int j = lane; j < NW * GSG; j += 64) {
                 const u32 b = g4[j];
                 const bool second = NW == 2 && j >= GSG;
-                *(float4 *)((char *)(second ? ob1 : ob0) + 16u * (unsigned)(second ? j - GSG : j)) =
+                (second ? o41 : o40)[second ? j - GSG : j] =
                     make_float4((float)(b & 0xffu), (float)((b >> 8) & 0xffu), (float)((b >> 16) & 0xffu), (float)(b >> 24));
             }
         } else { // the ragged last wave, or one with an env outside the domain (fused_step_env below writes that env's rows)

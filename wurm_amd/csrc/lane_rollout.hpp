@@ -810,7 +810,9 @@ __global__ __launch_bounds__(256) void lane_rollout_kernel(StepArgs p)
                     for (int j = lane; j < NGRP; j += 64) {
                         const float4 v = lr_grid_group<OBSK>(gbits, tab, tabB, j);
                         const int s = EPW == 64 ? 0 : j / GSG;
-                        *(float4 *)(ob + (size_t)s * step_bytes + 16u * (unsigned)(j - s * GSG)) = v;
+                        // (a float4 pointer indexed by group: through `char * + 16 j` the EPW = 64 instantiations came out with
+                        // every 16-byte store split into four dword stores — see lane_resident.hpp)
+                        ((float4 *)(ob + (size_t)s * step_bytes))[j - s * GSG] = v;
                     }
                 } else { // the ragged last wave, the last chunk of a tape that is not a multiple of TC: float by float
                     lr_write_generic<EPW>(p, io, lut, obs_c, nt, nenv, lane);
@@ -828,7 +830,7 @@ __global__ __launch_bounds__(256) void lane_rollout_kernel(StepArgs p)
                     for (int j = lane; j < NGRP; j += 64) {
                         const u32 b = g4[j];
                         const int s = EPW == 64 ? 0 : j / GSG;
-                        *(float4 *)(ob + (size_t)s * step_bytes + 16u * (unsigned)(j - s * GSG)) =
+                        ((float4 *)(ob + (size_t)s * step_bytes))[j - s * GSG] =
                             make_float4((float)(b & 0xffu), (float)((b >> 8) & 0xffu), (float)((b >> 16) & 0xffu), (float)(b >> 24));
                     }
                 } else { // the ragged last wave, the last chunk of a tape that is not a multiple of TC: float by float
@@ -928,21 +930,26 @@ bool lane_rollout_eligible(const StepArgs &p)
 }
 
 // envs per wave: automatic unless the option WURM_LANE_ROLLOUT_EPW forces it (tests and the tuning sweep).
-static int lane_rollout_epw(long long N)
+static int lane_rollout_epw(long long N, int obs_mode)
 {
     {
         const int v = (int)opt.lane_rollout_epw;
         if (v == 4 || v == 8 || v == 16 || v == 32 || v == 64) return v;
     }
-    // measured (tools/tune_lane_rollout.py, profiles/r03_tune_lane_rollout.jsonl): 8 192 envs 8 per wave, 16 384 and 32 768: 16,
-    // 65 536: 16 or 32 (64 per wave = one wave per SIMD: nothing covers its LDS round trips)
-    return N >= 40960 ? 32 : N >= 12288 ? 16 : N >= 6144 ? 8 : 4;
+    // Round 6, measured again by observation mode once the 64-envs-per-wave instantiations stored 16 bytes per instruction
+    // (they had been writing dword by dword: tools/check_split_stores.py) — tools/lane_modes_probe.py, 64 steps per launch,
+    // profiles/r06_lane_epw.txt: 65 536 envs 64 per wave in every mode (partial_2 0.301 -> 0.287 ms, one_channel 0.336 -> 0.287,
+    // default 0.806 -> 0.784); 49 152 and 40 960: 64 but for one_channel (32); 24 576: 32 (partial_2 0.132 -> 0.110 ms) but for
+    // one_channel (16); 16 384: 32 for default / raw (0.217 -> 0.196), 16 for the rest.  (Round 3's sweep had 16 / 32 at 65 536.)
+    if (obs_mode == WURM_OBS_ONE_CHANNEL) return N >= 57344 ? 64 : N >= 40960 ? 32 : N >= 12288 ? 16 : N >= 6144 ? 8 : 4;
+    if (obs_mode == WURM_OBS_DEFAULT || obs_mode == WURM_OBS_RAW) return N >= 40960 ? 64 : N >= 16384 ? 32 : N >= 12288 ? 16 : N >= 6144 ? 8 : 4;
+    return N >= 40960 ? 64 : N >= 24576 ? 32 : N >= 12288 ? 16 : N >= 6144 ? 8 : 4;
 }
 
 // the kernel addresses the crops of a chunk (64 / epw steps) with 32-bit byte offsets
-static int lane_rollout_epw_checked(long long N)
+static int lane_rollout_epw_checked(long long N, int obs_mode)
 {
-    int epw = lane_rollout_epw(N);
+    int epw = lane_rollout_epw(N, obs_mode);
     while (epw < 64 && (64 / epw) * N * (LR_E * 4) >= (1ll << 32)) epw *= 2; // (partial_2 only: the generic writer uses 64-bit rows)
     return epw;
 }
@@ -951,7 +958,7 @@ template <int OBSK>
 static hipError_t launch_lane_rollout_obs(const StepArgs &p, hipStream_t stream)
 {
     const bool inj = p.inject_food != nullptr;
-    const int epw = inj ? 16 : lane_rollout_epw_checked(p.N);
+    const int epw = inj ? 16 : lane_rollout_epw_checked(p.N, p.obs_mode);
     const long long waves = (p.N + epw - 1) / epw;
     const int wpb = waves >= 2048 ? 4 : 1;
     dim3 block(64 * wpb), grid((unsigned)((waves + wpb - 1) / wpb));

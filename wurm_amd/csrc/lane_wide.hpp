@@ -114,7 +114,8 @@ __device__ __forceinline__ u64 lw_window(u64 a0, u64 a1, int pos)
 //      seed cell << 7 | tail cell << 14 | direction << 21 | food cell + 1 << 23), cur.z = food word (INJ: food cell + 1);
 // out: occ_rec = occupancy of the stepped state, rz = head cell before the move | sanitised action << 8,
 //      rw = food cell + 1 | ate << 8 | self collision << 9 | edge collision << 10 | valid << 15
-template <int S, bool INJ>
+// RESET = false: the step alone (the per-call kernel of lane_wide_resident.hpp rebuilds finished envs in the NEXT launch)
+template <int S, bool INJ, bool RESET = true>
 __device__ __forceinline__ void lw_transition(u64 &o0, u64 &o1, u64 &qa, u64 &qb, u64 &qc, int &c, int &tc, int &L, int &o, int &food,
                                               const bool act, const uint4 &cur, u64 &rec0, u64 &rec1, u32 &rz, u32 &rw)
 {
@@ -159,7 +160,7 @@ __device__ __forceinline__ void lw_transition(u64 &o0, u64 &o1, u64 &qa, u64 &qb
     rec0 = o0; rec1 = o1;
     rz = (u32)c_prev | (((u32)a_out & 0xffu) << 8);
     rw = (u32)(food + 1) | ((u32)eat << 8) | (selfc << 9) | (edge << 10) | 0x8000u;
-    if (selfc | edge) {                                          // :322-387
+    if (RESET && (selfc | edge)) {                               // :322-387
         const u32 r = cur.y;
         const int hc = (int)(r & 127u), sc = (int)((r >> 7) & 127u), d = (int)((r >> 21) & 3u);
         tc = (int)((r >> 14) & 127u);
@@ -662,6 +663,8 @@ static hipError_t launch_lane_wide_obs(const StepArgs &p, hipStream_t stream)
 {
     const bool inj = p.inject_food != nullptr;
     int epw = (int)opt.lane_rollout_epw;
+    // (64 envs per wave, instantiated and measured at 65 536 envs, is no faster here than 32 — one_channel 0.257 against 0.238 ms
+    // per 32 steps, default 0.323 against 0.303 per 16 — unlike lane_rollout.hpp's after its round-6 sweep: profiles/r06_lane_epw.txt)
     if (!(epw == 8 || epw == 16 || epw == 32)) epw = p.N >= 40960 ? 32 : p.N >= 12288 ? 16 : 8;
     if (inj) epw = 16;
     const long long waves = (p.N + epw - 1) / epw;

@@ -1679,7 +1679,7 @@ static int pick_cpl(int S)
 //   step / fused     | gridworld, RNG mode, no immediate reset, N >= lane_step_min_envs                | R_GRIDWORLD_LANE_STEP gridworld_lane.hip (+ generic for the rest)
 //   rollout          | otherwise                                                                      | R_GENERIC
 // (the resident 9 x 9 step, lane_resident.hpp, is chosen by fused_entry: it needs the caller's mirror)
-enum Route { R_GENERIC, R_GRID_STEP, R_LANE_STEP, R_GRID_ROLLOUT, R_LANE_ROLLOUT, R_LANE_WIDE, R_S9_INJ, R_S9, R_LEAN, R_GENERIC_PARTIAL, R_GENERIC_NONE, R_LANE_RESIDENT, R_GRIDWORLD_LANE, R_GRIDWORLD_LANE_STEP };
+enum Route { R_GENERIC, R_GRID_STEP, R_LANE_STEP, R_GRID_ROLLOUT, R_LANE_ROLLOUT, R_LANE_WIDE, R_S9_INJ, R_S9, R_LEAN, R_GENERIC_PARTIAL, R_GENERIC_NONE, R_LANE_RESIDENT, R_LANE_WIDE_RESIDENT, R_GRIDWORLD_LANE, R_GRIDWORLD_LANE_STEP };
 // (wurm_single_last_route: the route of the CALLING THREAD's last launch — a diagnostic the tests and bench.py name a launch by; no
 // state that a later call depends on.  One object for both translation units of this file: see WURM_TU_GRID below.)
 extern thread_local Route last_route;
@@ -1701,6 +1701,7 @@ static const char *route_name(Route r)
     case R_GENERIC_PARTIAL: return "rollout_generic_partial";
     case R_GENERIC_NONE: return "rollout_generic_none";
     case R_LANE_RESIDENT: return "lane_resident";
+    case R_LANE_WIDE_RESIDENT: return "lane_wide_resident";
     case R_GRIDWORLD_LANE: return "gridworld_lane";
     case R_GRIDWORLD_LANE_STEP: return "gridworld_lane_step";
     default: return "generic";
@@ -1807,6 +1808,7 @@ static hipError_t launch_one(Kind kind, const StepArgs &p, dim3 grid, dim3 block
         if constexpr (SNAKE && CPL == 2) WURM_LAUNCH((rollout_kernel<CPL, SNAKE, WURM_OBS_NONE, false>), grid, block, lds, st, p);
         break;
     case R_LANE_RESIDENT: // (chosen by fused_entry, which launches it itself)
+    case R_LANE_WIDE_RESIDENT:
     case R_GENERIC:
         switch (kind) {
         case K_STEP: WURM_LAUNCH((step_kernel<CPL, SNAKE>), grid, block, lds, st, p); break;
@@ -1998,6 +2000,15 @@ static int fused_entry(bool snake, const wurm_single_call *c, void *stream, int 
             if (mirror_state) *mirror_state = 1;
             return WURM_OK;
         }
+        if (lane_wide_resident_eligible(p) && c->resident_lazy) {
+            // 10 x 10 / 11 x 11: the same on lane_wide.hpp's state (lane_wide_resident.hpp), lazy form only — a caller that
+            // wants envs written every call gets the kernels without a mirror below, and the mirror reported stale
+            if (launch_lane_wide_resident(p, c->resident, c->resident_valid != 0, c->check_mask, (hipStream_t)stream) != hipSuccess)
+                return WURM_ERR_HIP;
+            last_route = R_LANE_WIDE_RESIDENT;
+            if (mirror_state) *mirror_state = 1;
+            return WURM_OK;
+        }
         if (no_mask() != WURM_OK) return WURM_ERR_HIP;
         if (grid_resident_eligible(p)) {
             // 12 x 12 and larger: the LDS clock-grid step keeps its grids in the mirror (grid_rollout.hip)
@@ -2012,6 +2023,7 @@ static int fused_entry(bool snake, const wurm_single_call *c, void *stream, int 
         if (c->resident_lazy && c->resident_valid) {
             hipError_t err = hipSuccess;
             if (p.S == 9) err = launch_lane_resident_flush(p, c->resident, (hipStream_t)stream);
+            else if (p.S == 10 || p.S == 11) err = launch_lane_wide_resident_flush(p, c->resident, (hipStream_t)stream);
             else if (grid_step_eligible(p)) { StepArgs q = p; q.resident = c->resident; err = launch_grid_resident_flush(q, (hipStream_t)stream); }
             if (err != hipSuccess) return WURM_ERR_HIP;
         }
@@ -2068,6 +2080,7 @@ int wurm_single_resident_flush(const wurm_single_call *c, void *stream)
     p.envs = c->envs; p.N = c->num_envs; p.S = c->size; p.resident = c->resident;
     hipError_t err;
     if (c->size == 9) err = launch_lane_resident_flush(p, c->resident, (hipStream_t)stream);
+    else if (c->size == 10 || c->size == 11) err = launch_lane_wide_resident_flush(p, c->resident, (hipStream_t)stream);
     else if (grid_step_eligible(p)) err = launch_grid_resident_flush(p, (hipStream_t)stream);
     else return WURM_ERR_INVALID_ARG;
     return err == hipSuccess ? WURM_OK : WURM_ERR_HIP;
@@ -2077,6 +2090,7 @@ int64_t wurm_single_resident_size(int64_t num_envs, int size, int obs_mode, int 
 {
     if (num_envs <= 0) return 0;
     if (lane_resident_shape(size, obs_mode, obs_n)) return num_envs * 32; // 9 x 9: 32 bytes per env (lane_resident.hpp)
+    if (lane_wide_resident_shape(size, obs_mode, obs_n)) return num_envs * 48; // 10 x 10 / 11 x 11: 48 (lane_wide_resident.hpp)
     StepArgs p = {};
     p.S = size;
     if (grid_step_eligible(p) && obs_elems(true, obs_mode, obs_n, size) >= 0) // 12 x 12 and larger: grid + record per env
@@ -2089,7 +2103,7 @@ int64_t wurm_single_resident_bytes(int64_t num_envs, int size, int obs_mode, int
     if (num_envs <= 0) return 0;
     const long long e = opt.resident_min_envs; // -1: by shape
     const bool big = e >= 0 ? num_envs >= e
-                            : (lane_resident_shape(size, obs_mode, obs_n) ? num_envs >= 4096
+                            : ((lane_resident_shape(size, obs_mode, obs_n) || lane_wide_resident_shape(size, obs_mode, obs_n)) ? num_envs >= 4096
                                                                           : num_envs * (long long)size * size >= (1ll << 20));
     return big ? wurm_single_resident_size(num_envs, size, obs_mode, obs_n) : 0;
 }
@@ -2344,6 +2358,7 @@ int wurm_single_rollout_resident(float *envs, void *actions, int actions_dtype, 
     if (resident_lazy && *resident_valid) {
         hipError_t err = hipSuccess;
         if (size == 9) err = launch_lane_resident_flush(p, resident, (hipStream_t)stream);
+        else if (size == 10 || size == 11) err = launch_lane_wide_resident_flush(p, resident, (hipStream_t)stream);
         else if (grid_step_eligible(p)) { StepArgs q = p; q.resident = resident; err = launch_grid_resident_flush(q, (hipStream_t)stream); }
         if (err != hipSuccess) return WURM_ERR_HIP;
     }

@@ -79,6 +79,12 @@ hipError_t launch_lane_rollout(const StepArgs &p, hipStream_t stream);
 bool lane_wide_eligible(const StepArgs &p);
 hipError_t launch_lane_wide(const StepArgs &p, hipStream_t stream);
 
+// ... and their per-call step on a caller-owned mirror (lane_wide_resident.hpp; lazy form only)
+bool lane_wide_resident_shape(int S, int obs_mode, int obs_n);
+bool lane_wide_resident_eligible(const StepArgs &p);
+hipError_t launch_lane_wide_resident(const StepArgs &p, void *resident, bool valid, uint32_t *check_mask, hipStream_t stream);
+hipError_t launch_lane_wide_resident_flush(const StepArgs &p, void *resident, hipStream_t stream);
+
 // per-call step of large 9 x 9 batches on a caller-owned compact mirror of the state (lane_resident.hpp, in lane_rollout.hip)
 bool lane_resident_shape(int S, int obs_mode, int obs_n);
 bool lane_resident_eligible(const StepArgs &p);
