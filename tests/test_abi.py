@@ -110,7 +110,10 @@ def test_resident_mirror_sizes():
     assert l.wurm_single_resident_bytes(65536, 9, _lib.OBS_RAW, 0) == 65536 * 32       # (round 5) 'raw': body values from the move queue
     assert l.wurm_single_resident_bytes(65536, 9, _lib.OBS_PARTIAL, 3) == 65536 * 32   # (round 5) 7 x 7 crops through bit planes
     assert l.wurm_single_resident_bytes(65536, 9, _lib.OBS_PARTIAL, 4) == 0            # 9 x 9 crops: the one-env-per-wave kernels
-    assert l.wurm_single_resident_bytes(65536, 10, *part2) == 0 and l.wurm_single_resident_bytes(65536, 11, *part2) == 0
+    # (round 6) 10 x 10 / 11 x 11: 48 bytes per env (lane_wide_resident.hpp) for the observations its bit planes serve
+    assert l.wurm_single_resident_bytes(65536, 10, *part2) == 65536 * 48 and l.wurm_single_resident_bytes(4096, 11, *default) == 4096 * 48
+    assert l.wurm_single_resident_bytes(4095, 10, *part2) == 0
+    assert l.wurm_single_resident_bytes(65536, 11, _lib.OBS_RAW, 0) == 0 and l.wurm_single_resident_bytes(65536, 10, _lib.OBS_PARTIAL, 4) == 0
     # 12 x 12 and larger: the 16-bit clock grid (runs of 256 cells) + 48 bytes, every observation mode, from 2^20 cells on
     assert l.wurm_single_resident_bytes(8192, 36, *default) == 8192 * (6 * 512 + 48)
     assert l.wurm_single_resident_bytes(8192, 12, *default) == 8192 * (1 * 512 + 48)

@@ -241,3 +241,59 @@ def test_check_masks_of_the_step_launch_equal_the_checker(hip):
         env.check_consistency(~d.squeeze(-1))
         env.reset(d, return_observations=False)
     env.check_consistency()
+
+
+@pytest.mark.parametrize('S,mode', [(10, 'default'), (11, 'partial_2')])
+def test_rollouts_between_per_call_steps_write_the_lazy_mirror_out(S, mode):
+    """SingleSnake.rollout of these sizes runs on the planes (lane_wide.hpp has no mirror-keeping form): the entry point writes a
+    lazy mirror out first and reports it stale, the next step rebuilds it — against the same object without a mirror"""
+    import torch
+    from wurm_amd.envs import SingleSnake
+    dev = torch.device('cuda:0')
+    N = 200
+    g = torch.Generator().manual_seed(7)
+    plan = [torch.randint(4, (6, N), generator=g).to(dev) for _ in range(5)]
+    outs = []
+    for policy in (True, False):
+        env = SingleSnake(N, S, observation_mode=mode, device=dev, seed=4, resident_mirror=policy)
+        rec = []
+        for tape in plan:
+            for t in range(3):
+                o, r, d, _ = env.step(tape[t].clone())
+                if policy is True:
+                    assert _route() == 'lane_wide_resident'
+                env.reset(d, return_observations=False)
+                rec += [o.clone(), r.clone(), d.clone()]
+            out = env.rollout(tape.clone())
+            rec += [out['observations'].clone(), out['rewards'].clone(), out['dones'].clone()]
+        rec.append(env.envs.clone())
+        outs.append(rec)
+    for i, (x, y) in enumerate(zip(*outs)):
+        assert torch.equal(x, y), f'record {i}'
+
+
+def test_deepcopy_and_pickle_with_the_mirror():
+    """a copied / unpickled env object continues exactly like the original (the mirror is rebuilt or copied, never shared)"""
+    import copy
+    import pickle
+    import torch
+    from wurm_amd.envs import SingleSnake
+    dev = torch.device('cuda:0')
+    N = 150
+    env = SingleSnake(N, 11, observation_mode='one_channel', device=dev, seed=6, resident_mirror=True)
+    g = torch.Generator().manual_seed(2)
+    acts = torch.randint(4, (30, N), generator=g).to(dev)
+    for t in range(10):
+        o, r, d, _ = env.step(acts[t].clone())
+        env.reset(d, return_observations=False)
+    twins = [copy.deepcopy(env), pickle.loads(pickle.dumps(env))]
+    for t in range(10, 30):
+        ref = env.step(acts[t].clone())
+        env.reset(ref[2], return_observations=False)
+        for tw in twins:
+            got = tw.step(acts[t].clone())
+            tw.reset(got[2], return_observations=False)
+            for a, b in zip(ref[:3], got[:3]):
+                assert torch.equal(a, b), f't={t}'
+    for tw in twins:
+        assert torch.equal(env.envs, tw.envs)

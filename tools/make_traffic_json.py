@@ -54,11 +54,11 @@ def total(t):
 
 detail = {
     'rollout_512x9_chunk1024': traffic('void wurm::rollout_s9_kernel<4', 32768),
-    # one env per LANE from 6 144 envs on (lane_rollout.hpp): 8 / 16 / 16 / 32 envs per wave at these batch sizes
+    # one env per LANE from 6 144 envs on (lane_rollout.hpp): 8 / 16 / 32 / 64 envs per wave at these batch sizes (round 6's sweep)
     'rollout_8192x9_chunk128': traffic('void wurm::lane_rollout_kernel<8, 4, false>', 65536),
     'rollout_16384x9_chunk128': traffic('void wurm::lane_rollout_kernel<16, 4, false>', 65536),
-    'rollout_32768x9_chunk64': traffic('void wurm::lane_rollout_kernel<16, 4, false>', 131072),
-    'rollout_65536x9_chunk64': traffic('void wurm::lane_rollout_kernel<32, 4, false>', 131072),
+    'rollout_32768x9_chunk64': traffic('void wurm::lane_rollout_kernel<32, 4, false>', 65536),
+    'rollout_65536x9_chunk64': traffic('void wurm::lane_rollout_kernel<64, 4, false>', 65536),
     'rollout_cfg5_8192x36_default_chunk16': traffic('void wurm::(anonymous namespace)::grid_rollout_kernel<true>', 524288),
     # round 4: G envs per workgroup (multi_rollout_group_kernel): cfg4 512 workgroups of 8 steppers + 4 writers, the speeds.py
     # shape 1024 workgroups of 4 + 10
@@ -68,12 +68,12 @@ detail = {
                                                   traffic('void wurm::multi_rollout_group_kernel<8, 4, 1, 6, false, false', 393216),
     'multi_rollout_speeds_4096x36_k10_chunk4': traffic('void wurm::multi_rollout_group_kernel<4, 10, 1, 4, true, false', 917504),
     # round 4: one_channel / default of 65 536 x 9 x 9 through the lane kernels (bit planes): rollout, and per call (reference form)
-    'rollout_65536x9_one_channel_chunk32': traffic('void wurm::lane_rollout_kernel<32, -2, false>', 131072),
-    'rollout_65536x9_default_chunk32': traffic('void wurm::lane_rollout_kernel<32, -3, false>', 131072),
+    'rollout_65536x9_one_channel_chunk32': traffic('void wurm::lane_rollout_kernel<64, -2, false>', 65536),
+    'rollout_65536x9_default_chunk32': traffic('void wurm::lane_rollout_kernel<64, -3, false>', 65536),
     'resident_step_65536x9_one_channel_reset_obs': traffic('void wurm::lane_resident_step_kernel<32, 2, -2, true>', 131072),
     'resident_step_65536x9_default_reset_obs': traffic('void wurm::lane_resident_step_kernel<32, 2, -3, true>', 131072),
-    'rollout_65536x9_raw_chunk32': traffic('void wurm::lane_rollout_kernel<32, -5, false>', 131072),
-    'rollout_65536x9_partial_3_chunk32': traffic('void wurm::lane_rollout_kernel<32, -4, false>', 131072),
+    'rollout_65536x9_raw_chunk32': traffic('void wurm::lane_rollout_kernel<64, -5, false>', 65536),
+    'rollout_65536x9_partial_3_chunk32': traffic('void wurm::lane_rollout_kernel<64, -4, false>', 65536),
     # round 6: 10 x 10 / 11 x 11 one env per lane (lane_wide.hpp), 32 envs per wave at this batch size
     'rollout_65536x10_partial_2_chunk32': traffic('void wurm::lane_wide_rollout_kernel<32, 10, 4, 5, false>', 131072),
     'rollout_65536x11_default_chunk32': traffic('void wurm::lane_wide_rollout_kernel<32, 11, -3, 0, false>', 131072),
