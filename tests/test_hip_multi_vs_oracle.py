@@ -167,3 +167,42 @@ def test_env_beyond_160kb_is_unsupported(hip):
     from wurm_amd.envs import MultiSnake
     with pytest.raises(NotImplementedError):
         MultiSnake(2, 40, 64, device='cuda:0', seed=1)   # 2 x 40 x 4096 bytes of body clocks alone
+
+
+def test_food_under_a_dying_snake_counts_twice_towards_max_food(hip):
+    """`self.foods += food_on_death` (multi_snake.py:672) leaves a 2 where a dead body lay over food until the clamp at :692,
+    and `_add_food` (:680) sums the plane in between: with max_food - 1 cells of food, one of them under the snake that dies,
+    the sum is max_food and NO rate food is added (round 6's fuzz, seed 722: the kernel counted cells and added two).
+    Hand-made state (the dynamics never leave food under a body), both with and without a snake that survives."""
+    cfg = dict(boost=True, food_on_death_prob=1.0, boost_cost_prob=0.0, food_mode='random_rate', food_rate=0.2,
+               reward_on_death=-2, respawn_mode='all', colour_mode='random')
+    N, K, S = 6, 2, 12
+    o, h = OracleBackend(seed=11, env_offset=4), hip(seed=11, env_offset=4)
+    st = _o.multi_empty_state(N, K, S)
+    st['colours'][...] = o.multi_colours(N, K, False, call=0)
+    for e in range(N):
+        # snake 0: along row 4, head at (4, 7) facing east; snake 1: row 8, head at (8, 10) — one step east of it is the wall
+        for s, (y, x0) in enumerate(((4, 5), (8, 8))):
+            a = e * K + s
+            for v, x in enumerate(range(x0, x0 + 3), start=1):
+                st['bodies'][a, 0, y, x] = v
+            st['heads'][a, 0, y, x0 + 2] = 1
+            st['orientations'][a] = 1
+        # max_food = 8 K = 16: env e holds 15 - (e % 3) cells of food, one of them under the middle of snake 1
+        cells = [(1, 2), (1, 9), (2, 1), (2, 6), (3, 3), (5, 1), (5, 9), (6, 2), (6, 6), (6, 10), (9, 1), (9, 4), (10, 2), (10, 7), (8, 9)]
+        for (y, x) in cells[e % 3:]:
+            st['foods'][e, 0, y, x] = 1
+    sh = {k: v.copy() for k, v in st.items()}
+    actions = np.zeros((K, N), np.int64)
+    actions[0] = 1   # snake 0 keeps going east
+    actions[1] = 1   # snake 1 runs into the wall and dies: food on its body cells, (8, 9) among them
+    o.call = h.call = 9
+    ro, rh = o.multi_step(st, actions, cfg, 'full'), h.multi_step(sh, actions, cfg, 'full')
+    assert st['dones'].reshape(N, K)[:, 1].all() and not st['dones'].reshape(N, K)[:, 0].any()
+    _same_state(st, sh, 'state')
+    for k in ro:
+        _same(ro[k], rh[k], k)
+    # envs with 15 cells of food: the doubled cell makes the sum 16 -> no rate food (the same count in both of them: the cells
+    # they had + the dead body's other cell); the others, one and two cells short of that, got rate food on top
+    total = st['foods'].reshape(N, -1).sum(1)
+    assert total[0] == total[3] == 16 and (total[[1, 2, 4, 5]] > np.array([15, 14, 15, 14])).any()

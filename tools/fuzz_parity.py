@@ -867,6 +867,9 @@ if __name__ == '__main__':
     ap.add_argument('--summary', default=None,
                     help='append a JSON record of this run (library sha256, seed, cases per family, forced thresholds, '
                          'mismatches) to this file, e.g. profiles/r03_fuzz_summary.json')
+    ap.add_argument('--save-failures', default=None, help='directory: a failing case leaves the generator state in front of it there (fuzz_fail_<seed>_<n>.pkl)')
+    ap.add_argument('--replay-state', default=None, help='such a file: re-run exactly that case')
+    ap.add_argument('--repeat', type=int, default=1)
     args = ap.parse_args()
     rng = np.random.RandomState(args.seed)
     if args.replay:
@@ -876,11 +879,29 @@ if __name__ == '__main__':
         FAMILIES[fam](rng)
         print('replay: no mismatch')
         sys.exit(0)
+    if args.replay_state:
+        # a case that failed in an earlier run, from the generator state saved in front of it: the same case, --repeat times
+        import pickle
+        kind, st = pickle.load(open(args.replay_state, 'rb'))
+        bad = 0
+        for r in range(args.repeat):
+            rng.set_state(st)
+            try:
+                desc = FAMILIES[kind](rng)
+            except AssertionError as e:
+                bad += 1
+                print(f'run {r}: MISMATCH: {str(e)[:600]}', flush=True)
+            else:
+                if r == 0:
+                    print('run 0: ok —', desc, flush=True)
+        print(f'replay of one {kind} case: {bad} of {args.repeat} runs mismatched')
+        sys.exit(1 if bad else 0)
     kinds = [k for k in FAMILIES if args.only is None or k in args.only.split(',')]
     t0, n, fails, messages = time.time(), {k: 0 for k in kinds}, 0, []
     while time.time() - t0 < args.seconds:
         w = np.array([WEIGHTS[k] for k in kinds])
         kind = kinds[rng.choice(len(kinds), p=w / w.sum())]
+        state_before = rng.get_state()
         try:
             FAMILIES[kind](rng)
             n[kind] += 1
@@ -888,6 +909,10 @@ if __name__ == '__main__':
             fails += 1
             messages.append(str(e)[:600])
             print('MISMATCH:', str(e)[:600])
+            if args.save_failures:   # the generator state in front of the case: --replay-state re-runs exactly this case
+                import pickle
+                os.makedirs(args.save_failures, exist_ok=True)
+                pickle.dump((kind, state_before), open(os.path.join(args.save_failures, f'fuzz_fail_{args.seed}_{fails}.pkl'), 'wb'))
         except Exception:
             fails += 1
             messages.append(traceback.format_exc()[-600:])

@@ -473,14 +473,18 @@ __device__ __forceinline__ void run_phase(const Ctx &cx, bool who, int dir, int 
     wave_lds_sync();
 }
 
-// _food_from_death (:416-428) as applied at :565-576 / :662-673
-__device__ __forceinline__ void food_from_death(const Ctx &cx, bool done, bool has_body, const uint8_t *inj,
-                                                float thr, u64 seed, u64 call, u64 env_id, u32 purpose)
+// _food_from_death (:416-428) as applied at :565-576 / :662-673.  Returns the number of cells where the food landed on a cell
+// that held food already: `self.foods += food_on_death` makes those 2 until the clamp at the end of the phase (:603 / :692),
+// and the second phase's _add_food (:680) sums the food plane BEFORE its clamp — the test against max_food sees them twice
+// (a dead body over food only comes from a hand-edited state; round 6's fuzz found the step after one: seed 722).
+__device__ __forceinline__ int food_from_death(const Ctx &cx, bool done, bool has_body, const uint8_t *inj,
+                                               float thr, u64 seed, u64 call, u64 env_id, u32 purpose)
 {
     const int S = cx.S, C = cx.C, lane = cx.lane;
     const bool snake = lane < cx.K;
     const u64 dead = ballot(snake && done && has_body);
-    if (!dead) return;
+    if (!dead) return 0;
+    int doubled = 0;
     const u64 live = ballot(snake && !done);
     for (int k = 0; k < cx.cpl; ++k) {
         int c = lane + 64 * k;
@@ -494,9 +498,13 @@ __device__ __forceinline__ void food_from_death(const Ctx &cx, bool done, bool h
         for (u64 m = live; m; m &= m - 1) l |= BV(cx, first_bit(m), c) > 0;
         if (l) continue; // :426 not under a living body
         bool hit = inj ? inj[c] != 0 : cell_u01(seed, call, env_id, purpose, (u32)c) > thr; // :424
-        if (hit) cx.food[c] = 1; // += 1 then clamp(0,1) (:575,603 / :672,692)
+        if (hit) { // += 1 then clamp(0,1) (:575,603 / :672,692)
+            doubled += (int)(cx.food[c] != 0);
+            cx.food[c] = 1;
+        }
     }
     wave_lds_sync();
+    return wave_sum_i32(doubled);
 }
 
 // delete done snakes (:595-596 / :676-677)
@@ -1108,9 +1116,10 @@ __device__ __forceinline__ void multi_step_body(const Ctx &cx, const MultiArgs &
     WURM_TLS(cx, 3);
     run_phase(cx, snake, dir, hc, L, done, reward, foodcons, snakecol, edgecol); // :613-660
     WURM_TLS(cx, 4);
+    int doubled_b = 0;                          // (food cells the sum of :382 sees twice: food_from_death)
     if (p.cfg.food_on_death)                    // :662-673
-        food_from_death(cx, done, has_body, p.has_inj ? p.inj.death_b + offC + env * C : nullptr,
-                        p.cfg.death_threshold, p.seed, call, env_id, RNG_DEATH_FOOD_B);
+        doubled_b = food_from_death(cx, done, has_body, p.has_inj ? p.inj.death_b + offC + env * C : nullptr,
+                                    p.cfg.death_threshold, p.seed, call, env_id, RNG_DEATH_FOOD_B);
     delete_done(cx, done, has_body, hc);        // :676-677
     WURM_TLS(cx, 5);
 
@@ -1128,9 +1137,9 @@ __device__ __forceinline__ void multi_step_body(const Ctx &cx, const MultiArgs &
         if (p.obs_mode == WURM_OBS_PARTIAL && cx.has_ring) {
             cc = cell_codes(cx, hc, cx.hmap, cx.ring);
             cmap_ok = true;
-            nfood = cc.nfood;
+            nfood = cc.nfood + doubled_b;
         } else {
-            nfood = food_count(cx);
+            nfood = food_count(cx) + doubled_b;
             const bool want_free = p.cfg.food_mode == 0 ? (nfood == 0 && !p.has_inj) : nfood < p.cfg.max_food;
             if (p.obs_mode == WURM_OBS_NONE && cx.has_ring && want_free) {
                 cc = cell_codes(cx, hc, cx.hmap, cx.ring);
