@@ -478,6 +478,10 @@ def fuzz_multi(rng):
             for k in so:
                 same(so[k], sh[k], f'{desc} reset {k} t={t}')
             same(o.last_reset_obs, h.last_reset_obs, f'{desc} reset obs t={t}')
+            if rng.rand() < 0.06:   # hand-made: food anywhere inside the ring — under a body or a head too —, sometimes ON the ring
+                lo, hi = (0, S) if rng.rand() < 0.2 else (1, S - 1)
+                so['foods'][int(rng.randint(N)), 0, int(rng.randint(lo, hi)), int(rng.randint(lo, hi))] = 1
+                sh['foods'][...] = so['foods']
     else:
         ro, rh = o.multi_rollout(so, a, cfg, mode), h.multi_rollout(sh, a, cfg, mode)
         for k in ro:
@@ -558,7 +562,9 @@ def fuzz_multi_resident(rng):
                 prev, prev_call = ro['all_done'], call + 1
             call += 2
             if edit:
-                so['foods'][int(rng.randint(N)), 0, int(rng.randint(1, S - 1)), int(rng.randint(1, S - 1))] = 1
+                # (hand-made: food anywhere inside the ring — under a body or a head too; one time in five ON the ring)
+                lo, hi = (0, S) if rng.rand() < 0.2 else (1, S - 1)
+                so['foods'][int(rng.randint(N)), 0, int(rng.randint(lo, hi)), int(rng.randint(lo, hi))] = 1
                 sh['foods'][...] = so['foods']
                 mirror['valid'] = 0
     finally:
